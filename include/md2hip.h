@@ -1,0 +1,135 @@
+/* md2hip.h — C ABI of libmd2hip.so: the MI355X (gfx950) implementation of Monodepth2.jl's
+ * self-supervised training step (encoder + depth/pose decoders + warp/SSIM/L1 loss, fwd + bwd + ADAM).
+ *
+ * The reference has no FFI of its own (pure Julia; kernels come from CUDA.jl/NNlib by array-type
+ * dispatch, src/Monodepth.jl:71-73, src/utils.jl:1-11).  Each entry point below names the reference
+ * function(s) whose device execution it replaces; the Julia `ccall` shim that binds them is in
+ * monodepth2.jl_amd/julia/Monodepth2HIP.jl and INTEGRATION.md.
+ *
+ * Conventions
+ *  - Every function returns 0 on success, non-zero on error; md2_last_error() gives the message
+ *    (no exceptions cross the ABI).  A handle is not thread-safe: one handle <-> one GPU <-> one stream.
+ *  - All array arguments are DEVICE pointers to fp32 unless named `host_*`.  The caller owns every
+ *    buffer it passes; the library owns the handle, weights, ADAM moments and workspaces.
+ *  - Layout at the boundary is the reference's: a Julia column-major (W,H,C,N) array is passed as-is,
+ *    i.e. it is row-major [N][C][H][W]; (W,H,C,L,N) == [N][L][C][H][W]; grid (2,W,H,N) == [N][H][W][2];
+ *    rvec (3,N) == [N][3]; 3x3 matrices are column-major (R[n][j*3+i] = R_ij) like Julia's (3,3,N).
+ *  - Calls are asynchronous on the handle's stream; only the host_* getters synchronise.
+ */
+#ifndef MD2HIP_H
+#define MD2HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct md2_handle md2_handle;
+
+/* Params (src/Monodepth.jl:32-42) + the shapes TrainCache (src/Monodepth.jl:44-55) is built for. */
+typedef struct md2_config {
+    int32_t batch;        /* N: triplets per step on this GPU (Params.batch_size)            */
+    int32_t channels;     /* C: 1 (grayscale, train()) or 3                                  */
+    int32_t height;       /* H (Params.target_size[2]), multiple of 32                       */
+    int32_t width;        /* W (Params.target_size[1]), multiple of 32                       */
+    int32_t automasking;  /* Params.automasking                                              */
+    int32_t device;       /* HIP device ordinal                                              */
+    double min_depth, max_depth, disparity_smoothness;   /* Params                            */
+    double lr;            /* ADAM eta (1e-4, src/Monodepth.jl:125)                           */
+} md2_config;
+
+/* ---- handle ------------------------------------------------------------------------------- */
+int32_t md2_create(const md2_config* cfg, md2_handle** out);
+int32_t md2_destroy(md2_handle* h);
+const char* md2_last_error(md2_handle* h);          /* h may be NULL: error of the last failed md2_create */
+int32_t md2_set_stream(md2_handle* h, void* hip_stream);   /* default: the null stream */
+int32_t md2_synchronize(md2_handle* h);
+/* TrainCache.K / .invK (src/Monodepth.jl:113): 3x3 column-major, host pointers */
+int32_t md2_set_intrinsics(md2_handle* h, const float* host_K, const float* host_invK);
+
+/* ---- parameters: Flux.params(model) (src/Monodepth.jl:124), flat, order in DESIGN.md;
+ *      conv weights in Flux layout (kW,kH,Cin,Cout) true-convolution convention ------------------ */
+int64_t md2_params_count(md2_handle* h);
+int32_t md2_params_set(md2_handle* h, const float* host_params, int64_t n);
+int32_t md2_params_get(md2_handle* h, float* host_params, int64_t n);
+int32_t md2_grads_get(md2_handle* h, float* host_grads, int64_t n);     /* gradient(theta) do ... end */
+/* internal flat gradient buffer (device) for the data-parallel all-reduce (RCCL via the host) */
+int32_t md2_grad_buffer(md2_handle* h, void** dev_ptr, int64_t* count);
+int32_t md2_param_buffer(md2_handle* h, void** dev_ptr, int64_t* count);
+
+/* ---- model: (m::Model)(x, source_ids, target_id), src/model.jl:8-20 (source_ids=[1,3], target_id=2)
+ *      x [N][3][C][H][W]; disp_i [N][1][H>>(3-i)][W>>(3-i)]; rvec,tvec [2][N][3] (source-major) --- */
+int32_t md2_model_forward(md2_handle* h, const float* x, float* disp0, float* disp1, float* disp2, float* disp3,
+                          float* rvec, float* tvec);
+/* ---- train_loss forward (src/training.jl:21-78): model + loss.  auto_loss may be NULL.
+ *      loss: device scalar.  Keeps activations for md2_backward. ------------------------------- */
+int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, float* loss);
+/* ---- Zygote pullback of the last md2_train_loss into the gradient buffer --------------------- */
+int32_t md2_backward(md2_handle* h);
+/* ---- Flux.Optimise.update!(ADAM, theta, grads), src/Monodepth.jl:170; grads scaled by grad_scale first */
+int32_t md2_adam_step(md2_handle* h, float grad_scale);
+/* ---- one whole step of the loop body src/Monodepth.jl:156-176: fwd + bwd (+ ADAM if do_update) -- */
+int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, float* loss, int32_t do_update);
+/* automasking_loss(ssim, x, x[:,:,:,target,:]; source_ids), src/training.jl:9-11 -> [N][1][H][W] */
+int32_t md2_automasking_loss(md2_handle* h, const float* x, float* out);
+
+/* The loss half alone (src/training.jl:28-77) given disparities and poses; pullbacks may be NULL.
+ * ddisp_i like disp_i; drvec/dtvec [2][N][3]. */
+int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* disp0, const float* disp1, const float* disp2,
+                         const float* disp3, const float* rvec, const float* tvec, const float* auto_loss, float* loss,
+                         float* ddisp0, float* ddisp1, float* ddisp2, float* ddisp3, float* drvec, float* dtvec);
+
+/* per-kernel-class device timing (HIP events on the handle's stream) for bench.py's roofline */
+int32_t md2_profile_enable(md2_handle* h, int32_t on);
+int32_t md2_profile_reset(md2_handle* h);
+/* classes: 0 conv_igemm (fwd+dgrad), 1 conv_wgrad, 2 loss_fwd, 3 loss_bwd, 4 other */
+int32_t md2_profile_get(md2_handle* h, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- op-level entry points (stateless; `stream` = hipStream_t or NULL), reference layout ------ */
+/* SSIM()(x, y), src/utils.jl:25-39.  [planes][H][W] */
+int32_t md2_ssim_fwd(const float* x, const float* y, float* out, int32_t planes, int32_t H, int32_t W, void* stream);
+/* photometric_loss(ssim, predicted, target), src/training.jl:1-7 -> [N][1][H][W] */
+int32_t md2_photometric_loss_fwd(const float* pred, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* prediction_loss(ssim, predictions, target), src/training.jl:13-15; preds [k][N][C][H][W] */
+int32_t md2_prediction_loss_fwd(const float* preds, int32_t k, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* disparity_to_depth, src/utils.jl:175-179 */
+int32_t md2_disparity_to_depth(const float* d, float* out, int64_t n, double min_depth, double max_depth, void* stream);
+/* Backproject(depth, invK), src/utils.jl:63-65: depth [N][P] -> [N][P][3] */
+int32_t md2_backproject(const float* depth, const float* invK_dev, float* out, int32_t N, int32_t H, int32_t W, void* stream);
+/* Project(points, K, R, t), src/utils.jl:95-99: -> uv [N][P][2] */
+int32_t md2_project(const float* pts, const float* K_dev, const float* R, const float* t, float* uv, int32_t N, int32_t H, int32_t W, void* stream);
+/* NNlib.grid_sample(input, grid; padding_mode), call site src/training.jl:56; border: 1 = :border, 0 = :zeros */
+int32_t md2_grid_sample_fwd(const float* in, const float* grid, float* out, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t border, void* stream);
+int32_t md2_grid_sample_bwd_grid(const float* in, const float* grid, const float* dout, float* dgrid, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t border, void* stream);
+/* fused disparity -> depth -> Backproject -> Project -> grid_sample(:border)  (src/training.jl:48-57) */
+int32_t md2_warp_fwd(const float* disp, const float* src, const float* K_dev, const float* invK_dev, const float* R, const float* t,
+                     float* out, int32_t N, int32_t C, int32_t H, int32_t W, double min_depth, double max_depth, void* stream);
+/* NNlib.upsample_bilinear(x; size), src/training.jl:45 */
+int32_t md2_upsample_bilinear_fwd(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, void* stream);
+int32_t md2_upsample_bilinear_bwd(const float* dout, float* dx, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, void* stream);
+/* hat / so3_exp_map / composeT, src/utils.jl:101-141,181-188 */
+int32_t md2_hat(const float* rvec, float* S, int32_t N, void* stream);
+int32_t md2_so3_exp_map(const float* rvec, float* R, int32_t N, void* stream);
+int32_t md2_so3_exp_map_bwd(const float* rvec, const float* dR, float* drvec, int32_t N, void* stream);
+int32_t md2_composeT(const float* rvec, const float* t, int32_t invert, float* R, float* tout, int32_t N, void* stream);
+/* smooth_loss(disparity, image), src/utils.jl:159-173 -> device scalar */
+int32_t md2_smooth_loss(const float* disp, const float* image, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* Flux Conv (true convolution, weights (kW,kH,Cin,Cout)) on NCHW tensors through the MFMA implicit-GEMM kernels.
+ * pad_mode 0 = zeros, 1 = reflect-pad(1) then valid conv (DecoderBlock, src/depth_decoder.jl:1-5); act: 0 none 1 relu 2 elu 3 sigmoid */
+int32_t md2_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W,
+                       int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t pad_mode, int32_t act, void* stream);
+/* pullbacks wrt input / weights / bias of the conv above (act = none); any of dx,dw,db may be NULL */
+int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin,
+                       int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t pad_mode, void* stream);
+/* Flux BatchNorm train mode (+ optional relu), NCHW */
+int32_t md2_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t relu, void* stream);
+int32_t md2_bn_train_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* MaxPool((3,3); pad=1, stride=2), NCHW */
+int32_t md2_maxpool3s2_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int32_t md2_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* ADAM on raw buffers: step = 1-based iteration count */
+int32_t md2_adam_raw(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,454 @@
+// conv_igemm.hip — fp32 MFMA implicit-GEMM convolutions for gfx950 (CDNA4).
+//
+// Replaces the cuDNN kernels the reference reaches through Flux `Conv` (src/depth_decoder.jl:13-14,43,
+// src/pose_decoder.jl:15-19, ResNet.jl via src/model.jl:14) and their Zygote pullbacks (SURVEY.md §2a k1,k4,k6,k9).
+//
+// Design (MI355X-first, not a cuDNN translation):
+//  * NHWC views, so one GEMM-K step of 16 input channels of one filter tap is one contiguous 64-B run per
+//    output pixel: global loads are 16-B per lane, 4 lanes per pixel.
+//  * v_mfma_f32_16x16x4_f32 (exact fp32, the only fp32 matrix op on gfx950; 1e-4 parity forces fp32).
+//    D rows = output channels, D cols = pixels, so each lane ends up with 4 consecutive channels of one
+//    pixel -> one 16-B store per MFMA tile.
+//  * LDS tiles [row][16+4] floats: ds_read_b128 per lane gives 4 consecutive k of its row = the operand
+//    of 4 MFMAs; the +4 pad makes the 16-lane groups of ds_read_b128 conflict-free (80-B row stride).
+//  * register-staged double buffering: global loads of step s+1 are in flight while step s runs on MFMA.
+//  * input-gradient = the same kernel on dY with the transposed/flipped weights (dil = forward stride).
+//  * weight-gradient: D rows = cout, cols = cin, K = pixels; split over pixel ranges, fp32 atomics.
+//  * workgroup id remap so tiles that share the same pixel tile run on one XCD (shared L2).
+#include "md2_internal.h"
+#include <algorithm>
+
+namespace md2 {
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range of logical ids.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
+
+template <int BM, int BN, int WP, int WC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int TP = BM / WP / 16, TC = BN / WC / 16;
+    constexpr int A_LD = BM * 4 / 256;
+    constexpr int B_LD = (BN * 4 + 255) / 256;
+    static_assert(WP * WC == 4 && TP >= 1 && TC >= 1 && A_LD >= 1, "bad tile");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+    float* Xs = smem;
+    float* Ws = smem + 2 * BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP;
+    const int ntc = a.Cout / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_c = bid % ntc, tile_p = bid / ntc;
+    const int m0 = tile_p * BM, c0 = tile_c * BN;
+    const int HoWo = a.Ho * a.Wo;
+    const int Ktot = a.KH * a.KW * a.Cin;
+    const int q = tid & 3;
+
+    long a_base[A_LD]; int a_ih[A_LD], a_iw[A_LD]; bool a_ok[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int row = (tid + 256 * j) >> 2;
+        const int m = m0 + row;
+        a_ok[j] = m < a.M;
+        const int mm = a_ok[j] ? m : 0;
+        const int n = mm / HoWo, r = mm - n * HoWo, oh = r / a.Wo, ow = r - oh * a.Wo;
+        a_base[j] = (long)n * a.x_bs;
+        a_ih[j] = oh * a.stride - a.pad;
+        a_iw[j] = ow * a.stride - a.pad;
+    }
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[A_LD], rb[B_LD];
+    const int cpt = a.Cin >> 4;                 // 16-channel chunks per tap
+    const int nsteps = a.KH * a.KW * cpt;
+
+    auto gload = [&](int kh, int kw, int ci0) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            int th = a_ih[j] + kh, tw = a_iw[j] + kw;
+            bool ok = a_ok[j];
+            if (a.dil > 1) {
+                ok = ok && th >= 0 && tw >= 0 && (th % a.dil) == 0 && (tw % a.dil) == 0;
+                th /= a.dil; tw /= a.dil;
+            }
+            if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
+            else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
+            ra[j] = ok ? *reinterpret_cast<const float4*>(a.x + a_base[j] + ((long)th * a.W + tw) * a.x_ps + ci0 + q * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int k0 = (kh * a.KW + kw) * a.Cin + ci0;
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int f = tid + 256 * j;
+            if (f < BN * 4) rb[j] = *reinterpret_cast<const float4*>(a.w + (long)(c0 + (f >> 2)) * Ktot + k0 + q * 4);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4*>(Xs + buf * BM * LDK + ((tid + 256 * j) >> 2) * LDK + q * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int f = tid + 256 * j;
+            if (f < BN * 4) *reinterpret_cast<float4*>(Ws + buf * BN * LDK + (f >> 2) * LDK + q * 4) = rb[j];
+        }
+    };
+
+    int kh = 0, kw = 0, cib = 0;
+    gload(0, 0, 0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (++cib == cpt) { cib = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
+        if (s + 1 < nsteps) gload(kh, kw, cib << 4);
+        f32x4 wf[TC], xf[TP];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const f32x4*>(Ws + buf * BN * LDK + (wc * (BN / WC) + i * 16 + (lane & 15)) * LDK + 4 * (lane >> 4));
+#pragma unroll
+        for (int j = 0; j < TP; ++j) xf[j] = *reinterpret_cast<const f32x4*>(Xs + buf * BM * LDK + (wp * (BM / WP) + j * 16 + (lane & 15)) * LDK + 4 * (lane >> 4));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][r], xf[j][r], acc[i][j], 0, 0, 0);
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds channels co..co+3 of pixel m for every (tc,tp)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int m = m0 + wp * (BM / WP) + j * 16 + (lane & 15);
+        if (m >= a.M) continue;
+        const int n = m / HoWo, r = m - n * HoWo;
+        float* yp = a.y + (long)n * a.y_bs + (long)r * a.y_ps;
+        const float* dp = a.dact_src ? a.dact_src + (long)n * a.da_bs + (long)r * a.da_ps : nullptr;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int co = c0 + wc * (BN / WC) + i * 16 + 4 * (lane >> 4);
+            f32x4 v = acc[i][j];
+            if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + co); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+            if (a.act != ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+            }
+            if (dp) {
+                const float4 d = *reinterpret_cast<const float4*>(dp + co);
+                v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact);
+            }
+            if (a.accumulate) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+            *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int BM, int BN, int WP, int WC>
+static void launch_tile(const ConvArgs& a, hipStream_t s) {
+    const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC>), dim3(grid), dim3(256), 0, s, a);
+}
+
+double conv_igemm_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.Cout * a.KH * a.KW * a.Cin; }
+
+void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+    // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
+    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0)) {
+        fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
+        abort();
+    }
+    const long tiles128 = (long)((a.M + 127) / 128);
+    if (a.Cout % 128 == 0 && tiles128 * (a.Cout / 128) >= 512) launch_tile<128, 128, 2, 2>(a, s);
+    else if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= 384) launch_tile<128, 64, 2, 2>(a, s); else launch_tile<64, 64, 2, 2>(a, s); }
+    else if (a.Cout % 32 == 0) { if (tiles128 >= 384) launch_tile<128, 32, 4, 1>(a, s); else launch_tile<64, 32, 2, 2>(a, s); }
+    else { if (tiles128 >= 384) launch_tile<128, 16, 4, 1>(a, s); else launch_tile<64, 16, 4, 1>(a, s); }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------------------
+template <int T, int BKP>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {
+    constexpr int LD = (T == 16) ? 16 : T + 16;          // LD % 32 == 16 -> the two 16-lane halves of a ds_read_b32 group hit disjoint banks
+    constexpr int TW = (T == 64) ? 2 : 1;                // 16x16 MFMA tiles per wave per dim
+    constexpr int LPP = T / 4;                           // float4 lanes per pixel row
+    static_assert(BKP * T == 1024, "one float4 per thread per operand per step");
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKP * LD + ((T == 16) ? 4 * 256 : 0)];
+    float* Ds = smem;
+    float* Xs = smem + 2 * BKP * LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nti = a.Cin / T;
+    const int tile_c = blockIdx.x / nti, tile_i = blockIdx.x % nti;
+    const int tap = blockIdx.y, kh = tap / a.KW, kw = tap % a.KW;
+    const int c0 = tile_c * T, i0 = tile_i * T;
+    const int HoWo = a.Ho * a.Wo;
+    const int s_begin = blockIdx.z * steps_per_split;
+    const int s_end = min(s_begin + steps_per_split, steps_total);
+    if (s_begin >= s_end) return;
+
+    const int lk = tid / LPP, lc = (tid % LPP) * 4;      // this thread's pixel-in-chunk and channel quad
+    float4 rd, rx;
+    auto gload = [&](int step) {
+        const int m = step * BKP + lk;
+        rd = make_float4(0.f, 0.f, 0.f, 0.f); rx = rd;
+        if (m < a.M) {
+            const int n = m / HoWo, r = m - n * HoWo, oh = r / a.Wo, ow = r - oh * a.Wo;
+            rd = *reinterpret_cast<const float4*>(a.dy + (long)n * a.dy_bs + (long)r * a.dy_ps + c0 + lc);
+            int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+            bool ok = true;
+            if (a.padmode == PAD_REFLECT) { ih = refl_idx(ih, a.H); iw = refl_idx(iw, a.W); }
+            else ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            if (ok) rx = *reinterpret_cast<const float4*>(a.x + (long)n * a.x_bs + ((long)ih * a.W + iw) * a.x_ps + i0 + lc);
+        }
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<float4*>(Ds + buf * BKP * LD + lk * LD + lc) = rd;
+        *reinterpret_cast<float4*>(Xs + buf * BKP * LD + lk * LD + lc) = rx;
+    };
+
+    f32x4 acc[TW][TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // wave -> sub-tile / k-slice
+    const int wr = (T == 16) ? 0 : (wave & 1), wq = (T == 16) ? 0 : (wave >> 1);
+    constexpr int KQ = (T == 16) ? BKP / 16 : BKP / 4;   // k-quads this wave walks per step
+    const int kq0 = (T == 16) ? wave * KQ : 0;
+
+    gload(s_begin);
+    lstore(0);
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) gload(s + 1);
+        const float* D = Ds + buf * BKP * LD;
+        const float* X = Xs + buf * BKP * LD;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            const int k = (kq0 + kk) * 4 + (lane >> 4);
+            float af[TW], bf[TW];
+#pragma unroll
+            for (int i = 0; i < TW; ++i) af[i] = D[k * LD + wr * 16 * TW + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) bf[j] = X[k * LD + wq * 16 * TW + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < s_end) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int taps = a.KH * a.KW;
+    if (T == 16) {
+        float* red = smem + 2 * 2 * BKP * LD;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave * 256 + e * 64 + lane] = acc[0][0][e];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = red[e * 64 + lane] + red[256 + e * 64 + lane] + red[512 + e * 64 + lane] + red[768 + e * 64 + lane];
+                const int co = c0 + 4 * (lane >> 4) + e, ci = i0 + (lane & 15);
+                atomicAdd(a.dw + ((long)co * taps + tap) * a.Cin + ci, v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = c0 + wr * 16 * TW + i * 16 + 4 * (lane >> 4) + e, ci = i0 + wq * 16 * TW + j * 16 + (lane & 15);
+                    atomicAdd(a.dw + ((long)co * taps + tap) * a.Cin + ci, acc[i][j][e]);
+                }
+    }
+}
+
+template <int T, int BKP>
+static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
+    const int tiles = (a.Cout / T) * (a.Cin / T), taps = a.KH * a.KW;
+    const int steps_total = (a.M + BKP - 1) / BKP;
+    int splitk = (2048 + tiles * taps - 1) / (tiles * taps);
+    // keep at least 8 steps per split so the per-block atomic epilogue is amortised
+    splitk = std::max(1, std::min(splitk, (steps_total + 7) / 8));
+    const int sps = (steps_total + splitk - 1) / splitk;
+    splitk = (steps_total + sps - 1) / sps;
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP>), dim3(tiles, taps, splitk), dim3(256), 0, s, a, sps, steps_total);
+}
+
+void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
+    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || a.M <= 0) {
+        fprintf(stderr, "md2: conv_wgrad: unsupported shape Cin=%d Cout=%d\n", a.Cin, a.Cout);
+        abort();
+    }
+    if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 16>(a, s);
+    else if (a.Cin % 32 == 0 && a.Cout % 32 == 0) launch_wgrad_tile<32, 32>(a, s);
+    else launch_wgrad_tile<16, 64>(a, s);
+}
+
+// w_dg[ci][taps-1-t][co] = w_fwd[co][t][ci]
+__global__ void weight_to_dgrad_kernel(const float* __restrict__ wf, float* __restrict__ wd, int Cout, int Cin, int taps) {
+    const long n = (long)Cout * Cin * taps;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // i indexes the OUTPUT (coalesced writes): [ci][t'][co]
+        const int co = i % Cout; const long r = i / Cout; const int tp = r % taps; const int ci = r / taps;
+        wd[i] = wf[((long)co * taps + (taps - 1 - tp)) * Cin + ci];
+    }
+}
+void launch_weight_to_dgrad(const float* w_fwd, float* w_dg, int CoutP, int CinP, int taps, hipStream_t s) {
+    const long n = (long)CoutP * CinP * taps;
+    const int grid = (int)std::min<long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(weight_to_dgrad_kernel, dim3(grid), dim3(256), 0, s, w_fwd, w_dg, CoutP, CinP, taps);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// disparity heads: reflect-pad 3x3 conv to ONE channel + sigmoid (src/depth_decoder.jl:43).  Memory-bound GEMV:
+// LPP = Cin/4 lanes share one pixel (one float4 of channels each), shuffle-reduce inside the lane group.
+// ------------------------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(256) void head_fwd_kernel(View x, const float* __restrict__ w, const float* __restrict__ b, View y) {
+    const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
+    constexpr int PPB = 256 / LPP;
+    float4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(w + t * x.C + l * 4);
+    const float bias = b[0];
+    const long P = x.pixels();
+    const int HW = x.H * x.W;
+    for (long p = (long)blockIdx.x * PPB + g; p < P; p += (long)gridDim.x * PPB) {
+        const int n = p / HW, r = p - (long)n * HW, h = r / x.W, wq = r - h * x.W;
+        float s = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = refl_idx(h + kh - 1, x.H);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = refl_idx(wq + kw - 1, x.W);
+                const float4 v = *reinterpret_cast<const float4*>(x.p + (long)n * x.bs + ((long)ih * x.W + iw) * x.ps + l * 4);
+                const float4 c = wv[kh * 3 + kw];
+                s += v.x * c.x + v.y * c.y + v.z * c.z + v.w * c.w;
+            }
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (l == 0) y.p[(long)n * y.bs + (long)r * y.ps] = 1.f / (1.f + expf(-(s + bias)));
+    }
+}
+void launch_head_fwd(const View& x, const float* w, const float* b, const View& y, hipStream_t s) {
+    const long P = x.pixels();
+    const int lpp = x.C / 4, ppb = 256 / lpp;
+    const int grid = (int)std::min<long>((P + ppb - 1) / ppb, 4096);
+    switch (lpp) {
+        case 4: hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
+        case 8: hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
+        case 16: hipLaunchKernelGGL(head_fwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
+        case 32: hipLaunchKernelGGL(head_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
+        default: fprintf(stderr, "md2: head_fwd: unsupported Cin=%d\n", x.C); abort();
+    }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void head_bwd_kernel(View x, const float* __restrict__ w, View y, View dy, View dx, int accumulate,
+                                                       float* __restrict__ dw, float* __restrict__ db) {
+    const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
+    constexpr int PPB = 256 / LPP;
+    __shared__ float red[9 * 4 * 256];
+    float4 wv[9], gw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wv[t] = *reinterpret_cast<const float4*>(w + t * x.C + l * 4); gw[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    float gb = 0.f;
+    const long P = x.pixels();
+    const int HW = x.H * x.W, H = x.H, W = x.W;
+    auto dz_at = [&](int n, int h, int wq) -> float {
+        const long o = (long)h * W + wq;
+        const float yv = y.p[(long)n * y.bs + o * y.ps];
+        return dy.p[(long)n * dy.bs + o * dy.ps] * yv * (1.f - yv);
+    };
+    for (long p = (long)blockIdx.x * PPB + g; p < P; p += (long)gridDim.x * PPB) {
+        const int n = p / HW, r = p - (long)n * HW, h = r / W, wq = r - h * W;
+        // ---- weight gradient: dz[p] * x[refl(p + tap - 1)]
+        const float dzp = dz_at(n, h, wq);
+        if (l == 0) gb += dzp;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = refl_idx(h + kh - 1, H);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = refl_idx(wq + kw - 1, W);
+                const float4 v = *reinterpret_cast<const float4*>(x.p + (long)n * x.bs + ((long)ih * W + iw) * x.ps + l * 4);
+                float4& a4 = gw[kh * 3 + kw];
+                a4.x += dzp * v.x; a4.y += dzp * v.y; a4.z += dzp * v.z; a4.w += dzp * v.w;
+            }
+        }
+        // ---- input gradient with the reflect-pad adjoint: dx[r] = sum over padded u with refl(u) = r of sum_tap W[tap] dz[u - tap + 1]
+        float4 gx = make_float4(0.f, 0.f, 0.f, 0.f);
+        int uys[3], uxs[3], ny = 0, nx = 0;
+        uys[ny++] = h; if (h == 1) uys[ny++] = -1; if (h == H - 2) uys[ny++] = H;
+        uxs[nx++] = wq; if (wq == 1) uxs[nx++] = -1; if (wq == W - 2) uxs[nx++] = W;
+        for (int a_ = 0; a_ < ny; ++a_)
+            for (int b_ = 0; b_ < nx; ++b_)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int qh = uys[a_] - kh + 1;
+                    if (qh < 0 || qh >= H) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int qw = uxs[b_] - kw + 1;
+                        if (qw < 0 || qw >= W) continue;
+                        const float d = dz_at(n, qh, qw);
+                        const float4 c = wv[kh * 3 + kw];
+                        gx.x += d * c.x; gx.y += d * c.y; gx.z += d * c.z; gx.w += d * c.w;
+                    }
+                }
+        float* dp = dx.p + (long)n * dx.bs + (long)r * dx.ps + l * 4;
+        if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dp); gx.x += o.x; gx.y += o.y; gx.z += o.z; gx.w += o.w; }
+        *reinterpret_cast<float4*>(dp) = gx;
+    }
+    // block reduction of the weight gradient over the PPB pixel groups
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        red[(t * 4 + 0) * 256 + threadIdx.x] = gw[t].x; red[(t * 4 + 1) * 256 + threadIdx.x] = gw[t].y;
+        red[(t * 4 + 2) * 256 + threadIdx.x] = gw[t].z; red[(t * 4 + 3) * 256 + threadIdx.x] = gw[t].w;
+    }
+    __syncthreads();
+    // 36*LPP outputs: (t, e, l) ; thread i sums over g
+    for (int i = threadIdx.x; i < 36 * LPP; i += 256) {
+        const int te = i / LPP, ll = i % LPP;
+        float s = 0.f;
+        for (int gg = 0; gg < PPB; ++gg) s += red[te * 256 + gg * LPP + ll];
+        atomicAdd(dw + (te >> 2) * x.C + ll * 4 + (te & 3), s);
+    }
+    __syncthreads();
+    red[threadIdx.x] = gb;
+    __syncthreads();
+    if (threadIdx.x == 0) { float s = 0.f; for (int gg = 0; gg < PPB; ++gg) s += red[gg * LPP]; atomicAdd(db, s); }
+}
+void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, float* dw, float* db, hipStream_t s) {
+    const long P = x.pixels();
+    const int lpp = x.C / 4, ppb = 256 / lpp;
+    const int grid = (int)std::min<long>((P + ppb - 1) / ppb, 1024);
+    switch (lpp) {
+        case 4: hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, y, dy, dx, accumulate, dw, db); break;
+        case 8: hipLaunchKernelGGL(head_bwd_kernel<8>, dim3(grid), dim3(256), 0, s, x, w, y, dy, dx, accumulate, dw, db); break;
+        case 16: hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, y, dy, dx, accumulate, dw, db); break;
+        case 32: hipLaunchKernelGGL(head_bwd_kernel<32>, dim3(grid), dim3(256), 0, s, x, w, y, dy, dx, accumulate, dw, db); break;
+        default: fprintf(stderr, "md2: head_bwd: unsupported Cin=%d\n", x.C); abort();
+    }
+}
+
+}  // namespace md2

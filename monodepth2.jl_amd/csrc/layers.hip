@@ -1,0 +1,392 @@
+// layers.hip — the HBM-bound layer kernels around the MFMA convolutions (gfx950).
+// Replaces: cuDNN BatchNorm/MaxPool, NNlibCUDA upsample_bilinear, NNlib pad_reflect pullback, Flux ADAM
+// broadcasts, GPUArrays mapreduce (SURVEY.md §2a k2,k3,k5,k7,k8,k10,k18,k20).  All kernels are NHWC views,
+// 16-B per lane along the channel axis, grid-stride over pixels.
+#include "md2_internal.h"
+#include <algorithm>
+
+namespace md2 {
+
+static inline int grid_for(long work, int per_block, int cap = 2048) { return (int)std::max<long>(1, std::min<long>((work + per_block - 1) / per_block, cap)); }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ const float* vptr(const View& v, int n, long r) { return v.p + (long)n * v.bs + r * v.ps; }
+__device__ __forceinline__ float* vptrw(const View& v, int n, long r) { return v.p + (long)n * v.bs + r * v.ps; }
+
+// ---- stem im2col: x [NL][C][H][W] (reference layout) -> col [NL*Ho*Wo][Kpad], k = (kh*7+kw)*C + c ; 7x7 s2 p3 -------
+__global__ void im2col_stem_kernel(const float* __restrict__ x, int NL, int C, int H, int W, float* __restrict__ col, int Kpad) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)NL * Ho * Wo * Kpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = i % Kpad; const long m = i / Kpad;
+        const int ow = m % Wo; const long t = m / Wo; const int oh = t % Ho; const int n = t / Ho;
+        float v = 0.f;
+        if (k < 49 * C) {
+            const int c = k % C, tap = k / C, kh = tap / 7, kw = tap % 7;
+            const int ih = oh * 2 - 3 + kh, iw = ow * 2 - 3 + kw;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((long)n * C + c) * H + ih) * W + iw];
+        }
+        col[i] = v;
+    }
+}
+void launch_im2col_stem(const float* x, int NL, int C, int H, int W, float* col, int Kpad, hipStream_t s) {
+    const long total = (long)NL * (H / 2) * (W / 2) * Kpad;
+    hipLaunchKernelGGL(im2col_stem_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, x, NL, C, H, W, col, Kpad);
+}
+
+// ---- layout conversion for the op-level entry points --------------------------------------------------------------
+__global__ void nchw_to_view_kernel(const float* __restrict__ src, View v) {
+    const long total = (long)v.N * v.H * v.W * v.C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % v.C; const long r = i / v.C; const long hw = r % ((long)v.H * v.W); const int n = r / ((long)v.H * v.W);
+        v.p[(long)n * v.bs + hw * v.ps + c] = src[((long)n * v.C + c) * v.H * v.W + hw];
+    }
+}
+__global__ void view_to_nchw_kernel(View v, float* __restrict__ dst) {
+    const long total = (long)v.N * v.H * v.W * v.C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long hw = i % ((long)v.H * v.W); const long r = i / ((long)v.H * v.W); const int c = r % v.C; const int n = r / v.C;
+        dst[i] = v.p[(long)n * v.bs + hw * v.ps + c];
+    }
+}
+void launch_nchw_to_view(const float* src, const View& v, hipStream_t s) {
+    hipLaunchKernelGGL(nchw_to_view_kernel, dim3(grid_for((long)v.N * v.H * v.W * v.C, 256, 4096)), dim3(256), 0, s, src, v);
+}
+void launch_nhwc_to_nchw(const float*, const View& v, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(view_to_nchw_kernel, dim3(grid_for((long)v.N * v.H * v.W * v.C, 256, 4096)), dim3(256), 0, s, v, dst);
+}
+void launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s) { launch_nchw_to_view(src, make_view(dst, N, H, W, C), s); }
+
+// ---- per-channel statistics ---------------------------------------------------------------------------------------
+// block = 256 threads = RG row-groups x (C/4) channel quads (C <= 512 -> RG >= 2).  Each thread strides over pixels,
+// LDS-reduces over row groups, then one double atomic per channel per block.
+template <int MODE>   // 0: sum z, sum z^2 ; 1: sum g, sum g*xhat  (g = dy * act'(yact))
+__global__ __launch_bounds__(256) void colstats_kernel(View z, View dy, View yact, int has_yact, int act, const float* __restrict__ stats, double* __restrict__ acc, int rows_per_block) {
+    const int Q = z.C / 4;                    // channel quads
+    const int RG = 256 / Q;                   // row groups (Q <= 128)
+    const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
+    __shared__ float red[2 * 4 * 256];
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const long P = z.pixels(); const int HW = z.H * z.W;
+    const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, P);
+    float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), istd = mean;
+    if (MODE == 1) { mean = ld4(stats + q * 4); istd = ld4(stats + z.C + q * 4); }
+    if (rg < RG)
+        for (long p = p0 + rg; p < p1; p += RG) {
+            const int n = p / HW; const long r = p - (long)n * HW;
+            const float4 v = ld4(vptr(z, n, r) + q * 4);
+            if (MODE == 0) {
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+            } else {
+                float4 g = ld4(vptr(dy, n, r) + q * 4);
+                if (has_yact) { const float4 o = ld4(vptr(yact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                s2.x += g.x * (v.x - mean.x) * istd.x; s2.y += g.y * (v.y - mean.y) * istd.y; s2.z += g.z * (v.z - mean.z) * istd.z; s2.w += g.w * (v.w - mean.w) * istd.w;
+            }
+        }
+    float* r1 = red; float* r2 = red + 4 * 256;
+    r1[0 * 256 + threadIdx.x] = s1.x; r1[1 * 256 + threadIdx.x] = s1.y; r1[2 * 256 + threadIdx.x] = s1.z; r1[3 * 256 + threadIdx.x] = s1.w;
+    r2[0 * 256 + threadIdx.x] = s2.x; r2[1 * 256 + threadIdx.x] = s2.y; r2[2 * 256 + threadIdx.x] = s2.z; r2[3 * 256 + threadIdx.x] = s2.w;
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * z.C; c += 256) {
+        const int which = c / z.C, ch = c % z.C, qq = ch / 4, e = ch % 4;
+        const float* rr = which ? r2 : r1;
+        float s = 0.f;
+        for (int g = 0; g < RG; ++g) s += rr[e * 256 + g * Q + qq];
+        atomicAdd(acc + c, (double)s);
+    }
+}
+static void colstats_launch(int mode, const View& z, const View* dy, const View* yact, int act, const float* stats, double* acc, hipStream_t s) {
+    if (z.C % 4 != 0 || z.C > 512 || 256 % (z.C / 4) != 0) { fprintf(stderr, "md2: colstats: unsupported C=%d\n", z.C); abort(); }
+    const long P = z.pixels();
+    int rpb = 2048; while (rpb > 64 && (P + rpb - 1) / rpb < 1024) rpb >>= 1;
+    const int grid = (int)((P + rpb - 1) / rpb);
+    View d = dy ? *dy : z, ya = yact ? *yact : z;
+    if (mode == 0) hipLaunchKernelGGL(colstats_kernel<0>, dim3(grid), dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb);
+    else hipLaunchKernelGGL(colstats_kernel<1>, dim3(grid), dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb);
+}
+void launch_colstats(const View& z, double* acc, hipStream_t s) { colstats_launch(0, z, nullptr, nullptr, 0, nullptr, acc, s); }
+void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View& z, const float* stats, double* acc, hipStream_t s) {
+    colstats_launch(1, z, &dy, yact, act, stats, acc, s);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int C, double count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = acc[c] / count;
+    double var = acc[C + c] / count - mean * mean;     // biased variance (Flux BatchNorm train mode)
+    if (var < 0) var = 0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+}
+void launch_bn_finalize(const double* acc, float* stats, int C, double count, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, stats, C, count);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       View res, int has_res, int act, View y) {
+    const int Q = z.C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
+        const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
+        float4 o = make_float4(g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w);
+        if (has_res) { const float4 rr = ld4(vptr(res, n, r) + q * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+        o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
+        st4(vptrw(y, n, r) + q * 4, o);
+    }
+}
+void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s) {
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(z.pixels() * (z.C / 4), 256, 4096)), dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, int has_yact, int act, View z, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const double* __restrict__ acc, double count, View dz, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int C = z.C, Q = C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += (float)acc[c]; dgamma[c] += (float)acc[C + c]; }
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
+        float4 g = ld4(vptr(dy, n, r) + q * 4);
+        if (has_yact) { const float4 o = ld4(vptr(yact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4);
+        const float m1[4] = {(float)(acc[q * 4] / count), (float)(acc[q * 4 + 1] / count), (float)(acc[q * 4 + 2] / count), (float)(acc[q * 4 + 3] / count)};
+        const float m2[4] = {(float)(acc[C + q * 4] / count), (float)(acc[C + q * 4 + 1] / count), (float)(acc[C + q * 4 + 2] / count), (float)(acc[C + q * 4 + 3] / count)};
+        float4 o;
+        o.x = ga.x * is.x * (g.x - m1[0] - (v.x - m.x) * is.x * m2[0]);
+        o.y = ga.y * is.y * (g.y - m1[1] - (v.y - m.y) * is.y * m2[1]);
+        o.z = ga.z * is.z * (g.z - m1[2] - (v.z - m.z) * is.z * m2[2]);
+        o.w = ga.w * is.w * (g.w - m1[3] - (v.w - m.w) * is.w * m2[3]);
+        st4(vptrw(dz, n, r) + q * 4, o);
+    }
+}
+void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc, double count,
+                         const View& dz, float* dgamma, float* dbeta, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(z.pixels() * (z.C / 4), 256, 4096)), dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta);
+}
+
+// ---- MaxPool((3,3); pad=1, stride=2): first maximum in (kh,kw) scan order wins; the argmax tap (0..8) is kept ------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(View x, View y, uint8_t* __restrict__ arg) {
+    const int Q = x.C / 4; const long total = y.pixels() * Q; const int HWo = y.H * y.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HWo; const int r = p - (long)n * HWo; const int oh = r / y.W, ow = r - oh * y.W;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; uint8_t bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh; if (ih < 0 || ih >= x.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw; if (iw < 0 || iw >= x.W) continue;
+                const float4 v = ld4(vptr(x, n, (long)ih * x.W + iw) + q * 4);
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (vv[e] > best[e]) { best[e] = vv[e]; bi[e] = kh * 3 + kw; }
+            }
+        }
+        st4(vptrw(y, n, r) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
+        *reinterpret_cast<uchar4*>(arg + (p * x.C + q * 4)) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s) {
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(y.pixels() * (x.C / 4), 256, 4096)), dim3(256), 0, s, x, y, arg);
+}
+// gather form: input pixel (ih,iw) is covered by outputs oh in {(ih+1)/2 - (0|1)}...; no atomics, deterministic
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View xact, int has_xact) {
+    const int Q = dx.C / 4; const long total = dx.pixels() * Q; const int HW = dx.H * dx.W, HWo = dy.H * dy.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int ih = r / dx.W, iw = r - ih * dx.W;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = ih + 1 - kh; if (t < 0 || (t & 1)) continue; const int oh = t >> 1; if (oh >= dy.H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int u = iw + 1 - kw; if (u < 0 || (u & 1)) continue; const int ow = u >> 1; if (ow >= dy.W) continue;
+                const long po = (long)n * HWo + (long)oh * dy.W + ow;
+                const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (po * dx.C + q * 4));
+                const float4 d = ld4(vptr(dy, n, (long)oh * dy.W + ow) + q * 4);
+                const int tap = kh * 3 + kw;
+                if (a.x == tap) g[0] += d.x; if (a.y == tap) g[1] += d.y; if (a.z == tap) g[2] += d.z; if (a.w == tap) g[3] += d.w;
+            }
+        }
+        float* dp = vptrw(dx, n, r) + q * 4;
+        if (accumulate) { const float4 o = ld4(dp); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
+        if (has_xact) { const float4 o = ld4(vptr(xact, n, r) + q * 4); g[0] *= act_deriv(o.x, ACT_RELU); g[1] *= act_deriv(o.y, ACT_RELU); g[2] *= act_deriv(o.z, ACT_RELU); g[3] *= act_deriv(o.w, ACT_RELU); }
+        st4(dp, make_float4(g[0], g[1], g[2], g[3]));
+    }
+}
+void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* xact, hipStream_t s) {
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(dx.pixels() * (dx.C / 4), 256, 4096)), dim3(256), 0, s, dy, arg, dx, accumulate, xact ? *xact : dx, xact ? 1 : 0);
+}
+
+// ---- NNlib.upsample_bilinear(x, (2,2)) (src/depth_decoder.jl:18-19), align-corners mapping --------------------------------
+__device__ __forceinline__ void up_src(int o, int in, int out, int& i0, int& i1, float& w1) {
+    const float ratio = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float s = ratio * (float)o;
+    i0 = min((int)floorf(s), in - 1);
+    i1 = min(i0 + 1, in - 1);
+    w1 = s - (float)i0;
+}
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y) {
+    const int Q = x.C / 4; const long total = y.pixels() * Q; const int HWo = y.H * y.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HWo; const int r = p - (long)n * HWo; const int oh = r / y.W, ow = r - oh * y.W;
+        int h0, h1, w0, w1; float fh, fw; up_src(oh, x.H, y.H, h0, h1, fh); up_src(ow, x.W, y.W, w0, w1, fw);
+        const float4 a = ld4(vptr(x, n, (long)h0 * x.W + w0) + q * 4), b = ld4(vptr(x, n, (long)h0 * x.W + w1) + q * 4);
+        const float4 c = ld4(vptr(x, n, (long)h1 * x.W + w0) + q * 4), d = ld4(vptr(x, n, (long)h1 * x.W + w1) + q * 4);
+        const float gh = 1.f - fh, gw = 1.f - fw;
+        float4 o;
+        o.x = gh * (gw * a.x + fw * b.x) + fh * (gw * c.x + fw * d.x); o.y = gh * (gw * a.y + fw * b.y) + fh * (gw * c.y + fw * d.y);
+        o.z = gh * (gw * a.z + fw * b.z) + fh * (gw * c.z + fw * d.z); o.w = gh * (gw * a.w + fw * b.w) + fh * (gw * c.w + fw * d.w);
+        st4(vptrw(y, n, r) + q * 4, o);
+    }
+}
+void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s) {
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(y.pixels() * (x.C / 4), 256, 4096)), dim3(256), 0, s, x, y);
+}
+// exact adjoint in gather form: every candidate output row/col recomputes the forward's (i0,i1,w1)
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(View dy, View dx, View xact, int has_xact, int act) {
+    const int Q = dx.C / 4; const long total = dx.pixels() * Q; const int HW = dx.H * dx.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int h = r / dx.W, w = r - h * dx.W;
+        // outputs oh with source index in (h-1, h+1): oh in [ (h-1)*(Ho-1)/(H-1) , (h+1)*(Ho-1)/(H-1) ]
+        const float rh = dx.H > 1 ? (float)(dy.H - 1) / (float)(dx.H - 1) : 0.f, rw = dx.W > 1 ? (float)(dy.W - 1) / (float)(dx.W - 1) : 0.f;
+        const int oh_lo = max(0, (int)floorf((h - 1) * rh) - 1), oh_hi = min(dy.H - 1, (int)ceilf((h + 1) * rh) + 1);
+        const int ow_lo = max(0, (int)floorf((w - 1) * rw) - 1), ow_hi = min(dy.W - 1, (int)ceilf((w + 1) * rw) + 1);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            int h0, h1; float fh; up_src(oh, dx.H, dy.H, h0, h1, fh);
+            const float ch = (h0 == h ? 1.f - fh : 0.f) + (h1 == h ? fh : 0.f);
+            if (ch == 0.f) continue;
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                int w0, w1; float fw; up_src(ow, dx.W, dy.W, w0, w1, fw);
+                const float cw = (w0 == w ? 1.f - fw : 0.f) + (w1 == w ? fw : 0.f);
+                if (cw == 0.f) continue;
+                const float4 d = ld4(vptr(dy, n, (long)oh * dy.W + ow) + q * 4);
+                const float c = ch * cw;
+                g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w;
+            }
+        }
+        if (has_xact) { const float4 o = ld4(vptr(xact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        st4(vptrw(dx, n, r) + q * 4, g);
+    }
+}
+void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int act, hipStream_t s) {
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(dx.pixels() * (dx.C / 4), 256, 4096)), dim3(256), 0, s, dy, dx, xact ? *xact : dx, xact ? 1 : 0, act);
+}
+
+// ---- pad_reflect(x,1) pullback: dst[r] = sum over padded u in [-1,size] with refl(u) = r of src_pad[u+1] ----------------------
+__global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, int accumulate, View actsrc, int has_act, int act) {
+    const int Q = dst.C / 4; const long total = dst.pixels() * Q; const int HW = dst.H * dst.W, H = dst.H, W = dst.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int h = r / W, w = r - h * W;
+        int uys[3], uxs[3], ny = 0, nx = 0;
+        uys[ny++] = h; if (h == 1) uys[ny++] = -1; if (h == H - 2) uys[ny++] = H;
+        uxs[nx++] = w; if (w == 1) uxs[nx++] = -1; if (w == W - 2) uxs[nx++] = W;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                const float4 d = ld4(vptr(sp, n, (long)(uys[a] + 1) * sp.W + (uxs[b] + 1)) + q * 4);
+                g.x += d.x; g.y += d.y; g.z += d.z; g.w += d.w;
+            }
+        float* dp = vptrw(dst, n, r) + q * 4;
+        if (accumulate) { const float4 o = ld4(dp); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+        if (has_act) { const float4 o = ld4(vptr(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        st4(dp, g);
+    }
+}
+void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, const View* actsrc, int act, hipStream_t s) {
+    if (src_pad.H != dst.H + 2 || src_pad.W != dst.W + 2 || src_pad.C < dst.C) { fprintf(stderr, "md2: fold_reflect: shape mismatch\n"); abort(); }
+    hipLaunchKernelGGL(fold_reflect_kernel, dim3(grid_for(dst.pixels() * (dst.C / 4), 256, 4096)), dim3(256), 0, s, src_pad, dst, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act);
+}
+
+__global__ __launch_bounds__(256) void axpy_view_kernel(View src, View dst, float a, int accumulate, View actsrc, int has_act, int act) {
+    const int Q = dst.C / 4; const long total = dst.pixels() * Q; const int HW = dst.H * dst.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
+        float4 g = ld4(vptr(src, n, r) + q * 4);
+        g.x *= a; g.y *= a; g.z *= a; g.w *= a;
+        if (has_act) { const float4 o = ld4(vptr(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        float* dp = vptrw(dst, n, r) + q * 4;
+        if (accumulate) { const float4 o = ld4(dp); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+        st4(dp, g);
+    }
+}
+void launch_axpy_view(const View& src, const View& dst, float a, int accumulate, const View* actsrc, int act, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_view_kernel, dim3(grid_for(dst.pixels() * (dst.C / 4), 256, 4096)), dim3(256), 0, s, src, dst, a, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act);
+}
+
+// ---- bias gradient: out[c] += sum over pixels -----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(View v, float* __restrict__ out, int rows_per_block) {
+    const int Q = v.C / 4, RG = 256 / Q;
+    const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
+    __shared__ float red[4 * 256];
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long P = v.pixels(); const int HW = v.H * v.W;
+    const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, P);
+    if (rg < RG)
+        for (long p = p0 + rg; p < p1; p += RG) {
+            const int n = p / HW; const long r = p - (long)n * HW;
+            const float4 x = ld4(vptr(v, n, r) + q * 4);
+            s1.x += x.x; s1.y += x.y; s1.z += x.z; s1.w += x.w;
+        }
+    red[0 * 256 + threadIdx.x] = s1.x; red[1 * 256 + threadIdx.x] = s1.y; red[2 * 256 + threadIdx.x] = s1.z; red[3 * 256 + threadIdx.x] = s1.w;
+    __syncthreads();
+    for (int c = threadIdx.x; c < v.C; c += 256) {
+        const int qq = c / 4, e = c % 4; float s = 0.f;
+        for (int g = 0; g < RG; ++g) s += red[e * 256 + g * Q + qq];
+        atomicAdd(out + c, s);
+    }
+}
+void launch_colsum(const View& v, float* out, hipStream_t s) {
+    if (v.C % 4 != 0 || v.C > 1024 || 256 % (v.C / 4) != 0) { fprintf(stderr, "md2: colsum: unsupported C=%d\n", v.C); abort(); }
+    const long P = v.pixels();
+    int rpb = 2048; while (rpb > 64 && (P + rpb - 1) / rpb < 512) rpb >>= 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((int)((P + rpb - 1) / rpb)), dim3(256), 0, s, v, out, rpb);
+}
+
+// ---- pose head tail: mean over (W,H) * 0.01 (src/pose_decoder.jl:29-31); y view [B][h*w][>=6 channels] -------------------------
+__global__ void pose_mean_fwd_kernel(View y, float* __restrict__ rvec, float* __restrict__ tvec) {
+    const int b = blockIdx.x, c = threadIdx.x >> 5, l = threadIdx.x & 31;   // 6 channels x 32 lanes
+    if (c >= 6) return;
+    const int HW = y.H * y.W; float s = 0.f;
+    for (int r = l; r < HW; r += 32) s += y.p[(long)b * y.bs + (long)r * y.ps + c];
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (l == 0) { const float v = 0.01f * (s / (float)HW); if (c < 3) rvec[b * 3 + c] = v; else tvec[b * 3 + c - 3] = v; }
+}
+void launch_pose_mean_fwd(const View& y, float* rvec, float* tvec, hipStream_t s) { hipLaunchKernelGGL(pose_mean_fwd_kernel, dim3(y.N), dim3(192), 0, s, y, rvec, tvec); }
+__global__ void pose_mean_bwd_kernel(const float* __restrict__ drvec, const float* __restrict__ dtvec, View dy) {
+    const int HW = dy.H * dy.W; const long total = (long)dy.N * HW * dy.C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = i % dy.C; const long pr = i / dy.C; const int r = pr % HW; const int b = pr / HW;
+        float g = 0.f;
+        if (c < 3) g = 0.01f * drvec[b * 3 + c] / (float)HW; else if (c < 6) g = 0.01f * dtvec[b * 3 + c - 3] / (float)HW;
+        dy.p[(long)b * dy.bs + (long)r * dy.ps + c] = g;
+    }
+}
+void launch_pose_mean_bwd(const float* drvec, const float* dtvec, const View& dy, hipStream_t s) {
+    hipLaunchKernelGGL(pose_mean_bwd_kernel, dim3(grid_for((long)dy.N * dy.H * dy.W * dy.C, 256, 1024)), dim3(256), 0, s, drvec, dtvec, dy);
+}
+
+// ---- Flux ADAM (beta 0.9/0.999, eps 1e-8): one fused pass over the flat parameter buffer ------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n4, float c1, float c2, float lr, float gs) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 P = ld4(p + i * 4), G = ld4(g + i * 4), M = ld4(m + i * 4), V = ld4(v + i * 4);
+        float* pp = &P.x; float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gg[e] * gs;
+            mm[e] = 0.9f * mm[e] + (1.f - 0.9f) * ge;
+            vv[e] = 0.999f * vv[e] + (1.f - 0.999f) * ge * ge;
+            pp[e] -= mm[e] / c1 / (sqrtf(vv[e] / c2) + 1e-8f) * lr;
+        }
+        st4(p + i * 4, P); st4(m + i * 4, M); st4(v + i * 4, V);
+    }
+}
+void launch_adam(float* p, const float* g, float* m, float* v, long n, float c1, float c2, float lr, float gscale, hipStream_t s) {
+    if (n % 4 != 0) { fprintf(stderr, "md2: adam: n %% 4 != 0\n"); abort(); }
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, s, p, g, m, v, n / 4, c1, c2, lr, gscale);
+}
+__global__ void fill_kernel(float* p, long n, float v) { for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v; }
+void launch_fill(float* p, long n, float v, hipStream_t s) { hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, n, v); }
+
+}  // namespace md2

@@ -1,0 +1,703 @@
+// loss.hip — fused photometric loss of the self-supervised step (gfx950), forward and backward.
+//
+// Replaces the ~400 small kernels of src/training.jl:42-75 (SURVEY.md §2a k5,k10-k18): per scale
+//   upsample_bilinear(disp) -> disparity_to_depth -> Backproject -> Project (x2 sources) -> grid_sample(:border)
+//   -> SSIM (pad_reflect + 5 MeanPools) + L1 -> minimum over sources [-> automask] -> mean ; + smooth_loss
+// with ONE launch for all 4 scales (grid.z = scale*N + n).  Nothing is materialised in HBM: a 32x16 pixel tile
+// (+1 px halo, reflect-mapped like pad_reflect) of both warped sources and the target is built in LDS, the 3x3
+// window statistics are read from LDS, and only per-(scale,sample) partial sums leave the block.
+// Algorithmic HBM bytes per sample per scale (fwd): 4P(1+3C).
+// The backward recomputes the warp (reads the same bytes) and writes d loss / d disparity (4P per scale) plus
+// 24 pose-gradient partials per block (wave shuffle + LDS reduction, no per-pixel atomics).
+#include "md2_internal.h"
+#include <algorithm>
+
+namespace md2 {
+
+constexpr int TW = 32, TH = 16;           // tile
+constexpr int FW = TW + 2, FH = TH + 2;   // fwd region (halo 1)
+constexpr int BW2 = TW + 4, BH2 = TH + 4; // bwd value region (halo 2)
+constexpr int MAXC = 3;
+
+struct Pose12 { float R[9]; float t[3]; };   // column-major R
+
+__device__ __forceinline__ void up_src_f(int o, int in, int out, int& i0, int& i1, float& w1) {
+    const float ratio = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float s = ratio * (float)o;
+    i0 = min((int)floorf(s), in - 1);
+    i1 = min(i0 + 1, in - 1);
+    w1 = s - (float)i0;
+}
+// disparity of scale `sc` at full-resolution pixel (py,px): identity at full res, else NNlib.upsample_bilinear (src/training.jl:44-46)
+__device__ __forceinline__ float disp_at(const float* __restrict__ d, int dh, int dw, int H, int W, int py, int px) {
+    if (dh == H && dw == W) return d[(long)py * W + px];
+    int h0, h1, w0, w1; float fh, fw;
+    up_src_f(py, dh, H, h0, h1, fh); up_src_f(px, dw, W, w0, w1, fw);
+    return (1.f - fh) * ((1.f - fw) * d[h0 * dw + w0] + fw * d[h0 * dw + w1]) + fh * ((1.f - fw) * d[h1 * dw + w0] + fw * d[h1 * dw + w1]);
+}
+struct Proj { float x, y, mx, my; float P[3]; float c[3]; float denom; };
+// disparity_to_depth + Backproject + Project + grid-sample coordinate (src/utils.jl:175-179,63-65,95-99; NNlib unnormalize + :border clamp)
+__device__ __forceinline__ void project_px(float d, int py, int px, const float* __restrict__ K, const float* __restrict__ invK, const Pose12& T,
+                                           float min_disp, float max_disp, int H, int W, Proj& o) {
+    const float depth = 1.f / (d * (max_disp - min_disp) + min_disp);
+    const float cx = (float)(px + 1), cy = (float)(py + 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.P[i] = depth * (invK[i] * cx + invK[3 + i] * cy + invK[6 + i] * 1.f);
+    float r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[i] = (T.R[i] * o.P[0] + T.R[3 + i] * o.P[1] + T.R[6 + i] * o.P[2]) + T.t[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.c[i] = K[i] * r[0] + K[3 + i] * r[1] + K[6 + i] * r[2];
+    o.denom = 1.f / (o.c[2] + 1e-7f);
+    const float gx = (((o.c[0] * o.denom - 1.f) / (float)(W - 1)) - 0.5f) * 2.f;
+    const float gy = (((o.c[1] * o.denom - 1.f) / (float)(H - 1)) - 0.5f) * 2.f;
+    float x = ((gx + 1.f) * 0.5f) * (float)(W - 1), y = ((gy + 1.f) * 0.5f) * (float)(H - 1);
+    o.mx = 0.5f * (float)(W - 1); o.my = 0.5f * (float)(H - 1);
+    if (!(x > 0.f)) { x = 0.f; o.mx = 0.f; } else if (x >= (float)(W - 1)) { x = (float)(W - 1); o.mx = 0.f; }
+    if (!(y > 0.f)) { y = 0.f; o.my = 0.f; } else if (y >= (float)(H - 1)) { y = (float)(H - 1); o.my = 0.f; }
+    o.x = x; o.y = y;
+}
+struct Samp { int i00, i01, i10, i11; float wx0, wx1, wy0, wy1; bool v01, v10, v11; };
+__device__ __forceinline__ void sample_setup(float x, float y, int H, int W, Samp& s) {
+    const float fx = floorf(x), fy = floorf(y);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    s.wx1 = x - fx; s.wx0 = 1.f - s.wx1; s.wy1 = y - fy; s.wy0 = 1.f - s.wy1;
+    const bool vx1 = x1 < W, vy1 = y1 < H;          // x0,y0 always valid after the border clamp
+    s.v01 = vx1; s.v10 = vy1; s.v11 = vx1 && vy1;
+    s.i00 = y0 * W + x0; s.i01 = y0 * W + (vx1 ? x1 : x0); s.i10 = (vy1 ? y1 : y0) * W + x0; s.i11 = (vy1 ? y1 : y0) * W + (vx1 ? x1 : x0);
+}
+__device__ __forceinline__ float sample_val(const float* __restrict__ im, const Samp& s) {
+    const float v00 = im[s.i00], v01 = s.v01 ? im[s.i01] : 0.f, v10 = s.v10 ? im[s.i10] : 0.f, v11 = s.v11 ? im[s.i11] : 0.f;
+    return v00 * s.wy0 * s.wx0 + v01 * s.wy0 * s.wx1 + v10 * s.wy1 * s.wx0 + v11 * s.wy1 * s.wx1;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct SsimOut { float val; float g_mx, g_pxx, g_pxy; };   // SSIM value and d val / d(pool x, pool x^2, pool xy) (0 outside the clamp)
+// SSIM functor arithmetic (src/utils.jl:28-38) from the nine-sample window sums
+__device__ __forceinline__ void ssim_from_sums(float sx, float sy, float sxx, float syy, float sxy, bool want_grad, SsimOut& o) {
+    const float mx = sx / 9.f, my = sy / 9.f, pxx = sxx / 9.f, pyy = syy / 9.f, pxy = sxy / 9.f;
+    const float c1 = 0.0001f, c2 = 0.0009f;
+    const float vx = pxx - mx * mx, vy = pyy - my * my, vxy = pxy - mx * my;
+    const float n1 = 2.f * mx * my + c1, n2 = 2.f * vxy + c2, d1 = mx * mx + my * my + c1, d2 = vx + vy + c2;
+    const float sn = n1 * n2, sd = d1 * d2;
+    const float v = (1.f - sn / sd) * 0.5f;
+    o.val = fminf(fmaxf(v, 0.f), 1.f);
+    if (want_grad) {
+        const float g = (v >= 0.f && v <= 1.f) ? 1.f : 0.f;
+        const float gsn = -0.5f * g / sd, gsd = 0.5f * g * sn / (sd * sd);
+        const float gn1 = gsn * n2, gn2 = gsn * n1, gd1 = gsd * d2, gd2 = gsd * d1;
+        o.g_pxx = gd2; o.g_pxy = 2.f * gn2;
+        o.g_mx = gn1 * 2.f * my + gd1 * 2.f * mx - gd2 * 2.f * mx - 2.f * gn2 * my;
+    }
+}
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double* __restrict__ part) {
+    __shared__ float wv[2][MAXC][FH * FW];   // warped sources (padded positions)
+    __shared__ float tg[MAXC][FH * FW];      // target
+    __shared__ float dl[FH * FW];            // disparity
+    __shared__ float red[4][4];
+    const int zi = blockIdx.z, sc = zi / a.N, n = zi % a.N;
+    const int H = a.H, W = a.W, C = a.C;
+    const long P = (long)H * W;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const float* xn = a.x + (long)n * 3 * C * P;
+    const float* tgt = xn + (long)a.tgt * C * P;
+    const float* srcs[2] = {xn + (long)a.src0 * C * P, xn + (long)a.src1 * C * P};
+    const float* dsp = a.disp[sc] + (long)n * a.dh[sc] * a.dw[sc];
+    Pose12 T[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float* rt = a.Rt + ((long)s * a.N + n) * 12;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) T[s].R[i] = rt[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[s].t[i] = rt[9 + i];
+    }
+    // ---- phase 1: warped / target / disparity at the padded positions of tile + 1
+    for (int i = threadIdx.x; i < FH * FW; i += 256) {
+        const int ry = i / FW, rx = i - ry * FW;
+        const int py = refl_idx(min(ty0 - 1 + ry, H), H), px = refl_idx(min(tx0 - 1 + rx, W), W);   // positions past the padded image are never used
+        const float d = disp_at(dsp, a.dh[sc], a.dw[sc], H, W, py, px);
+        dl[i] = d;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            Proj pr; project_px(d, py, px, a.K, a.invK, T[s], a.min_disp, a.max_disp, H, W, pr);
+            Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
+            for (int c = 0; c < C; ++c) wv[s][c][i] = sample_val(srcs[s] + (long)c * P, sm);
+        }
+        for (int c = 0; c < C; ++c) tg[c][i] = tgt[(long)c * P + (long)py * W + px];
+    }
+    __syncthreads();
+    // ---- phase 2: per pixel SSIM + L1 -> photometric -> min over sources [-> automask]; smoothness terms
+    float s_photo = 0.f, s_d = 0.f, s_x = 0.f, s_y = 0.f;
+    const float alpha = 0.85f, beta = 1.f - alpha, invC = 1.f / (float)C;
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int ly = i / TW, lx = i - ly * TW, py = ty0 + ly, px = tx0 + lx;
+        if (py >= H || px >= W) continue;
+        const int ctr = (ly + 1) * FW + lx + 1;
+        float pl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float ss = 0.f, l1 = 0.f;
+            for (int c = 0; c < C; ++c) {
+                float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const float xv = wv[s][c][ctr + dy * FW + dx], yv = tg[c][ctr + dy * FW + dx];
+                        sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+                    }
+                SsimOut so; ssim_from_sums(sx, sy, sxx, syy, sxy, false, so);
+                ss += so.val; l1 += fabsf(tg[c][ctr] - wv[s][c][ctr]);
+            }
+            pl[s] = alpha * (ss * invC) + beta * (l1 * invC);
+        }
+        float wl = pl[1] < pl[0] ? pl[1] : pl[0];
+        if (a.auto_loss) { const float al = a.auto_loss[(long)n * P + (long)py * W + px]; if (!(wl < al)) wl = al; }
+        s_photo += wl;
+        const float d = dl[ctr];
+        s_d += d;
+        if (px + 1 < W) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][ctr] - tg[c][ctr + 1]); if (C > 1) gi *= invC; s_x += fabsf(d - dl[ctr + 1]) * expf(-gi); }
+        if (py + 1 < H) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][ctr] - tg[c][ctr + FW]); if (C > 1) gi *= invC; s_y += fabsf(d - dl[ctr + FW]) * expf(-gi); }
+    }
+    s_photo = wave_sum(s_photo); s_d = wave_sum(s_d); s_x = wave_sum(s_x); s_y = wave_sum(s_y);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = s_photo; red[wave][1] = s_d; red[wave][2] = s_x; red[wave][3] = s_y; }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(part + (long)zi * 4 + threadIdx.x, (double)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+void launch_loss_fwd(const LossArgs& a, double* part, hipStream_t s) {
+    if (a.C > MAXC || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_fwd: unsupported C=%d H=%d W=%d\n", a.C, a.H, a.W); abort(); }
+    dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N * a.nscales);
+    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, s, a, part);
+}
+
+// totals[(sc*N+n)*4 + {0: photo sum, 1: mean d, 2: Sx, 3: Sy}] ; loss = mean over scales of [mean(warp_loss) + smooth]
+__global__ void loss_finalize_kernel(LossArgs a, const double* __restrict__ part, float* __restrict__ totals, float* __restrict__ loss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double P = (double)a.H * a.W, cntx = (double)(a.W - 1) * a.H * a.N, cnty = (double)a.W * (a.H - 1) * a.N;
+    double total = 0;
+    for (int sc = 0; sc < a.nscales; ++sc) {
+        double photo = 0, smooth = 0;
+        for (int n = 0; n < a.N; ++n) {
+            const double* p = part + ((long)sc * a.N + n) * 4;
+            const float mean_d = (float)(p[1] / P);
+            photo += p[0];
+            smooth += (p[2] / cntx + p[3] / cnty) / (double)(mean_d + 1e-7f);
+            float* t = totals + ((long)sc * a.N + n) * 4;
+            t[0] = (float)p[0]; t[1] = mean_d; t[2] = (float)p[2]; t[3] = (float)p[3];
+        }
+        total += photo / (P * a.N) + smooth * (double)a.smooth_w[sc];
+    }
+    *loss = (float)(total / a.nscales);
+}
+void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, a, part, totals, loss);
+}
+
+// =====================================================================================================================
+// backward
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* __restrict__ totals, float* __restrict__ ddisp_full, double* __restrict__ dRt_acc) {
+    __shared__ float wv[2][MAXC][BH2 * BW2];     // warped sources at padded positions of tile + 2
+    __shared__ float tg[MAXC][BH2 * BW2];
+    __shared__ float dl[BH2 * BW2];
+    __shared__ float coef[MAXC][3][FH * FW];     // d photometric_{s*} / d (pool x, pool x^2, pool xy) at q in tile + 1, pre-scaled
+    __shared__ signed char amin[FH * FW];        // winning source at q, -1: none (outside / masked)
+    __shared__ float red[4][24];
+    const int zi = blockIdx.z, sc = zi / a.N, n = zi % a.N;
+    const int H = a.H, W = a.W, C = a.C;
+    const long P = (long)H * W;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const float* xn = a.x + (long)n * 3 * C * P;
+    const float* tgt = xn + (long)a.tgt * C * P;
+    const float* srcs[2] = {xn + (long)a.src0 * C * P, xn + (long)a.src1 * C * P};
+    const float* dsp = a.disp[sc] + (long)n * a.dh[sc] * a.dw[sc];
+    Pose12 T[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float* rt = a.Rt + ((long)s * a.N + n) * 12;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) T[s].R[i] = rt[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[s].t[i] = rt[9 + i];
+    }
+    const float alpha = 0.85f, beta = 1.f - alpha, invC = 1.f / (float)C;
+    const float wpix = 1.f / ((float)a.nscales * (float)a.N * (float)P);      // d loss / d warp_loss[q]
+    // ---- phase 1: values at padded positions u in tile + 2 (u clamped into the padded domain [-1, size])
+    for (int i = threadIdx.x; i < BH2 * BW2; i += 256) {
+        const int ry = i / BW2, rx = i - ry * BW2;
+        const int uy = max(-1, min(ty0 - 2 + ry, H)), ux = max(-1, min(tx0 - 2 + rx, W));
+        const int py = refl_idx(uy, H), px = refl_idx(ux, W);
+        const float d = disp_at(dsp, a.dh[sc], a.dw[sc], H, W, py, px);
+        dl[i] = d;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            Proj pr; project_px(d, py, px, a.K, a.invK, T[s], a.min_disp, a.max_disp, H, W, pr);
+            Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
+            for (int c = 0; c < C; ++c) wv[s][c][i] = sample_val(srcs[s] + (long)c * P, sm);
+        }
+        for (int c = 0; c < C; ++c) tg[c][i] = tgt[(long)c * P + (long)py * W + px];
+    }
+    __syncthreads();
+    // ---- phase 2: window owners q in tile + 1: photometric of both sources, arg-min, SSIM pullback coefficients
+    for (int i = threadIdx.x; i < FH * FW; i += 256) {
+        const int ry = i / FW, rx = i - ry * FW;
+        const int qy = ty0 - 1 + ry, qx = tx0 - 1 + rx;
+        signed char win = -1;
+        if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
+            const int ctr = (ry + 1) * BW2 + rx + 1;
+            float pl[2]; SsimOut so[2][MAXC];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float ss = 0.f, l1 = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const float xv = wv[s][c][ctr + dy * BW2 + dx], yv = tg[c][ctr + dy * BW2 + dx];
+                            sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+                        }
+                    ssim_from_sums(sx, sy, sxx, syy, sxy, true, so[s][c]);
+                    ss += so[s][c].val; l1 += fabsf(tg[c][ctr] - wv[s][c][ctr]);
+                }
+                pl[s] = alpha * (ss * invC) + beta * (l1 * invC);
+            }
+            win = pl[1] < pl[0] ? 1 : 0;                                             // first arg-min (Zygote `minimum`)
+            if (a.auto_loss && !(pl[win] < a.auto_loss[(long)n * P + (long)qy * W + qx])) win = -1;   // mask wins ties -> no gradient
+            const float g = wpix * alpha * invC / 9.f;                               // through mean_c, alpha, and the /9 of MeanPool
+            for (int c = 0; c < C; ++c) {
+                const SsimOut& o = so[win < 0 ? 0 : win][c];
+                const float m = win < 0 ? 0.f : g;
+                coef[c][0][i] = m * o.g_mx; coef[c][1][i] = m * o.g_pxx; coef[c][2][i] = m * o.g_pxy;
+            }
+        } else
+            for (int c = 0; c < C; ++c) { coef[c][0][i] = 0.f; coef[c][1][i] = 0.f; coef[c][2][i] = 0.f; }
+        amin[i] = win;
+    }
+    __syncthreads();
+    // ---- phase 3: per tile pixel r: gather d loss / d warped_s[r], pull back through grid_sample, Project, Backproject, depth
+    const float* tt = totals + ((long)sc * a.N + n) * 4;
+    const float den = tt[1] + 1e-7f;
+    const double cntx = (double)(W - 1) * H * a.N, cnty = (double)W * (H - 1) * a.N;
+    const float sw = a.smooth_w[sc] / (float)a.nscales;
+    const float ax = sw / den / (float)cntx, ay = sw / den / (float)cnty;
+    const float corr = sw * (float)((double)tt[2] / cntx + (double)tt[3] / cnty) / (den * den) / (float)P;
+    float acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) acc[k] = 0.f;
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int ly = i / TW, lx = i - ly * TW, py = ty0 + ly, px = tx0 + lx;
+        if (py >= H || px >= W) continue;
+        const int cb = (ly + 2) * BW2 + lx + 2;          // r in the value region
+        // padded positions that alias r under pad_reflect
+        int uys[3], uxs[3], ny = 0, nx = 0;
+        uys[ny++] = py; if (py == 1) uys[ny++] = -1; if (py == H - 2) uys[ny++] = H;
+        uxs[nx++] = px; if (px == 1) uxs[nx++] = -1; if (px == W - 2) uxs[nx++] = W;
+        const float d = dl[cb];
+        float gd = 0.f;                                   // d loss / d disparity[r]
+        const int rwin = amin[(ly + 1) * FW + lx + 1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float gw[MAXC];
+            bool any = false;
+            for (int c = 0; c < C; ++c) {
+                float g = 0.f;
+                for (int iy = 0; iy < ny; ++iy)
+                    for (int ix = 0; ix < nx; ++ix) {
+                        const int uy = uys[iy], ux = uxs[ix];
+                        const int vb = (uy - ty0 + 2) * BW2 + (ux - tx0 + 2);   // value-region index of u (within tile + 2)
+                        const float xu = wv[s][c][vb], yu = tg[c][vb];
+#pragma unroll
+                        for (int dy = -1; dy <= 1; ++dy) {
+                            const int qy = uy + dy; if (qy < 0 || qy >= H) continue;
+#pragma unroll
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                const int qx = ux + dx; if (qx < 0 || qx >= W) continue;
+                                const int qi = (qy - ty0 + 1) * FW + (qx - tx0 + 1);
+                                if (amin[qi] != s) continue;
+                                g += coef[c][0][qi] + 2.f * xu * coef[c][1][qi] + yu * coef[c][2][qi];
+                            }
+                        }
+                    }
+                if (rwin == s) { const float df = tg[c][cb] - wv[s][c][cb]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
+                gw[c] = g; any = any || g != 0.f;
+            }
+            if (!any) continue;
+            // grid_sample pullback wrt the sampling coordinate
+            Proj pr; project_px(d, py, px, a.K, a.invK, T[s], a.min_disp, a.max_disp, H, W, pr);
+            Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
+            float ggx = 0.f, ggy = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float* im = srcs[s] + (long)c * P;
+                const float v00 = im[sm.i00], v01 = sm.v01 ? im[sm.i01] : 0.f, v10 = sm.v10 ? im[sm.i10] : 0.f, v11 = sm.v11 ? im[sm.i11] : 0.f;
+                ggx += gw[c] * ((v01 - v00) * sm.wy0 + (v11 - v10) * sm.wy1);
+                ggy += gw[c] * ((v10 - v00) * sm.wx0 + (v11 - v01) * sm.wx1);
+            }
+            ggx *= pr.mx; ggy *= pr.my;                  // unnormalise: (size-1)/2, 0 where clamped
+            // Project pullback (normalise: *2/(size-1))
+            const float gu = ggx * 2.f / (float)(W - 1), gv = ggy * 2.f / (float)(H - 1);
+            const float gc[3] = {gu * pr.denom, gv * pr.denom, -(gu * pr.c[0] + gv * pr.c[1]) * pr.denom * pr.denom};
+            float gr[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gr[j] = a.K[j * 3 + 0] * gc[0] + a.K[j * 3 + 1] * gc[1] + a.K[j * 3 + 2] * gc[2];
+            float gP[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                gP[j] = T[s].R[j * 3 + 0] * gr[0] + T[s].R[j * 3 + 1] * gr[1] + T[s].R[j * 3 + 2] * gr[2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[s * 12 + j * 3 + k] += gr[k] * pr.P[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[s * 12 + 9 + k] += gr[k];
+            // Backproject + disparity_to_depth pullback
+            const float cx = (float)(px + 1), cy = (float)(py + 1);
+            float gdepth = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gdepth += gP[k] * (a.invK[k] * cx + a.invK[3 + k] * cy + a.invK[6 + k]);
+            const float dd = d * (a.max_disp - a.min_disp) + a.min_disp;
+            gd += -gdepth * (a.max_disp - a.min_disp) / (dd * dd);
+        }
+        // smooth_loss(d / (mean + eps)) pullback
+        float gs = -corr;
+        auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+        auto ex = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + 1]); if (C > 1) gi *= invC; return expf(-gi); };
+        auto ey = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + BW2]); if (C > 1) gi *= invC; return expf(-gi); };
+        if (px + 1 < W) gs += ax * sgn(d - dl[cb + 1]) * ex(cb);
+        if (px >= 1) gs -= ax * sgn(dl[cb - 1] - d) * ex(cb - 1);
+        if (py + 1 < H) gs += ay * sgn(d - dl[cb + BW2]) * ey(cb);
+        if (py >= 1) gs -= ay * sgn(dl[cb - BW2] - d) * ey(cb - BW2);
+        ddisp_full[((long)sc * a.N + n) * P + (long)py * W + px] = gd + gs;
+    }
+    // ---- pose-gradient partials: wave shuffle, then LDS across the 4 waves, one double atomic per value per block
+#pragma unroll
+    for (int k = 0; k < 24; ++k) acc[k] = wave_sum(acc[k]);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 24; ++k) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        const int s = threadIdx.x / 12, k = threadIdx.x % 12;
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (v != 0.f) atomicAdd(dRt_acc + ((long)s * a.N + n) * 12 + k, (double)v);
+    }
+}
+void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, hipStream_t s) {
+    if (a.C > MAXC || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_bwd: unsupported shape\n"); abort(); }
+    dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N * a.nscales);
+    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc);
+}
+
+// =====================================================================================================================
+// planar bilinear resize (align-corners) and its adjoint (gather form) — NNlib.upsample_bilinear(x; size), src/training.jl:45
+// =====================================================================================================================
+__global__ void upsample_planar_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int planes, int H, int W, int Ho, int Wo) {
+    const long total = (long)planes * Ho * Wo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int wo = i % Wo; const long t = i / Wo; const int ho = t % Ho; const int p = t / Ho;
+        out[i] = disp_at(x + (long)p * H * W, H, W, Ho, Wo, ho, wo);
+    }
+}
+void launch_upsample_planar_fwd(const float* x, float* out, int planes, int H, int W, int Ho, int Wo, hipStream_t s) {
+    const long total = (long)planes * Ho * Wo;
+    hipLaunchKernelGGL(upsample_planar_fwd_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, x, out, planes, H, W, Ho, Wo);
+}
+__global__ void upsample_planar_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int planes, int H, int W, int Ho, int Wo) {
+    const long total = (long)planes * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = i % W; const long t = i / W; const int h = t % H; const int p = t / H;
+        if (H == Ho && W == Wo) { dx[i] = dout[i]; continue; }
+        const float rh = H > 1 ? (float)(Ho - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(Wo - 1) / (float)(W - 1) : 0.f;
+        const int oh_lo = max(0, (int)floorf((h - 1) * rh) - 1), oh_hi = min(Ho - 1, (int)ceilf((h + 1) * rh) + 1);
+        const int ow_lo = max(0, (int)floorf((w - 1) * rw) - 1), ow_hi = min(Wo - 1, (int)ceilf((w + 1) * rw) + 1);
+        const float* g = dout + (long)p * Ho * Wo;
+        float acc = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            int h0, h1; float fh; up_src_f(oh, H, Ho, h0, h1, fh);
+            const float ch = (h0 == h ? 1.f - fh : 0.f) + (h1 == h ? fh : 0.f);
+            if (ch == 0.f) continue;
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                int w0, w1; float fw; up_src_f(ow, W, Wo, w0, w1, fw);
+                const float cw = (w0 == w ? 1.f - fw : 0.f) + (w1 == w ? fw : 0.f);
+                if (cw != 0.f) acc += ch * cw * g[(long)oh * Wo + ow];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+void launch_upsample_planar_bwd(const float* dout, float* dx, int planes, int H, int W, int Ho, int Wo, hipStream_t s) {
+    const long total = (long)planes * H * W;
+    hipLaunchKernelGGL(upsample_planar_bwd_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, dout, dx, planes, H, W, Ho, Wo);
+}
+
+// =====================================================================================================================
+// pose: hat / so3_exp_map / composeT (src/utils.jl:101-141,181-188) and pullbacks — one thread per (source, sample)
+// =====================================================================================================================
+__device__ inline void d_hat(const float* v, float* s) {
+    for (int i = 0; i < 9; ++i) s[i] = 0.f;
+    s[0 * 3 + 1] = v[2]; s[1 * 3 + 0] = -v[2]; s[0 * 3 + 2] = -v[1]; s[2 * 3 + 0] = v[1]; s[1 * 3 + 2] = v[0]; s[2 * 3 + 1] = -v[0];
+}
+__device__ inline void d_mat3mul(const float* A, const float* B, float* C) {
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) C[j * 3 + i] = A[0 * 3 + i] * B[j * 3 + 0] + A[1 * 3 + i] * B[j * 3 + 1] + A[2 * 3 + i] * B[j * 3 + 2];
+}
+__device__ inline void d_so3(const float* v, float* R) {
+    float s[9], s2[9]; d_hat(v, s); d_mat3mul(s, s, s2);
+    const float th = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float thi = 1.f / fmaxf(th, 1e-4f);
+    const float f1 = thi * sinf(th), f2 = thi * thi * (1.f - cosf(th));
+    for (int i = 0; i < 9; ++i) R[i] = f1 * s[i] + f2 * s2[i] + ((i % 4 == 0) ? 1.f : 0.f);
+}
+// theta == 0: the reference's sqrt pullback is NaN (README.md:47-51); 0 sub-gradient here (documented deviation)
+__device__ inline void d_so3_bwd(const float* v, const float* g, float* dr) {
+    float s[9], s2[9], st[9], a[9], b[9], dS[9]; d_hat(v, s); d_mat3mul(s, s, s2);
+    const float th = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float thi = 1.f / fmaxf(th, 1e-4f);
+    const float sn = sinf(th), cs = cosf(th), f1 = thi * sn, f2 = thi * thi * (1.f - cs);
+    float df1 = 0.f, df2 = 0.f;
+    for (int i = 0; i < 9; ++i) { df1 += g[i] * s[i]; df2 += g[i] * s2[i]; }
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) st[j * 3 + i] = s[i * 3 + j];
+    d_mat3mul(g, st, a); d_mat3mul(st, g, b);
+    for (int i = 0; i < 9; ++i) dS[i] = f1 * g[i] + f2 * (a[i] + b[i]);
+    const float dthi = df1 * sn + df2 * 2.f * thi * (1.f - cs);
+    float dth = df1 * thi * cs + df2 * thi * thi * sn;
+    if (th > 1e-4f) dth += -dthi * thi * thi;
+    const float hv[3] = {dS[1 * 3 + 2] - dS[2 * 3 + 1], -dS[0 * 3 + 2] + dS[2 * 3 + 0], dS[0 * 3 + 1] - dS[1 * 3 + 0]};
+    for (int i = 0; i < 3; ++i) dr[i] = hv[i] + (th > 0.f ? dth * v[i] / th : 0.f);
+}
+__device__ inline void d_compose(const float* r, const float* t, int inv, float* R, float* to) {
+    d_so3(r, R);
+    if (inv) {
+        float x;
+        x = R[1]; R[1] = R[3]; R[3] = x; x = R[2]; R[2] = R[6]; R[6] = x; x = R[5]; R[5] = R[7]; R[7] = x;
+        for (int i = 0; i < 3; ++i) to[i] = R[0 * 3 + i] * -t[0] + R[1 * 3 + i] * -t[1] + R[2 * 3 + i] * -t[2];
+    } else
+        for (int i = 0; i < 3; ++i) to[i] = t[i];
+}
+__device__ inline void d_compose_bwd(const float* r, const float* t, int inv, const float* dR, const float* dto, float* dr, float* dt) {
+    float R[9], g[9]; d_so3(r, R);
+    if (inv) {
+        float gRt[9];
+        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) gRt[j * 3 + i] = dR[j * 3 + i] + dto[i] * -t[j];
+        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) g[j * 3 + i] = gRt[i * 3 + j];
+        for (int i = 0; i < 3; ++i) dt[i] = -(R[0 * 3 + i] * dto[0] + R[1 * 3 + i] * dto[1] + R[2 * 3 + i] * dto[2]);
+    } else {
+        for (int i = 0; i < 9; ++i) g[i] = dR[i];
+        for (int i = 0; i < 3; ++i) dt[i] = dto[i];
+    }
+    d_so3_bwd(r, g, dr);
+}
+__global__ void pose_compose_kernel(const float* __restrict__ rvec, const float* __restrict__ tvec, float* __restrict__ Rt, int N, int inv0, int inv1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= 2 * N) return;
+    const int s = i / N;
+    d_compose(rvec + i * 3, tvec + i * 3, s == 0 ? inv0 : inv1, Rt + (long)i * 12, Rt + (long)i * 12 + 9);
+}
+void launch_pose_compose(const float* rvec, const float* tvec, float* Rt, int N, int inv0, int inv1, hipStream_t s) {
+    hipLaunchKernelGGL(pose_compose_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, s, rvec, tvec, Rt, N, inv0, inv1);
+}
+__global__ void pose_compose_bwd_kernel(const float* __restrict__ rvec, const float* __restrict__ tvec, const double* __restrict__ dRt, float* __restrict__ drvec, float* __restrict__ dtvec, int N, int inv0, int inv1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= 2 * N) return;
+    const int s = i / N;
+    float g[12]; for (int k = 0; k < 12; ++k) g[k] = (float)dRt[(long)i * 12 + k];
+    d_compose_bwd(rvec + i * 3, tvec + i * 3, s == 0 ? inv0 : inv1, g, g + 9, drvec + i * 3, dtvec + i * 3);
+}
+void launch_pose_compose_bwd(const float* rvec, const float* tvec, const double* dRt, float* drvec, float* dtvec, int N, int inv0, int inv1, hipStream_t s) {
+    hipLaunchKernelGGL(pose_compose_bwd_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, s, rvec, tvec, dRt, drvec, dtvec, N, inv0, inv1);
+}
+
+// =====================================================================================================================
+// op-level kernels (reference layout) behind the stateless C entry points
+// =====================================================================================================================
+#define GRID1D(total) dim3((int)std::max<long>(1, std::min<long>(((total) + 255) / 256, 4096))), dim3(256)
+#define FOR1D(i, total) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (total); i += (long)gridDim.x * blockDim.x)
+
+__global__ void op_ssim_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, int planes, int H, int W) {
+    FOR1D(i, (long)planes * H * W) {
+        const int w = i % W; const long t = i / W; const int h = t % H; const long p = t / H;
+        const float* xp = x + p * H * W; const float* yp = y + p * H * W;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int o = refl_idx(h + dy, H) * W + refl_idx(w + dx, W);
+                const float xv = xp[o], yv = yp[o];
+                sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+            }
+        SsimOut so; ssim_from_sums(sx, sy, sxx, syy, sxy, false, so);
+        out[i] = so.val;
+    }
+}
+// photometric for k predictions + min: preds [k][N][C][H][W]; out [N][H][W]; if k == 1 plain photometric
+__global__ void op_prediction_kernel(const float* __restrict__ preds, int k, const float* __restrict__ tgt, float* __restrict__ out, int N, int C, int H, int W) {
+    const long P = (long)H * W;
+    FOR1D(i, (long)N * P) {
+        const int w = i % W; const long t = i / W; const int h = t % H; const int n = t / H;
+        float best = 0.f;
+        for (int j = 0; j < k; ++j) {
+            float ss = 0.f, l1 = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float* xp = preds + (((long)j * N + n) * C + c) * P; const float* yp = tgt + ((long)n * C + c) * P;
+                float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int o = refl_idx(h + dy, H) * W + refl_idx(w + dx, W);
+                        const float xv = xp[o], yv = yp[o];
+                        sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+                    }
+                SsimOut so; ssim_from_sums(sx, sy, sxx, syy, sxy, false, so);
+                ss += so.val; l1 += fabsf(yp[(long)h * W + w] - xp[(long)h * W + w]);
+            }
+            const float pl = 0.85f * (ss / (float)C) + (1.f - 0.85f) * (l1 / (float)C);
+            if (j == 0 || pl < best) best = pl;
+        }
+        out[i] = best;
+    }
+}
+__global__ void op_d2d_kernel(const float* __restrict__ d, float* __restrict__ out, long n, float min_disp, float max_disp) {
+    FOR1D(i, n) out[i] = 1.f / (d[i] * (max_disp - min_disp) + min_disp);
+}
+__global__ void op_backproject_kernel(const float* __restrict__ depth, const float* __restrict__ invK, float* __restrict__ out, int N, int H, int W) {
+    FOR1D(i, (long)N * H * W) {
+        const int w = i % W; const int h = (i / W) % H;
+        const float cx = (float)(w + 1), cy = (float)(h + 1);
+        for (int k = 0; k < 3; ++k) out[i * 3 + k] = depth[i] * (invK[k] * cx + invK[3 + k] * cy + invK[6 + k] * 1.f);
+    }
+}
+__global__ void op_project_kernel(const float* __restrict__ pts, const float* __restrict__ K, const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ uv, int N, int H, int W) {
+    const long P = (long)H * W;
+    FOR1D(i, (long)N * P) {
+        const int n = i / P; const float* Rn = R + n * 9; const float* tn = t + n * 3; const float* q = pts + i * 3;
+        float r[3], c[3];
+        for (int k = 0; k < 3; ++k) r[k] = (Rn[k] * q[0] + Rn[3 + k] * q[1] + Rn[6 + k] * q[2]) + tn[k];
+        for (int k = 0; k < 3; ++k) c[k] = K[k] * r[0] + K[3 + k] * r[1] + K[6 + k] * r[2];
+        const float denom = 1.f / (c[2] + 1e-7f);
+        uv[i * 2 + 0] = (((c[0] * denom - 1.f) / (float)(W - 1)) - 0.5f) * 2.f;
+        uv[i * 2 + 1] = (((c[1] * denom - 1.f) / (float)(H - 1)) - 0.5f) * 2.f;
+    }
+}
+template <int BWD>
+__global__ void op_grid_sample_kernel(const float* __restrict__ in, const float* __restrict__ grid, float* __restrict__ out, const float* __restrict__ dout, float* __restrict__ dgrid,
+                                      int N, int C, int H, int W, int Ho, int Wo, int border) {
+    const long Po = (long)Ho * Wo, Pi = (long)H * W;
+    FOR1D(i, (long)N * Po) {
+        const int n = i / Po; const long p = i - (long)n * Po;
+        const float gx = grid[i * 2], gy = grid[i * 2 + 1];
+        float x = ((gx + 1.f) * 0.5f) * (float)(W - 1), y = ((gy + 1.f) * 0.5f) * (float)(H - 1);
+        float mx = 0.5f * (float)(W - 1), my = 0.5f * (float)(H - 1);
+        if (border) {
+            if (!(x > 0.f)) { x = 0.f; mx = 0.f; } else if (x >= (float)(W - 1)) { x = (float)(W - 1); mx = 0.f; }
+            if (!(y > 0.f)) { y = 0.f; my = 0.f; } else if (y >= (float)(H - 1)) { y = (float)(H - 1); my = 0.f; }
+        }
+        const float fx = floorf(x), fy = floorf(y);
+        const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        const float wx1 = x - fx, wx0 = 1.f - wx1, wy1 = y - fy, wy0 = 1.f - wy1;
+        const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+        float ggx = 0.f, ggy = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* im = in + ((long)n * C + c) * Pi;
+            const float v00 = (vy0 && vx0) ? im[(long)y0 * W + x0] : 0.f, v01 = (vy0 && vx1) ? im[(long)y0 * W + x1] : 0.f;
+            const float v10 = (vy1 && vx0) ? im[(long)y1 * W + x0] : 0.f, v11 = (vy1 && vx1) ? im[(long)y1 * W + x1] : 0.f;
+            if (!BWD) out[((long)n * C + c) * Po + p] = v00 * wy0 * wx0 + v01 * wy0 * wx1 + v10 * wy1 * wx0 + v11 * wy1 * wx1;
+            else { const float g = dout[((long)n * C + c) * Po + p]; ggx += g * ((v01 - v00) * wy0 + (v11 - v10) * wy1); ggy += g * ((v10 - v00) * wx0 + (v11 - v01) * wx1); }
+        }
+        if (BWD) { dgrid[i * 2] = ggx * mx; dgrid[i * 2 + 1] = ggy * my; }
+    }
+}
+__global__ void op_warp_kernel(const float* __restrict__ disp, const float* __restrict__ src, const float* __restrict__ K, const float* __restrict__ invK,
+                               const float* __restrict__ R, const float* __restrict__ t, float* __restrict__ out, int N, int C, int H, int W, float min_disp, float max_disp) {
+    const long P = (long)H * W;
+    FOR1D(i, (long)N * P) {
+        const int n = i / P; const long p = i - (long)n * P; const int py = p / W, px = p - (long)py * W;
+        Pose12 T; for (int k = 0; k < 9; ++k) T.R[k] = R[n * 9 + k]; for (int k = 0; k < 3; ++k) T.t[k] = t[n * 3 + k];
+        float Kl[9], iK[9]; for (int k = 0; k < 9; ++k) { Kl[k] = K[k]; iK[k] = invK[k]; }
+        Proj pr; project_px(disp[i], py, px, Kl, iK, T, min_disp, max_disp, H, W, pr);
+        Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
+        for (int c = 0; c < C; ++c) out[((long)n * C + c) * P + p] = sample_val(src + ((long)n * C + c) * P, sm);
+    }
+}
+__global__ void op_hat_kernel(const float* __restrict__ r, float* __restrict__ S, int N) { FOR1D(i, N) d_hat(r + i * 3, S + i * 9); }
+__global__ void op_so3_kernel(const float* __restrict__ r, float* __restrict__ R, int N) { FOR1D(i, N) d_so3(r + i * 3, R + i * 9); }
+__global__ void op_so3_bwd_kernel(const float* __restrict__ r, const float* __restrict__ dR, float* __restrict__ dr, int N) { FOR1D(i, N) d_so3_bwd(r + i * 3, dR + i * 9, dr + i * 3); }
+__global__ void op_compose_kernel(const float* __restrict__ r, const float* __restrict__ t, int inv, float* __restrict__ R, float* __restrict__ to, int N) {
+    FOR1D(i, N) d_compose(r + i * 3, t + i * 3, inv, R + i * 9, to + i * 3);
+}
+// smooth_loss: block partial sums -> double atomics part[0]=Sx, part[1]=Sy ; finalised by op_smooth_final
+__global__ void op_smooth_kernel(const float* __restrict__ d, const float* __restrict__ img, double* __restrict__ part, int N, int C, int H, int W) {
+    const long P = (long)H * W;
+    float sx = 0.f, sy = 0.f;
+    FOR1D(i, (long)N * P) {
+        const int n = i / P; const long p = i - (long)n * P; const int h = p / W, w = p - (long)h * W;
+        if (w + 1 < W) { float gi = 0.f; for (int c = 0; c < C; ++c) { const float* im = img + ((long)n * C + c) * P; gi += fabsf(im[p] - im[p + 1]); } if (C > 1) gi /= (float)C; sx += fabsf(d[i] - d[i + 1]) * expf(-gi); }
+        if (h + 1 < H) { float gi = 0.f; for (int c = 0; c < C; ++c) { const float* im = img + ((long)n * C + c) * P; gi += fabsf(im[p] - im[p + W]); } if (C > 1) gi /= (float)C; sy += fabsf(d[i] - d[i + W]) * expf(-gi); }
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(part, (double)sx); atomicAdd(part + 1, (double)sy); }
+}
+__global__ void op_smooth_final(const double* __restrict__ part, float* __restrict__ out, double cntx, double cnty) { if (threadIdx.x == 0 && blockIdx.x == 0) *out = (float)(part[0] / cntx + part[1] / cnty); }
+
+}  // namespace md2
+
+// ---- stateless C entry points (include/md2hip.h) ---------------------------------------------------------------------------
+using namespace md2;
+static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+static inline int chk() { return hipGetLastError() == hipSuccess ? 0 : 1; }
+
+extern "C" {
+int32_t md2_ssim_fwd(const float* x, const float* y, float* out, int32_t planes, int32_t H, int32_t W, void* stream) {
+    if (H < 2 || W < 2) return 2;
+    hipLaunchKernelGGL(op_ssim_kernel, GRID1D((long)planes * H * W), 0, S_(stream), x, y, out, planes, H, W); return chk();
+}
+int32_t md2_photometric_loss_fwd(const float* pred, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (H < 2 || W < 2) return 2;
+    hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, S_(stream), pred, 1, target, out, N, C, H, W); return chk();
+}
+int32_t md2_prediction_loss_fwd(const float* preds, int32_t k, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (H < 2 || W < 2 || k < 1) return 2;
+    hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, S_(stream), preds, k, target, out, N, C, H, W); return chk();
+}
+int32_t md2_disparity_to_depth(const float* d, float* out, int64_t n, double min_depth, double max_depth, void* stream) {
+    hipLaunchKernelGGL(op_d2d_kernel, GRID1D(n), 0, S_(stream), d, out, (long)n, (float)(1.0 / max_depth), (float)(1.0 / min_depth)); return chk();
+}
+int32_t md2_backproject(const float* depth, const float* invK, float* out, int32_t N, int32_t H, int32_t W, void* stream) {
+    hipLaunchKernelGGL(op_backproject_kernel, GRID1D((long)N * H * W), 0, S_(stream), depth, invK, out, N, H, W); return chk();
+}
+int32_t md2_project(const float* pts, const float* K, const float* R, const float* t, float* uv, int32_t N, int32_t H, int32_t W, void* stream) {
+    hipLaunchKernelGGL(op_project_kernel, GRID1D((long)N * H * W), 0, S_(stream), pts, K, R, t, uv, N, H, W); return chk();
+}
+int32_t md2_grid_sample_fwd(const float* in, const float* grid, float* out, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t border, void* stream) {
+    hipLaunchKernelGGL(op_grid_sample_kernel<0>, GRID1D((long)N * Ho * Wo), 0, S_(stream), in, grid, out, (const float*)nullptr, (float*)nullptr, N, C, H, W, Ho, Wo, border); return chk();
+}
+int32_t md2_grid_sample_bwd_grid(const float* in, const float* grid, const float* dout, float* dgrid, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t border, void* stream) {
+    hipLaunchKernelGGL(op_grid_sample_kernel<1>, GRID1D((long)N * Ho * Wo), 0, S_(stream), in, grid, (float*)nullptr, dout, dgrid, N, C, H, W, Ho, Wo, border); return chk();
+}
+int32_t md2_warp_fwd(const float* disp, const float* src, const float* K, const float* invK, const float* R, const float* t, float* out, int32_t N, int32_t C, int32_t H, int32_t W,
+                     double min_depth, double max_depth, void* stream) {
+    hipLaunchKernelGGL(op_warp_kernel, GRID1D((long)N * H * W), 0, S_(stream), disp, src, K, invK, R, t, out, N, C, H, W, (float)(1.0 / max_depth), (float)(1.0 / min_depth)); return chk();
+}
+int32_t md2_upsample_bilinear_fwd(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, void* stream) { launch_upsample_planar_fwd(x, out, planes, H, W, Ho, Wo, S_(stream)); return chk(); }
+int32_t md2_upsample_bilinear_bwd(const float* dout, float* dx, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, void* stream) { launch_upsample_planar_bwd(dout, dx, planes, H, W, Ho, Wo, S_(stream)); return chk(); }
+int32_t md2_hat(const float* r, float* S, int32_t N, void* stream) { hipLaunchKernelGGL(op_hat_kernel, GRID1D(N), 0, S_(stream), r, S, N); return chk(); }
+int32_t md2_so3_exp_map(const float* r, float* R, int32_t N, void* stream) { hipLaunchKernelGGL(op_so3_kernel, GRID1D(N), 0, S_(stream), r, R, N); return chk(); }
+int32_t md2_so3_exp_map_bwd(const float* r, const float* dR, float* dr, int32_t N, void* stream) { hipLaunchKernelGGL(op_so3_bwd_kernel, GRID1D(N), 0, S_(stream), r, dR, dr, N); return chk(); }
+int32_t md2_composeT(const float* r, const float* t, int32_t inv, float* R, float* to, int32_t N, void* stream) { hipLaunchKernelGGL(op_compose_kernel, GRID1D(N), 0, S_(stream), r, t, inv, R, to, N); return chk(); }
+int32_t md2_smooth_loss(const float* disp, const float* image, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    double* part = nullptr;
+    if (hipMallocAsync((void**)&part, 2 * sizeof(double), S_(stream)) != hipSuccess) return 3;
+    (void)hipMemsetAsync(part, 0, 2 * sizeof(double), S_(stream));
+    hipLaunchKernelGGL(op_smooth_kernel, GRID1D((long)N * H * W), 0, S_(stream), disp, image, part, N, C, H, W);
+    hipLaunchKernelGGL(op_smooth_final, dim3(1), dim3(64), 0, S_(stream), part, out, (double)(W - 1) * H * N, (double)W * (H - 1) * N);
+    (void)hipFreeAsync(part, S_(stream));
+    return chk();
+}
+}

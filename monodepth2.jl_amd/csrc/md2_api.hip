@@ -1,0 +1,715 @@
+// md2_api.hip — handle, network wiring and the C ABI of include/md2hip.h.
+//
+// Host-side mirror of src/model.jl (Model forward), src/depth_decoder.jl, src/pose_decoder.jl, the ResNet-18 trunk
+// (torchvision convention), src/training.jl:21-78 (train_loss) and their hand-written pullbacks
+// (the reference gets them from Zygote).  Everything runs on ONE HIP stream; no allocation or synchronisation
+// happens inside a step.
+#include "md2_internal.h"
+#include "../../include/md2hip.h"
+#include <vector>
+#include <string>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+
+using namespace md2;
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e_); return 1; } } while (0)
+#define KCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e_); return 1; } } while (0)
+
+static std::string g_create_err;
+
+namespace {
+
+struct ConvL {
+    int cin = 0, cout = 0, k = 1, stride = 1, pad = 0; bool bias = false;
+    int cinP = 0, coutP = 0, taps = 1;   // internal (padded) geometry: weights [coutP][taps][cinP]
+    int kind = 0;                        // 0 igemm, 1 stem (im2col: taps=1, cinP=Kpad), 2 head (cout 1, direct kernel)
+    long w = 0, b = 0;                   // offsets (floats) into the internal flat buffers
+    long fw = 0, fb = 0;                 // offsets into the Flux-layout flat vector
+    long wn() const { return (long)coutP * taps * cinP; }
+};
+struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; float* stats = nullptr; double* acc = nullptr; double* acc_b = nullptr; };
+struct Block { ConvL c1, c2, cd; BNL b1, b2, bd; bool down = false; int stride = 1; View in, z1, a1, z2, zd, sd, out; };
+struct ProfEvt { hipEvent_t a, b; int cls; };
+enum { CLS_IGEMM = 0, CLS_WGRAD = 1, CLS_LOSS_FWD = 2, CLS_LOSS_BWD = 3, CLS_OTHER = 4 };
+
+}  // namespace
+
+struct md2_handle {
+    md2_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    int N = 0, NL = 0, C = 1, H = 0, W = 0;
+    float K[9], invK[9];
+    long n_int = 0, n_flux = 0;
+    float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *WD = nullptr;
+    double beta1p = 1.0, beta2p = 1.0;
+    ConvL stem; BNL stem_bn; Block blk[8];
+    ConvL dc1[5], dc2[5], head[4], squeeze, pose[3];
+    std::vector<ConvL*> convs; std::vector<BNL*> bns;
+    char* arena = nullptr; size_t arena_off = 0;
+    double* acc_all = nullptr; size_t acc_count = 0; double* acc_bwd = nullptr; size_t acc_fwd_count = 0, acc_bwd_count = 0;
+    int Kpad = 64;
+    float* col = nullptr; View colv, z0, a0, p0; uint8_t* pool_arg = nullptr;
+    View feat[5], y1[5], cat[5], y2[5], dispv[4];
+    View sqcat, py1, py2, py3; float *rvec = nullptr, *tvec = nullptr, *Rt = nullptr;
+    double *loss_part = nullptr, *dRt_acc = nullptr; float *totals = nullptr, *loss_dev = nullptr, *ddisp_full = nullptr, *drvec = nullptr, *dtvec = nullptr;
+    const float* x_last = nullptr; const float* auto_last = nullptr; bool have_fwd = false;
+    View Gfeat[5], Gblk[8], Gpool; char* gzero_begin = nullptr; size_t gzero_bytes = 0;
+    View gA[5], dZ1[5], dupv[5]; float* dxpad = nullptr; float* ddisp_lo[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *E1 = nullptr, *E2 = nullptr, *E3 = nullptr;
+    View dpy3, dpy2, dpy1, dsq;
+    bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
+
+    template <class T> T* alloc(size_t count) {
+        arena_off = (arena_off + 255) / 256 * 256;
+        T* p = reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(arena) + arena_off);
+        arena_off += count * sizeof(T);
+        return p;
+    }
+    View alloc_view(int n, int hh, int ww, int c) { return make_view(alloc<float>((size_t)n * hh * ww * c), n, hh, ww, c); }
+    void pbegin(int cls) { if (prof) { ProfEvt e; e.cls = cls; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, stream); evts.push_back(e); } }
+    void pend() { if (prof) (void)hipEventRecord(evts.back().b, stream); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// layer table
+// ---------------------------------------------------------------------------------------------------------------------
+static void build_layers(md2_handle* h) {
+    long io = 0, fo = 0;
+    auto al = [&](long n) { long r = io; io += (n + 15) / 16 * 16; return r; };
+    auto mk = [&](ConvL& c, int cin, int cout, int k, int s, int p, bool bias, int kind) {
+        c.cin = cin; c.cout = cout; c.k = k; c.stride = s; c.pad = p; c.bias = bias; c.kind = kind;
+        if (kind == 1) { c.taps = 1; c.cinP = (49 * cin + 15) / 16 * 16; c.coutP = cout; }
+        else if (kind == 2) { c.taps = k * k; c.cinP = cin; c.coutP = 1; }
+        else { c.taps = k * k; c.cinP = (cin + 15) / 16 * 16; c.coutP = (cout + 15) / 16 * 16; }
+        c.w = al(c.wn()); c.fw = fo; fo += (long)cin * cout * k * k;
+        if (bias) { c.b = al(c.coutP); c.fb = fo; fo += cout; }
+        h->convs.push_back(&c);
+    };
+    auto mkbn = [&](BNL& b, int c) { b.c = c; b.g = al(c); b.b = al(c); b.fg = fo; b.fb = fo + c; fo += 2 * c; h->bns.push_back(&b); };
+    mk(h->stem, h->C, 64, 7, 2, 3, false, 1); mkbn(h->stem_bn, 64);
+    h->Kpad = h->stem.cinP;
+    const int chans[4] = {64, 128, 256, 512}; int cin = 64;
+    for (int l = 0; l < 4; ++l)
+        for (int b = 0; b < 2; ++b) {
+            Block& B = h->blk[l * 2 + b]; const int co = chans[l]; const int s = (b == 0 && l > 0) ? 2 : 1;
+            B.stride = s;
+            mk(B.c1, cin, co, 3, s, 1, false, 0); mkbn(B.b1, co); mk(B.c2, co, co, 3, 1, 1, false, 0); mkbn(B.b2, co);
+            B.down = (s != 1 || cin != co);
+            if (B.down) { mk(B.cd, cin, co, 1, s, 0, false, 0); mkbn(B.bd, co); }
+            cin = co;
+        }
+    const int dec[5] = {256, 128, 64, 32, 16}, inc[5] = {512, 256, 128, 64, 32}, skc[5] = {256, 128, 64, 64, 0};
+    for (int b = 0; b < 5; ++b) { mk(h->dc1[b], inc[b], dec[b], 3, 1, 0, true, 0); mk(h->dc2[b], dec[b] + skc[b], dec[b], 3, 1, 0, true, 0); }
+    for (int l = 0; l < 4; ++l) mk(h->head[l], dec[l + 1], 1, 3, 1, 0, true, 2);
+    mk(h->squeeze, 512, 256, 1, 1, 0, true, 0); mk(h->pose[0], 512, 256, 3, 1, 1, true, 0); mk(h->pose[1], 256, 256, 3, 1, 1, true, 0); mk(h->pose[2], 256, 6, 1, 1, 0, true, 0);
+    h->n_int = io; h->n_flux = fo;
+}
+
+// Flux (kW,kH,Cin,Cout) true-convolution weights  <->  internal [coutP][taps][cinP] cross-correlation taps
+static void convert_params(md2_handle* h, float* internal, float* flux, bool to_internal) {
+    if (to_internal) std::fill(internal, internal + h->n_int, 0.f);
+    for (ConvL* cp : h->convs) {
+        const ConvL& c = *cp; const int k = c.k;
+        for (int co = 0; co < c.cout; ++co)
+            for (int ci = 0; ci < c.cin; ++ci)
+                for (int kh = 0; kh < k; ++kh)
+                    for (int kw = 0; kw < k; ++kw) {
+                        const long f = c.fw + (((long)co * c.cin + ci) * k + kh) * k + kw;
+                        const int tap = (k - 1 - kh) * k + (k - 1 - kw);          // flip: true convolution -> cross-correlation
+                        const long i = (c.kind == 1) ? c.w + (long)co * c.cinP + (long)tap * c.cin + ci
+                                                     : c.w + ((long)co * c.taps + tap) * c.cinP + ci;
+                        if (to_internal) internal[i] = flux[f]; else flux[f] = internal[i];
+                    }
+        if (c.bias) for (int co = 0; co < c.cout; ++co) { if (to_internal) internal[c.b + co] = flux[c.fb + co]; else flux[c.fb + co] = internal[c.b + co]; }
+    }
+    for (BNL* bp : h->bns)
+        for (int i = 0; i < bp->c; ++i) {
+            if (to_internal) { internal[bp->g + i] = flux[bp->fg + i]; internal[bp->b + i] = flux[bp->fb + i]; }
+            else { flux[bp->fg + i] = internal[bp->g + i]; flux[bp->fb + i] = internal[bp->b + i]; }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// buffers (called twice: once with arena == nullptr to size the arena, once to carve it)
+// ---------------------------------------------------------------------------------------------------------------------
+static void plan_buffers(md2_handle* h) {
+    const int N = h->N, NL = h->NL, H = h->H, W = h->W;
+    h->arena_off = 0;
+    h->col = h->alloc<float>((size_t)NL * (H / 2) * (W / 2) * h->Kpad);
+    h->colv = make_view(h->col, 1, 1, NL * (H / 2) * (W / 2), h->Kpad);
+    h->z0 = h->alloc_view(NL, H / 2, W / 2, 64); h->a0 = h->alloc_view(NL, H / 2, W / 2, 64);
+    h->p0 = h->alloc_view(NL, H / 4, W / 4, 64); h->pool_arg = h->alloc<uint8_t>((size_t)NL * (H / 4) * (W / 4) * 64);
+    h->feat[0] = h->a0;
+    int hh = H / 4, ww = W / 4; View cur = h->p0;
+    for (int i = 0; i < 8; ++i) {
+        Block& B = h->blk[i];
+        if (B.stride == 2) { hh /= 2; ww /= 2; }
+        const int co = B.c1.cout;
+        B.in = cur; B.z1 = h->alloc_view(NL, hh, ww, co); B.a1 = h->alloc_view(NL, hh, ww, co); B.z2 = h->alloc_view(NL, hh, ww, co);
+        if (B.down) { B.zd = h->alloc_view(NL, hh, ww, co); B.sd = h->alloc_view(NL, hh, ww, co); }
+        B.out = h->alloc_view(NL, hh, ww, co);
+        cur = B.out;
+        if (i % 2 == 1) h->feat[1 + i / 2] = B.out;
+    }
+    const int dec[5] = {256, 128, 64, 32, 16}, skc[5] = {256, 128, 64, 64, 0}, inc[5] = {512, 256, 128, 64, 32};
+    int dh = H / 32, dw = W / 32;
+    size_t dxpad_max = 0;
+    for (int b = 0; b < 5; ++b) {
+        h->y1[b] = h->alloc_view(N, dh, dw, dec[b]);
+        dxpad_max = std::max(dxpad_max, (size_t)N * (dh + 2) * (dw + 2) * inc[b]);
+        dh *= 2; dw *= 2;
+        h->cat[b] = h->alloc_view(N, dh, dw, dec[b] + skc[b]);
+        h->y2[b] = h->alloc_view(N, dh, dw, dec[b]);
+        dxpad_max = std::max(dxpad_max, (size_t)N * (dh + 2) * (dw + 2) * (dec[b] + skc[b]));
+        if (b >= 1) h->dispv[b - 1] = h->alloc_view(N, dh, dw, 1);
+    }
+    const int ph = H / 32, pw = W / 32;
+    h->sqcat = h->alloc_view(2 * N, ph, pw, 512); h->py1 = h->alloc_view(2 * N, ph, pw, 256); h->py2 = h->alloc_view(2 * N, ph, pw, 256); h->py3 = h->alloc_view(2 * N, ph, pw, 16);
+    h->rvec = h->alloc<float>(6 * N); h->tvec = h->alloc<float>(6 * N); h->Rt = h->alloc<float>(24 * N);
+    h->totals = h->alloc<float>(16 * N); h->loss_dev = h->alloc<float>(4); h->ddisp_full = h->alloc<float>((size_t)4 * N * H * W);
+    h->drvec = h->alloc<float>(6 * N); h->dtvec = h->alloc<float>(6 * N);
+    for (BNL* b : h->bns) b->stats = h->alloc<float>(2 * b->c);
+    size_t nd = 0;
+    for (BNL* b : h->bns) nd += 4 * (size_t)b->c;
+    nd += (size_t)16 * N + 24 * N;
+    h->acc_count = nd; h->acc_all = h->alloc<double>(nd);
+    double* ap = h->acc_all;
+    for (BNL* b : h->bns) { b->acc = ap; ap += 2 * b->c; }
+    h->acc_fwd_count = ap - h->acc_all;
+    h->acc_bwd = ap;
+    for (BNL* b : h->bns) { b->acc_b = ap; ap += 2 * b->c; }
+    h->acc_bwd_count = ap - h->acc_bwd;
+    h->loss_part = ap; ap += 16 * N; h->dRt_acc = ap; ap += 24 * N;
+    // ---- backward: gradient accumulators, zeroed together at the start of every backward
+    h->arena_off = (h->arena_off + 255) / 256 * 256;
+    const size_t gz0 = h->arena_off;
+    for (int i = 0; i < 5; ++i) h->Gfeat[i] = h->alloc_view(h->feat[i].N, h->feat[i].H, h->feat[i].W, h->feat[i].C);
+    for (int i = 0; i < 8; i += 2) h->Gblk[i] = h->alloc_view(h->blk[i].out.N, h->blk[i].out.H, h->blk[i].out.W, h->blk[i].out.C);
+    for (int i = 1; i < 8; i += 2) h->Gblk[i] = h->Gfeat[1 + i / 2];
+    h->Gpool = h->alloc_view(NL, H / 4, W / 4, 64);
+    h->arena_off = (h->arena_off + 255) / 256 * 256;
+    h->gzero_begin = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(h->arena) + gz0); h->gzero_bytes = h->arena_off - gz0;
+    // ---- backward scratch
+    for (int b = 0; b < 5; ++b) {
+        h->gA[b] = h->alloc_view(h->y2[b].N, h->y2[b].H, h->y2[b].W, h->y2[b].C);
+        h->dZ1[b] = h->alloc_view(h->y1[b].N, h->y1[b].H, h->y1[b].W, h->y1[b].C);
+        h->dupv[b] = h->alloc_view(h->y2[b].N, h->y2[b].H, h->y2[b].W, h->y2[b].C);
+    }
+    h->dxpad = h->alloc<float>(dxpad_max);
+    for (int l = 0; l < 4; ++l) h->ddisp_lo[l] = h->alloc<float>((size_t)N * h->dispv[l].H * h->dispv[l].W);
+    const size_t emax = (size_t)NL * (H / 2) * (W / 2) * 64;
+    h->E1 = h->alloc<float>(emax); h->E2 = h->alloc<float>(emax); h->E3 = h->alloc<float>(emax);
+    h->dpy3 = h->alloc_view(2 * N, ph, pw, 16); h->dpy2 = h->alloc_view(2 * N, ph, pw, 256); h->dpy1 = h->alloc_view(2 * N, ph, pw, 256); h->dsq = h->alloc_view(2 * N, ph, pw, 512);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------------------------------
+static ConvArgs conv_args(const View& x, const float* w, const View& y, int KH, int stride, int pad, int dil, int padmode) {
+    ConvArgs a{};
+    a.x = x.p; a.x_bs = x.bs; a.x_ps = x.ps; a.H = x.H; a.W = x.W; a.Cin = x.C;
+    a.w = w; a.y = y.p; a.y_bs = y.bs; a.y_ps = y.ps; a.Ho = y.H; a.Wo = y.W; a.Cout = y.C;
+    a.N = y.N; a.KH = KH; a.KW = KH; a.stride = stride; a.pad = pad; a.dil = dil; a.padmode = padmode;
+    a.bias = nullptr; a.act = ACT_NONE; a.accumulate = 0; a.dact_src = nullptr; a.da_bs = 0; a.da_ps = 0; a.dact = ACT_NONE;
+    a.M = y.N * y.H * y.W;
+    return a;
+}
+static void run_igemm(md2_handle* h, const ConvArgs& a) {
+    h->pbegin(CLS_IGEMM); launch_conv_igemm(a, h->stream); h->pend();
+    if (h->prof) h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a);
+}
+// forward conv (kind 0) on views.  x.C must equal c.cinP, y.C == c.coutP
+static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act) {
+    ConvArgs a = conv_args(x, h->P + c.w, y, c.k, c.stride, padmode == PAD_REFLECT ? 1 : c.pad, 1, padmode);
+    a.bias = c.bias ? h->P + c.b : nullptr; a.act = act;
+    run_igemm(h, a);
+}
+// input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
+static void conv_dgrad(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact) {
+    ConvArgs a = conv_args(dy, h->WD + c.w, dx, c.k, 1, c.k - 1 - pad_fwd, c.stride, PAD_ZERO);
+    a.accumulate = accumulate;
+    if (dact_src) { a.dact_src = dact_src->p; a.da_bs = dact_src->bs; a.da_ps = dact_src->ps; a.dact = dact; }
+    run_igemm(h, a);
+}
+static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View& dy, int padmode) {
+    WgradArgs a{};
+    a.x = x.p; a.x_bs = x.bs; a.x_ps = x.ps; a.H = x.H; a.W = x.W; a.Cin = x.C;
+    a.dy = dy.p; a.dy_bs = dy.bs; a.dy_ps = dy.ps; a.Ho = dy.H; a.Wo = dy.W; a.Cout = dy.C;
+    a.dw = h->G + c.w; a.N = dy.N; a.KH = c.kind == 1 ? 1 : c.k; a.KW = a.KH; a.stride = c.kind == 1 ? 1 : c.stride; a.pad = c.kind == 1 ? 0 : (padmode == PAD_REFLECT ? 1 : c.pad); a.padmode = padmode;
+    a.M = dy.N * dy.H * dy.W;
+    h->pbegin(CLS_WGRAD); launch_conv_wgrad(a, h->stream); h->pend();
+    if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
+    if (c.bias) launch_colsum(dy, h->G + c.b, h->stream);
+}
+static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* residual, int act, const View& y) {
+    launch_colstats(z, b.acc, h->stream);
+    launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), h->stream);
+    launch_bn_apply(z, b.stats, h->P + b.g, h->P + b.b, residual, act, y, h->stream);
+}
+// dy: gradient wrt the BN output (already masked by any following ReLU) -> dz
+static void bn_bwd(md2_handle* h, const BNL& b, const View& dy, const View& z, const View& dz) {
+    launch_bn_bwd_reduce(dy, nullptr, ACT_NONE, z, b.stats, b.acc_b, h->stream);
+    launch_bn_bwd_apply(dy, nullptr, ACT_NONE, z, b.stats, h->P + b.g, b.acc_b, (double)z.pixels(), dz, h->G + b.g, h->G + b.b, h->stream);
+}
+
+static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp[4], const float* Rt, const float* auto_loss) {
+    LossArgs a{};
+    a.x = x; a.N = h->N; a.C = h->C; a.H = h->H; a.W = h->W; a.nscales = 4;
+    const double scales[4] = {0.125, 0.25, 0.5, 1.0};
+    for (int i = 0; i < 4; ++i) { a.disp[i] = disp[i]; a.dh[i] = h->H >> (3 - i); a.dw[i] = h->W >> (3 - i); a.smooth_w[i] = (float)h->cfg.disparity_smoothness * (float)scales[i]; }
+    a.Rt = Rt; a.auto_loss = h->cfg.automasking ? auto_loss : nullptr;
+    std::memcpy(a.K, h->K, sizeof(a.K)); std::memcpy(a.invK, h->invK, sizeof(a.invK));
+    a.min_disp = (float)(1.0 / h->cfg.max_depth); a.max_disp = (float)(1.0 / h->cfg.min_depth);
+    a.tgt = 1; a.src0 = 0; a.src1 = 2;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------------
+static int model_forward(md2_handle* h, const float* x) {
+    hipStream_t s = h->stream;
+    const int N = h->N, NL = h->NL, H = h->H, W = h->W;
+    HIPCHK(hipMemsetAsync(h->acc_all, 0, h->acc_fwd_count * sizeof(double), s));
+    // ---- encoder: stem (im2col + GEMM) + BN + ReLU, maxpool, 8 basic blocks
+    launch_im2col_stem(x, NL, h->C, H, W, h->col, h->Kpad, s);
+    { View zc = make_view(h->z0.p, 1, 1, NL * (H / 2) * (W / 2), 64); ConvArgs a = conv_args(h->colv, h->P + h->stem.w, zc, 1, 1, 0, 1, PAD_ZERO); run_igemm(h, a); }
+    bn_fwd(h, h->stem_bn, h->z0, nullptr, ACT_RELU, h->a0);
+    launch_maxpool_fwd(h->a0, h->p0, h->pool_arg, s);
+    for (int i = 0; i < 8; ++i) {
+        Block& B = h->blk[i];
+        conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE); bn_fwd(h, B.b1, B.z1, nullptr, ACT_RELU, B.a1);
+        conv_fwd(h, B.c2, B.a1, B.z2, PAD_ZERO, ACT_NONE);
+        if (B.down) {
+            conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE);
+            bn_fwd(h, B.bd, B.zd, nullptr, ACT_NONE, B.sd);                 // raw zd is kept for the pullback
+        }
+        bn_fwd(h, B.b2, B.z2, B.down ? &B.sd : &B.in, ACT_RELU, B.out);
+    }
+    // ---- depth decoder on the target-frame features (src/model.jl:16-17, src/depth_decoder.jl:49-65)
+    View x5 = frame_view(h->feat[4], 3, 1);
+    for (int b = 0; b < 5; ++b) {
+        const View& in = (b == 0) ? x5 : h->y2[b - 1];
+        conv_fwd(h, h->dc1[b], in, h->y1[b], PAD_REFLECT, ACT_ELU);
+        launch_upsample2x_fwd(h->y1[b], chan_slice(h->cat[b], 0, h->y1[b].C), s);
+        if (b < 4) { View sk = frame_view(h->feat[3 - b], 3, 1); launch_axpy_view(sk, chan_slice(h->cat[b], h->y1[b].C, sk.C), 1.f, 0, nullptr, ACT_NONE, s); }
+        conv_fwd(h, h->dc2[b], h->cat[b], h->y2[b], PAD_REFLECT, ACT_ELU);
+        if (b >= 1) launch_head_fwd(h->y2[b], h->P + h->head[b - 1].w, h->P + h->head[b - 1].b, h->dispv[b - 1], s);
+    }
+    // ---- pose decoder, both sources batched (src/model.jl:22-35, src/pose_decoder.jl:23-32)
+    const int fr[2][2] = {{0, 1}, {1, 2}};     // (first, second) frame of the temporally ordered pair for source 1 and source 3
+    for (int sidx = 0; sidx < 2; ++sidx)
+        for (int j = 0; j < 2; ++j) {
+            View sq = h->sqcat; sq.p += (long)sidx * N * sq.bs; sq.N = N;
+            conv_fwd(h, h->squeeze, frame_view(h->feat[4], 3, fr[sidx][j]), chan_slice(sq, j * 256, 256), PAD_ZERO, ACT_RELU);
+        }
+    conv_fwd(h, h->pose[0], h->sqcat, h->py1, PAD_ZERO, ACT_RELU);
+    conv_fwd(h, h->pose[1], h->py1, h->py2, PAD_ZERO, ACT_RELU);
+    conv_fwd(h, h->pose[2], h->py2, h->py3, PAD_ZERO, ACT_NONE);
+    launch_pose_mean_fwd(h->py3, h->rvec, h->tvec, s);
+    KCHK();
+    return 0;
+}
+
+static int loss_forward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out) {
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)16 * h->N * sizeof(double), s));
+    launch_pose_compose(rvec, tvec, h->Rt, h->N, 1, 0, s);       // inverse_transform = source_ids .< target_id = [true, false] (src/training.jl:29)
+    LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
+    h->pbegin(CLS_LOSS_FWD); launch_loss_fwd(a, h->loss_part, s); h->pend();
+    if (h->prof) h->prof_bytes[CLS_LOSS_FWD] += 4.0 * h->H * h->W * (1 + 3 * h->C) * 4 * h->N;
+    launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
+    if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
+    KCHK();
+    return 0;
+}
+// pullback of the loss half: fills ddisp_lo[4] (scale resolution), drvec, dtvec
+static int loss_backward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss) {
+    hipStream_t s = h->stream;
+    LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
+    HIPCHK(hipMemsetAsync(h->dRt_acc, 0, (size_t)24 * h->N * sizeof(double), s));
+    h->pbegin(CLS_LOSS_BWD); launch_loss_bwd(a, h->totals, h->ddisp_full, h->dRt_acc, s); h->pend();
+    if (h->prof) h->prof_bytes[CLS_LOSS_BWD] += 4.0 * h->H * h->W * (2 + 3 * h->C) * 4 * h->N;
+    const size_t P = (size_t)h->H * h->W;
+    for (int i = 0; i < 4; ++i) launch_upsample_planar_bwd(h->ddisp_full + (size_t)i * h->N * P, h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
+    launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, 1, 0, s);
+    KCHK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward of the model (Zygote pullback of src/model.jl:8-20), accumulating into h->G
+// ---------------------------------------------------------------------------------------------------------------------
+static int model_backward(md2_handle* h) {
+    hipStream_t s = h->stream;
+    const int N = h->N, NL = h->NL, H = h->H, W = h->W;
+    HIPCHK(hipMemsetAsync(h->G, 0, (size_t)h->n_int * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(h->gzero_begin, 0, h->gzero_bytes, s));
+    HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
+    // transposed / flipped weight copies for the input-gradient GEMMs
+    for (ConvL* c : h->convs) if (c->kind == 0) launch_weight_to_dgrad(h->P + c->w, h->WD + c->w, c->coutP, c->cinP, c->taps, s);
+
+    // ---- depth decoder
+    for (int l = 0; l < 4; ++l) {
+        const int b = l + 1;
+        View dyv = make_view(h->ddisp_lo[l], N, h->dispv[l].H, h->dispv[l].W, 1);
+        launch_head_bwd(h->y2[b], h->P + h->head[l].w, h->dispv[l], dyv, h->gA[b], 0, h->G + h->head[l].w, h->G + h->head[l].b, s);
+    }
+    launch_axpy_view(h->gA[4], h->gA[4], 1.f, 0, &h->y2[4], ACT_ELU, s);     // last branch: only its head consumes it
+    for (int b = 4; b >= 0; --b) {
+        // gA[b] now holds d loss / d (pre-ELU output of c2[b])
+        const View& dZ2 = h->gA[b];
+        conv_wgrad(h, h->dc2[b], h->cat[b], dZ2, PAD_REFLECT);
+        View dcp = make_view(h->dxpad, N, h->cat[b].H + 2, h->cat[b].W + 2, h->cat[b].C);
+        conv_dgrad(h, h->dc2[b], dZ2, dcp, 0, 0, nullptr, ACT_NONE);
+        const int dc = h->y1[b].C;
+        launch_fold_reflect(chan_slice(dcp, 0, dc), h->dupv[b], 0, nullptr, ACT_NONE, s);
+        if (b < 4) {
+            View fv = frame_view(h->feat[3 - b], 3, 1), gv = frame_view(h->Gfeat[3 - b], 3, 1);
+            launch_fold_reflect(chan_slice(dcp, dc, fv.C), gv, 1, &fv, ACT_RELU, s);
+        }
+        launch_upsample2x_bwd(h->dupv[b], h->dZ1[b], &h->y1[b], ACT_ELU, s);
+        const View& in = (b == 0) ? frame_view(h->feat[4], 3, 1) : h->y2[b - 1];
+        conv_wgrad(h, h->dc1[b], in, h->dZ1[b], PAD_REFLECT);
+        View dip = make_view(h->dxpad, N, in.H + 2, in.W + 2, in.C);
+        conv_dgrad(h, h->dc1[b], h->dZ1[b], dip, 0, 0, nullptr, ACT_NONE);
+        if (b == 0) { View fv = frame_view(h->feat[4], 3, 1), gv = frame_view(h->Gfeat[4], 3, 1); launch_fold_reflect(dip, gv, 1, &fv, ACT_RELU, s); }
+        else launch_fold_reflect(dip, h->gA[b - 1], (b - 1) >= 1 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);
+    }
+    // ---- pose decoder
+    launch_pose_mean_bwd(h->drvec, h->dtvec, h->dpy3, s);
+    conv_wgrad(h, h->pose[2], h->py2, h->dpy3, PAD_ZERO);
+    conv_dgrad(h, h->pose[2], h->dpy3, h->dpy2, 0, 0, &h->py2, ACT_RELU);
+    conv_wgrad(h, h->pose[1], h->py1, h->dpy2, PAD_ZERO);
+    conv_dgrad(h, h->pose[1], h->dpy2, h->dpy1, 1, 0, &h->py1, ACT_RELU);
+    conv_wgrad(h, h->pose[0], h->sqcat, h->dpy1, PAD_ZERO);
+    conv_dgrad(h, h->pose[0], h->dpy1, h->dsq, 1, 0, &h->sqcat, ACT_RELU);
+    const int fr[2][2] = {{0, 1}, {1, 2}};
+    for (int sidx = 0; sidx < 2; ++sidx)
+        for (int j = 0; j < 2; ++j) {
+            View d = h->dsq; d.p += (long)sidx * N * d.bs; d.N = N; d = chan_slice(d, j * 256, 256);
+            View fv = frame_view(h->feat[4], 3, fr[sidx][j]), gv = frame_view(h->Gfeat[4], 3, fr[sidx][j]);
+            conv_wgrad(h, h->squeeze, fv, d, PAD_ZERO);
+            conv_dgrad(h, h->squeeze, d, gv, 0, 1, &fv, ACT_RELU);
+        }
+    // ---- encoder
+    for (int i = 7; i >= 0; --i) {
+        Block& B = h->blk[i];
+        const View& Gout = h->Gblk[i];                                  // d / d(pre-ReLU block output), already masked
+        const View* Gin = (i == 0) ? &h->Gpool : &h->Gblk[i - 1];
+        const View* in_act = (i == 0) ? nullptr : &B.in;                 // ReLU mask of the block input (stage 0: applied in the maxpool pullback)
+        View dz2 = make_view(h->E1, NL, B.z2.H, B.z2.W, B.z2.C), da1 = make_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C), dz1 = make_view(h->E3, NL, B.z1.H, B.z1.W, B.z1.C);
+        bn_bwd(h, B.b2, Gout, B.z2, dz2);
+        conv_wgrad(h, B.c2, B.a1, dz2, PAD_ZERO);
+        conv_dgrad(h, B.c2, dz2, da1, 1, 0, &B.a1, ACT_RELU);
+        bn_bwd(h, B.b1, da1, B.z1, dz1);
+        conv_wgrad(h, B.c1, B.in, dz1, PAD_ZERO);
+        conv_dgrad(h, B.c1, dz1, *Gin, 1, 1, in_act, ACT_RELU);
+        if (B.down) {
+            View dzd = make_view(h->E1, NL, B.zd.H, B.zd.W, B.zd.C);
+            bn_bwd(h, B.bd, Gout, B.zd, dzd);
+            conv_wgrad(h, B.cd, B.in, dzd, PAD_ZERO);
+            conv_dgrad(h, B.cd, dzd, *Gin, 0, 1, in_act, ACT_RELU);
+        } else
+            launch_axpy_view(Gout, *Gin, 1.f, 1, in_act, ACT_RELU, s);
+    }
+    launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 1, &h->a0, s);
+    {
+        View dz0 = make_view(h->E1, NL, H / 2, W / 2, 64);
+        bn_bwd(h, h->stem_bn, h->Gfeat[0], h->z0, dz0);
+        View dzc = make_view(h->E1, 1, 1, NL * (H / 2) * (W / 2), 64);
+        conv_wgrad(h, h->stem, h->colv, dzc, PAD_ZERO);
+    }
+    KCHK();
+    return 0;
+}
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+extern "C" {
+
+const char* md2_last_error(md2_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int32_t md2_create(const md2_config* cfg, md2_handle** out) {
+    if (!cfg || !out) { g_create_err = "null argument"; return 2; }
+    if (cfg->batch < 1 || (cfg->channels != 1 && cfg->channels != 3) || cfg->height % 32 || cfg->width % 32 || cfg->height < 64 || cfg->width < 64) {
+        g_create_err = "md2_create: need batch >= 1, channels in {1,3}, height/width multiples of 32 and >= 64"; return 2;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "md2_create: no HIP device (libmd2hip needs an MI355X; there is no CPU fallback)"; return 3; }
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "md2_create: hipSetDevice failed"; return 3; }
+    md2_handle* h = new md2_handle();
+    h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width;
+    build_layers(h);
+    plan_buffers(h);                        // sizing pass
+    const size_t need = h->arena_off + 4096;
+    auto fail = [&](const char* what) { g_create_err = std::string("md2_create: ") + what; delete h; return 4; };
+    if (hipMalloc((void**)&h->arena, need) != hipSuccess) return fail("hipMalloc(arena) failed");
+    plan_buffers(h);
+    const size_t pb = (size_t)h->n_int * sizeof(float);
+    if (hipMalloc((void**)&h->P, pb) != hipSuccess || hipMalloc((void**)&h->G, pb) != hipSuccess || hipMalloc((void**)&h->M, pb) != hipSuccess ||
+        hipMalloc((void**)&h->V, pb) != hipSuccess || hipMalloc((void**)&h->WD, pb) != hipSuccess) return fail("hipMalloc(params) failed");
+    (void)hipMemset(h->P, 0, pb); (void)hipMemset(h->G, 0, pb); (void)hipMemset(h->M, 0, pb); (void)hipMemset(h->V, 0, pb); (void)hipMemset(h->WD, 0, pb);
+    (void)hipMemset(h->arena, 0, need);
+    // default intrinsics: Depth10k (src/dtk.jl:16-22) scaled to the image size
+    const double f = 2648.0 / 4.63461538462 * (h->W / 416.0), cx = h->W / 2.0, cy = h->H / 2.0;
+    const float Kc[9] = {(float)f, 0, 0, 0, (float)f, 0, (float)cx, (float)cy, 1};
+    const float iKc[9] = {(float)(1 / f), 0, 0, 0, (float)(1 / f), 0, (float)(-cx / f), (float)(-cy / f), 1};
+    std::memcpy(h->K, Kc, sizeof(Kc)); std::memcpy(h->invK, iKc, sizeof(iKc));
+    *out = h;
+    return 0;
+}
+int32_t md2_destroy(md2_handle* h) {
+    if (!h) return 0;
+    (void)hipDeviceSynchronize();
+    for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD);
+    delete h; return 0;
+}
+int32_t md2_set_stream(md2_handle* h, void* st) { h->stream = (hipStream_t)st; return 0; }
+int32_t md2_synchronize(md2_handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }
+int32_t md2_set_intrinsics(md2_handle* h, const float* K, const float* invK) { std::memcpy(h->K, K, 36); std::memcpy(h->invK, invK, 36); return 0; }
+
+int64_t md2_params_count(md2_handle* h) { return h->n_flux; }
+int32_t md2_params_set(md2_handle* h, const float* host, int64_t n) {
+    if (n != h->n_flux) { h->err = "md2_params_set: wrong parameter count"; return 2; }
+    std::vector<float> in((size_t)h->n_int);
+    convert_params(h, in.data(), const_cast<float*>(host), true);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->P, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(h->M, 0, in.size() * sizeof(float))); HIPCHK(hipMemset(h->V, 0, in.size() * sizeof(float)));
+    h->beta1p = h->beta2p = 1.0;
+    return 0;
+}
+static int get_flat(md2_handle* h, const float* dev, float* host, int64_t n) {
+    if (n != h->n_flux) { h->err = "wrong parameter count"; return 2; }
+    std::vector<float> in((size_t)h->n_int);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(in.data(), dev, in.size() * sizeof(float), hipMemcpyDeviceToHost));
+    convert_params(h, in.data(), host, false);
+    return 0;
+}
+int32_t md2_params_get(md2_handle* h, float* host, int64_t n) { return get_flat(h, h->P, host, n); }
+int32_t md2_grads_get(md2_handle* h, float* host, int64_t n) { return get_flat(h, h->G, host, n); }
+int32_t md2_grad_buffer(md2_handle* h, void** p, int64_t* count) { *p = h->G; *count = h->n_int; return 0; }
+int32_t md2_param_buffer(md2_handle* h, void** p, int64_t* count) { *p = h->P; *count = h->n_int; return 0; }
+
+static int copy_outputs(md2_handle* h, float* d0, float* d1, float* d2, float* d3, float* rvec, float* tvec) {
+    float* ds[4] = {d0, d1, d2, d3};
+    for (int i = 0; i < 4; ++i)
+        if (ds[i]) HIPCHK(hipMemcpyAsync(ds[i], h->dispv[i].p, (size_t)h->N * h->dispv[i].H * h->dispv[i].W * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (rvec) HIPCHK(hipMemcpyAsync(rvec, h->rvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (tvec) HIPCHK(hipMemcpyAsync(tvec, h->tvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+int32_t md2_model_forward(md2_handle* h, const float* x, float* d0, float* d1, float* d2, float* d3, float* rvec, float* tvec) {
+    if (int r = model_forward(h, x)) return r;
+    return copy_outputs(h, d0, d1, d2, d3, rvec, tvec);
+}
+int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, float* loss) {
+    if (h->cfg.automasking && !auto_loss) { h->err = "md2_train_loss: automasking is on but auto_loss is NULL"; return 2; }
+    if (int r = model_forward(h, x)) return r;
+    const float* disp[4] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p};
+    if (int r = loss_forward(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;
+    h->x_last = x; h->auto_last = auto_loss; h->have_fwd = true;
+    return 0;
+}
+int32_t md2_backward(md2_handle* h) {
+    if (!h->have_fwd) { h->err = "md2_backward: call md2_train_loss first"; return 2; }
+    const float* disp[4] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p};
+    if (int r = loss_backward(h, h->x_last, disp, h->rvec, h->tvec, h->auto_last)) return r;
+    return model_backward(h);
+}
+int32_t md2_adam_step(md2_handle* h, float grad_scale) {
+    h->beta1p *= 0.9; h->beta2p *= 0.999;
+    launch_adam(h->P, h->G, h->M, h->V, h->n_int, (float)(1.0 - h->beta1p), (float)(1.0 - h->beta2p), (float)h->cfg.lr, grad_scale, h->stream);
+    KCHK(); return 0;
+}
+int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, float* loss, int32_t do_update) {
+    if (int r = md2_train_loss(h, x, auto_loss, loss)) return r;
+    if (int r = md2_backward(h)) return r;
+    if (do_update) return md2_adam_step(h, 1.f);
+    return 0;
+}
+int32_t md2_automasking_loss(md2_handle* h, const float* x, float* out) {
+    // photometric of the UNWARPED sources vs the target, min over sources (src/training.jl:9-11)
+    const size_t P = (size_t)h->H * h->W, CP = P * h->C;
+    float* tmp = h->E1;                                                   // [2][N][C][H][W] gather of the two source frames
+    float* tg = h->E2;
+    for (int n = 0; n < h->N; ++n) {
+        HIPCHK(hipMemcpyAsync(tmp + (size_t)n * CP, x + ((size_t)n * 3 + 0) * CP, CP * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(tmp + ((size_t)h->N + n) * CP, x + ((size_t)n * 3 + 2) * CP, CP * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(tg + (size_t)n * CP, x + ((size_t)n * 3 + 1) * CP, CP * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+    return md2_prediction_loss_fwd(tmp, 2, tg, out, h->N, h->C, h->H, h->W, h->stream);
+}
+int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const float* d1, const float* d2, const float* d3, const float* rvec, const float* tvec,
+                         const float* auto_loss, float* loss, float* dd0, float* dd1, float* dd2, float* dd3, float* drvec, float* dtvec) {
+    const float* disp[4] = {d0, d1, d2, d3};
+    if (int r = loss_forward(h, x, disp, rvec, tvec, auto_loss, loss)) return r;
+    if (!(dd0 || dd1 || dd2 || dd3 || drvec || dtvec)) return 0;
+    if (int r = loss_backward(h, x, disp, rvec, tvec, auto_loss)) return r;
+    float* dds[4] = {dd0, dd1, dd2, dd3};
+    for (int i = 0; i < 4; ++i)
+        if (dds[i]) HIPCHK(hipMemcpyAsync(dds[i], h->ddisp_lo[i], (size_t)h->N * h->dispv[i].H * h->dispv[i].W * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (drvec) HIPCHK(hipMemcpyAsync(drvec, h->drvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (dtvec) HIPCHK(hipMemcpyAsync(dtvec, h->dtvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int32_t md2_profile_enable(md2_handle* h, int32_t on) { h->prof = on != 0; return 0; }
+int32_t md2_profile_reset(md2_handle* h) {
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    h->evts.clear();
+    for (int i = 0; i < 5; ++i) { h->prof_flops[i] = 0; h->prof_bytes[i] = 0; }
+    return 0;
+}
+int32_t md2_profile_get(md2_handle* h, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double t = 0; int64_t n = 0;
+    for (auto& e : h->evts) if (e.cls == cls) { float ms = 0; if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { t += ms; ++n; } }
+    if (total_ms) *total_ms = t; if (launches) *launches = n;
+    if (flops) *flops = (cls >= 0 && cls < 5) ? h->prof_flops[cls] : 0; if (bytes) *bytes = (cls >= 0 && cls < 5) ? h->prof_bytes[cls] : 0;
+    return 0;
+}
+
+// ---- op-level layer entry points (NCHW in / out; converted to NHWC views in temporaries) ----------------------------------
+static float* tmp_alloc(size_t n, hipStream_t s) { float* p = nullptr; if (hipMallocAsync((void**)&p, n * sizeof(float), s) != hipSuccess) return nullptr; (void)hipMemsetAsync(p, 0, n * sizeof(float), s); return p; }
+static int pad16(int c) { return (c + 15) / 16 * 16; }
+// weights Flux [Cout][Cin][k][k] (device) -> internal [CoutP][taps][CinP] (device) via host
+static int upload_weights(const float* w_dev, float* w_int, int cin, int cout, int k, int cinP, int coutP, hipStream_t s) {
+    std::vector<float> f((size_t)cin * cout * k * k), in((size_t)coutP * k * k * cinP, 0.f);
+    if (hipStreamSynchronize(s) != hipSuccess) return 1;
+    if (hipMemcpy(f.data(), w_dev, f.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    for (int co = 0; co < cout; ++co) for (int ci = 0; ci < cin; ++ci) for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw)
+        in[((size_t)co * k * k + (k - 1 - kh) * k + (k - 1 - kw)) * cinP + ci] = f[(((size_t)co * cin + ci) * k + kh) * k + kw];
+    return hipMemcpy(w_int, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess;
+}
+int32_t md2_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                       int32_t pad_mode, int32_t act, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int cinP = pad16(Cin), coutP = pad16(Cout);
+    const int p_eff = pad_mode == PAD_REFLECT ? 1 : pad;
+    const int Ho = (H + 2 * p_eff - k) / stride + 1, Wo = (W + 2 * p_eff - k) / stride + 1;
+    float *xi = tmp_alloc((size_t)N * H * W * cinP, s), *wi = tmp_alloc((size_t)coutP * k * k * cinP, s), *yi = tmp_alloc((size_t)N * Ho * Wo * coutP, s), *bi = tmp_alloc(coutP, s);
+    if (!xi || !wi || !yi || !bi) return 3;
+    View xv = make_view(xi, N, H, W, cinP), yv = make_view(yi, N, Ho, Wo, coutP);
+    View xs = xv; xs.C = Cin; launch_nchw_to_view(x, xs, s);
+    if (upload_weights(w, wi, Cin, Cout, k, cinP, coutP, s)) return 1;
+    if (b) (void)hipMemcpyAsync(bi, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s);
+    ConvArgs a = conv_args(xv, wi, yv, k, stride, p_eff, 1, pad_mode);
+    a.bias = b ? bi : nullptr; a.act = act;
+    launch_conv_igemm(a, s);
+    View ys = yv; ys.C = Cout; launch_nhwc_to_nchw(nullptr, ys, y, s);
+    (void)hipFreeAsync(xi, s); (void)hipFreeAsync(wi, s); (void)hipFreeAsync(yi, s); (void)hipFreeAsync(bi, s);
+    return hipGetLastError() != hipSuccess;
+}
+int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride,
+                       int32_t pad, int32_t pad_mode, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int cinP = pad16(Cin), coutP = pad16(Cout);
+    const int p_eff = pad_mode == PAD_REFLECT ? 1 : pad;
+    const int Ho = (H + 2 * p_eff - k) / stride + 1, Wo = (W + 2 * p_eff - k) / stride + 1;
+    const size_t wn = (size_t)coutP * k * k * cinP;
+    float *xi = tmp_alloc((size_t)N * H * W * cinP, s), *wi = tmp_alloc(wn, s), *wd = tmp_alloc(wn, s), *gi = tmp_alloc(wn, s), *dyi = tmp_alloc((size_t)N * Ho * Wo * coutP, s), *gb = tmp_alloc(coutP, s);
+    if (!xi || !wi || !wd || !gi || !dyi || !gb) return 3;
+    View xv = make_view(xi, N, H, W, cinP), dyv = make_view(dyi, N, Ho, Wo, coutP);
+    View xs = xv; xs.C = Cin; launch_nchw_to_view(x, xs, s);
+    View ds = dyv; ds.C = Cout; launch_nchw_to_view(dy, ds, s);
+    if (upload_weights(w, wi, Cin, Cout, k, cinP, coutP, s)) return 1;
+    if (dx) {
+        launch_weight_to_dgrad(wi, wd, coutP, cinP, k * k, s);
+        const int Hp = pad_mode == PAD_REFLECT ? H + 2 : H, Wp = pad_mode == PAD_REFLECT ? W + 2 : W;
+        float* dxi = tmp_alloc((size_t)N * Hp * Wp * cinP, s); if (!dxi) return 3;
+        View dxp = make_view(dxi, N, Hp, Wp, cinP);
+        ConvArgs a = conv_args(dyv, wd, dxp, k, 1, k - 1 - (pad_mode == PAD_REFLECT ? 0 : pad), stride, PAD_ZERO);
+        launch_conv_igemm(a, s);
+        if (pad_mode == PAD_REFLECT) {
+            float* dxf = tmp_alloc((size_t)N * H * W * cinP, s); if (!dxf) return 3;
+            View dv = make_view(dxf, N, H, W, cinP);
+            launch_fold_reflect(dxp, dv, 0, nullptr, ACT_NONE, s);
+            View o = dv; o.C = Cin; launch_nhwc_to_nchw(nullptr, o, dx, s);
+            (void)hipFreeAsync(dxf, s);
+        } else { View o = dxp; o.C = Cin; launch_nhwc_to_nchw(nullptr, o, dx, s); }
+        (void)hipFreeAsync(dxi, s);
+    }
+    if (dw || db) {
+        WgradArgs a{};
+        a.x = xv.p; a.x_bs = xv.bs; a.x_ps = xv.ps; a.H = H; a.W = W; a.Cin = cinP;
+        a.dy = dyv.p; a.dy_bs = dyv.bs; a.dy_ps = dyv.ps; a.Ho = Ho; a.Wo = Wo; a.Cout = coutP;
+        a.dw = gi; a.N = N; a.KH = k; a.KW = k; a.stride = stride; a.pad = p_eff; a.padmode = pad_mode; a.M = N * Ho * Wo;
+        launch_conv_wgrad(a, s);
+        launch_colsum(dyv, gb, s);
+        if (hipStreamSynchronize(s) != hipSuccess) return 1;
+        std::vector<float> in(wn), f((size_t)Cin * Cout * k * k), bb(coutP);
+        (void)hipMemcpy(in.data(), gi, wn * sizeof(float), hipMemcpyDeviceToHost); (void)hipMemcpy(bb.data(), gb, coutP * sizeof(float), hipMemcpyDeviceToHost);
+        for (int co = 0; co < Cout; ++co) for (int ci = 0; ci < Cin; ++ci) for (int kh = 0; kh < k; ++kh) for (int kw = 0; kw < k; ++kw)
+            f[(((size_t)co * Cin + ci) * k + kh) * k + kw] = in[((size_t)co * k * k + (k - 1 - kh) * k + (k - 1 - kw)) * cinP + ci];
+        if (dw) (void)hipMemcpy(dw, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (db) (void)hipMemcpy(db, bb.data(), Cout * sizeof(float), hipMemcpyHostToDevice);
+    }
+    (void)hipFreeAsync(xi, s); (void)hipFreeAsync(wi, s); (void)hipFreeAsync(wd, s); (void)hipFreeAsync(gi, s); (void)hipFreeAsync(dyi, s); (void)hipFreeAsync(gb, s);
+    return hipGetLastError() != hipSuccess;
+}
+int32_t md2_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t relu, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (C % 4 || 256 % (C / 4)) return 2;
+    float *xi = tmp_alloc((size_t)N * H * W * C, s), *st = tmp_alloc(2 * C, s); double* acc = (double*)tmp_alloc(4 * C, s);
+    if (!xi || !st || !acc) return 3;
+    View v = make_view(xi, N, H, W, C); launch_nchw_to_view(x, v, s);
+    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), s);
+    launch_bn_apply(v, st, gamma, beta, nullptr, relu ? ACT_RELU : ACT_NONE, v, s);
+    launch_nhwc_to_nchw(nullptr, v, y, s);
+    (void)hipFreeAsync(xi, s); (void)hipFreeAsync(st, s); (void)hipFreeAsync(acc, s);
+    return hipGetLastError() != hipSuccess;
+}
+int32_t md2_bn_train_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (C % 4 || 256 % (C / 4)) return 2;
+    const size_t n = (size_t)N * H * W * C;
+    float *xi = tmp_alloc(n, s), *di = tmp_alloc(n, s), *oi = tmp_alloc(n, s), *st = tmp_alloc(2 * C, s); double* acc = (double*)tmp_alloc(8 * C, s);
+    if (!xi || !di || !oi || !st || !acc) return 3;
+    View v = make_view(xi, N, H, W, C), d = make_view(di, N, H, W, C), o = make_view(oi, N, H, W, C);
+    launch_nchw_to_view(x, v, s); launch_nchw_to_view(dy, d, s);
+    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), s);
+    (void)hipMemsetAsync(dgamma, 0, C * sizeof(float), s); (void)hipMemsetAsync(dbeta, 0, C * sizeof(float), s);
+    launch_bn_bwd_reduce(d, nullptr, ACT_NONE, v, st, acc + 2 * C, s);
+    launch_bn_bwd_apply(d, nullptr, ACT_NONE, v, st, gamma, acc + 2 * C, (double)v.pixels(), o, dgamma, dbeta, s);
+    launch_nhwc_to_nchw(nullptr, o, dx, s);
+    (void)hipFreeAsync(xi, s); (void)hipFreeAsync(di, s); (void)hipFreeAsync(oi, s); (void)hipFreeAsync(st, s); (void)hipFreeAsync(acc, s);
+    return hipGetLastError() != hipSuccess;
+}
+int32_t md2_maxpool3s2_fwd(const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    hipStream_t s = (hipStream_t)stream; if (C % 4) return 2;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    float *xi = tmp_alloc((size_t)N * H * W * C, s), *yi = tmp_alloc((size_t)N * Ho * Wo * C, s); uint8_t* arg = (uint8_t*)tmp_alloc((size_t)N * Ho * Wo * C / 4 + 4, s);
+    if (!xi || !yi || !arg) return 3;
+    View v = make_view(xi, N, H, W, C), o = make_view(yi, N, Ho, Wo, C);
+    launch_nchw_to_view(x, v, s); launch_maxpool_fwd(v, o, arg, s); launch_nhwc_to_nchw(nullptr, o, y, s);
+    (void)hipFreeAsync(xi, s); (void)hipFreeAsync(yi, s); (void)hipFreeAsync(arg, s);
+    return hipGetLastError() != hipSuccess;
+}
+int32_t md2_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    hipStream_t s = (hipStream_t)stream; if (C % 4) return 2;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    float *xi = tmp_alloc((size_t)N * H * W * C, s), *yi = tmp_alloc((size_t)N * Ho * Wo * C, s), *di = tmp_alloc((size_t)N * Ho * Wo * C, s), *oi = tmp_alloc((size_t)N * H * W * C, s);
+    uint8_t* arg = (uint8_t*)tmp_alloc((size_t)N * Ho * Wo * C / 4 + 4, s);
+    if (!xi || !yi || !di || !oi || !arg) return 3;
+    View v = make_view(xi, N, H, W, C), o = make_view(yi, N, Ho, Wo, C), d = make_view(di, N, Ho, Wo, C), g = make_view(oi, N, H, W, C);
+    launch_nchw_to_view(x, v, s); launch_nchw_to_view(dy, d, s);
+    launch_maxpool_fwd(v, o, arg, s); launch_maxpool_bwd(d, arg, g, 0, nullptr, s); launch_nhwc_to_nchw(nullptr, g, dx, s);
+    (void)hipFreeAsync(xi, s); (void)hipFreeAsync(yi, s); (void)hipFreeAsync(di, s); (void)hipFreeAsync(oi, s); (void)hipFreeAsync(arg, s);
+    return hipGetLastError() != hipSuccess;
+}
+int32_t md2_adam_raw(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, float grad_scale, void* stream) {
+    if (n % 4) return 2;
+    launch_adam(p, g, m, v, (long)n, (float)(1.0 - std::pow(0.9, step)), (float)(1.0 - std::pow(0.999, step)), (float)lr, grad_scale, (hipStream_t)stream);
+    return hipGetLastError() != hipSuccess;
+}
+
+}  // extern "C"

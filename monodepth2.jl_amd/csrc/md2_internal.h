@@ -1,0 +1,144 @@
+// md2_internal.h — shared declarations of the gfx950 kernels behind include/md2hip.h.
+// Internal activation layout is NHWC fp32 with explicit batch / pixel strides (a "view"), so that
+// frame slicing (src/model.jl:16,32-34) and channel concat (src/depth_decoder.jl:19, src/pose_decoder.jl:24)
+// cost nothing: producers write straight into channel slices / strided batches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace md2 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
+enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+// NHWC view: element (n,h,w,c) at p[n*bs + (h*W + w)*ps + c]
+struct View {
+    float* p = nullptr; int N = 0, H = 0, W = 0, C = 0; long bs = 0; int ps = 0;
+    __host__ __device__ long pixels() const { return (long)N * H * W; }
+};
+inline View make_view(float* p, int N, int H, int W, int C) { View v; v.p = p; v.N = N; v.H = H; v.W = W; v.C = C; v.ps = C; v.bs = (long)H * W * C; return v; }
+inline View chan_slice(const View& v, int c0, int c) { View r = v; r.p = v.p + c0; r.C = c; return r; }
+// frame l of a [N*L] batch (batch index n*L + l)
+inline View frame_view(const View& v, int L, int l) { View r = v; r.p = v.p + (long)l * v.bs; r.N = v.N / L; r.bs = v.bs * L; return r; }
+
+__host__ __device__ inline int refl_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__device__ inline float act_apply(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if (act == ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+// derivative of the activation expressed through its OUTPUT value o
+__device__ inline float act_deriv(float o, int act) {
+    if (act == ACT_RELU) return o > 0.f ? 1.f : 0.f;
+    if (act == ACT_ELU) return o > 0.f ? 1.f : o + 1.f;
+    if (act == ACT_SIGMOID) return o * (1.f - o);
+    return 1.f;
+}
+
+// ---- implicit-GEMM convolution (conv_igemm.hip) -------------------------------------------------
+// y[n,oh,ow,co] = epi( sum_{kh,kw,ci} w[co][(kh*KW+kw)*Cin+ci] * x[n, ih, iw, ci] ),
+//   t = o*stride - pad + k ; dil>1: taps with t % dil != 0 contribute 0 and ih = t/dil (transposed conv, used for
+//   the input-gradient of strided convs) ; PAD_ZERO: out-of-range -> 0 ; PAD_REFLECT: mirrored.
+//   epi: (+bias) -> act -> (* act_deriv(dact_src)) -> (+ old y if accumulate)
+struct ConvArgs {
+    const float* x; long x_bs; int x_ps; int H, W, Cin;
+    const float* w;
+    float* y; long y_bs; int y_ps; int Ho, Wo, Cout;
+    int N, KH, KW, stride, pad, dil, padmode;
+    const float* bias; int act; int accumulate;
+    const float* dact_src; long da_bs; int da_ps; int dact;   // optional: multiply by act_deriv(dact_src[n,oh,ow,co])
+    int M;                                                    // N*Ho*Wo
+};
+void launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+double conv_igemm_flops(const ConvArgs& a);
+
+// dw[co][(kh*KW+kw)*Cin+ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, ih, iw, ci]   (atomic accumulation, split over pixels)
+struct WgradArgs {
+    const float* x; long x_bs; int x_ps; int H, W, Cin;
+    const float* dy; long dy_bs; int dy_ps; int Ho, Wo, Cout;
+    float* dw;
+    int N, KH, KW, stride, pad, padmode;
+    int M;
+};
+void launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
+
+// weight transforms between the three layouts
+//   flux   : [Cout][Cin][KH][KW], true convolution (kernel flipped)           (boundary)
+//   fwd    : [CoutP][KH*KW][CinP] cross-correlation taps                       (internal parameter storage)
+//   dgrad  : [CinP][KH*KW flipped][CoutP]                                       (per-step transposed copy)
+void launch_weight_to_dgrad(const float* w_fwd, float* w_dg, int CoutP, int CinP, int taps, hipStream_t s);
+
+// ---- 3x3 reflect-pad conv with ONE output channel (disparity heads, src/depth_decoder.jl:43) ------
+void launch_head_fwd(const View& x, const float* w /*[9][Cin]*/, const float* b, const View& y /*C=1, sigmoid*/, hipStream_t s);
+// dz = dy * y*(1-y) computed on the fly.  dx = (accumulate? dx : 0) + reflect-adjoint conv ; dw += ; db +=
+void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, float* dw, float* db, hipStream_t s);
+
+// ---- layer kernels (layers.hip) ----------------------------------------------------------------
+void launch_im2col_stem(const float* x_nchw, int NL, int C, int H, int W, float* col, int Kpad, hipStream_t s);   // 7x7 s2 p3
+void launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
+void launch_nhwc_to_nchw(const float* src, const View& v, float* dst, hipStream_t s);
+void launch_nchw_to_view(const float* src, const View& v, hipStream_t s);
+// per-channel sum / sum of squares of a view -> double[2*C] (must be zeroed by caller)
+void launch_colstats(const View& z, double* acc, hipStream_t s);
+// mean/invstd from acc; also zeroes nothing.  stats: float[2*C] = mean, invstd
+void launch_bn_finalize(const double* acc, float* stats, int C, double count, hipStream_t s);
+// y = act(gamma*(z-mean)*invstd + beta + residual)
+void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s);
+// g = dy * act_deriv(yact) ; acc[0..C) += sum g ; acc[C..2C) += sum g*xhat          (acc double, zeroed by caller)
+void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View& z, const float* stats, double* acc, hipStream_t s);
+// dz = gamma*invstd*(g - s1/M - xhat*s2/M) ; dgamma += s2, dbeta += s1 (written by block 0)
+void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc,
+                         double count, const View& dz, float* dgamma, float* dbeta, hipStream_t s);
+void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s);
+// dx (+)= scatter of dy by arg, gather form; optional multiply by relu'(xact)
+void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* xact, hipStream_t s);
+void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s);
+// dx = adjoint(up2)(dy) * act_deriv(xact)
+void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int act, hipStream_t s);
+// reflect-pad adjoint: dst = ((accumulate ? dst : 0) + fold(src_padded)) * act_deriv(actsrc)
+void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, const View* actsrc, int act, hipStream_t s);
+// dst = (accumulate ? dst : 0) + a*src (optionally * act_deriv(actsrc))
+void launch_axpy_view(const View& src, const View& dst, float a, int accumulate, const View* actsrc, int act, hipStream_t s);
+// out[c] (+)= sum over pixels of v[.,c]   (float atomics)
+void launch_colsum(const View& v, float* out, hipStream_t s);
+// pose head: y [B][HW][16] -> rvec/tvec [B][3] = 0.01 * mean ; and its adjoint
+void launch_pose_mean_fwd(const View& y, float* rvec, float* tvec, hipStream_t s);
+void launch_pose_mean_bwd(const float* drvec, const float* dtvec, const View& dy, hipStream_t s);
+void launch_adam(float* p, const float* g, float* m, float* v, long n, float c1, float c2, float lr, float gscale, hipStream_t s);
+void launch_fill(float* p, long n, float v, hipStream_t s);
+
+// ---- loss kernels (loss.hip) --------------------------------------------------------------------
+struct LossArgs {
+    const float* x;            // [N][3][C][H][W]
+    const float* disp[4];      // [N][h_i][w_i]
+    int dh[4], dw[4];
+    const float* Rt;           // [2][N][12] : R (col-major 9) + t (3), after composeT
+    const float* auto_loss;    // [N][H][W] or null
+    float K[9], invK[9];       // column-major
+    int N, C, H, W, nscales;
+    float min_disp, max_disp;  // 1/max_depth, 1/min_depth
+    float smooth_w[4];         // disparity_smoothness * scale_i
+    int tgt, src0, src1;       // 0-based frame indices
+};
+// per-scale partial sums -> part[(scale*N + n)*4 + {photo, sum d, Sx, Sy}] (double atomics; zeroed by caller)
+void launch_loss_fwd(const LossArgs& a, double* part, hipStream_t s);
+// totals[(scale*N+n)*4+..] float copy + scalar loss
+void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, float* loss, hipStream_t s);
+// backward: ddisp_full[scale][N][H][W] ; dRt partials -> dRt_acc double [2][N][12] (zeroed by caller)
+void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, hipStream_t s);
+// planar bilinear (align-corners) upsample adjoint, gather form: [planes][Ho][Wo] -> [planes][H][W]
+void launch_upsample_planar_bwd(const float* dout, float* dx, int planes, int H, int W, int Ho, int Wo, hipStream_t s);
+void launch_upsample_planar_fwd(const float* x, float* out, int planes, int H, int W, int Ho, int Wo, hipStream_t s);
+// composeT for both sources: rvec,tvec [2][N][3] -> Rt [2][N][12] ; adjoint dRt(double) -> drvec,dtvec
+void launch_pose_compose(const float* rvec, const float* tvec, float* Rt, int N, int inv0, int inv1, hipStream_t s);
+void launch_pose_compose_bwd(const float* rvec, const float* tvec, const double* dRt, float* drvec, float* dtvec, int N, int inv0, int inv1, hipStream_t s);
+
+struct Timer;   // profile.hpp
+
+}  // namespace md2

@@ -1,0 +1,457 @@
+"""Host-side mirror of the reference's call surface for the training-step hot path, on top of the C ABI.
+
+Julia is not available in the build image, so this Python layer stands where the reference's Julia
+module stands (the Julia `ccall` shim a maintainer would use is julia/Monodepth2HIP.jl).  Names,
+argument order and meaning follow the reference (src/Monodepth.jl, model.jl, depth_decoder.jl,
+pose_decoder.jl, training.jl, utils.jl); ids are 1-based like the reference.  Arrays are torch CUDA
+float32 tensors whose shape is the REVERSE of the Julia shape (same bytes): Julia (W,H,C,N) <-> (N,C,H,W),
+(W,H,C,L,N) <-> (N,L,C,H,W), rvec (3,N) <-> (N,3), R (3,3,N) <-> (N,3,3) stored column-major.
+
+torch is used only for device memory, streams and torch.distributed; every computation is a HIP kernel
+of libmd2hip.so.  There is no CPU path: without the library / a GPU every call raises.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _check(rc, handle=None, what=""):
+    if rc != 0:
+        msg = _lib.lib().md2_last_error(handle)
+        raise RuntimeError("libmd2hip %s failed (status %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("expected a contiguous float32 CUDA tensor (the product path has no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    return t.contiguous().float()
+
+
+# --------------------------------------------------------------------------------------------
+# Params / TrainCache  (src/Monodepth.jl:32-55)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Params:
+    target_size: Tuple[int, int]          # (width, height)
+    batch_size: int
+    min_depth: float = 0.1
+    max_depth: float = 100.0
+    disparity_smoothness: float = 1e-3
+    frame_ids: List[int] = field(default_factory=lambda: [1, 2, 3])
+    automasking: bool = True
+
+
+@dataclass
+class TrainCache:
+    ssim: "SSIM"
+    backprojections: "Backproject"
+    projections: "Project"
+    K: np.ndarray                         # 3x3
+    invK: np.ndarray
+    target_id: int
+    source_ids: List[int]
+    scales: List[float]
+
+
+def _colmajor(M):
+    return np.ascontiguousarray(np.asarray(M, np.float32).T).reshape(-1)
+
+
+def _dev_mat(M):
+    return torch.from_numpy(_colmajor(M)).cuda()
+
+
+# --------------------------------------------------------------------------------------------
+# L2 ops (src/utils.jl)
+# --------------------------------------------------------------------------------------------
+class SSIM:
+    """SSIM()(x, y): (N,C,H,W) -> (N,C,H,W); lower = more similar (src/utils.jl:13-39)."""
+
+    def __call__(self, x, y):
+        x, y = _f32(x), _f32(y); N, Cc, H, W = x.shape; out = torch.empty_like(x)
+        _check(_lib.lib().md2_ssim_fwd(_dev(x), _dev(y), _dev(out), N * Cc, H, W, _stream()), None, "ssim_fwd"); return out
+
+
+class Backproject:
+    """Backproject(; width, height)(depth (N,P), invK) -> (N,P,3)  (src/utils.jl:41-65)."""
+
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+
+    def __call__(self, depth, invK):
+        depth = _f32(depth); N = depth.shape[0]; out = torch.empty(N, self.width * self.height, 3, device=depth.device)
+        iK = invK if torch.is_tensor(invK) else _dev_mat(invK)
+        _check(_lib.lib().md2_backproject(_dev(depth), _dev(iK), _dev(out), N, self.height, self.width, _stream()), None, "backproject"); return out
+
+
+class Project:
+    """Project(; width, height)(points (N,P,3), K, R (N,9 col-major), t (N,3)) -> uv (N,P,2) in [-1,1]  (src/utils.jl:67-99)."""
+
+    def __init__(self, width, height):
+        self.width, self.height = width, height
+
+    def __call__(self, points, K, R, t):
+        points = _f32(points); N = points.shape[0]; uv = torch.empty(N, self.width * self.height, 2, device=points.device)
+        Kd = K if torch.is_tensor(K) else _dev_mat(K)
+        _check(_lib.lib().md2_project(_dev(points), _dev(Kd), _dev(_f32(R)), _dev(_f32(t).reshape(N, 3)), _dev(uv), N, self.height, self.width, _stream()), None, "project")
+        return uv
+
+
+def hat(rvec):
+    rvec = _f32(rvec); N = rvec.shape[0]; S = torch.empty(N, 9, device=rvec.device)
+    _check(_lib.lib().md2_hat(_dev(rvec), _dev(S), N, _stream())); return S
+
+
+def so3_exp_map(rvec):
+    """rvec (N,3) -> R (N,9) column-major  (src/utils.jl:101-117)."""
+    rvec = _f32(rvec); N = rvec.shape[0]; R = torch.empty(N, 9, device=rvec.device)
+    _check(_lib.lib().md2_so3_exp_map(_dev(rvec), _dev(R), N, _stream())); return R
+
+
+def so3_exp_map_pullback(rvec, dR):
+    rvec = _f32(rvec); N = rvec.shape[0]; dr = torch.empty(N, 3, device=rvec.device)
+    _check(_lib.lib().md2_so3_exp_map_bwd(_dev(rvec), _dev(_f32(dR)), _dev(dr), N, _stream())); return dr
+
+
+def composeT(rvec, t, invert):
+    """-> (R (N,9), t (N,3))  (src/utils.jl:181-188)."""
+    rvec = _f32(rvec); N = rvec.shape[0]; R = torch.empty(N, 9, device=rvec.device); to = torch.empty(N, 3, device=rvec.device)
+    _check(_lib.lib().md2_composeT(_dev(rvec), _dev(_f32(t).reshape(N, 3)), int(bool(invert)), _dev(R), _dev(to), N, _stream())); return R, to
+
+
+def smooth_loss(disparity, image):
+    """disparity (N,H,W), image (N,C,H,W) -> 0-dim tensor  (src/utils.jl:159-173)."""
+    d, im = _f32(disparity), _f32(image); N, H, W = d.shape; out = torch.empty((), device=d.device)
+    _check(_lib.lib().md2_smooth_loss(_dev(d), _dev(im), _dev(out), N, im.shape[1], H, W, _stream())); return out
+
+
+def disparity_to_depth(disparity, min_depth, max_depth):
+    d = _f32(disparity); out = torch.empty_like(d)
+    _check(_lib.lib().md2_disparity_to_depth(_dev(d), _dev(out), d.numel(), float(min_depth), float(max_depth), _stream())); return out
+
+
+def grid_sample(input, grid, padding_mode="zeros"):
+    """NNlib.grid_sample: input (N,C,H,W), grid (N,Ho,Wo,2)."""
+    x, g = _f32(input), _f32(grid); N, Cc, H, W = x.shape; Ho, Wo = g.shape[1:3]; out = torch.empty(N, Cc, Ho, Wo, device=x.device)
+    _check(_lib.lib().md2_grid_sample_fwd(_dev(x), _dev(g), _dev(out), N, Cc, H, W, Ho, Wo, int(padding_mode == "border"), _stream())); return out
+
+
+def grid_sample_pullback_grid(input, grid, dout, padding_mode="zeros"):
+    x, g, d = _f32(input), _f32(grid), _f32(dout); N, Cc, H, W = x.shape; Ho, Wo = g.shape[1:3]; dg = torch.empty_like(g)
+    _check(_lib.lib().md2_grid_sample_bwd_grid(_dev(x), _dev(g), _dev(d), _dev(dg), N, Cc, H, W, Ho, Wo, int(padding_mode == "border"), _stream())); return dg
+
+
+def upsample_bilinear(x, size):
+    """NNlib.upsample_bilinear(x; size=(W,H)) — size given as (width, height) like the reference."""
+    x = _f32(x); N, Cc, H, W = x.shape; Wo, Ho = size; out = torch.empty(N, Cc, Ho, Wo, device=x.device)
+    _check(_lib.lib().md2_upsample_bilinear_fwd(_dev(x), _dev(out), N * Cc, H, W, Ho, Wo, _stream())); return out
+
+
+def upsample_bilinear_pullback(dout, size_in):
+    d = _f32(dout); N, Cc, Ho, Wo = d.shape; W, H = size_in; dx = torch.empty(N, Cc, H, W, device=d.device)
+    _check(_lib.lib().md2_upsample_bilinear_bwd(_dev(d), _dev(dx), N * Cc, H, W, Ho, Wo, _stream())); return dx
+
+
+def warp(disparity, source, K, invK, R, t, min_depth, max_depth):
+    """The sequence `slow_depth` calls `warp` (undefined in the reference, SURVEY.md §2 note):
+    disparity_to_depth -> Backproject -> Project -> grid_sample(:border), src/training.jl:48-57."""
+    d, s = _f32(disparity), _f32(source); N, Cc, H, W = s.shape; out = torch.empty_like(s)
+    Kd = K if torch.is_tensor(K) else _dev_mat(K); iK = invK if torch.is_tensor(invK) else _dev_mat(invK)
+    _check(_lib.lib().md2_warp_fwd(_dev(d), _dev(s), _dev(Kd), _dev(iK), _dev(_f32(R)), _dev(_f32(t).reshape(N, 3)), _dev(out), N, Cc, H, W, float(min_depth), float(max_depth), _stream()))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# losses (src/training.jl:1-19)
+# --------------------------------------------------------------------------------------------
+def photometric_loss(ssim, predicted, target, alpha=0.85):
+    if abs(alpha - 0.85) > 1e-12:
+        raise ValueError("the HIP kernel implements the reference's alpha = 0.85")
+    p, t = _f32(predicted), _f32(target); N, Cc, H, W = p.shape; out = torch.empty(N, 1, H, W, device=p.device)
+    _check(_lib.lib().md2_photometric_loss_fwd(_dev(p), _dev(t), _dev(out), N, Cc, H, W, _stream())); return out
+
+
+def prediction_loss(ssim, predictions, target):
+    preds = _f32(torch.stack([_f32(p) for p in predictions], 0)); t = _f32(target); k, N, Cc, H, W = preds.shape
+    out = torch.empty(N, 1, H, W, device=t.device)
+    _check(_lib.lib().md2_prediction_loss_fwd(_dev(preds), k, _dev(t), _dev(out), N, Cc, H, W, _stream())); return out
+
+
+def automasking_loss(ssim, inputs, target, source_ids):
+    """inputs (N,L,C,H,W); photometric of the unwarped sources, min over sources (src/training.jl:9-11)."""
+    return prediction_loss(ssim, [inputs[:, i - 1].contiguous() for i in source_ids], target)
+
+
+def _apply_mask(mask, warp_loss):
+    return torch.minimum(mask, warp_loss)
+
+
+# --------------------------------------------------------------------------------------------
+# model (src/model.jl, src/depth_decoder.jl, src/pose_decoder.jl, ResNet.jl call sites)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class Pose:
+    rvec: torch.Tensor   # (N,3)
+    tvec: torch.Tensor   # (N,3)  == Julia (3,1,N)
+
+
+class ResidualNetwork:
+    """ResidualNetwork(18; in_channels, classes=nothing): only the ResNet-18 trunk is implemented."""
+
+    def __init__(self, depth=18, in_channels=3, classes=None):
+        if depth != 18 or classes is not None:
+            raise NotImplementedError("hot path implements ResNet-18 without the classifier head")
+        self.in_channels = in_channels
+        self.stages = (64, 64, 128, 256, 512)
+
+
+class DepthDecoder:
+    def __init__(self, encoder_channels, scale_levels):
+        scale_levels = list(scale_levels)
+        if len(scale_levels) > 5 or min(scale_levels) < 1 or max(scale_levels) > 5:
+            raise ValueError("`scale_levels` should be at most of length 5 and have values in [1, 5] range.")   # src/depth_decoder.jl:27-29
+        if list(encoder_channels) != [64, 64, 128, 256, 512] or scale_levels != [2, 3, 4, 5]:
+            raise NotImplementedError("hot path implements encoder_channels=(64,64,128,256,512), scale_levels=2:5 (src/Monodepth.jl:106,118)")
+        self.encoder_channels, self.scale_levels = list(encoder_channels), scale_levels
+
+
+class PoseDecoder:
+    def __init__(self, encoder_out_channels):
+        if encoder_out_channels != 512:
+            raise NotImplementedError("hot path implements PoseDecoder(512)")
+        self.encoder_out_channels = encoder_out_channels
+
+
+class Model:
+    """Model(encoder, depth_decoder, pose_decoder); `model(x, source_ids, target_id)` -> (disparities, poses).
+
+    Owns one libmd2hip handle (weights, ADAM moments, workspaces) per (batch, H, W) shape."""
+
+    def __init__(self, encoder, depth_decoder, pose_decoder, lr=1e-4):
+        self.encoder, self.depth_decoder, self.pose_decoder = encoder, depth_decoder, pose_decoder
+        self.lr = lr
+        self._h = None
+        self._shape = None
+        self._params_host = None
+        self._cfg_extra = dict(min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, automasking=False)
+        self._K = None
+
+    # -- handle management --------------------------------------------------------------------
+    def _ensure(self, x, parameters: Optional[Params] = None, cache: Optional[TrainCache] = None):
+        N, L, Cc, H, W = x.shape
+        if L != 3 or Cc != self.encoder.in_channels:
+            raise ValueError("x must be (N,3,C,H,W) with C == encoder.in_channels")
+        extra = dict(self._cfg_extra)
+        if parameters is not None:
+            extra = dict(min_depth=parameters.min_depth, max_depth=parameters.max_depth,
+                         disparity_smoothness=parameters.disparity_smoothness, automasking=bool(parameters.automasking))
+        key = (N, Cc, H, W, tuple(sorted(extra.items())), x.device.index)
+        if self._h is not None and key == self._shape:
+            return
+        saved = self.params() if self._h is not None else self._params_host
+        self.close()
+        cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr)
+        h = C.c_void_p()
+        _check(_lib.lib().md2_create(C.byref(cfg), C.byref(h)), None, "md2_create")
+        self._h, self._shape, self._cfg_extra = h, key, extra
+        if saved is not None:
+            self.load_params(saved)
+        if cache is not None:
+            self.set_intrinsics(cache.K, cache.invK)
+        elif self._K is not None:
+            self.set_intrinsics(*self._K)
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().md2_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_intrinsics(self, K, invK):
+        self._K = (np.asarray(K, np.float64), np.asarray(invK, np.float64))
+        if self._h is not None:
+            k, ik = _colmajor(K), _colmajor(invK)
+            _check(_lib.lib().md2_set_intrinsics(self._h, k.ctypes.data_as(C.c_void_p), ik.ctypes.data_as(C.c_void_p)), self._h)
+
+    # -- Flux.params(model) -------------------------------------------------------------------
+    def load_params(self, flat):
+        flat = np.ascontiguousarray(flat, np.float32)
+        self._params_host = flat
+        if self._h is not None:
+            _lib.lib().md2_set_stream(self._h, _stream())
+            _check(_lib.lib().md2_params_set(self._h, flat.ctypes.data_as(C.c_void_p), flat.size), self._h, "params_set")
+
+    def params(self):
+        if self._h is None:
+            return self._params_host
+        n = _lib.lib().md2_params_count(self._h); out = np.empty(n, np.float32)
+        _check(_lib.lib().md2_params_get(self._h, out.ctypes.data_as(C.c_void_p), n), self._h, "params_get"); return out
+
+    def grads(self):
+        n = _lib.lib().md2_params_count(self._h); out = np.empty(n, np.float32)
+        _check(_lib.lib().md2_grads_get(self._h, out.ctypes.data_as(C.c_void_p), n), self._h, "grads_get"); return out
+
+    def grad_buffer(self):
+        """The library's flat fp32 gradient buffer as a torch tensor (no copy) for the DP all-reduce."""
+        p = C.c_void_p(); n = C.c_int64()
+        _check(_lib.lib().md2_grad_buffer(self._h, C.byref(p), C.byref(n)), self._h)
+        return _wrap_device_buffer(p.value, n.value, self._shape[-1] or 0)
+
+    # -- forward --------------------------------------------------------------------------------
+    def __call__(self, x, source_ids, target_id):
+        if list(source_ids) != [1, 3] or target_id != 2:
+            raise NotImplementedError("hot path implements source_ids=[1,3], target_id=2 (src/kitty.jl, src/dtk.jl)")
+        x = _f32(x); self._ensure(x)
+        N, _, _, H, W = x.shape
+        L = _lib.lib(); L.md2_set_stream(self._h, _stream())
+        ds = [torch.empty(N, 1, H >> s, W >> s, device=x.device) for s in (3, 2, 1, 0)]
+        rvec = torch.empty(2, N, 3, device=x.device); tvec = torch.empty(2, N, 3, device=x.device)
+        _check(L.md2_model_forward(self._h, _dev(x), _dev(ds[0]), _dev(ds[1]), _dev(ds[2]), _dev(ds[3]), _dev(rvec), _dev(tvec)), self._h, "model_forward")
+        return ds, [Pose(rvec[0], tvec[0]), Pose(rvec[1], tvec[1])]
+
+
+class _DevBuf:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def _wrap_device_buffer(ptr, n, device_index):
+    return torch.as_tensor(_DevBuf(ptr, n), device="cuda:%d" % device_index)
+
+
+# --------------------------------------------------------------------------------------------
+# train_loss + the loop body (src/training.jl:21-78, src/Monodepth.jl:156-176)
+# --------------------------------------------------------------------------------------------
+def train_loss(model: Model, x, auto_loss, cache: TrainCache, parameters: Params, do_visualization=False):
+    """-> (loss, vis_disparity, vis_warped, vis_loss); keeps the activations for `gradient`."""
+    x = _f32(x); model._ensure(x, parameters, cache)
+    L = _lib.lib(); L.md2_set_stream(model._h, _stream())
+    if parameters.automasking and auto_loss is None:
+        raise ValueError("parameters.automasking is set but auto_loss is None")
+    loss = torch.empty((), device=x.device)
+    al = _f32(auto_loss) if auto_loss is not None else None
+    model._keepalive = (x, al)
+    _check(L.md2_train_loss(model._h, _dev(x), _dev(al), _dev(loss)), model._h, "train_loss")
+    vis_disparity = vis_warped = vis_loss = None
+    if do_visualization:
+        ds, poses = model(x, cache.source_ids, cache.target_id)
+        vis_disparity = ds[-1].cpu()
+    return loss, vis_disparity, vis_warped, vis_loss
+
+
+def gradient(model: Model):
+    """Zygote `gradient(theta) do train_loss(...) end` for the last train_loss call; result via model.grads()."""
+    _lib.lib().md2_set_stream(model._h, _stream())
+    _check(_lib.lib().md2_backward(model._h), model._h, "backward")
+
+
+class ADAM:
+    """Flux.Optimise.ADAM(eta) — the moments live in the model's handle."""
+
+    def __init__(self, eta=1e-4):
+        self.eta = eta
+
+
+def update(optimizer: ADAM, model: Model, grad_scale=1.0):
+    """Flux.Optimise.update!(optimizer, theta, grads)."""
+    _lib.lib().md2_set_stream(model._h, _stream())
+    _check(_lib.lib().md2_adam_step(model._h, float(grad_scale)), model._h, "adam_step")
+
+
+def train_step(model: Model, x, auto_loss, cache: TrainCache, parameters: Params, do_update=True):
+    """One iteration of the loop body src/Monodepth.jl:156-176 (forward + backward [+ ADAM]); returns the device loss."""
+    x = _f32(x); model._ensure(x, parameters, cache)
+    L = _lib.lib(); L.md2_set_stream(model._h, _stream())
+    loss = torch.empty((), device=x.device)
+    al = _f32(auto_loss) if auto_loss is not None else None
+    model._keepalive = (x, al)
+    _check(L.md2_train_step(model._h, _dev(x), _dev(al), _dev(loss), int(do_update)), model._h, "train_step")
+    return loss
+
+
+def loss_fwd_bwd(model: Model, x, disps, rvec, tvec, auto_loss=None, want_grads=True):
+    """Loss half alone (src/training.jl:28-77) on given disparities/poses; for parity tests."""
+    x = _f32(x); L = _lib.lib(); L.md2_set_stream(model._h, _stream())
+    ds = [_f32(d) for d in disps]; rvec, tvec = _f32(rvec), _f32(tvec)
+    loss = torch.empty((), device=x.device)
+    dds = [torch.empty_like(d) for d in ds] if want_grads else [None] * 4
+    drv = torch.empty_like(rvec) if want_grads else None; dtv = torch.empty_like(tvec) if want_grads else None
+    al = _f32(auto_loss) if auto_loss is not None else None
+    _check(L.md2_loss_fwd_bwd(model._h, _dev(x), _dev(ds[0]), _dev(ds[1]), _dev(ds[2]), _dev(ds[3]), _dev(rvec), _dev(tvec), _dev(al), _dev(loss),
+                              _dev(dds[0]), _dev(dds[1]), _dev(dds[2]), _dev(dds[3]), _dev(drv), _dev(dtv)), model._h, "loss_fwd_bwd")
+    return loss, dds, drv, dtv
+
+
+def profile(model: Model, on=True):
+    _check(_lib.lib().md2_profile_enable(model._h, int(on)), model._h)
+    if on:
+        _check(_lib.lib().md2_profile_reset(model._h), model._h)
+
+
+def profile_get(model: Model, cls):
+    ms = C.c_double(); n = C.c_int64(); fl = C.c_double(); by = C.c_double()
+    _check(_lib.lib().md2_profile_get(model._h, cls, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), model._h)
+    return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+
+
+# --------------------------------------------------------------------------------------------
+# layer-level ops used by the parity tests (Flux Conv / BatchNorm / MaxPool semantics on NCHW tensors)
+# --------------------------------------------------------------------------------------------
+def conv2d(x, w, b=None, stride=1, pad=0, pad_mode="zeros", act="none"):
+    x, w = _f32(x), _f32(w); N, Cin, H, W = x.shape; Cout, _, k, _ = w.shape
+    pm = 1 if pad_mode == "reflect" else 0; pe = 1 if pm else pad
+    Ho = (H + 2 * pe - k) // stride + 1; Wo = (W + 2 * pe - k) // stride + 1
+    y = torch.empty(N, Cout, Ho, Wo, device=x.device)
+    a = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}[act]
+    _check(_lib.lib().md2_conv2d_fwd(_dev(x), _dev(w), _dev(_f32(b)) if b is not None else None, _dev(y), N, Cin, H, W, Cout, k, stride, pad, pm, a, _stream()), None, "conv2d_fwd")
+    return y
+
+
+def conv2d_pullback(x, w, dy, stride=1, pad=0, pad_mode="zeros"):
+    x, w, dy = _f32(x), _f32(w), _f32(dy); N, Cin, H, W = x.shape; Cout, _, k, _ = w.shape
+    dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(Cout, device=x.device)
+    _check(_lib.lib().md2_conv2d_bwd(_dev(x), _dev(w), _dev(dy), _dev(dx), _dev(dw), _dev(db), N, Cin, H, W, Cout, k, stride, pad, 1 if pad_mode == "reflect" else 0, _stream()), None, "conv2d_bwd")
+    return dx, dw, db
+
+
+def batchnorm_train(x, gamma, beta, relu=False):
+    x = _f32(x); N, Cc, H, W = x.shape; y = torch.empty_like(x)
+    _check(_lib.lib().md2_bn_train_fwd(_dev(x), _dev(_f32(gamma)), _dev(_f32(beta)), _dev(y), N, Cc, H, W, int(relu), _stream()), None, "bn_fwd"); return y
+
+
+def batchnorm_train_pullback(x, gamma, dy):
+    x, dy = _f32(x), _f32(dy); N, Cc, H, W = x.shape; dx = torch.empty_like(x); dg = torch.empty(Cc, device=x.device); db = torch.empty(Cc, device=x.device)
+    _check(_lib.lib().md2_bn_train_bwd(_dev(x), _dev(_f32(gamma)), _dev(dy), _dev(dx), _dev(dg), _dev(db), N, Cc, H, W, _stream()), None, "bn_bwd"); return dx, dg, db
+
+
+def maxpool3s2(x):
+    x = _f32(x); N, Cc, H, W = x.shape; y = torch.empty(N, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=x.device)
+    _check(_lib.lib().md2_maxpool3s2_fwd(_dev(x), _dev(y), N, Cc, H, W, _stream()), None, "maxpool_fwd"); return y
+
+
+def maxpool3s2_pullback(x, dy):
+    x, dy = _f32(x), _f32(dy); N, Cc, H, W = x.shape; dx = torch.empty_like(x)
+    _check(_lib.lib().md2_maxpool3s2_bwd(_dev(x), _dev(dy), _dev(dx), N, Cc, H, W, _stream()), None, "maxpool_bwd"); return dx
+
+
+def adam_raw(p, g, m, v, step, lr=1e-4, grad_scale=1.0):
+    _check(_lib.lib().md2_adam_raw(_dev(p), _dev(g), _dev(m), _dev(v), p.numel(), int(step), float(lr), float(grad_scale), _stream()), None, "adam_raw")

@@ -1,0 +1,121 @@
+"""Oracle (C++ restatement) vs the committed torch-derived golden fixtures and a live torch-CPU cross-check.
+Torch-derived, not Flux-derived: see tests/golden/make_golden.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import md2amd
+import oracle
+import torch_ref as tr
+
+syn = md2amd.synthetic
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+rng = np.random.default_rng(1)
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def grad_close(a, b, tol=1e-3, frac=0.02, cap=5e-2):
+    """fp32 vs fp64 gradients differ discretely where an arg-min / clamp / ReLU decision flips on a near-tie:
+    require (1 - frac) of the elements within tol of the max magnitude and every element within cap."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64); d = np.abs(a - b) / (np.abs(b).max() + 1e-30)
+    return (d > tol).sum() <= max(frac * d.size, 2) and d.max() < cap
+
+
+@pytest.mark.parametrize("name", ["loss_c1_64x96", "loss_c3_32x64"])
+def test_loss_half_vs_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    N, C, H, W = int(g["N"]), int(g["C"]), int(g["H"]), int(g["W"])
+    x = syn.synthetic_triplets(N, C, H, W, seed=int(g["seed"]))
+    K, iK = syn.depth10k_intrinsics(W, H)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK)
+    r = oracle.loss_fwd_bwd(x, cfg, [g["disp%d" % i] for i in range(4)], g["rvec"], g["tvec"])
+    assert abs(r["loss"] - float(g["loss"])) / float(g["loss"]) < 1e-5
+    for i in range(4):
+        assert grad_close(r["ddisp"][i], g["ddisp%d" % i])
+    assert rel(r["drvec"], g["drvec"]) < 2e-3 and rel(r["dtvec"], g["dtvec"]) < 2e-3
+
+
+@pytest.mark.parametrize("name", ["net_c1_64x96", "net_c3_64x96_automask"])
+def test_network_vs_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    N, C, H, W = int(g["N"]), int(g["C"]), int(g["H"]), int(g["W"])
+    theta = syn.init_params(C, seed=int(g["pseed"]), randomize_affine=True)
+    x = syn.synthetic_triplets(N, C, H, W, seed=int(g["xseed"]))
+    K, iK = syn.depth10k_intrinsics(W, H)
+    automask = bool(int(g["automask"]))
+    cfg = oracle.make_cfg(N, C, H, W, K, iK, automasking=automask)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    ds, rv, tv = net.model_forward(x, cfg)
+    for i in range(4):
+        assert rel(ds[i], g["disp%d" % i]) < 1e-4
+    assert rel(rv, g["rvec"]) < 1e-4 and rel(tv, g["tvec"]) < 1e-4
+    al = None
+    if automask:
+        al = oracle.automasking_loss(x, cfg)
+        assert rel(al, g["auto_loss"]) < 1e-3      # per-pixel fp32 SSIM (E[x^2]-mu^2 cancellation) vs the fp64 fixture
+    loss = net.train_loss(x, cfg, al, True)
+    assert abs(loss - float(g["loss"])) / float(g["loss"]) < 1e-4          # the north-star's forward+loss tolerance
+    grads = net.get_grads()
+    # gradients: fp32 vs fp64 differ at ReLU / arg-min flips (measured: torch fp32 vs fp64 shows the same ~1e-2), so norm-wise
+    off = 0; norms = []
+    for _, _, shape in syn.param_layout(C):
+        n = int(np.prod(shape)); norms.append(np.linalg.norm(grads[off:off + n])); off += n
+    norms = np.array(norms); gn = g["grad_norms"]
+    big = gn > 1e-3 * gn.max()
+    assert np.abs(norms[big] - gn[big]).max() / gn.max() < 2e-2
+    assert abs(np.linalg.norm(grads) - float(g["grad_norm_total"])) / float(g["grad_norm_total"]) < 1e-2
+
+
+def test_layers_vs_torch_live():
+    x = rng.standard_normal((2, 16, 9, 11)).astype(np.float32); w = rng.standard_normal((8, 16, 3, 3)).astype(np.float32) * 0.1; b = rng.standard_normal(8).astype(np.float32)
+    for stride, pad in ((1, 1), (2, 1), (1, 0)):
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True); wt = torch.tensor(w, dtype=torch.float64, requires_grad=True); bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+        y = tr.flux_conv(xt, wt, bt, stride, pad); gy = rng.standard_normal(y.shape).astype(np.float32); y.backward(torch.tensor(gy, dtype=torch.float64))
+        assert rel(oracle.conv2d_fwd(x, w, b, stride, pad), y.detach()) < 1e-5
+        dx, dw, db = oracle.conv2d_bwd(x, w, gy, stride, pad)
+        assert rel(dx, xt.grad) < 1e-5 and rel(dw, wt.grad) < 1e-5 and rel(db, bt.grad) < 1e-5
+    gam = rng.random(16).astype(np.float32) + 0.5; bet = rng.standard_normal(16).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True); gt = torch.tensor(gam, dtype=torch.float64, requires_grad=True)
+    y = tr.bn_train(xt, gt, torch.tensor(bet, dtype=torch.float64)); gy = rng.standard_normal(y.shape).astype(np.float32); y.backward(torch.tensor(gy, dtype=torch.float64))
+    assert rel(oracle.bn_train_fwd(x, gam, bet)[0], y.detach()) < 1e-5
+    dx, dg, db = oracle.bn_train_bwd(x, gam, gy)
+    assert rel(dx, xt.grad) < 1e-4 and rel(dg, gt.grad) < 1e-5
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.max_pool2d(xt, 3, 2, 1); gy = rng.standard_normal(y.shape).astype(np.float32); y.backward(torch.tensor(gy, dtype=torch.float64))
+    assert rel(oracle.maxpool3s2_fwd(x), y.detach()) == 0
+    assert rel(oracle.maxpool3s2_bwd(x, gy), xt.grad) < 1e-6
+
+
+def test_ops_vs_torch_live_f64():
+    N, C, H, W = 2, 3, 10, 12
+    x = rng.random((N, C, H, W)); y = rng.random((N, C, H, W))
+    xt = torch.tensor(x, requires_grad=True)
+    pl = tr.photometric_loss(xt, torch.tensor(y)); g = rng.random(pl.shape); pl.backward(torch.tensor(g))
+    assert rel(oracle.photometric_loss(x, y), pl.detach()) < 1e-12
+    assert rel(oracle.photometric_loss_bwd(x, y, g), xt.grad) < 1e-12
+    inp = rng.random((N, C, H, W)); grid = rng.random((N, H, W, 2)) * 2.4 - 1.2
+    for border in (True, False):
+        it = torch.tensor(inp, requires_grad=True); gt = torch.tensor(grid, requires_grad=True)
+        o = tr.grid_sample(it, gt, border); go = rng.random(o.shape); o.backward(torch.tensor(go))
+        dg, di = oracle.grid_sample_bwd(inp, grid, go, border)
+        assert rel(oracle.grid_sample(inp, grid, border), o.detach()) < 1e-12 and rel(dg, gt.grad) < 1e-12 and rel(di, it.grad) < 1e-12
+    xs = rng.random((N, C, 4, 6)); xt = torch.tensor(xs, requires_grad=True); o = tr.up_to(xt, 16, 24); go = rng.random(o.shape); o.backward(torch.tensor(go))
+    assert rel(oracle.upsample_bilinear(xs, 16, 24), o.detach()) < 1e-12 and rel(oracle.upsample_bilinear_bwd(go, 4, 6), xt.grad) < 1e-12
+
+
+def test_adam_vs_torch():
+    n = 1000; p = rng.standard_normal(n).astype(np.float32)
+    net = oracle.OracleNet(1)
+    theta = np.zeros(net.nparams, np.float32); theta[:n] = p; net.set_params(theta)
+    pt = torch.tensor(p.astype(np.float64)); m = torch.zeros(n, dtype=torch.float64); v = torch.zeros(n, dtype=torch.float64)
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32); gg = np.zeros(net.nparams, np.float32); gg[:n] = g
+        net.set_grads(gg); net.adam_step(1e-3)
+        tr.adam_step(pt, torch.tensor(g.astype(np.float64)), m, v, step, eta=1e-3)
+    assert rel(net.get_params()[:n], pt.numpy()) < 1e-5
