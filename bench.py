@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py — self-supervised training throughput (triplets/s) of the MI355X training step.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run with one
+rank per GPU (RCCL).  W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize, MAX over
+ranks, rank 0 prints ONE JSON line.  A step = forward + loss + backward + (all-reduce) + ADAM over one batch of synthetic
+416x128 triplets already resident in HBM (src/Monodepth.jl:156-176).  Weak scaling: every GPU gets `--batch` triplets
+(default 32 = BASELINE.json configs[2]'s per-GPU batch, so that N=1 and N=8 do the same per-GPU work; configs[1]'s
+batch-4 rate is measured as well at N=1 and reported under "extra").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def cpu_baseline(C, H, W, seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference algorithm — not Flux itself) timed on this box's host cores: one
+    triplet per step (B=1), 416x128, forward + loss + backward + ADAM; 1 warm-up + as many timed steps as fit the budget."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    import md2amd
+    syn = md2amd.synthetic
+    B = 1
+    theta = syn.init_params(C, seed=42)
+    x = syn.synthetic_triplets(B, C, H, W, seed=42)
+    K, iK = syn.depth10k_intrinsics(W, H)
+    cfg = oracle.make_cfg(B, C, H, W, K, iK)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    threads = oracle.num_threads()
+    t0 = time.time(); net.train_loss(x, cfg, None, True); net.adam_step(1e-4); warm = time.time() - t0
+    times = []
+    while sum(times) + warm < seconds_budget and len(times) < 5:
+        t0 = time.time(); net.train_loss(x, cfg, None, True); net.adam_step(1e-4); times.append(time.time() - t0)
+    if not times:
+        times = [warm]
+    med = sorted(times)[len(times) // 2]
+    return {"value": B / med, "unit": "triplets/s", "cores": int(threads), "kind": "port",
+            "sample": "B=1 triplet, %dx%d, C=%d, fwd+loss+bwd+ADAM, 1 warm-up + %d timed steps, median (CPU restatement of the reference algorithm, OpenMP, not Flux itself)" % (W, H, C, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="triplets per GPU per step")
+    ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=416)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import md2amd
+    md = md2amd.monodepth
+    par = md2amd.parallel
+    syn = md2amd.synthetic
+
+    rank, world, local = par.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local)
+    B, C, H, W = args.batch, args.channels, args.height, args.width
+
+    def setup(batch):
+        K, iK = syn.depth10k_intrinsics(W, H)
+        params = md.Params(target_size=(W, H), batch_size=batch, automasking=False)        # train(): automasking=false (src/Monodepth.jl:105)
+        cache = md.TrainCache(md.SSIM(), md.Backproject(W, H), md.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
+        enc = md.ResidualNetwork(18, in_channels=C)
+        model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(512), lr=1e-4)
+        model.load_params(syn.init_params(C, seed=42))                                      # same weights on every rank
+        base = syn.synthetic_triplets(min(batch, 8), C, H, W, seed=42 + rank)
+        x = torch.from_numpy(np.concatenate([base] * ((batch + len(base) - 1) // len(base)))[:batch].copy()).cuda()
+        return model, params, cache, x
+
+    model, params, cache, x = setup(B)
+    dp = par.DataParallel(model)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = dp.train_step(x, None, cache, params)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = dp.train_step(x, None, cache, params)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+    value = world * B * args.steps / dt
+
+    out = {"metric": "self-sup training imgs/sec, 416x128 ResNet-18 (1 img = 1 triplet: 3 frames through the encoder)", "value": value, "unit": "triplets/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "ResNet-18 depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, fp32 fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4 under extra)" % (W, H, C, B),
+                      "global_batch": world * B, "parallelism": "dp%d" % world, "loss": final_loss}}
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel class, measured live with HIP events on the launch stream (3 profiled steps)
+        md.profile(model, True)
+        for _ in range(3):
+            md.train_step(model, x, None, cache, params, do_update=True)
+        torch.cuda.synchronize()
+        ig, wg, lf, lb = (md.profile_get(model, c) for c in range(4))
+        md.profile(model, False)
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd + input-gradient implicit GEMMs, fp32 v_mfma_f32_16x16x4_f32)",
+                           "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                           "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1)}
+        extra = {}
+        if wg["ms"] > 0:
+            a = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
+            extra["roofline_conv_wgrad"] = {"bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TFLOPS, "ms_per_step": wg["ms"] / 3}
+        for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_bwd", lb)):
+            if p["ms"] > 0:
+                a = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+                extra[nm] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "ms_per_step": p["ms"] / 3,
+                             "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1)}
+        if world == 1 and not args.no_extra and B != 4:
+            # BASELINE.json configs[1]: batch = 4 on one MI355X
+            del dp, model
+            torch.cuda.empty_cache()
+            m4, p4, c4, x4 = setup(4)
+            for _ in range(5):
+                md.train_step(m4, x4, None, c4, p4, True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n4 = 20
+            for _ in range(n4):
+                md.train_step(m4, x4, None, c4, p4, True)
+            torch.cuda.synchronize(); d4 = time.perf_counter() - t0
+            extra["config1_batch4"] = {"value": 4 * n4 / d4, "unit": "triplets/s", "ms_per_step": d4 / n4 * 1e3}
+        out["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, H, W)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
