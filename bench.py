@@ -122,7 +122,7 @@ def main():
         ig, wg, lf, lb = (md.profile_get(model, c) for c in range(4))
         md.profile(model, False)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd + input-gradient implicit GEMMs, fp32 v_mfma_f32_16x16x4_f32)",
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<*> (fwd + input-gradient implicit GEMMs, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
                            "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1)}
         extra = {}

@@ -84,6 +84,9 @@ int32_t md2_profile_reset(md2_handle* h);
 /* classes: 0 conv_igemm (fwd+dgrad), 1 conv_wgrad, 2 loss_fwd, 3 loss_bwd, 4 other */
 int32_t md2_profile_get(md2_handle* h, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
 
+/* per-launch table of the profiled kernels (csv: class, ms, GFLOP, TFLOP/s, shape) */
+int32_t md2_profile_dump(md2_handle* h, const char* path);
+
 /* ---- op-level entry points (stateless; `stream` = hipStream_t or NULL), reference layout ------ */
 /* SSIM()(x, y), src/utils.jl:25-39.  [planes][H][W] */
 int32_t md2_ssim_fwd(const float* x, const float* y, float* out, int32_t planes, int32_t H, int32_t W, void* stream);

@@ -17,6 +17,7 @@
 //  * workgroup id remap so tiles that share the same pixel tile run on one XCD (shared L2).
 #include "md2_internal.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace md2 {
 
@@ -28,9 +29,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
 
-template <int BM, int BN, int WP, int WC>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BM, int BN, int WP, int WC, int MF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-    constexpr int TP = BM / WP / 16, TC = BN / WC / 16;
+    constexpr int TP = BM / WP / MF, TC = BN / WC / MF;       // MFMA tiles per wave (pixels x channels)
+    constexpr int NV = MF == 32 ? 4 : 1;                       // float4 groups per accumulator tile
     constexpr int A_LD = BM * 4 / 256;
     constexpr int B_LD = (BN * 4 + 255) / 256;
     static_assert(WP * WC == 4 && TP >= 1 && TC >= 1 && A_LD >= 1, "bad tile");
@@ -44,34 +48,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_c = bid % ntc, tile_p = bid / ntc;
     const int m0 = tile_p * BM, c0 = tile_c * BN;
-    const int HoWo = a.Ho * a.Wo;
+    const int HlWl = a.Hl * a.Wl;
     const int Ktot = a.KH * a.KW * a.Cin;
     const int q = tid & 3;
 
-    long a_base[A_LD]; int a_ih[A_LD], a_iw[A_LD]; bool a_ok[A_LD];
+    // per-row (output pixel) constants of this thread's A_LD gather rows
+    unsigned a_base[A_LD]; int a_ih[A_LD], a_iw[A_LD]; bool a_ok[A_LD];
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-        const int row = (tid + 256 * j) >> 2;
-        const int m = m0 + row;
+        const int m = m0 + ((tid + 256 * j) >> 2);
         a_ok[j] = m < a.M;
         const int mm = a_ok[j] ? m : 0;
-        const int n = mm / HoWo, r = mm - n * HoWo, oh = r / a.Wo, ow = r - oh * a.Wo;
-        a_base[j] = (long)n * a.x_bs;
-        a_ih[j] = oh * a.stride - a.pad;
-        a_iw[j] = ow * a.stride - a.pad;
+        const int n = mm / HlWl, r = mm - n * HlWl, li = r / a.Wl, lj = r - li * a.Wl;
+        a_base[j] = (unsigned)((long)n * a.x_bs) + q * 4;
+        a_ih[j] = (a.oy0 + li * a.ostep) * a.stride - a.pad;
+        a_iw[j] = (a.ox0 + lj * a.ostep) * a.stride - a.pad;
     }
+    // weights: row (c0 + f>>2), k runs linearly when the tap lattice is dense; per-tap base otherwise
+    unsigned b_row[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) b_row[j] = (unsigned)((c0 + (((tid + 256 * j) >> 2) & (BN - 1))) * Ktot) + q * 4;
 
-    f32x4 acc[TC][TP];
+    using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
+    acc_t acc[TC][TP];
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int j = 0; j < TP; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int e = 0; e < 4 * NV; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[A_LD], rb[B_LD];
+    unsigned a_off[A_LD], a_msk[A_LD]; unsigned b_tap = 0;
     const int cpt = a.Cin >> 4;                 // 16-channel chunks per tap
-    const int nsteps = a.KH * a.KW * cpt;
+    const int ntaps = a.nkh * a.nkw;
 
-    auto gload = [&](int kh, int kw, int ci0) {
+    // VALU-heavy part, once per filter tap: input pixel of every gather row for tap (ikh, ikw) of the tap lattice
+    auto tap_setup = [&](int ikh, int ikw) {
+        const int kh = a.kh0 + ikh * a.khs, kw = a.kw0 + ikw * a.kws;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             int th = a_ih[j] + kh, tw = a_iw[j] + kw;
@@ -82,107 +96,186 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             }
             if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
             else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
-            ra[j] = ok ? *reinterpret_cast<const float4*>(a.x + a_base[j] + ((long)th * a.W + tw) * a.x_ps + ci0 + q * 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            a_msk[j] = ok ? 0xFFFFFFFFu : 0u;
+            a_off[j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) : (unsigned)(q * 4);    // masked rows read a valid dummy address
         }
-        const int k0 = (kh * a.KW + kw) * a.Cin + ci0;
+        b_tap = (unsigned)((kh * a.KW + kw) * a.Cin);
+    };
+    // branch-free: every lane loads; masked rows are zeroed with an integer AND (keeps the steady-state loop one basic block,
+    // so the scheduler can interleave these loads and the LDS stores with the MFMAs)
+    auto gload = [&](int ci0) {
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            const int f = tid + 256 * j;
-            if (f < BN * 4) rb[j] = *reinterpret_cast<const float4*>(a.w + (long)(c0 + (f >> 2)) * Ktot + k0 + q * 4);
+        for (int j = 0; j < A_LD; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.x + a_off[j] + ci0);
+            const unsigned mk = a_msk[j];
+            ra[j] = make_float4(__uint_as_float(v.x & mk), __uint_as_float(v.y & mk), __uint_as_float(v.z & mk), __uint_as_float(v.w & mk));
         }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const float4*>(a.w + b_row[j] + b_tap + ci0);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4*>(Xs + buf * BM * LDK + ((tid + 256 * j) >> 2) * LDK + q * 4) = ra[j];
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-            const int f = tid + 256 * j;
-            if (f < BN * 4) *reinterpret_cast<float4*>(Ws + buf * BN * LDK + (f >> 2) * LDK + q * 4) = rb[j];
-        }
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(Ws + buf * BN * LDK + (((tid + 256 * j) >> 2) & (BN - 1)) * LDK + q * 4) = rb[j];   // BN < 64: duplicate rows, same data
     };
-
-    int kh = 0, kw = 0, cib = 0;
-    gload(0, 0, 0);
-    lstore(0);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        if (++cib == cpt) { cib = 0; if (++kw == a.KW) { kw = 0; ++kh; } }
-        if (s + 1 < nsteps) gload(kh, kw, cib << 4);
-        f32x4 wf[TC], xf[TP];
+    auto compute = [&](int buf) {
+        if constexpr (MF == 16) {
+            // 16x16x4: lane (row l&15, k-quad l>>4); MFMA r contracts k in {r, 4+r, 8+r, 12+r}
+            f32x4 wf[TC], xf[TP];
 #pragma unroll
-        for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const f32x4*>(Ws + buf * BN * LDK + (wc * (BN / WC) + i * 16 + (lane & 15)) * LDK + 4 * (lane >> 4));
+            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const f32x4*>(Ws + buf * BN * LDK + (wc * (BN / WC) + i * 16 + (lane & 15)) * LDK + 4 * (lane >> 4));
 #pragma unroll
-        for (int j = 0; j < TP; ++j) xf[j] = *reinterpret_cast<const f32x4*>(Xs + buf * BM * LDK + (wp * (BM / WP) + j * 16 + (lane & 15)) * LDK + 4 * (lane >> 4));
+            for (int j = 0; j < TP; ++j) xf[j] = *reinterpret_cast<const f32x4*>(Xs + buf * BM * LDK + (wp * (BM / WP) + j * 16 + (lane & 15)) * LDK + 4 * (lane >> 4));
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][r], xf[j][r], acc[i][j], 0, 0, 0);
+        } else {
+            // 32x32x2 (155 TF bare vs 140 for 16x16x4, full rate at one wave per SIMD): lane (row l&31, k-half l>>5);
+            // two ds_read_b128 per 32-row tile cover k = 8*jj + 4*h .. +3; MFMA (jj,r) contracts k in {8jj + r, 8jj + 4 + r}
+            f32x4 wf[TC][2], xf[TP][2];
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][r], xf[j][r], acc[i][j], 0, 0, 0);
-        if (s + 1 < nsteps) lstore(buf ^ 1);
+                for (int jj = 0; jj < 2; ++jj) wf[i][jj] = *reinterpret_cast<const f32x4*>(Ws + buf * BN * LDK + (wc * (BN / WC) + i * 32 + (lane & 31)) * LDK + 8 * jj + 4 * (lane >> 5));
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) xf[j][jj] = *reinterpret_cast<const f32x4*>(Xs + buf * BM * LDK + (wp * (BM / WP) + j * 32 + (lane & 31)) * LDK + 8 * jj + 4 * (lane >> 5));
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < TC; ++i)
+#pragma unroll
+                        for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][jj][r], xf[j][jj][r], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    int ikh = 0, ikw = 0, buf = 0;
+    tap_setup(0, 0);
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < ntaps; ++t) {
+        for (int c = 1; c < cpt; ++c) {          // steady state: prefetch the next chunk of the same tap
+            gload(c << 4);
+            compute(buf);
+            lstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        const bool more = t + 1 < ntaps;         // last chunk of the tap: prefetch chunk 0 of the next tap
+        if (more) { if (++ikw == a.nkw) { ikw = 0; ++ikh; } tap_setup(ikh, ikw); gload(0); }
+        compute(buf);
+        if (more) lstore(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
 
-    // epilogue: lane holds channels co..co+3 of pixel m for every (tc,tp)
+    // epilogue: every (tile, register group) is 4 consecutive channels of one pixel -> one 16-B NHWC store
+    //   16x16x4: D col = lane&15 (pixel), row = 4*(lane>>4) + e (channel)
+    //   32x32x2: D col = lane&31 (pixel), row = 8*g + 4*(lane>>5) + e, register 4g+e
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-        const int m = m0 + wp * (BM / WP) + j * 16 + (lane & 15);
+        const int m = m0 + wp * (BM / WP) + j * MF + (lane & (MF - 1));
         if (m >= a.M) continue;
-        const int n = m / HoWo, r = m - n * HoWo;
-        float* yp = a.y + (long)n * a.y_bs + (long)r * a.y_ps;
-        const float* dp = a.dact_src ? a.dact_src + (long)n * a.da_bs + (long)r * a.da_ps : nullptr;
+        const int n = m / HlWl, r = m - n * HlWl, li = r / a.Wl, lj = r - li * a.Wl;
+        const long pix = (long)(a.oy0 + li * a.ostep) * a.Wo + (a.ox0 + lj * a.ostep);
+        float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps;
+        const float* dp = a.dact_src ? a.dact_src + (long)n * a.da_bs + pix * a.da_ps : nullptr;
 #pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            const int co = c0 + wc * (BN / WC) + i * 16 + 4 * (lane >> 4);
-            f32x4 v = acc[i][j];
-            if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + co); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-            if (a.act != ACT_NONE) {
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+            for (int g = 0; g < NV; ++g) {
+                const int co = c0 + wc * (BN / WC) + i * MF + (MF == 32 ? 8 * g + 4 * (lane >> 5) : 4 * (lane >> 4));
+                float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + co); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (a.act != ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+                }
+                if (dp) {
+                    const float4 d = *reinterpret_cast<const float4*>(dp + co);
+                    v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact);
+                }
+                if (a.accumulate) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
             }
-            if (dp) {
-                const float4 d = *reinterpret_cast<const float4*>(dp + co);
-                v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact);
-            }
-            if (a.accumulate) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-            *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
-        }
     }
 }
 
-template <int BM, int BN, int WP, int WC>
+template <int BM, int BN, int WP, int WC, int MF>
 static void launch_tile(const ConvArgs& a, hipStream_t s) {
+    static_assert((BM / WP) % MF == 0 && (BN / WC) % MF == 0, "wave tile must be a multiple of the MFMA tile");
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF>), dim3(grid), dim3(256), 0, s, a);
 }
 
-double conv_igemm_flops(const ConvArgs& a) { return 2.0 * (double)a.M * a.Cout * a.KH * a.KW * a.Cin; }
+double conv_igemm_flops(const ConvArgs& a) {       // algorithmic: taps that can be non-zero
+    const double taps = a.dil > 1 && a.ostep == 1 ? (double)a.KH * a.KW / ((double)a.dil * a.dil) : (double)a.nkh * a.nkw;
+    return 2.0 * (double)a.M * a.Cout * taps * a.Cin;
+}
 
+static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s);
+
+// Input-gradient of a strided convolution (dil = forward stride): an output pixel of residue class (ph,pw) mod dil only
+// sees the taps kh = (pad - ph) mod dil (+ multiples of dil), so the problem splits into dil^2 dense sub-convolutions on
+// output/tap lattices with no multiply-by-zero work (k=3, s=2: 1+2+2+4 = 9 taps over 4 quarter-size launches).
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+    if (a.dil <= 1 || a.ostep != 1) { launch_conv_igemm_one(a, s); return; }
+    for (int ph = 0; ph < a.dil; ++ph)
+        for (int pw = 0; pw < a.dil; ++pw) {
+            ConvArgs b = a;
+            b.oy0 = ph; b.ox0 = pw; b.ostep = a.dil;
+            b.Hl = (a.Ho - ph + a.dil - 1) / a.dil; b.Wl = (a.Wo - pw + a.dil - 1) / a.dil;
+            b.kh0 = ((a.pad - ph) % a.dil + a.dil) % a.dil; b.khs = a.dil; b.nkh = b.kh0 < a.KH ? (a.KH - 1 - b.kh0) / a.dil + 1 : 0;
+            b.kw0 = ((a.pad - pw) % a.dil + a.dil) % a.dil; b.kws = a.dil; b.nkw = b.kw0 < a.KW ? (a.KW - 1 - b.kw0) / a.dil + 1 : 0;
+            b.M = a.N * b.Hl * b.Wl;
+            if (b.M <= 0) continue;
+            if (b.nkh == 0 || b.nkw == 0) {
+                if (!a.accumulate) { fprintf(stderr, "md2: conv_igemm: empty tap phase needs accumulate or a zeroed output\n"); abort(); }
+                continue;                                     // nothing to add for this residue class
+            }
+            launch_conv_igemm_one(b, s);
+        }
+}
+
+static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s) {
     // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
-    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0)) {
+    const long x_elems = (long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps, w_elems = (long)a.Cout * a.KH * a.KW * a.Cin;
+    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) ||
+        a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) || w_elems >= (1L << 32)) {
         fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
         abort();
     }
     const long tiles128 = (long)((a.M + 127) / 128);
-    if (a.Cout % 128 == 0 && tiles128 * (a.Cout / 128) >= 512) launch_tile<128, 128, 2, 2>(a, s);
-    else if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= 384) launch_tile<128, 64, 2, 2>(a, s); else launch_tile<64, 64, 2, 2>(a, s); }
-    else if (a.Cout % 32 == 0) { if (tiles128 >= 384) launch_tile<128, 32, 4, 1>(a, s); else launch_tile<64, 32, 2, 2>(a, s); }
-    else { if (tiles128 >= 384) launch_tile<128, 16, 4, 1>(a, s); else launch_tile<64, 16, 4, 1>(a, s); }
+    if (a.Cout % 128 == 0 && tiles128 * (a.Cout / 128) >= 512) launch_tile<128, 128, 2, 2, 32>(a, s);
+    else if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= 384) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
+    else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
+    else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------------------
-template <int T, int BKP>
+template <int T, int BKP, int MF>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {
-    constexpr int LD = (T == 16) ? 16 : T + 16;          // LD % 32 == 16 -> the two 16-lane halves of a ds_read_b32 group hit disjoint banks
-    constexpr int TW = (T == 64) ? 2 : 1;                // 16x16 MFMA tiles per wave per dim
+    // LDS tiles [pixel][channel]: A operand lane (row = channel, k = pixel) reads consecutive channels of one pixel row.
+    // 32x32x2: the two 32-lane halves are separate ds_read_b32 groups -> conflict-free for any row length.
+    // 16x16x4: 4 pixel rows per instruction, LD % 32 == 16 keeps the two 16-lane halves of a group on disjoint banks.
+    constexpr int LD = (MF == 32) ? T : ((T == 16) ? 16 : T + 16);
     constexpr int LPP = T / 4;                           // float4 lanes per pixel row
-    static_assert(BKP * T == 1024, "one float4 per thread per operand per step");
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKP * LD + ((T == 16) ? 4 * 256 : 0)];
+    constexpr int NLD = BKP * LPP / 256;                 // float4 loads per thread per operand per step
+    static_assert((BKP * LPP) % 256 == 0 && NLD >= 1, "bad wgrad tile");
+    constexpr bool KSPLIT = (T == 16);                   // the 4 waves split the pixels of a step instead of the tile
+    constexpr int TW = KSPLIT ? 1 : T / 2 / MF;          // MFMA tiles per wave per dim
+    constexpr int NV = MF == 32 ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKP * LD + (KSPLIT ? 4 * 256 : 0)];
     float* Ds = smem;
     float* Xs = smem + 2 * BKP * LD;
 
@@ -196,65 +289,100 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
     const int s_end = min(s_begin + steps_per_split, steps_total);
     if (s_begin >= s_end) return;
 
-    const int lk = tid / LPP, lc = (tid % LPP) * 4;      // this thread's pixel-in-chunk and channel quad
-    float4 rd, rx;
+    const float rcp_hw = 1.f / (float)HoWo, rcp_w = 1.f / (float)a.Wo;
+    // exact floor(m / d) for 0 <= m < 2^24 from the float reciprocal (+-1 correction): integer division costs ~40 VALU ops, this ~8
+    auto fdiv = [](int m, int d, float rcp) { int qq = (int)((float)m * rcp); const int r = m - qq * d; qq += (r >= d) ? 1 : 0; qq -= (r < 0) ? 1 : 0; return qq; };
+    float4 rd[NLD], rx[NLD];
     auto gload = [&](int step) {
-        const int m = step * BKP + lk;
-        rd = make_float4(0.f, 0.f, 0.f, 0.f); rx = rd;
-        if (m < a.M) {
-            const int n = m / HoWo, r = m - n * HoWo, oh = r / a.Wo, ow = r - oh * a.Wo;
-            rd = *reinterpret_cast<const float4*>(a.dy + (long)n * a.dy_bs + (long)r * a.dy_ps + c0 + lc);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int f = tid + 256 * j, lk = f / LPP, lc = (f % LPP) * 4;
+            const int m = step * BKP + lk;
+            const bool in = m < a.M;
+            const int mm = in ? m : 0;
+            const int n = fdiv(mm, HoWo, rcp_hw), r = mm - n * HoWo, oh = fdiv(r, a.Wo, rcp_w), ow = r - oh * a.Wo;
             int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
-            bool ok = true;
+            bool ok = in;
             if (a.padmode == PAD_REFLECT) { ih = refl_idx(ih, a.H); iw = refl_idx(iw, a.W); }
-            else ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            if (ok) rx = *reinterpret_cast<const float4*>(a.x + (long)n * a.x_bs + ((long)ih * a.W + iw) * a.x_ps + i0 + lc);
+            else { ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W; ih = ok ? ih : 0; iw = ok ? iw : 0; }
+            const uint4 vd = *reinterpret_cast<const uint4*>(a.dy + (long)n * a.dy_bs + (long)r * a.dy_ps + c0 + lc);
+            const uint4 vx = *reinterpret_cast<const uint4*>(a.x + (long)n * a.x_bs + ((long)ih * a.W + iw) * a.x_ps + i0 + lc);
+            const unsigned md = in ? 0xFFFFFFFFu : 0u, mx = ok ? 0xFFFFFFFFu : 0u;       // integer masks keep the loop branch-free
+            rd[j] = make_float4(__uint_as_float(vd.x & md), __uint_as_float(vd.y & md), __uint_as_float(vd.z & md), __uint_as_float(vd.w & md));
+            rx[j] = make_float4(__uint_as_float(vx.x & mx), __uint_as_float(vx.y & mx), __uint_as_float(vx.z & mx), __uint_as_float(vx.w & mx));
         }
     };
     auto lstore = [&](int buf) {
-        *reinterpret_cast<float4*>(Ds + buf * BKP * LD + lk * LD + lc) = rd;
-        *reinterpret_cast<float4*>(Xs + buf * BKP * LD + lk * LD + lc) = rx;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int f = tid + 256 * j, lk = f / LPP, lc = (f % LPP) * 4;
+            *reinterpret_cast<float4*>(Ds + buf * BKP * LD + lk * LD + lc) = rd[j];
+            *reinterpret_cast<float4*>(Xs + buf * BKP * LD + lk * LD + lc) = rx[j];
+        }
     };
 
-    f32x4 acc[TW][TW];
+    using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
+    acc_t acc[TW][TW];
 #pragma unroll
     for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < TW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4 * NV; ++e) acc[i][j][e] = 0.f;
 
-    // wave -> sub-tile / k-slice
-    const int wr = (T == 16) ? 0 : (wave & 1), wq = (T == 16) ? 0 : (wave >> 1);
-    constexpr int KQ = (T == 16) ? BKP / 16 : BKP / 4;   // k-quads this wave walks per step
-    const int kq0 = (T == 16) ? wave * KQ : 0;
-
+    const int wr = KSPLIT ? 0 : (wave & 1), wq = KSPLIT ? 0 : (wave >> 1);
+    auto compute = [&](int buf) {
+        const float* D = Ds + buf * BKP * LD;
+        const float* X = Xs + buf * BKP * LD;
+        if constexpr (MF == 32) {
+#pragma unroll
+            for (int kk = 0; kk < BKP / 2; ++kk) {
+                const int k = 2 * kk + (lane >> 5);
+                float af[TW], bf[TW];
+#pragma unroll
+                for (int i = 0; i < TW; ++i) af[i] = D[k * LD + wr * (T / 2) + i * 32 + (lane & 31)];
+#pragma unroll
+                for (int j = 0; j < TW; ++j) bf[j] = X[k * LD + wq * (T / 2) + j * 32 + (lane & 31)];
+#pragma unroll
+                for (int i = 0; i < TW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            constexpr int KQ = KSPLIT ? BKP / 16 : BKP / 4;   // k-quads this wave walks per step
+            const int kq0 = KSPLIT ? wave * KQ : 0;
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) {
+                const int k = (kq0 + kk) * 4 + (lane >> 4);
+                float af[TW], bf[TW];
+#pragma unroll
+                for (int i = 0; i < TW; ++i) af[i] = D[k * LD + wr * (T / 2) + i * 16 + (lane & 15)];
+#pragma unroll
+                for (int j = 0; j < TW; ++j) bf[j] = X[k * LD + wq * (T / 2) + j * 16 + (lane & 15)];
+#pragma unroll
+                for (int i = 0; i < TW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
     gload(s_begin);
     lstore(0);
     __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        if (s + 1 < s_end) gload(s + 1);
-        const float* D = Ds + buf * BKP * LD;
-        const float* X = Xs + buf * BKP * LD;
-#pragma unroll
-        for (int kk = 0; kk < KQ; ++kk) {
-            const int k = (kq0 + kk) * 4 + (lane >> 4);
-            float af[TW], bf[TW];
-#pragma unroll
-            for (int i = 0; i < TW; ++i) af[i] = D[k * LD + wr * 16 * TW + i * 16 + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < TW; ++j) bf[j] = X[k * LD + wq * 16 * TW + j * 16 + (lane & 15)];
-#pragma unroll
-            for (int i = 0; i < TW; ++i)
-#pragma unroll
-                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (s + 1 < s_end) lstore(buf ^ 1);
+    int buf = 0;
+    for (int s = s_begin + 1; s < s_end; ++s) {      // steady state (branch-free body): prefetch step s while computing step s-1
+        gload(s);
+        compute(buf);
+        lstore(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
+    compute(buf);
 
     const int taps = a.KH * a.KW;
-    if (T == 16) {
+    if (KSPLIT) {
         float* red = smem + 2 * 2 * BKP * LD;
+        __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[wave * 256 + e * 64 + lane] = acc[0][0][e];
         __syncthreads();
@@ -272,14 +400,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
 #pragma unroll
             for (int j = 0; j < TW; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int co = c0 + wr * 16 * TW + i * 16 + 4 * (lane >> 4) + e, ci = i0 + wq * 16 * TW + j * 16 + (lane & 15);
-                    atomicAdd(a.dw + ((long)co * taps + tap) * a.Cin + ci, acc[i][j][e]);
-                }
+                for (int g = 0; g < NV; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = c0 + wr * (T / 2) + i * MF + (MF == 32 ? 8 * g + 4 * (lane >> 5) : 4 * (lane >> 4)) + e;
+                        const int ci = i0 + wq * (T / 2) + j * MF + (lane & (MF - 1));
+                        atomicAdd(a.dw + ((long)co * taps + tap) * a.Cin + ci, acc[i][j][4 * g + e]);
+                    }
     }
 }
 
-template <int T, int BKP>
+template <int T, int BKP, int MF>
 static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     const int tiles = (a.Cout / T) * (a.Cin / T), taps = a.KH * a.KW;
     const int steps_total = (a.M + BKP - 1) / BKP;
@@ -288,17 +419,18 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     splitk = std::max(1, std::min(splitk, (steps_total + 7) / 8));
     const int sps = (steps_total + splitk - 1) / splitk;
     splitk = (steps_total + sps - 1) / sps;
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP>), dim3(tiles, taps, splitk), dim3(256), 0, s, a, sps, steps_total);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF>), dim3(tiles, taps, splitk), dim3(256), 0, s, a, sps, steps_total);
 }
 
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
-    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || a.M <= 0) {
-        fprintf(stderr, "md2: conv_wgrad: unsupported shape Cin=%d Cout=%d\n", a.Cin, a.Cout);
+    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || a.M <= 0 || a.M >= (1 << 24)) {
+        fprintf(stderr, "md2: conv_wgrad: unsupported shape Cin=%d Cout=%d M=%d\n", a.Cin, a.Cout, a.M);
         abort();
     }
-    if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 16>(a, s);
-    else if (a.Cin % 32 == 0 && a.Cout % 32 == 0) launch_wgrad_tile<32, 32>(a, s);
-    else launch_wgrad_tile<16, 64>(a, s);
+    if (a.Cin % 128 == 0 && a.Cout % 128 == 0) launch_wgrad_tile<128, 16, 32>(a, s);
+    else if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 32, 32>(a, s);
+    else if (a.Cin % 32 == 0 && a.Cout % 32 == 0) launch_wgrad_tile<32, 32, 16>(a, s);
+    else launch_wgrad_tile<16, 64, 16>(a, s);
 }
 
 // w_dg[ci][taps-1-t][co] = w_fwd[co][t][ci]

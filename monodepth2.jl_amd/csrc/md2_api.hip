@@ -31,7 +31,7 @@ struct ConvL {
 };
 struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; float* stats = nullptr; double* acc = nullptr; double* acc_b = nullptr; };
 struct Block { ConvL c1, c2, cd; BNL b1, b2, bd; bool down = false; int stride = 1; View in, z1, a1, z2, zd, sd, out; };
-struct ProfEvt { hipEvent_t a, b; int cls; };
+struct ProfEvt { hipEvent_t a, b; int cls; double flops; char desc[112]; };
 enum { CLS_IGEMM = 0, CLS_WGRAD = 1, CLS_LOSS_FWD = 2, CLS_LOSS_BWD = 3, CLS_OTHER = 4 };
 
 }  // namespace
@@ -69,7 +69,7 @@ struct md2_handle {
         return p;
     }
     View alloc_view(int n, int hh, int ww, int c) { return make_view(alloc<float>((size_t)n * hh * ww * c), n, hh, ww, c); }
-    void pbegin(int cls) { if (prof) { ProfEvt e; e.cls = cls; (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, stream); evts.push_back(e); } }
+    void pbegin(int cls, double flops = 0, const char* desc = "") { if (prof) { ProfEvt e; e.cls = cls; e.flops = flops; snprintf(e.desc, sizeof(e.desc), "%s", desc); (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, stream); evts.push_back(e); } }
     void pend() { if (prof) (void)hipEventRecord(evts.back().b, stream); }
 };
 
@@ -215,10 +215,13 @@ static ConvArgs conv_args(const View& x, const float* w, const View& y, int KH, 
     a.N = y.N; a.KH = KH; a.KW = KH; a.stride = stride; a.pad = pad; a.dil = dil; a.padmode = padmode;
     a.bias = nullptr; a.act = ACT_NONE; a.accumulate = 0; a.dact_src = nullptr; a.da_bs = 0; a.da_ps = 0; a.dact = ACT_NONE;
     a.M = y.N * y.H * y.W;
+    a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = y.H; a.Wl = y.W; a.kh0 = 0; a.khs = 1; a.nkh = KH; a.kw0 = 0; a.kws = 1; a.nkw = KH;
     return a;
 }
 static void run_igemm(md2_handle* h, const ConvArgs& a) {
-    h->pbegin(CLS_IGEMM); launch_conv_igemm(a, h->stream); h->pend();
+    char d[112] = "";
+    if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W);
+    h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->stream); h->pend();
     if (h->prof) h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a);
 }
 // forward conv (kind 0) on views.  x.C must equal c.cinP, y.C == c.coutP
@@ -240,7 +243,9 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     a.dy = dy.p; a.dy_bs = dy.bs; a.dy_ps = dy.ps; a.Ho = dy.H; a.Wo = dy.W; a.Cout = dy.C;
     a.dw = h->G + c.w; a.N = dy.N; a.KH = c.kind == 1 ? 1 : c.k; a.KW = a.KH; a.stride = c.kind == 1 ? 1 : c.stride; a.pad = c.kind == 1 ? 0 : (padmode == PAD_REFLECT ? 1 : c.pad); a.padmode = padmode;
     a.M = dy.N * dy.H * dy.W;
-    h->pbegin(CLS_WGRAD); launch_conv_wgrad(a, h->stream); h->pend();
+    char d[112] = "";
+    if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode);
+    h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d); launch_conv_wgrad(a, h->stream); h->pend();
     if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
     if (c.bias) launch_colsum(dy, h->G + c.b, h->stream);
 }
@@ -578,6 +583,14 @@ int32_t md2_profile_get(md2_handle* h, int32_t cls, double* total_ms, int64_t* l
     return 0;
 }
 
+int32_t md2_profile_dump(md2_handle* h, const char* path) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    FILE* f = fopen(path, "w"); if (!f) { h->err = "md2_profile_dump: cannot open file"; return 2; }
+    fprintf(f, "cls,ms,gflop,tflops,desc\n");
+    for (auto& e : h->evts) { float ms = 0; (void)hipEventElapsedTime(&ms, e.a, e.b); fprintf(f, "%d,%.5f,%.4f,%.2f,%s\n", e.cls, ms, e.flops * 1e-9, ms > 0 ? e.flops / (ms * 1e-3) * 1e-12 : 0.0, e.desc); }
+    fclose(f); return 0;
+}
+
 // ---- op-level layer entry points (NCHW in / out; converted to NHWC views in temporaries) ----------------------------------
 static float* tmp_alloc(size_t n, hipStream_t s) { float* p = nullptr; if (hipMallocAsync((void**)&p, n * sizeof(float), s) != hipSuccess) return nullptr; (void)hipMemsetAsync(p, 0, n * sizeof(float), s); return p; }
 static int pad16(int c) { return (c + 15) / 16 * 16; }
@@ -628,6 +641,7 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         float* dxi = tmp_alloc((size_t)N * Hp * Wp * cinP, s); if (!dxi) return 3;
         View dxp = make_view(dxi, N, Hp, Wp, cinP);
         ConvArgs a = conv_args(dyv, wd, dxp, k, 1, k - 1 - (pad_mode == PAD_REFLECT ? 0 : pad), stride, PAD_ZERO);
+        a.accumulate = 1;                                   // dxi is zero-initialised; strided pullbacks may have tap-free residue classes
         launch_conv_igemm(a, s);
         if (pad_mode == PAD_REFLECT) {
             float* dxf = tmp_alloc((size_t)N * H * W * cinP, s); if (!dxf) return 3;

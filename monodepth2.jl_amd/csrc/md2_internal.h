@@ -53,7 +53,11 @@ struct ConvArgs {
     int N, KH, KW, stride, pad, dil, padmode;
     const float* bias; int act; int accumulate;
     const float* dact_src; long da_bs; int da_ps; int dact;   // optional: multiply by act_deriv(dact_src[n,oh,ow,co])
-    int M;                                                    // N*Ho*Wo
+    int M;                                                    // N*Hl*Wl
+    // output lattice: this launch produces pixels (oy0 + i*ostep, ox0 + j*ostep), i < Hl, j < Wl (dense: 0,0,1,Ho,Wo)
+    int oy0, ox0, ostep, Hl, Wl;
+    // tap lattice: taps kh = kh0 + a*khs (a < nkh), kw = kw0 + b*kws (b < nkw)   (dense: 0,1,KH / 0,1,KW)
+    int kh0, khs, nkh, kw0, kws, nkw;
 };
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 double conv_igemm_flops(const ConvArgs& a);

@@ -407,6 +407,10 @@ def profile(model: Model, on=True):
         _check(_lib.lib().md2_profile_reset(model._h), model._h)
 
 
+def profile_dump(model: Model, path):
+    _check(_lib.lib().md2_profile_dump(model._h, str(path).encode()), model._h)
+
+
 def profile_get(model: Model, cls):
     ms = C.c_double(); n = C.c_int64(); fl = C.c_double(); by = C.c_double()
     _check(_lib.lib().md2_profile_get(model._h, cls, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), model._h)

@@ -187,3 +187,28 @@ def test_full_size_properties(B):
         lg, _, _, _ = md().loss_fwd_bwd(m1, x1, [d[:1].contiguous() for d in ds], torch.stack([poses[0].rvec[:1], poses[1].rvec[:1]]).contiguous(),
                                         torch.stack([poses[0].tvec[:1], poses[1].tvec[:1]]).contiguous(), want_grads=False)
         assert abs(float(lg) - r["loss"]) / r["loss"] < 1e-5
+
+
+def test_rccl_allreduce_on_library_gradient_buffer():
+    """The DP exchange on the real transport: torch.distributed 'nccl' (= RCCL) all-reduce of the library's flat gradient
+    buffer wrapped without a copy.  One GPU per box here, so world_size = 1; ranks > 1 are covered by the gloo test."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    N, C, H, W = 1, 1, 64, 96
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=4)
+    xd = dev(syn.synthetic_triplets(N, C, H, W, seed=3))
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        dp = md2amd.parallel.DataParallel(model)
+        md().train_step(model, xd, None, cache, params, do_update=False)
+        g0 = model.grads()
+        buf = model.grad_buffer()
+        assert buf.is_cuda and buf.numel() >= g0.size
+        dist.all_reduce(buf)                                        # sum over 1 rank: unchanged
+        torch.cuda.synchronize()
+        assert np.array_equal(model.grads(), g0)
+        loss = dp.train_step(xd, None, cache, params)               # fwd+bwd -> all-reduce -> ADAM(1/world)
+        assert np.isfinite(float(loss)) and not np.array_equal(model.params(), theta)
+    finally:
+        dist.destroy_process_group()
