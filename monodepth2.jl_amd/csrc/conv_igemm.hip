@@ -18,6 +18,7 @@
 #include "md2_internal.h"
 #include <algorithm>
 #include <type_traits>
+#include <cstdlib>
 
 namespace md2 {
 
@@ -31,16 +32,15 @@ constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int WP, int WC, int MF>
+template <int BM, int BN, int WP, int WC, int MF, int NT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int TP = BM / WP / MF, TC = BN / WC / MF;       // MFMA tiles per wave (pixels x channels)
     constexpr int NV = MF == 32 ? 4 : 1;                       // float4 groups per accumulator tile
     constexpr int A_LD = BM * 4 / 256;
     constexpr int B_LD = (BN * 4 + 255) / 256;
     static_assert(WP * WC == 4 && TP >= 1 && TC >= 1 && A_LD >= 1, "bad tile");
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
-    float* Xs = smem;
-    float* Ws = smem + 2 * BM * LDK;
+    constexpr int XS = BM * LDK, STAGE = (BM + BN) * LDK;      // floats: pixel tile, then weight tile, per pipeline stage
+    __shared__ __attribute__((aligned(16))) float smem[3 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave % WP, wc = wave / WP;
@@ -60,14 +60,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         a_ok[j] = m < a.M;
         const int mm = a_ok[j] ? m : 0;
         const int n = mm / HlWl, r = mm - n * HlWl, li = r / a.Wl, lj = r - li * a.Wl;
-        a_base[j] = (unsigned)((long)n * a.x_bs) + q * 4;
+        a_base[j] = ((unsigned)((long)n * a.x_bs) + q * 4) * 4u;      // BYTE offsets: one VGPR per address (SGPR base + 32-bit offset)
         a_ih[j] = (a.oy0 + li * a.ostep) * a.stride - a.pad;
         a_iw[j] = (a.ox0 + lj * a.ostep) * a.stride - a.pad;
     }
     // weights: row (c0 + f>>2), k runs linearly when the tap lattice is dense; per-tap base otherwise
     unsigned b_row[B_LD];
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) b_row[j] = (unsigned)((c0 + (((tid + 256 * j) >> 2) & (BN - 1))) * Ktot) + q * 4;
+    for (int j = 0; j < B_LD; ++j) b_row[j] = ((unsigned)((c0 + (((tid + 256 * j) >> 2) & (BN - 1))) * Ktot) + q * 4) * 4u;
 
     using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
     acc_t acc[TC][TP];
@@ -79,12 +79,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int e = 0; e < 4 * NV; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[A_LD], rb[B_LD];
-    unsigned a_off[A_LD], a_msk[A_LD]; unsigned b_tap = 0;
     const int cpt = a.Cin >> 4;                 // 16-channel chunks per tap
-    const int ntaps = a.nkh * a.nkw;
 
-    // VALU-heavy part, once per filter tap: input pixel of every gather row for tap (ikh, ikw) of the tap lattice
-    auto tap_setup = [&](int ikh, int ikw) {
+    // K order: channel chunk OUTER, filter tap INNER.  Consecutive steps then read the same 64-B lines shifted by one pixel
+    // (L1/L2 hits); with taps outer the 9x re-read of every input pixel is ~15 MB of other blocks' traffic apart and misses
+    // the 4 MB per-XCD L2.  The gather offsets of all NT taps live in registers (NT is static: 1, 2, 4 or 9).
+    unsigned a_off[NT][A_LD], a_mbits[A_LD], b_tap[NT];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) a_mbits[j] = 0u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ikh = t / a.nkw, ikw = t - ikh * a.nkw;
         const int kh = a.kh0 + ikh * a.khs, kw = a.kw0 + ikw * a.kws;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
@@ -96,87 +101,109 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             }
             if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
             else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
-            a_msk[j] = ok ? 0xFFFFFFFFu : 0u;
-            a_off[j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) : (unsigned)(q * 4);    // masked rows read a valid dummy address
+            a_mbits[j] |= ok ? (1u << t) : 0u;
+            a_off[t][j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * 4u : (unsigned)(q * 16);    // masked rows read a valid dummy address
         }
-        b_tap = (unsigned)((kh * a.KW + kw) * a.Cin);
-    };
-    // branch-free: every lane loads; masked rows are zeroed with an integer AND (keeps the steady-state loop one basic block,
-    // so the scheduler can interleave these loads and the LDS stores with the MFMAs)
-    auto gload = [&](int ci0) {
+        b_tap[t] = (unsigned)((kh * a.KW + kw) * a.Cin) * 4u;
+    }
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    const char* wb = reinterpret_cast<const char*>(a.w);
+    // branch-free: every lane loads; masked rows are zeroed with an integer AND so the steady-state loop stays one basic
+    // block and the scheduler can interleave the loads and the LDS stores with the MFMAs
+    auto gload = [&](int t, int ci0) {
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
-            const uint4 v = *reinterpret_cast<const uint4*>(a.x + a_off[j] + ci0);
-            const unsigned mk = a_msk[j];
+            const uint4 v = *reinterpret_cast<const uint4*>(xb + (a_off[t][j] + (unsigned)(ci0 * 4)));
+            const unsigned mk = 0u - ((a_mbits[j] >> t) & 1u);
             ra[j] = make_float4(__uint_as_float(v.x & mk), __uint_as_float(v.y & mk), __uint_as_float(v.z & mk), __uint_as_float(v.w & mk));
         }
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const float4*>(a.w + b_row[j] + b_tap + ci0);
+        for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const float4*>(wb + (b_row[j] + b_tap[t] + (unsigned)(ci0 * 4)));
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int so) {                 // so: float offset of the stage
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4*>(Xs + buf * BM * LDK + ((tid + 256 * j) >> 2) * LDK + q * 4) = ra[j];
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4*>(smem + so + ((tid + 256 * j) >> 2) * LDK + q * 4) = ra[j];
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(Ws + buf * BN * LDK + (((tid + 256 * j) >> 2) & (BN - 1)) * LDK + q * 4) = rb[j];   // BN < 64: duplicate rows, same data
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(smem + so + XS + (((tid + 256 * j) >> 2) & (BN - 1)) * LDK + q * 4) = rb[j];   // BN < 64: duplicate rows, same data
     };
-    auto compute = [&](int buf) {
-        if constexpr (MF == 16) {
-            // 16x16x4: lane (row l&15, k-quad l>>4); MFMA r contracts k in {r, 4+r, 8+r, 12+r}
-            f32x4 wf[TC], xf[TP];
+    // operand fragments of one K-step
+    //   16x16x4: lane (row l&15, k-quad l>>4), one ds_read_b128 per 16-row tile; MFMA r contracts k in {r, 4+r, 8+r, 12+r}
+    //   32x32x2 (155 TF bare vs 140, full rate at one wave per SIMD): lane (row l&31, k-half l>>5), two ds_read_b128 per
+    //            32-row tile cover k = 8*jj + 4*h .. +3; MFMA (jj,r) contracts k in {8jj + r, 8jj + 4 + r}
+    constexpr int NJ = MF == 32 ? 2 : 1;
+    struct Ops { f32x4 w[TC][NJ], x[TP][NJ]; };
+    const int lrow = lane & (MF - 1), lk4 = 4 * (lane / MF);
+    auto read_ops = [&](int so, Ops& o) {
 #pragma unroll
-            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const f32x4*>(Ws + buf * BN * LDK + (wc * (BN / WC) + i * 16 + (lane & 15)) * LDK + 4 * (lane >> 4));
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int j = 0; j < TP; ++j) xf[j] = *reinterpret_cast<const f32x4*>(Xs + buf * BM * LDK + (wp * (BM / WP) + j * 16 + (lane & 15)) * LDK + 4 * (lane >> 4));
+            for (int jj = 0; jj < NJ; ++jj) o.w[i][jj] = *reinterpret_cast<const f32x4*>(smem + so + XS + (wc * (BN / WC) + i * MF + lrow) * LDK + 8 * jj + lk4);
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) o.x[j][jj] = *reinterpret_cast<const f32x4*>(smem + so + (wp * (BM / WP) + j * MF + lrow) * LDK + 8 * jj + lk4);
+    };
+    auto mfmas = [&](const Ops& o) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][r], xf[j][r], acc[i][j], 0, 0, 0);
-        } else {
-            // 32x32x2 (155 TF bare vs 140 for 16x16x4, full rate at one wave per SIMD): lane (row l&31, k-half l>>5);
-            // two ds_read_b128 per 32-row tile cover k = 8*jj + 4*h .. +3; MFMA (jj,r) contracts k in {8jj + r, 8jj + 4 + r}
-            f32x4 wf[TC][2], xf[TP][2];
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) wf[i][jj] = *reinterpret_cast<const f32x4*>(Ws + buf * BN * LDK + (wc * (BN / WC) + i * 32 + (lane & 31)) * LDK + 8 * jj + 4 * (lane >> 5));
-#pragma unroll
-            for (int j = 0; j < TP; ++j)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) xf[j][jj] = *reinterpret_cast<const f32x4*>(Xs + buf * BM * LDK + (wp * (BM / WP) + j * 32 + (lane & 31)) * LDK + 8 * jj + 4 * (lane >> 5));
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int i = 0; i < TC; ++i)
-#pragma unroll
-                        for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][jj][r], xf[j][jj][r], acc[i][j], 0, 0, 0);
-        }
+                    for (int j = 0; j < TP; ++j) {
+                        if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.w[i][jj][r], o.x[j][jj][r], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w[i][jj][r], o.x[j][jj][r], acc[i][j], 0, 0, 0);
+                    }
     };
 
-    int ikh = 0, ikw = 0, buf = 0;
-    tap_setup(0, 0);
-    gload(0);
-    lstore(0);
+#ifdef MD2_ABLATE
+    const int abl = a.ablate;
+#endif
+    // Three-stage LDS pipeline, ONE barrier per K-step:
+    //   step s: global loads of step s+2 -> registers | LDS reads of step s+1 operands (stage written in step s-1, visible since
+    //   that step's barrier) | MFMAs of step s from registers | registers -> LDS stage of step s+2 | barrier.
+    // The ds_read latency and the barrier wait hide behind the MFMAs already issued, so the matrix pipe never starts a step cold.
+    const int nsteps = cpt * NT;
+    auto step_tc = [&](int sidx, int& t, int& ci0) { const int ss = min(sidx, nsteps - 1); const int c = ss / NT; t = ss - c * NT; ci0 = c << 4; };
+    int o0 = 0, o1 = STAGE, o2 = 2 * STAGE;
+    Ops cur, nxt;
+    gload(0, 0); lstore(o0);
+    { int t1, c1; step_tc(1, t1, c1); if (NT == 1) gload(0, c1); else gload(nsteps > 1 ? 1 : 0, 0); }
+    lstore(o1);
     __syncthreads();
-    for (int t = 0; t < ntaps; ++t) {
-        for (int c = 1; c < cpt; ++c) {          // steady state: prefetch the next chunk of the same tap
-            gload(c << 4);
-            compute(buf);
-            lstore(buf ^ 1);
+    read_ops(o0, cur);
+    for (int c = 0; c < cpt; ++c) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // step s = c*NT + t ; prefetch target s+2 = (c + (t+2)/NT, (t+2)%NT) with static tap index, clamped to the last step
+            constexpr int dummy = 0; (void)dummy;
+            const int t2 = (t + 2) % NT;
+            const int c2 = min(c + (t + 2) / NT, cpt - 1);
+            const bool last2 = (c + (t + 2) / NT) > cpt - 1;          // beyond the end: reload the final step (harmless)
+#ifdef MD2_ABLATE
+            if (!(abl & 1)) gload(last2 ? NT - 1 : t2, c2 << 4);
+            if (!(abl & 2)) read_ops(o1, nxt);
+            if (!(abl & 4)) mfmas(cur);
+            if (!(abl & 2)) lstore(o2);
+            if (!(abl & 8)) __syncthreads();
+            cur = nxt;
+            { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
+            continue;
+#endif
+            gload(last2 ? NT - 1 : t2, c2 << 4);
+            read_ops(o1, nxt);
+            mfmas(cur);
+            lstore(o2);
             __syncthreads();
-            buf ^= 1;
+            cur = nxt;
+            { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
         }
-        const bool more = t + 1 < ntaps;         // last chunk of the tap: prefetch chunk 0 of the next tap
-        if (more) { if (++ikw == a.nkw) { ikw = 0; ++ikh; } tap_setup(ikh, ikw); gload(0); }
-        compute(buf);
-        if (more) lstore(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
     }
 
+#ifdef MD2_ABLATE
+    if (abl & 16) { if (acc[0][0][0] == 123.456f) a.y[0] = 1.f; return; }      // skip the epilogue stores
+#endif
     // epilogue: every (tile, register group) is 4 consecutive channels of one pixel -> one 16-B NHWC store
     //   16x16x4: D col = lane&15 (pixel), row = 4*(lane>>4) + e (channel)
     //   32x32x2: D col = lane&31 (pixel), row = 8*g + 4*(lane>>5) + e, register 4g+e
@@ -213,7 +240,13 @@ template <int BM, int BN, int WP, int WC, int MF>
 static void launch_tile(const ConvArgs& a, hipStream_t s) {
     static_assert((BM / WP) % MF == 0 && (BN / WC) % MF == 0, "wave tile must be a multiple of the MFMA tile");
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF>), dim3(grid), dim3(256), 0, s, a);
+    switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
+        case 9: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), dim3(grid), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), dim3(grid), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), dim3(grid), dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), dim3(grid), dim3(256), 0, s, a); break;
+        default: fprintf(stderr, "md2: conv_igemm: unsupported tap count %d\n", a.nkh * a.nkw); abort();
+    }
 }
 
 double conv_igemm_flops(const ConvArgs& a) {       // algorithmic: taps that can be non-zero
@@ -247,15 +280,24 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
 
 static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s) {
     // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
-    const long x_elems = (long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps, w_elems = (long)a.Cout * a.KH * a.KW * a.Cin;
+    const long x_elems = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), w_elems = 4 * ((long)a.Cout * a.KH * a.KW * a.Cin);   // byte offsets must fit 32 bits
     if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) ||
         a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) || w_elems >= (1L << 32)) {
         fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
         abort();
     }
     const long tiles128 = (long)((a.M + 127) / 128);
-    if (a.Cout % 128 == 0 && tiles128 * (a.Cout / 128) >= 512) launch_tile<128, 128, 2, 2, 32>(a, s);
-    else if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= 384) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
+#ifdef MD2_ABLATE
+    switch (a.force_tile) {
+        case 2: launch_tile<128, 64, 2, 2, 32>(a, s); return;
+        case 3: launch_tile<64, 64, 2, 2, 32>(a, s); return;
+        case 4: launch_tile<256, 32, 4, 1, 32>(a, s); return;
+        case 5: launch_tile<128, 32, 4, 1, 32>(a, s); return;
+        case 6: launch_tile<128, 64, 2, 2, 16>(a, s); return;
+        default: break;
+    }
+#endif
+    if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= 384) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
 }
@@ -275,17 +317,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
     constexpr bool KSPLIT = (T == 16);                   // the 4 waves split the pixels of a step instead of the tile
     constexpr int TW = KSPLIT ? 1 : T / 2 / MF;          // MFMA tiles per wave per dim
     constexpr int NV = MF == 32 ? 4 : 1;
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BKP * LD + (KSPLIT ? 4 * 256 : 0)];
-    float* Ds = smem;
-    float* Xs = smem + 2 * BKP * LD;
+    constexpr int STAGE = 2 * BKP * LD;                  // floats per pipeline stage: dY tile then x tile
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(16))) float smem[(NST * STAGE > 4 * 256) ? NST * STAGE : 4 * 256];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nti = a.Cin / T;
-    const int tile_c = blockIdx.x / nti, tile_i = blockIdx.x % nti;
-    const int tap = blockIdx.y, kh = tap / a.KW, kw = tap % a.KW;
+    const int nti = a.Cin / T, ntaps = a.KH * a.KW;
+    // logical id: tap fastest, then tile, then pixel split; the XCD remap keeps consecutive ids on one XCD so the 9 taps of a
+    // (tile, split) stream the same dY rows / overlapping x rows out of one L2 instead of each re-fetching them
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = bid % ntaps; const int rest = bid / ntaps;
+    const int ntiles = (a.Cout / T) * nti;
+    const int tile = rest % ntiles, split = rest / ntiles;
+    const int tile_c = tile / nti, tile_i = tile % nti;
+    const int kh = tap / a.KW, kw = tap % a.KW;
     const int c0 = tile_c * T, i0 = tile_i * T;
     const int HoWo = a.Ho * a.Wo;
-    const int s_begin = blockIdx.z * steps_per_split;
+    const int s_begin = split * steps_per_split;
     const int s_end = min(s_begin + steps_per_split, steps_total);
     if (s_begin >= s_end) return;
 
@@ -293,31 +341,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
     // exact floor(m / d) for 0 <= m < 2^24 from the float reciprocal (+-1 correction): integer division costs ~40 VALU ops, this ~8
     auto fdiv = [](int m, int d, float rcp) { int qq = (int)((float)m * rcp); const int r = m - qq * d; qq += (r >= d) ? 1 : 0; qq -= (r < 0) ? 1 : 0; return qq; };
     float4 rd[NLD], rx[NLD];
-    auto gload = [&](int step) {
+    // Per-load pixel state (n, oh, ow, m), advanced incrementally: consecutive loads of one slot are BKP pixels apart, so the
+    // (n, oh, ow) split is a carry update (a few VALU ops) instead of two divisions per load per step.
+    int p_m[NLD], p_n[NLD], p_oh[NLD], p_ow[NLD];
+    const int adv_h = BKP / a.Wo, adv_w = BKP - adv_h * a.Wo;          // BKP pixels = adv_h rows + adv_w columns
+    const bool fast_adv = adv_h + 1 <= a.Ho;                            // at most one row-carry and one image-carry per advance
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int f = tid + 256 * j, lk = f / LPP;
+        const int m = s_begin * BKP + lk;
+        const int mm = min(m, a.M - 1);
+        const int n = fdiv(mm, HoWo, rcp_hw), r = mm - n * HoWo, oh = fdiv(r, a.Wo, rcp_w);
+        p_m[j] = m; p_n[j] = n; p_oh[j] = oh; p_ow[j] = r - oh * a.Wo;
+    }
+    auto gload = [&]() {                         // loads the next step of every slot and advances the slot by BKP pixels
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int f = tid + 256 * j, lk = f / LPP, lc = (f % LPP) * 4;
-            const int m = step * BKP + lk;
-            const bool in = m < a.M;
-            const int mm = in ? m : 0;
-            const int n = fdiv(mm, HoWo, rcp_hw), r = mm - n * HoWo, oh = fdiv(r, a.Wo, rcp_w), ow = r - oh * a.Wo;
+            const int f = tid + 256 * j, lc = (f % LPP) * 4;
+            const bool in = p_m[j] < a.M;
+            const int n = p_n[j], oh = p_oh[j], ow = p_ow[j];
             int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
             bool ok = in;
             if (a.padmode == PAD_REFLECT) { ih = refl_idx(ih, a.H); iw = refl_idx(iw, a.W); }
             else { ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W; ih = ok ? ih : 0; iw = ok ? iw : 0; }
-            const uint4 vd = *reinterpret_cast<const uint4*>(a.dy + (long)n * a.dy_bs + (long)r * a.dy_ps + c0 + lc);
+            const uint4 vd = *reinterpret_cast<const uint4*>(a.dy + (long)n * a.dy_bs + (long)(oh * a.Wo + ow) * a.dy_ps + c0 + lc);
             const uint4 vx = *reinterpret_cast<const uint4*>(a.x + (long)n * a.x_bs + ((long)ih * a.W + iw) * a.x_ps + i0 + lc);
             const unsigned md = in ? 0xFFFFFFFFu : 0u, mx = ok ? 0xFFFFFFFFu : 0u;       // integer masks keep the loop branch-free
             rd[j] = make_float4(__uint_as_float(vd.x & md), __uint_as_float(vd.y & md), __uint_as_float(vd.z & md), __uint_as_float(vd.w & md));
             rx[j] = make_float4(__uint_as_float(vx.x & mx), __uint_as_float(vx.y & mx), __uint_as_float(vx.z & mx), __uint_as_float(vx.w & mx));
+            // advance; positions past the end stay clamped to a valid pixel (their loads are masked by `in`)
+            p_m[j] += BKP;
+            if (fast_adv) {
+                int w2 = ow + adv_w, h2 = oh + adv_h, n2 = n;
+                const bool cw = w2 >= a.Wo; w2 -= cw ? a.Wo : 0; h2 += cw ? 1 : 0;
+                const bool ch = h2 >= a.Ho; h2 -= ch ? a.Ho : 0; n2 += ch ? 1 : 0;
+                const bool stay = p_m[j] >= a.M;
+                p_ow[j] = stay ? ow : w2; p_oh[j] = stay ? oh : h2; p_n[j] = stay ? n : n2;
+            } else {
+                const int mm = min(p_m[j], a.M - 1);
+                const int nn = fdiv(mm, HoWo, rcp_hw), r = mm - nn * HoWo, hh = fdiv(r, a.Wo, rcp_w);
+                p_n[j] = nn; p_oh[j] = hh; p_ow[j] = r - hh * a.Wo;
+            }
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int so) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int f = tid + 256 * j, lk = f / LPP, lc = (f % LPP) * 4;
-            *reinterpret_cast<float4*>(Ds + buf * BKP * LD + lk * LD + lc) = rd[j];
-            *reinterpret_cast<float4*>(Xs + buf * BKP * LD + lk * LD + lc) = rx[j];
+            *reinterpret_cast<float4*>(smem + so + lk * LD + lc) = rd[j];
+            *reinterpret_cast<float4*>(smem + so + BKP * LD + lk * LD + lc) = rx[j];
         }
     };
 
@@ -331,57 +403,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
             for (int e = 0; e < 4 * NV; ++e) acc[i][j][e] = 0.f;
 
     const int wr = KSPLIT ? 0 : (wave & 1), wq = KSPLIT ? 0 : (wave >> 1);
-    auto compute = [&](int buf) {
-        const float* D = Ds + buf * BKP * LD;
-        const float* X = Xs + buf * BKP * LD;
-        if constexpr (MF == 32) {
+    // operand fragments of one step (KK MFMA k-groups): A = dY[pixel k][channel row], B = x[pixel k][channel col]
+    constexpr int KK = MF == 32 ? BKP / 2 : (KSPLIT ? BKP / 16 : BKP / 4);
+    struct Ops { float a[KK][TW], b[KK][TW]; };
+    const int lrow = lane & (MF - 1), lkk = lane / MF;       // k within a group: 0..1 (32x32x2) or 0..3 (16x16x4)
+    const int kq0 = KSPLIT ? wave * KK : 0;
+    auto read_ops = [&](int so, Ops& o) {
+        const float* D = smem + so;
+        const float* X = smem + so + BKP * LD;
 #pragma unroll
-            for (int kk = 0; kk < BKP / 2; ++kk) {
-                const int k = 2 * kk + (lane >> 5);
-                float af[TW], bf[TW];
+        for (int kk = 0; kk < KK; ++kk) {
+            const int k = (kq0 + kk) * (MF == 32 ? 2 : 4) + lkk;
 #pragma unroll
-                for (int i = 0; i < TW; ++i) af[i] = D[k * LD + wr * (T / 2) + i * 32 + (lane & 31)];
+            for (int i = 0; i < TW; ++i) o.a[kk][i] = D[k * LD + wr * (T / 2) + i * MF + lrow];
 #pragma unroll
-                for (int j = 0; j < TW; ++j) bf[j] = X[k * LD + wq * (T / 2) + j * 32 + (lane & 31)];
-#pragma unroll
-                for (int i = 0; i < TW; ++i)
-#pragma unroll
-                    for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-            constexpr int KQ = KSPLIT ? BKP / 16 : BKP / 4;   // k-quads this wave walks per step
-            const int kq0 = KSPLIT ? wave * KQ : 0;
-#pragma unroll
-            for (int kk = 0; kk < KQ; ++kk) {
-                const int k = (kq0 + kk) * 4 + (lane >> 4);
-                float af[TW], bf[TW];
-#pragma unroll
-                for (int i = 0; i < TW; ++i) af[i] = D[k * LD + wr * (T / 2) + i * 16 + (lane & 15)];
-#pragma unroll
-                for (int j = 0; j < TW; ++j) bf[j] = X[k * LD + wq * (T / 2) + j * 16 + (lane & 15)];
-#pragma unroll
-                for (int i = 0; i < TW; ++i)
-#pragma unroll
-                    for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
+            for (int j = 0; j < TW; ++j) o.b[kk][j] = X[k * LD + wq * (T / 2) + j * MF + lrow];
         }
     };
-    gload(s_begin);
-    lstore(0);
+    auto mfmas = [&](const Ops& o) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[kk][i], o.b[kk][j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[kk][i], o.b[kk][j], acc[i][j], 0, 0, 0);
+                }
+    };
+    // three-stage pipeline, one barrier per step (same scheme as conv_igemm_kernel): global loads of step s+2, LDS reads of step
+    // s+1's operands, MFMAs of step s, registers -> LDS stage of step s+2, barrier
+    int o0 = 0, o1 = STAGE, o2 = 2 * STAGE;
+    Ops cur, nxt;
+    gload(); lstore(o0);
+    gload(); lstore(o1);                              // steps beyond s_end belong to the next split or lie past M: loaded but never used
     __syncthreads();
-    int buf = 0;
-    for (int s = s_begin + 1; s < s_end; ++s) {      // steady state (branch-free body): prefetch step s while computing step s-1
-        gload(s);
-        compute(buf);
-        lstore(buf ^ 1);
+    read_ops(o0, cur);
+    for (int s = s_begin; s < s_end; ++s) {
+        gload();
+        read_ops(o1, nxt);
+        mfmas(cur);
+        lstore(o2);
         __syncthreads();
-        buf ^= 1;
+        cur = nxt;
+        { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
     }
-    compute(buf);
 
     const int taps = a.KH * a.KW;
     if (KSPLIT) {
-        float* red = smem + 2 * 2 * BKP * LD;
+        float* red = smem;                          // the pipeline stages are dead after the final barrier
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) red[wave * 256 + e * 64 + lane] = acc[0][0][e];
@@ -414,12 +484,14 @@ template <int T, int BKP, int MF>
 static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     const int tiles = (a.Cout / T) * (a.Cin / T), taps = a.KH * a.KW;
     const int steps_total = (a.M + BKP - 1) / BKP;
-    int splitk = (2048 + tiles * taps - 1) / (tiles * taps);
-    // keep at least 8 steps per split so the per-block atomic epilogue is amortised
-    splitk = std::max(1, std::min(splitk, (steps_total + 7) / 8));
+    // Split the pixel (K) range until the grid has ~2048 blocks (measured on MI355X: 512 -> 56, 1024 -> 64, 1536..6144 -> 70 TFLOP/s
+    // over the whole network; the fp32-atomic epilogue is not the limiter).
+    static int target = getenv("MD2_WGRAD_BLOCKS") ? atoi(getenv("MD2_WGRAD_BLOCKS")) : 2048;
+    int splitk = (target + tiles * taps - 1) / (tiles * taps);
+    splitk = std::max(1, std::min(splitk, (steps_total + 15) / 16));
     const int sps = (steps_total + splitk - 1) / splitk;
     splitk = (steps_total + sps - 1) / sps;
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF>), dim3(tiles, taps, splitk), dim3(256), 0, s, a, sps, steps_total);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF>), dim3(tiles * taps * splitk), dim3(256), 0, s, a, sps, steps_total);
 }
 
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {

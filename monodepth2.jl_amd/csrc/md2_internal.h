@@ -58,6 +58,9 @@ struct ConvArgs {
     int oy0, ox0, ostep, Hl, Wl;
     // tap lattice: taps kh = kh0 + a*khs (a < nkh), kw = kw0 + b*kws (b < nkw)   (dense: 0,1,KH / 0,1,KW)
     int kh0, khs, nkh, kw0, kws, nkw;
+#ifdef MD2_ABLATE
+    int ablate, force_tile;       // tools/conv_bench only
+#endif
 };
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 double conv_igemm_flops(const ConvArgs& a);

@@ -1,0 +1,28 @@
+// Standalone timing harness for the implicit-GEMM conv kernel (ablations + forced tiles). Built with -DMD2_ABLATE.
+// usage: conv_bench N H W Cin Cout k [tile] [ablate]
+#include "../monodepth2.jl_amd/csrc/md2_internal.h"
+#include <vector>
+#include <cstdlib>
+using namespace md2;
+int main(int argc, char** argv) {
+    int N = atoi(argv[1]), H = atoi(argv[2]), W = atoi(argv[3]), Cin = atoi(argv[4]), Cout = atoi(argv[5]), k = atoi(argv[6]);
+    int tile = argc > 7 ? atoi(argv[7]) : 0, abl = argc > 8 ? atoi(argv[8]) : 0;
+    size_t nx = (size_t)N * H * W * Cin, ny = (size_t)N * H * W * Cout, nw = (size_t)Cout * k * k * Cin;
+    float *x, *y, *w; hipMalloc(&x, nx * 4); hipMalloc(&y, ny * 4); hipMalloc(&w, nw * 4);
+    std::vector<float> hx(nx), hw(nw);
+    for (auto& v : hx) v = (rand() % 2001 - 1000) * 1e-3f;
+    for (auto& v : hw) v = (rand() % 2001 - 1000) * 1e-3f;
+    hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
+    ConvArgs a{};
+    a.x = x; a.x_bs = (long)H * W * Cin; a.x_ps = Cin; a.H = H; a.W = W; a.Cin = Cin; a.w = w;
+    a.y = y; a.y_bs = (long)H * W * Cout; a.y_ps = Cout; a.Ho = H; a.Wo = W; a.Cout = Cout;
+    a.N = N; a.KH = k; a.KW = k; a.stride = 1; a.pad = k / 2; a.dil = 1; a.padmode = 0;
+    a.M = N * H * W; a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = H; a.Wl = W; a.kh0 = 0; a.khs = 1; a.nkh = k; a.kw0 = 0; a.kws = 1; a.nkw = k;
+    a.ablate = abl; a.force_tile = tile;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch_conv_igemm(a, 0);
+    hipEventRecord(e0); const int reps = 20; for (int i = 0; i < reps; ++i) launch_conv_igemm(a, 0); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("N=%d HxW=%dx%d Cin=%d Cout=%d k=%d tile=%d abl=%d : %.3f ms  %.1f TFLOP/s\n", N, H, W, Cin, Cout, k, tile, abl, ms, 2.0 * a.M * Cout * k * k * Cin / (ms * 1e-3) / 1e12);
+    return 0;
+}
