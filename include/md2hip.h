@@ -78,6 +78,12 @@ int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* disp0, cons
                          const float* disp3, const float* rvec, const float* tvec, const float* auto_loss, float* loss,
                          float* ddisp0, float* ddisp1, float* ddisp2, float* ddisp3, float* drvec, float* dtvec);
 
+/* slow_depth's objective (src/simple_depth.jl:25-42, BASELINE config #1): mean(prediction_loss(warp(disp, x, Ps))) +
+ * smooth_loss(disp) on ONE full-resolution disparity disp [N][1][H][W] (no sigmoid, no mean-normalisation, weight 1) and its
+ * pullbacks (any may be NULL): ddisp [N][1][H][W], drvec/dtvec [2][N][3]. */
+int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, const float* rvec, const float* tvec, float* loss,
+                              float* ddisp, float* drvec, float* dtvec);
+
 /* per-kernel-class device timing (HIP events on the handle's stream) for bench.py's roofline */
 int32_t md2_profile_enable(md2_handle* h, int32_t on);
 int32_t md2_profile_reset(md2_handle* h);

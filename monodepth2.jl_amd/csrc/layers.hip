@@ -382,9 +382,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         st4(p + i * 4, P); st4(m + i * 4, M); st4(v + i * 4, V);
     }
 }
+__global__ void adam_tail_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n, float c1, float c2, float lr, float gs) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x; if (i >= n) return;
+    const float ge = g[i] * gs;
+    m[i] = 0.9f * m[i] + (1.f - 0.9f) * ge; v[i] = 0.999f * v[i] + (1.f - 0.999f) * ge * ge;
+    p[i] -= m[i] / c1 / (sqrtf(v[i] / c2) + 1e-8f) * lr;
+}
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float c1, float c2, float lr, float gscale, hipStream_t s) {
-    if (n % 4 != 0) { fprintf(stderr, "md2: adam: n %% 4 != 0\n"); abort(); }
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, s, p, g, m, v, n / 4, c1, c2, lr, gscale);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const long n4 = aligned ? n / 4 : 0;
+    if (n4 > 0) hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 256, 4096)), dim3(256), 0, s, p, g, m, v, n4, c1, c2, lr, gscale);
+    const long rem = n - 4 * n4;                        // tail (or everything, for unaligned / tiny arrays such as a 3-vector pose)
+    if (rem > 0) hipLaunchKernelGGL(adam_tail_kernel, dim3(grid_for(rem, 256, 4096)), dim3(256), 0, s, p + 4 * n4, g + 4 * n4, m + 4 * n4, v + 4 * n4, rem, c1, c2, lr, gscale);
 }
 __global__ void fill_kernel(float* p, long n, float v) { for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v; }
 void launch_fill(float* p, long n, float v, hipStream_t s) { hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, n, v); }

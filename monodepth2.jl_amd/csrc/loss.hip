@@ -192,7 +192,7 @@ __global__ void loss_finalize_kernel(LossArgs a, const double* __restrict__ part
             const double* p = part + ((long)sc * a.N + n) * 4;
             const float mean_d = (float)(p[1] / P);
             photo += p[0];
-            smooth += (p[2] / cntx + p[3] / cnty) / (double)(mean_d + 1e-7f);
+            smooth += (p[2] / cntx + p[3] / cnty) / (a.normalize ? (double)(mean_d + 1e-7f) : 1.0);
             float* t = totals + ((long)sc * a.N + n) * 4;
             t[0] = (float)p[0]; t[1] = mean_d; t[2] = (float)p[2]; t[3] = (float)p[3];
         }
@@ -289,11 +289,11 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
     __syncthreads();
     // ---- phase 3: per tile pixel r: gather d loss / d warped_s[r], pull back through grid_sample, Project, Backproject, depth
     const float* tt = totals + ((long)sc * a.N + n) * 4;
-    const float den = tt[1] + 1e-7f;
+    const float den = a.normalize ? tt[1] + 1e-7f : 1.f;
     const double cntx = (double)(W - 1) * H * a.N, cnty = (double)W * (H - 1) * a.N;
     const float sw = a.smooth_w[sc] / (float)a.nscales;
     const float ax = sw / den / (float)cntx, ay = sw / den / (float)cnty;
-    const float corr = sw * (float)((double)tt[2] / cntx + (double)tt[3] / cnty) / (den * den) / (float)P;
+    const float corr = a.normalize ? sw * (float)((double)tt[2] / cntx + (double)tt[3] / cnty) / (den * den) / (float)P : 0.f;
     float acc[24];
 #pragma unroll
     for (int k = 0; k < 24; ++k) acc[k] = 0.f;

@@ -268,7 +268,7 @@ static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp
     a.Rt = Rt; a.auto_loss = h->cfg.automasking ? auto_loss : nullptr;
     std::memcpy(a.K, h->K, sizeof(a.K)); std::memcpy(a.invK, h->invK, sizeof(a.invK));
     a.min_disp = (float)(1.0 / h->cfg.max_depth); a.max_disp = (float)(1.0 / h->cfg.min_depth);
-    a.tgt = 1; a.src0 = 0; a.src1 = 2;
+    a.tgt = 1; a.src0 = 0; a.src1 = 2; a.normalize = 1;
     return a;
 }
 
@@ -319,11 +319,15 @@ static int model_forward(md2_handle* h, const float* x) {
     return 0;
 }
 
-static int loss_forward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out) {
+static void simple_mode(md2_handle* h, LossArgs& a) {      // slow_depth objective, src/simple_depth.jl:25-42
+    a.nscales = 1; a.dh[0] = h->H; a.dw[0] = h->W; a.smooth_w[0] = 1.f; a.normalize = 0; a.auto_loss = nullptr;
+}
+static int loss_forward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
     hipStream_t s = h->stream;
     HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)16 * h->N * sizeof(double), s));
     launch_pose_compose(rvec, tvec, h->Rt, h->N, 1, 0, s);       // inverse_transform = source_ids .< target_id = [true, false] (src/training.jl:29)
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
+    if (simple) simple_mode(h, a);
     h->pbegin(CLS_LOSS_FWD); launch_loss_fwd(a, h->loss_part, s); h->pend();
     if (h->prof) h->prof_bytes[CLS_LOSS_FWD] += 4.0 * h->H * h->W * (1 + 3 * h->C) * 4 * h->N;
     launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
@@ -332,14 +336,15 @@ static int loss_forward(md2_handle* h, const float* x, const float* const disp[4
     return 0;
 }
 // pullback of the loss half: fills ddisp_lo[4] (scale resolution), drvec, dtvec
-static int loss_backward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss) {
+static int loss_backward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, bool simple = false) {
     hipStream_t s = h->stream;
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
+    if (simple) simple_mode(h, a);
     HIPCHK(hipMemsetAsync(h->dRt_acc, 0, (size_t)24 * h->N * sizeof(double), s));
     h->pbegin(CLS_LOSS_BWD); launch_loss_bwd(a, h->totals, h->ddisp_full, h->dRt_acc, s); h->pend();
     if (h->prof) h->prof_bytes[CLS_LOSS_BWD] += 4.0 * h->H * h->W * (2 + 3 * h->C) * 4 * h->N;
     const size_t P = (size_t)h->H * h->W;
-    for (int i = 0; i < 4; ++i) launch_upsample_planar_bwd(h->ddisp_full + (size_t)i * h->N * P, h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
+    if (!simple) for (int i = 0; i < 4; ++i) launch_upsample_planar_bwd(h->ddisp_full + (size_t)i * h->N * P, h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
     launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, 1, 0, s);
     KCHK();
     return 0;
@@ -566,6 +571,17 @@ int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const f
     return 0;
 }
 
+int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, const float* rvec, const float* tvec, float* loss, float* ddisp, float* drvec, float* dtvec) {
+    const float* d4[4] = {disp, disp, disp, disp};
+    if (int r = loss_forward(h, x, d4, rvec, tvec, nullptr, loss, true)) return r;
+    if (!(ddisp || drvec || dtvec)) return 0;
+    if (int r = loss_backward(h, x, d4, rvec, tvec, nullptr, true)) return r;
+    if (ddisp) HIPCHK(hipMemcpyAsync(ddisp, h->ddisp_full, (size_t)h->N * h->H * h->W * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (drvec) HIPCHK(hipMemcpyAsync(drvec, h->drvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (dtvec) HIPCHK(hipMemcpyAsync(dtvec, h->dtvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
 int32_t md2_profile_enable(md2_handle* h, int32_t on) { h->prof = on != 0; return 0; }
 int32_t md2_profile_reset(md2_handle* h) {
     (void)hipStreamSynchronize(h->stream);
@@ -721,7 +737,7 @@ int32_t md2_maxpool3s2_bwd(const float* x, const float* dy, float* dx, int32_t N
     return hipGetLastError() != hipSuccess;
 }
 int32_t md2_adam_raw(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, double lr, float grad_scale, void* stream) {
-    if (n % 4) return 2;
+    if (n <= 0 || step < 1) return 2;
     launch_adam(p, g, m, v, (long)n, (float)(1.0 - std::pow(0.9, step)), (float)(1.0 - std::pow(0.999, step)), (float)lr, grad_scale, (hipStream_t)stream);
     return hipGetLastError() != hipSuccess;
 }

@@ -132,6 +132,7 @@ struct LossArgs {
     float min_disp, max_disp;  // 1/max_depth, 1/min_depth
     float smooth_w[4];         // disparity_smoothness * scale_i
     int tgt, src0, src1;       // 0-based frame indices
+    int normalize;             // 1: smooth_loss(d / (mean(d)+1e-7)) (train_loss, src/training.jl:64-67); 0: smooth_loss(d) (slow_depth, src/simple_depth.jl:39)
 };
 // per-scale partial sums -> part[(scale*N + n)*4 + {photo, sum d, Sx, Sy}] (double atomics; zeroed by caller)
 void launch_loss_fwd(const LossArgs& a, double* part, hipStream_t s);

@@ -401,6 +401,51 @@ def loss_fwd_bwd(model: Model, x, disps, rvec, tvec, auto_loss=None, want_grads=
     return loss, dds, drv, dtv
 
 
+def simple_depth_loss(model: Model, x, disp, rvec, tvec, want_grads=True):
+    """slow_depth's objective and pullbacks (src/simple_depth.jl:25-42): disp (N,1,H,W); rvec,tvec (2,N,3)."""
+    x, disp, rvec, tvec = _f32(x), _f32(disp), _f32(rvec), _f32(tvec)
+    L = _lib.lib(); L.md2_set_stream(model._h, _stream())
+    loss = torch.empty((), device=x.device)
+    dd = torch.empty_like(disp) if want_grads else None; dr = torch.empty_like(rvec) if want_grads else None; dt = torch.empty_like(tvec) if want_grads else None
+    _check(L.md2_simple_depth_loss(model._h, _dev(x), _dev(disp), _dev(rvec), _dev(tvec), _dev(loss), _dev(dd), _dev(dr), _dev(dt)), model._h, "simple_depth_loss")
+    return loss, dd, dr, dt
+
+
+def slow_depth(x, K, invK, target_id=2, source_ids=(1, 3), min_depth=0.1, max_depth=100.0, iters=500, lr=3e-4, log_every=0):
+    """slow_depth (src/simple_depth.jl:1-62): optimise a raw disparity map (init 0.5) and two poses (rvec=[0,0,0.01], tvec=0) for ONE
+    triplet with ADAM(3e-4).  The reference calls an undefined `warp`; the sequence it stands for is fused in the loss kernel.
+    x (1,3,C,H,W).  Returns (disp (1,1,H,W), [Pose, Pose], losses)."""
+    if list(source_ids) != [1, 3] or target_id != 2:
+        raise NotImplementedError("hot path implements source_ids=[1,3], target_id=2")
+    x = _f32(x); N, _, Cc, H, W = x.shape
+    enc = ResidualNetwork(18, in_channels=Cc)
+    model = Model(enc, DepthDecoder(list(enc.stages), [2, 3, 4, 5]), PoseDecoder(512))
+    params = Params(target_size=(W, H), batch_size=N, min_depth=min_depth, max_depth=max_depth, automasking=False)
+    model._ensure(x, params); model.set_intrinsics(K, invK)
+    dev = x.device
+    disp = torch.full((N, 1, H, W), 0.5, device=dev)
+    rvec = torch.zeros(2, N, 3, device=dev); rvec[:, :, 2] = 0.01
+    tvec = torch.zeros(2, N, 3, device=dev)
+    state = [(p, torch.zeros_like(p), torch.zeros_like(p)) for p in (disp, rvec, tvec)]
+    losses = []
+    for it in range(1, iters + 1):
+        loss, dd, dr, dt = simple_depth_loss(model, x, disp, rvec, tvec)
+        for (p, m, v), g in zip(state, (dd, dr, dt)):
+            adam_raw(p, g, m, v, it, lr=lr)
+        if log_every and (it % log_every == 0 or it == 1):
+            losses.append(float(loss))
+    model.close()
+    return disp, [Pose(rvec[0], tvec[0]), Pose(rvec[1], tvec[1])], losses
+
+
+def simple_depth(x, K=None, invK=None, **kw):
+    """simple_depth() (src/simple_depth.jl:64-97) without the dataset / PNG plumbing: Depth10k intrinsics by default."""
+    if K is None:
+        from . import synthetic
+        K, invK = synthetic.depth10k_intrinsics(x.shape[-1], x.shape[-2])
+    return slow_depth(x, K, invK, **kw)
+
+
 def profile(model: Model, on=True):
     _check(_lib.lib().md2_profile_enable(model._h, int(on)), model._h)
     if on:

@@ -93,12 +93,12 @@ O_API void o_act(float* y, long n, int act) { Tensor t(1, 1, 1, (int)n); std::me
 
 // ---- network handle ---------------------------------------------------------------------------
 struct o_cfg {
-    int N, C, H, W, automasking, reserved;
+    int N, C, H, W, automasking, simple;
     double min_depth, max_depth, smoothness;
     float K[9], invK[9];
 };
 static LossCfg to_cfg(const o_cfg* c) {
-    LossCfg l; l.N = c->N; l.C = c->C; l.H = c->H; l.W = c->W; l.automasking = c->automasking;
+    LossCfg l; l.N = c->N; l.C = c->C; l.H = c->H; l.W = c->W; l.automasking = c->automasking; l.simple = c->simple; if (c->simple) l.nscales = 1;
     l.min_depth = c->min_depth; l.max_depth = c->max_depth; l.smoothness = c->smoothness;
     std::memcpy(l.K, c->K, sizeof(l.K)); std::memcpy(l.invK, c->invK, sizeof(l.invK)); return l;
 }
@@ -154,14 +154,14 @@ O_API float o_loss_fwd_bwd(const float* x, const o_cfg* cfg, const float* d0, co
                            float* dd0, float* dd1, float* dd2, float* dd3, float* drvec, float* dtvec, float* warped_out, float* warp_loss_out) {
     LossCfg c = to_cfg(cfg);
     const float* ds[4] = {d0, d1, d2, d3}; Tensor disp[4], ddisp[4];
-    for (int i = 0; i < 4; ++i) { const int sh = 3 - i; disp[i] = wrap(ds[i], c.N, 1, c.H >> sh, c.W >> sh); }
+    for (int i = 0; i < c.nscales; ++i) { const int sh = c.simple ? 0 : 3 - i; disp[i] = wrap(ds[i], c.N, 1, c.H >> sh, c.W >> sh); }
     const float* rv[2] = {rvec, rvec + (size_t)c.N * 3}; const float* tv[2] = {tvec, tvec + (size_t)c.N * 3};
     Vec<float> drv((size_t)2 * c.N * 3, 0.f), dtv((size_t)2 * c.N * 3, 0.f);
     float* drp[2] = {drv.data(), drv.data() + (size_t)c.N * 3}; float* dtp[2] = {dtv.data(), dtv.data() + (size_t)c.N * 3};
     const float loss = loss_fwd_bwd(x, c, disp, rv, tv, auto_loss, do_bwd != 0, ddisp, drp, dtp, warped_out, warp_loss_out);
     if (do_bwd) {
         float* dds[4] = {dd0, dd1, dd2, dd3};
-        for (int i = 0; i < 4; ++i) if (dds[i]) std::memcpy(dds[i], ddisp[i].p(), sizeof(float) * ddisp[i].size());
+        for (int i = 0; i < c.nscales; ++i) if (dds[i]) std::memcpy(dds[i], ddisp[i].p(), sizeof(float) * ddisp[i].size());
         if (drvec) std::memcpy(drvec, drv.data(), sizeof(float) * drv.size());
         if (dtvec) std::memcpy(dtvec, dtv.data(), sizeof(float) * dtv.size());
     }

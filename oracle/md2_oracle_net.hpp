@@ -390,6 +390,9 @@ struct LossCfg {
     int N, C, H, W, L = 3, target_id = 2, nsrc = 2; int source_ids[2] = {1, 3};
     double min_depth = 0.1, max_depth = 100.0, smoothness = 1e-3; int automasking = 0;
     double scales[4] = {0.125, 0.25, 0.5, 1.0}; int nscales = 4;
+    // mode 1 = slow_depth (src/simple_depth.jl:25-42): ONE full-resolution scale, smooth_loss on the raw disparity (no mean
+    // normalisation) with weight 1
+    int simple = 0;
     float K[9], invK[9];
 };
 inline Tensor x_frame(const float* x, const LossCfg& c, int id1) {   // x[:, :, :, id, :], 1-based id
@@ -442,8 +445,8 @@ inline float loss_fwd_bwd(const float* x, const LossCfg& c, const Tensor disp[4]
         double wsum = 0; for (size_t j = 0; j < NP; ++j) wsum += wl[j];
         // normalized_disparity = d ./ (mean(d; dims=(1,2)) .+ 1e-7), :64-65
         Vec<float> mean_d(N); Tensor nd(N, 1, H, W);
-        for (int n = 0; n < N; ++n) { double s = 0; for (size_t j = 0; j < P; ++j) s += d.v[n * P + j]; mean_d[n] = (float)(s / (double)P); for (size_t j = 0; j < P; ++j) nd.v[n * P + j] = d.v[n * P + j] / (mean_d[n] + 1e-7f); }
-        const float sm_w = (float)c.smoothness * (float)c.scales[i];
+        for (int n = 0; n < N; ++n) { double s = 0; for (size_t j = 0; j < P; ++j) s += d.v[n * P + j]; mean_d[n] = (float)(s / (double)P); for (size_t j = 0; j < P; ++j) nd.v[n * P + j] = c.simple ? d.v[n * P + j] : d.v[n * P + j] / (mean_d[n] + 1e-7f); }
+        const float sm_w = c.simple ? 1.f : (float)c.smoothness * (float)c.scales[i];
         Tensor dnd; if (do_bwd) dnd.reset(N, 1, H, W);
         const float sl = smooth_loss_fwd_bwd<float>(nd.p(), tgt.p(), inv_scales * sm_w, do_bwd ? dnd.p() : nullptr, N, C, H, W);
         loss += (float)(wsum / (double)NP) + sl * sm_w;
@@ -451,6 +454,7 @@ inline float loss_fwd_bwd(const float* x, const LossCfg& c, const Tensor disp[4]
         // ---------------- pullback of scale i ----------------
         Tensor dd(N, 1, H, W);                                   // wrt the (upsampled) disparity
         for (int n = 0; n < N; ++n) {                            // through d / (mean + eps)
+            if (c.simple) { for (size_t j = 0; j < P; ++j) dd.v[n * P + j] = dnd.v[n * P + j]; continue; }
             const float den = mean_d[n] + 1e-7f; double dot = 0;
             for (size_t j = 0; j < P; ++j) dot += (double)dnd.v[n * P + j] * d.v[n * P + j];
             const float corr = (float)(dot / ((double)den * den) / (double)P);

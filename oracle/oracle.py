@@ -40,15 +40,15 @@ def lib():
 
 
 class OCfg(C.Structure):
-    _fields_ = [("N", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("automasking", C.c_int), ("reserved", C.c_int),
+    _fields_ = [("N", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("automasking", C.c_int), ("simple", C.c_int),
                 ("min_depth", C.c_double), ("max_depth", C.c_double), ("smoothness", C.c_double),
                 ("K", C.c_float * 9), ("invK", C.c_float * 9)]
 
 
-def make_cfg(N, Cc, H, W, K, invK, automasking=False, min_depth=0.1, max_depth=100.0, smoothness=1e-3):
+def make_cfg(N, Cc, H, W, K, invK, automasking=False, min_depth=0.1, max_depth=100.0, smoothness=1e-3, simple=False):
     """K, invK: 3x3 numpy matrices (mathematical row/col indexing); stored column-major like Julia."""
     c = OCfg()
-    c.N, c.C, c.H, c.W, c.automasking = N, Cc, H, W, int(automasking)
+    c.N, c.C, c.H, c.W, c.automasking, c.simple = N, Cc, H, W, int(automasking), int(simple)
     c.min_depth, c.max_depth, c.smoothness = min_depth, max_depth, smoothness
     Kc = np.asarray(K, np.float32).T.reshape(-1)       # column-major flatten
     iKc = np.asarray(invK, np.float32).T.reshape(-1)
@@ -291,8 +291,11 @@ def automasking_loss(x, cfg):
 
 
 def loss_fwd_bwd(x, cfg, disps, rvec, tvec, auto_loss=None, do_bwd=True, want_warped=False):
-    """disps: 4 arrays (N,1,h,w) coarse->fine; rvec,tvec (2,N,3).  Returns dict."""
+    """disps: 4 arrays (N,1,h,w) coarse->fine (cfg.simple: ONE full-resolution array); rvec,tvec (2,N,3).  Returns dict."""
     x = _c(x, np.float32); ds = [_c(d, np.float32) for d in disps]; rvec = _c(rvec, np.float32); tvec = _c(tvec, np.float32)
+    nreal = len(ds)
+    while len(ds) < 4:
+        ds.append(np.zeros((1,), np.float32))
     al = None if auto_loss is None else _c(auto_loss, np.float32)
     dds = [np.zeros_like(d) for d in ds]; drv = np.zeros_like(rvec); dtv = np.zeros_like(tvec)
     N, Cc, H, W = cfg.N, cfg.C, cfg.H, cfg.W
@@ -300,7 +303,7 @@ def loss_fwd_bwd(x, cfg, disps, rvec, tvec, auto_loss=None, do_bwd=True, want_wa
     wl = np.zeros((4, N, H, W), np.float32) if want_warped else None
     loss = lib().o_loss_fwd_bwd(_p(x), C.byref(cfg), _p(ds[0]), _p(ds[1]), _p(ds[2]), _p(ds[3]), _p(rvec), _p(tvec), _p(al), int(do_bwd),
                                 _p(dds[0]), _p(dds[1]), _p(dds[2]), _p(dds[3]), _p(drv), _p(dtv), _p(warped), _p(wl))
-    return dict(loss=float(loss), ddisp=dds, drvec=drv, dtvec=dtv, warped=warped, warp_loss=wl)
+    return dict(loss=float(loss), ddisp=dds[:nreal], drvec=drv, dtvec=dtv, warped=warped, warp_loss=wl)
 
 
 def num_threads():

@@ -119,3 +119,17 @@ def test_adam_vs_torch():
         net.set_grads(gg); net.adam_step(1e-3)
         tr.adam_step(pt, torch.tensor(g.astype(np.float64)), m, v, step, eta=1e-3)
     assert rel(net.get_params()[:n], pt.numpy()) < 1e-5
+
+
+def test_simple_depth_objective_vs_torch():
+    """slow_depth's objective (src/simple_depth.jl:25-42): one full-resolution scale, raw-disparity smoothness, weight 1."""
+    N, C, H, W = 1, 3, 32, 64
+    r_ = np.random.default_rng(3)
+    x = syn.synthetic_triplets(N, C, H, W, seed=4); K, iK = syn.depth10k_intrinsics(W, H)
+    d = (r_.random((N, 1, H, W)) * 0.8 + 0.1).astype(np.float32)
+    rv = ((r_.random((2, N, 3)) - 0.5) * 0.02).astype(np.float32); tv = ((r_.random((2, N, 3)) - 0.5) * 0.2).astype(np.float32)
+    r = oracle.loss_fwd_bwd(x, oracle.make_cfg(N, C, H, W, K, iK, simple=True), [d], rv, tv)
+    dt = torch.tensor(d, dtype=torch.float64, requires_grad=True); rt = torch.tensor(rv, dtype=torch.float64, requires_grad=True); tt = torch.tensor(tv, dtype=torch.float64, requires_grad=True)
+    l = tr.simple_depth_loss(torch.tensor(x, dtype=torch.float64), dt, [(rt[0], tt[0]), (rt[1], tt[1])], torch.tensor(K), torch.tensor(iK)); l.backward()
+    assert abs(r["loss"] - l.item()) / l.item() < 1e-5
+    assert grad_close(r["ddisp"][0], dt.grad.numpy()) and rel(r["drvec"], rt.grad.numpy()) < 2e-3 and rel(r["dtvec"], tt.grad.numpy()) < 2e-3

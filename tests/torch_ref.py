@@ -198,3 +198,14 @@ def automasking_loss(x, target_id=2, source_ids=(1, 3)):
 def adam_step(p, g, m, v, t, eta=1e-4, b1=0.9, b2=0.999, eps=1e-8):
     m.mul_(b1).add_(g, alpha=1 - b1); v.mul_(b2).addcmul_(g, g, value=1 - b2)
     p.sub_(m / (1 - b1 ** t) / (torch.sqrt(v / (1 - b2 ** t)) + eps) * eta)
+
+
+def simple_depth_loss(x, disp, poses, K, invK, target_id=2, source_ids=(1, 3), min_depth=0.1, max_depth=100.0):
+    """slow_depth's objective, src/simple_depth.jl:25-42: mean(prediction_loss(warp(...))) + smooth_loss(disp) (weight 1, raw disparity)."""
+    N, L, C, H, W = x.shape
+    tgt = x[:, target_id - 1]
+    Ps = [composeT(r, t, sid < target_id) for (r, t), sid in zip(poses, source_ids)]
+    depth = disparity_to_depth(disp, min_depth, max_depth)
+    coords = backproject(depth.reshape(N, H * W), invK, H, W)
+    warped = [grid_sample(x[:, sid - 1], project(coords, K, R, t, H, W).view(N, H, W, 2), True) for (R, t), sid in zip(Ps, source_ids)]
+    return prediction_loss(warped, tgt).mean() + smooth_loss(disp[:, 0], tgt)
