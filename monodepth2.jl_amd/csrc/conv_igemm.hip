@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int e = 0; e < 4 * NV; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[A_LD], rb[B_LD];
-    const int cpt = a.Cin >> 4;                 // 16-channel chunks per tap
+    // split-K (small grids only): this block covers channel chunks [c_lo, c_hi) of every tap
+    const int cpt_all = a.Cin >> 4;             // 16-channel chunks per tap
+    const int c_lo = (int)blockIdx.y * cpt_all / a.ksplit, c_hi = ((int)blockIdx.y + 1) * cpt_all / a.ksplit;
+    const int cpt = c_hi - c_lo;
 
     // K order: channel chunk OUTER, filter tap INNER.  Consecutive steps then read the same 64-B lines shifted by one pixel
     // (L1/L2 hits); with taps outer the 9x re-read of every input pixel is ~15 MB of other blocks' traffic apart and misses
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
             else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
             a_mbits[j] |= ok ? (1u << t) : 0u;
-            a_off[t][j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * 4u : (unsigned)(q * 16);    // masked rows read a valid dummy address
+            a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * 4u : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address
         }
-        b_tap[t] = (unsigned)((kh * a.KW + kw) * a.Cin) * 4u;
+        b_tap[t] = (unsigned)((kh * a.KW + kw) * a.Cin) * 4u + (unsigned)(c_lo * 64);
     }
     const char* xb = reinterpret_cast<const char*>(a.x);
     const char* wb = reinterpret_cast<const char*>(a.w);
@@ -221,6 +224,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int g = 0; g < NV; ++g) {
                 const int co = c0 + wc * (BN / WC) + i * MF + (MF == 32 ? 8 * g + 4 * (lane >> 5) : 4 * (lane >> 4));
                 float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (a.ksplit > 1) {            // partial sum: (x act') is linear, bias/activation are applied by the launcher's second pass
+                    if (dp) { const float4 d = *reinterpret_cast<const float4*>(dp + co); v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(yp + co + e, v[e]);
+                    continue;
+                }
                 if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + co); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                 if (a.act != ACT_NONE) {
 #pragma unroll
@@ -240,11 +249,12 @@ template <int BM, int BN, int WP, int WC, int MF>
 static void launch_tile(const ConvArgs& a, hipStream_t s) {
     static_assert((BM / WP) % MF == 0 && (BN / WC) % MF == 0, "wave tile must be a multiple of the MFMA tile");
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
+    const dim3 g(grid, a.ksplit);
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
-        case 9: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), dim3(grid), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), dim3(grid), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), dim3(grid), dim3(256), 0, s, a); break;
-        case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), dim3(grid), dim3(256), 0, s, a); break;
+        case 9: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), g, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), g, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), g, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), g, dim3(256), 0, s, a); break;
         default: fprintf(stderr, "md2: conv_igemm: unsupported tap count %d\n", a.nkh * a.nkw); abort();
     }
 }
@@ -278,13 +288,33 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         }
 }
 
-static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s) {
+static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    a.ksplit = 1;
     // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
     const long x_elems = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), w_elems = 4 * ((long)a.Cout * a.KH * a.KW * a.Cin);   // byte offsets must fit 32 bits
     if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) ||
         a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) || w_elems >= (1L << 32)) {
         fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
         abort();
+    }
+    // Small pixel counts (batch 4: M = 208 ... 2496) give only tens of tiles with a serial K loop of up to 288 steps.  Split the
+    // channel chunks over gridDim.y (>= 2 chunks per split), sum with fp32 atomics into a zeroed output and apply bias /
+    // activation in a second elementwise pass.
+    {
+        const long tiles64 = (long)((a.M + 63) / 64) * (a.Cout / (a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : 16)));
+        const int cpt = a.Cin / 16;
+        static const int want = getenv("MD2_IGEMM_SPLIT_BLOCKS") ? atoi(getenv("MD2_IGEMM_SPLIT_BLOCKS")) : 512;
+        if (tiles64 < 100 && cpt >= 4 && want > 0) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
+    }
+    View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
+    const float* bias2 = nullptr; int act2 = ACT_NONE;
+    if (a.ksplit > 1) {
+        if (a.ostep != 1) a.ksplit = 1;                      // residue-class launches write a sub-lattice: keep them single-pass
+        else {
+            if (!a.accumulate) launch_fill_view(yv, 0.f, s);
+            bias2 = a.bias; act2 = a.act; a.bias = nullptr; a.act = ACT_NONE;
+        }
     }
     const long tiles128 = (long)((a.M + 127) / 128);
 #ifdef MD2_ABLATE
@@ -300,6 +330,7 @@ static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s) {
     if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= 384) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
+    if (a.ksplit > 1 && (bias2 || act2 != ACT_NONE)) launch_bias_act_view(yv, bias2, act2, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -398,4 +398,27 @@ void launch_adam(float* p, const float* g, float* m, float* v, long n, float c1,
 __global__ void fill_kernel(float* p, long n, float v) { for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v; }
 void launch_fill(float* p, long n, float v, hipStream_t s) { hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, n, v); }
 
+__global__ __launch_bounds__(256) void fill_view_kernel(View v, float val) {
+    const int Q = v.C / 4; const long total = v.pixels() * Q; const int HW = v.H * v.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
+        st4(vptrw(v, n, r) + q * 4, make_float4(val, val, val, val));
+    }
+}
+void launch_fill_view(const View& v, float val, hipStream_t s) { hipLaunchKernelGGL(fill_view_kernel, dim3(grid_for(v.pixels() * (v.C / 4), 256, 4096)), dim3(256), 0, s, v, val); }
+__global__ __launch_bounds__(256) void bias_act_view_kernel(View y, const float* __restrict__ bias, int act) {
+    const int Q = y.C / 4; const long total = y.pixels() * Q; const int HW = y.H * y.W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
+        float* yp = vptrw(y, n, r) + q * 4;
+        float4 v = ld4(yp);
+        if (bias) { const float4 b = ld4(bias + q * 4); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+        st4(yp, v);
+    }
+}
+void launch_bias_act_view(const View& y, const float* bias, int act, hipStream_t s) {
+    hipLaunchKernelGGL(bias_act_view_kernel, dim3(grid_for(y.pixels() * (y.C / 4), 256, 4096)), dim3(256), 0, s, y, bias, act);
+}
+
 }  // namespace md2

@@ -58,6 +58,7 @@ struct ConvArgs {
     int oy0, ox0, ostep, Hl, Wl;
     // tap lattice: taps kh = kh0 + a*khs (a < nkh), kw = kw0 + b*kws (b < nkw)   (dense: 0,1,KH / 0,1,KW)
     int kh0, khs, nkh, kw0, kws, nkw;
+    int ksplit;                   // set by the launcher: >1 = the channel chunks are split over gridDim.y and summed with fp32 atomics
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only
 #endif
@@ -119,6 +120,9 @@ void launch_pose_mean_fwd(const View& y, float* rvec, float* tvec, hipStream_t s
 void launch_pose_mean_bwd(const float* drvec, const float* dtvec, const View& dy, hipStream_t s);
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float c1, float c2, float lr, float gscale, hipStream_t s);
 void launch_fill(float* p, long n, float v, hipStream_t s);
+void launch_fill_view(const View& v, float val, hipStream_t s);
+// y = act(y + bias[c])   (second pass of a split-K convolution)
+void launch_bias_act_view(const View& y, const float* bias, int act, hipStream_t s);
 
 // ---- loss kernels (loss.hip) --------------------------------------------------------------------
 struct LossArgs {
