@@ -19,6 +19,10 @@ sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+# HBM bytes per launch from the rocprofv3 PMC passes of THIS workload (B=32, C=1, 416x128), profiles/r01_pmc_hbm_traffic.md:
+# separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units, FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE exact.
+# PMC counters cannot be collected from inside bench.py, so the committed measurement is reported (null for other workloads).
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {"conv_igemm": 94.0e6, "conv_wgrad": 147.7e6, "loss_fwd": 236.0e6, "loss_bwd": 405.1e6}
 
 
 def cpu_baseline(C, H, W, seconds_budget=25.0):
@@ -123,7 +127,9 @@ def main():
         md.profile(model, False)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<*> (fwd + input-gradient implicit GEMMs, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
-                           "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                           "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                           "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH["conv_igemm"] if (B, C, H, W) == (32, 1, 128, 416) else None,
+                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1)}
         extra = {}
         if wg["ms"] > 0:
@@ -133,7 +139,9 @@ def main():
             if p["ms"] > 0:
                 a = p["bytes"] / (p["ms"] * 1e-3) / 1e9
                 extra[nm] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "ms_per_step": p["ms"] / 3,
-                             "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1)}
+                             "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1),
+                             "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH[nm[len("roofline_"):]] if (B, C, H, W) == (32, 1, 128, 416) else None,
+                             "note": "instruction-bound, not HBM-bound: ~350-550 VALU instructions per pixel and scale (DESIGN.md section 4)"}
         if world == 1 and not args.no_extra and B != 4:
             # BASELINE.json configs[1]: batch = 4 on one MI355X
             del dp, model

@@ -21,8 +21,20 @@ constexpr int MAXC = 3;
 
 struct Pose12 { float R[9]; float t[3]; };   // column-major R
 
+// v_rcp_f32 / v_exp_f32 (1 ulp / ~2 ulp): an IEEE fp32 division is ~10 VALU instructions and the fused loss kernels were
+// instruction-bound (~20 divisions per pixel and scale); the 1e-7 relative differences are far inside the 1e-4 parity budget.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+
 __device__ __forceinline__ void up_src_f(int o, int in, int out, int& i0, int& i1, float& w1) {
     const float ratio = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float s = ratio * (float)o;
+    i0 = min((int)floorf(s), in - 1);
+    i1 = min(i0 + 1, in - 1);
+    w1 = s - (float)i0;
+}
+// same with the ratio precomputed on the host (identical fp32 value: (in-1)/(out-1) rounded once)
+__device__ __forceinline__ void up_src_r(int o, int in, float ratio, int& i0, int& i1, float& w1) {
     const float s = ratio * (float)o;
     i0 = min((int)floorf(s), in - 1);
     i1 = min(i0 + 1, in - 1);
@@ -32,14 +44,15 @@ __device__ __forceinline__ void up_src_f(int o, int in, int out, int& i0, int& i
 __device__ __forceinline__ float disp_at(const float* __restrict__ d, int dh, int dw, int H, int W, int py, int px) {
     if (dh == H && dw == W) return d[(long)py * W + px];
     int h0, h1, w0, w1; float fh, fw;
-    up_src_f(py, dh, H, h0, h1, fh); up_src_f(px, dw, W, w0, w1, fw);
+    const float rh = H > 1 ? (float)(dh - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(dw - 1) / (float)(W - 1) : 0.f;   // block-uniform -> scalar unit
+    up_src_r(py, dh, rh, h0, h1, fh); up_src_r(px, dw, rw, w0, w1, fw);
     return (1.f - fh) * ((1.f - fw) * d[h0 * dw + w0] + fw * d[h0 * dw + w1]) + fh * ((1.f - fw) * d[h1 * dw + w0] + fw * d[h1 * dw + w1]);
 }
 struct Proj { float x, y, mx, my; float P[3]; float c[3]; float denom; };
 // disparity_to_depth + Backproject + Project + grid-sample coordinate (src/utils.jl:175-179,63-65,95-99; NNlib unnormalize + :border clamp)
 __device__ __forceinline__ void project_px(float d, int py, int px, const float* __restrict__ K, const float* __restrict__ invK, const Pose12& T,
                                            float min_disp, float max_disp, int H, int W, Proj& o) {
-    const float depth = 1.f / (d * (max_disp - min_disp) + min_disp);
+    const float depth = frcp(d * (max_disp - min_disp) + min_disp);
     const float cx = (float)(px + 1), cy = (float)(py + 1);
 #pragma unroll
     for (int i = 0; i < 3; ++i) o.P[i] = depth * (invK[i] * cx + invK[3 + i] * cy + invK[6 + i] * 1.f);
@@ -48,9 +61,10 @@ __device__ __forceinline__ void project_px(float d, int py, int px, const float*
     for (int i = 0; i < 3; ++i) r[i] = (T.R[i] * o.P[0] + T.R[3 + i] * o.P[1] + T.R[6 + i] * o.P[2]) + T.t[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) o.c[i] = K[i] * r[0] + K[3 + i] * r[1] + K[6 + i] * r[2];
-    o.denom = 1.f / (o.c[2] + 1e-7f);
-    const float gx = (((o.c[0] * o.denom - 1.f) / (float)(W - 1)) - 0.5f) * 2.f;
-    const float gy = (((o.c[1] * o.denom - 1.f) / (float)(H - 1)) - 0.5f) * 2.f;
+    o.denom = frcp(o.c[2] + 1e-7f);
+    const float rW = 1.f / (float)(W - 1), rH = 1.f / (float)(H - 1);        // uniform: evaluated once on the scalar/constant path
+    const float gx = (((o.c[0] * o.denom - 1.f) * rW) - 0.5f) * 2.f;
+    const float gy = (((o.c[1] * o.denom - 1.f) * rH) - 0.5f) * 2.f;
     float x = ((gx + 1.f) * 0.5f) * (float)(W - 1), y = ((gy + 1.f) * 0.5f) * (float)(H - 1);
     o.mx = 0.5f * (float)(W - 1); o.my = 0.5f * (float)(H - 1);
     if (!(x > 0.f)) { x = 0.f; o.mx = 0.f; } else if (x >= (float)(W - 1)) { x = (float)(W - 1); o.mx = 0.f; }
@@ -66,8 +80,10 @@ __device__ __forceinline__ void sample_setup(float x, float y, int H, int W, Sam
     s.v01 = vx1; s.v10 = vy1; s.v11 = vx1 && vy1;
     s.i00 = y0 * W + x0; s.i01 = y0 * W + (vx1 ? x1 : x0); s.i10 = (vy1 ? y1 : y0) * W + x0; s.i11 = (vy1 ? y1 : y0) * W + (vx1 ? x1 : x0);
 }
+// Branch-free gather: a corner that falls outside (only possible for x == W-1 / y == H-1 after the border clamp) is clamped
+// onto a valid texel by sample_setup and its bilinear weight is exactly 0, so it contributes 0 like NNlib's bounds check.
 __device__ __forceinline__ float sample_val(const float* __restrict__ im, const Samp& s) {
-    const float v00 = im[s.i00], v01 = s.v01 ? im[s.i01] : 0.f, v10 = s.v10 ? im[s.i10] : 0.f, v11 = s.v11 ? im[s.i11] : 0.f;
+    const float v00 = im[s.i00], v01 = im[s.i01], v10 = im[s.i10], v11 = im[s.i11];
     return v00 * s.wy0 * s.wx0 + v01 * s.wy0 * s.wx1 + v10 * s.wy1 * s.wx0 + v11 * s.wy1 * s.wx1;
 }
 
@@ -80,16 +96,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 struct SsimOut { float val; float g_mx, g_pxx, g_pxy; };   // SSIM value and d val / d(pool x, pool x^2, pool xy) (0 outside the clamp)
 // SSIM functor arithmetic (src/utils.jl:28-38) from the nine-sample window sums
 __device__ __forceinline__ void ssim_from_sums(float sx, float sy, float sxx, float syy, float sxy, bool want_grad, SsimOut& o) {
-    const float mx = sx / 9.f, my = sy / 9.f, pxx = sxx / 9.f, pyy = syy / 9.f, pxy = sxy / 9.f;
+    const float r9 = 1.f / 9.f;
+    const float mx = sx * r9, my = sy * r9, pxx = sxx * r9, pyy = syy * r9, pxy = sxy * r9;
     const float c1 = 0.0001f, c2 = 0.0009f;
     const float vx = pxx - mx * mx, vy = pyy - my * my, vxy = pxy - mx * my;
     const float n1 = 2.f * mx * my + c1, n2 = 2.f * vxy + c2, d1 = mx * mx + my * my + c1, d2 = vx + vy + c2;
-    const float sn = n1 * n2, sd = d1 * d2;
-    const float v = (1.f - sn / sd) * 0.5f;
+    const float sn = n1 * n2, sd = d1 * d2, rsd = frcp(sd);
+    const float v = (1.f - sn * rsd) * 0.5f;
     o.val = fminf(fmaxf(v, 0.f), 1.f);
     if (want_grad) {
         const float g = (v >= 0.f && v <= 1.f) ? 1.f : 0.f;
-        const float gsn = -0.5f * g / sd, gsd = 0.5f * g * sn / (sd * sd);
+        const float gsn = -0.5f * g * rsd, gsd = 0.5f * g * sn * rsd * rsd;
         const float gn1 = gsn * n2, gn2 = gsn * n1, gd1 = gsd * d2, gd2 = gsd * d1;
         o.g_pxx = gd2; o.g_pxy = 2.f * gn2;
         o.g_mx = gn1 * 2.f * my + gd1 * 2.f * mx - gd2 * 2.f * mx - 2.f * gn2 * my;
@@ -99,40 +116,64 @@ __device__ __forceinline__ void ssim_from_sums(float sx, float sy, float sxx, fl
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
+// forward-only projection: c = K (R P + t) = (K R) P + K t, P = depth * ray(px,py): 12 scalars per source instead of K, R, t
+struct ProjF { float M[9]; float v[3]; };       // M = K*R (column-major), v = K*t
+__device__ __forceinline__ void project_fwd(float depth, const float ray[3], const ProjF& T, int H, int W, float& x, float& y) {
+    const float P0 = depth * ray[0], P1 = depth * ray[1], P2 = depth * ray[2];
+    const float c0 = T.M[0] * P0 + T.M[3] * P1 + T.M[6] * P2 + T.v[0];
+    const float c1 = T.M[1] * P0 + T.M[4] * P1 + T.M[7] * P2 + T.v[1];
+    const float c2 = T.M[2] * P0 + T.M[5] * P1 + T.M[8] * P2 + T.v[2];
+    const float denom = frcp(c2 + 1e-7f);
+    const float rW = 1.f / (float)(W - 1), rH = 1.f / (float)(H - 1);
+    const float gx = (((c0 * denom - 1.f) * rW) - 0.5f) * 2.f, gy = (((c1 * denom - 1.f) * rH) - 0.5f) * 2.f;
+    x = ((gx + 1.f) * 0.5f) * (float)(W - 1); y = ((gy + 1.f) * 0.5f) * (float)(H - 1);
+    x = !(x > 0.f) ? 0.f : fminf(x, (float)(W - 1));       // :border clamp (NaN -> 0)
+    y = !(y > 0.f) ? 0.f : fminf(y, (float)(H - 1));
+}
+
+template <int C>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double* __restrict__ part) {
-    __shared__ float wv[2][MAXC][FH * FW];   // warped sources (padded positions)
-    __shared__ float tg[MAXC][FH * FW];      // target
+    __shared__ float wv[2][C][FH * FW];      // warped sources (padded positions)
+    __shared__ float tg[C][FH * FW];         // target
     __shared__ float dl[FH * FW];            // disparity
     __shared__ float red[4][4];
     const int zi = blockIdx.z, sc = zi / a.N, n = zi % a.N;
-    const int H = a.H, W = a.W, C = a.C;
+    const int H = a.H, W = a.W;
     const long P = (long)H * W;
     const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
     const float* xn = a.x + (long)n * 3 * C * P;
     const float* tgt = xn + (long)a.tgt * C * P;
     const float* srcs[2] = {xn + (long)a.src0 * C * P, xn + (long)a.src1 * C * P};
-    const float* dsp = a.disp[sc] + (long)n * a.dh[sc] * a.dw[sc];
-    Pose12 T[2];
+    const int dh = a.dh[sc], dw = a.dw[sc];
+    const float* dsp = a.disp[sc] + (long)n * dh * dw;
+    ProjF T[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const float* rt = a.Rt + ((long)s * a.N + n) * 12;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) T[s].R[i] = rt[i];
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) T[s].t[i] = rt[9 + i];
+            for (int i = 0; i < 3; ++i) T[s].M[j * 3 + i] = a.K[i] * rt[j * 3] + a.K[3 + i] * rt[j * 3 + 1] + a.K[6 + i] * rt[j * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[s].v[i] = a.K[i] * rt[9] + a.K[3 + i] * rt[10] + a.K[6 + i] * rt[11];
     }
     // ---- phase 1: warped / target / disparity at the padded positions of tile + 1
     for (int i = threadIdx.x; i < FH * FW; i += 256) {
         const int ry = i / FW, rx = i - ry * FW;
         const int py = refl_idx(min(ty0 - 1 + ry, H), H), px = refl_idx(min(tx0 - 1 + rx, W), W);   // positions past the padded image are never used
-        const float d = disp_at(dsp, a.dh[sc], a.dw[sc], H, W, py, px);
+        const float d = disp_at(dsp, dh, dw, H, W, py, px);
         dl[i] = d;
+        const float depth = frcp(d * (a.max_disp - a.min_disp) + a.min_disp);
+        const float cx = (float)(px + 1), cy = (float)(py + 1);
+        const float ray[3] = {a.invK[0] * cx + a.invK[3] * cy + a.invK[6], a.invK[1] * cx + a.invK[4] * cy + a.invK[7], a.invK[2] * cx + a.invK[5] * cy + a.invK[8]};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            Proj pr; project_px(d, py, px, a.K, a.invK, T[s], a.min_disp, a.max_disp, H, W, pr);
-            Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
+            float x, y; project_fwd(depth, ray, T[s], H, W, x, y);
+            Samp sm; sample_setup(x, y, H, W, sm);
+#pragma unroll
             for (int c = 0; c < C; ++c) wv[s][c][i] = sample_val(srcs[s] + (long)c * P, sm);
         }
+#pragma unroll
         for (int c = 0; c < C; ++c) tg[c][i] = tgt[(long)c * P + (long)py * W + px];
     }
     __syncthreads();
@@ -143,31 +184,28 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double* __res
         const int ly = i / TW, lx = i - ly * TW, py = ty0 + ly, px = tx0 + lx;
         if (py >= H || px >= W) continue;
         const int ctr = (ly + 1) * FW + lx + 1;
-        float pl[2];
+        float pl[2] = {0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float ss = 0.f, l1 = 0.f;
-            for (int c = 0; c < C; ++c) {
-                float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float yw[9], sy = 0.f, syy = 0.f;                  // target window: shared by both sources
 #pragma unroll
-                for (int dy = -1; dy <= 1; ++dy)
+            for (int k = 0; k < 9; ++k) { yw[k] = tg[c][ctr + (k / 3 - 1) * FW + (k % 3 - 1)]; sy += yw[k]; syy += yw[k] * yw[k]; }
 #pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const float xv = wv[s][c][ctr + dy * FW + dx], yv = tg[c][ctr + dy * FW + dx];
-                        sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
-                    }
+            for (int s = 0; s < 2; ++s) {
+                float sx = 0.f, sxx = 0.f, sxy = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { const float xv = wv[s][c][ctr + (k / 3 - 1) * FW + (k % 3 - 1)]; sx += xv; sxx += xv * xv; sxy += xv * yw[k]; }
                 SsimOut so; ssim_from_sums(sx, sy, sxx, syy, sxy, false, so);
-                ss += so.val; l1 += fabsf(tg[c][ctr] - wv[s][c][ctr]);
+                pl[s] += alpha * invC * so.val + beta * invC * fabsf(yw[4] - wv[s][c][ctr]);
             }
-            pl[s] = alpha * (ss * invC) + beta * (l1 * invC);
         }
         float wl = pl[1] < pl[0] ? pl[1] : pl[0];
         if (a.auto_loss) { const float al = a.auto_loss[(long)n * P + (long)py * W + px]; if (!(wl < al)) wl = al; }
         s_photo += wl;
         const float d = dl[ctr];
         s_d += d;
-        if (px + 1 < W) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][ctr] - tg[c][ctr + 1]); if (C > 1) gi *= invC; s_x += fabsf(d - dl[ctr + 1]) * expf(-gi); }
-        if (py + 1 < H) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][ctr] - tg[c][ctr + FW]); if (C > 1) gi *= invC; s_y += fabsf(d - dl[ctr + FW]) * expf(-gi); }
+        if (px + 1 < W) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][ctr] - tg[c][ctr + 1]); if (C > 1) gi *= invC; s_x += fabsf(d - dl[ctr + 1]) * fexp(-gi); }
+        if (py + 1 < H) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][ctr] - tg[c][ctr + FW]); if (C > 1) gi *= invC; s_y += fabsf(d - dl[ctr + FW]) * fexp(-gi); }
     }
     s_photo = wave_sum(s_photo); s_d = wave_sum(s_d); s_x = wave_sum(s_x); s_y = wave_sum(s_y);
     const int wave = threadIdx.x >> 6;
@@ -176,9 +214,10 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double* __res
     if (threadIdx.x < 4) atomicAdd(part + (long)zi * 4 + threadIdx.x, (double)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 void launch_loss_fwd(const LossArgs& a, double* part, hipStream_t s) {
-    if (a.C > MAXC || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_fwd: unsupported C=%d H=%d W=%d\n", a.C, a.H, a.W); abort(); }
+    if ((a.C != 1 && a.C != 3) || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_fwd: unsupported C=%d H=%d W=%d\n", a.C, a.H, a.W); abort(); }
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N * a.nscales);
-    hipLaunchKernelGGL(loss_fwd_kernel, grid, dim3(256), 0, s, a, part);
+    if (a.C == 1) hipLaunchKernelGGL(loss_fwd_kernel<1>, grid, dim3(256), 0, s, a, part);
+    else hipLaunchKernelGGL(loss_fwd_kernel<3>, grid, dim3(256), 0, s, a, part);
 }
 
 // totals[(sc*N+n)*4 + {0: photo sum, 1: mean d, 2: Sx, 3: Sy}] ; loss = mean over scales of [mean(warp_loss) + smooth]
@@ -207,15 +246,16 @@ void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, 
 // =====================================================================================================================
 // backward
 // =====================================================================================================================
+template <int C>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* __restrict__ totals, float* __restrict__ ddisp_full, double* __restrict__ dRt_acc) {
-    __shared__ float wv[2][MAXC][BH2 * BW2];     // warped sources at padded positions of tile + 2
-    __shared__ float tg[MAXC][BH2 * BW2];
+    __shared__ float wv[2][C][BH2 * BW2];        // warped sources at padded positions of tile + 2
+    __shared__ float tg[C][BH2 * BW2];
     __shared__ float dl[BH2 * BW2];
-    __shared__ float coef[MAXC][3][FH * FW];     // d photometric_{s*} / d (pool x, pool x^2, pool xy) at q in tile + 1, pre-scaled
+    __shared__ float coef[C][3][FH * FW];        // d photometric_{s*} / d (pool x, pool x^2, pool xy) at q in tile + 1, pre-scaled
     __shared__ signed char amin[FH * FW];        // winning source at q, -1: none (outside / masked)
     __shared__ float red[4][24];
     const int zi = blockIdx.z, sc = zi / a.N, n = zi % a.N;
-    const int H = a.H, W = a.W, C = a.C;
+    const int H = a.H, W = a.W;
     const long P = (long)H * W;
     const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
     const float* xn = a.x + (long)n * 3 * C * P;
@@ -256,27 +296,23 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
         signed char win = -1;
         if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
             const int ctr = (ry + 1) * BW2 + rx + 1;
-            float pl[2]; SsimOut so[2][MAXC];
+            float pl[2] = {0.f, 0.f}; SsimOut so[2][C];
+            for (int c = 0; c < C; ++c) {
+                float yw[9], sy = 0.f, syy = 0.f;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float ss = 0.f, l1 = 0.f;
-                for (int c = 0; c < C; ++c) {
-                    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+                for (int k = 0; k < 9; ++k) { yw[k] = tg[c][ctr + (k / 3 - 1) * BW2 + (k % 3 - 1)]; sy += yw[k]; syy += yw[k] * yw[k]; }
 #pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
+                for (int s = 0; s < 2; ++s) {
+                    float sx = 0.f, sxx = 0.f, sxy = 0.f;
 #pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const float xv = wv[s][c][ctr + dy * BW2 + dx], yv = tg[c][ctr + dy * BW2 + dx];
-                            sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
-                        }
+                    for (int k = 0; k < 9; ++k) { const float xv = wv[s][c][ctr + (k / 3 - 1) * BW2 + (k % 3 - 1)]; sx += xv; sxx += xv * xv; sxy += xv * yw[k]; }
                     ssim_from_sums(sx, sy, sxx, syy, sxy, true, so[s][c]);
-                    ss += so[s][c].val; l1 += fabsf(tg[c][ctr] - wv[s][c][ctr]);
+                    pl[s] += alpha * invC * so[s][c].val + beta * invC * fabsf(yw[4] - wv[s][c][ctr]);
                 }
-                pl[s] = alpha * (ss * invC) + beta * (l1 * invC);
             }
             win = pl[1] < pl[0] ? 1 : 0;                                             // first arg-min (Zygote `minimum`)
             if (a.auto_loss && !(pl[win] < a.auto_loss[(long)n * P + (long)qy * W + qx])) win = -1;   // mask wins ties -> no gradient
-            const float g = wpix * alpha * invC / 9.f;                               // through mean_c, alpha, and the /9 of MeanPool
+            const float g = wpix * alpha * invC * (1.f / 9.f);                       // through mean_c, alpha, and the /9 of MeanPool
             for (int c = 0; c < C; ++c) {
                 const SsimOut& o = so[win < 0 ? 0 : win][c];
                 const float m = win < 0 ? 0.f : g;
@@ -310,7 +346,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
         const int rwin = amin[(ly + 1) * FW + lx + 1];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            float gw[MAXC];
+            float gw[C];
             bool any = false;
             for (int c = 0; c < C; ++c) {
                 float g = 0.f;
@@ -341,13 +377,13 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
             float ggx = 0.f, ggy = 0.f;
             for (int c = 0; c < C; ++c) {
                 const float* im = srcs[s] + (long)c * P;
-                const float v00 = im[sm.i00], v01 = sm.v01 ? im[sm.i01] : 0.f, v10 = sm.v10 ? im[sm.i10] : 0.f, v11 = sm.v11 ? im[sm.i11] : 0.f;
+                const float v00 = im[sm.i00], v01 = sm.v01 ? im[sm.i01] : 0.f, v10 = sm.v10 ? im[sm.i10] : 0.f, v11 = sm.v11 ? im[sm.i11] : 0.f;   // NNlib: outside corners read as 0 in the coordinate pullback
                 ggx += gw[c] * ((v01 - v00) * sm.wy0 + (v11 - v10) * sm.wy1);
                 ggy += gw[c] * ((v10 - v00) * sm.wx0 + (v11 - v01) * sm.wx1);
             }
             ggx *= pr.mx; ggy *= pr.my;                  // unnormalise: (size-1)/2, 0 where clamped
             // Project pullback (normalise: *2/(size-1))
-            const float gu = ggx * 2.f / (float)(W - 1), gv = ggy * 2.f / (float)(H - 1);
+            const float gu = ggx * (2.f / (float)(W - 1)), gv = ggy * (2.f / (float)(H - 1));
             const float gc[3] = {gu * pr.denom, gv * pr.denom, -(gu * pr.c[0] + gv * pr.c[1]) * pr.denom * pr.denom};
             float gr[3];
 #pragma unroll
@@ -367,13 +403,14 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
 #pragma unroll
             for (int k = 0; k < 3; ++k) gdepth += gP[k] * (a.invK[k] * cx + a.invK[3 + k] * cy + a.invK[6 + k]);
             const float dd = d * (a.max_disp - a.min_disp) + a.min_disp;
-            gd += -gdepth * (a.max_disp - a.min_disp) / (dd * dd);
+            const float rdd = frcp(dd);
+            gd += -gdepth * (a.max_disp - a.min_disp) * rdd * rdd;
         }
         // smooth_loss(d / (mean + eps)) pullback
         float gs = -corr;
         auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
-        auto ex = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + 1]); if (C > 1) gi *= invC; return expf(-gi); };
-        auto ey = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + BW2]); if (C > 1) gi *= invC; return expf(-gi); };
+        auto ex = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + 1]); if (C > 1) gi *= invC; return fexp(-gi); };
+        auto ey = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + BW2]); if (C > 1) gi *= invC; return fexp(-gi); };
         if (px + 1 < W) gs += ax * sgn(d - dl[cb + 1]) * ex(cb);
         if (px >= 1) gs -= ax * sgn(dl[cb - 1] - d) * ex(cb - 1);
         if (py + 1 < H) gs += ay * sgn(d - dl[cb + BW2]) * ey(cb);
@@ -396,9 +433,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
     }
 }
 void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, hipStream_t s) {
-    if (a.C > MAXC || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_bwd: unsupported shape\n"); abort(); }
+    if ((a.C != 1 && a.C != 3) || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_bwd: unsupported shape\n"); abort(); }
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N * a.nscales);
-    hipLaunchKernelGGL(loss_bwd_kernel, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc);
+    if (a.C == 1) hipLaunchKernelGGL(loss_bwd_kernel<1>, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc);
+    else hipLaunchKernelGGL(loss_bwd_kernel<3>, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc);
 }
 
 // =====================================================================================================================
