@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     const float4 d = *reinterpret_cast<const float4*>(dp + co);
                     v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact);
                 }
-                if (a.accumulate) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
                 *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
             }
     }
@@ -281,7 +281,7 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
             b.M = a.N * b.Hl * b.Wl;
             if (b.M <= 0) continue;
             if (b.nkh == 0 || b.nkw == 0) {
-                if (!a.accumulate) { fprintf(stderr, "md2: conv_igemm: empty tap phase needs accumulate or a zeroed output\n"); abort(); }
+                if (a.accumulate != 1) { fprintf(stderr, "md2: conv_igemm: empty tap phase needs accumulate or a zeroed output\n"); abort(); }
                 continue;                                     // nothing to add for this residue class
             }
             launch_conv_igemm_one(b, s);
@@ -313,6 +313,10 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
         if (a.ostep != 1) a.ksplit = 1;                      // residue-class launches write a sub-lattice: keep them single-pass
         else {
             if (!a.accumulate) launch_fill_view(yv, 0.f, s);
+            else if (a.accumulate == 2) {                    // only the middle frame of every triplet holds earlier contributions
+                if (a.N % 3) { fprintf(stderr, "md2: conv_igemm: accumulate mode 2 needs a 3-frame batch\n"); abort(); }
+                for (int l = 0; l < 3; l += 2) { View f = yv; f.p = yv.p + (long)l * yv.bs; f.N = yv.N / 3; f.bs = yv.bs * 3; launch_fill_view(f, 0.f, s); }
+            }
             bias2 = a.bias; act2 = a.act; a.bias = nullptr; a.act = ACT_NONE;
         }
     }
@@ -530,7 +534,8 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
         fprintf(stderr, "md2: conv_wgrad: unsupported shape Cin=%d Cout=%d M=%d\n", a.Cin, a.Cout, a.M);
         abort();
     }
-    if (a.Cin % 128 == 0 && a.Cout % 128 == 0) launch_wgrad_tile<128, 16, 32>(a, s);
+    static const int max_t = getenv("MD2_WGRAD_MAXT") ? atoi(getenv("MD2_WGRAD_MAXT")) : 128;
+    if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && max_t >= 128) launch_wgrad_tile<128, 16, 32>(a, s);
     else if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 32, 32>(a, s);
     else if (a.Cin % 32 == 0 && a.Cout % 32 == 0) launch_wgrad_tile<32, 32, 16>(a, s);
     else launch_wgrad_tile<16, 64, 16>(a, s);
@@ -544,6 +549,18 @@ __global__ void weight_to_dgrad_kernel(const float* __restrict__ wf, float* __re
         const int co = i % Cout; const long r = i / Cout; const int tp = r % taps; const int ci = r / taps;
         wd[i] = wf[((long)co * taps + (taps - 1 - tp)) * Cin + ci];
     }
+}
+// all convolutions in one launch: desc[i] = {offset, CoutP, CinP, taps} (offsets into both flat buffers), blockIdx.y = layer
+__global__ void weight_to_dgrad_batched_kernel(const float* __restrict__ wf, float* __restrict__ wd, const long* __restrict__ desc) {
+    const long off = desc[blockIdx.y * 4]; const int Cout = (int)desc[blockIdx.y * 4 + 1], Cin = (int)desc[blockIdx.y * 4 + 2], taps = (int)desc[blockIdx.y * 4 + 3];
+    const long n = (long)Cout * Cin * taps;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int co = i % Cout; const long r = i / Cout; const int tp = r % taps; const int ci = r / taps;
+        wd[off + i] = wf[off + ((long)co * taps + (taps - 1 - tp)) * Cin + ci];
+    }
+}
+void launch_weight_to_dgrad_batched(const float* w_fwd, float* w_dg, const long* desc_dev, int nlayers, hipStream_t s) {
+    hipLaunchKernelGGL(weight_to_dgrad_batched_kernel, dim3(64, nlayers), dim3(256), 0, s, w_fwd, w_dg, desc_dev);
 }
 void launch_weight_to_dgrad(const float* w_fwd, float* w_dg, int CoutP, int CinP, int taps, hipStream_t s) {
     const long n = (long)CoutP * CinP * taps;

@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t
             }
         }
         float* dp = vptrw(dx, n, r) + q * 4;
-        if (accumulate) { const float4 o = ld4(dp); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
+        if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1)) {      // earlier contributions are already masked (mask^2 == mask)
+            const float4 o = ld4(dp); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
         if (has_xact) { const float4 o = ld4(vptr(xact, n, r) + q * 4); g[0] *= act_deriv(o.x, ACT_RELU); g[1] *= act_deriv(o.y, ACT_RELU); g[2] *= act_deriv(o.z, ACT_RELU); g[3] *= act_deriv(o.w, ACT_RELU); }
         st4(dp, make_float4(g[0], g[1], g[2], g[3]));
     }

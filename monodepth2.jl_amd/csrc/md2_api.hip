@@ -60,6 +60,7 @@ struct md2_handle {
     View gA[5], dZ1[5], dupv[5]; float* dxpad = nullptr; float* ddisp_lo[4] = {nullptr, nullptr, nullptr, nullptr};
     float *E1 = nullptr, *E2 = nullptr, *E3 = nullptr;
     View dpy3, dpy2, dpy1, dsq;
+    long* wdesc_dev = nullptr; int n_wdesc = 0;
     bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
 
     template <class T> T* alloc(size_t count) {
@@ -357,10 +358,12 @@ static int model_backward(md2_handle* h) {
     hipStream_t s = h->stream;
     const int N = h->N, NL = h->NL, H = h->H, W = h->W;
     HIPCHK(hipMemsetAsync(h->G, 0, (size_t)h->n_int * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(h->gzero_begin, 0, h->gzero_bytes, s));
     HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
-    // transposed / flipped weight copies for the input-gradient GEMMs
-    for (ConvL* c : h->convs) if (c->kind == 0) launch_weight_to_dgrad(h->P + c->w, h->WD + c->w, c->coutP, c->cinP, c->taps, s);
+    // The gradient accumulators (Gfeat / Gblk / Gpool, 715 MB at B=32) are NOT zeroed: every buffer's first writer overwrites
+    // (accumulate 0) and later writers add.  Stage buffers receive decoder / pose contributions in the target frame before the
+    // encoder pullback reaches them, so the encoder's first writer uses accumulate mode 2 (add only in target frames).
+    // transposed / flipped weight copies for the input-gradient GEMMs: one launch for all layers
+    launch_weight_to_dgrad_batched(h->P, h->WD, h->wdesc_dev, h->n_wdesc, s);
 
     // ---- depth decoder
     for (int l = 0; l < 4; ++l) {
@@ -379,14 +382,14 @@ static int model_backward(md2_handle* h) {
         launch_fold_reflect(chan_slice(dcp, 0, dc), h->dupv[b], 0, nullptr, ACT_NONE, s);
         if (b < 4) {
             View fv = frame_view(h->feat[3 - b], 3, 1), gv = frame_view(h->Gfeat[3 - b], 3, 1);
-            launch_fold_reflect(chan_slice(dcp, dc, fv.C), gv, 1, &fv, ACT_RELU, s);
+            launch_fold_reflect(chan_slice(dcp, dc, fv.C), gv, 0, &fv, ACT_RELU, s);      // first writer of this stage's target frames
         }
         launch_upsample2x_bwd(h->dupv[b], h->dZ1[b], &h->y1[b], ACT_ELU, s);
         const View& in = (b == 0) ? frame_view(h->feat[4], 3, 1) : h->y2[b - 1];
         conv_wgrad(h, h->dc1[b], in, h->dZ1[b], PAD_REFLECT);
         View dip = make_view(h->dxpad, N, in.H + 2, in.W + 2, in.C);
         conv_dgrad(h, h->dc1[b], h->dZ1[b], dip, 0, 0, nullptr, ACT_NONE);
-        if (b == 0) { View fv = frame_view(h->feat[4], 3, 1), gv = frame_view(h->Gfeat[4], 3, 1); launch_fold_reflect(dip, gv, 1, &fv, ACT_RELU, s); }
+        if (b == 0) { View fv = frame_view(h->feat[4], 3, 1), gv = frame_view(h->Gfeat[4], 3, 1); launch_fold_reflect(dip, gv, 0, &fv, ACT_RELU, s); }   // first writer of Gfeat[4] frame 1
         else launch_fold_reflect(dip, h->gA[b - 1], (b - 1) >= 1 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);
     }
     // ---- pose decoder
@@ -403,7 +406,7 @@ static int model_backward(md2_handle* h) {
             View d = h->dsq; d.p += (long)sidx * N * d.bs; d.N = N; d = chan_slice(d, j * 256, 256);
             View fv = frame_view(h->feat[4], 3, fr[sidx][j]), gv = frame_view(h->Gfeat[4], 3, fr[sidx][j]);
             conv_wgrad(h, h->squeeze, fv, d, PAD_ZERO);
-            conv_dgrad(h, h->squeeze, d, gv, 0, 1, &fv, ACT_RELU);
+            conv_dgrad(h, h->squeeze, d, gv, 0, fr[sidx][j] == 1 ? 1 : 0, &fv, ACT_RELU);   // frames 0 and 2 get exactly one contribution; frame 1 adds to the depth decoder's
         }
     // ---- encoder
     for (int i = 7; i >= 0; --i) {
@@ -417,7 +420,9 @@ static int model_backward(md2_handle* h) {
         conv_dgrad(h, B.c2, dz2, da1, 1, 0, &B.a1, ACT_RELU);
         bn_bwd(h, B.b1, da1, B.z1, dz1);
         conv_wgrad(h, B.c1, B.in, dz1, PAD_ZERO);
-        conv_dgrad(h, B.c1, dz1, *Gin, 1, 1, in_act, ACT_RELU);
+        // first encoder writer of Gin: own buffers (odd i, and the pool gradient) are overwritten; stage buffers (even i > 0) already hold
+        // the decoder's contribution in the target frames
+        conv_dgrad(h, B.c1, dz1, *Gin, 1, (i == 0 || (i & 1)) ? 0 : 2, in_act, ACT_RELU);
         if (B.down) {
             View dzd = make_view(h->E1, NL, B.zd.H, B.zd.W, B.zd.C);
             bn_bwd(h, B.bd, Gout, B.zd, dzd);
@@ -426,7 +431,7 @@ static int model_backward(md2_handle* h) {
         } else
             launch_axpy_view(Gout, *Gin, 1.f, 1, in_act, ACT_RELU, s);
     }
-    launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 1, &h->a0, s);
+    launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->a0, s);        // Gfeat[0]: decoder skip gradient in the target frames only
     {
         View dz0 = make_view(h->E1, NL, H / 2, W / 2, 64);
         bn_bwd(h, h->stem_bn, h->Gfeat[0], h->z0, dz0);
@@ -465,6 +470,13 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
         hipMalloc((void**)&h->V, pb) != hipSuccess || hipMalloc((void**)&h->WD, pb) != hipSuccess) return fail("hipMalloc(params) failed");
     (void)hipMemset(h->P, 0, pb); (void)hipMemset(h->G, 0, pb); (void)hipMemset(h->M, 0, pb); (void)hipMemset(h->V, 0, pb); (void)hipMemset(h->WD, 0, pb);
     (void)hipMemset(h->arena, 0, need);
+    {   // layer table of the batched weight transform
+        std::vector<long> d;
+        for (ConvL* c : h->convs) if (c->kind == 0) { d.push_back(c->w); d.push_back(c->coutP); d.push_back(c->cinP); d.push_back(c->taps); }
+        h->n_wdesc = (int)d.size() / 4;
+        if (hipMalloc((void**)&h->wdesc_dev, d.size() * sizeof(long)) != hipSuccess) return fail("hipMalloc(wdesc) failed");
+        (void)hipMemcpy(h->wdesc_dev, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice);
+    }
     // default intrinsics: Depth10k (src/dtk.jl:16-22) scaled to the image size
     const double f = 2648.0 / 4.63461538462 * (h->W / 416.0), cx = h->W / 2.0, cy = h->H / 2.0;
     const float Kc[9] = {(float)f, 0, 0, 0, (float)f, 0, (float)cx, (float)cy, 1};
@@ -477,7 +489,7 @@ int32_t md2_destroy(md2_handle* h) {
     if (!h) return 0;
     (void)hipDeviceSynchronize();
     for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD);
+    (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD);
     delete h; return 0;
 }
 int32_t md2_set_stream(md2_handle* h, void* st) { h->stream = (hipStream_t)st; return 0; }

@@ -51,7 +51,7 @@ struct ConvArgs {
     const float* w;
     float* y; long y_bs; int y_ps; int Ho, Wo, Cout;
     int N, KH, KW, stride, pad, dil, padmode;
-    const float* bias; int act; int accumulate;
+    const float* bias; int act; int accumulate;               // accumulate: 0 overwrite, 1 add to y, 2 add only where (batch index % 3) == 1 (target frames)
     const float* dact_src; long da_bs; int da_ps; int dact;   // optional: multiply by act_deriv(dact_src[n,oh,ow,co])
     int M;                                                    // N*Hl*Wl
     // output lattice: this launch produces pixels (oy0 + i*ostep, ox0 + j*ostep), i < Hl, j < Wl (dense: 0,0,1,Ho,Wo)
@@ -81,6 +81,7 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 //   fwd    : [CoutP][KH*KW][CinP] cross-correlation taps                       (internal parameter storage)
 //   dgrad  : [CinP][KH*KW flipped][CoutP]                                       (per-step transposed copy)
 void launch_weight_to_dgrad(const float* w_fwd, float* w_dg, int CoutP, int CinP, int taps, hipStream_t s);
+void launch_weight_to_dgrad_batched(const float* w_fwd, float* w_dg, const long* desc_dev, int nlayers, hipStream_t s);
 
 // ---- 3x3 reflect-pad conv with ONE output channel (disparity heads, src/depth_decoder.jl:43) ------
 void launch_head_fwd(const View& x, const float* w /*[9][Cin]*/, const float* b, const View& y /*C=1, sigmoid*/, hipStream_t s);
@@ -104,7 +105,7 @@ void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View&
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc,
                          double count, const View& dz, float* dgamma, float* dbeta, hipStream_t s);
 void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s);
-// dx (+)= scatter of dy by arg, gather form; optional multiply by relu'(xact)
+// dx (+)= scatter of dy by arg, gather form; optional multiply by relu'(xact).  accumulate as in ConvArgs (0 / 1 / 2)
 void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* xact, hipStream_t s);
 void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s);
 // dx = adjoint(up2)(dy) * act_deriv(xact)
