@@ -475,6 +475,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
     __syncthreads();
     read_ops(o0, cur);
     for (int s = s_begin; s < s_end; ++s) {
+#ifdef MD2_ABLATE
+        if (!(a.ablate & 1)) gload();
+        if (!(a.ablate & 2)) read_ops(o1, nxt);
+        if (!(a.ablate & 4)) mfmas(cur);
+        if (!(a.ablate & 2)) lstore(o2);
+        if (!(a.ablate & 8)) __syncthreads();
+        cur = nxt;
+        { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
+        continue;
+#endif
         gload();
         read_ops(o1, nxt);
         mfmas(cur);
@@ -483,6 +493,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
         cur = nxt;
         { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
     }
+#ifdef MD2_ABLATE
+    if (a.ablate & 16) { if (acc[0][0][0] == 123.456f) a.dw[0] = 1.f; return; }      // skip the atomic epilogue
+#endif
 
     const int taps = a.KH * a.KW;
     if (KSPLIT) {
@@ -519,10 +532,12 @@ template <int T, int BKP, int MF>
 static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     const int tiles = (a.Cout / T) * (a.Cin / T), taps = a.KH * a.KW;
     const int steps_total = (a.M + BKP - 1) / BKP;
-    // Split the pixel (K) range until the grid has ~2048 blocks (measured on MI355X: 512 -> 56, 1024 -> 64, 1536..6144 -> 70 TFLOP/s
-    // over the whole network; the fp32-atomic epilogue is not the limiter).
-    static int target = getenv("MD2_WGRAD_BLOCKS") ? atoi(getenv("MD2_WGRAD_BLOCKS")) : 2048;
-    int splitk = (target + tiles * taps - 1) / (tiles * taps);
+    // Split the pixel (K) range to fill the chip; every split adds one dW tile of fp32 atomics (2.2 GB/step in total at B=32).
+    // measured on MI355X (tools/conv_bench, WGRAD=1): the 128-wide tile is resident 2 blocks per CU and is fastest with ONE round of
+    // 512 blocks (75 vs 60-69 TFLOP/s at 768-4608); the narrower tiles prefer ~1536 blocks
+    static const int target_env = getenv("MD2_WGRAD_BLOCKS") ? atoi(getenv("MD2_WGRAD_BLOCKS")) : 0;
+    const int target = target_env > 0 ? target_env : (T == 128 ? 512 : 1536);
+    int splitk = std::max(1, target / (tiles * taps));          // round DOWN: one block over a multiple of the resident capacity costs a whole extra round
     splitk = std::max(1, std::min(splitk, (steps_total + 15) / 16));
     const int sps = (steps_total + splitk - 1) / splitk;
     splitk = (steps_total + sps - 1) / sps;

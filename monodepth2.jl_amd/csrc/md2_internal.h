@@ -73,6 +73,9 @@ struct WgradArgs {
     float* dw;
     int N, KH, KW, stride, pad, padmode;
     int M;
+#ifdef MD2_ABLATE
+    int ablate;
+#endif
 };
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 

@@ -3,6 +3,7 @@
 #include "../monodepth2.jl_amd/csrc/md2_internal.h"
 #include <vector>
 #include <cstdlib>
+#include <algorithm>
 using namespace md2;
 int main(int argc, char** argv) {
     int N = atoi(argv[1]), H = atoi(argv[2]), W = atoi(argv[3]), Cin = atoi(argv[4]), Cout = atoi(argv[5]), k = atoi(argv[6]);
@@ -20,6 +21,18 @@ int main(int argc, char** argv) {
     a.M = N * H * W; a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = H; a.Wl = W; a.kh0 = 0; a.khs = 1; a.nkh = k; a.kw0 = 0; a.kws = 1; a.nkw = k;
     a.ablate = abl; a.force_tile = tile;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    if (getenv("WGRAD")) {
+        float* dw; hipMalloc(&dw, nw * 4); hipMemset(dw, 0, nw * 4);
+        hipMemcpy(y, hx.data(), std::min(nx, ny) * 4, hipMemcpyHostToDevice);
+        WgradArgs g{};
+        g.x = x; g.x_bs = a.x_bs; g.x_ps = Cin; g.H = H; g.W = W; g.Cin = Cin; g.dy = y; g.dy_bs = a.y_bs; g.dy_ps = Cout; g.Ho = H; g.Wo = W; g.Cout = Cout;
+        g.dw = dw; g.N = N; g.KH = k; g.KW = k; g.stride = 1; g.pad = k / 2; g.padmode = 0; g.M = a.M; g.ablate = abl;
+        for (int i = 0; i < 3; ++i) launch_conv_wgrad(g, 0);
+        hipEventRecord(e0); const int reps = 20; for (int i = 0; i < reps; ++i) launch_conv_wgrad(g, 0); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+        printf("WGRAD N=%d HxW=%dx%d Cin=%d Cout=%d k=%d abl=%d : %.3f ms  %.1f TFLOP/s\n", N, H, W, Cin, Cout, k, abl, ms, 2.0 * a.M * Cout * k * k * Cin / (ms * 1e-3) / 1e12);
+        return 0;
+    }
     for (int i = 0; i < 3; ++i) launch_conv_igemm(a, 0);
     hipEventRecord(e0); const int reps = 20; for (int i = 0; i < reps; ++i) launch_conv_igemm(a, 0); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
