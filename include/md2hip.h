@@ -69,6 +69,13 @@ int32_t md2_backward(md2_handle* h);
 int32_t md2_adam_step(md2_handle* h, float grad_scale);
 /* ---- one whole step of the loop body src/Monodepth.jl:156-176: fwd + bwd (+ ADAM if do_update) -- */
 int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, float* loss, int32_t do_update);
+/* eval_disparity(m, x), src/model.jl:28: n single frames x [n][C][H][W] (n <= batch) -> the 4 disparities [n][1][h][w].
+ * BatchNorm on batch statistics (train mode, as in the reference's saved checkpoints). */
+int32_t md2_eval_disparity(md2_handle* h, const float* x, int32_t n, float* disp0, float* disp1, float* disp2, float* disp3);
+/* ADAM moments (Flux parameter layout, host) + running beta powers: the optimiser state the reference's BSON checkpoints
+ * (src/Monodepth.jl:191-194) omit; with md2_params_get/set this gives true resume. */
+int32_t md2_opt_state_get(md2_handle* h, float* host_m, float* host_v, int64_t n, double* beta1p, double* beta2p);
+int32_t md2_opt_state_set(md2_handle* h, const float* host_m, const float* host_v, int64_t n, double beta1p, double beta2p);
 /* automasking_loss(ssim, x, x[:,:,:,target,:]; source_ids), src/training.jl:9-11 -> [N][1][H][W] */
 int32_t md2_automasking_loss(md2_handle* h, const float* x, float* out);
 

@@ -48,6 +48,9 @@ _SIGS = {
     "md2_adam_step": (I32, [P, C.c_float]),
     "md2_train_step": (I32, [P, P, P, P, I32]),
     "md2_automasking_loss": (I32, [P, P, P]),
+    "md2_eval_disparity": (I32, [P, P, I32, P, P, P, P]),
+    "md2_opt_state_get": (I32, [P, P, P, I64, C.POINTER(F64), C.POINTER(F64)]),
+    "md2_opt_state_set": (I32, [P, P, P, I64, F64, F64]),
     "md2_loss_fwd_bwd": (I32, [P] * 16),
     "md2_simple_depth_loss": (I32, [P] * 9),
     "md2_profile_enable": (I32, [P, I32]),

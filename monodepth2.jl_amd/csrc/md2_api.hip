@@ -276,9 +276,19 @@ static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
-static int model_forward(md2_handle* h, const float* x) {
+// Temporarily re-batch every activation view: n_enc encoder images, n_dec decoder samples (<= the sizes the arena was planned for).
+static void set_batch(md2_handle* h, int n_enc, int n_dec) {
+    h->colv.W = n_enc * (h->H / 2) * (h->W / 2); h->colv.bs = (long)h->colv.W * h->colv.C;
+    h->z0.N = h->a0.N = h->p0.N = n_enc;
+    for (int i = 0; i < 8; ++i) { Block& B = h->blk[i]; B.in.N = B.z1.N = B.a1.N = B.z2.N = B.out.N = n_enc; if (B.down) B.zd.N = B.sd.N = n_enc; }
+    for (int i = 0; i < 5; ++i) { h->feat[i].N = n_enc; h->y1[i].N = h->cat[i].N = h->y2[i].N = n_dec; }
+    for (int i = 0; i < 4; ++i) h->dispv[i].N = n_dec;
+}
+
+// L frames per sample (3 for training, 1 for eval_disparity); tgt = index of the frame the depth decoder sees
+static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, bool with_pose = true) {
     hipStream_t s = h->stream;
-    const int N = h->N, NL = h->NL, H = h->H, W = h->W;
+    const int NL = h->z0.N, N = NL / L, H = h->H, W = h->W;
     HIPCHK(hipMemsetAsync(h->acc_all, 0, h->acc_fwd_count * sizeof(double), s));
     // ---- encoder: stem (im2col + GEMM) + BN + ReLU, maxpool, 8 basic blocks
     launch_im2col_stem(x, NL, h->C, H, W, h->col, h->Kpad, s);
@@ -296,15 +306,16 @@ static int model_forward(md2_handle* h, const float* x) {
         bn_fwd(h, B.b2, B.z2, B.down ? &B.sd : &B.in, ACT_RELU, B.out);
     }
     // ---- depth decoder on the target-frame features (src/model.jl:16-17, src/depth_decoder.jl:49-65)
-    View x5 = frame_view(h->feat[4], 3, 1);
+    View x5 = frame_view(h->feat[4], L, tgt);
     for (int b = 0; b < 5; ++b) {
         const View& in = (b == 0) ? x5 : h->y2[b - 1];
         conv_fwd(h, h->dc1[b], in, h->y1[b], PAD_REFLECT, ACT_ELU);
         launch_upsample2x_fwd(h->y1[b], chan_slice(h->cat[b], 0, h->y1[b].C), s);
-        if (b < 4) { View sk = frame_view(h->feat[3 - b], 3, 1); launch_axpy_view(sk, chan_slice(h->cat[b], h->y1[b].C, sk.C), 1.f, 0, nullptr, ACT_NONE, s); }
+        if (b < 4) { View sk = frame_view(h->feat[3 - b], L, tgt); launch_axpy_view(sk, chan_slice(h->cat[b], h->y1[b].C, sk.C), 1.f, 0, nullptr, ACT_NONE, s); }
         conv_fwd(h, h->dc2[b], h->cat[b], h->y2[b], PAD_REFLECT, ACT_ELU);
         if (b >= 1) launch_head_fwd(h->y2[b], h->P + h->head[b - 1].w, h->P + h->head[b - 1].b, h->dispv[b - 1], s);
     }
+    if (!with_pose) { KCHK(); return 0; }
     // ---- pose decoder, both sources batched (src/model.jl:22-35, src/pose_decoder.jl:23-32)
     const int fr[2][2] = {{0, 1}, {1, 2}};     // (first, second) frame of the temporally ordered pair for source 1 and source 3
     for (int sidx = 0; sidx < 2; ++sidx)
@@ -592,6 +603,37 @@ int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, 
     if (drvec) HIPCHK(hipMemcpyAsync(drvec, h->drvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (dtvec) HIPCHK(hipMemcpyAsync(dtvec, h->dtvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return 0;
+}
+
+// eval_disparity(m, x), src/model.jl:28: encoder + depth decoder on n single frames x [n][C][H][W], n <= batch.
+// BatchNorm uses batch statistics (train mode), like the reference's checkpoints do (src/Monodepth.jl:126,191-194).
+int32_t md2_eval_disparity(md2_handle* h, const float* x, int32_t n, float* d0, float* d1, float* d2, float* d3) {
+    if (n < 1 || n > h->N) { h->err = "md2_eval_disparity: need 1 <= n <= batch"; return 2; }
+    set_batch(h, n, n);
+    int r = model_forward(h, x, 1, 0, false);
+    if (!r) {
+        float* ds[4] = {d0, d1, d2, d3};
+        for (int i = 0; i < 4 && !r; ++i)
+            if (ds[i] && hipMemcpyAsync(ds[i], h->dispv[i].p, (size_t)n * h->dispv[i].H * h->dispv[i].W * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess) { h->err = "md2_eval_disparity: copy failed"; r = 1; }
+    }
+    set_batch(h, h->NL, h->N);
+    h->have_fwd = false;                 // the training activations were overwritten
+    return r;
+}
+// ADAM state (moments in Flux parameter layout + running beta powers) for true resume; the reference saves weights only
+// (src/Monodepth.jl:191-194) — this is the added optimiser state.
+int32_t md2_opt_state_get(md2_handle* h, float* host_m, float* host_v, int64_t n, double* beta1p, double* beta2p) {
+    if (int r = get_flat(h, h->M, host_m, n)) return r;
+    if (int r = get_flat(h, h->V, host_v, n)) return r;
+    *beta1p = h->beta1p; *beta2p = h->beta2p; return 0;
+}
+int32_t md2_opt_state_set(md2_handle* h, const float* host_m, const float* host_v, int64_t n, double beta1p, double beta2p) {
+    if (n != h->n_flux) { h->err = "md2_opt_state_set: wrong parameter count"; return 2; }
+    std::vector<float> in((size_t)h->n_int);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    convert_params(h, in.data(), const_cast<float*>(host_m), true); HIPCHK(hipMemcpy(h->M, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice));
+    convert_params(h, in.data(), const_cast<float*>(host_v), true); HIPCHK(hipMemcpy(h->V, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->beta1p = beta1p; h->beta2p = beta2p; return 0;
 }
 
 int32_t md2_profile_enable(md2_handle* h, int32_t on) { h->prof = on != 0; return 0; }

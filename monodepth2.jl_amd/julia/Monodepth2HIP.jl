@@ -81,6 +81,22 @@ function automasking_loss(h, x::ROCArray{Float32,5})
     check(h, ccall((:md2_automasking_loss, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h.ptr, dptr(x), dptr(out)), "automasking_loss"); out
 end
 
+# eval_disparity(m, x), src/model.jl:28.  x: ROCArray (W,H,C,n) single frames, n <= batch
+function eval_disparity(h, x::ROCArray{Float32,4})
+    W, H, C, n = size(x)
+    disps = [ROCArray{Float32}(undef, W >> s, H >> s, 1, n) for s in (3, 2, 1, 0)]
+    check(h, ccall((:md2_eval_disparity, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                h.ptr, dptr(x), n, dptr(disps[1]), dptr(disps[2]), dptr(disps[3]), dptr(disps[4])), "eval_disparity")
+    disps
+end
+# slow_depth's objective + pullbacks (src/simple_depth.jl:25-42): disp (1,W,H,N) == [N][1][H][W]
+function simple_depth_loss(h, x, disp, rvec, tvec)
+    loss = ROCArray{Float32}(undef, 1); dd = similar(disp); dr = similar(rvec); dt = similar(tvec)
+    check(h, ccall((:md2_simple_depth_loss, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                h.ptr, dptr(x), dptr(disp), dptr(rvec), dptr(tvec), dptr(loss), dptr(dd), dptr(dr), dptr(dt)), "simple_depth_loss")
+    loss, dd, dr, dt
+end
+
 # ---- op-level methods: device dispatch like src/utils.jl:1-11 (AbstractArray vs device array) --------------------------------
 # (ssim::SSIM)(x::ROCArray, y::ROCArray), src/utils.jl:25
 function ssim(x::ROCArray{Float32,4}, y::ROCArray{Float32,4})

@@ -329,6 +329,38 @@ class Model:
         return ds, [Pose(rvec[0], tvec[0]), Pose(rvec[1], tvec[1])]
 
 
+def eval_disparity(m: Model, x):
+    """eval_disparity(m, x) = m.depth_decoder(m.encoder(x, Val(:stages))), src/model.jl:28.  x (n,C,H,W) single frames; the model's
+    handle must exist (n <= its batch) or is created for batch n.  Returns the 4 disparities, coarse -> fine."""
+    x = _f32(x); n, Cc, H, W = x.shape
+    if m._h is None or m._shape[1:4] != (Cc, H, W) or m._shape[0] < n:
+        m._ensure(x.new_zeros((n, 3, Cc, H, W)))
+    L = _lib.lib(); L.md2_set_stream(m._h, _stream())
+    ds = [torch.empty(n, 1, H >> s, W >> s, device=x.device) for s in (3, 2, 1, 0)]
+    _check(L.md2_eval_disparity(m._h, _dev(x), n, _dev(ds[0]), _dev(ds[1]), _dev(ds[2]), _dev(ds[3])), m._h, "eval_disparity")
+    return ds
+
+
+def save_checkpoint(m: Model, path):
+    """Weights (what the reference's `@save ... model_host` keeps, src/Monodepth.jl:191-194) PLUS the ADAM moments and beta powers
+    the reference drops, so training can resume exactly.  numpy .npz, parameters in Flux layout / documented flat order."""
+    n = _lib.lib().md2_params_count(m._h)
+    mm = np.empty(n, np.float32); vv = np.empty(n, np.float32); b1 = C.c_double(); b2 = C.c_double()
+    _check(_lib.lib().md2_opt_state_get(m._h, mm.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), n, C.byref(b1), C.byref(b2)), m._h, "opt_state_get")
+    np.savez(path, params=m.params(), adam_m=mm, adam_v=vv, beta1p=b1.value, beta2p=b2.value, in_channels=m.encoder.in_channels, lr=m.lr)
+
+
+def load_checkpoint(m: Model, path):
+    ck = np.load(path)
+    if int(ck["in_channels"]) != m.encoder.in_channels:
+        raise ValueError("checkpoint was saved for in_channels=%d" % int(ck["in_channels"]))
+    m.load_params(ck["params"])
+    if m._h is None:
+        raise RuntimeError("load_checkpoint: run the model once (or call model._ensure) before restoring the optimiser state")
+    mm = np.ascontiguousarray(ck["adam_m"], np.float32); vv = np.ascontiguousarray(ck["adam_v"], np.float32)
+    _check(_lib.lib().md2_opt_state_set(m._h, mm.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), mm.size, float(ck["beta1p"]), float(ck["beta2p"])), m._h, "opt_state_set")
+
+
 class _DevBuf:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}

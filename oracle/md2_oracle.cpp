@@ -146,6 +146,14 @@ O_API float o_net_train_loss(o_net* h, const float* x, const o_cfg* cfg, const f
     LossCfg c = to_cfg(cfg); return model_loss(h->net, x, c, auto_loss, do_bwd != 0, h->out);
 }
 O_API void o_net_adam_step(o_net* h, double eta, double grad_scale) { adam_step(h->net, eta, grad_scale); }
+O_API void o_net_eval_disparity(o_net* h, const float* x, int N, int C, int H, int W, float* d0, float* d1, float* d2, float* d3) {
+    Tensor disp[4]; eval_disparity(h->net, x, N, C, H, W, disp);
+    float* ds[4] = {d0, d1, d2, d3};
+    for (int i = 0; i < 4; ++i) if (ds[i]) std::memcpy(ds[i], disp[i].p(), sizeof(float) * disp[i].size());
+}
+O_API void o_net_opt_state_get(o_net* h, float* m, float* v, double* b1p, double* b2p) {
+    std::memcpy(m, h->net.m.data(), sizeof(float) * h->net.np); std::memcpy(v, h->net.v.data(), sizeof(float) * h->net.np); *b1p = h->net.beta1p; *b2p = h->net.beta2p;
+}
 O_API void o_automasking_loss(const float* x, const o_cfg* cfg, float* out) { LossCfg c = to_cfg(cfg); Tensor t = automasking_loss(x, c); std::memcpy(out, t.p(), sizeof(float) * t.size()); }
 
 // The loss half alone: disparities + poses in, loss (+ pullbacks) out.  Any output pointer may be null.

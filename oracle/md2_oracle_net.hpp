@@ -522,6 +522,15 @@ inline float model_loss(Net& net, const float* x, const LossCfg& c, const float*
     return out.loss;
 }
 
+// eval_disparity(m, x) = m.depth_decoder(m.encoder(x, Val(:stages))), src/model.jl:28.  x: [N][C][H][W] single frames.
+// BatchNorm runs in TRAIN mode (batch statistics): train() calls trainmode!(model) (src/Monodepth.jl:126) and the checkpoints it
+// saves (cpu(model), :191-194) carry that flag, which is how eval_image / eval_video (:201-248) end up running the loaded model.
+inline void eval_disparity(Net& net, const float* x, int N, int C, int H, int W, Tensor disp[4]) {
+    Tensor xf(N, C, H, W); std::memcpy(xf.p(), x, sizeof(float) * xf.size());
+    auto enc = std::make_unique<EncSave>(); encoder_fwd(net, xf, *enc);
+    auto dep = std::make_unique<DepthSave>(); depth_fwd(net, enc->feat, *dep, disp);
+}
+
 // Flux.Optimise.ADAM(eta, (0.9, 0.999)), eps = 1e-8 (src/Monodepth.jl:125,170)
 inline void adam_step(Net& net, double eta, double grad_scale = 1.0) {
     const double b1 = 0.9, b2 = 0.999, eps = 1e-8;

@@ -281,6 +281,15 @@ class OracleNet:
         x = _c(x, np.float32); al = None if auto_loss is None else _c(auto_loss, np.float32)
         return float(lib().o_net_train_loss(self.h, _p(x), C.byref(cfg), _p(al), int(do_bwd)))
 
+    def eval_disparity(self, x):
+        x = _c(x, np.float32); N, Cc, H, W = x.shape
+        ds = [np.zeros((N, 1, H >> s, W >> s), np.float32) for s in (3, 2, 1, 0)]
+        lib().o_net_eval_disparity(self.h, _p(x), N, Cc, H, W, _p(ds[0]), _p(ds[1]), _p(ds[2]), _p(ds[3])); return ds
+
+    def opt_state(self):
+        m = np.zeros(self.nparams, np.float32); v = np.zeros(self.nparams, np.float32); b1 = C.c_double(); b2 = C.c_double()
+        lib().o_net_opt_state_get(self.h, _p(m), _p(v), C.byref(b1), C.byref(b2)); return m, v, b1.value, b2.value
+
     def adam_step(self, eta=1e-4, grad_scale=1.0):
         lib().o_net_adam_step(self.h, C.c_double(eta), C.c_double(grad_scale))
 

@@ -256,3 +256,40 @@ def test_gradients_do_not_depend_on_previous_step(C, automask):
     diff = np.linalg.norm(g_second - g_fresh) / np.linalg.norm(g_fresh)
     print("noise floor %.2e, second-step difference %.2e" % (noise, diff))
     assert diff < max(5 * noise, 1e-5) and diff < 5e-3
+
+
+def test_eval_disparity_vs_oracle():
+    """eval_disparity(m, x), src/model.jl:28, on single frames (encoder batch != 3N, no pose decoder)."""
+    N, C, H, W = 3, 1, 64, 96
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=6)
+    frames = syn.synthetic_triplets(N, C, H, W, seed=16)[:, 1]
+    for n in (3, 2):
+        ds = md().eval_disparity(model, dev(frames[:n]))
+        net = oracle.OracleNet(C); net.set_params(theta); do = net.eval_disparity(frames[:n])
+        for i in range(4):
+            assert ds[i].shape == do[i].shape and rel(host(ds[i]), do[i]) < 1e-4
+    # the training path still works on the same handle afterwards
+    xd = dev(syn.synthetic_triplets(N, C, H, W, seed=17))
+    loss = md().train_step(model, xd, None, cache, params, do_update=False)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    lo = net.train_loss(host(xd), oracle.make_cfg(N, C, H, W, K, iK), None, False)
+    assert abs(float(loss) - lo) / lo < 1e-4
+
+
+def test_checkpoint_resume(tmp_path):
+    """params + ADAM moments + beta powers round-trip: (2 steps, save, 1 step) == (load, 1 step)."""
+    N, C, H, W = 1, 1, 64, 96
+    xs = [dev(syn.synthetic_triplets(N, C, H, W, seed=40 + i)) for i in range(3)]
+    a, params, cache, theta, K, iK = make(N, C, H, W, pseed=12)
+    for x in xs[:2]:
+        md().train_step(a, x, None, cache, params, True)
+    md().save_checkpoint(a, tmp_path / "ck.npz")
+    md().train_step(a, xs[2], None, cache, params, True); pa = a.params()
+    b, _, _, _, _, _ = make(N, C, H, W, pseed=99)                      # different weights until the checkpoint is loaded
+    b._ensure(xs[2], params, cache)
+    md().load_checkpoint(b, str(tmp_path / "ck.npz"))
+    md().train_step(b, xs[2], None, cache, params, True); pb = b.params()
+    d = np.abs(pa - pb).max()
+    assert d < 2.5e-4, d                                                 # lr = 1e-4: at most a sign flip of a near-zero gradient (atomics noise)
+    assert np.mean(np.abs(pa - pb) > 1e-6) < 1e-3
+    assert np.abs(pa - theta).max() > 1e-4                               # and training really moved the weights

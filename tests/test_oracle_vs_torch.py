@@ -133,3 +133,12 @@ def test_simple_depth_objective_vs_torch():
     l = tr.simple_depth_loss(torch.tensor(x, dtype=torch.float64), dt, [(rt[0], tt[0]), (rt[1], tt[1])], torch.tensor(K), torch.tensor(iK)); l.backward()
     assert abs(r["loss"] - l.item()) / l.item() < 1e-5
     assert grad_close(r["ddisp"][0], dt.grad.numpy()) and rel(r["drvec"], rt.grad.numpy()) < 2e-3 and rel(r["dtvec"], tt.grad.numpy()) < 2e-3
+
+
+def test_eval_disparity_vs_torch():
+    N, C, H, W = 2, 1, 64, 96
+    theta = syn.init_params(C, seed=5, randomize_affine=True); x = syn.synthetic_triplets(N, C, H, W, seed=6)[:, 1]
+    net = oracle.OracleNet(C); net.set_params(theta); ds = net.eval_disparity(x)
+    dt = tr.eval_disparity(torch.tensor(theta, dtype=torch.float64), torch.tensor(x, dtype=torch.float64), C)
+    for a, b in zip(ds, dt):
+        assert rel(a, b.numpy()) < 1e-4

@@ -209,3 +209,9 @@ def simple_depth_loss(x, disp, poses, K, invK, target_id=2, source_ids=(1, 3), m
     coords = backproject(depth.reshape(N, H * W), invK, H, W)
     warped = [grid_sample(x[:, sid - 1], project(coords, K, R, t, H, W).view(N, H, W, 2), True) for (R, t), sid in zip(Ps, source_ids)]
     return prediction_loss(warped, tgt).mean() + smooth_loss(disp[:, 0], tgt)
+
+
+def eval_disparity(flat, x, C):
+    """eval_disparity (src/model.jl:28): encoder + depth decoder on single frames x (N,C,H,W); BN on batch statistics."""
+    disps, _ = model_forward(flat, x.unsqueeze(1), C, target_id=1, source_ids=())
+    return disps
