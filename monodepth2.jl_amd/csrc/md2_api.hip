@@ -540,6 +540,7 @@ static int copy_outputs(md2_handle* h, float* d0, float* d1, float* d2, float* d
     return 0;
 }
 int32_t md2_model_forward(md2_handle* h, const float* x, float* d0, float* d1, float* d2, float* d3, float* rvec, float* tvec) {
+    h->have_fwd = false;                    // overwrites the activations a pending md2_backward would need
     if (int r = model_forward(h, x)) return r;
     return copy_outputs(h, d0, d1, d2, d3, rvec, tvec);
 }

@@ -379,14 +379,14 @@ def train_loss(model: Model, x, auto_loss, cache: TrainCache, parameters: Params
     L = _lib.lib(); L.md2_set_stream(model._h, _stream())
     if parameters.automasking and auto_loss is None:
         raise ValueError("parameters.automasking is set but auto_loss is None")
+    vis_disparity = vis_warped = vis_loss = None
+    if do_visualization:                      # src/training.jl:35-37 (vis_warped / vis_loss stay on the device in this build)
+        ds, poses = model(x, cache.source_ids, cache.target_id)       # BEFORE the training forward: it reuses the activation buffers
+        vis_disparity = ds[-1].cpu()
     loss = torch.empty((), device=x.device)
     al = _f32(auto_loss) if auto_loss is not None else None
     model._keepalive = (x, al)
     _check(L.md2_train_loss(model._h, _dev(x), _dev(al), _dev(loss)), model._h, "train_loss")
-    vis_disparity = vis_warped = vis_loss = None
-    if do_visualization:
-        ds, poses = model(x, cache.source_ids, cache.target_id)
-        vis_disparity = ds[-1].cpu()
     return loss, vis_disparity, vis_warped, vis_loss
 
 

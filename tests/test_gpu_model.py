@@ -293,3 +293,32 @@ def test_checkpoint_resume(tmp_path):
     assert d < 2.5e-4, d                                                 # lr = 1e-4: at most a sign flip of a near-zero gradient (atomics noise)
     assert np.mean(np.abs(pa - pb) > 1e-6) < 1e-3
     assert np.abs(pa - theta).max() > 1e-4                               # and training really moved the weights
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 192, 640), (3, 1, 96, 160), (5, 3, 64, 64)])
+def test_other_shapes_forward_loss_and_gradient_vs_oracle(shape):
+    """Generality of the tiling / halo logic: BASELINE config #4's 640x192 RGB shape, a ragged 160x96 case (tiles overhang in both
+    loss-kernel dimensions) and a batch of 5."""
+    N, C, H, W = shape
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=21)
+    x = syn.synthetic_triplets(N, C, H, W, seed=22); xd = dev(x)
+    loss = md().train_step(model, xd, None, cache, params, do_update=False)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    lo = net.train_loss(x, oracle.make_cfg(N, C, H, W, K, iK), None, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    gh = model.grads(); go = net.get_grads()
+    assert np.isfinite(gh).all()
+    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+
+
+def test_backward_requires_a_training_forward():
+    """md2_backward after a plain model forward (which overwrites the activations) must fail loudly, not return stale gradients."""
+    N, C, H, W = 1, 1, 64, 96
+    model, params, cache, theta, K, iK = make(N, C, H, W)
+    xd = dev(syn.synthetic_triplets(N, C, H, W, seed=3))
+    loss, vis, _, _ = md().train_loss(model, xd, None, cache, params, True)          # do_visualization path
+    assert vis is not None and vis.shape == (N, 1, H, W)
+    md().gradient(model)                                                              # fine: the training forward was last
+    model(xd, [1, 3], 2)
+    with pytest.raises(RuntimeError):
+        md().gradient(model)
