@@ -322,3 +322,25 @@ def test_backward_requires_a_training_forward():
     model(xd, [1, 3], 2)
     with pytest.raises(RuntimeError):
         md().gradient(model)
+
+
+def test_config2_full_size_parity_vs_oracle():
+    """BASELINE.json configs[1] exactly: ResNet-18 depth+pose, 416x128, batch 4, fp32 forward + loss + backward vs the CPU oracle
+    (north-star tolerance: forward+loss within 1e-4 relative)."""
+    N, C, H, W = 4, 1, 128, 416
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=42)
+    x = syn.synthetic_triplets(N, C, H, W, seed=42); xd = dev(x)
+    ds, poses = model(xd, [1, 3], 2)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK)
+    dso, rvo, tvo = net.model_forward(x, cfg)
+    for i in range(4):
+        assert rel(host(ds[i]), dso[i]) < 1e-4
+    for s in range(2):
+        assert rel(host(poses[s].rvec), rvo[s]) < 1e-4 and rel(host(poses[s].tvec), tvo[s]) < 1e-4
+    loss = md().train_step(model, xd, None, cache, params, do_update=False)
+    lo = net.train_loss(x, cfg, None, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    gh = model.grads(); go = net.get_grads()
+    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+    assert abs(np.linalg.norm(gh) - np.linalg.norm(go)) / np.linalg.norm(go) < 2e-2
