@@ -91,6 +91,10 @@ int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* disp0, cons
 int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, const float* rvec, const float* tvec, float* loss,
                               float* ddisp, float* drvec, float* dtvec);
 
+/* Run the weight-gradient kernels on a second internal stream, overlapped with the input-gradient / BatchNorm-pullback chain
+ * (default 1; MD2_ONE_STREAM=1 in the environment sets the default to 0).  Results are identical up to fp32-atomic ordering. */
+int32_t md2_set_two_streams(md2_handle* h, int32_t on);
+
 /* per-kernel-class device timing (HIP events on the handle's stream) for bench.py's roofline */
 int32_t md2_profile_enable(md2_handle* h, int32_t on);
 int32_t md2_profile_reset(md2_handle* h);

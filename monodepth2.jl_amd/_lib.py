@@ -53,6 +53,7 @@ _SIGS = {
     "md2_opt_state_set": (I32, [P, P, P, I64, F64, F64]),
     "md2_loss_fwd_bwd": (I32, [P] * 16),
     "md2_simple_depth_loss": (I32, [P] * 9),
+    "md2_set_two_streams": (I32, [P, I32]),
     "md2_profile_enable": (I32, [P, I32]),
     "md2_profile_reset": (I32, [P]),
     "md2_profile_get": (I32, [P, I32, C.POINTER(F64), C.POINTER(I64), C.POINTER(F64), C.POINTER(F64)]),

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 
 using namespace md2;
 
@@ -30,7 +31,7 @@ struct ConvL {
     long wn() const { return (long)coutP * taps * cinP; }
 };
 struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; float* stats = nullptr; double* acc = nullptr; double* acc_b = nullptr; };
-struct Block { ConvL c1, c2, cd; BNL b1, b2, bd; bool down = false; int stride = 1; View in, z1, a1, z2, zd, sd, out; };
+struct Block { ConvL c1, c2, cd; BNL b1, b2, bd; bool down = false; int stride = 1; View in, z1, a1, z2, zd, sd, out; View dz1, dz2, dzd; };
 struct ProfEvt { hipEvent_t a, b; int cls; double flops; char desc[112]; };
 enum { CLS_IGEMM = 0, CLS_WGRAD = 1, CLS_LOSS_FWD = 2, CLS_LOSS_BWD = 3, CLS_OTHER = 4 };
 
@@ -61,6 +62,8 @@ struct md2_handle {
     float *E1 = nullptr, *E2 = nullptr, *E3 = nullptr;
     View dpy3, dpy2, dpy1, dsq;
     long* wdesc_dev = nullptr; int n_wdesc = 0;
+    // weight gradients run on a second stream, concurrently with the input-gradient / BN-pullback chain of the main stream
+    hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr; bool two_streams = true; bool forked = false; View dz0;
     bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
 
     template <class T> T* alloc(size_t count) {
@@ -70,8 +73,8 @@ struct md2_handle {
         return p;
     }
     View alloc_view(int n, int hh, int ww, int c) { return make_view(alloc<float>((size_t)n * hh * ww * c), n, hh, ww, c); }
-    void pbegin(int cls, double flops = 0, const char* desc = "") { if (prof) { ProfEvt e; e.cls = cls; e.flops = flops; snprintf(e.desc, sizeof(e.desc), "%s", desc); (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, stream); evts.push_back(e); } }
-    void pend() { if (prof) (void)hipEventRecord(evts.back().b, stream); }
+    void pbegin(int cls, double flops = 0, const char* desc = "", hipStream_t st = nullptr, bool own = false) { if (prof) { ProfEvt e; e.cls = cls; e.flops = flops; snprintf(e.desc, sizeof(e.desc), "%s", desc); (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, own ? st : stream); evts.push_back(e); } }
+    void pend(hipStream_t st = nullptr, bool own = false) { if (prof) (void)hipEventRecord(evts.back().b, own ? st : stream); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -203,6 +206,9 @@ static void plan_buffers(md2_handle* h) {
     for (int l = 0; l < 4; ++l) h->ddisp_lo[l] = h->alloc<float>((size_t)N * h->dispv[l].H * h->dispv[l].W);
     const size_t emax = (size_t)NL * (H / 2) * (W / 2) * 64;
     h->E1 = h->alloc<float>(emax); h->E2 = h->alloc<float>(emax); h->E3 = h->alloc<float>(emax);
+    // pre-activation gradients of every encoder conv: NOT shared scratch, the weight-gradient stream reads them while the main stream moves on
+    h->dz0 = h->alloc_view(NL, H / 2, W / 2, 64);
+    for (int i = 0; i < 8; ++i) { Block& B = h->blk[i]; B.dz1 = h->alloc_view(NL, B.z1.H, B.z1.W, B.z1.C); B.dz2 = h->alloc_view(NL, B.z2.H, B.z2.W, B.z2.C); if (B.down) B.dzd = h->alloc_view(NL, B.zd.H, B.zd.W, B.zd.C); }
     h->dpy3 = h->alloc_view(2 * N, ph, pw, 16); h->dpy2 = h->alloc_view(2 * N, ph, pw, 256); h->dpy1 = h->alloc_view(2 * N, ph, pw, 256); h->dsq = h->alloc_view(2 * N, ph, pw, 512);
 }
 
@@ -246,9 +252,15 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     a.M = dy.N * dy.H * dy.W;
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode);
-    h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d); launch_conv_wgrad(a, h->stream); h->pend();
+    hipStream_t st = h->stream;
+    if (h->two_streams && h->s2) {          // fork: everything enqueued on the main stream so far (dy is complete) happens-before this weight gradient
+        hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
+        (void)hipEventRecord(ev, h->stream); (void)hipStreamWaitEvent(h->s2, ev, 0);
+        st = h->s2; h->forked = true;
+    }
+    h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
     if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
-    if (c.bias) launch_colsum(dy, h->G + c.b, h->stream);
+    if (c.bias) launch_colsum(dy, h->G + c.b, st);
 }
 static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* residual, int act, const View& y) {
     launch_colstats(z, b.acc, h->stream);
@@ -425,7 +437,7 @@ static int model_backward(md2_handle* h) {
         const View& Gout = h->Gblk[i];                                  // d / d(pre-ReLU block output), already masked
         const View* Gin = (i == 0) ? &h->Gpool : &h->Gblk[i - 1];
         const View* in_act = (i == 0) ? nullptr : &B.in;                 // ReLU mask of the block input (stage 0: applied in the maxpool pullback)
-        View dz2 = make_view(h->E1, NL, B.z2.H, B.z2.W, B.z2.C), da1 = make_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C), dz1 = make_view(h->E3, NL, B.z1.H, B.z1.W, B.z1.C);
+        const View& dz2 = B.dz2; const View& dz1 = B.dz1; View da1 = make_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C);
         bn_bwd(h, B.b2, Gout, B.z2, dz2);
         conv_wgrad(h, B.c2, B.a1, dz2, PAD_ZERO);
         conv_dgrad(h, B.c2, dz2, da1, 1, 0, &B.a1, ACT_RELU);
@@ -435,7 +447,7 @@ static int model_backward(md2_handle* h) {
         // the decoder's contribution in the target frames
         conv_dgrad(h, B.c1, dz1, *Gin, 1, (i == 0 || (i & 1)) ? 0 : 2, in_act, ACT_RELU);
         if (B.down) {
-            View dzd = make_view(h->E1, NL, B.zd.H, B.zd.W, B.zd.C);
+            const View& dzd = B.dzd;
             bn_bwd(h, B.bd, Gout, B.zd, dzd);
             conv_wgrad(h, B.cd, B.in, dzd, PAD_ZERO);
             conv_dgrad(h, B.cd, dzd, *Gin, 0, 1, in_act, ACT_RELU);
@@ -444,10 +456,12 @@ static int model_backward(md2_handle* h) {
     }
     launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->a0, s);        // Gfeat[0]: decoder skip gradient in the target frames only
     {
-        View dz0 = make_view(h->E1, NL, H / 2, W / 2, 64);
-        bn_bwd(h, h->stem_bn, h->Gfeat[0], h->z0, dz0);
-        View dzc = make_view(h->E1, 1, 1, NL * (H / 2) * (W / 2), 64);
+        bn_bwd(h, h->stem_bn, h->Gfeat[0], h->z0, h->dz0);
+        View dzc = make_view(h->dz0.p, 1, 1, NL * (H / 2) * (W / 2), 64);
         conv_wgrad(h, h->stem, h->colv, dzc, PAD_ZERO);
+    }
+    if (h->forked) {                        // join: the gradient buffer is complete only when the weight-gradient stream has drained
+        (void)hipEventRecord(h->ev_join, h->s2); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); h->forked = false;
     }
     KCHK();
     return 0;
@@ -493,6 +507,10 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     const float Kc[9] = {(float)f, 0, 0, 0, (float)f, 0, (float)cx, (float)cy, 1};
     const float iKc[9] = {(float)(1 / f), 0, 0, 0, (float)(1 / f), 0, (float)(-cx / f), (float)(-cy / f), 1};
     std::memcpy(h->K, Kc, sizeof(Kc)); std::memcpy(h->invK, iKc, sizeof(iKc));
+    if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+    if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+    h->two_streams = getenv("MD2_ONE_STREAM") == nullptr;
     *out = h;
     return 0;
 }
@@ -500,6 +518,7 @@ int32_t md2_destroy(md2_handle* h) {
     if (!h) return 0;
     (void)hipDeviceSynchronize();
     for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (h->s2) { for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->ev_pool[i]); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->s2); }
     (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD);
     delete h; return 0;
 }
@@ -636,6 +655,10 @@ int32_t md2_opt_state_set(md2_handle* h, const float* host_m, const float* host_
     convert_params(h, in.data(), const_cast<float*>(host_v), true); HIPCHK(hipMemcpy(h->V, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice));
     h->beta1p = beta1p; h->beta2p = beta2p; return 0;
 }
+
+// weight gradients on the second stream (default on).  Off = every kernel runs alone on the main stream: used while timing single
+// kernels for the roofline, because overlapped launches inflate each other's duration.
+int32_t md2_set_two_streams(md2_handle* h, int32_t on) { HIPCHK(hipStreamSynchronize(h->stream)); h->two_streams = on != 0; return 0; }
 
 int32_t md2_profile_enable(md2_handle* h, int32_t on) { h->prof = on != 0; return 0; }
 int32_t md2_profile_reset(md2_handle* h) {

@@ -478,6 +478,11 @@ def simple_depth(x, K=None, invK=None, **kw):
     return slow_depth(x, K, invK, **kw)
 
 
+def set_two_streams(model: Model, on=True):
+    """Overlap the weight-gradient kernels with the rest of the backward pass on a second stream (default on)."""
+    _check(_lib.lib().md2_set_two_streams(model._h, int(on)), model._h)
+
+
 def profile(model: Model, on=True):
     _check(_lib.lib().md2_profile_enable(model._h, int(on)), model._h)
     if on:
