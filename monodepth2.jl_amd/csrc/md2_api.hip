@@ -63,6 +63,7 @@ struct md2_handle {
     View dpy3, dpy2, dpy1, dsq;
     long* wdesc_dev = nullptr; int n_wdesc = 0;
     // weight gradients run on a second stream, concurrently with the input-gradient / BN-pullback chain of the main stream
+    hipStream_t s3 = nullptr; hipStream_t cur = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // pose branch stream; `cur` = stream of the chain being enqueued
     hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr; bool two_streams = true; bool forked = false; View dz0;
     bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
 
@@ -73,8 +74,9 @@ struct md2_handle {
         return p;
     }
     View alloc_view(int n, int hh, int ww, int c) { return make_view(alloc<float>((size_t)n * hh * ww * c), n, hh, ww, c); }
-    void pbegin(int cls, double flops = 0, const char* desc = "", hipStream_t st = nullptr, bool own = false) { if (prof) { ProfEvt e; e.cls = cls; e.flops = flops; snprintf(e.desc, sizeof(e.desc), "%s", desc); (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, own ? st : stream); evts.push_back(e); } }
-    void pend(hipStream_t st = nullptr, bool own = false) { if (prof) (void)hipEventRecord(evts.back().b, own ? st : stream); }
+    hipStream_t chain() const { return cur ? cur : stream; }
+    void pbegin(int cls, double flops = 0, const char* desc = "", hipStream_t st = nullptr, bool own = false) { if (prof) { ProfEvt e; e.cls = cls; e.flops = flops; snprintf(e.desc, sizeof(e.desc), "%s", desc); (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, own ? st : chain()); evts.push_back(e); } }
+    void pend(hipStream_t st = nullptr, bool own = false) { if (prof) (void)hipEventRecord(evts.back().b, own ? st : chain()); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -228,7 +230,7 @@ static ConvArgs conv_args(const View& x, const float* w, const View& y, int KH, 
 static void run_igemm(md2_handle* h, const ConvArgs& a) {
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W);
-    h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->stream); h->pend();
+    h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
     if (h->prof) h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a);
 }
 // forward conv (kind 0) on views.  x.C must equal c.cinP, y.C == c.coutP
@@ -252,10 +254,10 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     a.M = dy.N * dy.H * dy.W;
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode);
-    hipStream_t st = h->stream;
-    if (h->two_streams && h->s2) {          // fork: everything enqueued on the main stream so far (dy is complete) happens-before this weight gradient
+    hipStream_t st = h->chain();
+    if (h->two_streams && h->s2) {          // fork: everything enqueued on this chain's stream so far (dy is complete) happens-before this weight gradient
         hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
-        (void)hipEventRecord(ev, h->stream); (void)hipStreamWaitEvent(h->s2, ev, 0);
+        (void)hipEventRecord(ev, h->chain()); (void)hipStreamWaitEvent(h->s2, ev, 0);
         st = h->s2; h->forked = true;
     }
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
@@ -263,14 +265,14 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     if (c.bias) launch_colsum(dy, h->G + c.b, st);
 }
 static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* residual, int act, const View& y) {
-    launch_colstats(z, b.acc, h->stream);
-    launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), h->stream);
-    launch_bn_apply(z, b.stats, h->P + b.g, h->P + b.b, residual, act, y, h->stream);
+    launch_colstats(z, b.acc, h->chain());
+    launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), h->chain());
+    launch_bn_apply(z, b.stats, h->P + b.g, h->P + b.b, residual, act, y, h->chain());
 }
 // dy: gradient wrt the BN output (already masked by any following ReLU) -> dz
 static void bn_bwd(md2_handle* h, const BNL& b, const View& dy, const View& z, const View& dz) {
-    launch_bn_bwd_reduce(dy, nullptr, ACT_NONE, z, b.stats, b.acc_b, h->stream);
-    launch_bn_bwd_apply(dy, nullptr, ACT_NONE, z, b.stats, h->P + b.g, b.acc_b, (double)z.pixels(), dz, h->G + b.g, h->G + b.b, h->stream);
+    launch_bn_bwd_reduce(dy, nullptr, ACT_NONE, z, b.stats, b.acc_b, h->chain());
+    launch_bn_bwd_apply(dy, nullptr, ACT_NONE, z, b.stats, h->P + b.g, b.acc_b, (double)z.pixels(), dz, h->G + b.g, h->G + b.b, h->chain());
 }
 
 static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp[4], const float* Rt, const float* auto_loss) {
@@ -297,6 +299,20 @@ static void set_batch(md2_handle* h, int n_enc, int n_dec) {
     for (int i = 0; i < 4; ++i) h->dispv[i].N = n_dec;
 }
 
+// pose decoder, both sources batched (src/model.jl:22-35, src/pose_decoder.jl:23-32); enqueued on h->chain()
+static void pose_forward(md2_handle* h, int N) {
+    const int fr[2][2] = {{0, 1}, {1, 2}};     // (first, second) frame of the temporally ordered pair for source 1 and source 3
+    for (int sidx = 0; sidx < 2; ++sidx)
+        for (int j = 0; j < 2; ++j) {
+            View sq = h->sqcat; sq.p += (long)sidx * N * sq.bs; sq.N = N;
+            conv_fwd(h, h->squeeze, frame_view(h->feat[4], 3, fr[sidx][j]), chan_slice(sq, j * 256, 256), PAD_ZERO, ACT_RELU);
+        }
+    conv_fwd(h, h->pose[0], h->sqcat, h->py1, PAD_ZERO, ACT_RELU);
+    conv_fwd(h, h->pose[1], h->py1, h->py2, PAD_ZERO, ACT_RELU);
+    conv_fwd(h, h->pose[2], h->py2, h->py3, PAD_ZERO, ACT_NONE);
+    launch_pose_mean_fwd(h->py3, h->rvec, h->tvec, h->chain());
+}
+
 // L frames per sample (3 for training, 1 for eval_disparity); tgt = index of the frame the depth decoder sees
 static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, bool with_pose = true) {
     hipStream_t s = h->stream;
@@ -317,6 +333,13 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
         }
         bn_fwd(h, B.b2, B.z2, B.down ? &B.sd : &B.in, ACT_RELU, B.out);
     }
+    // ---- pose decoder on its own stream, concurrently with the depth decoder (both only read the encoder features)
+    const bool pose_async = with_pose && h->two_streams && h->s3;
+    if (with_pose) {
+        if (pose_async) { (void)hipEventRecord(h->ev_a, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_a, 0); h->cur = h->s3; }
+        pose_forward(h, N);
+        if (pose_async) { (void)hipEventRecord(h->ev_b, h->s3); h->cur = nullptr; }
+    }
     // ---- depth decoder on the target-frame features (src/model.jl:16-17, src/depth_decoder.jl:49-65)
     View x5 = frame_view(h->feat[4], L, tgt);
     for (int b = 0; b < 5; ++b) {
@@ -327,18 +350,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
         conv_fwd(h, h->dc2[b], h->cat[b], h->y2[b], PAD_REFLECT, ACT_ELU);
         if (b >= 1) launch_head_fwd(h->y2[b], h->P + h->head[b - 1].w, h->P + h->head[b - 1].b, h->dispv[b - 1], s);
     }
-    if (!with_pose) { KCHK(); return 0; }
-    // ---- pose decoder, both sources batched (src/model.jl:22-35, src/pose_decoder.jl:23-32)
-    const int fr[2][2] = {{0, 1}, {1, 2}};     // (first, second) frame of the temporally ordered pair for source 1 and source 3
-    for (int sidx = 0; sidx < 2; ++sidx)
-        for (int j = 0; j < 2; ++j) {
-            View sq = h->sqcat; sq.p += (long)sidx * N * sq.bs; sq.N = N;
-            conv_fwd(h, h->squeeze, frame_view(h->feat[4], 3, fr[sidx][j]), chan_slice(sq, j * 256, 256), PAD_ZERO, ACT_RELU);
-        }
-    conv_fwd(h, h->pose[0], h->sqcat, h->py1, PAD_ZERO, ACT_RELU);
-    conv_fwd(h, h->pose[1], h->py1, h->py2, PAD_ZERO, ACT_RELU);
-    conv_fwd(h, h->pose[2], h->py2, h->py3, PAD_ZERO, ACT_NONE);
-    launch_pose_mean_fwd(h->py3, h->rvec, h->tvec, s);
+    if (pose_async) (void)hipStreamWaitEvent(h->stream, h->ev_b, 0);       // join: the loss needs the poses
     KCHK();
     return 0;
 }
@@ -374,6 +386,29 @@ static int loss_backward(md2_handle* h, const float* x, const float* const disp[
     return 0;
 }
 
+// pose decoder pullback on h->chain(); part 0: mean/pose3/pose2/pose1 (independent of the depth decoder), part 1: the squeezer
+// (writes Gfeat[4]; frame 1 accumulates onto the depth decoder's contribution)
+static void pose_backward(md2_handle* h, int N, int part) {
+    if (part == 0) {
+        launch_pose_mean_bwd(h->drvec, h->dtvec, h->dpy3, h->chain());
+        conv_wgrad(h, h->pose[2], h->py2, h->dpy3, PAD_ZERO);
+        conv_dgrad(h, h->pose[2], h->dpy3, h->dpy2, 0, 0, &h->py2, ACT_RELU);
+        conv_wgrad(h, h->pose[1], h->py1, h->dpy2, PAD_ZERO);
+        conv_dgrad(h, h->pose[1], h->dpy2, h->dpy1, 1, 0, &h->py1, ACT_RELU);
+        conv_wgrad(h, h->pose[0], h->sqcat, h->dpy1, PAD_ZERO);
+        conv_dgrad(h, h->pose[0], h->dpy1, h->dsq, 1, 0, &h->sqcat, ACT_RELU);
+        return;
+    }
+    const int fr[2][2] = {{0, 1}, {1, 2}};
+    for (int sidx = 0; sidx < 2; ++sidx)
+        for (int j = 0; j < 2; ++j) {
+            View d = h->dsq; d.p += (long)sidx * N * d.bs; d.N = N; d = chan_slice(d, j * 256, 256);
+            View fv = frame_view(h->feat[4], 3, fr[sidx][j]), gv = frame_view(h->Gfeat[4], 3, fr[sidx][j]);
+            conv_wgrad(h, h->squeeze, fv, d, PAD_ZERO);
+            conv_dgrad(h, h->squeeze, d, gv, 0, fr[sidx][j] == 1 ? 1 : 0, &fv, ACT_RELU);   // frames 0 and 2 get exactly one contribution; frame 1 adds to the depth decoder's
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // backward of the model (Zygote pullback of src/model.jl:8-20), accumulating into h->G
 // ---------------------------------------------------------------------------------------------------------------------
@@ -388,6 +423,10 @@ static int model_backward(md2_handle* h) {
     // transposed / flipped weight copies for the input-gradient GEMMs: one launch for all layers
     launch_weight_to_dgrad_batched(h->P, h->WD, h->wdesc_dev, h->n_wdesc, s);
 
+    // ---- pose decoder pullback on its own stream, overlapping the depth decoder pullback.  Its last four launches accumulate into
+    //      Gfeat[4] (frame 1 on top of the depth decoder's first write), so they wait for the depth decoder (ev_b) — see pose_backward.
+    const bool pose_async = h->two_streams && h->s3;
+    if (pose_async) { (void)hipEventRecord(h->ev_a, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_a, 0); h->cur = h->s3; pose_backward(h, N, 0); h->cur = nullptr; }
     // ---- depth decoder
     for (int l = 0; l < 4; ++l) {
         const int b = l + 1;
@@ -415,22 +454,12 @@ static int model_backward(md2_handle* h) {
         if (b == 0) { View fv = frame_view(h->feat[4], 3, 1), gv = frame_view(h->Gfeat[4], 3, 1); launch_fold_reflect(dip, gv, 0, &fv, ACT_RELU, s); }   // first writer of Gfeat[4] frame 1
         else launch_fold_reflect(dip, h->gA[b - 1], (b - 1) >= 1 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);
     }
-    // ---- pose decoder
-    launch_pose_mean_bwd(h->drvec, h->dtvec, h->dpy3, s);
-    conv_wgrad(h, h->pose[2], h->py2, h->dpy3, PAD_ZERO);
-    conv_dgrad(h, h->pose[2], h->dpy3, h->dpy2, 0, 0, &h->py2, ACT_RELU);
-    conv_wgrad(h, h->pose[1], h->py1, h->dpy2, PAD_ZERO);
-    conv_dgrad(h, h->pose[1], h->dpy2, h->dpy1, 1, 0, &h->py1, ACT_RELU);
-    conv_wgrad(h, h->pose[0], h->sqcat, h->dpy1, PAD_ZERO);
-    conv_dgrad(h, h->pose[0], h->dpy1, h->dsq, 1, 0, &h->sqcat, ACT_RELU);
-    const int fr[2][2] = {{0, 1}, {1, 2}};
-    for (int sidx = 0; sidx < 2; ++sidx)
-        for (int j = 0; j < 2; ++j) {
-            View d = h->dsq; d.p += (long)sidx * N * d.bs; d.N = N; d = chan_slice(d, j * 256, 256);
-            View fv = frame_view(h->feat[4], 3, fr[sidx][j]), gv = frame_view(h->Gfeat[4], 3, fr[sidx][j]);
-            conv_wgrad(h, h->squeeze, fv, d, PAD_ZERO);
-            conv_dgrad(h, h->squeeze, d, gv, 0, fr[sidx][j] == 1 ? 1 : 0, &fv, ACT_RELU);   // frames 0 and 2 get exactly one contribution; frame 1 adds to the depth decoder's
-        }
+    // ---- pose branch, second half: accumulate into Gfeat[4] after the depth decoder's write; then join (the encoder pullback reads Gfeat[4])
+    if (pose_async) {
+        (void)hipEventRecord(h->ev_b, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_b, 0);
+        h->cur = h->s3; pose_backward(h, N, 1); (void)hipEventRecord(h->ev_c, h->s3); h->cur = nullptr;
+        (void)hipStreamWaitEvent(h->stream, h->ev_c, 0);
+    } else { pose_backward(h, N, 0); pose_backward(h, N, 1); }
     // ---- encoder
     for (int i = 7; i >= 0; --i) {
         Block& B = h->blk[i];
@@ -507,7 +536,8 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     const float Kc[9] = {(float)f, 0, 0, 0, (float)f, 0, (float)cx, (float)cy, 1};
     const float iKc[9] = {(float)(1 / f), 0, 0, 0, (float)(1 / f), 0, (float)(-cx / f), (float)(-cy / f), 1};
     std::memcpy(h->K, Kc, sizeof(Kc)); std::memcpy(h->invK, iKc, sizeof(iKc));
-    if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    if (hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_c, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     h->two_streams = getenv("MD2_ONE_STREAM") == nullptr;
@@ -518,7 +548,7 @@ int32_t md2_destroy(md2_handle* h) {
     if (!h) return 0;
     (void)hipDeviceSynchronize();
     for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    if (h->s2) { for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->ev_pool[i]); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->s2); }
+    if (h->s2) { for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->ev_pool[i]); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->s2); (void)hipEventDestroy(h->ev_a); (void)hipEventDestroy(h->ev_b); (void)hipEventDestroy(h->ev_c); (void)hipStreamDestroy(h->s3); }
     (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD);
     delete h; return 0;
 }
