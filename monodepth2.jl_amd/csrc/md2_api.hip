@@ -64,6 +64,7 @@ struct md2_handle {
     long* wdesc_dev = nullptr; int n_wdesc = 0;
     // weight gradients run on a second stream, concurrently with the input-gradient / BN-pullback chain of the main stream
     hipStream_t s3 = nullptr; hipStream_t cur = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // pose branch stream; `cur` = stream of the chain being enqueued
+    hipStream_t s4 = nullptr; int wg_rr = 0; int n_wg_streams = 1; hipEvent_t ev_join4 = nullptr;
     hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr; bool two_streams = true; bool forked = false; View dz0;
     bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
 
@@ -257,8 +258,9 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     hipStream_t st = h->chain();
     if (h->two_streams && h->s2) {          // fork: everything enqueued on this chain's stream so far (dy is complete) happens-before this weight gradient
         hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
-        (void)hipEventRecord(ev, h->chain()); (void)hipStreamWaitEvent(h->s2, ev, 0);
-        st = h->s2; h->forked = true;
+        hipStream_t tgt = (h->n_wg_streams > 1 && (h->wg_rr++ & 1)) ? h->s4 : h->s2;      // round-robin over the weight-gradient streams
+        (void)hipEventRecord(ev, h->chain()); (void)hipStreamWaitEvent(tgt, ev, 0);
+        st = tgt; h->forked = true;
     }
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
     if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
@@ -491,6 +493,7 @@ static int model_backward(md2_handle* h) {
     }
     if (h->forked) {                        // join: the gradient buffer is complete only when the weight-gradient stream has drained
         (void)hipEventRecord(h->ev_join, h->s2); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); h->forked = false;
+        if (h->n_wg_streams > 1) { (void)hipEventRecord(h->ev_join4, h->s4); (void)hipStreamWaitEvent(h->stream, h->ev_join4, 0); }
     }
     KCHK();
     return 0;
@@ -541,6 +544,8 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     h->two_streams = getenv("MD2_ONE_STREAM") == nullptr;
+    if (hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming) != hipSuccess) return fail("hipStreamCreate failed");
+    h->n_wg_streams = getenv("MD2_WG_STREAMS") ? atoi(getenv("MD2_WG_STREAMS")) : 1;
     *out = h;
     return 0;
 }
@@ -548,7 +553,7 @@ int32_t md2_destroy(md2_handle* h) {
     if (!h) return 0;
     (void)hipDeviceSynchronize();
     for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    if (h->s2) { for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->ev_pool[i]); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->s2); (void)hipEventDestroy(h->ev_a); (void)hipEventDestroy(h->ev_b); (void)hipEventDestroy(h->ev_c); (void)hipStreamDestroy(h->s3); }
+    if (h->s2) { for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->ev_pool[i]); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->s2); (void)hipEventDestroy(h->ev_a); (void)hipEventDestroy(h->ev_b); (void)hipEventDestroy(h->ev_c); (void)hipStreamDestroy(h->s3); (void)hipEventDestroy(h->ev_join4); (void)hipStreamDestroy(h->s4); }
     (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD);
     delete h; return 0;
 }

@@ -27,3 +27,8 @@ for _ in range(10):
     md.train_step(model, x, None, cache, params, True)
 torch.cuda.synchronize()
 print("B=%d ms/step %.3f" % (B, (time.perf_counter() - t0) * 100))
+t0 = time.perf_counter()
+for _ in range(10):
+    md.train_loss(model, x, None, cache, params, False)
+torch.cuda.synchronize()
+print("B=%d forward+loss only ms %.3f" % (B, (time.perf_counter() - t0) * 100))
