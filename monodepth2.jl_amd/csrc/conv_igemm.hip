@@ -340,7 +340,9 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------------------------
-template <int T, int BKP, int MF>
+// REFLECT / FAST are compile-time so that the steady-state loop is ONE basic block (uniform branches would split it and the ~180
+// address/carry VALU instructions of the loader would run ahead of, instead of between, the 32 MFMAs of a step)
+template <int T, int BKP, int MF, bool REFLECT, bool FAST>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {
     // LDS tiles [pixel][channel]: A operand lane (row = channel, k = pixel) reads consecutive channels of one pixel row.
     // 32x32x2: the two 32-lane halves are separate ds_read_b32 groups -> conflict-free for any row length.
@@ -380,7 +382,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
     // (n, oh, ow) split is a carry update (a few VALU ops) instead of two divisions per load per step.
     int p_m[NLD], p_n[NLD], p_oh[NLD], p_ow[NLD];
     const int adv_h = BKP / a.Wo, adv_w = BKP - adv_h * a.Wo;          // BKP pixels = adv_h rows + adv_w columns
-    const bool fast_adv = adv_h + 1 <= a.Ho;                            // at most one row-carry and one image-carry per advance
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int f = tid + 256 * j, lk = f / LPP;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
             const int n = p_n[j], oh = p_oh[j], ow = p_ow[j];
             int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
             bool ok = in;
-            if (a.padmode == PAD_REFLECT) { ih = refl_idx(ih, a.H); iw = refl_idx(iw, a.W); }
+            if (REFLECT) { ih = refl_idx(ih, a.H); iw = refl_idx(iw, a.W); }
             else { ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W; ih = ok ? ih : 0; iw = ok ? iw : 0; }
             const uint4 vd = *reinterpret_cast<const uint4*>(a.dy + (long)n * a.dy_bs + (long)(oh * a.Wo + ow) * a.dy_ps + c0 + lc);
             const uint4 vx = *reinterpret_cast<const uint4*>(a.x + (long)n * a.x_bs + ((long)ih * a.W + iw) * a.x_ps + i0 + lc);
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
             rx[j] = make_float4(__uint_as_float(vx.x & mx), __uint_as_float(vx.y & mx), __uint_as_float(vx.z & mx), __uint_as_float(vx.w & mx));
             // advance; positions past the end stay clamped to a valid pixel (their loads are masked by `in`)
             p_m[j] += BKP;
-            if (fast_adv) {
+            if (FAST) {                                    // at most one row-carry and one image-carry per advance (adv_h + 1 <= Ho)
                 int w2 = ow + adv_w, h2 = oh + adv_h, n2 = n;
                 const bool cw = w2 >= a.Wo; w2 -= cw ? a.Wo : 0; h2 += cw ? 1 : 0;
                 const bool ch = h2 >= a.Ho; h2 -= ch ? a.Ho : 0; n2 += ch ? 1 : 0;
@@ -477,9 +478,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
     for (int s = s_begin; s < s_end; ++s) {
 #ifdef MD2_ABLATE
         if (!(a.ablate & 1)) gload();
-        if (!(a.ablate & 2)) read_ops(o1, nxt);
+        if (!(a.ablate & (2 | 32))) read_ops(o1, nxt);
         if (!(a.ablate & 4)) mfmas(cur);
-        if (!(a.ablate & 2)) lstore(o2);
+        if (!(a.ablate & (2 | 64))) lstore(o2);
         if (!(a.ablate & 8)) __syncthreads();
         cur = nxt;
         { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
 
 template <int T, int BKP, int MF>
 static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
+    const bool fast = BKP / a.Wo + 1 <= a.Ho, refl = a.padmode == PAD_REFLECT;
     const int tiles = (a.Cout / T) * (a.Cin / T), taps = a.KH * a.KW;
     const int steps_total = (a.M + BKP - 1) / BKP;
     // Split the pixel (K) range to fill the chip; every split adds one dW tile of fp32 atomics (2.2 GB/step in total at B=32).
@@ -541,7 +543,11 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     splitk = std::max(1, std::min(splitk, (steps_total + 15) / 16));
     const int sps = (steps_total + splitk - 1) / splitk;
     splitk = (steps_total + sps - 1) / sps;
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF>), dim3(tiles * taps * splitk), dim3(256), 0, s, a, sps, steps_total);
+    const dim3 g(tiles * taps * splitk);
+    if (fast && refl) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
+    else if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
+    else if (refl) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, true, false>), g, dim3(256), 0, s, a, sps, steps_total);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, false>), g, dim3(256), 0, s, a, sps, steps_total);
 }
 
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
