@@ -264,12 +264,176 @@ double conv_igemm_flops(const ConvArgs& a) {       // algorithmic: taps that can
     return 2.0 * (double)a.M * a.Cout * taps * a.Cin;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 convolution with the INPUT PATCH resident in LDS — for the full-resolution decoder layers with 16..96 channels
+// (src/depth_decoder.jl branches 4-5 and their input gradients).  There the implicit-GEMM kernel above is bound by its load path:
+// every filter tap re-reads the pixels through L1/L2 (9x) while only 16-32 output channels amortise them (35-78 TFLOP/s).  Here a
+// block owns an 8x32 pixel tile of one image and ALL output channels; per 16-channel chunk it loads the (8+2)x(32+2) patch and the
+// chunk's [Cout][9][16] weights into LDS once, then runs all 9 taps out of LDS (one load phase and two barriers per 9 K-steps).
+//   MFMA 16x16x4: D rows = output channels, cols = pixels; B operand = patch[(r+kh)*(TW+2) + (c+kw)][k..k+3] (ds_read_b128)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int PT_H = 8, PT_W = 32, PP_W = PT_W + 2, PP_N = (PT_H + 2) * PP_W;     // patch: 10 x 34 = 340 pixels
+
+template <int COUT>       // 16 or 32
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tiles_x, int tiles_y, int total_tiles) {
+    constexpr int TC = COUT / 16;
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* Ps = psm;                       // [PP_N][LDK]
+    float* Ws = psm + PP_N * LDK;          // [COUT*9][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    f32x4 acc[TC][4];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this wave's 64 pixels = tile rows 2*wave, 2*wave+1 ; MFMA pixel tile j covers row (2*wave + j/2), columns 16*(j&1) ..
+    const int lrow = lane & 15, lk4 = 4 * (lane >> 4);
+    int pbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pbase[j] = ((2 * wave + (j >> 1)) * PP_W + 16 * (j & 1) + lrow) * LDK + lk4;
+
+    // Persistent blocks: block b works on tiles b, b + gridDim.x, ...; its work is the flat sequence of (tile, 16-channel chunk) steps.
+    // Step s+1's global loads (NPL patch float4s + NWL weight float4s per thread) are issued into registers BEFORE step s's 9 taps of
+    // MFMAs and stored to LDS after them, so global latency is hidden across chunks AND across tiles (with Cin = 16 there is one chunk
+    // per tile, and without the cross-tile prefetch a block spends most of its life waiting for its single load phase).
+    constexpr int NPL = (PP_N * 4 + 255) / 256, NWL = (COUT * 9 * 4 + 255) / 256;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned poff[NPL], okbits = 0, okbits_next = 0;                 // bit i: load slot i is inside the image (zero padding)
+    u32x4 pv[NPL]; f32x4 wv[NWL];
+    const float* xin = a.x;
+    const int nchunks = a.Cin >> 4;
+    const bool wonce = nchunks == 1;                                 // one chunk: the weights are the same for every tile, load them once
+    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = my_tiles * nchunks;
+    for (int s = -1; s < nsteps; ++s) {                              // s = -1 is the prologue (only issues step 0's loads)
+        const int k = s < 0 ? 0 : s / nchunks, c = s - k * nchunks;
+        if (s >= 0) {
+            __syncthreads();                                         // the previous step's MFMAs are done reading LDS
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int f = tid + i * 256;
+                if (f < PP_N * 4) *reinterpret_cast<u32x4*>(Ps + (f >> 2) * LDK + (f & 3) * 4) = pv[i] & (0u - ((okbits >> i) & 1u));
+            }
+            if (!wonce || s == 0) {
+#pragma unroll
+                for (int i = 0; i < NWL; ++i) {
+                    const int f = tid + i * 256;
+                    if (f < COUT * 9 * 4) *reinterpret_cast<f32x4*>(Ws + (f >> 2) * LDK + (f & 3) * 4) = wv[i];
+                }
+            }
+            __syncthreads();
+        }
+        const int s1 = s + 1;
+        if (s1 < nsteps) {
+            const int k1 = s1 / nchunks, c1 = s1 - k1 * nchunks;
+            if (c1 == 0) {                                           // first chunk of a new tile: its patch addresses
+                const int tile = blockIdx.x + k1 * gridDim.x;
+                const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+                xin = a.x + (long)n * a.x_bs;
+#pragma unroll
+                for (int i = 0; i < NPL; ++i) {
+                    const int f = tid + i * 256, pp = min(f >> 2, PP_N - 1), q = f & 3, pr = pp / PP_W, pc = pp - pr * PP_W;
+                    int ih = ty * PT_H - a.pad + pr, iw = tx * PT_W - a.pad + pc;
+                    bool ok = true;
+                    if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }   // beyond the padded image: never used
+                    else { ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W; ih = ok ? ih : 0; iw = ok ? iw : 0; }
+                    poff[i] = (unsigned)(((long)ih * a.W + iw) * a.x_ps + q * 4);
+                    okbits_next = (okbits_next & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) pv[i] = *reinterpret_cast<const u32x4*>(xin + poff[i] + c1 * 16);
+            if (!wonce || s1 == 0) {
+#pragma unroll
+                for (int i = 0; i < NWL; ++i) {
+                    const int f = min(tid + i * 256, COUT * 9 * 4 - 1), row = f >> 2, q = f & 3;    // row = co*9 + tap ; global: w[co][tap][Cin]
+                    wv[i] = *reinterpret_cast<const f32x4*>(a.w + (long)row * a.Cin + c1 * 16 + q * 4);
+                }
+            }
+        }
+        okbits = okbits_next;                                        // the mask that goes with the registers now in flight
+        if (s < 0) continue;
+        // ---- 9 taps out of LDS
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * PP_W + (t % 3)) * LDK;
+            f32x4 wf[TC], xf[4];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) wf[i] = *reinterpret_cast<const f32x4*>(Ws + ((i * 16 + lrow) * 9 + t) * LDK + lk4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const f32x4*>(Ps + pbase[j] + toff);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][r], xf[j][r], acc[i][j], 0, 0, 0);
+        }
+        if (c != nchunks - 1) continue;
+        // ---- epilogue of this tile (same contract as conv_igemm_kernel): D col = pixel (lane&15), row = 4*(lane>>4) + e
+        const int tile = blockIdx.x + k * gridDim.x;
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oy = ty * PT_H + 2 * wave + (j >> 1), ox = tx * PT_W + 16 * (j & 1) + lrow;
+            if (oy < a.Ho && ox < a.Wo) {
+                const long pix = (long)oy * a.Wo + ox;
+                float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps;
+                const float* dp = a.dact_src ? a.dact_src + (long)n * a.da_bs + pix * a.da_ps : nullptr;
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int co = i * 16 + lk4;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + co); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (a.act != ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+                    }
+                    if (dp) { const float4 d = *reinterpret_cast<const float4*>(dp + co); v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
+                    if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                    *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TC; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+static int patch_min_h() { static const int v = getenv("MD2_PATCH_MIN_H") ? atoi(getenv("MD2_PATCH_MIN_H")) : 64; return v; }
+static bool patch_eligible(const ConvArgs& a) {
+    static const int off = getenv("MD2_NO_PATCH_CONV") ? 1 : 0;
+    if (off) return false;
+    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.Cin % 16 == 0 &&
+           (a.Cout == 16 || a.Cout == 32) && a.Cin <= 96 &&
+           a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.oy0 == 0 && a.ox0 == 0 && a.Hl == a.Ho && a.Wl == a.Wo &&
+           a.Ho >= patch_min_h() && a.Wo >= 2 * patch_min_h();
+}
+template <int COUT>
+static void launch_patch(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.Wo + PT_W - 1) / PT_W, tiles_y = (a.Ho + PT_H - 1) / PT_H;
+    const size_t lds = (size_t)(PP_N + COUT * 9) * LDK * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    static int per_cu = 0;
+    if (!per_cu) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_patch_kernel<COUT>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2; }
+    const int total = tiles_x * tiles_y * a.N, resident = 256 * per_cu;                     // persistent: exactly the co-resident blocks
+    hipLaunchKernelGGL((conv3x3_patch_kernel<COUT>), dim3(std::min(total, resident)), dim3(256), lds, s, a, tiles_x, tiles_y, total);
+}
+
 static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s);
 
 // Input-gradient of a strided convolution (dil = forward stride): an output pixel of residue class (ph,pw) mod dil only
 // sees the taps kh = (pad - ph) mod dil (+ multiples of dil), so the problem splits into dil^2 dense sub-convolutions on
 // output/tap lattices with no multiply-by-zero work (k=3, s=2: 1+2+2+4 = 9 taps over 4 quarter-size launches).
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
+    if (patch_eligible(a)) {
+        if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || (a.dact_src && a.da_ps % 4 != 0)) { fprintf(stderr, "md2: conv3x3_patch: unaligned view\n"); abort(); }
+        if (a.Cout == 16) launch_patch<16>(a, s); else launch_patch<32>(a, s);
+        return;
+    }
     if (a.dil <= 1 || a.ostep != 1) { launch_conv_igemm_one(a, s); return; }
     for (int ph = 0; ph < a.dil; ++ph)
         for (int pw = 0; pw < a.dil; ++pw) {
@@ -550,12 +714,144 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, false>), g, dim3(256), 0, s, a, sps, steps_total);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same full-resolution 3x3 / stride-1 decoder layers, ALL 9 TAPS PER BLOCK out of one LDS-resident input
+// patch.  conv_wgrad_kernel gives every filter tap its own blocks, so dy and x are re-read 9x through L1/L2 while a 16- or 32-wide
+// tile amortises little (24-50 TFLOP/s on these layers).  Here a persistent block walks 8x32 pixel tiles; per tile it stages
+// dy[256 px][Cout] and the (8+2)x(32+2) patch of ONE 16-channel chunk of x (blockIdx.y) in LDS, and each wave contracts its 64 pixels
+// against all 9 shifted patch positions:   D[co][ci] (tap) += sum_px dy[px][co] * patch[px + tap][ci]     (MFMA 16x16x4, K = pixels)
+// LDS rows are 16 floats with NO padding: operands are read one float per lane (4 consecutive pixels x 16 channels = 64 banks).
+// The 9*TCO accumulator tiles live in registers for the block's whole life; one LDS reduction over the 4 waves and one set of
+// fp32 atomics per block at the end.  Next tile's global loads are in flight during the current tile's MFMAs.
+// ------------------------------------------------------------------------------------------------------------
+template <int TCO>        // Cout / 16: 1 or 2
+__global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, int tiles_x, int tiles_y, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* Ys = psm;                          // [TCO][256][16]
+    float* Xs = psm + TCO * 256 * 16;         // [PP_N][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 15, lq = lane >> 4;
+    const int cg = blockIdx.y;                // 16-channel chunk of x / of dw's ci axis
+
+    f32x4 acc[9][TCO];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NPL = (PP_N * 4 + 255) / 256, NYL = TCO * 4;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned poff[NPL], yoff[4], yok = 0;       // poff bit 31: the input pixel is outside the image (zero padding); yok bit i: dy slot i is inside
+    u32x4 pv[NPL], yv[NYL];
+    const float* xin = a.x; const float* dyin = a.dy;
+    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int s = -1; s < my_tiles; ++s) {                            // s = -1 is the prologue (only issues tile 0's loads)
+        if (s >= 0) {
+            __syncthreads();                                         // the previous tile's MFMAs are done reading LDS
+            // (poff / yok still describe the registers being committed: they are recomputed for the next tile below)
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int f = tid + i * 256;
+                if (f < PP_N * 4) *reinterpret_cast<u32x4*>(Xs + f * 4) = pv[i] & ((poff[i] >> 31) - 1u);
+            }
+#pragma unroll
+            for (int i = 0; i < NYL; ++i)                            // slot i: chunk i/4, pixel (tid + (i%4)*256) >> 2
+                *reinterpret_cast<u32x4*>(Ys + (i >> 2) * 4096 + (tid + (i & 3) * 256) * 4) = yv[i] & (0u - ((yok >> (i & 3)) & 1u));
+            __syncthreads();
+        }
+        if (s + 1 < my_tiles) {
+            const int tile = blockIdx.x + (s + 1) * gridDim.x;
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+            xin = a.x + (long)n * a.x_bs + cg * 16; dyin = a.dy + (long)n * a.dy_bs;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int f = tid + i * 256, pp = min(f >> 2, PP_N - 1), q = f & 3, pr = pp / PP_W, pc = pp - pr * PP_W;
+                int ih = ty * PT_H - a.pad + pr, iw = tx * PT_W - a.pad + pc;
+                if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                ih = min(max(ih, 0), a.H - 1); iw = min(max(iw, 0), a.W - 1);
+                poff[i] = (unsigned)(((long)ih * a.W + iw) * a.x_ps + q * 4) | (ok ? 0u : 0x80000000u);
+            }
+            yok = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = tid + i * 256, pix = f >> 2, q = f & 3;
+                const int oy = ty * PT_H + (pix >> 5), ox = tx * PT_W + (pix & 31);
+                const bool ok = oy < a.Ho && ox < a.Wo;
+                yoff[i] = (unsigned)(((long)min(oy, a.Ho - 1) * a.Wo + min(ox, a.Wo - 1)) * a.dy_ps + q * 4);
+                yok |= (ok ? 1u : 0u) << i;
+            }
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) pv[i] = *reinterpret_cast<const u32x4*>(xin + (poff[i] & 0x7FFFFFFFu));
+#pragma unroll
+            for (int i = 0; i < NYL; ++i) yv[i] = *reinterpret_cast<const u32x4*>(dyin + yoff[i & 3] + (i >> 2) * 16);
+        }
+        if (s < 0) continue;
+        // ---- this wave's 64 pixels (tile rows 2*wave, 2*wave+1): 16 k-steps of 4 pixels, 9 taps each
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            const int r = 2 * wave + (kk >> 3), c = 4 * (kk & 7) + lq;
+            float av[TCO];
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) av[i] = Ys[i * 4096 + (r * 32 + c) * 16 + lcol];
+            float bv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bv[t] = Xs[((r + t / 3) * PP_W + c + t % 3) * 16 + lcol];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < TCO; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[t][i], 0, 0, 0);
+        }
+    }
+    // ---- reduce the 4 waves' accumulators through LDS, then one atomic per weight and block
+    float* red = psm;                          // [9*TCO][64 lanes][4]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < TCO; ++i) {
+                    f32x4* dst = reinterpret_cast<f32x4*>(red + ((t * TCO + i) * 64 + lane) * 4);
+                    *dst = w == 0 ? acc[t][i] : *dst + acc[t][i];
+                }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 9 * TCO * 256; e += 256) {
+        const int el = e & 3, ln = (e >> 2) & 63, ti = e >> 8, t = ti / TCO, i = ti - t * TCO;
+        const int co = i * 16 + 4 * (ln >> 4) + el, ci = cg * 16 + (ln & 15);
+        atomicAdd(a.dw + ((long)co * 9 + t) * a.Cin + ci, red[e]);
+    }
+}
+static bool wgrad_patch_eligible(const WgradArgs& a) {
+    static const int off = getenv("MD2_NO_PATCH_CONV") ? 1 : 0;
+    if (off) return false;
+    return a.KH == 3 && a.KW == 3 && a.stride == 1 && (a.Cout == 16 || a.Cout == 32) && a.Cin % 16 == 0 && a.Cin <= 96 &&
+           a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.Ho >= patch_min_h() && a.Wo >= 2 * patch_min_h();
+}
+template <int TCO>
+static void launch_wgrad_patch(const WgradArgs& a, hipStream_t s) {
+    const int tiles_x = (a.Wo + PT_W - 1) / PT_W, tiles_y = (a.Ho + PT_H - 1) / PT_H;
+    const size_t lds = (size_t)std::max((TCO * 256 + PP_N) * 16, 9 * TCO * 256) * sizeof(float);
+    static int per_cu = 0;
+    if (!per_cu) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_patch_kernel<TCO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_patch_kernel<TCO>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        per_cu = std::min(per_cu, 4);
+    }
+    const int total = tiles_x * tiles_y * a.N, groups = a.Cin / 16;
+    const int gx = std::max(1, std::min(total, 256 * per_cu / groups));              // persistent: the co-resident blocks, shared by the channel chunks
+    hipLaunchKernelGGL((conv3x3_wgrad_patch_kernel<TCO>), dim3(gx, groups), dim3(256), lds, s, a, tiles_x, tiles_y, total);
+}
+
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || a.M <= 0 || a.M >= (1 << 24)) {
         fprintf(stderr, "md2: conv_wgrad: unsupported shape Cin=%d Cout=%d M=%d\n", a.Cin, a.Cout, a.M);
         abort();
     }
     static const int max_t = getenv("MD2_WGRAD_MAXT") ? atoi(getenv("MD2_WGRAD_MAXT")) : 128;
+    if (wgrad_patch_eligible(a)) { if (a.Cout == 16) launch_wgrad_patch<1>(a, s); else launch_wgrad_patch<2>(a, s); return; }
     if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && max_t >= 128) launch_wgrad_tile<128, 16, 32>(a, s);
     else if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 32, 32>(a, s);
     else if (a.Cin % 32 == 0 && a.Cout % 32 == 0) launch_wgrad_tile<32, 32, 16>(a, s);

@@ -42,6 +42,11 @@ CONV_CASES = [
     (1, 16, 33, 35, 16, 3, 1, 0, "reflect"),      # ragged pixel count
     (7, 128, 16, 13, 64, 3, 1, 0, "reflect"),
     (40, 64, 32, 52, 64, 3, 1, 1, "zeros"),       # enough tiles to take the 128-wide tile path
+    # large enough (Ho >= 64, Wo >= 128) for the LDS-patch 3x3 kernel (forward, and the input gradient with the channel roles swapped)
+    (1, 16, 66, 135, 16, 3, 1, 0, "reflect"),     # decoder branch 5: ragged 8x32 tiles, one channel chunk (weights loaded once)
+    (1, 96, 64, 128, 32, 3, 1, 0, "reflect"),     # decoder c2 with skip: 6 channel chunks
+    (2, 32, 69, 131, 16, 3, 1, 0, "reflect"),     # several images per persistent block
+    (1, 32, 64, 136, 32, 3, 1, 1, "zeros"),       # zero padding: masked halo loads
 ]
 
 
@@ -65,9 +70,10 @@ def test_conv_fwd_dgrad_wgrad(case):
     assert rel(host(dx), dxo) < 1e-4 and rel(host(dw), dwo) < 1e-4 and rel(host(db), dbo) < 1e-4
 
 
+@pytest.mark.parametrize("hw", [(10, 14), (65, 131)])           # the second shape takes the LDS-patch kernel
 @pytest.mark.parametrize("act", ["relu", "elu", "sigmoid"])
-def test_conv_epilogue_activations(act):
-    x = rng.standard_normal((2, 32, 10, 14)).astype(np.float32); w = (rng.standard_normal((32, 32, 3, 3)) * 0.1).astype(np.float32); b = rng.standard_normal(32).astype(np.float32)
+def test_conv_epilogue_activations(act, hw):
+    x = rng.standard_normal((2, 32) + hw).astype(np.float32); w = (rng.standard_normal((32, 32, 3, 3)) * 0.1).astype(np.float32); b = rng.standard_normal(32).astype(np.float32)
     yo = oracle.conv2d_fwd(x, w, b, 1, 1)
     ref = {"relu": np.maximum(yo, 0), "elu": np.where(yo > 0, yo, np.expm1(yo)), "sigmoid": 1 / (1 + np.exp(-yo))}[act]
     assert rel(host(md().conv2d(dev(x), dev(w), dev(b), 1, 1, "zeros", act)), ref) < 1e-4
