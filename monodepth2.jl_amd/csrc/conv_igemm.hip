@@ -845,12 +845,142 @@ static void launch_wgrad_patch(const WgradArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((conv3x3_wgrad_patch_kernel<TCO>), dim3(gx, groups), dim3(256), lds, s, a, tiles_x, tiles_y, total);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same all-taps scheme on the 32x32x2 MFMA for every 3x3 / stride-1 layer with Cin, Cout multiples of 32 (encoder stages, decoder).
+// A block owns one (32 output channels) x (32 input channels) weight tile for ALL 9 taps (9 x 16 accumulator registers per lane,
+// blockIdx.y) and walks 4 x TW pixel tiles (TW <= 32 chosen by the launcher to divide the row, e.g. 26 for W = 26..416); wave w
+// contracts tile row w:   D[co][ci] (tap) += sum_px dy[px][co] * patch[px + tap][ci]       (K = 2 pixels per MFMA)
+// Per tile a block loads dy[4*TW][32] + patch[6*(TW+2)][32] (<= 42 KB) for TW/2 * 9 MFMAs per wave: ~9x less operand traffic per flop
+// than conv_wgrad_kernel's one-tap-per-block tiles, whose load path (not the MFMA rate) held it at ~75-85 TFLOP/s; this one runs the
+// encoder layers at ~107.  (Measured alternatives, both slower: 3 or 6 waves per block that each own one filter ROW -- 48 accumulator
+// registers, 3 waves per SIMD -- reach 86 and 78 TFLOP/s.)
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WT_MAXW = 32;
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs a, int TW, int tiles_x, int tiles_y, int total_tiles, int ci_groups) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];
+    float* Ys = psm;                               // [4*TW][32]
+    float* Xs = psm + 4 * WT_MAXW * 32;            // [6*(TW+2)][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 31, lp = lane >> 5;
+    const int cgi = blockIdx.y % ci_groups, cgo = blockIdx.y / ci_groups;
+    const int PW = TW + 2, npp = 6 * PW * 8, nyp = 4 * TW * 8;       // float4 slots per tile (patch, dy)
+    const unsigned mPW = 65536u / PW + 1, mTW = 65536u / TW + 1;      // x / PW == (x * mPW) >> 16 for x < 6*PW (exact: x * PW < 65536)
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    constexpr int NPL = (6 * (WT_MAXW + 2) * 8 + 255) / 256, NYL = (4 * WT_MAXW * 8 + 255) / 256;      // 7, 4
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned okbits = 0;                           // bit i (patch slots), bit 16+i (dy slots): the load is inside the image, else it is committed as zero
+    u32x4 pv[NPL], yv[NYL];
+    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int s = -1; s < my_tiles; ++s) {                            // s = -1 is the prologue (only issues tile 0's loads)
+        if (s >= 0) {
+            __syncthreads();                                         // the previous tile's MFMAs are done reading LDS
+            // (okbits still describes the registers being committed: it is recomputed for the next tile below)
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int f = tid + i * 256;
+                if (f < npp) *reinterpret_cast<u32x4*>(Xs + f * 4) = pv[i] & (0u - ((okbits >> i) & 1u));
+            }
+#pragma unroll
+            for (int i = 0; i < NYL; ++i) {
+                const int f = tid + i * 256;
+                if (f < nyp) *reinterpret_cast<u32x4*>(Ys + f * 4) = yv[i] & (0u - ((okbits >> (16 + i)) & 1u));
+            }
+            __syncthreads();
+        }
+        if (s + 1 < my_tiles) {
+            const int tile = blockIdx.x + (s + 1) * gridDim.x;
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+            const float* xin = a.x + (long)n * a.x_bs + cgi * 32; const float* dyin = a.dy + (long)n * a.dy_bs + cgo * 32;
+            okbits = 0;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int f = min(tid + i * 256, npp - 1), pp = f >> 3, q = f & 7, pr = (int)((pp * mPW) >> 16), pc = pp - pr * PW;
+                int ih = ty * 4 - a.pad + pr, iw = tx * TW - a.pad + pc;
+                if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                ih = min(max(ih, 0), a.H - 1); iw = min(max(iw, 0), a.W - 1);
+                okbits |= (ok ? 1u : 0u) << i;
+                pv[i] = *reinterpret_cast<const u32x4*>(xin + (unsigned)(((long)ih * a.W + iw) * a.x_ps + q * 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NYL; ++i) {
+                const int f = min(tid + i * 256, nyp - 1), pix = f >> 3, q = f & 7, r = (int)((pix * mTW) >> 16), c = pix - r * TW;
+                const int oy = ty * 4 + r, ox = tx * TW + c;
+                const bool ok = oy < a.Ho && ox < a.Wo;
+                okbits |= (ok ? 1u : 0u) << (16 + i);
+                yv[i] = *reinterpret_cast<const u32x4*>(dyin + (unsigned)(((long)min(oy, a.Ho - 1) * a.Wo + min(ox, a.Wo - 1)) * a.dy_ps + q * 4));
+            }
+        }
+        if (s < 0) continue;
+        // ---- wave w contracts tile row w: TW/2 k-steps of 2 pixels, 9 taps each
+        const float* yrow = Ys + (wave * TW + lp) * 32 + lcol;
+        const float* xrow = Xs + (wave * PW + lp) * 32 + lcol;
+        const int ksteps = TW >> 1;
+        for (int kk = 0; kk < ksteps; ++kk) {
+            const float av = yrow[kk * 64];
+            float bv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bv[t] = xrow[kk * 64 + ((t / 3) * PW + (t % 3)) * 32];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        }
+    }
+    // ---- reduce the 4 waves' accumulators through LDS, then one atomic per weight and block
+    float* red = psm;                              // [9*16][64 lanes]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* dst = red + (t * 16 + e) * 64 + lane;
+                    *dst = w == 0 ? acc[t][e] : *dst + acc[t][e];
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * 16 * 64; i += 256) {
+        const int ln = i & 63, e = (i >> 6) & 15, t = i >> 10;
+        const int co = cgo * 32 + (e >> 2) * 8 + (ln >> 5) * 4 + (e & 3), ci = cgi * 32 + (ln & 31);     // 32x32 D layout
+        atomicAdd(a.dw + ((long)co * 9 + t) * a.Cin + ci, red[i]);
+    }
+}
+static bool wgrad_taps32_eligible(const WgradArgs& a) {
+    static const int off = getenv("MD2_NO_TAPS_WGRAD") ? 1 : 0;
+    if (off) return false;
+    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.Cout % 32 == 0 && a.Cin % 32 == 0 &&
+           a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.Ho >= 2 && a.Wo >= 8;
+}
+static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
+    const int tiles_x = (a.Wo + WT_MAXW - 1) / WT_MAXW;
+    int TW = (a.Wo + tiles_x - 1) / tiles_x; TW += TW & 1;                                  // even, <= 32, least padding
+    const int tiles_y = (a.Ho + 3) / 4;
+    const size_t lds = (size_t)std::max((4 * WT_MAXW + 6 * (WT_MAXW + 2)) * 32, 9 * 16 * 64) * sizeof(float);
+    static int per_cu = 0;
+    if (!per_cu) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        per_cu = std::min(per_cu, 2);
+    }
+    const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
+    const int gx = std::max(1, std::min(total, 256 * per_cu / groups));                    // persistent: the co-resident blocks, shared by the weight tiles
+    hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
+}
+
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || a.M <= 0 || a.M >= (1 << 24)) {
         fprintf(stderr, "md2: conv_wgrad: unsupported shape Cin=%d Cout=%d M=%d\n", a.Cin, a.Cout, a.M);
         abort();
     }
     static const int max_t = getenv("MD2_WGRAD_MAXT") ? atoi(getenv("MD2_WGRAD_MAXT")) : 128;
+    if (wgrad_taps32_eligible(a)) { launch_wgrad_taps32(a, s); return; }
     if (wgrad_patch_eligible(a)) { if (a.Cout == 16) launch_wgrad_patch<1>(a, s); else launch_wgrad_patch<2>(a, s); return; }
     if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && max_t >= 128) launch_wgrad_tile<128, 16, 32>(a, s);
     else if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 32, 32>(a, s);
