@@ -52,6 +52,8 @@ int64_t md2_params_count(md2_handle* h);
 int32_t md2_params_set(md2_handle* h, const float* host_params, int64_t n);
 int32_t md2_params_get(md2_handle* h, float* host_params, int64_t n);
 int32_t md2_grads_get(md2_handle* h, float* host_grads, int64_t n);     /* gradient(theta) do ... end */
+/* The gradients are those of the last md2_backward; the NEXT md2_train_loss starts zeroing them (it prepares the pullback's
+ * accumulators on the second stream while the forward pass runs), so read / all-reduce them before calling it. */
 /* internal flat gradient buffer (device) for the data-parallel all-reduce (RCCL via the host) */
 int32_t md2_grad_buffer(md2_handle* h, void** dev_ptr, int64_t* count);
 int32_t md2_param_buffer(md2_handle* h, void** dev_ptr, int64_t* count);

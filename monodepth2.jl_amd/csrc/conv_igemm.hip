@@ -734,6 +734,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, i
     const int cg = blockIdx.y;                // 16-channel chunk of x / of dw's ci axis
 
     f32x4 acc[9][TCO];
+    float bsum[TCO];                           // bias gradient: this lane's share of sum_px dy[px][co = 16*i + lcol]
+#pragma unroll
+    for (int i = 0; i < TCO; ++i) bsum[i] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, i
             const int r = 2 * wave + (kk >> 3), c = 4 * (kk & 7) + lq;
             float av[TCO];
 #pragma unroll
-            for (int i = 0; i < TCO; ++i) av[i] = Ys[i * 4096 + (r * 32 + c) * 16 + lcol];
+            for (int i = 0; i < TCO; ++i) { av[i] = Ys[i * 4096 + (r * 32 + c) * 16 + lcol]; bsum[i] += av[i]; }
             float bv[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) bv[t] = Xs[((r + t / 3) * PP_W + c + t % 3) * 16 + lcol];
@@ -801,6 +804,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, i
             for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int i = 0; i < TCO; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[t], acc[t][i], 0, 0, 0);
+        }
+    }
+    if (a.db && cg == 0) {
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            float b = bsum[i]; b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+            if (lq == 0) atomicAdd(a.db + i * 16 + lcol, b);
         }
     }
     // ---- reduce the 4 waves' accumulators through LDS, then one atomic per weight and block
@@ -867,6 +877,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
     const unsigned mPW = 65536u / PW + 1, mTW = 65536u / TW + 1;      // x / PW == (x * mPW) >> 16 for x < 6*PW (exact: x * PW < 65536)
 
     f32x16 acc[9];
+    float bsum = 0.f;                              // bias gradient: this lane's share of sum_px dy[px][co = lcol]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -924,12 +935,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
         const int ksteps = TW >> 1;
         for (int kk = 0; kk < ksteps; ++kk) {
             const float av = yrow[kk * 64];
+            bsum += av;
             float bv[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) bv[t] = xrow[kk * 64 + ((t / 3) * PW + (t % 3)) * 32];
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
         }
+    }
+    if (a.db && cgi == 0) {                        // one block column per output-channel group owns the bias gradient
+        bsum += __shfl_xor(bsum, 32);
+        if (lp == 0) atomicAdd(a.db + cgo * 32 + lcol, bsum);
     }
     // ---- reduce the 4 waves' accumulators through LDS, then one atomic per weight and block
     float* red = psm;                              // [9*16][64 lanes]
@@ -982,6 +998,7 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     static const int max_t = getenv("MD2_WGRAD_MAXT") ? atoi(getenv("MD2_WGRAD_MAXT")) : 128;
     if (wgrad_taps32_eligible(a)) { launch_wgrad_taps32(a, s); return; }
     if (wgrad_patch_eligible(a)) { if (a.Cout == 16) launch_wgrad_patch<1>(a, s); else launch_wgrad_patch<2>(a, s); return; }
+    if (a.db) { View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s); }
     if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && max_t >= 128) launch_wgrad_tile<128, 16, 32>(a, s);
     else if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 32, 32>(a, s);
     else if (a.Cin % 32 == 0 && a.Cout % 32 == 0) launch_wgrad_tile<32, 32, 16>(a, s);

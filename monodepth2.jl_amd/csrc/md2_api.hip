@@ -65,7 +65,7 @@ struct md2_handle {
     // weight gradients run on a second stream, concurrently with the input-gradient / BN-pullback chain of the main stream
     hipStream_t s3 = nullptr; hipStream_t cur = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // pose branch stream; `cur` = stream of the chain being enqueued
     hipStream_t s4 = nullptr; int wg_rr = 0; int n_wg_streams = 1; hipEvent_t ev_join4 = nullptr;
-    hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr; bool two_streams = true; bool forked = false; View dz0;
+    hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr, ev_p0 = nullptr, ev_p1 = nullptr; bool prep_done = false; bool two_streams = true; bool forked = false; View dz0;
     bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
 
     template <class T> T* alloc(size_t count) {
@@ -252,7 +252,7 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     a.x = x.p; a.x_bs = x.bs; a.x_ps = x.ps; a.H = x.H; a.W = x.W; a.Cin = x.C;
     a.dy = dy.p; a.dy_bs = dy.bs; a.dy_ps = dy.ps; a.Ho = dy.H; a.Wo = dy.W; a.Cout = dy.C;
     a.dw = h->G + c.w; a.N = dy.N; a.KH = c.kind == 1 ? 1 : c.k; a.KW = a.KH; a.stride = c.kind == 1 ? 1 : c.stride; a.pad = c.kind == 1 ? 0 : (padmode == PAD_REFLECT ? 1 : c.pad); a.padmode = padmode;
-    a.M = dy.N * dy.H * dy.W;
+    a.M = dy.N * dy.H * dy.W; a.db = c.bias ? h->G + c.b : nullptr;
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode);
     hipStream_t st = h->chain();
@@ -264,7 +264,6 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     }
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
     if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
-    if (c.bias) launch_colsum(dy, h->G + c.b, st);
 }
 static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* residual, int act, const View& y) {
     launch_colstats(z, b.acc, h->chain());
@@ -414,16 +413,23 @@ static void pose_backward(md2_handle* h, int N, int part) {
 // ---------------------------------------------------------------------------------------------------------------------
 // backward of the model (Zygote pullback of src/model.jl:8-20), accumulating into h->G
 // ---------------------------------------------------------------------------------------------------------------------
+// What the pullback needs besides the activations: zeroed parameter-gradient / statistics accumulators and the transposed, flipped
+// weight copies for the input-gradient GEMMs (one launch for all layers).  None of it depends on the forward pass, so md2_train_loss
+// runs it on the (otherwise idle) second stream while the forward pass computes; without that stream it runs at the head of backward.
+static int backward_prepare(md2_handle* h, hipStream_t s) {
+    HIPCHK(hipMemsetAsync(h->G, 0, (size_t)h->n_int * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
+    launch_weight_to_dgrad_batched(h->P, h->WD, h->wdesc_dev, h->n_wdesc, s);
+    KCHK(); return 0;
+}
 static int model_backward(md2_handle* h) {
     hipStream_t s = h->stream;
     const int N = h->N, NL = h->NL, H = h->H, W = h->W;
-    HIPCHK(hipMemsetAsync(h->G, 0, (size_t)h->n_int * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
+    if (h->prep_done) { (void)hipStreamWaitEvent(s, h->ev_p1, 0); h->prep_done = false; }     // zeroed gradients + transposed weights were prepared during the forward pass
+    else if (int r = backward_prepare(h, s)) return r;
     // The gradient accumulators (Gfeat / Gblk / Gpool, 715 MB at B=32) are NOT zeroed: every buffer's first writer overwrites
     // (accumulate 0) and later writers add.  Stage buffers receive decoder / pose contributions in the target frame before the
     // encoder pullback reaches them, so the encoder's first writer uses accumulate mode 2 (add only in target frames).
-    // transposed / flipped weight copies for the input-gradient GEMMs: one launch for all layers
-    launch_weight_to_dgrad_batched(h->P, h->WD, h->wdesc_dev, h->n_wdesc, s);
 
     // ---- pose decoder pullback on its own stream, overlapping the depth decoder pullback.  Its last four launches accumulate into
     //      Gfeat[4] (frame 1 on top of the depth decoder's first write), so they wait for the depth decoder (ev_b) — see pose_backward.
@@ -542,7 +548,7 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     if (hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_c, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
-    if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+    if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_p0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_p1, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     h->two_streams = getenv("MD2_ONE_STREAM") == nullptr;
     if (hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming) != hipSuccess) return fail("hipStreamCreate failed");
     h->n_wg_streams = getenv("MD2_WG_STREAMS") ? atoi(getenv("MD2_WG_STREAMS")) : 1;
@@ -553,7 +559,7 @@ int32_t md2_destroy(md2_handle* h) {
     if (!h) return 0;
     (void)hipDeviceSynchronize();
     for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    if (h->s2) { for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->ev_pool[i]); (void)hipEventDestroy(h->ev_join); (void)hipStreamDestroy(h->s2); (void)hipEventDestroy(h->ev_a); (void)hipEventDestroy(h->ev_b); (void)hipEventDestroy(h->ev_c); (void)hipStreamDestroy(h->s3); (void)hipEventDestroy(h->ev_join4); (void)hipStreamDestroy(h->s4); }
+    if (h->s2) { for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->ev_pool[i]); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_p0); (void)hipEventDestroy(h->ev_p1); (void)hipStreamDestroy(h->s2); (void)hipEventDestroy(h->ev_a); (void)hipEventDestroy(h->ev_b); (void)hipEventDestroy(h->ev_c); (void)hipStreamDestroy(h->s3); (void)hipEventDestroy(h->ev_join4); (void)hipStreamDestroy(h->s4); }
     (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD);
     delete h; return 0;
 }
@@ -564,6 +570,7 @@ int32_t md2_set_intrinsics(md2_handle* h, const float* K, const float* invK) { s
 int64_t md2_params_count(md2_handle* h) { return h->n_flux; }
 int32_t md2_params_set(md2_handle* h, const float* host, int64_t n) {
     if (n != h->n_flux) { h->err = "md2_params_set: wrong parameter count"; return 2; }
+    h->have_fwd = false; h->prep_done = false;          // a pending md2_backward would mix old activations / weight copies with the new parameters
     std::vector<float> in((size_t)h->n_int);
     convert_params(h, in.data(), const_cast<float*>(host), true);
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -600,6 +607,12 @@ int32_t md2_model_forward(md2_handle* h, const float* x, float* d0, float* d1, f
 }
 int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, float* loss) {
     if (h->cfg.automasking && !auto_loss) { h->err = "md2_train_loss: automasking is on but auto_loss is NULL"; return 2; }
+    h->have_fwd = false; h->prep_done = false;
+    if (h->two_streams && h->s2) {          // ordered after everything already on the caller's stream (the previous ADAM step reads G and writes P)
+        (void)hipEventRecord(h->ev_p0, h->stream); (void)hipStreamWaitEvent(h->s2, h->ev_p0, 0);
+        if (int r = backward_prepare(h, h->s2)) return r;
+        (void)hipEventRecord(h->ev_p1, h->s2); h->prep_done = true;
+    }
     if (int r = model_forward(h, x)) return r;
     const float* disp[4] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p};
     if (int r = loss_forward(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;
@@ -785,9 +798,8 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         WgradArgs a{};
         a.x = xv.p; a.x_bs = xv.bs; a.x_ps = xv.ps; a.H = H; a.W = W; a.Cin = cinP;
         a.dy = dyv.p; a.dy_bs = dyv.bs; a.dy_ps = dyv.ps; a.Ho = Ho; a.Wo = Wo; a.Cout = coutP;
-        a.dw = gi; a.N = N; a.KH = k; a.KW = k; a.stride = stride; a.pad = p_eff; a.padmode = pad_mode; a.M = N * Ho * Wo;
+        a.dw = gi; a.N = N; a.KH = k; a.KW = k; a.stride = stride; a.pad = p_eff; a.padmode = pad_mode; a.M = N * Ho * Wo; a.db = gb;
         launch_conv_wgrad(a, s);
-        launch_colsum(dyv, gb, s);
         if (hipStreamSynchronize(s) != hipSuccess) return 1;
         std::vector<float> in(wn), f((size_t)Cin * Cout * k * k), bb(coutP);
         (void)hipMemcpy(in.data(), gi, wn * sizeof(float), hipMemcpyDeviceToHost); (void)hipMemcpy(bb.data(), gb, coutP * sizeof(float), hipMemcpyDeviceToHost);

@@ -73,6 +73,7 @@ struct WgradArgs {
     float* dw;
     int N, KH, KW, stride, pad, padmode;
     int M;
+    float* db;                    // optional bias gradient: db[co] += sum_{n,oh,ow} dy (fused into the all-taps kernels, a colsum launch otherwise)
 #ifdef MD2_ABLATE
     int ablate;
 #endif
