@@ -243,11 +243,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
             }
     }
+    // ---- optional BatchNorm statistics of this tile (the output rows past M were computed from masked loads and are exactly 0).
+    //      A lane holds 16 channels x (sum, sum of squares) over its TP pixels; the 32 pixel lanes of each half-wave are reduced with a
+    //      halving butterfly (step b: exchange the half of the values whose index bit 0 differs from lane bit b, 16+8+4+2+1 shuffles),
+    //      after which pixel lane p owns the total of value p = (g*4 + e)*2 + stat.
+    if constexpr (MF == 32 && TC == 1) {
+        if (a.stats) {
+            float v[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < TP; ++j) { const float z = acc[0][j][r]; s1 += z; s2 += z * z; }
+                v[2 * r] = s1; v[2 * r + 1] = s2;
+            }
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const bool up = (lane >> b) & 1;
+#pragma unroll
+                for (int k = 0; k < (16 >> b); ++k) {
+                    const float lo = v[2 * k], hi = v[2 * k + 1];
+                    v[k] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 1 << b);
+                }
+            }
+            const int p = lane & 31, r = p >> 1;                 // accumulator register r = 4g + e -> channel row 8g + 4*(lane>>5) + e
+            const int co = c0 + wc * (BN / WC) + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            atomicAdd(a.stats + (size_t)(blockIdx.x % BN_STAT_SLOTS) * 2 * a.Cout + (p & 1) * a.Cout + co, (double)v[0]);
+        }
+    }
 }
 
 template <int BM, int BN, int WP, int WC, int MF>
-static void launch_tile(const ConvArgs& a, hipStream_t s) {
+static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     static_assert((BM / WP) % MF == 0 && (BN / WC) % MF == 0, "wave tile must be a multiple of the MFMA tile");
+    ConvArgs a = a_in;
+    constexpr bool fuses_stats = MF == 32 && (BN / WC) == 32;
+    if (a.stats && (!fuses_stats || a.ksplit > 1 || a.ostep != 1 || a.bias || a.act != ACT_NONE || a.accumulate || a.dact_src)) a.stats = nullptr;
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
     const dim3 g(grid, a.ksplit);
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
@@ -256,6 +287,11 @@ static void launch_tile(const ConvArgs& a, hipStream_t s) {
         case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), g, dim3(256), 0, s, a); break;
         case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), g, dim3(256), 0, s, a); break;
         default: fprintf(stderr, "md2: conv_igemm: unsupported tap count %d\n", a.nkh * a.nkw); abort();
+    }
+    if (a_in.stats && !a.stats) {                  // not fused (16-wide tiles, split-K): one more pass over the output
+        if (a.ostep != 1 || a_in.bias || a_in.act != ACT_NONE) { fprintf(stderr, "md2: conv_igemm: BatchNorm statistics need a dense, bias-free, linear output\n"); abort(); }
+        View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
+        launch_colstats(yv, a_in.stats, s);
     }
 }
 
@@ -432,6 +468,7 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (patch_eligible(a)) {
         if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || (a.dact_src && a.da_ps % 4 != 0)) { fprintf(stderr, "md2: conv3x3_patch: unaligned view\n"); abort(); }
         if (a.Cout == 16) launch_patch<16>(a, s); else launch_patch<32>(a, s);
+        if (a.stats) { View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps; launch_colstats(yv, a.stats, s); }
         return;
     }
     if (a.dil <= 1 || a.ostep != 1) { launch_conv_igemm_one(a, s); return; }

@@ -112,17 +112,19 @@ void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View&
     colstats_launch(1, z, &dy, yact, act, stats, acc, s);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int C, double count) {
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int C, double count, int slots) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mean = acc[c] / count;
-    double var = acc[C + c] / count - mean * mean;     // biased variance (Flux BatchNorm train mode)
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < slots; ++k) { s1 += acc[(size_t)k * 2 * C + c]; s2 += acc[(size_t)k * 2 * C + C + c]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;             // biased variance (Flux BatchNorm train mode)
     if (var < 0) var = 0;
     stats[c] = (float)mean;
     stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
 }
-void launch_bn_finalize(const double* acc, float* stats, int C, double count, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, stats, C, count);
+void launch_bn_finalize(const double* acc, float* stats, int C, double count, int slots, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, stats, C, count, slots);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,

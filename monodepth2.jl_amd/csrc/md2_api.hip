@@ -180,11 +180,11 @@ static void plan_buffers(md2_handle* h) {
     h->drvec = h->alloc<float>(6 * N); h->dtvec = h->alloc<float>(6 * N);
     for (BNL* b : h->bns) b->stats = h->alloc<float>(2 * b->c);
     size_t nd = 0;
-    for (BNL* b : h->bns) nd += 4 * (size_t)b->c;
+    for (BNL* b : h->bns) nd += (size_t)(2 * BN_STAT_SLOTS + 2) * b->c;
     nd += (size_t)16 * N + 24 * N;
     h->acc_count = nd; h->acc_all = h->alloc<double>(nd);
     double* ap = h->acc_all;
-    for (BNL* b : h->bns) { b->acc = ap; ap += 2 * b->c; }
+    for (BNL* b : h->bns) { b->acc = ap; ap += (size_t)2 * BN_STAT_SLOTS * b->c; }      // [slot][sum | sum of squares][c]
     h->acc_fwd_count = ap - h->acc_all;
     h->acc_bwd = ap;
     for (BNL* b : h->bns) { b->acc_b = ap; ap += 2 * b->c; }
@@ -235,9 +235,9 @@ static void run_igemm(md2_handle* h, const ConvArgs& a) {
     if (h->prof) h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a);
 }
 // forward conv (kind 0) on views.  x.C must equal c.cinP, y.C == c.coutP
-static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act) {
+static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act, double* bn_stats = nullptr) {
     ConvArgs a = conv_args(x, h->P + c.w, y, c.k, c.stride, padmode == PAD_REFLECT ? 1 : c.pad, 1, padmode);
-    a.bias = c.bias ? h->P + c.b : nullptr; a.act = act;
+    a.bias = c.bias ? h->P + c.b : nullptr; a.act = act; a.stats = bn_stats;
     run_igemm(h, a);
 }
 // input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
@@ -265,9 +265,9 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
     if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
 }
+// the batch statistics were accumulated into b.acc by the convolution that produced z (conv_fwd(..., b.acc))
 static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* residual, int act, const View& y) {
-    launch_colstats(z, b.acc, h->chain());
-    launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), h->chain());
+    launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), BN_STAT_SLOTS, h->chain());
     launch_bn_apply(z, b.stats, h->P + b.g, h->P + b.b, residual, act, y, h->chain());
 }
 // dy: gradient wrt the BN output (already masked by any following ReLU) -> dz
@@ -321,15 +321,15 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
     HIPCHK(hipMemsetAsync(h->acc_all, 0, h->acc_fwd_count * sizeof(double), s));
     // ---- encoder: stem (im2col + GEMM) + BN + ReLU, maxpool, 8 basic blocks
     launch_im2col_stem(x, NL, h->C, H, W, h->col, h->Kpad, s);
-    { View zc = make_view(h->z0.p, 1, 1, NL * (H / 2) * (W / 2), 64); ConvArgs a = conv_args(h->colv, h->P + h->stem.w, zc, 1, 1, 0, 1, PAD_ZERO); run_igemm(h, a); }
+    { View zc = make_view(h->z0.p, 1, 1, NL * (H / 2) * (W / 2), 64); ConvArgs a = conv_args(h->colv, h->P + h->stem.w, zc, 1, 1, 0, 1, PAD_ZERO); a.stats = h->stem_bn.acc; run_igemm(h, a); }
     bn_fwd(h, h->stem_bn, h->z0, nullptr, ACT_RELU, h->a0);
     launch_maxpool_fwd(h->a0, h->p0, h->pool_arg, s);
     for (int i = 0; i < 8; ++i) {
         Block& B = h->blk[i];
-        conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE); bn_fwd(h, B.b1, B.z1, nullptr, ACT_RELU, B.a1);
-        conv_fwd(h, B.c2, B.a1, B.z2, PAD_ZERO, ACT_NONE);
+        conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_fwd(h, B.b1, B.z1, nullptr, ACT_RELU, B.a1);
+        conv_fwd(h, B.c2, B.a1, B.z2, PAD_ZERO, ACT_NONE, B.b2.acc);
         if (B.down) {
-            conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE);
+            conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc);
             bn_fwd(h, B.bd, B.zd, nullptr, ACT_NONE, B.sd);                 // raw zd is kept for the pullback
         }
         bn_fwd(h, B.b2, B.z2, B.down ? &B.sd : &B.in, ACT_RELU, B.out);
@@ -817,7 +817,7 @@ int32_t md2_bn_train_fwd(const float* x, const float* gamma, const float* beta, 
     float *xi = tmp_alloc((size_t)N * H * W * C, s), *st = tmp_alloc(2 * C, s); double* acc = (double*)tmp_alloc(4 * C, s);
     if (!xi || !st || !acc) return 3;
     View v = make_view(xi, N, H, W, C); launch_nchw_to_view(x, v, s);
-    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), s);
+    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), 1, s);
     launch_bn_apply(v, st, gamma, beta, nullptr, relu ? ACT_RELU : ACT_NONE, v, s);
     launch_nhwc_to_nchw(nullptr, v, y, s);
     (void)hipFreeAsync(xi, s); (void)hipFreeAsync(st, s); (void)hipFreeAsync(acc, s);
@@ -831,7 +831,7 @@ int32_t md2_bn_train_bwd(const float* x, const float* gamma, const float* dy, fl
     if (!xi || !di || !oi || !st || !acc) return 3;
     View v = make_view(xi, N, H, W, C), d = make_view(di, N, H, W, C), o = make_view(oi, N, H, W, C);
     launch_nchw_to_view(x, v, s); launch_nchw_to_view(dy, d, s);
-    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), s);
+    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), 1, s);
     (void)hipMemsetAsync(dgamma, 0, C * sizeof(float), s); (void)hipMemsetAsync(dbeta, 0, C * sizeof(float), s);
     launch_bn_bwd_reduce(d, nullptr, ACT_NONE, v, st, acc + 2 * C, s);
     launch_bn_bwd_apply(d, nullptr, ACT_NONE, v, st, gamma, acc + 2 * C, (double)v.pixels(), o, dgamma, dbeta, s);

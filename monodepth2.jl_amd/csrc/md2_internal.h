@@ -46,6 +46,7 @@ __device__ inline float act_deriv(float o, int act) {
 //   t = o*stride - pad + k ; dil>1: taps with t % dil != 0 contribute 0 and ih = t/dil (transposed conv, used for
 //   the input-gradient of strided convs) ; PAD_ZERO: out-of-range -> 0 ; PAD_REFLECT: mirrored.
 //   epi: (+bias) -> act -> (* act_deriv(dact_src)) -> (+ old y if accumulate)
+constexpr int BN_STAT_SLOTS = 8;
 struct ConvArgs {
     const float* x; long x_bs; int x_ps; int H, W, Cin;
     const float* w;
@@ -59,6 +60,9 @@ struct ConvArgs {
     // tap lattice: taps kh = kh0 + a*khs (a < nkh), kw = kw0 + b*kws (b < nkw)   (dense: 0,1,KH / 0,1,KW)
     int kh0, khs, nkh, kw0, kws, nkw;
     int ksplit;                   // set by the launcher: >1 = the channel chunks are split over gridDim.y and summed with fp32 atomics
+    // optional training-BatchNorm statistics of the OUTPUT (no bias / activation): stats[slot][0..Cout) += sum_pixels y, stats[slot][Cout..2Cout) += sum y^2,
+    // slot = blockIdx.x % BN_STAT_SLOTS spreads the double atomics; fused into the 32x32 tiles' epilogue, a colstats launch (slot 0) otherwise
+    double* stats;
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only
 #endif
@@ -100,7 +104,7 @@ void launch_nchw_to_view(const float* src, const View& v, hipStream_t s);
 // per-channel sum / sum of squares of a view -> double[2*C] (must be zeroed by caller)
 void launch_colstats(const View& z, double* acc, hipStream_t s);
 // mean/invstd from acc; also zeroes nothing.  stats: float[2*C] = mean, invstd
-void launch_bn_finalize(const double* acc, float* stats, int C, double count, hipStream_t s);
+void launch_bn_finalize(const double* acc /*[slots][2C]*/, float* stats, int C, double count, int slots, hipStream_t s);
 // y = act(gamma*(z-mean)*invstd + beta + residual)
 void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s);
 // g = dy * act_deriv(yact) ; acc[0..C) += sum g ; acc[C..2C) += sum g*xhat          (acc double, zeroed by caller)
