@@ -902,7 +902,7 @@ static void launch_wgrad_patch(const WgradArgs& a, hipStream_t s) {
 // encoder layers at ~107.  (Measured alternatives, both slower: 3 or 6 waves per block that each own one filter ROW -- 48 accumulator
 // registers, 3 waves per SIMD -- reach 86 and 78 TFLOP/s.)
 // ------------------------------------------------------------------------------------------------------------
-constexpr int WT_MAXW = 32;
+constexpr int WT_MAXW = 30;                            // tile columns; the patch is TW + 2 <= 32 columns = one column per 8 threads
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs a, int TW, int tiles_x, int tiles_y, int total_tiles, int ci_groups) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     float* Ys = psm;                               // [4*TW][32]
@@ -910,8 +910,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lcol = lane & 31, lp = lane >> 5;
     const int cgi = blockIdx.y % ci_groups, cgo = blockIdx.y / ci_groups;
-    const int PW = TW + 2, npp = 6 * PW * 8, nyp = 4 * TW * 8;       // float4 slots per tile (patch, dy)
-    const unsigned mPW = 65536u / PW + 1, mTW = 65536u / TW + 1;      // x / PW == (x * mPW) >> 16 for x < 6*PW (exact: x * PW < 65536)
+    const int PW = TW + 2;
 
     f32x16 acc[9];
     float bsum = 0.f;                              // bias gradient: this lane's share of sum_px dy[px][co = lcol]
@@ -920,62 +919,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-    constexpr int NPL = (6 * (WT_MAXW + 2) * 8 + 255) / 256, NYL = (4 * WT_MAXW * 8 + 255) / 256;      // 7, 4
+    // Loader mapping: thread = (column col = tid/8 of the tile / patch, channel quad q = tid%8); it loads that column of all 6 patch rows
+    // and all 4 dy rows.  Everything that depends on the row (bounds, reflection, row offset) is then uniform -> scalar instructions,
+    // and the per-thread address work per tile is one column offset (this section was ~440 VALU instructions per tile with a flat
+    // slot -> pixel mapping, as long as a third of the tile's MFMA time).
+    const int q = tid & 7, col = tid >> 3;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    unsigned okbits = 0;                           // bit i (patch slots), bit 16+i (dy slots): the load is inside the image, else it is committed as zero
-    u32x4 pv[NPL], yv[NYL];
+    unsigned okbits = 0;                           // bit i (patch rows), bit 16+i (dy rows): the load is inside the image, else it is committed as zero
+    u32x4 pv[6], yv[4];
     const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+#ifdef MD2_ABLATE
+    const int abl = a.ablate;      // tools/conv_bench only: 1 no global loads, 64 no LDS commit, 32 no LDS operand reads, 4 no MFMA, 16 no atomics tail, 8 no barriers
+#else
+    constexpr int abl = 0;
+#endif
     for (int s = -1; s < my_tiles; ++s) {                            // s = -1 is the prologue (only issues tile 0's loads)
         if (s >= 0) {
-            __syncthreads();                                         // the previous tile's MFMAs are done reading LDS
+            if (!(abl & 8)) __syncthreads();                         // the previous tile's MFMAs are done reading LDS
             // (okbits still describes the registers being committed: it is recomputed for the next tile below)
+            if (col < PW && !(abl & 64)) {
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-                const int f = tid + i * 256;
-                if (f < npp) *reinterpret_cast<u32x4*>(Xs + f * 4) = pv[i] & (0u - ((okbits >> i) & 1u));
+                for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(Xs + ((i * PW + col) * 8 + q) * 4) = pv[i] & (0u - ((okbits >> i) & 1u));
             }
+            if (col < TW && !(abl & 64)) {
 #pragma unroll
-            for (int i = 0; i < NYL; ++i) {
-                const int f = tid + i * 256;
-                if (f < nyp) *reinterpret_cast<u32x4*>(Ys + f * 4) = yv[i] & (0u - ((okbits >> (16 + i)) & 1u));
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(Ys + ((i * TW + col) * 8 + q) * 4) = yv[i] & (0u - ((okbits >> (16 + i)) & 1u));
             }
-            __syncthreads();
+            if (!(abl & 8)) __syncthreads();
         }
-        if (s + 1 < my_tiles) {
+        if (s + 1 < my_tiles && !(abl & 1)) {
             const int tile = blockIdx.x + (s + 1) * gridDim.x;
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            const float* xin = a.x + (long)n * a.x_bs + cgi * 32; const float* dyin = a.dy + (long)n * a.dy_bs + cgo * 32;
+            const float* xin = a.x + (long)n * a.x_bs + cgi * 32 + q * 4; const float* dyin = a.dy + (long)n * a.dy_bs + cgo * 32 + q * 4;
+            int iw = tx * TW - a.pad + col;
+            if (a.padmode == PAD_REFLECT) iw = refl_idx(max(min(iw, a.W), -1), a.W);
+            const bool wok = iw >= 0 && iw < a.W && col < PW;
+            const unsigned xcol = (unsigned)(min(max(iw, 0), a.W - 1) * a.x_ps);
+            const int ox = tx * TW + col;
+            const bool cok = col < TW && ox < a.Wo;
+            const unsigned ycol = (unsigned)(min(ox, a.Wo - 1) * a.dy_ps);
             okbits = 0;
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-                const int f = min(tid + i * 256, npp - 1), pp = f >> 3, q = f & 7, pr = (int)((pp * mPW) >> 16), pc = pp - pr * PW;
-                int ih = ty * 4 - a.pad + pr, iw = tx * TW - a.pad + pc;
-                if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
-                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                ih = min(max(ih, 0), a.H - 1); iw = min(max(iw, 0), a.W - 1);
-                okbits |= (ok ? 1u : 0u) << i;
-                pv[i] = *reinterpret_cast<const u32x4*>(xin + (unsigned)(((long)ih * a.W + iw) * a.x_ps + q * 4));
+            for (int i = 0; i < 6; ++i) {                            // row quantities are uniform (scalar)
+                int ih = ty * 4 - a.pad + i;
+                if (a.padmode == PAD_REFLECT) ih = refl_idx(max(min(ih, a.H), -1), a.H);
+                const bool hok = ih >= 0 && ih < a.H;
+                okbits |= ((hok && wok) ? 1u : 0u) << i;
+                pv[i] = *reinterpret_cast<const u32x4*>(xin + (unsigned)(min(max(ih, 0), a.H - 1) * a.W * a.x_ps) + xcol);
             }
 #pragma unroll
-            for (int i = 0; i < NYL; ++i) {
-                const int f = min(tid + i * 256, nyp - 1), pix = f >> 3, q = f & 7, r = (int)((pix * mTW) >> 16), c = pix - r * TW;
-                const int oy = ty * 4 + r, ox = tx * TW + c;
-                const bool ok = oy < a.Ho && ox < a.Wo;
-                okbits |= (ok ? 1u : 0u) << (16 + i);
-                yv[i] = *reinterpret_cast<const u32x4*>(dyin + (unsigned)(((long)min(oy, a.Ho - 1) * a.Wo + min(ox, a.Wo - 1)) * a.dy_ps + q * 4));
+            for (int i = 0; i < 4; ++i) {
+                const int oy = ty * 4 + i;
+                okbits |= ((oy < a.Ho && cok) ? 1u : 0u) << (16 + i);
+                yv[i] = *reinterpret_cast<const u32x4*>(dyin + (unsigned)(min(oy, a.Ho - 1) * a.Wo * a.dy_ps) + ycol);
             }
         }
         if (s < 0) continue;
-        // ---- wave w contracts tile row w: TW/2 k-steps of 2 pixels, 9 taps each
+    // ---- wave w contracts tile row w: TW/2 k-steps of 2 pixels, 9 taps each
         const float* yrow = Ys + (wave * TW + lp) * 32 + lcol;
         const float* xrow = Xs + (wave * PW + lp) * 32 + lcol;
         const int ksteps = TW >> 1;
+        // (reading step kk+1's operands ahead of step kk's MFMAs by hand -- sched_barrier + register rotation -- measured 6% SLOWER)
         for (int kk = 0; kk < ksteps; ++kk) {
-            const float av = yrow[kk * 64];
+            const float av = (abl & 32) ? (float)kk : yrow[kk * 64];
             bsum += av;
             float bv[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) bv[t] = xrow[kk * 64 + ((t / 3) * PW + (t % 3)) * 32];
+            for (int t = 0; t < 9; ++t) bv[t] = (abl & 32) ? (float)(kk + t) : xrow[kk * 64 + ((t / 3) * PW + (t % 3)) * 32];
+            if (abl & 4) { bsum += bv[0] + bv[8]; continue; }
 #pragma unroll
             for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
         }
@@ -984,6 +995,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
         bsum += __shfl_xor(bsum, 32);
         if (lp == 0) atomicAdd(a.db + cgo * 32 + lcol, bsum);
     }
+    if (abl & 16) { if (acc[0][0] == 123.456f && bsum == 1.f) a.dw[0] = 1.f; return; }
     // ---- reduce the 4 waves' accumulators through LDS, then one atomic per weight and block
     float* red = psm;                              // [9*16][64 lanes]
     for (int w = 0; w < 4; ++w) {
