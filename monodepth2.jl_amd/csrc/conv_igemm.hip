@@ -506,7 +506,11 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
         const long tiles64 = (long)((a.M + 63) / 64) * (a.Cout / (a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : 16)));
         const int cpt = a.Cin / 16;
         static const int want = getenv("MD2_IGEMM_SPLIT_BLOCKS") ? atoi(getenv("MD2_IGEMM_SPLIT_BLOCKS")) : 512;
-        if (tiles64 < 100 && cpt >= 4 && want > 0) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
+        // ... and the same for up to one tile per CU when the serial K loop is very long (>= 256 steps: the 512-channel 3x3 layers at 1/32 scale;
+        // measured: 0.175 -> 0.106 ms and 0.179 -> 0.138 ms there, but 0.092 -> 0.105 ms for the 256-channel layers with 144 steps)
+        static const int mid = getenv("MD2_IGEMM_SPLIT_MID") ? atoi(getenv("MD2_IGEMM_SPLIT_MID")) : 256;
+        const bool few = tiles64 < 100 || (tiles64 < mid && (long)cpt * a.nkh * a.nkw >= 256);
+        if (few && cpt >= 4 && want > 0) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
     }
     View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
     const float* bias2 = nullptr; int act2 = ACT_NONE;
@@ -1033,6 +1037,7 @@ static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
         per_cu = std::min(per_cu, 2);
+        if (getenv("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("MD2_TAPS_PER_CU"))));
     }
     const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
     const int gx = std::max(1, std::min(total, 256 * per_cu / groups));                    // persistent: the co-resident blocks, shared by the weight tiles

@@ -545,7 +545,12 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     const float Kc[9] = {(float)f, 0, 0, 0, (float)f, 0, (float)cx, (float)cy, 1};
     const float iKc[9] = {(float)(1 / f), 0, 0, 0, (float)(1 / f), 0, (float)(-cx / f), (float)(-cy / f), 1};
     std::memcpy(h->K, Kc, sizeof(Kc)); std::memcpy(h->invK, iKc, sizeof(iKc));
-    if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    {   // the weight-gradient stream only fills in around the dependency chain on the caller's stream: lowest priority (MD2_S2_PRIO: 0 default queue priority)
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const int want = getenv("MD2_S2_PRIO") ? atoi(getenv("MD2_S2_PRIO")) : 1;
+        const int prio = want > 0 ? lo : (want < 0 ? hi : 0);
+        if (hipStreamCreateWithPriority(&h->s2, hipStreamNonBlocking, prio) != hipSuccess || hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    }
     if (hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_c, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     for (int i = 0; i < 64; ++i) if (hipEventCreateWithFlags(&h->ev_pool[i], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_p0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_p1, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
