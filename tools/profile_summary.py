@@ -1,0 +1,74 @@
+"""Turn rocprofv3 CSV output into the markdown summaries kept under profiles/.
+
+  kernel stats :  profile_summary.py stats  <dir with *_kernel_stats.csv>  <steps in trace>  <title line>  > profiles/rNN_..._kernel_stats.md
+  HBM traffic  :  profile_summary.py pmc    <dir of the FETCH_SIZE pass>  <dir of the WRITE_SIZE pass>  <steps in trace>  > profiles/rNN_pmc_hbm_traffic.md
+
+FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE tallies a 128-B request of a wide coalesced read as 64 B, so reads are
+doubled (MI355X_MICROARCH.md, "HBM" section); the two counters do not fit one pass, hence two runs of the same command.
+"""
+import csv, glob, sys, collections
+
+
+def klass(name):
+    if "conv_igemm_kernel" in name or "conv3x3_patch_kernel" in name:
+        return "conv_igemm"
+    if "conv_wgrad_kernel" in name or "conv3x3_wgrad" in name:
+        return "conv_wgrad"
+    if "loss_fwd_kernel" in name:
+        return "loss_fwd"
+    if "loss_bwd_kernel" in name:
+        return "loss_bwd"
+    return "other"
+
+
+def stats(d, steps, title):
+    f = glob.glob(d + "/*kernel_stats.csv")[0]
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    print("# " + title)
+    print()
+    print("| kernel | calls | total ms | avg us | % |")
+    print("|---|---|---|---|---|")
+    for r in rows:
+        if float(r["TotalDurationNs"]) / tot < 0.004:
+            continue
+        print("| `%s` | %s | %.2f | %.1f | %.2f |" % (r["Name"][:110], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        k = klass(r["Name"]); agg[k][0] += int(r["Calls"]); agg[k][1] += float(r["TotalDurationNs"])
+    print()
+    print("sum of kernel durations: %.2f ms/step over %d steps in the trace" % (tot / 1e6 / steps, steps))
+    print()
+    print("| class | launches/step | ms/step | avg us |")
+    print("|---|---|---|---|")
+    for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd", "other"):
+        n, t = agg[k]
+        print("| %s | %.1f | %.3f | %.1f |" % (k, n / steps, t / 1e6 / steps, t / 1e3 / max(n, 1)))
+
+
+def pmc(df, dw, steps):
+    def load(d, counter):
+        f = glob.glob(d + "/*counter_collection.csv")[0]
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = klass(r["Kernel_Name"]); agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
+        return agg
+    fe, wr = load(df, "FETCH_SIZE"), load(dw, "WRITE_SIZE")
+    print("| kernel class | launches/step | FETCH_SIZE KiB/step (raw) | read MB/step (x2 corrected) | WRITE_SIZE MB/step | read+write MB per launch |")
+    print("|---|---|---|---|---|---|")
+    for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd", "other"):
+        n = fe[k][0] / steps
+        rd = 2 * fe[k][1] * 1024 / 1e6 / steps
+        w = wr[k][1] * 1024 / 1e6 / steps
+        print("| %s | %.1f | %.0f | %.1f | %.1f | %.2f |" % (k, n, fe[k][1] / steps, rd, w, (rd + w) / max(n, 1e-9)))
+    print()
+    print("bench.py table (bytes per launch):", {k: round((2 * fe[k][1] * 1024 + wr[k][1] * 1024) / max(fe[k][0], 1), -5) for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd")})
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    else:
+        pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]))
