@@ -47,6 +47,9 @@ CONV_CASES = [
     (1, 96, 64, 128, 32, 3, 1, 0, "reflect"),     # decoder c2 with skip: 6 channel chunks
     (2, 32, 69, 131, 16, 3, 1, 0, "reflect"),     # several images per persistent block
     (1, 32, 64, 136, 32, 3, 1, 1, "zeros"),       # zero padding: masked halo loads
+    # all-taps weight gradient (every 3x3 / stride-1 layer with Cin, Cout % 32 == 0): odd sizes -> partial tile rows, a masked last column
+    (3, 32, 5, 9, 64, 3, 1, 1, "zeros"),          # Ho = 5: second tile row has one valid row; Wo = 9 -> TW = 10
+    (2, 64, 7, 33, 32, 3, 1, 0, "reflect"),       # Wo = 33 -> two tiles of 18 columns, the second ragged; reflected halo
 ]
 
 
