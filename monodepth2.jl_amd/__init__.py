@@ -9,7 +9,7 @@ from . import _lib  # noqa: F401
 
 def __getattr__(name):
     # lazy: importing the package must work on the CPU-only build box; using the product API must not silently fall back
-    if name in ("monodepth", "parallel"):
+    if name in ("monodepth", "parallel", "data", "train"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

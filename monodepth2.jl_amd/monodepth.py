@@ -380,9 +380,18 @@ def train_loss(model: Model, x, auto_loss, cache: TrainCache, parameters: Params
     if parameters.automasking and auto_loss is None:
         raise ValueError("parameters.automasking is set but auto_loss is None")
     vis_disparity = vis_warped = vis_loss = None
-    if do_visualization:                      # src/training.jl:35-37 (vis_warped / vis_loss stay on the device in this build)
+    if do_visualization:                      # src/training.jl:34-37, 72-75: host copies of the last scale's disparity / warps / loss map
         ds, poses = model(x, cache.source_ids, cache.target_id)       # BEFORE the training forward: it reuses the activation buffers
         vis_disparity = ds[-1].cpu()
+        target_x = x[:, cache.target_id - 1].contiguous()
+        warped = []
+        for pose, sid in zip(poses, cache.source_ids):
+            R, t = composeT(pose.rvec, pose.tvec, sid < cache.target_id)
+            warped.append(warp(ds[-1], x[:, sid - 1].contiguous(), cache.K, cache.invK, R, t, parameters.min_depth, parameters.max_depth))
+        wl = prediction_loss(cache.ssim, warped, target_x)
+        if parameters.automasking and auto_loss is not None:
+            wl = _apply_mask(_f32(auto_loss), wl)
+        vis_warped, vis_loss = [w.cpu() for w in warped], wl.cpu()
     loss = torch.empty((), device=x.device)
     al = _f32(auto_loss) if auto_loss is not None else None
     model._keepalive = (x, al)

@@ -58,6 +58,11 @@ class DataParallel:
     def train_step(self, x, auto_loss, cache, parameters):
         from . import monodepth as md
         loss = md.train_step(self.model, x, auto_loss, cache, parameters, do_update=False)
+        self.allreduce_and_update()
+        return loss
+
+    def allreduce_and_update(self):
+        """After a local `gradient(model)`: sum the gradient buffers over the ranks, then ADAM on the mean."""
+        from . import monodepth as md
         allreduce_sum_(self.model.grad_buffer(), self.group)
         md.update(md.ADAM(self.model.lr), self.model, grad_scale=1.0 / world_size(self.group))
-        return loss
