@@ -14,27 +14,6 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ const float* vptr(const View& v, int n, long r) { return v.p + (long)n * v.bs + r * v.ps; }
 __device__ __forceinline__ float* vptrw(const View& v, int n, long r) { return v.p + (long)n * v.bs + r * v.ps; }
 
-// ---- stem im2col: x [NL][C][H][W] (reference layout) -> col [NL*Ho*Wo][Kpad], k = (kh*7+kw)*C + c ; 7x7 s2 p3 -------
-__global__ void im2col_stem_kernel(const float* __restrict__ x, int NL, int C, int H, int W, float* __restrict__ col, int Kpad) {
-    const int Ho = H / 2, Wo = W / 2;
-    const long total = (long)NL * Ho * Wo * Kpad;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = i % Kpad; const long m = i / Kpad;
-        const int ow = m % Wo; const long t = m / Wo; const int oh = t % Ho; const int n = t / Ho;
-        float v = 0.f;
-        if (k < 49 * C) {
-            const int c = k % C, tap = k / C, kh = tap / 7, kw = tap % 7;
-            const int ih = oh * 2 - 3 + kh, iw = ow * 2 - 3 + kw;
-            if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((long)n * C + c) * H + ih) * W + iw];
-        }
-        col[i] = v;
-    }
-}
-void launch_im2col_stem(const float* x, int NL, int C, int H, int W, float* col, int Kpad, hipStream_t s) {
-    const long total = (long)NL * (H / 2) * (W / 2) * Kpad;
-    hipLaunchKernelGGL(im2col_stem_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, x, NL, C, H, W, col, Kpad);
-}
-
 // ---- layout conversion for the op-level entry points --------------------------------------------------------------
 __global__ void nchw_to_view_kernel(const float* __restrict__ src, View v) {
     const long total = (long)v.N * v.H * v.W * v.C;

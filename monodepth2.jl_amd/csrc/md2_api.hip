@@ -25,7 +25,7 @@ namespace {
 struct ConvL {
     int cin = 0, cout = 0, k = 1, stride = 1, pad = 0; bool bias = false;
     int cinP = 0, coutP = 0, taps = 1;   // internal (padded) geometry: weights [coutP][taps][cinP]
-    int kind = 0;                        // 0 igemm, 1 stem (im2col: taps=1, cinP=Kpad), 2 head (cout 1, direct kernel)
+    int kind = 0;                        // 0 igemm, 1 stem (direct 7x7 kernels, weights [64][Kpad]: taps=1, cinP=Kpad), 2 head (cout 1, direct kernel)
     long w = 0, b = 0;                   // offsets (floats) into the internal flat buffers
     long fw = 0, fb = 0;                 // offsets into the Flux-layout flat vector
     long wn() const { return (long)coutP * taps * cinP; }
@@ -52,7 +52,7 @@ struct md2_handle {
     char* arena = nullptr; size_t arena_off = 0;
     double* acc_all = nullptr; size_t acc_count = 0; double* acc_bwd = nullptr; size_t acc_fwd_count = 0, acc_bwd_count = 0;
     int Kpad = 64;
-    float* col = nullptr; View colv, z0, a0, p0; uint8_t* pool_arg = nullptr;
+    View z0, a0, p0; uint8_t* pool_arg = nullptr;
     View feat[5], y1[5], cat[5], y2[5], dispv[4];
     View sqcat, py1, py2, py3; float *rvec = nullptr, *tvec = nullptr, *Rt = nullptr;
     double *loss_part = nullptr, *dRt_acc = nullptr; float *totals = nullptr, *loss_dev = nullptr, *ddisp_full = nullptr, *drvec = nullptr, *dtvec = nullptr;
@@ -145,8 +145,6 @@ static void convert_params(md2_handle* h, float* internal, float* flux, bool to_
 static void plan_buffers(md2_handle* h) {
     const int N = h->N, NL = h->NL, H = h->H, W = h->W;
     h->arena_off = 0;
-    h->col = h->alloc<float>((size_t)NL * (H / 2) * (W / 2) * h->Kpad);
-    h->colv = make_view(h->col, 1, 1, NL * (H / 2) * (W / 2), h->Kpad);
     h->z0 = h->alloc_view(NL, H / 2, W / 2, 64); h->a0 = h->alloc_view(NL, H / 2, W / 2, 64);
     h->p0 = h->alloc_view(NL, H / 4, W / 4, 64); h->pool_arg = h->alloc<uint8_t>((size_t)NL * (H / 4) * (W / 4) * 64);
     h->feat[0] = h->a0;
@@ -247,6 +245,17 @@ static void conv_dgrad(md2_handle* h, const ConvL& c, const View& dy, const View
     if (dact_src) { a.dact_src = dact_src->p; a.da_bs = dact_src->bs; a.da_ps = dact_src->ps; a.dact = dact; }
     run_igemm(h, a);
 }
+// stream a weight gradient is enqueued on: the side stream, forked by event from the chain at this point (its dy is complete)
+static hipStream_t wgrad_stream(md2_handle* h) {
+    hipStream_t st = h->chain();
+    if (h->two_streams && h->s2) {          // fork: everything enqueued on this chain's stream so far happens-before this weight gradient
+        hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
+        hipStream_t tgt = (h->n_wg_streams > 1 && (h->wg_rr++ & 1)) ? h->s4 : h->s2;      // round-robin over the weight-gradient streams
+        (void)hipEventRecord(ev, h->chain()); (void)hipStreamWaitEvent(tgt, ev, 0);
+        st = tgt; h->forked = true;
+    }
+    return st;
+}
 static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View& dy, int padmode) {
     WgradArgs a{};
     a.x = x.p; a.x_bs = x.bs; a.x_ps = x.ps; a.H = x.H; a.W = x.W; a.Cin = x.C;
@@ -255,13 +264,7 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     a.M = dy.N * dy.H * dy.W; a.db = c.bias ? h->G + c.b : nullptr;
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode);
-    hipStream_t st = h->chain();
-    if (h->two_streams && h->s2) {          // fork: everything enqueued on this chain's stream so far (dy is complete) happens-before this weight gradient
-        hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
-        hipStream_t tgt = (h->n_wg_streams > 1 && (h->wg_rr++ & 1)) ? h->s4 : h->s2;      // round-robin over the weight-gradient streams
-        (void)hipEventRecord(ev, h->chain()); (void)hipStreamWaitEvent(tgt, ev, 0);
-        st = tgt; h->forked = true;
-    }
+    hipStream_t st = wgrad_stream(h);
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
     if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
 }
@@ -293,7 +296,6 @@ static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp
 // ---------------------------------------------------------------------------------------------------------------------
 // Temporarily re-batch every activation view: n_enc encoder images, n_dec decoder samples (<= the sizes the arena was planned for).
 static void set_batch(md2_handle* h, int n_enc, int n_dec) {
-    h->colv.W = n_enc * (h->H / 2) * (h->W / 2); h->colv.bs = (long)h->colv.W * h->colv.C;
     h->z0.N = h->a0.N = h->p0.N = n_enc;
     for (int i = 0; i < 8; ++i) { Block& B = h->blk[i]; B.in.N = B.z1.N = B.a1.N = B.z2.N = B.out.N = n_enc; if (B.down) B.zd.N = B.sd.N = n_enc; }
     for (int i = 0; i < 5; ++i) { h->feat[i].N = n_enc; h->y1[i].N = h->cat[i].N = h->y2[i].N = n_dec; }
@@ -319,9 +321,12 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
     hipStream_t s = h->stream;
     const int NL = h->z0.N, N = NL / L, H = h->H, W = h->W;
     HIPCHK(hipMemsetAsync(h->acc_all, 0, h->acc_fwd_count * sizeof(double), s));
-    // ---- encoder: stem (im2col + GEMM) + BN + ReLU, maxpool, 8 basic blocks
-    launch_im2col_stem(x, NL, h->C, H, W, h->col, h->Kpad, s);
-    { View zc = make_view(h->z0.p, 1, 1, NL * (H / 2) * (W / 2), 64); ConvArgs a = conv_args(h->colv, h->P + h->stem.w, zc, 1, 1, 0, 1, PAD_ZERO); a.stats = h->stem_bn.acc; run_igemm(h, a); }
+    // ---- encoder: stem + BN + ReLU, maxpool, 8 basic blocks
+    {   // direct 7x7 stride-2 convolution on the boundary tensor (+ its BatchNorm statistics)
+        const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
+        h->pbegin(CLS_IGEMM, fl, "stem fwd 7x7 s2 (direct)"); launch_stem_fwd(x, NL, h->C, H, W, h->P + h->stem.w, h->Kpad, h->z0, h->stem_bn.acc, s); h->pend();
+        if (h->prof) h->prof_flops[CLS_IGEMM] += fl;
+    }
     bn_fwd(h, h->stem_bn, h->z0, nullptr, ACT_RELU, h->a0);
     launch_maxpool_fwd(h->a0, h->p0, h->pool_arg, s);
     for (int i = 0; i < 8; ++i) {
@@ -494,8 +499,10 @@ static int model_backward(md2_handle* h) {
     launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->a0, s);        // Gfeat[0]: decoder skip gradient in the target frames only
     {
         bn_bwd(h, h->stem_bn, h->Gfeat[0], h->z0, h->dz0);
-        View dzc = make_view(h->dz0.p, 1, 1, NL * (H / 2) * (W / 2), 64);
-        conv_wgrad(h, h->stem, h->colv, dzc, PAD_ZERO);
+        const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
+        hipStream_t st = wgrad_stream(h);
+        h->pbegin(CLS_WGRAD, fl, "stem wgrad 7x7 s2 (direct)", st, true); launch_stem_wgrad(h->x_last, NL, h->C, H, W, h->dz0, h->G + h->stem.w, h->Kpad, st); h->pend(st, true);
+        if (h->prof) h->prof_flops[CLS_WGRAD] += fl;
     }
     if (h->forked) {                        // join: the gradient buffer is complete only when the weight-gradient stream has drained
         (void)hipEventRecord(h->ev_join, h->s2); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); h->forked = false;

@@ -97,7 +97,9 @@ void launch_head_fwd(const View& x, const float* w /*[9][Cin]*/, const float* b,
 void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, float* dw, float* db, hipStream_t s);
 
 // ---- layer kernels (layers.hip) ----------------------------------------------------------------
-void launch_im2col_stem(const float* x_nchw, int NL, int C, int H, int W, float* col, int Kpad, hipStream_t s);   // 7x7 s2 p3
+// ---- ResNet stem, 7x7 stride 2 pad 3 on the boundary tensor x [NL][C][H][W] (stem.hip); w / dw: [64][Kpad], k = (kh*7+kw)*C + c
+void launch_stem_fwd(const float* x, int NL, int C, int H, int W, const float* w, int Kpad, const View& z, double* bn_stats /*[BN_STAT_SLOTS][128] or null*/, hipStream_t s);
+void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& dz, float* dw, int Kpad, hipStream_t s);
 void launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 void launch_nhwc_to_nchw(const float* src, const View& v, float* dst, hipStream_t s);
 void launch_nchw_to_view(const float* src, const View& v, hipStream_t s);

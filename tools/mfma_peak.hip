@@ -40,5 +40,17 @@ int main() {
             if (rep) printf("32x32x2 x4acc blocks=%d: %.3f ms  %.1f TFLOP/s\n", blocks, ms, (double)blocks * 4 * iters * 4 * 4096 / (ms * 1e-3) / 1e12);
         }
     }
+    // sustained: ~3 s of back-to-back launches on bit-rich per-lane operands; the chip lowers its clock under a dense MFMA load
+    // (MI355X_MICROARCH.md, "DVFS give-back"), so this -- not the first launch -- is the rate a long MFMA-bound kernel can expect
+    {
+        const int blocks = 1024, iters = 200000;
+        double last = 0;
+        for (int rep = 0; rep < 24; ++rep) {
+            hipEventRecord(e0); hipLaunchKernelGGL(k32, dim3(blocks), dim3(256), 0, 0, out, iters, 1.2345678f + rep * 0.37f, 0.7654321f); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            last = (double)blocks * 4 * iters * 4 * 4096 / (ms * 1e-3) / 1e12;
+            if (rep % 4 == 3) printf("sustained 32x32x2 launch %d: %.1f ms  %.1f TFLOP/s\n", rep, ms, last);
+        }
+    }
     return 0;
 }
