@@ -13,6 +13,8 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ const float* vptr(const View& v, int n, long r) { return v.p + (long)n * v.bs + r * v.ps; }
 __device__ __forceinline__ float* vptrw(const View& v, int n, long r) { return v.p + (long)n * v.bs + r * v.ps; }
+static inline bool dense_view_h(const View& v) { return v.ps == v.C && v.bs == (long)v.H * v.W * v.C; }
+static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // ---- layout conversion for the op-level entry points --------------------------------------------------------------
 __global__ void nchw_to_view_kernel(const float* __restrict__ src, View v) {
@@ -40,7 +42,7 @@ void launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int 
 // ---- per-channel statistics ---------------------------------------------------------------------------------------
 // block = 256 threads = RG row-groups x (C/4) channel quads (C <= 512 -> RG >= 2).  Each thread strides over pixels,
 // LDS-reduces over row groups, then one double atomic per channel per block.
-template <int MODE>   // 0: sum z, sum z^2 ; 1: sum g, sum g*xhat  (g = dy * act'(yact))
+template <int MODE, bool FLAT>   // 0: sum z, sum z^2 ; 1: sum g, sum g*xhat  (g = dy * act'(yact)); FLAT: dense NHWC views, pixel p at p*C
 __global__ __launch_bounds__(256) void colstats_kernel(View z, View dy, View yact, int has_yact, int act, const float* __restrict__ stats, double* __restrict__ acc, int rows_per_block) {
     const int Q = z.C / 4;                    // channel quads
     const int RG = 256 / Q;                   // row groups (Q <= 128)
@@ -52,8 +54,9 @@ __global__ __launch_bounds__(256) void colstats_kernel(View z, View dy, View yac
     float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), istd = mean;
     if (MODE == 1) { mean = ld4(stats + q * 4); istd = ld4(stats + z.C + q * 4); }
     if (rg < RG)
+#pragma unroll 2
         for (long p = p0 + rg; p < p1; p += RG) {
-            const int n = p / HW; const long r = p - (long)n * HW;
+            const int n = FLAT ? 0 : (int)(p / HW); const long r = FLAT ? p : p - (long)n * HW;      // dense: bs == HW*ps, so (0, p) addresses pixel p
             const float4 v = ld4(vptr(z, n, r) + q * 4);
             if (MODE == 0) {
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
@@ -83,8 +86,9 @@ static void colstats_launch(int mode, const View& z, const View* dy, const View*
     int rpb = 2048; while (rpb > 64 && (P + rpb - 1) / rpb < 1024) rpb >>= 1;
     const int grid = (int)((P + rpb - 1) / rpb);
     View d = dy ? *dy : z, ya = yact ? *yact : z;
-    if (mode == 0) hipLaunchKernelGGL(colstats_kernel<0>, dim3(grid), dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb);
-    else hipLaunchKernelGGL(colstats_kernel<1>, dim3(grid), dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb);
+    const bool flat = dense_view_h(z) && dense_view_h(d) && dense_view_h(ya);
+    if (mode == 0) { if (flat) hipLaunchKernelGGL((colstats_kernel<0, true>), dim3(grid), dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); else hipLaunchKernelGGL((colstats_kernel<0, false>), dim3(grid), dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); }
+    else { if (flat) hipLaunchKernelGGL((colstats_kernel<1, true>), dim3(grid), dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); else hipLaunchKernelGGL((colstats_kernel<1, false>), dim3(grid), dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); }
 }
 void launch_colstats(const View& z, double* acc, hipStream_t s) { colstats_launch(0, z, nullptr, nullptr, 0, nullptr, acc, s); }
 void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View& z, const float* stats, double* acc, hipStream_t s) {
@@ -106,9 +110,25 @@ void launch_bn_finalize(const double* acc, float* stats, int C, double count, in
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, stats, C, count, slots);
 }
 
+// FAST: the channel-quad count Q is a power of two (it divides the grid stride, so a thread keeps ONE quad for its whole life and the
+// per-channel constants are loaded once) and every view is dense NHWC (element i of the [pixels][Q] float4 array is at float offset 4 i:
+// no per-element 64-bit divisions).  Every BatchNorm of the encoder qualifies; the generic path serves strided views.
+template <bool FAST>
 __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        View res, int has_res, int act, View y) {
     const int Q = z.C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
+    if (FAST) {
+        const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
+        const float4 m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const float4 v = ld4(z.p + i * 4);
+            float4 o = make_float4(g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w);
+            if (has_res) { const float4 rr = ld4(res.p + i * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+            o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
+            st4(y.p + i * 4, o);
+        }
+        return;
+    }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
         const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
@@ -119,14 +139,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __re
     }
 }
 void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s) {
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(z.pixels() * (z.C / 4), 256, 4096)), dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y);
+    const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(y) && (!residual || dense_view_h(*residual));
+    const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
+    if (fast) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y);
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, int has_yact, int act, View z, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const double* __restrict__ acc, double count, View dz, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int C = z.C, Q = C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += (float)acc[c]; dgamma[c] += (float)acc[C + c]; }
+    if (FAST) {                                 // one channel quad per thread: the per-channel constants (incl. 8 double divisions) leave the loop
+        const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
+        const float4 m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4);
+        const float m1[4] = {(float)(acc[q * 4] / count), (float)(acc[q * 4 + 1] / count), (float)(acc[q * 4 + 2] / count), (float)(acc[q * 4 + 3] / count)};
+        const float m2[4] = {(float)(acc[C + q * 4] / count), (float)(acc[C + q * 4 + 1] / count), (float)(acc[C + q * 4 + 2] / count), (float)(acc[C + q * 4 + 3] / count)};
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            float4 g = ld4(dy.p + i * 4);
+            if (has_yact) { const float4 o = ld4(yact.p + i * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+            const float4 v = ld4(z.p + i * 4);
+            float4 o;
+            o.x = ga.x * is.x * (g.x - m1[0] - (v.x - m.x) * is.x * m2[0]);
+            o.y = ga.y * is.y * (g.y - m1[1] - (v.y - m.y) * is.y * m2[1]);
+            o.z = ga.z * is.z * (g.z - m1[2] - (v.z - m.z) * is.z * m2[2]);
+            o.w = ga.w * is.w * (g.w - m1[3] - (v.w - m.w) * is.w * m2[3]);
+            st4(dz.p + i * 4, o);
+        }
+        return;
+    }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
         float4 g = ld4(vptr(dy, n, r) + q * 4);
@@ -144,7 +186,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
 }
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc, double count,
                          const View& dz, float* dgamma, float* dbeta, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(z.pixels() * (z.C / 4), 256, 4096)), dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta);
+    const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(dy) && dense_view_h(dz) && (!yact || dense_view_h(*yact));
+    const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
+    if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta);
 }
 
 // ---- MaxPool((3,3); pad=1, stride=2): first maximum in (kh,kw) scan order wins; the argmax tap (0..8) is kept ------------
