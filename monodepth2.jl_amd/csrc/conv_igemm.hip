@@ -33,19 +33,18 @@ constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int BM, int BN, int WP, int WC, int MF, int NT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __restrict__ smem, const int block_x, const int nblocks_x) {
     constexpr int TP = BM / WP / MF, TC = BN / WC / MF;       // MFMA tiles per wave (pixels x channels)
     constexpr int NV = MF == 32 ? 4 : 1;                       // float4 groups per accumulator tile
     constexpr int A_LD = BM * 4 / 256;
     constexpr int B_LD = (BN * 4 + 255) / 256;
     static_assert(WP * WC == 4 && TP >= 1 && TC >= 1 && A_LD >= 1, "bad tile");
-    constexpr int XS = BM * LDK, STAGE = (BM + BN) * LDK;      // floats: pixel tile, then weight tile, per pipeline stage
-    __shared__ __attribute__((aligned(16))) float smem[3 * STAGE];
+    constexpr int XS = BM * LDK, STAGE = (BM + BN) * LDK;      // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave % WP, wc = wave / WP;
     const int ntc = a.Cout / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = xcd_remap(block_x, nblocks_x);
     const int tile_c = bid % ntc, tile_p = bid / ntc;
     const int m0 = tile_p * BM, c0 = tile_c * BN;
     const int HlWl = a.Hl * a.Wl;
@@ -268,8 +267,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             }
             const int p = lane & 31, r = p >> 1;                 // accumulator register r = 4g + e -> channel row 8g + 4*(lane>>5) + e
             const int co = c0 + wc * (BN / WC) + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            atomicAdd(a.stats + (size_t)(blockIdx.x % BN_STAT_SLOTS) * 2 * a.Cout + (p & 1) * a.Cout + co, (double)v[0]);
+            atomicAdd(a.stats + (size_t)(block_x % BN_STAT_SLOTS) * 2 * a.Cout + (p & 1) * a.Cout + co, (double)v[0]);
         }
+    }
+}
+
+template <int BM, int BN, int WP, int WC, int MF, int NT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * LDK];
+    conv_igemm_body<BM, BN, WP, WC, MF, NT>(a, smem, blockIdx.x, gridDim.x);
+}
+// The residue classes of a stride-2 input gradient (1, 2, 2 and 4 taps, a quarter of the output pixels each) in ONE launch: a block
+// picks its class from its index and runs that class's statically-unrolled tap loop.  As four launches every class paid its own
+// under-filled tail (312 blocks x 32..128 K-steps on 256 CUs at B=32; 40 blocks at B=4).
+struct ConvClasses { ConvArgs c[4]; int first[5]; };      // blocks [first[i], first[i+1]) belong to class i
+template <int BM, int BN, int WP, int WC, int MF>
+__global__ __launch_bounds__(256) void conv_igemm_classes_kernel(ConvClasses k) {
+    __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * LDK];
+    const int b = blockIdx.x;
+    const int cls = b < k.first[1] ? 0 : (b < k.first[2] ? 1 : (b < k.first[3] ? 2 : 3));
+    const int bx = b - k.first[cls], nb = k.first[cls + 1] - k.first[cls];
+    switch (k.c[cls].nkh * k.c[cls].nkw) {
+        case 1: conv_igemm_body<BM, BN, WP, WC, MF, 1>(k.c[cls], smem, bx, nb); break;
+        case 2: conv_igemm_body<BM, BN, WP, WC, MF, 2>(k.c[cls], smem, bx, nb); break;
+        default: conv_igemm_body<BM, BN, WP, WC, MF, 4>(k.c[cls], smem, bx, nb); break;
     }
 }
 
@@ -461,6 +482,28 @@ static void launch_patch(const ConvArgs& a, hipStream_t s) {
 
 static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s);
 
+static void check_igemm_args(const ConvArgs& a) {
+    // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
+    const long x_elems = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), w_elems = 4 * ((long)a.Cout * a.KH * a.KW * a.Cin);   // byte offsets must fit 32 bits
+    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) ||
+        a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) || w_elems >= (1L << 32)) {
+        fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
+        abort();
+    }
+}
+template <int BM>
+static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
+    k.first[0] = 0;
+    for (int i = 0; i < 4; ++i) k.first[i + 1] = k.first[i] + (i < n ? ((k.c[i].M + BM - 1) / BM) * (k.c[i].Cout / 64) : 0);
+    for (int i = n; i < 4; ++i) k.c[i] = k.c[0];
+    hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32>), dim3(k.first[4]), dim3(256), 0, s, k);
+}
+static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
+    long tiles128 = 0;
+    for (int i = 0; i < n; ++i) { check_igemm_args(k.c[i]); tiles128 += (k.c[i].M + 127) / 128; }
+    if (tiles128 * (k.c[0].Cout / 64) >= 384) launch_classes_t<128>(k, n, s); else launch_classes_t<64>(k, n, s);
+}
+
 // Input-gradient of a strided convolution (dil = forward stride): an output pixel of residue class (ph,pw) mod dil only
 // sees the taps kh = (pad - ph) mod dil (+ multiples of dil), so the problem splits into dil^2 dense sub-convolutions on
 // output/tap lattices with no multiply-by-zero work (k=3, s=2: 1+2+2+4 = 9 taps over 4 quarter-size launches).
@@ -472,6 +515,9 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
         return;
     }
     if (a.dil <= 1 || a.ostep != 1) { launch_conv_igemm_one(a, s); return; }
+    ConvClasses kc{}; int ncls = 0;
+    static const bool merge_ok = !getenv("MD2_NO_CLASS_MERGE");
+    const bool merge = merge_ok && a.dil == 2 && a.Cout % 64 == 0 && !a.stats;       // the encoder's stride-2 input gradients
     for (int ph = 0; ph < a.dil; ++ph)
         for (int pw = 0; pw < a.dil; ++pw) {
             ConvArgs b = a;
@@ -485,20 +531,16 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
                 if (a.accumulate != 1) { fprintf(stderr, "md2: conv_igemm: empty tap phase needs accumulate or a zeroed output\n"); abort(); }
                 continue;                                     // nothing to add for this residue class
             }
-            launch_conv_igemm_one(b, s);
+            if (merge && ncls < 4 && b.nkh * b.nkw <= 4 && b.nkh * b.nkw != 3) { b.ksplit = 1; kc.c[ncls++] = b; }
+            else launch_conv_igemm_one(b, s);
         }
+    if (ncls) launch_classes(kc, ncls, s);
 }
 
 static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     a.ksplit = 1;
-    // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
-    const long x_elems = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), w_elems = 4 * ((long)a.Cout * a.KH * a.KW * a.Cin);   // byte offsets must fit 32 bits
-    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) ||
-        a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) || w_elems >= (1L << 32)) {
-        fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
-        abort();
-    }
+    check_igemm_args(a);
     // Small pixel counts (batch 4: M = 208 ... 2496) give only tens of tiles with a serial K loop of up to 288 steps.  Split the
     // channel chunks over gridDim.y (>= 2 chunks per split), sum with fp32 atomics into a zeroed output and apply bias /
     // activation in a second elementwise pass.
