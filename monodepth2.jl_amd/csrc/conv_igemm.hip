@@ -195,7 +195,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #endif
             gload(last2 ? NT - 1 : t2, c2 << 4);
             read_ops(o1, nxt);
-            mfmas(cur);
+            __builtin_amdgcn_s_setprio(1);          // raised priority around the MFMA cluster (also keeps hipcc from spreading it among the loads): -3 % class time;
+            mfmas(cur);                             // the same pair in the all-taps weight-gradient loop was 3 % SLOWER
+            __builtin_amdgcn_s_setprio(0);
             lstore(o2);
             __syncthreads();
             cur = nxt;
@@ -551,7 +553,8 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
         // ... and the same for up to one tile per CU when the serial K loop is very long (>= 256 steps: the 512-channel 3x3 layers at 1/32 scale;
         // measured: 0.175 -> 0.106 ms and 0.179 -> 0.138 ms there, but 0.092 -> 0.105 ms for the 256-channel layers with 144 steps)
         static const int mid = getenv("MD2_IGEMM_SPLIT_MID") ? atoi(getenv("MD2_IGEMM_SPLIT_MID")) : 256;
-        const bool few = tiles64 < 100 || (tiles64 < mid && (long)cpt * a.nkh * a.nkw >= 256);
+        static const int long_k = getenv("MD2_IGEMM_SPLIT_KSTEPS") ? atoi(getenv("MD2_IGEMM_SPLIT_KSTEPS")) : 256;
+        const bool few = tiles64 < 100 || (tiles64 < mid && (long)cpt * a.nkh * a.nkw >= long_k);
         if (few && cpt >= 4 && want > 0) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
     }
     View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
