@@ -22,7 +22,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 # HBM bytes per launch from the rocprofv3 PMC passes of THIS workload (B=32, C=1, 416x128), profiles/r01_pmc_hbm_traffic.md:
 # separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units, FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE exact.
 # PMC counters cannot be collected from inside bench.py, so the committed measurement is reported (null for other workloads).
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {"conv_igemm": 94.1e6, "conv_wgrad": 128.3e6, "loss_fwd": 231.3e6, "loss_bwd": 427.8e6}
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {"conv_igemm": 103.3e6, "conv_wgrad": 119.3e6, "loss_fwd": 235.7e6, "loss_bwd": 434.3e6}
 
 
 def cpu_baseline(C, H, W, seconds_budget=25.0):
@@ -131,7 +131,7 @@ def main():
         md.profile(model, False)
         md.set_two_streams(model, True)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<*> + conv3x3_patch_kernel<*> (forward + input-gradient implicit GEMMs, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
                            "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
                            "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH["conv_igemm"] if (B, C, H, W) == (32, 1, 128, 416) else None,
                            "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
