@@ -225,6 +225,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             for (int g = 0; g < NV; ++g) {
                 const int co = c0 + wc * (BN / WC) + i * MF + (MF == 32 ? 8 * g + 4 * (lane >> 5) : 4 * (lane >> 4));
                 float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (a.res && (a.ksplit == 1 || blockIdx.y == 0)) {        // residual gradient (identity shortcut), once per output element
+                    const float4 rr = *reinterpret_cast<const float4*>(a.res + (long)n * a.res_bs + pix * a.res_ps + co);
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                }
                 if (a.ksplit > 1) {            // partial sum: (x act') is linear, bias/activation are applied by the launcher's second pass
                     if (dp) { const float4 d = *reinterpret_cast<const float4*>(dp + co); v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
 #pragma unroll
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
 static int patch_min_h() { static const int v = getenv("MD2_PATCH_MIN_H") ? atoi(getenv("MD2_PATCH_MIN_H")) : 64; return v; }
 static bool patch_eligible(const ConvArgs& a) {
     static const int off = getenv("MD2_NO_PATCH_CONV") ? 1 : 0;
-    if (off) return false;
+    if (off || a.res) return false;
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.Cin % 16 == 0 &&
            (a.Cout == 16 || a.Cout == 32) && a.Cin <= 96 &&
            a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.oy0 == 0 && a.ox0 == 0 && a.Hl == a.Ho && a.Wl == a.Wo &&
@@ -487,7 +491,7 @@ static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s);
 static void check_igemm_args(const ConvArgs& a) {
     // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
     const long x_elems = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), w_elems = 4 * ((long)a.Cout * a.KH * a.KW * a.Cin);   // byte offsets must fit 32 bits
-    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) ||
+    if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) || (a.res && (a.res_ps % 4 != 0 || a.act != ACT_NONE || a.bias)) ||
         a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) || w_elems >= (1L << 32)) {
         fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
         abort();
@@ -1183,7 +1187,7 @@ void launch_head_fwd(const View& x, const float* w, const float* b, const View& 
 // adjoint) from the dz tile.  The first version gathered everything from global memory per pixel: ~450 instructions per pixel-lane, most of
 // them 64-bit address arithmetic (0.21 ms for the full-resolution head against 0.04 ms of HBM time).
 template <int LPP>
-__global__ __launch_bounds__(256) void head_bwd_kernel(View x, const float* __restrict__ w, View y, View dy, View dx, int accumulate,
+__global__ __launch_bounds__(256) void head_bwd_kernel(View x, const float* __restrict__ w, View y, View dy, View dx, int accumulate, int x_act,
                                                        float* __restrict__ dw, float* __restrict__ db, int tiles_x, int tiles_y, int total_tiles) {
     constexpr int PPB = 256 / LPP;                                   // pixels per pass
     constexpr int TH = LPP <= 8 ? 8 : 4, TW = 4 * PPB / TH;          // 4 passes per tile
@@ -1253,6 +1257,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(View x, const float* __re
                             gx.x += d * cw.x; gx.y += d * cw.y; gx.z += d * cw.z; gx.w += d * cw.w;
                         }
                     }
+            if (x_act != ACT_NONE) {                                  // x is the activation output of its producer and this head its only consumer: dx is d/d(pre-activation)
+                const float4 o = *reinterpret_cast<const float4*>(xs + (XW + 1) * C);
+                gx.x *= act_deriv(o.x, x_act); gx.y *= act_deriv(o.y, x_act); gx.z *= act_deriv(o.z, x_act); gx.w *= act_deriv(o.w, x_act);
+            }
             float* dp = dx.p + (long)n * dx.bs + ((long)h * W + wq) * dx.ps + l * 4;
             if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dp); gx.x += o.x; gx.y += o.y; gx.z += o.z; gx.w += o.w; }
             *reinterpret_cast<float4*>(dp) = gx;
@@ -1280,18 +1288,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(View x, const float* __re
     if (threadIdx.x == 0) { float s = 0.f; for (int gg = 0; gg < PPB; ++gg) s += red[gg * LPP]; atomicAdd(db, s); }
 }
 template <int LPP>
-static void launch_head_bwd_t(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, float* dw, float* db, hipStream_t s) {
+static void launch_head_bwd_t(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, int x_act, float* dw, float* db, hipStream_t s) {
     constexpr int PPB = 256 / LPP, TH = LPP <= 8 ? 8 : 4, TW = 4 * PPB / TH;
     const int tiles_x = (x.W + TW - 1) / TW, tiles_y = (x.H + TH - 1) / TH, total = tiles_x * tiles_y * x.N;
-    hipLaunchKernelGGL(head_bwd_kernel<LPP>, dim3(std::min(total, 768)), dim3(256), 0, s, x, w, y, dy, dx, accumulate, dw, db, tiles_x, tiles_y, total);      // persistent: 3 blocks per CU fit (162 VGPRs)
+    hipLaunchKernelGGL(head_bwd_kernel<LPP>, dim3(std::min(total, 768)), dim3(256), 0, s, x, w, y, dy, dx, accumulate, x_act, dw, db, tiles_x, tiles_y, total);      // persistent: 3 blocks per CU fit (162 VGPRs)
 }
-void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, float* dw, float* db, hipStream_t s) {
+void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, int x_act, float* dw, float* db, hipStream_t s) {
     if (x.H < 3 || x.W < 3 || x.ps % 4 != 0 || dx.ps % 4 != 0) { fprintf(stderr, "md2: head_bwd: unsupported view\n"); abort(); }
     switch (x.C / 4) {
-        case 4: launch_head_bwd_t<4>(x, w, y, dy, dx, accumulate, dw, db, s); break;
-        case 8: launch_head_bwd_t<8>(x, w, y, dy, dx, accumulate, dw, db, s); break;
-        case 16: launch_head_bwd_t<16>(x, w, y, dy, dx, accumulate, dw, db, s); break;
-        case 32: launch_head_bwd_t<32>(x, w, y, dy, dx, accumulate, dw, db, s); break;
+        case 4: launch_head_bwd_t<4>(x, w, y, dy, dx, accumulate, x_act, dw, db, s); break;
+        case 8: launch_head_bwd_t<8>(x, w, y, dy, dx, accumulate, x_act, dw, db, s); break;
+        case 16: launch_head_bwd_t<16>(x, w, y, dy, dx, accumulate, x_act, dw, db, s); break;
+        case 32: launch_head_bwd_t<32>(x, w, y, dy, dx, accumulate, x_act, dw, db, s); break;
         default: fprintf(stderr, "md2: head_bwd: unsupported Cin=%d\n", x.C); abort();
     }
 }

@@ -239,10 +239,11 @@ static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y
     run_igemm(h, a);
 }
 // input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
-static void conv_dgrad(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact) {
+static void conv_dgrad(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact, const View* res = nullptr) {
     ConvArgs a = conv_args(dy, h->WD + c.w, dx, c.k, 1, c.k - 1 - pad_fwd, c.stride, PAD_ZERO);
     a.accumulate = accumulate;
     if (dact_src) { a.dact_src = dact_src->p; a.da_bs = dact_src->bs; a.da_ps = dact_src->ps; a.dact = dact; }
+    if (res) { a.res = res->p; a.res_bs = res->bs; a.res_ps = res->ps; }
     run_igemm(h, a);
 }
 // stream a weight gradient is enqueued on: the side stream, forked by event from the chain at this point (its dy is complete)
@@ -444,9 +445,9 @@ static int model_backward(md2_handle* h) {
     for (int l = 0; l < 4; ++l) {
         const int b = l + 1;
         View dyv = make_view(h->ddisp_lo[l], N, h->dispv[l].H, h->dispv[l].W, 1);
-        launch_head_bwd(h->y2[b], h->P + h->head[l].w, h->dispv[l], dyv, h->gA[b], 0, h->G + h->head[l].w, h->G + h->head[l].b, s);
+        // last branch (b == 4): only its head consumes it, so the ELU derivative of y2[4] is applied right there
+        launch_head_bwd(h->y2[b], h->P + h->head[l].w, h->dispv[l], dyv, h->gA[b], 0, b == 4 ? ACT_ELU : ACT_NONE, h->G + h->head[l].w, h->G + h->head[l].b, s);
     }
-    launch_axpy_view(h->gA[4], h->gA[4], 1.f, 0, &h->y2[4], ACT_ELU, s);     // last branch: only its head consumes it
     for (int b = 4; b >= 0; --b) {
         // gA[b] now holds d loss / d (pre-ELU output of c2[b])
         const View& dZ2 = h->gA[b];
@@ -487,14 +488,14 @@ static int model_backward(md2_handle* h) {
         conv_wgrad(h, B.c1, B.in, dz1, PAD_ZERO);
         // first encoder writer of Gin: own buffers (odd i, and the pool gradient) are overwritten; stage buffers (even i > 0) already hold
         // the decoder's contribution in the target frames
-        conv_dgrad(h, B.c1, dz1, *Gin, 1, (i == 0 || (i & 1)) ? 0 : 2, in_act, ACT_RELU);
+        // identity shortcut: d(block input) = relu'(in) * (conv1 pullback + Gout) -- Gout is added in the same epilogue (was an axpy pass)
+        conv_dgrad(h, B.c1, dz1, *Gin, 1, (i == 0 || (i & 1)) ? 0 : 2, in_act, ACT_RELU, B.down ? nullptr : &Gout);
         if (B.down) {
             const View& dzd = B.dzd;
             bn_bwd(h, B.bd, Gout, B.zd, dzd);
             conv_wgrad(h, B.cd, B.in, dzd, PAD_ZERO);
             conv_dgrad(h, B.cd, dzd, *Gin, 0, 1, in_act, ACT_RELU);
-        } else
-            launch_axpy_view(Gout, *Gin, 1.f, 1, in_act, ACT_RELU, s);
+        }
     }
     launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->a0, s);        // Gfeat[0]: decoder skip gradient in the target frames only
     {

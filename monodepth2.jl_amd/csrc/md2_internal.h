@@ -54,6 +54,7 @@ struct ConvArgs {
     int N, KH, KW, stride, pad, dil, padmode;
     const float* bias; int act; int accumulate;               // accumulate: 0 overwrite, 1 add to y, 2 add only where (batch index % 3) == 1 (target frames)
     const float* dact_src; long da_bs; int da_ps; int dact;   // optional: multiply by act_deriv(dact_src[n,oh,ow,co])
+    const float* res; long res_bs; int res_ps;                // optional residual gradient added BEFORE the act_deriv factor: y = (conv + res) * act'(dact_src) [+ y]
     int M;                                                    // N*Hl*Wl
     // output lattice: this launch produces pixels (oy0 + i*ostep, ox0 + j*ostep), i < Hl, j < Wl (dense: 0,0,1,Ho,Wo)
     int oy0, ox0, ostep, Hl, Wl;
@@ -94,7 +95,8 @@ void launch_weight_to_dgrad_batched(const float* w_fwd, float* w_dg, const long*
 // ---- 3x3 reflect-pad conv with ONE output channel (disparity heads, src/depth_decoder.jl:43) ------
 void launch_head_fwd(const View& x, const float* w /*[9][Cin]*/, const float* b, const View& y /*C=1, sigmoid*/, hipStream_t s);
 // dz = dy * y*(1-y) computed on the fly.  dx = (accumulate? dx : 0) + reflect-adjoint conv ; dw += ; db +=
-void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, float* dw, float* db, hipStream_t s);
+// x_act != ACT_NONE: x is the activation OUTPUT of its producer and this head is its only consumer -> dx is multiplied by act'(x)
+void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, int x_act, float* dw, float* db, hipStream_t s);
 
 // ---- layer kernels (layers.hip) ----------------------------------------------------------------
 // ---- ResNet stem, 7x7 stride 2 pad 3 on the boundary tensor x [NL][C][H][W] (stem.hip); w / dw: [64][Kpad], k = (kh*7+kw)*C + c
