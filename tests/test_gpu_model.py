@@ -313,6 +313,25 @@ def test_other_shapes_forward_loss_and_gradient_vs_oracle(shape):
     assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
 
 
+def test_config5_shape_1024x320_with_automasking_vs_oracle():
+    """BASELINE config #5's resolution (1024x320, RGB) with the min-reprojection automask, in fp32 (the build has no bf16 path): forward +
+    loss within 1e-4 of the oracle, gradient direction identical.  Exercises every kernel's tiling at 2.5x the headline width/height."""
+    N, C, H, W = 1, 3, 320, 1024
+    model, params, cache, theta, K, iK = make(N, C, H, W, automask=True, pseed=31)
+    x = syn.synthetic_triplets(N, C, H, W, seed=32); xd = dev(x)
+    al = md().automasking_loss(md().SSIM(), xd, xd[:, 1].contiguous(), [1, 3])
+    loss = md().train_step(model, xd, al, cache, params, do_update=False)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK, automasking=True)
+    alo = oracle.automasking_loss(x, cfg)
+    assert np.abs(host(al) - alo).max() < 1e-4
+    net = oracle.OracleNet(C); net.set_params(theta)
+    lo = net.train_loss(x, cfg, alo, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    gh = model.grads(); go = net.get_grads()
+    assert np.isfinite(gh).all()
+    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+
+
 def test_backward_requires_a_training_forward():
     """md2_backward after a plain model forward (which overwrites the activations) must fail loudly, not return stale gradients."""
     N, C, H, W = 1, 1, 64, 96
