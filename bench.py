@@ -147,7 +147,7 @@ def main():
                 extra[nm] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "ms_per_step": p["ms"] / 3,
                              "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1),
                              "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH[nm[len("roofline_"):]] if (B, C, H, W) == (32, 1, 128, 416) else None,
-                             "note": "instruction-bound, not HBM-bound: ~350-550 VALU instructions per pixel and scale (DESIGN.md section 4)"}
+                             "note": "instruction-bound, not HBM-bound: 541 (fwd) / 1490 (bwd) VALU lane-instructions per pixel and scale (rocprofv3 SQ_INSTS_VALU) = 48 % / 37 % of the VALU issue peak (DESIGN.md section 4)"}
         if world == 1 and not args.no_extra and B != 4:
             # BASELINE.json configs[1]: batch = 4 on one MI355X
             del dp, model

@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
         if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
             const int ctr = (ry + 1) * BW2 + rx + 1;
             float pl[2] = {0.f, 0.f}; SsimOut so[2][C];
+#pragma unroll
             for (int c = 0; c < C; ++c) {
                 float yw[9], sy = 0.f, syy = 0.f;
 #pragma unroll
@@ -313,10 +314,13 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
             win = pl[1] < pl[0] ? 1 : 0;                                             // first arg-min (Zygote `minimum`)
             if (a.auto_loss && !(pl[win] < a.auto_loss[(long)n * P + (long)qy * W + qx])) win = -1;   // mask wins ties -> no gradient
             const float g = wpix * alpha * invC * (1.f / 9.f);                       // through mean_c, alpha, and the /9 of MeanPool
-            for (int c = 0; c < C; ++c) {
-                const SsimOut& o = so[win < 0 ? 0 : win][c];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {                                            // select by value: a runtime index into so[][] would put it in scratch
+                const bool w1 = win == 1;
                 const float m = win < 0 ? 0.f : g;
-                coef[c][0][i] = m * o.g_mx; coef[c][1][i] = m * o.g_pxx; coef[c][2][i] = m * o.g_pxy;
+                coef[c][0][i] = m * (w1 ? so[1][c].g_mx : so[0][c].g_mx);
+                coef[c][1][i] = m * (w1 ? so[1][c].g_pxx : so[0][c].g_pxx);
+                coef[c][2][i] = m * (w1 ? so[1][c].g_pxy : so[0][c].g_pxy);
             }
         } else
             for (int c = 0; c < C; ++c) { coef[c][0][i] = 0.f; coef[c][1][i] = 0.f; coef[c][2][i] = 0.f; }
