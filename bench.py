@@ -137,7 +137,7 @@ def main():
                            "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1),
                            "timing": "HIP events per launch on the launch stream, 3 steps with the second (weight-gradient) stream disabled; `value` is measured with it enabled"}
-        extra = {}
+        extra = {"frames_per_s": 3.0 * value}         # one triplet = 3 frames through the encoder
         if wg["ms"] > 0:
             a = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
             extra["roofline_conv_wgrad"] = {"bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TFLOPS, "ms_per_step": wg["ms"] / 3}
