@@ -218,7 +218,9 @@ void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t 
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(y.pixels() * (x.C / 4), 256, 4096)), dim3(256), 0, s, x, y, arg);
 }
 // gather form: input pixel (ih,iw) is covered by outputs oh in {(ih+1)/2 - (0|1)}...; no atomics, deterministic
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View xact, int has_xact) {
+// yrelu: the pooled OUTPUT of a max-pool over post-ReLU activations; the ReLU derivative of the winning input equals (pooled value > 0),
+// so the mask is read from the 4x smaller pooled tensor instead of the activations themselves
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View yrelu, int has_yrelu) {
     const int Q = dx.C / 4; const long total = dx.pixels() * Q; const int HW = dx.H * dx.W, HWo = dy.H * dy.W;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int ih = r / dx.W, iw = r - ih * dx.W;
@@ -229,20 +231,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t
                 const int u = iw + 1 - kw; if (u < 0 || (u & 1)) continue; const int ow = u >> 1; if (ow >= dy.W) continue;
                 const long po = (long)n * HWo + (long)oh * dy.W + ow;
                 const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (po * dx.C + q * 4));
-                const float4 d = ld4(vptr(dy, n, (long)oh * dy.W + ow) + q * 4);
+                float4 d = ld4(vptr(dy, n, (long)oh * dy.W + ow) + q * 4);
+                if (has_yrelu) { const float4 o = ld4(vptr(yrelu, n, (long)oh * dy.W + ow) + q * 4); d.x *= act_deriv(o.x, ACT_RELU); d.y *= act_deriv(o.y, ACT_RELU); d.z *= act_deriv(o.z, ACT_RELU); d.w *= act_deriv(o.w, ACT_RELU); }
                 const int tap = kh * 3 + kw;
                 if (a.x == tap) g[0] += d.x; if (a.y == tap) g[1] += d.y; if (a.z == tap) g[2] += d.z; if (a.w == tap) g[3] += d.w;
             }
         }
         float* dp = vptrw(dx, n, r) + q * 4;
-        if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1)) {      // earlier contributions are already masked (mask^2 == mask)
+        if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1)) {      // earlier contributions are already masked
             const float4 o = ld4(dp); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
-        if (has_xact) { const float4 o = ld4(vptr(xact, n, r) + q * 4); g[0] *= act_deriv(o.x, ACT_RELU); g[1] *= act_deriv(o.y, ACT_RELU); g[2] *= act_deriv(o.z, ACT_RELU); g[3] *= act_deriv(o.w, ACT_RELU); }
         st4(dp, make_float4(g[0], g[1], g[2], g[3]));
     }
 }
-void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* xact, hipStream_t s) {
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(dx.pixels() * (dx.C / 4), 256, 4096)), dim3(256), 0, s, dy, arg, dx, accumulate, xact ? *xact : dx, xact ? 1 : 0);
+void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu, hipStream_t s) {
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(dx.pixels() * (dx.C / 4), 256, 4096)), dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0);
 }
 
 // ---- NNlib.upsample_bilinear(x, (2,2)) (src/depth_decoder.jl:18-19), align-corners mapping --------------------------------

@@ -497,7 +497,7 @@ static int model_backward(md2_handle* h) {
             conv_dgrad(h, B.cd, dzd, *Gin, 0, 1, in_act, ACT_RELU);
         }
     }
-    launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->a0, s);        // Gfeat[0]: decoder skip gradient in the target frames only
+    launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s);        // Gfeat[0]: decoder skip gradient in the target frames only; ReLU mask from the pooled output
     {
         bn_bwd(h, h->stem_bn, h->Gfeat[0], h->z0, h->dz0);
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;

@@ -118,7 +118,7 @@ void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& 
                          double count, const View& dz, float* dgamma, float* dbeta, hipStream_t s);
 void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s);
 // dx (+)= scatter of dy by arg, gather form; optional multiply by relu'(xact).  accumulate as in ConvArgs (0 / 1 / 2)
-void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* xact, hipStream_t s);
+void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu /* pooled output of a post-ReLU input, or null */, hipStream_t s);
 void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s);
 // dx = adjoint(up2)(dy) * act_deriv(xact)
 void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int act, hipStream_t s);
