@@ -70,9 +70,13 @@ def main():
     par = md2amd.parallel
     syn = md2amd.synthetic
 
-    rank, world, local = par.init_from_env("nccl")
+    # one rank per GPU over RCCL.  MD2_BENCH_BACKEND=gloo + MD2_BENCH_DEVICE=0 exist only to rehearse the multi-rank code path on a
+    # one-GPU box (two processes sharing the card, all-reduce through the host); the driver's runs never set them.
+    rank, world, local = par.init_from_env(os.environ.get("MD2_BENCH_BACKEND", "nccl"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if "MD2_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["MD2_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     B, C, H, W = args.batch, args.channels, args.height, args.width
 
