@@ -22,7 +22,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 # HBM bytes per launch from the rocprofv3 PMC passes of THIS workload (B=32, C=1, 416x128), profiles/r01_pmc_hbm_traffic.md:
 # separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units, FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE exact.
 # PMC counters cannot be collected from inside bench.py, so the committed measurement is reported (null for other workloads).
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {"conv_igemm": 103.3e6, "conv_wgrad": 119.3e6, "loss_fwd": 235.7e6, "loss_bwd": 434.3e6}
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {"conv_igemm": 108.1e6, "conv_wgrad": 119.4e6, "loss_fwd": 229.2e6, "loss_bwd": 300.3e6}
 
 
 def cpu_baseline(C, H, W, seconds_budget=25.0):
