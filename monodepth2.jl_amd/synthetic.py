@@ -8,12 +8,26 @@ import numpy as np
 DEC_CH = [256, 128, 64, 32, 16]
 IN_CH = [512, 256, 128, 64, 32]
 SKIP_CH = [256, 128, 64, 64, 0]
+BLOCKS = {18: (2, 2, 2, 2), 50: (3, 4, 6, 3)}       # torchvision trunk: BasicBlock x (2,2,2,2) / Bottleneck x (3,4,6,3)
 
 
-def param_layout(C=1):
+def stages(depth=18):
+    """ResidualNetwork(depth).stages (src/depth_decoder.jl:31-35 consumes them)."""
+    return (64, 64, 128, 256, 512) if depth == 18 else (64, 256, 512, 1024, 2048)
+
+
+def decoder_channels(depth=18):
+    """(in, dec, skip) channels of the five DepthDecoder branches for an encoder of this depth."""
+    st = stages(depth)
+    return [st[4]] + DEC_CH[:4], list(DEC_CH), [st[3], st[2], st[1], st[0], 0]
+
+
+def param_layout(C=1, depth=18):
     """Flat parameter order shared by the oracle and the HIP library (documented in DESIGN.md).
     Returns a list of (name, kind, shape) with kind in {"W","b","gamma","beta"}; conv weights are in
     Flux layout (kW,kH,Cin,Cout) column-major == numpy (Cout,Cin,KH,KW)."""
+    if depth not in BLOCKS:
+        raise ValueError("encoder depth must be 18 or 50")
     out = []
 
     def conv(name, cin, cout, k, bias):
@@ -27,33 +41,42 @@ def param_layout(C=1):
 
     conv("enc.stem", C, 64, 7, False); bn("enc.stem.bn", 64)
     cin = 64
-    for li, co in enumerate((64, 128, 256, 512)):
-        for bi in range(2):
+    for li, planes in enumerate((64, 128, 256, 512)):
+        for bi in range(BLOCKS[depth][li]):
             s = 2 if (bi == 0 and li > 0) else 1
             p = "enc.layer%d.%d" % (li + 1, bi)
-            conv(p + ".conv1", cin, co, 3, False); bn(p + ".bn1", co); conv(p + ".conv2", co, co, 3, False); bn(p + ".bn2", co)
+            if depth == 18:
+                co = planes
+                conv(p + ".conv1", cin, co, 3, False); bn(p + ".bn1", co); conv(p + ".conv2", co, co, 3, False); bn(p + ".bn2", co)
+            else:                                  # bottleneck: 1x1 -> 3x3 (carries the stride) -> 1x1 x4
+                co = 4 * planes
+                conv(p + ".conv1", cin, planes, 1, False); bn(p + ".bn1", planes)
+                conv(p + ".conv2", planes, planes, 3, False); bn(p + ".bn2", planes)
+                conv(p + ".conv3", planes, co, 1, False); bn(p + ".bn3", co)
             if s != 1 or cin != co:
                 conv(p + ".down", cin, co, 1, False); bn(p + ".down.bn", co)
             cin = co
+    inc, dec, skc = decoder_channels(depth)
     for b in range(5):
-        conv("dec.branch%d.c1" % (b + 1), IN_CH[b], DEC_CH[b], 3, True)
-        conv("dec.branch%d.c2" % (b + 1), DEC_CH[b] + SKIP_CH[b], DEC_CH[b], 3, True)
+        conv("dec.branch%d.c1" % (b + 1), inc[b], dec[b], 3, True)
+        conv("dec.branch%d.c2" % (b + 1), dec[b] + skc[b], dec[b], 3, True)
     for l in range(4):
-        conv("dec.head%d" % (l + 2), DEC_CH[l + 1], 1, 3, True)
-    conv("pose.squeezer", 512, 256, 1, True); conv("pose.pose1", 512, 256, 3, True); conv("pose.pose2", 256, 256, 3, True); conv("pose.pose3", 256, 6, 1, True)
+        conv("dec.head%d" % (l + 2), dec[l + 1], 1, 3, True)
+    top = stages(depth)[4]
+    conv("pose.squeezer", top, 256, 1, True); conv("pose.pose1", 512, 256, 3, True); conv("pose.pose2", 256, 256, 3, True); conv("pose.pose3", 256, 6, 1, True)
     return out
 
 
-def num_params(C=1):
-    return int(sum(int(np.prod(s)) for _, _, s in param_layout(C)))
+def num_params(C=1, depth=18):
+    return int(sum(int(np.prod(s)) for _, _, s in param_layout(C, depth)))
 
 
-def init_params(C=1, seed=42, randomize_affine=False):
+def init_params(C=1, seed=42, randomize_affine=False, depth=18):
     """Flux defaults: conv W Glorot-uniform, bias 0, BN gamma 1 / beta 0.  With
     randomize_affine the biases/gamma/beta are perturbed so tests exercise those gradients."""
     rng = np.random.default_rng(seed)
     parts = []
-    for name, kind, shape in param_layout(C):
+    for name, kind, shape in param_layout(C, depth):
         if kind == "W":
             cout, cin, kh, kw = shape
             lim = np.sqrt(24.0 / (kh * kw * cin + kh * kw * cout))

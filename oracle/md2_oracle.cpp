@@ -102,9 +102,10 @@ static LossCfg to_cfg(const o_cfg* c) {
     l.min_depth = c->min_depth; l.max_depth = c->max_depth; l.smoothness = c->smoothness;
     std::memcpy(l.K, c->K, sizeof(l.K)); std::memcpy(l.invK, c->invK, sizeof(l.invK)); return l;
 }
-struct o_net { Net net; StepOut out; explicit o_net(int C) : net(C) {} };
+struct o_net { Net net; StepOut out; explicit o_net(int C, int depth = 18) : net(C, depth) {} };
 
 O_API o_net* o_net_create(int C) { return new o_net(C); }
+O_API o_net* o_net_create_depth(int C, int depth) { return (depth == 18 || depth == 50) ? new o_net(C, depth) : nullptr; }
 O_API void o_net_destroy(o_net* h) { delete h; }
 O_API long o_net_nparams(o_net* h) { return (long)h->net.np; }
 O_API void o_net_params_set(o_net* h, const float* p) { std::memcpy(h->net.th.data(), p, sizeof(float) * h->net.np); }
@@ -117,7 +118,7 @@ O_API int o_net_layout(o_net* h, long* offs, long* counts, int* kinds, int cap) 
     auto conv = [&](const ConvP& c) { if (n < cap) { offs[n] = (long)c.w; counts[n] = (long)c.cin * c.cout * c.k * c.k; kinds[n] = 0; } ++n; if (c.has_b) { if (n < cap) { offs[n] = (long)c.b; counts[n] = c.cout; kinds[n] = 1; } ++n; } };
     auto bn = [&](const BNP& b) { if (n < cap) { offs[n] = (long)b.g; counts[n] = b.c; kinds[n] = 2; } ++n; if (n < cap) { offs[n] = (long)b.b; counts[n] = b.c; kinds[n] = 3; } ++n; };
     conv(N.stem); bn(N.stem_bn);
-    for (int i = 0; i < 8; ++i) { conv(N.blk[i].c1); bn(N.blk[i].b1); conv(N.blk[i].c2); bn(N.blk[i].b2); if (N.blk[i].down) { conv(N.blk[i].cd); bn(N.blk[i].bd); } }
+    for (int i = 0; i < N.nblk; ++i) { conv(N.blk[i].c1); bn(N.blk[i].b1); conv(N.blk[i].c2); bn(N.blk[i].b2); if (N.blk[i].bottleneck) { conv(N.blk[i].c3); bn(N.blk[i].b3); } if (N.blk[i].down) { conv(N.blk[i].cd); bn(N.blk[i].bd); } }
     for (int b = 0; b < 5; ++b) { conv(N.dc1[b]); conv(N.dc2[b]); }
     for (int l = 0; l < 4; ++l) conv(N.head[l]);
     conv(N.squeeze); for (int i = 0; i < 3; ++i) conv(N.pose[i]);
@@ -128,7 +129,7 @@ O_API int o_net_convs(o_net* h, int* desc, int cap) {
     int n = 0; Net& N = h->net;
     auto conv = [&](const ConvP& c) { if (n < cap) { desc[n * 6 + 0] = c.cin; desc[n * 6 + 1] = c.cout; desc[n * 6 + 2] = c.k; desc[n * 6 + 3] = c.s; desc[n * 6 + 4] = c.p; desc[n * 6 + 5] = c.has_b; } ++n; };
     conv(N.stem);
-    for (int i = 0; i < 8; ++i) { conv(N.blk[i].c1); conv(N.blk[i].c2); if (N.blk[i].down) conv(N.blk[i].cd); }
+    for (int i = 0; i < N.nblk; ++i) { conv(N.blk[i].c1); conv(N.blk[i].c2); if (N.blk[i].bottleneck) conv(N.blk[i].c3); if (N.blk[i].down) conv(N.blk[i].cd); }
     for (int b = 0; b < 5; ++b) { conv(N.dc1[b]); conv(N.dc2[b]); }
     for (int l = 0; l < 4; ++l) conv(N.head[l]);
     conv(N.squeeze); for (int i = 0; i < 3; ++i) conv(N.pose[i]);

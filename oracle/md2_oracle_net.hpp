@@ -4,9 +4,11 @@
 //   SURVEY.md §8c.  TEST INFRASTRUCTURE ONLY (see md2_oracle.h).  fp32 storage like the reference
 //   (`precision = f32`, src/Monodepth.jl:72); long reductions accumulate in double.
 //
-// Encoder: ResNet.jl is not vendored in the reference tree; the torchvision ResNet-18 trunk is assumed
+// Encoder: ResNet.jl is not vendored in the reference tree; the torchvision trunks are assumed: ResNet-18
 // (7x7 s2 p3 conv no-bias + BN + ReLU | 3x3 s2 p1 maxpool | 4 layers x 2 BasicBlocks, 1x1-s2 conv+BN
-// shortcut), stages = (64,64,128,256,512) as required by src/depth_decoder.jl:31-35.  PARITY UNPINNED.
+// shortcut), stages = (64,64,128,256,512) as required by src/depth_decoder.jl:31-35, and ResNet-50
+// (Bottleneck x (3,4,6,3): 1x1 -> 3x3 carrying the stride -> 1x1 x4; stages (64,256,512,1024,2048);
+// BASELINE config "ResNet-50 encoder, 640x192").  PARITY UNPINNED.
 #pragma once
 #include "md2_oracle_ops.hpp"
 #include <memory>
@@ -233,27 +235,36 @@ struct Net {
     double beta1p = 1.0, beta2p = 1.0; // running beta powers (Flux ADAM state)
     size_t np = 0;
     ConvP stem; BNP stem_bn;
-    struct Block { ConvP c1, c2, cd; BNP b1, b2, bd; bool down; };
-    Block blk[8];
+    struct Block { ConvP c1, c2, c3, cd; BNP b1, b2, b3, bd; bool down; bool bottleneck; bool stage_end; };
+    int depth = 18, nblk = 8;
+    Block blk[16];
     ConvP dc1[5], dc2[5], head[4], squeeze, pose[3];
     int dec_ch[5] = {256, 128, 64, 32, 16}, in_ch[5] = {512, 256, 128, 64, 32}, skip_ch[5] = {256, 128, 64, 64, 0};
 
     ConvP mk(int cin, int cout, int k, int s, int p, bool bias) { ConvP c{cin, cout, k, s, p, np, 0, bias}; np += (size_t)cin * cout * k * k; if (bias) { c.b = np; np += cout; } return c; }
     BNP mkbn(int c) { BNP b{c, np, np + (size_t)c}; np += 2 * (size_t)c; return b; }
-    explicit Net(int C_) : C(C_) {
+    explicit Net(int C_, int depth_ = 18) : C(C_), depth(depth_) {
         stem = mk(C, 64, 7, 2, 3, false); stem_bn = mkbn(64);
-        int chans[4] = {64, 128, 256, 512}; int cin = 64;
+        const int planes[4] = {64, 128, 256, 512}; int cin = 64;
+        const int nb18[4] = {2, 2, 2, 2}, nb50[4] = {3, 4, 6, 3};
+        const int* nb = depth == 50 ? nb50 : nb18;
+        nblk = 0;
         for (int l = 0; l < 4; ++l)
-            for (int b = 0; b < 2; ++b) {
-                Block& B = blk[l * 2 + b]; const int co = chans[l]; const int s = (b == 0 && l > 0) ? 2 : 1;
-                B.c1 = mk(cin, co, 3, s, 1, false); B.b1 = mkbn(co); B.c2 = mk(co, co, 3, 1, 1, false); B.b2 = mkbn(co);
+            for (int b = 0; b < nb[l]; ++b) {
+                Block& B = blk[nblk++]; const int s = (b == 0 && l > 0) ? 2 : 1;
+                B.bottleneck = depth == 50; B.stage_end = (b == nb[l] - 1);
+                int co;
+                if (!B.bottleneck) { co = planes[l]; B.c1 = mk(cin, co, 3, s, 1, false); B.b1 = mkbn(co); B.c2 = mk(co, co, 3, 1, 1, false); B.b2 = mkbn(co); }
+                else { co = 4 * planes[l]; B.c1 = mk(cin, planes[l], 1, 1, 0, false); B.b1 = mkbn(planes[l]); B.c2 = mk(planes[l], planes[l], 3, s, 1, false); B.b2 = mkbn(planes[l]);
+                       B.c3 = mk(planes[l], co, 1, 1, 0, false); B.b3 = mkbn(co); }
                 B.down = (s != 1 || cin != co);
                 if (B.down) { B.cd = mk(cin, co, 1, s, 0, false); B.bd = mkbn(co); }
                 cin = co;
             }
+        if (depth == 50) { const int st[5] = {64, 256, 512, 1024, 2048}; in_ch[0] = st[4]; skip_ch[0] = st[3]; skip_ch[1] = st[2]; skip_ch[2] = st[1]; skip_ch[3] = st[0]; }
         for (int b = 0; b < 5; ++b) { dc1[b] = mk(in_ch[b], dec_ch[b], 3, 1, 0, true); dc2[b] = mk(dec_ch[b] + skip_ch[b], dec_ch[b], 3, 1, 0, true); }
         for (int l = 0; l < 4; ++l) head[l] = mk(dec_ch[l + 1], 1, 3, 1, 0, true);
-        squeeze = mk(512, 256, 1, 1, 0, true); pose[0] = mk(512, 256, 3, 1, 1, true); pose[1] = mk(256, 256, 3, 1, 1, true); pose[2] = mk(256, 6, 1, 1, 0, true);
+        squeeze = mk(cin, 256, 1, 1, 0, true); pose[0] = mk(512, 256, 3, 1, 1, true); pose[1] = mk(256, 256, 3, 1, 1, true); pose[2] = mk(256, 6, 1, 1, 0, true);
         th.assign(np, 0); g.assign(np, 0); m.assign(np, 0); v.assign(np, 0);
     }
     const float* W(const ConvP& c) const { return th.data() + c.w; }
@@ -264,8 +275,8 @@ struct Net {
 
 // ---- saved state of one forward pass -----------------------------------------------------------
 struct ConvBN { Tensor x, z, a; BNSave sv; };                     // a = act(bn(conv(x)))
-struct BlockSave { ConvBN c1, c2, cd; Tensor out; };
-struct EncSave { ConvBN stem; Tensor pooled; Vec<int32_t> arg; BlockSave blk[8]; Tensor feat[5]; };
+struct BlockSave { ConvBN c1, c2, c3, cd; Tensor out; };
+struct EncSave { ConvBN stem; Tensor pooled; Vec<int32_t> arg; BlockSave blk[16]; Tensor feat[5]; };
 struct DecConv { Tensor xin, xpad, y; };                          // y = act(conv(pad_reflect(xin)))
 struct DepthSave { DecConv c1[5], c2[5], head[4]; Tensor up[5], cat[5]; };
 struct PoseSave { Tensor f[2], sq[2], cat, y1, y2, y3; int order[2]; };   // f: the (first,second) feature pair
@@ -285,28 +296,32 @@ inline void encoder_fwd(const Net& N, const Tensor& x, EncSave& S) {
     S.feat[0] = S.stem.a;
     maxpool3s2_fwd(S.stem.a, S.pooled, S.arg);
     const Tensor* cur = &S.pooled;
-    for (int i = 0; i < 8; ++i) {
+    int stage = 1;
+    for (int i = 0; i < N.nblk; ++i) {
         const Net::Block& B = N.blk[i]; BlockSave& bs = S.blk[i];
         convbn_fwd(N, B.c1, B.b1, *cur, bs.c1, ACT_RELU);
-        convbn_fwd(N, B.c2, B.b2, bs.c1.a, bs.c2, ACT_NONE);
-        bs.out = bs.c2.a;
+        if (!B.bottleneck) { convbn_fwd(N, B.c2, B.b2, bs.c1.a, bs.c2, ACT_NONE); bs.out = bs.c2.a; }
+        else { convbn_fwd(N, B.c2, B.b2, bs.c1.a, bs.c2, ACT_RELU); convbn_fwd(N, B.c3, B.b3, bs.c2.a, bs.c3, ACT_NONE); bs.out = bs.c3.a; }
         if (B.down) { convbn_fwd(N, B.cd, B.bd, *cur, bs.cd, ACT_NONE); for (size_t j = 0; j < bs.out.size(); ++j) bs.out.v[j] += bs.cd.a.v[j]; }
         else for (size_t j = 0; j < bs.out.size(); ++j) bs.out.v[j] += cur->v[j];
         act_fwd(bs.out, ACT_RELU);
         cur = &bs.out;
-        if (i % 2 == 1) S.feat[1 + i / 2] = bs.out;
+        if (B.stage_end) S.feat[stage++] = bs.out;
     }
 }
 // dfeat[5]: pullbacks of the five stage outputs (consumed; modified in place)
 inline void encoder_bwd(Net& N, EncSave& S, Tensor dfeat[5]) {
     Tensor dcur;   // gradient wrt the running activation (output of block i)
-    for (int i = 7; i >= 0; --i) {
+    int stage = 4;
+    for (int i = N.nblk - 1; i >= 0; --i) {
         const Net::Block& B = N.blk[i]; BlockSave& bs = S.blk[i];
-        if (i % 2 == 1) { if (dcur.size() == 0) dcur = dfeat[1 + i / 2]; else for (size_t j = 0; j < dcur.size(); ++j) dcur.v[j] += dfeat[1 + i / 2].v[j]; }
+        if (B.stage_end) { if (dcur.size() == 0) dcur = dfeat[stage]; else for (size_t j = 0; j < dcur.size(); ++j) dcur.v[j] += dfeat[stage].v[j]; --stage; }
         act_bwd(bs.out, dcur, ACT_RELU);                       // through the final ReLU
         Tensor din;                                             // gradient wrt the block input
         if (B.down) convbn_bwd(N, B.cd, B.bd, bs.cd, dcur, &din); else din = dcur;
-        Tensor da1; convbn_bwd(N, B.c2, B.b2, bs.c2, dcur, &da1);
+        Tensor da1;
+        if (!B.bottleneck) convbn_bwd(N, B.c2, B.b2, bs.c2, dcur, &da1);
+        else { Tensor da2; convbn_bwd(N, B.c3, B.b3, bs.c3, dcur, &da2); act_bwd(bs.c2.a, da2, ACT_RELU); convbn_bwd(N, B.c2, B.b2, bs.c2, da2, &da1); }
         act_bwd(bs.c1.a, da1, ACT_RELU);
         Tensor dmain; convbn_bwd(N, B.c1, B.b1, bs.c1, da1, &dmain);
         for (size_t j = 0; j < din.size(); ++j) din.v[j] += dmain.v[j];

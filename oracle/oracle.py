@@ -33,6 +33,7 @@ def lib():
         _LIB.o_smooth_loss_bwd_f32.restype = C.c_double
         _LIB.o_smooth_loss_bwd_f64.restype = C.c_double
         _LIB.o_net_create.restype = C.c_void_p
+        _LIB.o_net_create_depth.restype = C.c_void_p
         _LIB.o_net_nparams.restype = C.c_long
         _LIB.o_net_train_loss.restype = C.c_float
         _LIB.o_loss_fwd_bwd.restype = C.c_float
@@ -239,8 +240,10 @@ def maxpool3s2_bwd(x, dy):
 
 # ---------------- network handle ----------------
 class OracleNet:
-    def __init__(self, channels=1):
-        self.h = C.c_void_p(lib().o_net_create(channels)); self.C = channels
+    def __init__(self, channels=1, depth=18):
+        self.h = C.c_void_p(lib().o_net_create_depth(channels, depth)); self.C = channels; self.depth = depth
+        if not self.h:
+            raise ValueError("encoder depth must be 18 or 50")
         self.nparams = lib().o_net_nparams(self.h)
 
     def __del__(self):
@@ -255,7 +258,7 @@ class OracleNet:
         return [(offs[i], cnts[i], kinds[i]) for i in range(n)]
 
     def convs(self):
-        cap = 64; d = (C.c_int * (cap * 6))(); n = lib().o_net_convs(self.h, d, cap)
+        cap = 128; d = (C.c_int * (cap * 6))(); n = lib().o_net_convs(self.h, d, cap)
         return [tuple(d[i * 6 + j] for j in range(6)) for i in range(n)]
 
     def set_params(self, p):

@@ -72,6 +72,32 @@ def test_network_vs_golden(name):
     assert abs(np.linalg.norm(grads) - float(g["grad_norm_total"])) / float(g["grad_norm_total"]) < 1e-2
 
 
+def test_resnet50_network_vs_torch_live():
+    """BASELINE config "ResNet-50 encoder": the oracle's Bottleneck trunk (torchvision convention, stages 64/256/512/1024/2048 feeding
+    the decoder's channel arithmetic, src/depth_decoder.jl:31-35) against the torch implementation, forward + loss + gradients."""
+    N, C, H, W = 1, 1, 64, 96
+    theta = syn.init_params(C, seed=11, randomize_affine=True, depth=50)
+    x = syn.synthetic_triplets(N, C, H, W, seed=12)
+    K, iK = syn.depth10k_intrinsics(W, H)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK)
+    net = oracle.OracleNet(C, depth=50); net.set_params(theta)
+    assert net.nparams == syn.num_params(C, 50) == theta.size
+    ds, rv, tv = net.model_forward(x, cfg)
+    flat = torch.tensor(theta, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64)
+    dt, poses = tr.model_forward(flat, xt, C, depth=50)
+    for i in range(4):
+        assert ds[i].shape == tuple(dt[i].shape) and rel(ds[i], dt[i].detach().numpy()) < 1e-4
+    assert rel(rv[0], poses[0][0].detach().numpy()) < 1e-4 and rel(tv[1], poses[1][1].detach().numpy()) < 1e-4
+    lt = tr.loss_from_outputs(xt, dt, poses, torch.tensor(K), torch.tensor(iK))
+    lo = net.train_loss(x, cfg, None, True)
+    assert abs(lo - float(lt)) / float(lt) < 1e-4
+    lt.backward()
+    go = net.get_grads(); gt = flat.grad.numpy()
+    assert float(np.dot(go, gt) / (np.linalg.norm(go) * np.linalg.norm(gt))) > 0.999
+    assert abs(np.linalg.norm(go) - np.linalg.norm(gt)) / np.linalg.norm(gt) < 2e-2
+
+
 def test_layers_vs_torch_live():
     x = rng.standard_normal((2, 16, 9, 11)).astype(np.float32); w = rng.standard_normal((8, 16, 3, 3)).astype(np.float32) * 0.1; b = rng.standard_normal(8).astype(np.float32)
     for stride, pad in ((1, 1), (2, 1), (1, 0)):

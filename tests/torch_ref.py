@@ -112,20 +112,29 @@ class Params:
         return g, b
 
 
-def model_forward(flat, x, C, target_id=2, source_ids=(1, 3)):
+def model_forward(flat, x, C, target_id=2, source_ids=(1, 3), depth=18):
     """x (N,L,C,H,W) -> (disps[4] (N,1,h,w), [(rvec (N,3), tvec (N,3))]*2).  src/model.jl:8-20"""
     P = Params(flat); N, L = x.shape[:2]
     h = x.reshape(N * L, C, x.shape[3], x.shape[4])
-    # encoder (torchvision ResNet-18 trunk)
+    # encoder (torchvision ResNet-18 / ResNet-50 trunk)
     w, _ = P.conv(C, 64, 7, False); g, b = P.bn(64)
     h = F.relu(bn_train(flux_conv(h, w, None, 2, 3), g, b)); feats = [h]
     h = F.max_pool2d(h, 3, 2, 1)
     cin = 64
-    for li, co in enumerate((64, 128, 256, 512)):
-        for bi in range(2):
+    nblocks = {18: (2, 2, 2, 2), 50: (3, 4, 6, 3)}[depth]
+    for li, planes in enumerate((64, 128, 256, 512)):
+        for bi in range(nblocks[li]):
             s = 2 if (bi == 0 and li > 0) else 1
-            w1, _ = P.conv(cin, co, 3, False); g1, b1 = P.bn(co); w2, _ = P.conv(co, co, 3, False); g2, b2 = P.bn(co)
-            o = F.relu(bn_train(flux_conv(h, w1, None, s, 1), g1, b1)); o = bn_train(flux_conv(o, w2, None, 1, 1), g2, b2)
+            if depth == 18:
+                co = planes
+                w1, _ = P.conv(cin, co, 3, False); g1, b1 = P.bn(co); w2, _ = P.conv(co, co, 3, False); g2, b2 = P.bn(co)
+                o = F.relu(bn_train(flux_conv(h, w1, None, s, 1), g1, b1)); o = bn_train(flux_conv(o, w2, None, 1, 1), g2, b2)
+            else:                                  # bottleneck, stride on the 3x3
+                co = 4 * planes
+                w1, _ = P.conv(cin, planes, 1, False); g1, b1 = P.bn(planes); w2, _ = P.conv(planes, planes, 3, False); g2, b2 = P.bn(planes)
+                w3, _ = P.conv(planes, co, 1, False); g3, b3 = P.bn(co)
+                o = F.relu(bn_train(flux_conv(h, w1, None, 1, 0), g1, b1)); o = F.relu(bn_train(flux_conv(o, w2, None, s, 1), g2, b2))
+                o = bn_train(flux_conv(o, w3, None, 1, 0), g3, b3)
             if s != 1 or cin != co:
                 wd, _ = P.conv(cin, co, 1, False); gd, bd = P.bn(co); sc = bn_train(flux_conv(h, wd, None, s, 0), gd, bd)
             else:
@@ -135,7 +144,7 @@ def model_forward(flat, x, C, target_id=2, source_ids=(1, 3)):
     f5 = [f.view(N, L, *f.shape[1:]) for f in feats]
     tf = [f[:, target_id - 1] for f in f5]
     # depth decoder
-    dec = [256, 128, 64, 32, 16]; inc = [512, 256, 128, 64, 32]; skc = [256, 128, 64, 64, 0]
+    dec = [256, 128, 64, 32, 16]; inc = [cin, 256, 128, 64, 32]; skc = [feats[3].shape[1], feats[2].shape[1], feats[1].shape[1], 64, 0]
     dconvs = [(P.conv(inc[b_], dec[b_], 3, True), P.conv(dec[b_] + skc[b_], dec[b_], 3, True)) for b_ in range(5)]
     heads = [P.conv(dec[l + 1], 1, 3, True) for l in range(4)]
     rp = lambda a: F.pad(a, (1, 1, 1, 1), mode="reflect")
@@ -149,7 +158,7 @@ def model_forward(flat, x, C, target_id=2, source_ids=(1, 3)):
         if b_ >= 1:
             wh, bh = heads[b_ - 1]; disps.append(torch.sigmoid(flux_conv(rp(xx), wh, bh)))
     # pose decoder
-    ws, bs = P.conv(512, 256, 1, True); wp1, bp1 = P.conv(512, 256, 3, True); wp2, bp2 = P.conv(256, 256, 3, True); wp3, bp3 = P.conv(256, 6, 1, True)
+    ws, bs = P.conv(cin, 256, 1, True); wp1, bp1 = P.conv(512, 256, 3, True); wp2, bp2 = P.conv(256, 256, 3, True); wp3, bp3 = P.conv(256, 6, 1, True)
     assert P.o == flat.numel(), (P.o, flat.numel())
     poses = []
     for sid in source_ids:
