@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=416)
+    ap.add_argument("--depth", type=int, default=18, help="encoder: ResidualNetwork(18) or (50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -80,13 +81,13 @@ def main():
     torch.cuda.set_device(local)
     B, C, H, W = args.batch, args.channels, args.height, args.width
 
-    def setup(batch):
+    def setup(batch, depth=args.depth, C=C, H=H, W=W):
         K, iK = syn.depth10k_intrinsics(W, H)
         params = md.Params(target_size=(W, H), batch_size=batch, automasking=False)        # train(): automasking=false (src/Monodepth.jl:105)
         cache = md.TrainCache(md.SSIM(), md.Backproject(W, H), md.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
-        enc = md.ResidualNetwork(18, in_channels=C)
-        model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(512), lr=1e-4)
-        model.load_params(syn.init_params(C, seed=42))                                      # same weights on every rank
+        enc = md.ResidualNetwork(depth, in_channels=C)
+        model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), lr=1e-4)
+        model.load_params(syn.init_params(C, seed=42, depth=depth))                         # same weights on every rank
         base = syn.synthetic_triplets(min(batch, 8), C, H, W, seed=42 + rank)
         x = torch.from_numpy(np.concatenate([base] * ((batch + len(base) - 1) // len(base)))[:batch].copy()).cuda()
         return model, params, cache, x
@@ -118,7 +119,7 @@ def main():
     out = {"metric": "self-sup training imgs/sec, 416x128 ResNet-18 (1 img = 1 triplet: 3 frames through the encoder)", "value": value, "unit": "triplets/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "ResNet-18 depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, fp32 fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4 under extra)" % (W, H, C, B),
+           "config": {"workload": "ResNet-%d depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, fp32 fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4 and configs[3] ResNet-50 640x192 batch=16 under extra)" % (args.depth, W, H, C, B),
                       "global_batch": world * B, "parallelism": "dp%d" % world, "loss": final_loss}}
 
     if rank == 0:
@@ -165,6 +166,18 @@ def main():
                 md.train_step(m4, x4, None, c4, p4, True)
             torch.cuda.synchronize(); d4 = time.perf_counter() - t0
             extra["config1_batch4"] = {"value": 4 * n4 / d4, "unit": "triplets/s", "ms_per_step": d4 / n4 * 1e3}
+            # BASELINE.json configs[3]: ResNet-50 encoder, 640x192, batch = 16 per GPU (RGB)
+            del m4, x4
+            torch.cuda.empty_cache()
+            m5, p5, c5, x5 = setup(16, depth=50, C=3, H=192, W=640)
+            for _ in range(3):
+                md.train_step(m5, x5, None, c5, p5, True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n5 = 10
+            for _ in range(n5):
+                md.train_step(m5, x5, None, c5, p5, True)
+            torch.cuda.synchronize(); d5 = time.perf_counter() - t0
+            extra["config3_resnet50_640x192_batch16"] = {"value": 16 * n5 / d5, "unit": "triplets/s", "ms_per_step": d5 / n5 * 1e3}
         out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W)

@@ -35,6 +35,8 @@ typedef struct md2_config {
     int32_t device;       /* HIP device ordinal                                              */
     double min_depth, max_depth, disparity_smoothness;   /* Params                            */
     double lr;            /* ADAM eta (1e-4, src/Monodepth.jl:125)                           */
+    int32_t encoder_depth;/* ResidualNetwork(n): 18 (default when 0; src/Monodepth.jl:117) or 50    */
+    int32_t reserved;     /* 0                                                               */
 } md2_config;
 
 /* ---- handle ------------------------------------------------------------------------------- */

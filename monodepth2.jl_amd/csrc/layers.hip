@@ -44,9 +44,10 @@ void launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int 
 // LDS-reduces over row groups, then one double atomic per channel per block.
 template <int MODE, bool FLAT>   // 0: sum z, sum z^2 ; 1: sum g, sum g*xhat  (g = dy * act'(yact)); FLAT: dense NHWC views, pixel p at p*C
 __global__ __launch_bounds__(256) void colstats_kernel(View z, View dy, View yact, int has_yact, int act, const float* __restrict__ stats, double* __restrict__ acc, int rows_per_block) {
-    const int Q = z.C / 4;                    // channel quads
-    const int RG = 256 / Q;                   // row groups (Q <= 128)
-    const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
+    const int Qall = z.C / 4;                 // channel quads; more than 256 of them (C = 2048, ResNet-50) are split over blockIdx.y
+    const int qoff = blockIdx.y * 256, Q = min(Qall - qoff, 256);
+    const int RG = 256 / Q;                   // row groups
+    const int q = qoff + threadIdx.x % Q, rg = threadIdx.x / Q;
     __shared__ float red[2 * 4 * 256];
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     const long P = z.pixels(); const int HW = z.H * z.W;
@@ -72,23 +73,24 @@ __global__ __launch_bounds__(256) void colstats_kernel(View z, View dy, View yac
     r1[0 * 256 + threadIdx.x] = s1.x; r1[1 * 256 + threadIdx.x] = s1.y; r1[2 * 256 + threadIdx.x] = s1.z; r1[3 * 256 + threadIdx.x] = s1.w;
     r2[0 * 256 + threadIdx.x] = s2.x; r2[1 * 256 + threadIdx.x] = s2.y; r2[2 * 256 + threadIdx.x] = s2.z; r2[3 * 256 + threadIdx.x] = s2.w;
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * z.C; c += 256) {
-        const int which = c / z.C, ch = c % z.C, qq = ch / 4, e = ch % 4;
+    for (int c = threadIdx.x; c < 2 * 4 * Q; c += 256) {                 // this block's 4*Q channels
+        const int which = c / (4 * Q), ch = c % (4 * Q), qq = ch / 4, e = ch % 4;
         const float* rr = which ? r2 : r1;
         float s = 0.f;
         for (int g = 0; g < RG; ++g) s += rr[e * 256 + g * Q + qq];
-        atomicAdd(acc + c, (double)s);
+        atomicAdd(acc + which * z.C + qoff * 4 + ch, (double)s);
     }
 }
 static void colstats_launch(int mode, const View& z, const View* dy, const View* yact, int act, const float* stats, double* acc, hipStream_t s) {
-    if (z.C % 4 != 0 || z.C > 512 || 256 % (z.C / 4) != 0) { fprintf(stderr, "md2: colstats: unsupported C=%d\n", z.C); abort(); }
+    const int Qh = z.C / 4;
+    if (z.C % 4 != 0 || (Qh <= 256 ? 256 % Qh != 0 : Qh % 256 != 0)) { fprintf(stderr, "md2: colstats: unsupported C=%d\n", z.C); abort(); }
     const long P = z.pixels();
     int rpb = 2048; while (rpb > 64 && (P + rpb - 1) / rpb < 1024) rpb >>= 1;
-    const int grid = (int)((P + rpb - 1) / rpb);
+    const dim3 grid((unsigned)((P + rpb - 1) / rpb), (unsigned)((Qh + 255) / 256));
     View d = dy ? *dy : z, ya = yact ? *yact : z;
     const bool flat = dense_view_h(z) && dense_view_h(d) && dense_view_h(ya);
-    if (mode == 0) { if (flat) hipLaunchKernelGGL((colstats_kernel<0, true>), dim3(grid), dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); else hipLaunchKernelGGL((colstats_kernel<0, false>), dim3(grid), dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); }
-    else { if (flat) hipLaunchKernelGGL((colstats_kernel<1, true>), dim3(grid), dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); else hipLaunchKernelGGL((colstats_kernel<1, false>), dim3(grid), dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); }
+    if (mode == 0) { if (flat) hipLaunchKernelGGL((colstats_kernel<0, true>), grid, dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); else hipLaunchKernelGGL((colstats_kernel<0, false>), grid, dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); }
+    else { if (flat) hipLaunchKernelGGL((colstats_kernel<1, true>), grid, dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); else hipLaunchKernelGGL((colstats_kernel<1, false>), grid, dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); }
 }
 void launch_colstats(const View& z, double* acc, hipStream_t s) { colstats_launch(0, z, nullptr, nullptr, 0, nullptr, acc, s); }
 void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View& z, const float* stats, double* acc, hipStream_t s) {

@@ -31,7 +31,10 @@ struct ConvL {
     long wn() const { return (long)coutP * taps * cinP; }
 };
 struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; float* stats = nullptr; double* acc = nullptr; double* acc_b = nullptr; };
-struct Block { ConvL c1, c2, cd; BNL b1, b2, bd; bool down = false; int stride = 1; View in, z1, a1, z2, zd, sd, out; View dz1, dz2, dzd; };
+// BasicBlock (ResNet-18): c1 3x3(stride) - b1 - relu - c2 3x3 - b2 (+ shortcut) - relu
+// Bottleneck (ResNet-50): c1 1x1 - b1 - relu - c2 3x3(stride) - b2 - relu - c3 1x1 x4 - b3 (+ shortcut) - relu     (torchvision convention)
+struct Block { ConvL c1, c2, c3, cd; BNL b1, b2, b3, bd; bool down = false, bottleneck = false, stage_end = false; int stride = 1;
+               View in, z1, a1, z2, a2, z3, zd, sd, out; View dz1, dz2, dz3, dzd; };
 struct ProfEvt { hipEvent_t a, b; int cls; double flops; char desc[112]; };
 enum { CLS_IGEMM = 0, CLS_WGRAD = 1, CLS_LOSS_FWD = 2, CLS_LOSS_BWD = 3, CLS_OTHER = 4 };
 
@@ -46,7 +49,7 @@ struct md2_handle {
     long n_int = 0, n_flux = 0;
     float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *WD = nullptr;
     double beta1p = 1.0, beta2p = 1.0;
-    ConvL stem; BNL stem_bn; Block blk[8];
+    ConvL stem; BNL stem_bn; Block blk[16]; int nblk = 8, depth = 18; int stages[5] = {64, 64, 128, 256, 512};
     ConvL dc1[5], dc2[5], head[4], squeeze, pose[3];
     std::vector<ConvL*> convs; std::vector<BNL*> bns;
     char* arena = nullptr; size_t arena_off = 0;
@@ -57,7 +60,7 @@ struct md2_handle {
     View sqcat, py1, py2, py3; float *rvec = nullptr, *tvec = nullptr, *Rt = nullptr;
     double *loss_part = nullptr, *dRt_acc = nullptr; float *totals = nullptr, *loss_dev = nullptr, *ddisp_full = nullptr, *drvec = nullptr, *dtvec = nullptr;
     const float* x_last = nullptr; const float* auto_last = nullptr; bool have_fwd = false;
-    View Gfeat[5], Gblk[8], Gpool; char* gzero_begin = nullptr; size_t gzero_bytes = 0;
+    View Gfeat[5], Gblk[16], Gpool; char* gzero_begin = nullptr; size_t gzero_bytes = 0;
     View gA[5], dZ1[5], dupv[5]; float* dxpad = nullptr; float* ddisp_lo[4] = {nullptr, nullptr, nullptr, nullptr};
     float *E1 = nullptr, *E2 = nullptr, *E3 = nullptr;
     View dpy3, dpy2, dpy1, dsq;
@@ -98,20 +101,30 @@ static void build_layers(md2_handle* h) {
     auto mkbn = [&](BNL& b, int c) { b.c = c; b.g = al(c); b.b = al(c); b.fg = fo; b.fb = fo + c; fo += 2 * c; h->bns.push_back(&b); };
     mk(h->stem, h->C, 64, 7, 2, 3, false, 1); mkbn(h->stem_bn, 64);
     h->Kpad = h->stem.cinP;
-    const int chans[4] = {64, 128, 256, 512}; int cin = 64;
-    for (int l = 0; l < 4; ++l)
-        for (int b = 0; b < 2; ++b) {
-            Block& B = h->blk[l * 2 + b]; const int co = chans[l]; const int s = (b == 0 && l > 0) ? 2 : 1;
-            B.stride = s;
-            mk(B.c1, cin, co, 3, s, 1, false, 0); mkbn(B.b1, co); mk(B.c2, co, co, 3, 1, 1, false, 0); mkbn(B.b2, co);
+    const int planes[4] = {64, 128, 256, 512}; int cin = 64;
+    const int nb18[4] = {2, 2, 2, 2}, nb50[4] = {3, 4, 6, 3};
+    const int* nb = h->depth == 50 ? nb50 : nb18;
+    h->nblk = 0; h->stages[0] = 64;
+    for (int l = 0; l < 4; ++l) {
+        for (int b = 0; b < nb[l]; ++b) {
+            Block& B = h->blk[h->nblk++]; const int s = (b == 0 && l > 0) ? 2 : 1;
+            B.stride = s; B.bottleneck = h->depth == 50; B.stage_end = (b == nb[l] - 1);
+            int co;
+            if (!B.bottleneck) { co = planes[l]; mk(B.c1, cin, co, 3, s, 1, false, 0); mkbn(B.b1, co); mk(B.c2, co, co, 3, 1, 1, false, 0); mkbn(B.b2, co); }
+            else { co = 4 * planes[l]; mk(B.c1, cin, planes[l], 1, 1, 0, false, 0); mkbn(B.b1, planes[l]); mk(B.c2, planes[l], planes[l], 3, s, 1, false, 0); mkbn(B.b2, planes[l]);
+                   mk(B.c3, planes[l], co, 1, 1, 0, false, 0); mkbn(B.b3, co); }
             B.down = (s != 1 || cin != co);
             if (B.down) { mk(B.cd, cin, co, 1, s, 0, false, 0); mkbn(B.bd, co); }
             cin = co;
         }
-    const int dec[5] = {256, 128, 64, 32, 16}, inc[5] = {512, 256, 128, 64, 32}, skc[5] = {256, 128, 64, 64, 0};
+        h->stages[l + 1] = cin;
+    }
+    // DepthDecoder channel arithmetic from the encoder stages (src/depth_decoder.jl:31-35)
+    const int dec[5] = {256, 128, 64, 32, 16};
+    const int inc[5] = {h->stages[4], 256, 128, 64, 32}, skc[5] = {h->stages[3], h->stages[2], h->stages[1], h->stages[0], 0};
     for (int b = 0; b < 5; ++b) { mk(h->dc1[b], inc[b], dec[b], 3, 1, 0, true, 0); mk(h->dc2[b], dec[b] + skc[b], dec[b], 3, 1, 0, true, 0); }
     for (int l = 0; l < 4; ++l) mk(h->head[l], dec[l + 1], 1, 3, 1, 0, true, 2);
-    mk(h->squeeze, 512, 256, 1, 1, 0, true, 0); mk(h->pose[0], 512, 256, 3, 1, 1, true, 0); mk(h->pose[1], 256, 256, 3, 1, 1, true, 0); mk(h->pose[2], 256, 6, 1, 1, 0, true, 0);
+    mk(h->squeeze, h->stages[4], 256, 1, 1, 0, true, 0); mk(h->pose[0], 512, 256, 3, 1, 1, true, 0); mk(h->pose[1], 256, 256, 3, 1, 1, true, 0); mk(h->pose[2], 256, 6, 1, 1, 0, true, 0);
     h->n_int = io; h->n_flux = fo;
 }
 
@@ -149,17 +162,26 @@ static void plan_buffers(md2_handle* h) {
     h->p0 = h->alloc_view(NL, H / 4, W / 4, 64); h->pool_arg = h->alloc<uint8_t>((size_t)NL * (H / 4) * (W / 4) * 64);
     h->feat[0] = h->a0;
     int hh = H / 4, ww = W / 4; View cur = h->p0;
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0, stage = 1; i < h->nblk; ++i) {
         Block& B = h->blk[i];
+        const int hi = hh, wi = ww;                      // resolution of the block input (the bottleneck's 1x1 conv1 keeps it)
         if (B.stride == 2) { hh /= 2; ww /= 2; }
-        const int co = B.c1.cout;
-        B.in = cur; B.z1 = h->alloc_view(NL, hh, ww, co); B.a1 = h->alloc_view(NL, hh, ww, co); B.z2 = h->alloc_view(NL, hh, ww, co);
+        B.in = cur;
+        if (!B.bottleneck) {
+            const int co = B.c1.cout;
+            B.z1 = h->alloc_view(NL, hh, ww, co); B.a1 = h->alloc_view(NL, hh, ww, co); B.z2 = h->alloc_view(NL, hh, ww, co);
+        } else {
+            const int pl = B.c1.cout, co = B.c3.cout;
+            B.z1 = h->alloc_view(NL, hi, wi, pl); B.a1 = h->alloc_view(NL, hi, wi, pl);
+            B.z2 = h->alloc_view(NL, hh, ww, pl); B.a2 = h->alloc_view(NL, hh, ww, pl); B.z3 = h->alloc_view(NL, hh, ww, co);
+        }
+        const int co = B.bottleneck ? B.c3.cout : B.c1.cout;
         if (B.down) { B.zd = h->alloc_view(NL, hh, ww, co); B.sd = h->alloc_view(NL, hh, ww, co); }
         B.out = h->alloc_view(NL, hh, ww, co);
         cur = B.out;
-        if (i % 2 == 1) h->feat[1 + i / 2] = B.out;
+        if (B.stage_end) h->feat[stage++] = B.out;
     }
-    const int dec[5] = {256, 128, 64, 32, 16}, skc[5] = {256, 128, 64, 64, 0}, inc[5] = {512, 256, 128, 64, 32};
+    const int dec[5] = {256, 128, 64, 32, 16}, skc[5] = {h->stages[3], h->stages[2], h->stages[1], h->stages[0], 0}, inc[5] = {h->stages[4], 256, 128, 64, 32};
     int dh = H / 32, dw = W / 32;
     size_t dxpad_max = 0;
     for (int b = 0; b < 5; ++b) {
@@ -192,8 +214,10 @@ static void plan_buffers(md2_handle* h) {
     h->arena_off = (h->arena_off + 255) / 256 * 256;
     const size_t gz0 = h->arena_off;
     for (int i = 0; i < 5; ++i) h->Gfeat[i] = h->alloc_view(h->feat[i].N, h->feat[i].H, h->feat[i].W, h->feat[i].C);
-    for (int i = 0; i < 8; i += 2) h->Gblk[i] = h->alloc_view(h->blk[i].out.N, h->blk[i].out.H, h->blk[i].out.W, h->blk[i].out.C);
-    for (int i = 1; i < 8; i += 2) h->Gblk[i] = h->Gfeat[1 + i / 2];
+    for (int i = 0, stage = 1; i < h->nblk; ++i) {       // the gradient of a stage output IS the stage's feature gradient buffer
+        if (h->blk[i].stage_end) h->Gblk[i] = h->Gfeat[stage++];
+        else h->Gblk[i] = h->alloc_view(h->blk[i].out.N, h->blk[i].out.H, h->blk[i].out.W, h->blk[i].out.C);
+    }
     h->Gpool = h->alloc_view(NL, H / 4, W / 4, 64);
     h->arena_off = (h->arena_off + 255) / 256 * 256;
     h->gzero_begin = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(h->arena) + gz0); h->gzero_bytes = h->arena_off - gz0;
@@ -209,7 +233,7 @@ static void plan_buffers(md2_handle* h) {
     h->E1 = h->alloc<float>(emax); h->E2 = h->alloc<float>(emax); h->E3 = h->alloc<float>(emax);
     // pre-activation gradients of every encoder conv: NOT shared scratch, the weight-gradient stream reads them while the main stream moves on
     h->dz0 = h->alloc_view(NL, H / 2, W / 2, 64);
-    for (int i = 0; i < 8; ++i) { Block& B = h->blk[i]; B.dz1 = h->alloc_view(NL, B.z1.H, B.z1.W, B.z1.C); B.dz2 = h->alloc_view(NL, B.z2.H, B.z2.W, B.z2.C); if (B.down) B.dzd = h->alloc_view(NL, B.zd.H, B.zd.W, B.zd.C); }
+    for (int i = 0; i < h->nblk; ++i) { Block& B = h->blk[i]; B.dz1 = h->alloc_view(NL, B.z1.H, B.z1.W, B.z1.C); B.dz2 = h->alloc_view(NL, B.z2.H, B.z2.W, B.z2.C); if (B.bottleneck) B.dz3 = h->alloc_view(NL, B.z3.H, B.z3.W, B.z3.C); if (B.down) B.dzd = h->alloc_view(NL, B.zd.H, B.zd.W, B.zd.C); }
     h->dpy3 = h->alloc_view(2 * N, ph, pw, 16); h->dpy2 = h->alloc_view(2 * N, ph, pw, 256); h->dpy1 = h->alloc_view(2 * N, ph, pw, 256); h->dsq = h->alloc_view(2 * N, ph, pw, 512);
 }
 
@@ -298,7 +322,7 @@ static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp
 // Temporarily re-batch every activation view: n_enc encoder images, n_dec decoder samples (<= the sizes the arena was planned for).
 static void set_batch(md2_handle* h, int n_enc, int n_dec) {
     h->z0.N = h->a0.N = h->p0.N = n_enc;
-    for (int i = 0; i < 8; ++i) { Block& B = h->blk[i]; B.in.N = B.z1.N = B.a1.N = B.z2.N = B.out.N = n_enc; if (B.down) B.zd.N = B.sd.N = n_enc; }
+    for (int i = 0; i < h->nblk; ++i) { Block& B = h->blk[i]; B.in.N = B.z1.N = B.a1.N = B.z2.N = B.out.N = n_enc; if (B.bottleneck) B.a2.N = B.z3.N = n_enc; if (B.down) B.zd.N = B.sd.N = n_enc; }
     for (int i = 0; i < 5; ++i) { h->feat[i].N = n_enc; h->y1[i].N = h->cat[i].N = h->y2[i].N = n_dec; }
     for (int i = 0; i < 4; ++i) h->dispv[i].N = n_dec;
 }
@@ -330,15 +354,17 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
     }
     bn_fwd(h, h->stem_bn, h->z0, nullptr, ACT_RELU, h->a0);
     launch_maxpool_fwd(h->a0, h->p0, h->pool_arg, s);
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < h->nblk; ++i) {
         Block& B = h->blk[i];
         conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_fwd(h, B.b1, B.z1, nullptr, ACT_RELU, B.a1);
         conv_fwd(h, B.c2, B.a1, B.z2, PAD_ZERO, ACT_NONE, B.b2.acc);
+        if (B.bottleneck) { bn_fwd(h, B.b2, B.z2, nullptr, ACT_RELU, B.a2); conv_fwd(h, B.c3, B.a2, B.z3, PAD_ZERO, ACT_NONE, B.b3.acc); }
         if (B.down) {
             conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc);
             bn_fwd(h, B.bd, B.zd, nullptr, ACT_NONE, B.sd);                 // raw zd is kept for the pullback
         }
-        bn_fwd(h, B.b2, B.z2, B.down ? &B.sd : &B.in, ACT_RELU, B.out);
+        if (B.bottleneck) bn_fwd(h, B.b3, B.z3, B.down ? &B.sd : &B.in, ACT_RELU, B.out);
+        else bn_fwd(h, B.b2, B.z2, B.down ? &B.sd : &B.in, ACT_RELU, B.out);
     }
     // ---- pose decoder on its own stream, concurrently with the depth decoder (both only read the encoder features)
     const bool pose_async = with_pose && h->two_streams && h->s3;
@@ -475,21 +501,32 @@ static int model_backward(md2_handle* h) {
         (void)hipStreamWaitEvent(h->stream, h->ev_c, 0);
     } else { pose_backward(h, N, 0); pose_backward(h, N, 1); }
     // ---- encoder
-    for (int i = 7; i >= 0; --i) {
+    for (int i = h->nblk - 1; i >= 0; --i) {
         Block& B = h->blk[i];
         const View& Gout = h->Gblk[i];                                  // d / d(pre-ReLU block output), already masked
         const View* Gin = (i == 0) ? &h->Gpool : &h->Gblk[i - 1];
         const View* in_act = (i == 0) ? nullptr : &B.in;                 // ReLU mask of the block input (stage 0: applied in the maxpool pullback)
-        const View& dz2 = B.dz2; const View& dz1 = B.dz1; View da1 = make_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C);
-        bn_bwd(h, B.b2, Gout, B.z2, dz2);
-        conv_wgrad(h, B.c2, B.a1, dz2, PAD_ZERO);
-        conv_dgrad(h, B.c2, dz2, da1, 1, 0, &B.a1, ACT_RELU);
+        const View& dz1 = B.dz1; View da1 = make_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C);
+        if (!B.bottleneck) {
+            bn_bwd(h, B.b2, Gout, B.z2, B.dz2);
+            conv_wgrad(h, B.c2, B.a1, B.dz2, PAD_ZERO);
+            conv_dgrad(h, B.c2, B.dz2, da1, 1, 0, &B.a1, ACT_RELU);
+        } else {
+            View da2 = make_view(h->E3, NL, B.a2.H, B.a2.W, B.a2.C);
+            bn_bwd(h, B.b3, Gout, B.z3, B.dz3);
+            conv_wgrad(h, B.c3, B.a2, B.dz3, PAD_ZERO);
+            conv_dgrad(h, B.c3, B.dz3, da2, 0, 0, &B.a2, ACT_RELU);
+            bn_bwd(h, B.b2, da2, B.z2, B.dz2);
+            conv_wgrad(h, B.c2, B.a1, B.dz2, PAD_ZERO);
+            conv_dgrad(h, B.c2, B.dz2, da1, 1, 0, &B.a1, ACT_RELU);          // carries the block's stride
+        }
         bn_bwd(h, B.b1, da1, B.z1, dz1);
         conv_wgrad(h, B.c1, B.in, dz1, PAD_ZERO);
-        // first encoder writer of Gin: own buffers (odd i, and the pool gradient) are overwritten; stage buffers (even i > 0) already hold
-        // the decoder's contribution in the target frames
+        // first encoder writer of Gin: own buffers (and the pool gradient) are overwritten; stage buffers already hold the decoder's
+        // contribution in the target frames
         // identity shortcut: d(block input) = relu'(in) * (conv1 pullback + Gout) -- Gout is added in the same epilogue (was an axpy pass)
-        conv_dgrad(h, B.c1, dz1, *Gin, 1, (i == 0 || (i & 1)) ? 0 : 2, in_act, ACT_RELU, B.down ? nullptr : &Gout);
+        const int first_mode = (i == 0 || !h->blk[i - 1].stage_end) ? 0 : 2;
+        conv_dgrad(h, B.c1, dz1, *Gin, B.c1.pad, first_mode, in_act, ACT_RELU, B.down ? nullptr : &Gout);
         if (B.down) {
             const View& dzd = B.dzd;
             bn_bwd(h, B.bd, Gout, B.zd, dzd);
@@ -525,11 +562,13 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     if (cfg->batch < 1 || (cfg->channels != 1 && cfg->channels != 3) || cfg->height % 32 || cfg->width % 32 || cfg->height < 64 || cfg->width < 64) {
         g_create_err = "md2_create: need batch >= 1, channels in {1,3}, height/width multiples of 32 and >= 64"; return 2;
     }
+    if (cfg->encoder_depth != 0 && cfg->encoder_depth != 18 && cfg->encoder_depth != 50) { g_create_err = "md2_create: encoder_depth must be 18 (or 0) or 50"; return 2; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "md2_create: no HIP device (libmd2hip needs an MI355X; there is no CPU fallback)"; return 3; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "md2_create: hipSetDevice failed"; return 3; }
     md2_handle* h = new md2_handle();
     h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width;
+    h->depth = cfg->encoder_depth == 50 ? 50 : 18;
     build_layers(h);
     plan_buffers(h);                        // sizing pass
     const size_t need = h->arena_off + 4096;

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import synthetic
 
 
 def _check(rc, handle=None, what=""):
@@ -211,13 +212,13 @@ class Pose:
 
 
 class ResidualNetwork:
-    """ResidualNetwork(18; in_channels, classes=nothing): only the ResNet-18 trunk is implemented."""
+    """ResidualNetwork(n; in_channels, classes=nothing): the ResNet-18 (BasicBlock) and ResNet-50 (Bottleneck) trunks."""
 
     def __init__(self, depth=18, in_channels=3, classes=None):
-        if depth != 18 or classes is not None:
-            raise NotImplementedError("hot path implements ResNet-18 without the classifier head")
-        self.in_channels = in_channels
-        self.stages = (64, 64, 128, 256, 512)
+        if depth not in (18, 50) or classes is not None:
+            raise NotImplementedError("hot path implements the ResNet-18 / ResNet-50 trunks without the classifier head")
+        self.depth, self.in_channels = depth, in_channels
+        self.stages = synthetic.stages(depth)
 
 
 class DepthDecoder:
@@ -225,15 +226,15 @@ class DepthDecoder:
         scale_levels = list(scale_levels)
         if len(scale_levels) > 5 or min(scale_levels) < 1 or max(scale_levels) > 5:
             raise ValueError("`scale_levels` should be at most of length 5 and have values in [1, 5] range.")   # src/depth_decoder.jl:27-29
-        if list(encoder_channels) != [64, 64, 128, 256, 512] or scale_levels != [2, 3, 4, 5]:
-            raise NotImplementedError("hot path implements encoder_channels=(64,64,128,256,512), scale_levels=2:5 (src/Monodepth.jl:106,118)")
+        if tuple(encoder_channels) not in (synthetic.stages(18), synthetic.stages(50)) or scale_levels != [2, 3, 4, 5]:
+            raise NotImplementedError("hot path implements the ResNet-18 / ResNet-50 stage channels and scale_levels=2:5 (src/Monodepth.jl:106,118)")
         self.encoder_channels, self.scale_levels = list(encoder_channels), scale_levels
 
 
 class PoseDecoder:
     def __init__(self, encoder_out_channels):
-        if encoder_out_channels != 512:
-            raise NotImplementedError("hot path implements PoseDecoder(512)")
+        if encoder_out_channels not in (512, 2048):
+            raise NotImplementedError("hot path implements PoseDecoder(512) and PoseDecoder(2048)")
         self.encoder_out_channels = encoder_out_channels
 
 
@@ -244,6 +245,8 @@ class Model:
 
     def __init__(self, encoder, depth_decoder, pose_decoder, lr=1e-4):
         self.encoder, self.depth_decoder, self.pose_decoder = encoder, depth_decoder, pose_decoder
+        if tuple(depth_decoder.encoder_channels) != tuple(encoder.stages) or pose_decoder.encoder_out_channels != encoder.stages[-1]:
+            raise ValueError("decoder channels do not match the encoder's stages")
         self.lr = lr
         self._h = None
         self._shape = None
@@ -265,7 +268,8 @@ class Model:
             return
         saved = self.params() if self._h is not None else self._params_host
         self.close()
-        cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr)
+        cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr,
+                             self.encoder.depth, 0)
         h = C.c_void_p()
         _check(_lib.lib().md2_create(C.byref(cfg), C.byref(h)), None, "md2_create")
         self._h, self._shape, self._cfg_extra = h, key, extra
@@ -347,13 +351,15 @@ def save_checkpoint(m: Model, path):
     n = _lib.lib().md2_params_count(m._h)
     mm = np.empty(n, np.float32); vv = np.empty(n, np.float32); b1 = C.c_double(); b2 = C.c_double()
     _check(_lib.lib().md2_opt_state_get(m._h, mm.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), n, C.byref(b1), C.byref(b2)), m._h, "opt_state_get")
-    np.savez(path, params=m.params(), adam_m=mm, adam_v=vv, beta1p=b1.value, beta2p=b2.value, in_channels=m.encoder.in_channels, lr=m.lr)
+    np.savez(path, params=m.params(), adam_m=mm, adam_v=vv, beta1p=b1.value, beta2p=b2.value, in_channels=m.encoder.in_channels, encoder_depth=m.encoder.depth, lr=m.lr)
 
 
 def load_checkpoint(m: Model, path):
     ck = np.load(path)
     if int(ck["in_channels"]) != m.encoder.in_channels:
         raise ValueError("checkpoint was saved for in_channels=%d" % int(ck["in_channels"]))
+    if "encoder_depth" in ck and int(ck["encoder_depth"]) != m.encoder.depth:
+        raise ValueError("checkpoint was saved for ResidualNetwork(%d)" % int(ck["encoder_depth"]))
     m.load_params(ck["params"])
     if m._h is None:
         raise RuntimeError("load_checkpoint: run the model once (or call model._ensure) before restoring the optimiser state")

@@ -37,14 +37,14 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def make(N, C, H, W, automask=False, pseed=1, lr=1e-4):
+def make(N, C, H, W, automask=False, pseed=1, lr=1e-4, depth=18):
     m = md()
     K, iK = syn.depth10k_intrinsics(W, H)
     params = m.Params(target_size=(W, H), batch_size=N, automasking=automask)
     cache = m.TrainCache(m.SSIM(), m.Backproject(W, H), m.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
-    enc = m.ResidualNetwork(18, in_channels=C)
-    model = m.Model(enc, m.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), m.PoseDecoder(512), lr=lr)
-    theta = syn.init_params(C, seed=pseed, randomize_affine=True)
+    enc = m.ResidualNetwork(depth, in_channels=C)
+    model = m.Model(enc, m.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), m.PoseDecoder(enc.stages[-1]), lr=lr)
+    theta = syn.init_params(C, seed=pseed, randomize_affine=True, depth=depth)
     model.load_params(theta)
     return model, params, cache, theta, K, iK
 
@@ -326,6 +326,48 @@ def test_config5_shape_1024x320_with_automasking_vs_oracle():
     assert np.abs(host(al) - alo).max() < 1e-4
     net = oracle.OracleNet(C); net.set_params(theta)
     lo = net.train_loss(x, cfg, alo, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    gh = model.grads(); go = net.get_grads()
+    assert np.isfinite(gh).all()
+    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 64, 96), (1, 3, 96, 160)])
+def test_resnet50_encoder_forward_loss_gradient_and_adam_vs_oracle(shape):
+    """BASELINE config "ResNet-50 encoder": Bottleneck trunk (1x1 - 3x3 carrying the stride - 1x1 x4, torchvision convention), stages
+    (64,256,512,1024,2048) feeding the decoders.  Forward outputs and loss within 1e-4 of the oracle, gradients in the same direction,
+    one ADAM step equal to the oracle's."""
+    N, C, H, W = shape
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=41, depth=50)
+    assert theta.size == syn.num_params(C, 50)
+    x = syn.synthetic_triplets(N, C, H, W, seed=42); xd = dev(x)
+    net = oracle.OracleNet(C, depth=50); net.set_params(theta)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK)
+    ds, poses = model(xd, [1, 3], 2)
+    do, rvo, tvo = net.model_forward(x, cfg)
+    for i in range(4):
+        assert rel(host(ds[i]), do[i]) < 1e-4
+    assert rel(host(poses[0].rvec), rvo[0]) < 1e-3 and rel(host(poses[1].tvec), tvo[1]) < 1e-3
+    loss = md().train_step(model, xd, None, cache, params, do_update=False)
+    lo = net.train_loss(x, cfg, None, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    gh = model.grads(); go = net.get_grads()
+    assert np.isfinite(gh).all()
+    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+    assert abs(np.linalg.norm(gh) - np.linalg.norm(go)) / np.linalg.norm(go) < 2e-2
+    md().update(md().ADAM(1e-4), model); net.adam_step(1e-4)
+    assert np.abs(model.params() - net.get_params()).max() < 5e-3 * 1e-4 / 1e-4 * 1e-1     # |delta| <= lr per element; sign flips only on ~0 gradients
+
+
+def test_config4_resnet50_640x192_vs_oracle():
+    """BASELINE config "ResNet-50 encoder, 640x192, 4-scale photometric loss" at its full resolution (RGB, one triplet): loss within 1e-4
+    of the oracle and the gradient in the same direction."""
+    N, C, H, W = 1, 3, 192, 640
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=51, depth=50)
+    x = syn.synthetic_triplets(N, C, H, W, seed=52); xd = dev(x)
+    loss = md().train_step(model, xd, None, cache, params, do_update=False)
+    net = oracle.OracleNet(C, depth=50); net.set_params(theta)
+    lo = net.train_loss(x, oracle.make_cfg(N, C, H, W, K, iK), None, True)
     assert abs(float(loss) - lo) / lo < 1e-4
     gh = model.grads(); go = net.get_grads()
     assert np.isfinite(gh).all()
