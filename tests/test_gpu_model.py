@@ -260,20 +260,21 @@ def test_gradients_do_not_depend_on_previous_step(C, automask):
     assert diff < max(5 * noise, 2e-3)
 
 
-def test_eval_disparity_vs_oracle():
+@pytest.mark.parametrize("depth", [18, 50])
+def test_eval_disparity_vs_oracle(depth):
     """eval_disparity(m, x), src/model.jl:28, on single frames (encoder batch != 3N, no pose decoder)."""
     N, C, H, W = 3, 1, 64, 96
-    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=6)
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=6, depth=depth)
     frames = syn.synthetic_triplets(N, C, H, W, seed=16)[:, 1]
     for n in (3, 2):
         ds = md().eval_disparity(model, dev(frames[:n]))
-        net = oracle.OracleNet(C); net.set_params(theta); do = net.eval_disparity(frames[:n])
+        net = oracle.OracleNet(C, depth=depth); net.set_params(theta); do = net.eval_disparity(frames[:n])
         for i in range(4):
             assert ds[i].shape == do[i].shape and rel(host(ds[i]), do[i]) < 1e-4
     # the training path still works on the same handle afterwards
     xd = dev(syn.synthetic_triplets(N, C, H, W, seed=17))
     loss = md().train_step(model, xd, None, cache, params, do_update=False)
-    net = oracle.OracleNet(C); net.set_params(theta)
+    net = oracle.OracleNet(C, depth=depth); net.set_params(theta)
     lo = net.train_loss(host(xd), oracle.make_cfg(N, C, H, W, K, iK), None, False)
     assert abs(float(loss) - lo) / lo < 1e-4
 
