@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=416)
     ap.add_argument("--depth", type=int, default=18, help="encoder: ResidualNetwork(18) or (50)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="f32 = the reference's precision (parity mode); bf16 = bf16 MFMA operands, fp32 everything else")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -81,12 +82,12 @@ def main():
     torch.cuda.set_device(local)
     B, C, H, W = args.batch, args.channels, args.height, args.width
 
-    def setup(batch, depth=args.depth, C=C, H=H, W=W):
+    def setup(batch, depth=args.depth, C=C, H=H, W=W, precision=args.precision, automask=False):
         K, iK = syn.depth10k_intrinsics(W, H)
-        params = md.Params(target_size=(W, H), batch_size=batch, automasking=False)        # train(): automasking=false (src/Monodepth.jl:105)
+        params = md.Params(target_size=(W, H), batch_size=batch, automasking=automask)     # train(): automasking=false (src/Monodepth.jl:105)
         cache = md.TrainCache(md.SSIM(), md.Backproject(W, H), md.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
         enc = md.ResidualNetwork(depth, in_channels=C)
-        model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), lr=1e-4)
+        model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), lr=1e-4, precision=precision)
         model.load_params(syn.init_params(C, seed=42, depth=depth))                         # same weights on every rank
         base = syn.synthetic_triplets(min(batch, 8), C, H, W, seed=42 + rank)
         x = torch.from_numpy(np.concatenate([base] * ((batch + len(base) - 1) // len(base)))[:batch].copy()).cuda()
@@ -118,7 +119,7 @@ def main():
 
     out = {"metric": "self-sup training imgs/sec, 416x128 ResNet-18 (1 img = 1 triplet: 3 frames through the encoder)", "value": value, "unit": "triplets/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
            "config": {"workload": "ResNet-%d depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, fp32 fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4 and configs[3] ResNet-50 640x192 batch=16 under extra)" % (args.depth, W, H, C, B),
                       "global_batch": world * B, "parallelism": "dp%d" % world, "loss": final_loss}}
 
@@ -178,6 +179,33 @@ def main():
                 md.train_step(m5, x5, None, c5, p5, True)
             torch.cuda.synchronize(); d5 = time.perf_counter() - t0
             extra["config3_resnet50_640x192_batch16"] = {"value": 16 * n5 / d5, "unit": "triplets/s", "ms_per_step": d5 / n5 * 1e3}
+            # BASELINE.json configs[4]: 1024x320, bf16 mixed precision + min-reprojection automask, batch = 8 per GPU (NOT a parity mode:
+            # bf16 MFMA operands, fp32 accumulation / activations / master weights; tests bound its loss to 2 % of the fp32 oracle)
+            del m5, x5
+            torch.cuda.empty_cache()
+            m6, p6, c6, x6 = setup(8, depth=18, C=3, H=320, W=1024, precision="bf16", automask=True)
+            a6 = md.automasking_loss(c6.ssim, x6, x6[:, 1].contiguous(), [1, 3])
+            for _ in range(3):
+                md.train_step(m6, x6, a6, c6, p6, True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n6 = 10
+            for _ in range(n6):
+                a6 = md.automasking_loss(c6.ssim, x6, x6[:, 1].contiguous(), [1, 3])        # recomputed per batch like src/Monodepth.jl:159-164
+                md.train_step(m6, x6, a6, c6, p6, True)
+            torch.cuda.synchronize(); d6 = time.perf_counter() - t0
+            extra["config4_1024x320_bf16_automask_batch8"] = {"value": 8 * n6 / d6, "unit": "triplets/s", "ms_per_step": d6 / n6 * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate"}
+            # and the headline shape in the same mixed precision, for reference next to `value` (which is fp32)
+            del m6, x6
+            torch.cuda.empty_cache()
+            m7, p7, c7, x7 = setup(B, precision="bf16")
+            for _ in range(3):
+                md.train_step(m7, x7, None, c7, p7, True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n7 = 10
+            for _ in range(n7):
+                md.train_step(m7, x7, None, c7, p7, True)
+            torch.cuda.synchronize(); d7 = time.perf_counter() - t0
+            extra["headline_shape_bf16_mixed"] = {"value": B * n7 / d7, "unit": "triplets/s", "ms_per_step": d7 / n7 * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate"}
         out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W)

@@ -36,7 +36,9 @@ typedef struct md2_config {
     double min_depth, max_depth, disparity_smoothness;   /* Params                            */
     double lr;            /* ADAM eta (1e-4, src/Monodepth.jl:125)                           */
     int32_t encoder_depth;/* ResidualNetwork(n): 18 (default when 0; src/Monodepth.jl:117) or 50    */
-    int32_t reserved;     /* 0                                                               */
+    int32_t precision;    /* 0: fp32 everywhere (parity mode, the reference's precision = f32, src/Monodepth.jl:72);
+                             1: bf16 mixed precision -- the MFMA operands of the 32-wide conv / weight-gradient tiles are rounded to
+                                bf16, accumulation, activations, master weights, BatchNorm, loss and ADAM stay fp32          */
 } md2_config;
 
 /* ---- handle ------------------------------------------------------------------------------- */

@@ -49,7 +49,7 @@ struct md2_handle {
     long n_int = 0, n_flux = 0;
     float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *WD = nullptr;
     double beta1p = 1.0, beta2p = 1.0;
-    ConvL stem; BNL stem_bn; Block blk[16]; int nblk = 8, depth = 18; int stages[5] = {64, 64, 128, 256, 512};
+    ConvL stem; BNL stem_bn; Block blk[16]; int nblk = 8, depth = 18, bf16 = 0; int stages[5] = {64, 64, 128, 256, 512};
     ConvL dc1[5], dc2[5], head[4], squeeze, pose[3];
     std::vector<ConvL*> convs; std::vector<BNL*> bns;
     char* arena = nullptr; size_t arena_off = 0;
@@ -250,7 +250,8 @@ static ConvArgs conv_args(const View& x, const float* w, const View& y, int KH, 
     a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = y.H; a.Wl = y.W; a.kh0 = 0; a.khs = 1; a.nkh = KH; a.kw0 = 0; a.kws = 1; a.nkw = KH;
     return a;
 }
-static void run_igemm(md2_handle* h, const ConvArgs& a) {
+static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
+    ConvArgs a = a_in; a.bf16 = h->bf16;
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W);
     h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
@@ -286,7 +287,7 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     a.x = x.p; a.x_bs = x.bs; a.x_ps = x.ps; a.H = x.H; a.W = x.W; a.Cin = x.C;
     a.dy = dy.p; a.dy_bs = dy.bs; a.dy_ps = dy.ps; a.Ho = dy.H; a.Wo = dy.W; a.Cout = dy.C;
     a.dw = h->G + c.w; a.N = dy.N; a.KH = c.kind == 1 ? 1 : c.k; a.KW = a.KH; a.stride = c.kind == 1 ? 1 : c.stride; a.pad = c.kind == 1 ? 0 : (padmode == PAD_REFLECT ? 1 : c.pad); a.padmode = padmode;
-    a.M = dy.N * dy.H * dy.W; a.db = c.bias ? h->G + c.b : nullptr;
+    a.M = dy.N * dy.H * dy.W; a.db = c.bias ? h->G + c.b : nullptr; a.bf16 = h->bf16;
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode);
     hipStream_t st = wgrad_stream(h);
@@ -563,12 +564,13 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
         g_create_err = "md2_create: need batch >= 1, channels in {1,3}, height/width multiples of 32 and >= 64"; return 2;
     }
     if (cfg->encoder_depth != 0 && cfg->encoder_depth != 18 && cfg->encoder_depth != 50) { g_create_err = "md2_create: encoder_depth must be 18 (or 0) or 50"; return 2; }
+    if (cfg->precision != 0 && cfg->precision != 1) { g_create_err = "md2_create: precision must be 0 (fp32) or 1 (bf16 mixed precision)"; return 2; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "md2_create: no HIP device (libmd2hip needs an MI355X; there is no CPU fallback)"; return 3; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "md2_create: hipSetDevice failed"; return 3; }
     md2_handle* h = new md2_handle();
     h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width;
-    h->depth = cfg->encoder_depth == 50 ? 50 : 18;
+    h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision == 1;
     build_layers(h);
     plan_buffers(h);                        // sizing pass
     const size_t need = h->arena_off + 4096;

@@ -64,6 +64,9 @@ struct ConvArgs {
     // optional training-BatchNorm statistics of the OUTPUT (no bias / activation): stats[slot][0..Cout) += sum_pixels y, stats[slot][Cout..2Cout) += sum y^2,
     // slot = blockIdx.x % BN_STAT_SLOTS spreads the double atomics; fused into the 32x32 tiles' epilogue, a colstats launch (slot 0) otherwise
     double* stats;
+    // bf16 mixed precision (md2_config.precision = 1): the operands of the 32x32 MFMA tiles are rounded to bf16 on their way from LDS to the
+    // matrix pipe (v_cvt_pk_bf16_f32 + v_mfma_f32_32x32x16_bf16); accumulation, storage, weights and every other kernel stay fp32
+    int bf16;
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only
 #endif
@@ -78,6 +81,7 @@ struct WgradArgs {
     float* dw;
     int N, KH, KW, stride, pad, padmode;
     int M;
+    int bf16;                     // same switch for the all-taps weight gradient (conv3x3_wgrad_taps32_kernel)
     float* db;                    // optional bias gradient: db[co] += sum_{n,oh,ow} dy (fused into the all-taps kernels, a colsum launch otherwise)
 #ifdef MD2_ABLATE
     int ablate;

@@ -14,7 +14,7 @@ struct MD2Config
     batch::Int32; channels::Int32; height::Int32; width::Int32
     automasking::Int32; device::Int32
     min_depth::Float64; max_depth::Float64; disparity_smoothness::Float64; lr::Float64
-    encoder_depth::Int32; reserved::Int32        # ResidualNetwork(18 | 50)
+    encoder_depth::Int32; precision::Int32       # ResidualNetwork(18 | 50); 0 = f32, 1 = bf16 MFMA operands
 end
 
 mutable struct Handle
@@ -32,8 +32,8 @@ dptr(::Nothing) = C_NULL
 
 # Params (src/Monodepth.jl:32-42) -> handle
 function Handle(; batch, channels, width, height, automasking=false, device=0,
-                min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, lr=1e-4, encoder_depth=18)
-    cfg = Ref(MD2Config(batch, channels, height, width, automasking, device, min_depth, max_depth, disparity_smoothness, lr, encoder_depth, 0))
+                min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, lr=1e-4, encoder_depth=18, precision=0)
+    cfg = Ref(MD2Config(batch, channels, height, width, automasking, device, min_depth, max_depth, disparity_smoothness, lr, encoder_depth, precision))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:md2_create, LIB), Int32, (Ref{MD2Config}, Ref{Ptr{Cvoid}}), cfg, out)
     check(nothing, rc, "md2_create")

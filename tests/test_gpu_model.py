@@ -37,13 +37,13 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def make(N, C, H, W, automask=False, pseed=1, lr=1e-4, depth=18):
+def make(N, C, H, W, automask=False, pseed=1, lr=1e-4, depth=18, precision="f32"):
     m = md()
     K, iK = syn.depth10k_intrinsics(W, H)
     params = m.Params(target_size=(W, H), batch_size=N, automasking=automask)
     cache = m.TrainCache(m.SSIM(), m.Backproject(W, H), m.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
     enc = m.ResidualNetwork(depth, in_channels=C)
-    model = m.Model(enc, m.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), m.PoseDecoder(enc.stages[-1]), lr=lr)
+    model = m.Model(enc, m.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), m.PoseDecoder(enc.stages[-1]), lr=lr, precision=precision)
     theta = syn.init_params(C, seed=pseed, randomize_affine=True, depth=depth)
     model.load_params(theta)
     return model, params, cache, theta, K, iK
@@ -373,6 +373,32 @@ def test_config4_resnet50_640x192_vs_oracle():
     gh = model.grads(); go = net.get_grads()
     assert np.isfinite(gh).all()
     assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+
+
+@pytest.mark.parametrize("cfgd", [(2, 1, 128, 416, 18, False), (1, 3, 320, 1024, 18, True)])
+def test_bf16_mixed_precision_tracks_the_fp32_oracle(cfgd):
+    """BASELINE config #5's "bf16 mixed precision": only the MFMA operands are bf16 (8 mantissa bits), accumulation / activations /
+    master weights / BatchNorm / loss / ADAM stay fp32.  Not a parity mode: the loss must stay within 2 % of the fp32 oracle and the
+    gradient must point the same way (cosine > 0.95; measured 0.97); the fp32 mode on the same handle class stays at 1e-4 (the other tests)."""
+    N, C, H, W, depth, automask = cfgd
+    model, params, cache, theta, K, iK = make(N, C, H, W, automask=automask, pseed=61, depth=depth, precision="bf16")
+    x = syn.synthetic_triplets(N, C, H, W, seed=62); xd = dev(x)
+    al = md().automasking_loss(md().SSIM(), xd, xd[:, 1].contiguous(), [1, 3]) if automask else None
+    loss = md().train_step(model, xd, al, cache, params, do_update=False)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK, automasking=automask)
+    net = oracle.OracleNet(C, depth=depth); net.set_params(theta)
+    lo = net.train_loss(x, cfg, oracle.automasking_loss(x, cfg) if automask else None, True)
+    assert abs(float(loss) - lo) / lo < 2e-2
+    gh = model.grads(); go = net.get_grads()
+    assert np.isfinite(gh).all()
+    # with the automask most pixels carry no gradient and the few mask / arg-min decisions that flip under the bf16 perturbation of the
+    # disparities dominate the difference (measured 0.81), without it the directions agree to 0.97
+    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > (0.7 if automask else 0.95)
+    # and it trains: a few ADAM steps reduce the loss
+    l0 = float(md().train_step(model, xd, al, cache, params, do_update=True))
+    for _ in range(8):
+        l1 = float(md().train_step(model, xd, al, cache, params, do_update=True))
+    assert np.isfinite(l1) and l1 < l0
 
 
 def test_backward_requires_a_training_forward():
