@@ -1,5 +1,5 @@
 """Per-layer timing of the conv kernels inside a real training step (HIP events per launch).
-usage: layer_profile.py B out.csv [depth C H W]"""
+usage: layer_profile.py B out.csv [depth C H W [f32|bf16]]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, md2amd
@@ -12,7 +12,7 @@ K, iK = syn.depth10k_intrinsics(W, H)
 params = md.Params(target_size=(W, H), batch_size=B, automasking=False)
 cache = md.TrainCache(md.SSIM(), md.Backproject(W, H), md.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
 enc = md.ResidualNetwork(depth, in_channels=C)
-model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]))
+model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), precision=(sys.argv[7] if len(sys.argv) > 7 else "f32"))
 model.load_params(syn.init_params(C, seed=42, depth=depth))
 x = torch.from_numpy(np.concatenate([syn.synthetic_triplets(min(B, 4), C, H, W)] * ((B + 3) // 4))[:B].copy()).cuda()
 for _ in range(3):
