@@ -39,7 +39,29 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const f32x4& lo, const f32x4& hi) {
     for (int i = 0; i < 4; ++i) { r[i] = (__bf16)lo[i]; r[4 + i] = (__bf16)hi[i]; }
     return r;
 }
-template <int BM, int BN, int WP, int WC, int MF, int NT, bool BF = false>
+// x = hi + lo + lo2 with three bf16 terms (8 + 8 + 8 mantissa bits): the products hi*hi, hi*lo, lo*hi, lo*lo, hi*lo2, lo2*hi reproduce the
+// fp32 product to ~2^-23 relative (the dropped terms are 2^-24 and below), accumulated in fp32 by the MFMA like the fp32 path
+struct Bf3 { bf16x8 hi, lo, lo2; };
+__device__ __forceinline__ Bf3 split_bf16x3(const f32x4& a, const f32x4& b) {
+    Bf3 r; float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i]; const float r1 = v[i] - (float)h;
+        const __bf16 l = (__bf16)r1; const float r2 = r1 - (float)l;
+        r.hi[i] = h; r.lo[i] = l; r.lo2[i] = (__bf16)r2;
+    }
+    return r;
+}
+__device__ __forceinline__ f32x16 mfma_bf16x3(const Bf3& a, const Bf3& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo2, b.hi, c, 0, 0, 0);         // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo2, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+// BF: 0 fp32 MFMA, 1 bf16 operands (mixed precision), 2 bf16x3 operand split (fp32-equivalent products on the bf16 matrix pipe)
+template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __restrict__ smem, const int block_x, const int nblocks_x) {
     constexpr int TP = BM / WP / MF, TC = BN / WC / MF;       // MFMA tiles per wave (pixels x channels)
     constexpr int NV = MF == 32 ? 4 : 1;                       // float4 groups per accumulator tile
@@ -153,7 +175,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             for (int jj = 0; jj < NJ; ++jj) o.x[j][jj] = *reinterpret_cast<const f32x4*>(smem + so + (wp * (BM / WP) + j * MF + lrow) * LDK + 8 * jj + lk4);
     };
     auto mfmas = [&](const Ops& o) {
-        if constexpr (BF && MF == 32) {            // one 32x32x16 bf16 MFMA per tile pair instead of eight 32x32x2 fp32 ones: lane half h contracts
+        if constexpr (BF == 2 && MF == 32) {
+            Bf3 ws[TC], xs[TP];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) ws[i] = split_bf16x3(o.w[i][0], o.w[i][1]);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) xs[j] = split_bf16x3(o.x[j][0], o.x[j][1]);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) acc[i][j] = mfma_bf16x3(ws[i], xs[j], acc[i][j]);
+            return;
+        }
+        if constexpr (BF == 1 && MF == 32) {       // one 32x32x16 bf16 MFMA per tile pair instead of eight 32x32x2 fp32 ones: lane half h contracts
             bf16x8 wv[TC], xv[TP];                 // k in {4h..4h+3} + {8+4h..8+4h+3}, the same set for both operands
 #pragma unroll
             for (int i = 0; i < TC; ++i) wv[i] = to_bf16x8(o.w[i][0], o.w[i][1]);
@@ -297,7 +331,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     }
 }
 
-template <int BM, int BN, int WP, int WC, int MF, int NT, bool BF = false>
+template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * LDK];
     conv_igemm_body<BM, BN, WP, WC, MF, NT, BF>(a, smem, blockIdx.x, gridDim.x);
@@ -306,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // picks its class from its index and runs that class's statically-unrolled tap loop.  As four launches every class paid its own
 // under-filled tail (312 blocks x 32..128 K-steps on 256 CUs at B=32; 40 blocks at B=4).
 struct ConvClasses { ConvArgs c[4]; int first[5]; };      // blocks [first[i], first[i+1]) belong to class i
-template <int BM, int BN, int WP, int WC, int MF, bool BF = false>
+template <int BM, int BN, int WP, int WC, int MF, int BF = 0>
 __global__ __launch_bounds__(256) void conv_igemm_classes_kernel(ConvClasses k) {
     __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * LDK];
     const int b = blockIdx.x;
@@ -328,10 +362,10 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
     const dim3 g(grid, a.ksplit);
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
-        case 9: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, MF == 32>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), g, dim3(256), 0, s, a); break;
-        case 4: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4, MF == 32>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), g, dim3(256), 0, s, a); break;
-        case 2: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2, MF == 32>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), g, dim3(256), 0, s, a); break;
-        case 1: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, MF == 32>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), g, dim3(256), 0, s, a); break;
+        case 9: if (MF == 32 && a.bf16 == 1) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else if (MF == 32 && a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, (MF == 32 ? 2 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), g, dim3(256), 0, s, a); break;
+        case 4: if (MF == 32 && a.bf16 == 1) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else if (MF == 32 && a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4, (MF == 32 ? 2 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), g, dim3(256), 0, s, a); break;
+        case 2: if (MF == 32 && a.bf16 == 1) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else if (MF == 32 && a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2, (MF == 32 ? 2 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), g, dim3(256), 0, s, a); break;
+        case 1: if (MF == 32 && a.bf16 == 1) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else if (MF == 32 && a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, (MF == 32 ? 2 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), g, dim3(256), 0, s, a); break;
         default: fprintf(stderr, "md2: conv_igemm: unsupported tap count %d\n", a.nkh * a.nkw); abort();
     }
     if (a_in.stats && !a.stats) {                  // not fused (16-wide tiles, split-K): one more pass over the output
@@ -521,7 +555,8 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
     k.first[0] = 0;
     for (int i = 0; i < 4; ++i) k.first[i + 1] = k.first[i] + (i < n ? ((k.c[i].M + BM - 1) / BM) * (k.c[i].Cout / 64) : 0);
     for (int i = n; i < 4; ++i) k.c[i] = k.c[0];
-    if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, true>), dim3(k.first[4]), dim3(256), 0, s, k);
+    if (k.c[0].bf16 == 1) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+    else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2>), dim3(k.first[4]), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32>), dim3(k.first[4]), dim3(256), 0, s, k);
 }
 static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
@@ -976,7 +1011,7 @@ static void launch_wgrad_patch(const WgradArgs& a, hipStream_t s) {
 // registers, 3 waves per SIMD -- reach 86 and 78 TFLOP/s.)
 // ------------------------------------------------------------------------------------------------------------
 constexpr int WT_MAXW = 30;                            // tile columns; the patch is TW + 2 <= 32 columns = one column per 8 threads
-template <bool BF>
+template <int BF>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs a, int TW, int tiles_x, int tiles_y, int total_tiles, int ci_groups) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     float* Ys = psm;                               // [4*TW][32]
@@ -1052,8 +1087,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
     // ---- wave w contracts tile row w: TW/2 k-steps of 2 pixels, 9 taps each
         const float* yrow = Ys + (wave * TW + lp) * 32 + lcol;
         const float* xrow = Xs + (wave * PW + lp) * 32 + lcol;
-        if constexpr (BF) {
-            // bf16 mixed precision: 16 pixels per MFMA (v_mfma_f32_32x32x16_bf16); lane half lp takes pixels 2i + lp of the chunk (even / odd
+        if constexpr (BF != 0) {
+            // bf16 operands (mixed precision, or the 3-term split): 16 pixels per MFMA (v_mfma_f32_32x32x16_bf16); lane half lp takes pixels 2i + lp of the chunk (even / odd
             // pixels sit on disjoint bank halves); pixels past the tile row are masked in the dy operand
             const float* y0 = Ys + (wave * TW) * 32 + lcol;
             const float* x0 = Xs + (wave * PW) * 32 + lcol;
@@ -1066,7 +1101,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
                     bsum += v;
                     if (i < 4) alo[i] = v; else ahi[i - 4] = v;
                 }
-                const bf16x8 av = to_bf16x8(alo, ahi);
+                Bf3 a3; bf16x8 av;
+                if constexpr (BF == 2) a3 = split_bf16x3(alo, ahi); else av = to_bf16x8(alo, ahi);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     f32x4 blo, bhi;
@@ -1076,7 +1112,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
                         const float v = x0[((t / 3) * PW + px) * 32];
                         if (i < 4) blo[i] = v; else bhi[i - 4] = v;
                     }
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, to_bf16x8(blo, bhi), acc[t], 0, 0, 0);
+                    if constexpr (BF == 2) acc[t] = mfma_bf16x3(a3, split_bf16x3(blo, bhi), acc[t]);
+                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, to_bf16x8(blo, bhi), acc[t], 0, 0, 0);
                 }
             }
             continue;
@@ -1133,16 +1170,18 @@ static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
     const size_t lds = (size_t)std::max((4 * WT_MAXW + 6 * (WT_MAXW + 2)) * 32, 9 * 16 * 64) * sizeof(float);
     static int per_cu = 0;
     if (!per_cu) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<false>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<0>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
         per_cu = std::min(per_cu, 2);
         if (getenv("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("MD2_TAPS_PER_CU"))));
     }
     const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
     const int gx = std::max(1, std::min(total, 256 * per_cu / groups));                    // persistent: the co-resident blocks, shared by the weight tiles
-    if (a.bf16) hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<true>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
-    else hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<false>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
+    if (a.bf16 == 2) { static bool once = false; if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+                       hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<2>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups); }
+    else if (a.bf16) hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<1>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
+    else hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<0>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
 }
 
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
