@@ -38,9 +38,7 @@ typedef struct md2_config {
     int32_t encoder_depth;/* ResidualNetwork(n): 18 (default when 0; src/Monodepth.jl:117) or 50    */
     int32_t precision;    /* 0: fp32 everywhere (parity mode, the reference's precision = f32, src/Monodepth.jl:72);
                              1: bf16 mixed precision -- the MFMA operands of the 32-wide conv / weight-gradient tiles are rounded to
-                                bf16, accumulation, activations, master weights, BatchNorm, loss and ADAM stay fp32;
-                             2: bf16x3 -- the same operands split into three bf16 terms, six bf16 MFMAs per product: fp32-equivalent
-                                arithmetic on the bf16 matrix pipe (experimental; meets the fp32 parity bar)                 */
+                                bf16, accumulation, activations, master weights, BatchNorm, loss and ADAM stay fp32          */
 } md2_config;
 
 /* ---- handle ------------------------------------------------------------------------------- */

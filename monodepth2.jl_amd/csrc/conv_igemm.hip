@@ -39,28 +39,7 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const f32x4& lo, const f32x4& hi) {
     for (int i = 0; i < 4; ++i) { r[i] = (__bf16)lo[i]; r[4 + i] = (__bf16)hi[i]; }
     return r;
 }
-// x = hi + lo + lo2 with three bf16 terms (8 + 8 + 8 mantissa bits): the products hi*hi, hi*lo, lo*hi, lo*lo, hi*lo2, lo2*hi reproduce the
-// fp32 product to ~2^-23 relative (the dropped terms are 2^-24 and below), accumulated in fp32 by the MFMA like the fp32 path
-struct Bf3 { bf16x8 hi, lo, lo2; };
-__device__ __forceinline__ Bf3 split_bf16x3(const f32x4& a, const f32x4& b) {
-    Bf3 r; float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)v[i]; const float r1 = v[i] - (float)h;
-        const __bf16 l = (__bf16)r1; const float r2 = r1 - (float)l;
-        r.hi[i] = h; r.lo[i] = l; r.lo2[i] = (__bf16)r2;
-    }
-    return r;
-}
-__device__ __forceinline__ f32x16 mfma_bf16x3(const Bf3& a, const Bf3& b, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo2, b.hi, c, 0, 0, 0);         // smallest terms first
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo2, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.lo, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
-}
-// BF: 0 fp32 MFMA, 1 bf16 operands (mixed precision), 2 bf16x3 operand split (fp32-equivalent products on the bf16 matrix pipe)
+// BF: 0 fp32 MFMA, 1 bf16 operands (mixed precision)
 template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __restrict__ smem, const int block_x, const int nblocks_x) {
     constexpr int TP = BM / WP / MF, TC = BN / WC / MF;       // MFMA tiles per wave (pixels x channels)
@@ -68,7 +47,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     constexpr int A_LD = BM * 4 / 256;
     constexpr int B_LD = (BN * 4 + 255) / 256;
     static_assert(WP * WC == 4 && TP >= 1 && TC >= 1 && A_LD >= 1, "bad tile");
-    constexpr int XS = BM * LDK, STAGE = (BM + BN) * LDK;      // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
+    // LDS row of a tile: fp32 -> 16 k-values + 4 pad floats; bf16 mode -> the row is converted ONCE on its way into LDS: 16 bf16 (32 B)
+    // padded to a 48-B stride that keeps 16 consecutive rows' 16-B reads on distinct banks
+    constexpr int ROWF = BF == 0 ? LDK : 12;
+    constexpr int XS = BM * ROWF, STAGE = (BM + BN) * ROWF;    // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave % WP, wc = wave / WP;
@@ -151,7 +133,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const float4*>(wb + (b_row[j] + b_tap[t] + (unsigned)(ci0 * 4)));
     };
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    auto put_bf = [&](float* row, const float4& v) {        // 4 k-values (chunk q) of one row -> 4 bf16
+        bf16x4 h; h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(row + q * 2) = h;
+    };
     auto lstore = [&](int so) {                 // so: float offset of the stage
+        if constexpr (BF != 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) put_bf(smem + so + ((tid + 256 * j) >> 2) * ROWF, ra[j]);
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) put_bf(smem + so + XS + (((tid + 256 * j) >> 2) & (BN - 1)) * ROWF, rb[j]);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4*>(smem + so + ((tid + 256 * j) >> 2) * LDK + q * 4) = ra[j];
 #pragma unroll
@@ -162,9 +156,25 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     //   32x32x2 (155 TF bare vs 140, full rate at one wave per SIMD): lane (row l&31, k-half l>>5), two ds_read_b128 per
     //            32-row tile cover k = 8*jj + 4*h .. +3; MFMA (jj,r) contracts k in {8jj + r, 8jj + 4 + r}
     constexpr int NJ = MF == 32 ? 2 : 1;
-    struct Ops { f32x4 w[TC][NJ], x[TP][NJ]; };
+    // bf16 mode: one ds_read_b128 per tile delivers this lane half's 8 k-values (k = 8h .. 8h+7) ready for the MFMA
+    constexpr int NPL = 1;
+    struct OpsF { f32x4 w[TC][NJ], x[TP][NJ]; };
+    struct OpsB { bf16x8 w[TC][NPL], x[TP][NPL]; };
+    using Ops = typename std::conditional<BF != 0, OpsB, OpsF>::type;
     const int lrow = lane & (MF - 1), lk4 = 4 * (lane / MF);
     auto read_ops = [&](int so, Ops& o) {
+        if constexpr (BF != 0) {
+            const int lh = 4 * (lane >> 5);        // float offset of this lane half's 16 bytes
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) o.w[i][pl] = *reinterpret_cast<const bf16x8*>(smem + so + XS + (wc * (BN / WC) + i * MF + lrow) * ROWF + 8 * pl + lh);
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) o.x[j][pl] = *reinterpret_cast<const bf16x8*>(smem + so + (wp * (BM / WP) + j * MF + lrow) * ROWF + 8 * pl + lh);
+            return;
+        } else {
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -173,32 +183,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         for (int j = 0; j < TP; ++j)
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) o.x[j][jj] = *reinterpret_cast<const f32x4*>(smem + so + (wp * (BM / WP) + j * MF + lrow) * LDK + 8 * jj + lk4);
+        }
     };
     auto mfmas = [&](const Ops& o) {
-        if constexpr (BF == 2 && MF == 32) {
-            Bf3 ws[TC], xs[TP];
-#pragma unroll
-            for (int i = 0; i < TC; ++i) ws[i] = split_bf16x3(o.w[i][0], o.w[i][1]);
-#pragma unroll
-            for (int j = 0; j < TP; ++j) xs[j] = split_bf16x3(o.x[j][0], o.x[j][1]);
+        if constexpr (BF == 1) {                   // one 32x32x16 bf16 MFMA per tile pair instead of eight 32x32x2 fp32 ones
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int j = 0; j < TP; ++j) acc[i][j] = mfma_bf16x3(ws[i], xs[j], acc[i][j]);
+                for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[i][0], o.x[j][0], acc[i][j], 0, 0, 0);
             return;
-        }
-        if constexpr (BF == 1 && MF == 32) {       // one 32x32x16 bf16 MFMA per tile pair instead of eight 32x32x2 fp32 ones: lane half h contracts
-            bf16x8 wv[TC], xv[TP];                 // k in {4h..4h+3} + {8+4h..8+4h+3}, the same set for both operands
-#pragma unroll
-            for (int i = 0; i < TC; ++i) wv[i] = to_bf16x8(o.w[i][0], o.w[i][1]);
-#pragma unroll
-            for (int j = 0; j < TP; ++j) xv[j] = to_bf16x8(o.x[j][0], o.x[j][1]);
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i], xv[j], acc[i][j], 0, 0, 0);
-            return;
-        }
+        } else {
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
@@ -210,6 +204,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                         if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.w[i][jj][r], o.x[j][jj][r], acc[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w[i][jj][r], o.x[j][jj][r], acc[i][j], 0, 0, 0);
                     }
+        }
     };
 
 #ifdef MD2_ABLATE
@@ -333,7 +328,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 
 template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * LDK];
+    __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * (BF == 0 ? LDK : 12)];
     conv_igemm_body<BM, BN, WP, WC, MF, NT, BF>(a, smem, blockIdx.x, gridDim.x);
 }
 // The residue classes of a stride-2 input gradient (1, 2, 2 and 4 taps, a quarter of the output pixels each) in ONE launch: a block
@@ -342,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 struct ConvClasses { ConvArgs c[4]; int first[5]; };      // blocks [first[i], first[i+1]) belong to class i
 template <int BM, int BN, int WP, int WC, int MF, int BF = 0>
 __global__ __launch_bounds__(256) void conv_igemm_classes_kernel(ConvClasses k) {
-    __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * LDK];
+    __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * (BF == 0 ? LDK : 12)];
     const int b = blockIdx.x;
     const int cls = b < k.first[1] ? 0 : (b < k.first[2] ? 1 : (b < k.first[3] ? 2 : 3));
     const int bx = b - k.first[cls], nb = k.first[cls + 1] - k.first[cls];
@@ -362,10 +357,10 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
     const dim3 g(grid, a.ksplit);
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
-        case 9: if (MF == 32 && a.bf16 == 1) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else if (MF == 32 && a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, (MF == 32 ? 2 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), g, dim3(256), 0, s, a); break;
-        case 4: if (MF == 32 && a.bf16 == 1) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else if (MF == 32 && a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4, (MF == 32 ? 2 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), g, dim3(256), 0, s, a); break;
-        case 2: if (MF == 32 && a.bf16 == 1) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else if (MF == 32 && a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2, (MF == 32 ? 2 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), g, dim3(256), 0, s, a); break;
-        case 1: if (MF == 32 && a.bf16 == 1) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else if (MF == 32 && a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, (MF == 32 ? 2 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), g, dim3(256), 0, s, a); break;
+        case 9: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), g, dim3(256), 0, s, a); break;
+        case 4: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), g, dim3(256), 0, s, a); break;
+        case 2: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), g, dim3(256), 0, s, a); break;
+        case 1: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), g, dim3(256), 0, s, a); break;
         default: fprintf(stderr, "md2: conv_igemm: unsupported tap count %d\n", a.nkh * a.nkw); abort();
     }
     if (a_in.stats && !a.stats) {                  // not fused (16-wide tiles, split-K): one more pass over the output
@@ -555,8 +550,7 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
     k.first[0] = 0;
     for (int i = 0; i < 4; ++i) k.first[i + 1] = k.first[i] + (i < n ? ((k.c[i].M + BM - 1) / BM) * (k.c[i].Cout / 64) : 0);
     for (int i = n; i < 4; ++i) k.c[i] = k.c[0];
-    if (k.c[0].bf16 == 1) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
-    else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2>), dim3(k.first[4]), dim3(256), 0, s, k);
+    if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32>), dim3(k.first[4]), dim3(256), 0, s, k);
 }
 static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
@@ -1088,7 +1082,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
         const float* yrow = Ys + (wave * TW + lp) * 32 + lcol;
         const float* xrow = Xs + (wave * PW + lp) * 32 + lcol;
         if constexpr (BF != 0) {
-            // bf16 operands (mixed precision, or the 3-term split): 16 pixels per MFMA (v_mfma_f32_32x32x16_bf16); lane half lp takes pixels 2i + lp of the chunk (even / odd
+            // bf16 operands (mixed precision): 16 pixels per MFMA (v_mfma_f32_32x32x16_bf16); lane half lp takes pixels 2i + lp of the chunk (even / odd
             // pixels sit on disjoint bank halves); pixels past the tile row are masked in the dy operand
             const float* y0 = Ys + (wave * TW) * 32 + lcol;
             const float* x0 = Xs + (wave * PW) * 32 + lcol;
@@ -1101,8 +1095,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
                     bsum += v;
                     if (i < 4) alo[i] = v; else ahi[i - 4] = v;
                 }
-                Bf3 a3; bf16x8 av;
-                if constexpr (BF == 2) a3 = split_bf16x3(alo, ahi); else av = to_bf16x8(alo, ahi);
+                const bf16x8 av = to_bf16x8(alo, ahi);
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     f32x4 blo, bhi;
@@ -1112,8 +1105,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
                         const float v = x0[((t / 3) * PW + px) * 32];
                         if (i < 4) blo[i] = v; else bhi[i - 4] = v;
                     }
-                    if constexpr (BF == 2) acc[t] = mfma_bf16x3(a3, split_bf16x3(blo, bhi), acc[t]);
-                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, to_bf16x8(blo, bhi), acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, to_bf16x8(blo, bhi), acc[t], 0, 0, 0);
                 }
             }
             continue;
@@ -1178,9 +1170,7 @@ static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
     }
     const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
     const int gx = std::max(1, std::min(total, 256 * per_cu / groups));                    // persistent: the co-resident blocks, shared by the weight tiles
-    if (a.bf16 == 2) { static bool once = false; if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
-                       hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<2>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups); }
-    else if (a.bf16) hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<1>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
+    if (a.bf16) hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<1>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
     else hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<0>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
 }
 

@@ -564,13 +564,13 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
         g_create_err = "md2_create: need batch >= 1, channels in {1,3}, height/width multiples of 32 and >= 64"; return 2;
     }
     if (cfg->encoder_depth != 0 && cfg->encoder_depth != 18 && cfg->encoder_depth != 50) { g_create_err = "md2_create: encoder_depth must be 18 (or 0) or 50"; return 2; }
-    if (cfg->precision < 0 || cfg->precision > 2) { g_create_err = "md2_create: precision must be 0 (fp32), 1 (bf16 mixed precision) or 2 (bf16x3 operand split)"; return 2; }
+    if (cfg->precision != 0 && cfg->precision != 1) { g_create_err = "md2_create: precision must be 0 (fp32) or 1 (bf16 mixed precision)"; return 2; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "md2_create: no HIP device (libmd2hip needs an MI355X; there is no CPU fallback)"; return 3; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "md2_create: hipSetDevice failed"; return 3; }
     md2_handle* h = new md2_handle();
     h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width;
-    h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = (cfg->precision == 1 || cfg->precision == 2) ? cfg->precision : 0;
+    h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision == 1;
     build_layers(h);
     plan_buffers(h);                        // sizing pass
     const size_t need = h->arena_off + 4096;

@@ -247,9 +247,8 @@ class Model:
         self.encoder, self.depth_decoder, self.pose_decoder = encoder, depth_decoder, pose_decoder
         if tuple(depth_decoder.encoder_channels) != tuple(encoder.stages) or pose_decoder.encoder_out_channels != encoder.stages[-1]:
             raise ValueError("decoder channels do not match the encoder's stages")
-        if precision not in ("f32", "bf16", "bf16x3"):
-            raise ValueError("precision must be 'f32' (the reference's), 'bf16' (mixed: bf16 MFMA operands, fp32 everything else) or "
-                             "'bf16x3' (fp32 operands split into three bf16 terms, six bf16 MFMAs per product: fp32-equivalent)")
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' (the reference's) or 'bf16' (mixed: bf16 MFMA operands, fp32 everything else)")
         self.lr, self.precision = lr, precision
         self._h = None
         self._shape = None
@@ -272,7 +271,7 @@ class Model:
         saved = self.params() if self._h is not None else self._params_host
         self.close()
         cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr,
-                             self.encoder.depth, {"f32": 0, "bf16": 1, "bf16x3": 2}[self.precision])
+                             self.encoder.depth, 1 if self.precision == "bf16" else 0)
         h = C.c_void_p()
         _check(_lib.lib().md2_create(C.byref(cfg), C.byref(h)), None, "md2_create")
         self._h, self._shape, self._cfg_extra = h, key, extra

@@ -401,28 +401,6 @@ def test_bf16_mixed_precision_tracks_the_fp32_oracle(cfgd):
     assert np.isfinite(l1) and l1 < l0
 
 
-@pytest.mark.parametrize("cfgd", [(2, 1, 128, 416, 18), (1, 3, 96, 160, 50)])
-def test_bf16x3_operand_split_meets_the_fp32_parity_bar(cfgd):
-    """precision="bf16x3": every fp32 MFMA operand is split into three bf16 terms (8+8+8 mantissa bits) and each product is six bf16 MFMAs
-    (hi*hi, hi*lo, lo*hi, lo*lo, hi*lo2, lo2*hi; dropped terms <= 2^-24) accumulated in fp32 -- fp32-equivalent arithmetic on the bf16 matrix
-    pipe.  It must meet the SAME bar as the fp32 mode: forward outputs and loss within 1e-4 of the oracle, gradient cosine > 0.999."""
-    N, C, H, W, depth = cfgd
-    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=71, depth=depth, precision="bf16x3")
-    x = syn.synthetic_triplets(N, C, H, W, seed=72); xd = dev(x)
-    net = oracle.OracleNet(C, depth=depth); net.set_params(theta)
-    cfg = oracle.make_cfg(N, C, H, W, K, iK)
-    ds, poses = model(xd, [1, 3], 2)
-    do, rvo, tvo = net.model_forward(x, cfg)
-    for i in range(4):
-        assert rel(host(ds[i]), do[i]) < 1e-4
-    loss = md().train_step(model, xd, None, cache, params, do_update=False)
-    lo = net.train_loss(x, cfg, None, True)
-    assert abs(float(loss) - lo) / lo < 1e-4
-    gh = model.grads(); go = net.get_grads()
-    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
-    assert abs(np.linalg.norm(gh) - np.linalg.norm(go)) / np.linalg.norm(go) < 2e-2
-
-
 def test_backward_requires_a_training_forward():
     """md2_backward after a plain model forward (which overwrites the activations) must fail loudly, not return stale gradients."""
     N, C, H, W = 1, 1, 64, 96
