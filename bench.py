@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
+MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (--precision bf16 prices against this one)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 # HBM bytes per launch from the rocprofv3 PMC passes of THIS workload (B=32, C=1, 416x128), profiles/r01_pmc_hbm_traffic.md:
 # separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units, FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE exact.
@@ -137,22 +138,23 @@ def main():
         md.profile(model, False)
         md.set_two_streams(model, True)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
-                           "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                           "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH["conv_igemm"] if (B, C, H, W) == (32, 1, 128, 416) else None,
+                           "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
+                           "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH["conv_igemm"] if (B, C, H, W, args.depth, args.precision) == (32, 1, 128, 416, 18, "f32") else None,
                            "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1),
                            "timing": "HIP events per launch on the launch stream, 3 steps with the second (weight-gradient) stream disabled; `value` is measured with it enabled"}
         extra = {"frames_per_s": 3.0 * value}         # one triplet = 3 frames through the encoder
         if wg["ms"] > 0:
             a = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
-            extra["roofline_conv_wgrad"] = {"bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TFLOPS, "ms_per_step": wg["ms"] / 3}
+            extra["roofline_conv_wgrad"] = {"bound": "mfma", "achieved": a, "peak": peak_tf, "unit": "TFLOP/s", "frac": a / peak_tf, "ms_per_step": wg["ms"] / 3}
         for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_bwd", lb)):
             if p["ms"] > 0:
                 a = p["bytes"] / (p["ms"] * 1e-3) / 1e9
                 extra[nm] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "ms_per_step": p["ms"] / 3,
                              "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1),
-                             "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH[nm[len("roofline_"):]] if (B, C, H, W) == (32, 1, 128, 416) else None,
+                             "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH[nm[len("roofline_"):]] if (B, C, H, W, args.depth, args.precision) == (32, 1, 128, 416, 18, "f32") else None,
                              "note": "instruction-bound, not HBM-bound: 541 (fwd) / 1490 (bwd) VALU lane-instructions per pixel and scale (rocprofv3 SQ_INSTS_VALU) = 48 % / 37 % of the VALU issue peak (DESIGN.md section 4)"}
         if world == 1 and not args.no_extra and B != 4:
             # BASELINE.json configs[1]: batch = 4 on one MI355X

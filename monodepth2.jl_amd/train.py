@@ -15,11 +15,11 @@ from . import parallel as par
 from . import synthetic as syn
 
 
-def build_model(in_channels, lr=1e-4, seed=42):
-    """src/Monodepth.jl:117-125 — ResNet-18 trunk + depth decoder (levels 2:5) + pose decoder, Glorot weights."""
-    enc = md.ResidualNetwork(18, in_channels=in_channels)
-    model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), lr=lr)
-    model.load_params(syn.init_params(in_channels, seed=seed))
+def build_model(in_channels, lr=1e-4, seed=42, depth=18, precision="f32"):
+    """src/Monodepth.jl:117-125 — ResNet trunk + depth decoder (levels 2:5) + pose decoder, Glorot weights."""
+    enc = md.ResidualNetwork(depth, in_channels=in_channels)
+    model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), lr=lr, precision=precision)
+    model.load_params(syn.init_params(in_channels, seed=seed, depth=depth))
     return model
 
 
