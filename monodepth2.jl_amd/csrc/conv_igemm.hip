@@ -608,7 +608,8 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
         static const int mid = getenv("MD2_IGEMM_SPLIT_MID") ? atoi(getenv("MD2_IGEMM_SPLIT_MID")) : 256;
         static const int long_k = getenv("MD2_IGEMM_SPLIT_KSTEPS") ? atoi(getenv("MD2_IGEMM_SPLIT_KSTEPS")) : 256;
         const bool few = tiles64 < 100 || (tiles64 < mid && (long)cpt * a.nkh * a.nkw >= long_k);
-        if (few && cpt >= 4 && want > 0) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
+        // (a serial K loop of fewer than 64 steps -- the 1x1 convolutions -- is cheaper than the fill + atomics + bias/activation passes of a split)
+        if (few && cpt >= 4 && (long)cpt * a.nkh * a.nkw >= 64 && want > 0) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
     }
     View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
     const float* bias2 = nullptr; int act2 = ACT_NONE;
