@@ -42,6 +42,8 @@ typedef struct md2_config {
 } md2_config;
 
 /* ---- handle ------------------------------------------------------------------------------- */
+/* height / width: multiples of 32 and >= 64 for the network; multiples of 8 and >= 16 give a LOSS-ONLY handle (md2_loss_fwd_bwd, md2_simple_depth_loss,
+ * md2_automasking_loss work, the model entry points return an error).  Shape limits of the kernels are checked here, never by aborting in a step. */
 int32_t md2_create(const md2_config* cfg, md2_handle** out);
 int32_t md2_destroy(md2_handle* h);
 const char* md2_last_error(md2_handle* h);          /* h may be NULL: error of the last failed md2_create */
@@ -73,17 +75,42 @@ int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, fl
 int32_t md2_backward(md2_handle* h);
 /* ---- Flux.Optimise.update!(ADAM, theta, grads), src/Monodepth.jl:170; grads scaled by grad_scale first */
 int32_t md2_adam_step(md2_handle* h, float grad_scale);
+/* ADAM's eta (ADAM(1e-4), src/Monodepth.jl:125) can be changed between steps */
+int32_t md2_set_lr(md2_handle* h, double lr);
 /* ---- one whole step of the loop body src/Monodepth.jl:156-176: fwd + bwd (+ ADAM if do_update) -- */
 int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, float* loss, int32_t do_update);
 /* eval_disparity(m, x), src/model.jl:28: n single frames x [n][C][H][W] (n <= batch) -> the 4 disparities [n][1][h][w].
- * BatchNorm on batch statistics (train mode, as in the reference's saved checkpoints). */
+ * BatchNorm follows the handle's mode (md2_set_testmode): batch statistics under trainmode! (default), tracked statistics under testmode!. */
 int32_t md2_eval_disparity(md2_handle* h, const float* x, int32_t n, float* disp0, float* disp1, float* disp2, float* disp3);
+/* Flux.testmode!(model) / trainmode!(model) (src/Monodepth.jl:126,209,237): on = 1 makes every BatchNorm normalise with its tracked running mean /
+ * variance (momentum 0.1, updated by every train-mode forward pass like Flux's `_track_stats!`); md2_train_loss needs train mode. */
+int32_t md2_set_testmode(md2_handle* h, int32_t on);
+/* The BatchNorm running statistics (Flux BatchNorm.mu / .sigma2, part of what `@save model_host` keeps, src/Monodepth.jl:191-194): for every BatchNorm in
+ * parameter order, mean[c] then variance[c]. */
+int64_t md2_bn_state_count(md2_handle* h);
+int32_t md2_bn_state_get(md2_handle* h, float* host_state, int64_t n);
+int32_t md2_bn_state_set(md2_handle* h, const float* host_state, int64_t n);
+/* Bit-reproducible mode (also MD2_DETERMINISTIC=1 in the environment at md2_create): no split-K, one workgroup per weight-gradient tile, ordered loss /
+ * BatchNorm / bias sums.  Process-wide, much slower; for bisecting parity failures. */
+int32_t md2_set_deterministic(int32_t on);
 /* ADAM moments (Flux parameter layout, host) + running beta powers: the optimiser state the reference's BSON checkpoints
  * (src/Monodepth.jl:191-194) omit; with md2_params_get/set this gives true resume. */
 int32_t md2_opt_state_get(md2_handle* h, float* host_m, float* host_v, int64_t n, double* beta1p, double* beta2p);
 int32_t md2_opt_state_set(md2_handle* h, const float* host_m, const float* host_v, int64_t n, double beta1p, double beta2p);
 /* automasking_loss(ssim, x, x[:,:,:,target,:]; source_ids), src/training.jl:9-11 -> [N][1][H][W] */
 int32_t md2_automasking_loss(md2_handle* h, const float* x, float* out);
+
+/* ---- data parallelism: one process per GPU, RCCL over xGMI, called by the library itself (the reference is single-GPU, the
+ *      insertion point is its update!, src/Monodepth.jl:170).  Rank 0 draws a 128-byte id and passes it to the other ranks through the host's own channel;
+ *      after md2_comm_init, md2_backward all-reduces the flat gradient buffer in up to 4 buckets on a communication stream while the rest of the pullback
+ *      computes, and md2_train_step applies ADAM to the mean (grad_scale = 1/world).  BatchNorm statistics stay per replica (= the reference at batch B). */
+int32_t md2_comm_unique_id(void* out_128_bytes);
+int32_t md2_comm_init(md2_handle* h, int32_t rank, int32_t world, const void* unique_id_128_bytes);
+int32_t md2_comm_destroy(md2_handle* h);
+int32_t md2_comm_world(md2_handle* h, int32_t* rank, int32_t* world);
+int32_t md2_allreduce_grads(md2_handle* h);                 /* sum over ranks of the gradient buffer; no-op when md2_backward already reduced it */
+int32_t md2_comm_allreduce(md2_handle* h, float* dev_buf, int64_t n);   /* in-place sum of any device buffer (loss logging, self-checks) */
+int32_t md2_broadcast_state(md2_handle* h, int32_t root);   /* parameters, ADAM moments + beta powers, BatchNorm running statistics of `root` to every rank */
 
 /* The loss half alone (src/training.jl:28-77) given disparities and poses; pullbacks may be NULL.
  * ddisp_i like disp_i; drvec/dtvec [2][N][3]. */
@@ -146,6 +173,19 @@ int32_t md2_conv2d_fwd(const float* x, const float* w, const float* b, float* y,
 /* pullbacks wrt input / weights / bias of the conv above (act = none); any of dx,dw,db may be NULL */
 int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin,
                        int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t pad_mode, void* stream);
+/* The encoder's conv -> BatchNorm pair (ResNet.jl via src/model.jl:14): bias-free convolution whose epilogue also accumulates the training-BatchNorm batch
+ * statistics; bn_mean / bn_invstd [Cout] = mean and 1/sqrt(biased var + 1e-5) over (N,H,W) of y */
+int32_t md2_conv2d_bnstats_fwd(const float* x, const float* w, float* y, float* bn_mean, float* bn_invstd, int32_t N, int32_t Cin, int32_t H, int32_t W,
+                               int32_t Cout, int32_t k, int32_t stride, int32_t pad, void* stream);
+/* The direct kernels of the ResNet stem (7x7, stride 2, pad 3, no bias; ResidualNetwork(...), src/Monodepth.jl:117): x [N][C][H][W], w Flux [64][C][7][7]
+ * -> z [N][64][H/2][W/2] (+ the BatchNorm statistics of z, optional); and its weight gradient from dz */
+int32_t md2_stem_conv_fwd(const float* x, const float* w, float* z, float* bn_mean, float* bn_invstd, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+int32_t md2_stem_conv_wgrad(const float* x, const float* dz, float* dw, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* The disparity heads (src/depth_decoder.jl:43): reflect-pad + 3x3 conv to ONE channel + sigmoid, Cin in {16,32,64,128}; x [N][Cin][H][W], w Flux [1][Cin][3][3],
+ * b [1] -> y [N][1][H][W]; pullback of dy -> dx, dw, db (x_act = 2: x is an ELU output and dx is taken w.r.t. its pre-activation, as the last branch does) */
+int32_t md2_head_conv_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream);
+int32_t md2_head_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin, int32_t H,
+                          int32_t W, int32_t x_act, void* stream);
 /* Flux BatchNorm train mode (+ optional relu), NCHW */
 int32_t md2_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t relu, void* stream);
 int32_t md2_bn_train_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);

@@ -82,6 +82,24 @@ _SIGS = {
     "md2_maxpool3s2_fwd": (I32, [P, P, I32, I32, I32, I32, P]),
     "md2_maxpool3s2_bwd": (I32, [P, P, P, I32, I32, I32, I32, P]),
     "md2_adam_raw": (I32, [P, P, P, P, I64, I32, F64, C.c_float, P]),
+    "md2_set_lr": (I32, [P, F64]),
+    "md2_set_testmode": (I32, [P, I32]),
+    "md2_bn_state_count": (I64, [P]),
+    "md2_bn_state_get": (I32, [P, P, I64]),
+    "md2_bn_state_set": (I32, [P, P, I64]),
+    "md2_set_deterministic": (I32, [I32]),
+    "md2_comm_unique_id": (I32, [P]),
+    "md2_comm_init": (I32, [P, I32, I32, P]),
+    "md2_comm_destroy": (I32, [P]),
+    "md2_comm_world": (I32, [P, C.POINTER(I32), C.POINTER(I32)]),
+    "md2_allreduce_grads": (I32, [P]),
+    "md2_comm_allreduce": (I32, [P, P, I64]),
+    "md2_broadcast_state": (I32, [P, I32]),
+    "md2_conv2d_bnstats_fwd": (I32, [P, P, P, P, P] + [I32] * 8 + [P]),
+    "md2_stem_conv_fwd": (I32, [P, P, P, P, P, I32, I32, I32, I32, P]),
+    "md2_stem_conv_wgrad": (I32, [P, P, P, I32, I32, I32, I32, P]),
+    "md2_head_conv_fwd": (I32, [P, P, P, P, I32, I32, I32, I32, P]),
+    "md2_head_conv_bwd": (I32, [P] * 7 + [I32] * 5 + [P]),
 }
 
 EXPORTS = sorted(_SIGS)

@@ -22,6 +22,8 @@
 
 namespace md2 {
 
+int g_deterministic = 0;
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range of logical ids.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -353,7 +355,7 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     static_assert((BM / WP) % MF == 0 && (BN / WC) % MF == 0, "wave tile must be a multiple of the MFMA tile");
     ConvArgs a = a_in;
     constexpr bool fuses_stats = MF == 32 && (BN / WC) == 32;
-    if (a.stats && (!fuses_stats || a.ksplit > 1 || a.ostep != 1 || a.bias || a.act != ACT_NONE || a.accumulate || a.dact_src)) a.stats = nullptr;
+    if (a.stats && (!fuses_stats || g_deterministic || a.ksplit > 1 || a.ostep != 1 || a.bias || a.act != ACT_NONE || a.accumulate || a.dact_src)) a.stats = nullptr;
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
     const dim3 g(grid, a.ksplit);
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
@@ -609,7 +611,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
         static const int long_k = getenv("MD2_IGEMM_SPLIT_KSTEPS") ? atoi(getenv("MD2_IGEMM_SPLIT_KSTEPS")) : 256;
         const bool few = tiles64 < 100 || (tiles64 < mid && (long)cpt * a.nkh * a.nkw >= long_k);
         // (a serial K loop of fewer than 64 steps -- the 1x1 convolutions -- is cheaper than the fill + atomics + bias/activation passes of a split)
-        if (few && cpt >= 4 && (long)cpt * a.nkh * a.nkw >= 64 && want > 0) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
+        if (few && cpt >= 4 && (long)cpt * a.nkh * a.nkw >= 64 && want > 0 && !g_deterministic) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
     }
     View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
     const float* bias2 = nullptr; int act2 = ACT_NONE;
@@ -845,6 +847,7 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     const int target = target_env > 0 ? target_env : (T == 128 ? 512 : 1536);
     int splitk = std::max(1, target / (tiles * taps));          // round DOWN: one block over a multiple of the resident capacity costs a whole extra round
     splitk = std::max(1, std::min(splitk, (steps_total + 15) / 16));
+    if (g_deterministic) splitk = 1;                             // one block per (tile, tap): exactly one atomic per weight
     const int sps = (steps_total + splitk - 1) / splitk;
     splitk = (steps_total + sps - 1) / sps;
     const dim3 g(tiles * taps * splitk);
@@ -991,7 +994,7 @@ static void launch_wgrad_patch(const WgradArgs& a, hipStream_t s) {
         per_cu = std::min(per_cu, 4);
     }
     const int total = tiles_x * tiles_y * a.N, groups = a.Cin / 16;
-    const int gx = std::max(1, std::min(total, 256 * per_cu / groups));              // persistent: the co-resident blocks, shared by the channel chunks
+    const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));              // persistent: the co-resident blocks, shared by the channel chunks
     hipLaunchKernelGGL((conv3x3_wgrad_patch_kernel<TCO>), dim3(gx, groups), dim3(256), lds, s, a, tiles_x, tiles_y, total);
 }
 
@@ -1170,7 +1173,7 @@ static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
         if (getenv("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("MD2_TAPS_PER_CU"))));
     }
     const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
-    const int gx = std::max(1, std::min(total, 256 * per_cu / groups));                    // persistent: the co-resident blocks, shared by the weight tiles
+    const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));                    // persistent: the co-resident blocks, shared by the weight tiles
     if (a.bf16) hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<1>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
     else hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<0>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
 }
@@ -1181,6 +1184,12 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
         abort();
     }
     static const int max_t = getenv("MD2_WGRAD_MAXT") ? atoi(getenv("MD2_WGRAD_MAXT")) : 128;
+    if (g_deterministic && a.db && (wgrad_taps32_eligible(a) || wgrad_patch_eligible(a))) {      // the fused bias gradient adds one atomic per wave: use the ordered column sum
+        View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s);
+        WgradArgs b = a; b.db = nullptr;
+        if (wgrad_taps32_eligible(b)) launch_wgrad_taps32(b, s); else if (b.Cout == 16) launch_wgrad_patch<1>(b, s); else launch_wgrad_patch<2>(b, s);
+        return;
+    }
     if (wgrad_taps32_eligible(a)) { launch_wgrad_taps32(a, s); return; }
     if (wgrad_patch_eligible(a)) { if (a.Cout == 16) launch_wgrad_patch<1>(a, s); else launch_wgrad_patch<2>(a, s); return; }
     if (a.db) { View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s); }
@@ -1373,7 +1382,7 @@ template <int LPP>
 static void launch_head_bwd_t(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, int x_act, float* dw, float* db, hipStream_t s) {
     constexpr int PPB = 256 / LPP, TH = LPP <= 8 ? 8 : 4, TW = 4 * PPB / TH;
     const int tiles_x = (x.W + TW - 1) / TW, tiles_y = (x.H + TH - 1) / TH, total = tiles_x * tiles_y * x.N;
-    hipLaunchKernelGGL(head_bwd_kernel<LPP>, dim3(std::min(total, 768)), dim3(256), 0, s, x, w, y, dy, dx, accumulate, x_act, dw, db, tiles_x, tiles_y, total);      // persistent: 3 blocks per CU fit (162 VGPRs)
+    hipLaunchKernelGGL(head_bwd_kernel<LPP>, dim3(g_deterministic ? 1 : std::min(total, 768)), dim3(256), 0, s, x, w, y, dy, dx, accumulate, x_act, dw, db, tiles_x, tiles_y, total);      // persistent: 3 blocks per CU fit (162 VGPRs)
 }
 void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, int x_act, float* dw, float* db, hipStream_t s) {
     if (x.H < 3 || x.W < 3 || x.ps % 4 != 0 || dx.ps % 4 != 0) { fprintf(stderr, "md2: head_bwd: unsupported view\n"); abort(); }

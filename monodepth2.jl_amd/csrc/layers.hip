@@ -86,6 +86,7 @@ static void colstats_launch(int mode, const View& z, const View* dy, const View*
     if (z.C % 4 != 0 || (Qh <= 256 ? 256 % Qh != 0 : Qh % 256 != 0)) { fprintf(stderr, "md2: colstats: unsupported C=%d\n", z.C); abort(); }
     const long P = z.pixels();
     int rpb = 2048; while (rpb > 64 && (P + rpb - 1) / rpb < 1024) rpb >>= 1;
+    if (g_deterministic) rpb = (int)std::min<long>(P, 1 << 30);          // one workgroup per channel group: one atomic per channel
     const dim3 grid((unsigned)((P + rpb - 1) / rpb), (unsigned)((Qh + 255) / 256));
     View d = dy ? *dy : z, ya = yact ? *yact : z;
     const bool flat = dense_view_h(z) && dense_view_h(d) && dense_view_h(ya);
@@ -97,7 +98,9 @@ void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View&
     colstats_launch(1, z, &dy, yact, act, stats, acc, s);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int C, double count, int slots) {
+// running (optional, [mean[C] | var[C]]): Flux BatchNorm's tracked statistics, mu = (1 - mtm) mu + mtm mean, sigma^2 = (1 - mtm) sigma^2 + mtm * m/(m-1) * var
+// (Flux `_track_stats!`, momentum 0.1, unbiased correction of the batch variance)
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int C, double count, int slots, float* __restrict__ running, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0, s2 = 0;
@@ -107,9 +110,24 @@ __global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __rest
     if (var < 0) var = 0;
     stats[c] = (float)mean;
     stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+    if (running) {
+        const float corr = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
+        running[c] = (1.f - momentum) * running[c] + momentum * (float)mean;
+        running[C + c] = (1.f - momentum) * running[C + c] + momentum * corr * (float)var;
+    }
 }
-void launch_bn_finalize(const double* acc, float* stats, int C, double count, int slots, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, stats, C, count, slots);
+void launch_bn_finalize(const double* acc, float* stats, int C, double count, int slots, float* running, float momentum, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, stats, C, count, slots, running, momentum);
+}
+// Flux.testmode!: normalise with the tracked statistics, (x - mu) / sqrt(sigma^2 + eps)
+__global__ void bn_stats_from_running_kernel(const float* __restrict__ running, float* __restrict__ stats, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    stats[c] = running[c];
+    stats[C + c] = 1.f / sqrtf(running[C + c] + 1e-5f);
+}
+void launch_bn_stats_from_running(const float* running, float* stats, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_stats_from_running_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running, stats, C);
 }
 
 // FAST: the channel-quad count Q is a power of two (it divides the grid stride, so a thread keeps ONE quad for its whole life and the
@@ -372,6 +390,7 @@ void launch_colsum(const View& v, float* out, hipStream_t s) {
     if (v.C % 4 != 0 || v.C > 1024 || 256 % (v.C / 4) != 0) { fprintf(stderr, "md2: colsum: unsupported C=%d\n", v.C); abort(); }
     const long P = v.pixels();
     int rpb = 2048; while (rpb > 64 && (P + rpb - 1) / rpb < 512) rpb >>= 1;
+    if (g_deterministic) rpb = (int)std::min<long>(P, 1 << 30);
     hipLaunchKernelGGL(colsum_kernel, dim3((int)((P + rpb - 1) / rpb)), dim3(256), 0, s, v, out, rpb);
 }
 

@@ -132,7 +132,7 @@ __device__ __forceinline__ void project_fwd(float depth, const float ray[3], con
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double* __restrict__ part, double* __restrict__ blk) {
     __shared__ float wv[2][C][FH * FW];      // warped sources (padded positions)
     __shared__ float tg[C][FH * FW];         // target
     __shared__ float dl[FH * FW];            // disparity
@@ -211,13 +211,27 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double* __res
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[wave][0] = s_photo; red[wave][1] = s_d; red[wave][2] = s_x; red[wave][3] = s_y; }
     __syncthreads();
-    if (threadIdx.x < 4) atomicAdd(part + (long)zi * 4 + threadIdx.x, (double)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (threadIdx.x < 4) {
+        const double v = (double)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (blk) blk[((long)zi * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = v;     // deterministic mode: summed in order afterwards
+        else atomicAdd(part + (long)zi * 4 + threadIdx.x, v);
+    }
 }
-void launch_loss_fwd(const LossArgs& a, double* part, hipStream_t s) {
+// deterministic mode: out[g*nv + k] = sum over the nb blocks of group g, in block order (one thread per value)
+__global__ void loss_part_reduce_kernel(const double* __restrict__ blk, double* __restrict__ out, int groups, int nb, int nv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= groups * nv) return;
+    const int g = i / nv, k = i - g * nv;
+    double s = 0;
+    for (int b = 0; b < nb; ++b) s += blk[((long)g * nb + b) * nv + k];
+    out[i] = s;
+}
+int loss_blocks_per_image(const LossArgs& a) { return ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH); }
+void launch_loss_fwd(const LossArgs& a, double* part, double* blk, hipStream_t s) {
     if ((a.C != 1 && a.C != 3) || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_fwd: unsupported C=%d H=%d W=%d\n", a.C, a.H, a.W); abort(); }
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N * a.nscales);
-    if (a.C == 1) hipLaunchKernelGGL(loss_fwd_kernel<1>, grid, dim3(256), 0, s, a, part);
-    else hipLaunchKernelGGL(loss_fwd_kernel<3>, grid, dim3(256), 0, s, a, part);
+    if (a.C == 1) hipLaunchKernelGGL(loss_fwd_kernel<1>, grid, dim3(256), 0, s, a, part, blk);
+    else hipLaunchKernelGGL(loss_fwd_kernel<3>, grid, dim3(256), 0, s, a, part, blk);
+    if (blk) { const int groups = a.N * a.nscales; hipLaunchKernelGGL(loss_part_reduce_kernel, dim3((groups * 4 + 63) / 64), dim3(64), 0, s, blk, part, groups, (int)(grid.x * grid.y), 4); }
 }
 
 // totals[(sc*N+n)*4 + {0: photo sum, 1: mean d, 2: Sx, 3: Sy}] ; loss = mean over scales of [mean(warp_loss) + smooth]
@@ -247,7 +261,7 @@ void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, 
 // backward
 // =====================================================================================================================
 template <int C>
-__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* __restrict__ totals, float* __restrict__ ddisp_full, double* __restrict__ dRt_acc) {
+__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* __restrict__ totals, float* __restrict__ ddisp_full, double* __restrict__ dRt_acc, double* __restrict__ blk) {
     __shared__ float wv[2][C][BH2 * BW2];        // warped sources at padded positions of tile + 2
     __shared__ float tg[C][BH2 * BW2];
     __shared__ float dl[BH2 * BW2];
@@ -433,14 +447,25 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* 
     if (threadIdx.x < 24) {
         const int s = threadIdx.x / 12, k = threadIdx.x % 12;
         const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (v != 0.f) atomicAdd(dRt_acc + ((long)s * a.N + n) * 12 + k, (double)v);
+        if (blk) blk[((long)zi * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 24 + threadIdx.x] = (double)v;
+        else if (v != 0.f) atomicAdd(dRt_acc + ((long)s * a.N + n) * 12 + k, (double)v);
     }
 }
-void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, hipStream_t s) {
+// deterministic mode: dRt_acc[(s*N+n)*12+k] = sum over scales, then blocks, in order
+__global__ void loss_dRt_reduce_kernel(const double* __restrict__ blk, double* __restrict__ dRt_acc, int N, int nscales, int nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= 24 * N) return;
+    const int k = i % 12, n = (i / 12) % N, s = i / (12 * N);
+    double acc = 0;
+    for (int sc = 0; sc < nscales; ++sc)
+        for (int b = 0; b < nb; ++b) acc += blk[(((long)sc * N + n) * nb + b) * 24 + s * 12 + k];
+    dRt_acc[((long)s * N + n) * 12 + k] = acc;
+}
+void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, double* blk, hipStream_t s) {
     if ((a.C != 1 && a.C != 3) || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_bwd: unsupported shape\n"); abort(); }
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N * a.nscales);
-    if (a.C == 1) hipLaunchKernelGGL(loss_bwd_kernel<1>, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc);
-    else hipLaunchKernelGGL(loss_bwd_kernel<3>, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc);
+    if (a.C == 1) hipLaunchKernelGGL(loss_bwd_kernel<1>, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc, blk);
+    else hipLaunchKernelGGL(loss_bwd_kernel<3>, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc, blk);
+    if (blk) hipLaunchKernelGGL(loss_dRt_reduce_kernel, dim3((24 * a.N + 63) / 64), dim3(64), 0, s, blk, dRt_acc, a.N, a.nscales, (int)(grid.x * grid.y));
 }
 
 // =====================================================================================================================
@@ -581,7 +606,8 @@ __global__ void op_ssim_kernel(const float* __restrict__ x, const float* __restr
     }
 }
 // photometric for k predictions + min: preds [k][N][C][H][W]; out [N][H][W]; if k == 1 plain photometric
-__global__ void op_prediction_kernel(const float* __restrict__ preds, int k, const float* __restrict__ tgt, float* __restrict__ out, int N, int C, int H, int W) {
+// prediction j of sample n starts at preds + j*pj + n*pn, the target of sample n at tgt + n*tn (floats): the automasking loss reads the frames of x in place
+__global__ void op_prediction_kernel(const float* __restrict__ preds, int k, const float* __restrict__ tgt, float* __restrict__ out, int N, int C, int H, int W, long pj, long pn, long tn) {
     const long P = (long)H * W;
     FOR1D(i, (long)N * P) {
         const int w = i % W; const long t = i / W; const int h = t % H; const int n = t / H;
@@ -589,7 +615,7 @@ __global__ void op_prediction_kernel(const float* __restrict__ preds, int k, con
         for (int j = 0; j < k; ++j) {
             float ss = 0.f, l1 = 0.f;
             for (int c = 0; c < C; ++c) {
-                const float* xp = preds + (((long)j * N + n) * C + c) * P; const float* yp = tgt + ((long)n * C + c) * P;
+                const float* xp = preds + (long)j * pj + (long)n * pn + (long)c * P; const float* yp = tgt + (long)n * tn + (long)c * P;
                 float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
                 for (int dy = -1; dy <= 1; ++dy)
                     for (int dx = -1; dx <= 1; ++dx) {
@@ -688,6 +714,12 @@ __global__ void op_smooth_kernel(const float* __restrict__ d, const float* __res
 }
 __global__ void op_smooth_final(const double* __restrict__ part, float* __restrict__ out, double cntx, double cnty) { if (threadIdx.x == 0 && blockIdx.x == 0) *out = (float)(part[0] / cntx + part[1] / cnty); }
 
+// automasking_loss (src/training.jl:9-11) on the triplet tensor x [N][3][C][H][W] in place: predictions = frames src0, src1, target = frame tgt
+void launch_automask(const float* x, float* out, int N, int C, int H, int W, int src0, int src1, int tgt, hipStream_t s) {
+    const long CP = (long)C * H * W;
+    hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, s, x + src0 * CP, 2, x + tgt * CP, out, N, C, H, W, (long)(src1 - src0) * CP, 3 * CP, 3 * CP);
+}
+
 }  // namespace md2
 
 // ---- stateless C entry points (include/md2hip.h) ---------------------------------------------------------------------------
@@ -702,11 +734,11 @@ int32_t md2_ssim_fwd(const float* x, const float* y, float* out, int32_t planes,
 }
 int32_t md2_photometric_loss_fwd(const float* pred, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
     if (H < 2 || W < 2) return 2;
-    hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, S_(stream), pred, 1, target, out, N, C, H, W); return chk();
+    hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, S_(stream), pred, 1, target, out, N, C, H, W, 0L, (long)C * H * W, (long)C * H * W); return chk();
 }
 int32_t md2_prediction_loss_fwd(const float* preds, int32_t k, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
     if (H < 2 || W < 2 || k < 1) return 2;
-    hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, S_(stream), preds, k, target, out, N, C, H, W); return chk();
+    hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, S_(stream), preds, k, target, out, N, C, H, W, (long)N * C * H * W, (long)C * H * W, (long)C * H * W); return chk();
 }
 int32_t md2_disparity_to_depth(const float* d, float* out, int64_t n, double min_depth, double max_depth, void* stream) {
     hipLaunchKernelGGL(op_d2d_kernel, GRID1D(n), 0, S_(stream), d, out, (long)n, (float)(1.0 / max_depth), (float)(1.0 / min_depth)); return chk();

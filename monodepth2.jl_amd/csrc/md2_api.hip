@@ -2,8 +2,8 @@
 //
 // Host-side mirror of src/model.jl (Model forward), src/depth_decoder.jl, src/pose_decoder.jl, the ResNet-18 trunk
 // (torchvision convention), src/training.jl:21-78 (train_loss) and their hand-written pullbacks
-// (the reference gets them from Zygote).  Everything runs on ONE HIP stream; no allocation or synchronisation
-// happens inside a step.
+// (the reference gets them from Zygote).  A step is enqueued on the caller's stream plus internal side streams (weight gradients,
+// pose branch, RCCL buckets) forked and joined by events; no allocation or host synchronisation happens inside a step.
 #include "md2_internal.h"
 #include "../../include/md2hip.h"
 #include <vector>
@@ -12,6 +12,8 @@
 #include <cmath>
 #include <algorithm>
 #include <cstdlib>
+#include <dlfcn.h>
+#include <rccl/rccl.h>        // types only: the RCCL entry points are resolved with dlsym at md2_comm_init (no link-time dependency)
 
 using namespace md2;
 
@@ -30,7 +32,7 @@ struct ConvL {
     long fw = 0, fb = 0;                 // offsets into the Flux-layout flat vector
     long wn() const { return (long)coutP * taps * cinP; }
 };
-struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; float* stats = nullptr; double* acc = nullptr; double* acc_b = nullptr; };
+struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; long rs = 0; float* stats = nullptr; double* acc = nullptr; double* acc_b = nullptr; };   // rs: offset of (running mean[c], running var[c]) in md2_handle::RS
 // BasicBlock (ResNet-18): c1 3x3(stride) - b1 - relu - c2 3x3 - b2 (+ shortcut) - relu
 // Bottleneck (ResNet-50): c1 1x1 - b1 - relu - c2 3x3(stride) - b2 - relu - c3 1x1 x4 - b3 (+ shortcut) - relu     (torchvision convention)
 struct Block { ConvL c1, c2, c3, cd; BNL b1, b2, b3, bd; bool down = false, bottleneck = false, stage_end = false; int stride = 1;
@@ -69,6 +71,11 @@ struct md2_handle {
     hipStream_t s3 = nullptr; hipStream_t cur = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // pose branch stream; `cur` = stream of the chain being enqueued
     hipStream_t s4 = nullptr; int wg_rr = 0; int n_wg_streams = 1; hipEvent_t ev_join4 = nullptr;
     hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr, ev_p0 = nullptr, ev_p1 = nullptr; bool prep_done = false; bool two_streams = true; bool forked = false; View dz0;
+    bool net_ok = true;                 // false: the image is too small for the network (H or W < 64): only the loss-half entry points work
+    float* RS = nullptr; long n_rs = 0; bool testmode = false;     // BatchNorm running mean / variance (Flux BatchNorm mu, sigma^2; momentum 0.1) and Flux.testmode!
+    double* loss_blk = nullptr;         // deterministic mode: per-block partial sums of the loss kernels
+    // data parallelism: RCCL communicator + bucketed all-reduce of the flat gradient buffer, overlapped with the rest of the pullback
+    void* comm = nullptr; int rank = 0, world = 1; hipStream_t scomm = nullptr; hipEvent_t ev_cm[8], ev_cs[8], ev_cdone = nullptr; bool grads_reduced = false; long bucket_lo[8]; int n_bucket_done = 0;
     bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
 
     template <class T> T* alloc(size_t count) {
@@ -82,6 +89,8 @@ struct md2_handle {
     void pbegin(int cls, double flops = 0, const char* desc = "", hipStream_t st = nullptr, bool own = false) { if (prof) { ProfEvt e; e.cls = cls; e.flops = flops; snprintf(e.desc, sizeof(e.desc), "%s", desc); (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, own ? st : chain()); evts.push_back(e); } }
     void pend(hipStream_t st = nullptr, bool own = false) { if (prof) (void)hipEventRecord(evts.back().b, own ? st : chain()); }
 };
+
+static int comm_bucket(md2_handle* h, long lo, long hi);      // RCCL all-reduce of a finished slice of the gradient buffer on the communication stream (below)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // layer table
@@ -98,7 +107,8 @@ static void build_layers(md2_handle* h) {
         if (bias) { c.b = al(c.coutP); c.fb = fo; fo += cout; }
         h->convs.push_back(&c);
     };
-    auto mkbn = [&](BNL& b, int c) { b.c = c; b.g = al(c); b.b = al(c); b.fg = fo; b.fb = fo + c; fo += 2 * c; h->bns.push_back(&b); };
+    long ro = 0;
+    auto mkbn = [&](BNL& b, int c) { b.c = c; b.g = al(c); b.b = al(c); b.fg = fo; b.fb = fo + c; fo += 2 * c; b.rs = ro; ro += 2 * c; h->bns.push_back(&b); };
     mk(h->stem, h->C, 64, 7, 2, 3, false, 1); mkbn(h->stem_bn, 64);
     h->Kpad = h->stem.cinP;
     const int planes[4] = {64, 128, 256, 512}; int cin = 64;
@@ -125,7 +135,7 @@ static void build_layers(md2_handle* h) {
     for (int b = 0; b < 5; ++b) { mk(h->dc1[b], inc[b], dec[b], 3, 1, 0, true, 0); mk(h->dc2[b], dec[b] + skc[b], dec[b], 3, 1, 0, true, 0); }
     for (int l = 0; l < 4; ++l) mk(h->head[l], dec[l + 1], 1, 3, 1, 0, true, 2);
     mk(h->squeeze, h->stages[4], 256, 1, 1, 0, true, 0); mk(h->pose[0], 512, 256, 3, 1, 1, true, 0); mk(h->pose[1], 256, 256, 3, 1, 1, true, 0); mk(h->pose[2], 256, 6, 1, 1, 0, true, 0);
-    h->n_int = io; h->n_flux = fo;
+    h->n_int = io; h->n_flux = fo; h->n_rs = ro;
 }
 
 // Flux (kW,kH,Cin,Cout) true-convolution weights  <->  internal [coutP][taps][cinP] cross-correlation taps
@@ -198,6 +208,7 @@ static void plan_buffers(md2_handle* h) {
     h->rvec = h->alloc<float>(6 * N); h->tvec = h->alloc<float>(6 * N); h->Rt = h->alloc<float>(24 * N);
     h->totals = h->alloc<float>(16 * N); h->loss_dev = h->alloc<float>(4); h->ddisp_full = h->alloc<float>((size_t)4 * N * H * W);
     h->drvec = h->alloc<float>(6 * N); h->dtvec = h->alloc<float>(6 * N);
+    h->loss_blk = h->alloc<double>((size_t)4 * N * ((W + 15) / 16) * ((H + 7) / 8) * 24);        // deterministic mode: [scale*N][block][24] partials (bound for loss tiles >= 16x8)
     for (BNL* b : h->bns) b->stats = h->alloc<float>(2 * b->c);
     size_t nd = 0;
     for (BNL* b : h->bns) nd += (size_t)(2 * BN_STAT_SLOTS + 2) * b->c;
@@ -260,7 +271,7 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
 // forward conv (kind 0) on views.  x.C must equal c.cinP, y.C == c.coutP
 static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act, double* bn_stats = nullptr) {
     ConvArgs a = conv_args(x, h->P + c.w, y, c.k, c.stride, padmode == PAD_REFLECT ? 1 : c.pad, 1, padmode);
-    a.bias = c.bias ? h->P + c.b : nullptr; a.act = act; a.stats = bn_stats;
+    a.bias = c.bias ? h->P + c.b : nullptr; a.act = act; a.stats = h->testmode ? nullptr : bn_stats;
     run_igemm(h, a);
 }
 // input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
@@ -295,8 +306,10 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
 }
 // the batch statistics were accumulated into b.acc by the convolution that produced z (conv_fwd(..., b.acc))
+// (test mode, Flux.testmode!: the tracked running statistics instead; train mode also updates them, momentum 0.1)
 static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* residual, int act, const View& y) {
-    launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), BN_STAT_SLOTS, h->chain());
+    if (h->testmode) launch_bn_stats_from_running(h->RS + b.rs, b.stats, b.c, h->chain());
+    else launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), BN_STAT_SLOTS, h->RS + b.rs, 0.1f, h->chain());
     launch_bn_apply(z, b.stats, h->P + b.g, h->P + b.b, residual, act, y, h->chain());
 }
 // dy: gradient wrt the BN output (already masked by any following ReLU) -> dz
@@ -350,7 +363,8 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
     // ---- encoder: stem + BN + ReLU, maxpool, 8 basic blocks
     {   // direct 7x7 stride-2 convolution on the boundary tensor (+ its BatchNorm statistics)
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
-        h->pbegin(CLS_IGEMM, fl, "stem fwd 7x7 s2 (direct)"); launch_stem_fwd(x, NL, h->C, H, W, h->P + h->stem.w, h->Kpad, h->z0, h->stem_bn.acc, s); h->pend();
+        h->pbegin(CLS_IGEMM, fl, "stem fwd 7x7 s2 (direct)"); launch_stem_fwd(x, NL, h->C, H, W, h->P + h->stem.w, h->Kpad, h->z0, (h->testmode || g_deterministic) ? nullptr : h->stem_bn.acc, s); h->pend();
+        if (g_deterministic && !h->testmode) launch_colstats(h->z0, h->stem_bn.acc, s);
         if (h->prof) h->prof_flops[CLS_IGEMM] += fl;
     }
     bn_fwd(h, h->stem_bn, h->z0, nullptr, ACT_RELU, h->a0);
@@ -398,7 +412,7 @@ static int loss_forward(md2_handle* h, const float* x, const float* const disp[4
     launch_pose_compose(rvec, tvec, h->Rt, h->N, 1, 0, s);       // inverse_transform = source_ids .< target_id = [true, false] (src/training.jl:29)
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
     if (simple) simple_mode(h, a);
-    h->pbegin(CLS_LOSS_FWD); launch_loss_fwd(a, h->loss_part, s); h->pend();
+    h->pbegin(CLS_LOSS_FWD); launch_loss_fwd(a, h->loss_part, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
     if (h->prof) h->prof_bytes[CLS_LOSS_FWD] += 4.0 * h->H * h->W * (1 + 3 * h->C) * 4 * h->N;
     launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
     if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -411,7 +425,7 @@ static int loss_backward(md2_handle* h, const float* x, const float* const disp[
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
     if (simple) simple_mode(h, a);
     HIPCHK(hipMemsetAsync(h->dRt_acc, 0, (size_t)24 * h->N * sizeof(double), s));
-    h->pbegin(CLS_LOSS_BWD); launch_loss_bwd(a, h->totals, h->ddisp_full, h->dRt_acc, s); h->pend();
+    h->pbegin(CLS_LOSS_BWD); launch_loss_bwd(a, h->totals, h->ddisp_full, h->dRt_acc, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
     if (h->prof) h->prof_bytes[CLS_LOSS_BWD] += 4.0 * h->H * h->W * (2 + 3 * h->C) * 4 * h->N;
     const size_t P = (size_t)h->H * h->W;
     if (!simple) for (int i = 0; i < 4; ++i) launch_upsample_planar_bwd(h->ddisp_full + (size_t)i * h->N * P, h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
@@ -460,6 +474,12 @@ static int model_backward(md2_handle* h) {
     const int N = h->N, NL = h->NL, H = h->H, W = h->W;
     if (h->prep_done) { (void)hipStreamWaitEvent(s, h->ev_p1, 0); h->prep_done = false; }     // zeroed gradients + transposed weights were prepared during the forward pass
     else if (int r = backward_prepare(h, s)) return r;
+    // data parallel: the gradient buffer is all-reduced in up to 4 buckets as they complete (decoders | stage 5 | stages 3-4 | stage 2 + stem), MD2_COMM_BUCKETS=0: one
+    // all-reduce by md2_allreduce_grads after the pullback
+    static const bool buckets_on = !(getenv("MD2_COMM_BUCKETS") && atoi(getenv("MD2_COMM_BUCKETS")) == 0);
+    h->grads_reduced = false; h->n_bucket_done = (h->comm && buckets_on) ? 0 : -1;
+    int stage_first[4] = {0, 0, 0, 0};                                 // first block of encoder layers 1..4
+    for (int i = 0, l = 0; i < h->nblk && l < 4; ++i) if (i == 0 || h->blk[i - 1].stage_end) stage_first[l++] = i;
     // The gradient accumulators (Gfeat / Gblk / Gpool, 715 MB at B=32) are NOT zeroed: every buffer's first writer overwrites
     // (accumulate 0) and later writers add.  Stage buffers receive decoder / pose contributions in the target frame before the
     // encoder pullback reaches them, so the encoder's first writer uses accumulate mode 2 (add only in target frames).
@@ -501,6 +521,7 @@ static int model_backward(md2_handle* h) {
         h->cur = h->s3; pose_backward(h, N, 1); (void)hipEventRecord(h->ev_c, h->s3); h->cur = nullptr;
         (void)hipStreamWaitEvent(h->stream, h->ev_c, 0);
     } else { pose_backward(h, N, 0); pose_backward(h, N, 1); }
+    if (int r = comm_bucket(h, h->dc1[0].w, h->n_int)) return r;           // depth decoder, heads, pose decoder
     // ---- encoder
     for (int i = h->nblk - 1; i >= 0; --i) {
         Block& B = h->blk[i];
@@ -534,6 +555,8 @@ static int model_backward(md2_handle* h) {
             conv_wgrad(h, B.cd, B.in, dzd, PAD_ZERO);
             conv_dgrad(h, B.cd, dzd, *Gin, 0, 1, in_act, ACT_RELU);
         }
+        if (i == stage_first[3]) { if (int r = comm_bucket(h, h->blk[i].c1.w, h->dc1[0].w)) return r; }                                  // encoder layer 4
+        else if (i == stage_first[1] && stage_first[1] != stage_first[3]) { if (int r = comm_bucket(h, h->blk[i].c1.w, h->blk[stage_first[3]].c1.w)) return r; }   // layers 2-3
     }
     launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s);        // Gfeat[0]: decoder skip gradient in the target frames only; ReLU mask from the pooled output
     {
@@ -542,6 +565,11 @@ static int model_backward(md2_handle* h) {
         hipStream_t st = wgrad_stream(h);
         h->pbegin(CLS_WGRAD, fl, "stem wgrad 7x7 s2 (direct)", st, true); launch_stem_wgrad(h->x_last, NL, h->C, H, W, h->dz0, h->G + h->stem.w, h->Kpad, st); h->pend(st, true);
         if (h->prof) h->prof_flops[CLS_WGRAD] += fl;
+    }
+    if (h->n_bucket_done >= 0) {            // last bucket (layer 1 + stem), then the caller's stream waits for the communication stream
+        if (int r = comm_bucket(h, 0, h->blk[stage_first[1]].c1.w)) return r;
+        (void)hipEventRecord(h->ev_cdone, h->scomm); (void)hipStreamWaitEvent(h->stream, h->ev_cdone, 0);
+        h->grads_reduced = true;
     }
     if (h->forked) {                        // join: the gradient buffer is complete only when the weight-gradient stream has drained
         (void)hipEventRecord(h->ev_join, h->s2); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); h->forked = false;
@@ -552,29 +580,91 @@ static int model_backward(md2_handle* h) {
 }
 
 // =====================================================================================================================
+// RCCL (data parallelism): one process per GPU, all-reduce(sum) of the flat gradient buffer over xGMI.
+// The library calls RCCL itself (no torch, no host framework in between) so that a Julia host gets the same multi-GPU step; the entry points are
+// resolved with dlsym at md2_comm_init -- librccl.so.1 already mapped into the process (e.g. by a host framework) is reused, else it is loaded.
+// =====================================================================================================================
+namespace {
+struct RcclApi {
+    void* lib = nullptr; bool tried = false; std::string err;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr; decltype(&ncclBroadcast) Broadcast = nullptr; decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+RcclApi g_rccl;
+bool rccl_load() {
+    RcclApi& r = g_rccl;
+    if (r.tried) return r.lib != nullptr;
+    r.tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // already in the process: share it
+    if (!r.lib) for (const char* n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!r.lib) { r.err = std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "?"); return false; }
+#define MD2_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.lib, "nccl" #f)); if (!r.f) { r.err = "librccl lacks nccl" #f; r.lib = nullptr; return false; }
+    MD2_SYM(GetUniqueId) MD2_SYM(CommInitRank) MD2_SYM(CommDestroy) MD2_SYM(AllReduce) MD2_SYM(Broadcast) MD2_SYM(GetErrorString) MD2_SYM(GroupStart) MD2_SYM(GroupEnd)
+#undef MD2_SYM
+    return true;
+}
+}  // namespace
+#define NCCLCHK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { h->err = std::string(#expr) + ": " + g_rccl.GetErrorString(r_); return 1; } } while (0)
+
+// Gradient bucket [lo, hi) of the flat buffer is complete on the streams that write it: order the communication stream after them and enqueue its all-reduce there,
+// so that it runs while the rest of the pullback computes.  (The buckets are walked from the end of the buffer: decoders, then encoder stages 4 .. 1.)
+static int comm_bucket(md2_handle* h, long lo, long hi) {
+    if (!h->comm || h->n_bucket_done < 0 || hi <= lo) return 0;
+    const int i = h->n_bucket_done++;
+    if (i >= 8) { h->err = "comm_bucket: too many buckets"; return 1; }
+    (void)hipEventRecord(h->ev_cm[i], h->stream); (void)hipStreamWaitEvent(h->scomm, h->ev_cm[i], 0);
+    if (h->forked) { (void)hipEventRecord(h->ev_cs[i], h->s2); (void)hipStreamWaitEvent(h->scomm, h->ev_cs[i], 0); }
+    if (h->forked && h->n_wg_streams > 1) { (void)hipEventRecord(h->ev_join4, h->s4); (void)hipStreamWaitEvent(h->scomm, h->ev_join4, 0); }
+    NCCLCHK(g_rccl.AllReduce(h->G + lo, h->G + lo, (size_t)(hi - lo), ncclFloat, ncclSum, (ncclComm_t)h->comm, h->scomm));
+    return 0;
+}
+static void comm_destroy(md2_handle* h) {
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)h->comm);
+    h->comm = nullptr; h->world = 1; h->rank = 0;
+}
+
+// =====================================================================================================================
 // C ABI
 // =====================================================================================================================
 extern "C" {
 
 const char* md2_last_error(md2_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
+static void destroy_handle(md2_handle* h);
+
 int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     if (!cfg || !out) { g_create_err = "null argument"; return 2; }
-    if (cfg->batch < 1 || (cfg->channels != 1 && cfg->channels != 3) || cfg->height % 32 || cfg->width % 32 || cfg->height < 64 || cfg->width < 64) {
-        g_create_err = "md2_create: need batch >= 1, channels in {1,3}, height/width multiples of 32 and >= 64"; return 2;
+    // The network needs height/width multiples of 32 and >= 64 (five stride-2 stages, then reflect padding at 1/32 scale).  Smaller images
+    // (multiples of 8, >= 16) give a LOSS-ONLY handle: md2_loss_fwd_bwd / md2_simple_depth_loss / md2_automasking_loss work, the model entry points fail.
+    if (cfg->batch < 1 || (cfg->channels != 1 && cfg->channels != 3) || cfg->height % 8 || cfg->width % 8 || cfg->height < 16 || cfg->width < 16) {
+        g_create_err = "md2_create: need batch >= 1, channels in {1,3}, height/width multiples of 8 and >= 16 (multiples of 32 and >= 64 for the network)"; return 2;
     }
+    const bool net_ok = cfg->height % 32 == 0 && cfg->width % 32 == 0 && cfg->height >= 64 && cfg->width >= 64;
     if (cfg->encoder_depth != 0 && cfg->encoder_depth != 18 && cfg->encoder_depth != 50) { g_create_err = "md2_create: encoder_depth must be 18 (or 0) or 50"; return 2; }
     if (cfg->precision != 0 && cfg->precision != 1) { g_create_err = "md2_create: precision must be 0 (fp32) or 1 (bf16 mixed precision)"; return 2; }
+    {   // shape limits of the kernels (32-bit byte offsets inside one activation tensor, 24-bit pixel counts in the weight gradients): refuse here, with a
+        // status code, instead of aborting inside a launcher in the middle of a step
+        const double px_half = 3.0 * cfg->batch * (cfg->height / 2.0) * (cfg->width / 2.0);          // pixels of the largest activation (stem output, 64 channels)
+        const double widest = px_half * 64.0 * 4.0, dec_full = (double)cfg->batch * (cfg->height + 2.0) * (cfg->width + 2.0) * 32.0 * 4.0;
+        if (widest >= 4294967296.0 || dec_full >= 4294967296.0 || px_half >= 16777216.0) {
+            g_create_err = "md2_create: batch x resolution too large for one handle (an activation tensor must stay below 4 GiB and 2^24 pixels); use a smaller per-GPU batch"; return 2;
+        }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "md2_create: no HIP device (libmd2hip needs an MI355X; there is no CPU fallback)"; return 3; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "md2_create: hipSetDevice failed"; return 3; }
+    if (const char* e = getenv("MD2_DETERMINISTIC")) g_deterministic = atoi(e) != 0;
     md2_handle* h = new md2_handle();
-    h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width;
+    h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width; h->net_ok = net_ok;
     h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision == 1;
+    for (int i = 0; i < 64; ++i) h->ev_pool[i] = nullptr;
+    for (int i = 0; i < 8; ++i) { h->ev_cm[i] = nullptr; h->ev_cs[i] = nullptr; }
     build_layers(h);
     plan_buffers(h);                        // sizing pass
     const size_t need = h->arena_off + 4096;
-    auto fail = [&](const char* what) { g_create_err = std::string("md2_create: ") + what; delete h; return 4; };
+    auto fail = [&](const char* what) { g_create_err = std::string("md2_create: ") + what; destroy_handle(h); return 4; };
     if (hipMalloc((void**)&h->arena, need) != hipSuccess) return fail("hipMalloc(arena) failed");
     plan_buffers(h);
     const size_t pb = (size_t)h->n_int * sizeof(float);
@@ -582,6 +672,12 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
         hipMalloc((void**)&h->V, pb) != hipSuccess || hipMalloc((void**)&h->WD, pb) != hipSuccess) return fail("hipMalloc(params) failed");
     (void)hipMemset(h->P, 0, pb); (void)hipMemset(h->G, 0, pb); (void)hipMemset(h->M, 0, pb); (void)hipMemset(h->V, 0, pb); (void)hipMemset(h->WD, 0, pb);
     (void)hipMemset(h->arena, 0, need);
+    {   // BatchNorm running statistics: Flux initialises mu = 0, sigma^2 = 1
+        std::vector<float> rs((size_t)h->n_rs, 0.f);
+        for (BNL* b : h->bns) for (int i = 0; i < b->c; ++i) rs[b->rs + b->c + i] = 1.f;
+        if (hipMalloc((void**)&h->RS, rs.size() * sizeof(float)) != hipSuccess) return fail("hipMalloc(bn state) failed");
+        (void)hipMemcpy(h->RS, rs.data(), rs.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     {   // layer table of the batched weight transform
         std::vector<long> d;
         for (ConvL* c : h->convs) if (c->kind == 0) { d.push_back(c->w); d.push_back(c->coutP); d.push_back(c->cinP); d.push_back(c->taps); }
@@ -609,13 +705,23 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     *out = h;
     return 0;
 }
+static void comm_destroy(md2_handle* h);
+static void destroy_handle(md2_handle* h) {          // also the failure path of md2_create: every member is null until it was created
+    (void)hipDeviceSynchronize();
+    comm_destroy(h);
+    for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (int i = 0; i < 64; ++i) if (h->ev_pool[i]) (void)hipEventDestroy(h->ev_pool[i]);
+    for (int i = 0; i < 8; ++i) { if (h->ev_cm[i]) (void)hipEventDestroy(h->ev_cm[i]); if (h->ev_cs[i]) (void)hipEventDestroy(h->ev_cs[i]); }
+    hipEvent_t evs[] = {h->ev_join, h->ev_p0, h->ev_p1, h->ev_a, h->ev_b, h->ev_c, h->ev_join4, h->ev_cdone};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    hipStream_t sts[] = {h->s2, h->s3, h->s4, h->scomm};
+    for (hipStream_t st : sts) if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD); (void)hipFree(h->RS);
+    delete h;
+}
 int32_t md2_destroy(md2_handle* h) {
     if (!h) return 0;
-    (void)hipDeviceSynchronize();
-    for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-    if (h->s2) { for (int i = 0; i < 64; ++i) (void)hipEventDestroy(h->ev_pool[i]); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_p0); (void)hipEventDestroy(h->ev_p1); (void)hipStreamDestroy(h->s2); (void)hipEventDestroy(h->ev_a); (void)hipEventDestroy(h->ev_b); (void)hipEventDestroy(h->ev_c); (void)hipStreamDestroy(h->s3); (void)hipEventDestroy(h->ev_join4); (void)hipStreamDestroy(h->s4); }
-    (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD);
-    delete h; return 0;
+    destroy_handle(h); return 0;
 }
 int32_t md2_set_stream(md2_handle* h, void* st) { h->stream = (hipStream_t)st; return 0; }
 int32_t md2_synchronize(md2_handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); return 0; }
@@ -655,12 +761,15 @@ static int copy_outputs(md2_handle* h, float* d0, float* d1, float* d2, float* d
     return 0;
 }
 int32_t md2_model_forward(md2_handle* h, const float* x, float* d0, float* d1, float* d2, float* d3, float* rvec, float* tvec) {
+    if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
     h->have_fwd = false;                    // overwrites the activations a pending md2_backward would need
     if (int r = model_forward(h, x)) return r;
     return copy_outputs(h, d0, d1, d2, d3, rvec, tvec);
 }
 int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, float* loss) {
+    if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
     if (h->cfg.automasking && !auto_loss) { h->err = "md2_train_loss: automasking is on but auto_loss is NULL"; return 2; }
+    if (h->testmode) { h->err = "md2_train_loss: the handle is in test mode (md2_set_testmode(h, 0) = Flux.trainmode! first)"; return 2; }
     h->have_fwd = false; h->prep_done = false;
     if (h->two_streams && h->s2) {          // ordered after everything already on the caller's stream (the previous ADAM step reads G and writes P)
         (void)hipEventRecord(h->ev_p0, h->stream); (void)hipStreamWaitEvent(h->s2, h->ev_p0, 0);
@@ -687,24 +796,20 @@ int32_t md2_adam_step(md2_handle* h, float grad_scale) {
 int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, float* loss, int32_t do_update) {
     if (int r = md2_train_loss(h, x, auto_loss, loss)) return r;
     if (int r = md2_backward(h)) return r;
-    if (do_update) return md2_adam_step(h, 1.f);
+    if (h->comm) { if (int r = md2_allreduce_grads(h)) return r; }                  // data parallel: gradient of the global batch = mean over the ranks
+    if (do_update) return md2_adam_step(h, h->comm ? 1.f / (float)h->world : 1.f);
     return 0;
 }
 int32_t md2_automasking_loss(md2_handle* h, const float* x, float* out) {
-    // photometric of the UNWARPED sources vs the target, min over sources (src/training.jl:9-11)
-    const size_t P = (size_t)h->H * h->W, CP = P * h->C;
-    float* tmp = h->E1;                                                   // [2][N][C][H][W] gather of the two source frames
-    float* tg = h->E2;
-    for (int n = 0; n < h->N; ++n) {
-        HIPCHK(hipMemcpyAsync(tmp + (size_t)n * CP, x + ((size_t)n * 3 + 0) * CP, CP * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(tmp + ((size_t)h->N + n) * CP, x + ((size_t)n * 3 + 2) * CP, CP * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(tg + (size_t)n * CP, x + ((size_t)n * 3 + 1) * CP, CP * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    }
-    return md2_prediction_loss_fwd(tmp, 2, tg, out, h->N, h->C, h->H, h->W, h->stream);
+    // photometric of the UNWARPED sources vs the target, min over sources (src/training.jl:9-11); the frames are read in place
+    if (h->H < 2 || h->W < 2) { h->err = "md2_automasking_loss: image too small"; return 2; }
+    launch_automask(x, out, h->N, h->C, h->H, h->W, 0, 2, 1, h->stream);
+    KCHK(); return 0;
 }
 int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const float* d1, const float* d2, const float* d3, const float* rvec, const float* tvec,
                          const float* auto_loss, float* loss, float* dd0, float* dd1, float* dd2, float* dd3, float* drvec, float* dtvec) {
     const float* disp[4] = {d0, d1, d2, d3};
+    h->have_fwd = false;                    // overwrites Rt / totals of a pending md2_train_loss
     if (int r = loss_forward(h, x, disp, rvec, tvec, auto_loss, loss)) return r;
     if (!(dd0 || dd1 || dd2 || dd3 || drvec || dtvec)) return 0;
     if (int r = loss_backward(h, x, disp, rvec, tvec, auto_loss)) return r;
@@ -718,6 +823,7 @@ int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const f
 
 int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, const float* rvec, const float* tvec, float* loss, float* ddisp, float* drvec, float* dtvec) {
     const float* d4[4] = {disp, disp, disp, disp};
+    h->have_fwd = false;
     if (int r = loss_forward(h, x, d4, rvec, tvec, nullptr, loss, true)) return r;
     if (!(ddisp || drvec || dtvec)) return 0;
     if (int r = loss_backward(h, x, d4, rvec, tvec, nullptr, true)) return r;
@@ -728,9 +834,11 @@ int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, 
 }
 
 // eval_disparity(m, x), src/model.jl:28: encoder + depth decoder on n single frames x [n][C][H][W], n <= batch.
-// BatchNorm uses batch statistics (train mode), like the reference's checkpoints do (src/Monodepth.jl:126,191-194).
+// BatchNorm follows the handle's mode like Flux's: batch statistics under trainmode! (the default, src/Monodepth.jl:126), the tracked running
+// statistics after md2_set_testmode(h, 1) -- what the reference's eval_image / eval_video do (testmode!, src/Monodepth.jl:209,237).
 int32_t md2_eval_disparity(md2_handle* h, const float* x, int32_t n, float* d0, float* d1, float* d2, float* d3) {
     if (n < 1 || n > h->N) { h->err = "md2_eval_disparity: need 1 <= n <= batch"; return 2; }
+    if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
     set_batch(h, n, n);
     int r = model_forward(h, x, 1, 0, false);
     if (!r) {
@@ -799,24 +907,39 @@ static int upload_weights(const float* w_dev, float* w_int, int cin, int cout, i
         in[((size_t)co * k * k + (k - 1 - kh) * k + (k - 1 - kw)) * cinP + ci] = f[(((size_t)co * cin + ci) * k + kh) * k + kw];
     return hipMemcpy(w_int, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess;
 }
-int32_t md2_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
-                       int32_t pad_mode, int32_t act, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
+static int conv2d_fwd_impl(const float* x, const float* w, const float* b, float* y, float* bn_mean, float* bn_invstd, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                           int32_t pad_mode, int32_t act, hipStream_t s) {
     const int cinP = pad16(Cin), coutP = pad16(Cout);
     const int p_eff = pad_mode == PAD_REFLECT ? 1 : pad;
     const int Ho = (H + 2 * p_eff - k) / stride + 1, Wo = (W + 2 * p_eff - k) / stride + 1;
     float *xi = tmp_alloc((size_t)N * H * W * cinP, s), *wi = tmp_alloc((size_t)coutP * k * k * cinP, s), *yi = tmp_alloc((size_t)N * Ho * Wo * coutP, s), *bi = tmp_alloc(coutP, s);
-    if (!xi || !wi || !yi || !bi) return 3;
+    float* st = bn_mean ? tmp_alloc(2 * coutP, s) : nullptr; double* acc = bn_mean ? (double*)tmp_alloc((size_t)4 * BN_STAT_SLOTS * coutP, s) : nullptr;
+    if (!xi || !wi || !yi || !bi || (bn_mean && (!st || !acc))) return 3;
     View xv = make_view(xi, N, H, W, cinP), yv = make_view(yi, N, Ho, Wo, coutP);
     View xs = xv; xs.C = Cin; launch_nchw_to_view(x, xs, s);
     if (upload_weights(w, wi, Cin, Cout, k, cinP, coutP, s)) return 1;
     if (b) (void)hipMemcpyAsync(bi, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s);
     ConvArgs a = conv_args(xv, wi, yv, k, stride, p_eff, 1, pad_mode);
-    a.bias = b ? bi : nullptr; a.act = act;
+    a.bias = b ? bi : nullptr; a.act = act; a.stats = acc;          // stats: fused into the epilogue of the 32-wide tiles, a column-statistics pass otherwise
     launch_conv_igemm(a, s);
+    if (bn_mean) {
+        launch_bn_finalize(acc, st, coutP, (double)yv.pixels(), BN_STAT_SLOTS, nullptr, 0.f, s);
+        (void)hipMemcpyAsync(bn_mean, st, Cout * sizeof(float), hipMemcpyDeviceToDevice, s); (void)hipMemcpyAsync(bn_invstd, st + coutP, Cout * sizeof(float), hipMemcpyDeviceToDevice, s);
+        (void)hipFreeAsync(st, s); (void)hipFreeAsync(acc, s);
+    }
     View ys = yv; ys.C = Cout; launch_nhwc_to_nchw(nullptr, ys, y, s);
     (void)hipFreeAsync(xi, s); (void)hipFreeAsync(wi, s); (void)hipFreeAsync(yi, s); (void)hipFreeAsync(bi, s);
     return hipGetLastError() != hipSuccess;
+}
+int32_t md2_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
+                       int32_t pad_mode, int32_t act, void* stream) {
+    return conv2d_fwd_impl(x, w, b, y, nullptr, nullptr, N, Cin, H, W, Cout, k, stride, pad, pad_mode, act, (hipStream_t)stream);
+}
+// The encoder's conv -> BatchNorm pair: bias-free convolution whose epilogue also accumulates the training-BatchNorm batch statistics (mean, 1/sqrt(var + eps))
+int32_t md2_conv2d_bnstats_fwd(const float* x, const float* w, float* y, float* bn_mean, float* bn_invstd, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k,
+                               int32_t stride, int32_t pad, void* stream) {
+    if (!bn_mean || !bn_invstd) return 2;
+    return conv2d_fwd_impl(x, w, nullptr, y, bn_mean, bn_invstd, N, Cin, H, W, Cout, k, stride, pad, 0, ACT_NONE, (hipStream_t)stream);
 }
 int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride,
                        int32_t pad, int32_t pad_mode, void* stream) {
@@ -871,7 +994,7 @@ int32_t md2_bn_train_fwd(const float* x, const float* gamma, const float* beta, 
     float *xi = tmp_alloc((size_t)N * H * W * C, s), *st = tmp_alloc(2 * C, s); double* acc = (double*)tmp_alloc(4 * C, s);
     if (!xi || !st || !acc) return 3;
     View v = make_view(xi, N, H, W, C); launch_nchw_to_view(x, v, s);
-    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), 1, s);
+    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), 1, nullptr, 0.f, s);
     launch_bn_apply(v, st, gamma, beta, nullptr, relu ? ACT_RELU : ACT_NONE, v, s);
     launch_nhwc_to_nchw(nullptr, v, y, s);
     (void)hipFreeAsync(xi, s); (void)hipFreeAsync(st, s); (void)hipFreeAsync(acc, s);
@@ -885,7 +1008,7 @@ int32_t md2_bn_train_bwd(const float* x, const float* gamma, const float* dy, fl
     if (!xi || !di || !oi || !st || !acc) return 3;
     View v = make_view(xi, N, H, W, C), d = make_view(di, N, H, W, C), o = make_view(oi, N, H, W, C);
     launch_nchw_to_view(x, v, s); launch_nchw_to_view(dy, d, s);
-    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), 1, s);
+    launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), 1, nullptr, 0.f, s);
     (void)hipMemsetAsync(dgamma, 0, C * sizeof(float), s); (void)hipMemsetAsync(dbeta, 0, C * sizeof(float), s);
     launch_bn_bwd_reduce(d, nullptr, ACT_NONE, v, st, acc + 2 * C, s);
     launch_bn_bwd_apply(d, nullptr, ACT_NONE, v, st, gamma, acc + 2 * C, (double)v.pixels(), o, dgamma, dbeta, s);
@@ -919,6 +1042,167 @@ int32_t md2_adam_raw(float* p, const float* g, float* m, float* v, int64_t n, in
     if (n <= 0 || step < 1) return 2;
     launch_adam(p, g, m, v, (long)n, (float)(1.0 - std::pow(0.9, step)), (float)(1.0 - std::pow(0.999, step)), (float)lr, grad_scale, (hipStream_t)stream);
     return hipGetLastError() != hipSuccess;
+}
+
+
+// ---- Flux.testmode! / trainmode!, the BatchNorm running statistics, deterministic mode ------------------------------------------------
+int32_t md2_set_testmode(md2_handle* h, int32_t on) { h->testmode = on != 0; h->have_fwd = false; h->prep_done = false; return 0; }
+int64_t md2_bn_state_count(md2_handle* h) { return h->n_rs; }
+int32_t md2_bn_state_get(md2_handle* h, float* host, int64_t n) {
+    if (n != h->n_rs) { h->err = "md2_bn_state_get: wrong element count"; return 2; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(host, h->RS, (size_t)n * sizeof(float), hipMemcpyDeviceToHost)); return 0;
+}
+int32_t md2_bn_state_set(md2_handle* h, const float* host, int64_t n) {
+    if (n != h->n_rs) { h->err = "md2_bn_state_set: wrong element count"; return 2; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(h->RS, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); return 0;
+}
+int32_t md2_set_deterministic(int32_t on) { g_deterministic = on != 0; return 0; }
+int32_t md2_set_lr(md2_handle* h, double lr) { if (!(lr > 0)) { h->err = "md2_set_lr: lr must be positive"; return 2; } h->cfg.lr = lr; return 0; }
+
+// ---- op-level hooks for the direct kernels the network uses besides the implicit GEMM (parity tests) ------------------------------------
+// ResNet stem (7x7, stride 2, pad 3, no bias): x [N][C][H][W], w Flux [64][C][7][7] -> z [N][64][H/2][W/2]; bn_mean / bn_invstd [64] (optional) are the
+// training-BatchNorm statistics the kernel's epilogue accumulates
+int32_t md2_stem_conv_fwd(const float* x, const float* w, float* z, float* bn_mean, float* bn_invstd, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if ((C != 1 && C != 3) || (H & 1) || (W & 1) || H < 8 || W < 8) return 2;
+    const int Kpad = (49 * C + 15) / 16 * 16, Ho = H / 2, Wo = W / 2;
+    std::vector<float> f((size_t)64 * C * 49), in((size_t)64 * Kpad, 0.f);
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(f.data(), w, f.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    for (int co = 0; co < 64; ++co) for (int ci = 0; ci < C; ++ci) for (int kh = 0; kh < 7; ++kh) for (int kw = 0; kw < 7; ++kw)
+        in[(size_t)co * Kpad + ((6 - kh) * 7 + (6 - kw)) * C + ci] = f[(((size_t)co * C + ci) * 7 + kh) * 7 + kw];
+    float *wi = tmp_alloc(in.size(), s), *zi = tmp_alloc((size_t)N * Ho * Wo * 64, s), *st = tmp_alloc(128, s); double* acc = (double*)tmp_alloc((size_t)2 * BN_STAT_SLOTS * 128, s);
+    if (!wi || !zi || !st || !acc) return 3;
+    if (hipMemcpy(wi, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return 1;
+    View zv = make_view(zi, N, Ho, Wo, 64);
+    const bool fused = !g_deterministic;
+    launch_stem_fwd(x, N, C, H, W, wi, Kpad, zv, (bn_mean && fused) ? acc : nullptr, s);
+    if (bn_mean && !fused) launch_colstats(zv, acc, s);
+    if (bn_mean) {
+        launch_bn_finalize(acc, st, 64, (double)zv.pixels(), BN_STAT_SLOTS, nullptr, 0.f, s);
+        (void)hipMemcpyAsync(bn_mean, st, 64 * sizeof(float), hipMemcpyDeviceToDevice, s); (void)hipMemcpyAsync(bn_invstd, st + 64, 64 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
+    launch_nhwc_to_nchw(nullptr, zv, z, s);
+    (void)hipFreeAsync(wi, s); (void)hipFreeAsync(zi, s); (void)hipFreeAsync(st, s); (void)hipFreeAsync(acc, s);
+    return hipGetLastError() != hipSuccess;
+}
+// dz [N][64][H/2][W/2] -> dw Flux [64][C][7][7]
+int32_t md2_stem_conv_wgrad(const float* x, const float* dz, float* dw, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if ((C != 1 && C != 3) || (H & 1) || (W & 1) || H < 8 || W < 8) return 2;
+    const int Kpad = (49 * C + 15) / 16 * 16, Ho = H / 2, Wo = W / 2;
+    float *gi = tmp_alloc((size_t)64 * Kpad, s), *di = tmp_alloc((size_t)N * Ho * Wo * 64, s);
+    if (!gi || !di) return 3;
+    View dv = make_view(di, N, Ho, Wo, 64); launch_nchw_to_view(dz, dv, s);
+    launch_stem_wgrad(x, N, C, H, W, dv, gi, Kpad, s);
+    std::vector<float> in((size_t)64 * Kpad), f((size_t)64 * C * 49);
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(in.data(), gi, in.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    for (int co = 0; co < 64; ++co) for (int ci = 0; ci < C; ++ci) for (int kh = 0; kh < 7; ++kh) for (int kw = 0; kw < 7; ++kw)
+        f[(((size_t)co * C + ci) * 7 + kh) * 7 + kw] = in[(size_t)co * Kpad + ((6 - kh) * 7 + (6 - kw)) * C + ci];
+    if (hipMemcpy(dw, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return 1;
+    (void)hipFreeAsync(gi, s); (void)hipFreeAsync(di, s);
+    return hipGetLastError() != hipSuccess;
+}
+// disparity head (src/depth_decoder.jl:43): reflect-pad + 3x3 conv to ONE channel + sigmoid.  x [N][Cin][H][W], w Flux [1][Cin][3][3], b [1] -> y [N][1][H][W]
+static int head_weights(const float* w_dev, float* w_int, int Cin, hipStream_t s) {
+    std::vector<float> f((size_t)Cin * 9), in((size_t)9 * Cin);
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(f.data(), w_dev, f.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    for (int ci = 0; ci < Cin; ++ci) for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) in[(size_t)((2 - kh) * 3 + (2 - kw)) * Cin + ci] = f[((size_t)ci * 3 + kh) * 3 + kw];
+    return hipMemcpy(w_int, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess;
+}
+int32_t md2_head_conv_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if ((Cin != 16 && Cin != 32 && Cin != 64 && Cin != 128) || H < 3 || W < 3) return 2;
+    float *xi = tmp_alloc((size_t)N * H * W * Cin, s), *wi = tmp_alloc((size_t)9 * Cin, s);
+    if (!xi || !wi) return 3;
+    View xv = make_view(xi, N, H, W, Cin); launch_nchw_to_view(x, xv, s);
+    if (head_weights(w, wi, Cin, s)) return 1;
+    launch_head_fwd(xv, wi, b, make_view(y, N, H, W, 1), s);
+    (void)hipFreeAsync(xi, s); (void)hipFreeAsync(wi, s);
+    return hipGetLastError() != hipSuccess;
+}
+// pullback: dy [N][1][H][W] -> dx [N][Cin][H][W], dw Flux [1][Cin][3][3], db [1].  x_act: 0, or 2 (ELU) when x is the ELU OUTPUT of its producer and
+// dx is wanted with respect to the pre-activation (how the last decoder branch uses it)
+int32_t md2_head_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t x_act, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if ((Cin != 16 && Cin != 32 && Cin != 64 && Cin != 128) || H < 3 || W < 3) return 2;
+    const size_t n = (size_t)N * H * W * Cin;
+    float *xi = tmp_alloc(n, s), *oi = tmp_alloc(n, s), *wi = tmp_alloc((size_t)9 * Cin, s), *gi = tmp_alloc((size_t)9 * Cin, s), *gb = tmp_alloc(4, s);
+    if (!xi || !oi || !wi || !gi || !gb) return 3;
+    View xv = make_view(xi, N, H, W, Cin), ov = make_view(oi, N, H, W, Cin); launch_nchw_to_view(x, xv, s);
+    if (head_weights(w, wi, Cin, s)) return 1;
+    launch_head_bwd(xv, wi, make_view(const_cast<float*>(y), N, H, W, 1), make_view(const_cast<float*>(dy), N, H, W, 1), ov, 0, x_act, gi, gb, s);
+    launch_nhwc_to_nchw(nullptr, ov, dx, s);
+    std::vector<float> in((size_t)9 * Cin), f((size_t)Cin * 9);
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(in.data(), gi, in.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    for (int ci = 0; ci < Cin; ++ci) for (int kh = 0; kh < 3; ++kh) for (int kw = 0; kw < 3; ++kw) f[((size_t)ci * 3 + kh) * 3 + kw] = in[(size_t)((2 - kh) * 3 + (2 - kw)) * Cin + ci];
+    if (hipMemcpy(dw, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return 1;
+    (void)hipMemcpyAsync(db, gb, sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipFreeAsync(xi, s); (void)hipFreeAsync(oi, s); (void)hipFreeAsync(wi, s); (void)hipFreeAsync(gi, s); (void)hipFreeAsync(gb, s);
+    return hipGetLastError() != hipSuccess;
+}
+
+
+// ---- data parallelism over RCCL (one process per GPU; the insertion point in the reference's loop is the update!, src/Monodepth.jl:170) -------------
+// rank 0 creates the 128-byte id and hands it to the other ranks by whatever channel the host has (MPI, a file, a TCP store, torch.distributed ...)
+int32_t md2_comm_unique_id(void* out128) {
+    if (!out128) return 2;
+    if (!rccl_load()) { g_create_err = g_rccl.err; return 3; }
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) { g_create_err = "ncclGetUniqueId failed"; return 1; }
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(out128, &id, sizeof(id)); return 0;
+}
+int32_t md2_comm_init(md2_handle* h, int32_t rank, int32_t world, const void* unique_id128) {
+    if (world < 1 || rank < 0 || rank >= world || !unique_id128) { h->err = "md2_comm_init: bad rank / world / id"; return 2; }
+    if (!rccl_load()) { h->err = g_rccl.err; return 3; }
+    if (h->comm) comm_destroy(h);
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h->scomm) {
+        int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&h->scomm, hipStreamNonBlocking, hi));              // the collective must not queue behind the compute it overlaps
+        for (int i = 0; i < 8; ++i) { HIPCHK(hipEventCreateWithFlags(&h->ev_cm[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_cs[i], hipEventDisableTiming)); }
+        HIPCHK(hipEventCreateWithFlags(&h->ev_cdone, hipEventDisableTiming));
+    }
+    ncclUniqueId id; std::memcpy(&id, unique_id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&c, world, id, rank));
+    h->comm = c; h->rank = rank; h->world = world; h->grads_reduced = false;
+    return 0;
+}
+int32_t md2_comm_destroy(md2_handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); if (h->scomm) HIPCHK(hipStreamSynchronize(h->scomm)); comm_destroy(h); return 0; }
+int32_t md2_comm_world(md2_handle* h, int32_t* rank, int32_t* world) { if (rank) *rank = h->rank; if (world) *world = h->world; return 0; }
+// gradient(theta) summed over the ranks.  md2_backward already did it bucket by bucket (overlapped with the pullback) when a communicator is attached; this is then a no-op.
+int32_t md2_allreduce_grads(md2_handle* h) {
+    if (!h->comm) { h->err = "md2_allreduce_grads: call md2_comm_init first"; return 2; }
+    if (h->grads_reduced) return 0;
+    NCCLCHK(g_rccl.AllReduce(h->G, h->G, (size_t)h->n_int, ncclFloat, ncclSum, (ncclComm_t)h->comm, h->stream));
+    h->grads_reduced = true; return 0;
+}
+// in-place sum over the ranks of any device fp32 buffer on the handle's stream (loss logging, self-checks)
+int32_t md2_comm_allreduce(md2_handle* h, float* dev_buf, int64_t n) {
+    if (!h->comm) { h->err = "md2_comm_allreduce: call md2_comm_init first"; return 2; }
+    NCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)n, ncclFloat, ncclSum, (ncclComm_t)h->comm, h->stream)); return 0;
+}
+// replicas must start identical: parameters, ADAM moments, BatchNorm running statistics and the beta powers of `root` go to every rank
+int32_t md2_broadcast_state(md2_handle* h, int32_t root) {
+    if (!h->comm) { h->err = "md2_broadcast_state: call md2_comm_init first"; return 2; }
+    h->have_fwd = false; h->prep_done = false;
+    double bp[2] = {h->beta1p, h->beta2p}; double* dbp = nullptr;
+    HIPCHK(hipMalloc((void**)&dbp, sizeof(bp))); HIPCHK(hipMemcpy(dbp, bp, sizeof(bp), hipMemcpyHostToDevice));
+    ncclComm_t c = (ncclComm_t)h->comm;
+    NCCLCHK(g_rccl.GroupStart());
+    NCCLCHK(g_rccl.Broadcast(h->P, h->P, (size_t)h->n_int, ncclFloat, root, c, h->stream));
+    NCCLCHK(g_rccl.Broadcast(h->M, h->M, (size_t)h->n_int, ncclFloat, root, c, h->stream));
+    NCCLCHK(g_rccl.Broadcast(h->V, h->V, (size_t)h->n_int, ncclFloat, root, c, h->stream));
+    NCCLCHK(g_rccl.Broadcast(h->RS, h->RS, (size_t)h->n_rs, ncclFloat, root, c, h->stream));
+    NCCLCHK(g_rccl.Broadcast(dbp, dbp, 2, ncclDouble, root, c, h->stream));
+    NCCLCHK(g_rccl.GroupEnd());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(bp, dbp, sizeof(bp), hipMemcpyDeviceToHost)); (void)hipFree(dbp);
+    h->beta1p = bp[0]; h->beta2p = bp[1];
+    return 0;
 }
 
 }  // extern "C"

@@ -12,6 +12,11 @@ namespace md2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// MD2_DETERMINISTIC=1 (read by md2_create) or md2_set_deterministic(): every cross-workgroup reduction is done in a fixed order -- no split-K,
+// one workgroup per weight-gradient tile, BatchNorm / bias sums by a single workgroup per channel group, per-block loss partials summed
+// sequentially -- so two runs on the same inputs are bit-identical.  Much slower; exists to bisect parity failures.
+extern int g_deterministic;
+
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
@@ -112,7 +117,8 @@ void launch_nchw_to_view(const float* src, const View& v, hipStream_t s);
 // per-channel sum / sum of squares of a view -> double[2*C] (must be zeroed by caller)
 void launch_colstats(const View& z, double* acc, hipStream_t s);
 // mean/invstd from acc; also zeroes nothing.  stats: float[2*C] = mean, invstd
-void launch_bn_finalize(const double* acc /*[slots][2C]*/, float* stats, int C, double count, int slots, hipStream_t s);
+void launch_bn_finalize(const double* acc /*[slots][2C]*/, float* stats, int C, double count, int slots, float* running /* [2C] or null */, float momentum, hipStream_t s);
+void launch_bn_stats_from_running(const float* running, float* stats, int C, hipStream_t s);
 // y = act(gamma*(z-mean)*invstd + beta + residual)
 void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s);
 // g = dy * act_deriv(yact) ; acc[0..C) += sum g ; acc[C..2C) += sum g*xhat          (acc double, zeroed by caller)
@@ -156,11 +162,14 @@ struct LossArgs {
     int normalize;             // 1: smooth_loss(d / (mean(d)+1e-7)) (train_loss, src/training.jl:64-67); 0: smooth_loss(d) (slow_depth, src/simple_depth.jl:39)
 };
 // per-scale partial sums -> part[(scale*N + n)*4 + {photo, sum d, Sx, Sy}] (double atomics; zeroed by caller)
-void launch_loss_fwd(const LossArgs& a, double* part, hipStream_t s);
+// blk (deterministic mode, else null): per-block partials [nscales*N][blocks][4] summed in order by launch_loss_part_reduce instead of atomics
+void launch_loss_fwd(const LossArgs& a, double* part, double* blk, hipStream_t s);
+int loss_blocks_per_image(const LossArgs& a);
 // totals[(scale*N+n)*4+..] float copy + scalar loss
 void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, float* loss, hipStream_t s);
 // backward: ddisp_full[scale][N][H][W] ; dRt partials -> dRt_acc double [2][N][12] (zeroed by caller)
-void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, hipStream_t s);
+void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, double* blk /* [nscales*N][blocks][24] or null */, hipStream_t s);
+void launch_automask(const float* x, float* out, int N, int C, int H, int W, int src0, int src1, int tgt, hipStream_t s);
 // planar bilinear (align-corners) upsample adjoint, gather form: [planes][Ho][Wo] -> [planes][H][W]
 void launch_upsample_planar_bwd(const float* dout, float* dx, int planes, int H, int W, int Ho, int Wo, hipStream_t s);
 void launch_upsample_planar_fwd(const float* x, float* out, int planes, int H, int W, int Ho, int Wo, hipStream_t s);

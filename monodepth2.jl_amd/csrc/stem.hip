@@ -284,7 +284,7 @@ void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& 
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, 256, lds) != hipSuccess || pc < 1) pc = 1;
         pc = std::min(pc, 3);
     }
-    const int gx = std::max(1, std::min(total, 256 * pc / kgroups));       // persistent: the co-resident blocks, shared by the k groups
+    const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * pc / kgroups));       // persistent: the co-resident blocks, shared by the k groups
     if (C == 1) hipLaunchKernelGGL(stem_wgrad_kernel<1>, dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total);
     else hipLaunchKernelGGL(stem_wgrad_kernel<3>, dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total);
 }

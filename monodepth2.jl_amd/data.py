@@ -196,13 +196,16 @@ class DataLoader:
     """DataLoader(shuffleobs(data), batch_size) (src/Monodepth.jl:158): full batches only (partial = false is DataLoaders.jl's
     default), samples collated into ONE reusable pinned host buffer per slot so the H2D copy can be asynchronous."""
 
-    def __init__(self, dataset, batch_size, shuffle=False, seed=0, pin_memory=True, slots=2):
+    def __init__(self, dataset, batch_size, shuffle=False, seed=0, pin_memory=True, slots=2, shard=(0, 1)):
+        """shard = (rank, world): every rank draws the same permutation (same seed) of GLOBAL batches of batch_size * world samples and decodes only its own
+        contiguous slice of each (data parallelism: host IO per rank stays constant as the world grows)."""
         self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
         self.rng = np.random.default_rng(seed)
         self.pin, self.slots, self._bufs = pin_memory, max(1, slots), None
+        self.rank, self.world = shard
 
     def __len__(self):
-        return len(self.dataset) // self.batch_size
+        return len(self.dataset) // (self.batch_size * self.world)
 
     def _buffers(self, shape):
         if self._bufs is None or tuple(self._bufs[0].shape) != shape:
@@ -213,13 +216,15 @@ class DataLoader:
 
     def __iter__(self):
         order = self.rng.permutation(len(self.dataset)) if self.shuffle else np.arange(len(self.dataset))
+        G = self.batch_size * self.world
         for b in range(len(self)):
-            first = self.dataset[int(order[b * self.batch_size])]
+            base = b * G + self.rank * self.batch_size
+            first = self.dataset[int(order[base])]
             buf = self._buffers((self.batch_size,) + first.shape)[b % self.slots]
             view = buf.numpy()
             view[0] = first
             for j in range(1, self.batch_size):
-                view[j] = self.dataset[int(order[b * self.batch_size + j])]
+                view[j] = self.dataset[int(order[base + j])]
             yield buf
 
 

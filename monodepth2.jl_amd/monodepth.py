@@ -255,6 +255,8 @@ class Model:
         self._params_host = None
         self._cfg_extra = dict(min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, automasking=False)
         self._K = None
+        self._testmode = False
+        self._comm_spec = None
 
     # -- handle management --------------------------------------------------------------------
     def _ensure(self, x, parameters: Optional[Params] = None, cache: Optional[TrainCache] = None):
@@ -267,8 +269,13 @@ class Model:
                          disparity_smoothness=parameters.disparity_smoothness, automasking=bool(parameters.automasking))
         key = (N, Cc, H, W, tuple(sorted(extra.items())), x.device.index)
         if self._h is not None and key == self._shape:
+            if cache is not None:                 # the reference reads cache.K / cache.invK on every call (src/training.jl:48-57)
+                self.set_intrinsics(cache.K, cache.invK)
             return
+        # a new shape / Params needs a new handle: carry the weights AND the optimiser / BatchNorm state across, or training would silently restart ADAM
         saved = self.params() if self._h is not None else self._params_host
+        state = self._opt_and_bn_state() if self._h is not None else None
+        comm = self._comm_spec
         self.close()
         cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr,
                              self.encoder.depth, 1 if self.precision == "bf16" else 0)
@@ -277,14 +284,60 @@ class Model:
         self._h, self._shape, self._cfg_extra = h, key, extra
         if saved is not None:
             self.load_params(saved)
+        if state is not None:
+            self._restore_opt_and_bn_state(state)
+        if self._testmode:
+            _check(_lib.lib().md2_set_testmode(self._h, 1), self._h)
+        if comm is not None:
+            raise RuntimeError("the handle had to be rebuilt (new batch / resolution / Params) while an RCCL communicator was attached: call comm_init again on every rank")
         if cache is not None:
             self.set_intrinsics(cache.K, cache.invK)
         elif self._K is not None:
             self.set_intrinsics(*self._K)
 
+    def _opt_and_bn_state(self):
+        L = _lib.lib(); n = L.md2_params_count(self._h)
+        mm = np.empty(n, np.float32); vv = np.empty(n, np.float32); b1 = C.c_double(); b2 = C.c_double()
+        _check(L.md2_opt_state_get(self._h, mm.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), n, C.byref(b1), C.byref(b2)), self._h, "opt_state_get")
+        return mm, vv, b1.value, b2.value, self.bn_state()
+
+    def _restore_opt_and_bn_state(self, state):
+        mm, vv, b1, b2, bn = state; L = _lib.lib()
+        _check(L.md2_opt_state_set(self._h, mm.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), mm.size, float(b1), float(b2)), self._h, "opt_state_set")
+        self.load_bn_state(bn)
+
+    # -- Flux BatchNorm state: running mean / variance per BatchNorm (what `@save model_host` keeps besides the weights) -----------------------
+    def bn_state(self):
+        n = _lib.lib().md2_bn_state_count(self._h); out = np.empty(n, np.float32)
+        _check(_lib.lib().md2_bn_state_get(self._h, out.ctypes.data_as(C.c_void_p), n), self._h, "bn_state_get"); return out
+
+    def load_bn_state(self, st):
+        st = np.ascontiguousarray(st, np.float32)
+        _check(_lib.lib().md2_bn_state_set(self._h, st.ctypes.data_as(C.c_void_p), st.size), self._h, "bn_state_set")
+
     def close(self):
         if self._h is not None:
             _lib.lib().md2_destroy(self._h); self._h = None
+        self._comm_spec = None
+
+    # -- data parallelism: the library's own RCCL communicator (include/md2hip.h, md2_comm_*) -------------------------------------------
+    def comm_init(self, rank, world, unique_id):
+        """Attach an RCCL communicator: `unique_id` = the 128 bytes rank 0 got from `comm_unique_id()`, passed around by the host."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        _check(_lib.lib().md2_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p)), self._h, "comm_init")
+        self._comm_spec = (rank, world)
+
+    def broadcast_state(self, root=0):
+        _lib.lib().md2_set_stream(self._h, _stream())
+        _check(_lib.lib().md2_broadcast_state(self._h, int(root)), self._h, "broadcast_state")
+
+    def allreduce_grads(self):
+        _lib.lib().md2_set_stream(self._h, _stream())
+        _check(_lib.lib().md2_allreduce_grads(self._h), self._h, "allreduce_grads")
+
+    def comm_allreduce(self, t):
+        _lib.lib().md2_set_stream(self._h, _stream())
+        _check(_lib.lib().md2_comm_allreduce(self._h, _dev(t), t.numel()), self._h, "comm_allreduce"); return t
 
     def __del__(self):
         try:
@@ -322,6 +375,11 @@ class Model:
         _check(_lib.lib().md2_grad_buffer(self._h, C.byref(p), C.byref(n)), self._h)
         return _wrap_device_buffer(p.value, n.value, self._shape[-1] or 0)
 
+    def param_buffer(self):
+        p = C.c_void_p(); n = C.c_int64()
+        _check(_lib.lib().md2_param_buffer(self._h, C.byref(p), C.byref(n)), self._h)
+        return _wrap_device_buffer(p.value, n.value, self._shape[-1] or 0)
+
     # -- forward --------------------------------------------------------------------------------
     def __call__(self, x, source_ids, target_id):
         if list(source_ids) != [1, 3] or target_id != 2:
@@ -353,7 +411,7 @@ def save_checkpoint(m: Model, path):
     n = _lib.lib().md2_params_count(m._h)
     mm = np.empty(n, np.float32); vv = np.empty(n, np.float32); b1 = C.c_double(); b2 = C.c_double()
     _check(_lib.lib().md2_opt_state_get(m._h, mm.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), n, C.byref(b1), C.byref(b2)), m._h, "opt_state_get")
-    np.savez(path, params=m.params(), adam_m=mm, adam_v=vv, beta1p=b1.value, beta2p=b2.value, in_channels=m.encoder.in_channels, encoder_depth=m.encoder.depth, lr=m.lr)
+    np.savez(path, params=m.params(), adam_m=mm, adam_v=vv, beta1p=b1.value, beta2p=b2.value, bn_state=m.bn_state(), in_channels=m.encoder.in_channels, encoder_depth=m.encoder.depth, lr=m.lr)
 
 
 def load_checkpoint(m: Model, path):
@@ -367,6 +425,31 @@ def load_checkpoint(m: Model, path):
         raise RuntimeError("load_checkpoint: run the model once (or call model._ensure) before restoring the optimiser state")
     mm = np.ascontiguousarray(ck["adam_m"], np.float32); vv = np.ascontiguousarray(ck["adam_v"], np.float32)
     _check(_lib.lib().md2_opt_state_set(m._h, mm.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), mm.size, float(ck["beta1p"]), float(ck["beta2p"])), m._h, "opt_state_set")
+    if "bn_state" in ck:                  # BatchNorm running statistics: needed to reproduce test-mode inference (eval_image / eval_video, src/Monodepth.jl:209,237)
+        m.load_bn_state(ck["bn_state"])
+
+
+def testmode(m: Model, on=True):
+    """Flux.testmode!(model) / trainmode!(model): BatchNorm uses its tracked running statistics (src/Monodepth.jl:126,209,237)."""
+    m._testmode = bool(on)
+    if m._h is not None:
+        _check(_lib.lib().md2_set_testmode(m._h, int(bool(on))), m._h, "set_testmode")
+
+
+def trainmode(m: Model):
+    testmode(m, False)
+
+
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it; every rank passes the same bytes to Model.comm_init)."""
+    buf = (C.c_char * 128)()
+    _check(_lib.lib().md2_comm_unique_id(C.cast(buf, C.c_void_p)), None, "comm_unique_id")
+    return bytes(buf)
+
+
+def set_deterministic(on=True):
+    """Bit-reproducible (ordered reductions, no split-K) mode of the whole library: for bisecting parity failures, much slower."""
+    _check(_lib.lib().md2_set_deterministic(int(bool(on))), None, "set_deterministic")
 
 
 class _DevBuf:
@@ -421,8 +504,11 @@ class ADAM:
 
 
 def update(optimizer: ADAM, model: Model, grad_scale=1.0):
-    """Flux.Optimise.update!(optimizer, theta, grads)."""
+    """Flux.Optimise.update!(optimizer, theta, grads) — the step size is the optimiser's eta."""
     _lib.lib().md2_set_stream(model._h, _stream())
+    if optimizer is not None and optimizer.eta != model.lr:
+        model.lr = optimizer.eta
+        _check(_lib.lib().md2_set_lr(model._h, float(optimizer.eta)), model._h, "set_lr")
     _check(_lib.lib().md2_adam_step(model._h, float(grad_scale)), model._h, "adam_step")
 
 
@@ -558,3 +644,38 @@ def maxpool3s2_pullback(x, dy):
 
 def adam_raw(p, g, m, v, step, lr=1e-4, grad_scale=1.0):
     _check(_lib.lib().md2_adam_raw(_dev(p), _dev(g), _dev(m), _dev(v), p.numel(), int(step), float(lr), float(grad_scale), _stream()), None, "adam_raw")
+
+
+def conv2d_bnstats(x, w, stride=1, pad=0):
+    """Encoder conv (no bias) + the training-BatchNorm statistics its epilogue accumulates: -> (y, mean[Cout], invstd[Cout])."""
+    x, w = _f32(x), _f32(w); N, Cin, H, W = x.shape; Cout, _, k, _ = w.shape
+    Ho = (H + 2 * pad - k) // stride + 1; Wo = (W + 2 * pad - k) // stride + 1
+    y = torch.empty(N, Cout, Ho, Wo, device=x.device); mean = torch.empty(Cout, device=x.device); invstd = torch.empty(Cout, device=x.device)
+    _check(_lib.lib().md2_conv2d_bnstats_fwd(_dev(x), _dev(w), _dev(y), _dev(mean), _dev(invstd), N, Cin, H, W, Cout, k, stride, pad, _stream()), None, "conv2d_bnstats_fwd")
+    return y, mean, invstd
+
+
+def stem_conv(x, w, want_stats=True):
+    """The ResNet stem through its direct kernel: x (N,C,H,W), w (64,C,7,7) Flux layout -> (z (N,64,H/2,W/2), mean, invstd)."""
+    x, w = _f32(x), _f32(w); N, Cc, H, W = x.shape
+    z = torch.empty(N, 64, H // 2, W // 2, device=x.device); mean = torch.empty(64, device=x.device) if want_stats else None; invstd = torch.empty(64, device=x.device) if want_stats else None
+    _check(_lib.lib().md2_stem_conv_fwd(_dev(x), _dev(w), _dev(z), _dev(mean), _dev(invstd), N, Cc, H, W, _stream()), None, "stem_conv_fwd")
+    return z, mean, invstd
+
+
+def stem_conv_wgrad(x, dz):
+    x, dz = _f32(x), _f32(dz); N, Cc, H, W = x.shape; dw = torch.empty(64, Cc, 7, 7, device=x.device)
+    _check(_lib.lib().md2_stem_conv_wgrad(_dev(x), _dev(dz), _dev(dw), N, Cc, H, W, _stream()), None, "stem_conv_wgrad"); return dw
+
+
+def head_conv(x, w, b):
+    """Disparity head: sigmoid(conv3x3(pad_reflect(x)) + b), x (N,Cin,H,W), w (1,Cin,3,3), b (1,) -> (N,1,H,W)."""
+    x, w, b = _f32(x), _f32(w), _f32(b); N, Cin, H, W = x.shape; y = torch.empty(N, 1, H, W, device=x.device)
+    _check(_lib.lib().md2_head_conv_fwd(_dev(x), _dev(w), _dev(b), _dev(y), N, Cin, H, W, _stream()), None, "head_conv_fwd"); return y
+
+
+def head_conv_pullback(x, w, y, dy, x_act="none"):
+    x, w, y, dy = _f32(x), _f32(w), _f32(y), _f32(dy); N, Cin, H, W = x.shape
+    dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty(1, device=x.device)
+    _check(_lib.lib().md2_head_conv_bwd(_dev(x), _dev(w), _dev(y), _dev(dy), _dev(dx), _dev(dw), _dev(db), N, Cin, H, W, {"none": 0, "elu": 2}[x_act], _stream()), None, "head_conv_bwd")
+    return dx, dw, db

@@ -50,13 +50,53 @@ def broadcast_params_(flat, src=0, group=None):
 
 
 class DataParallel:
-    """Wraps a Model: step = local fwd+bwd -> all-reduce(sum) of the gradient buffer -> ADAM(grad_scale = 1/world)."""
+    """Wraps a Model for data-parallel training.
 
-    def __init__(self, model, group=None):
+    comm="rccl" (default when torch.distributed runs on the nccl backend): the LIBRARY's own RCCL communicator (md2_comm_init) — the same path a Julia
+    host uses: md2_backward all-reduces the flat gradient buffer bucket by bucket on a communication stream while the rest of the pullback computes, and
+    md2_train_step applies ADAM to the mean.  torch.distributed only carries the 128-byte RCCL id from rank 0 to the others.
+    comm="torch": local fwd+bwd -> torch.distributed all-reduce(sum) of the wrapped gradient buffer -> ADAM(grad_scale = 1/world); the cross-check, and the only
+    choice on a gloo group (CPU transport, e.g. two ranks rehearsing on one card).
+
+    Construction makes the replicas identical: parameters, ADAM moments, beta powers and BatchNorm running statistics of rank 0 are broadcast."""
+
+    def __init__(self, model, group=None, comm=None, x_like=None, parameters=None, cache=None):
         self.model, self.group = model, group
+        w = world_size(group)
+        if comm is None:
+            comm = "rccl" if (w > 1 and dist.get_backend(group) == "nccl") else "torch"
+        self.comm = comm
+        self._ready = False
+        if x_like is not None:
+            self._setup(x_like, parameters, cache)
+
+    def _setup(self, x, parameters, cache):
+        """Needs the handle (shape-specific), so it runs with the first batch."""
+        from . import monodepth as md
+        self.model._ensure(md._f32(x), parameters, cache)
+        w = world_size(self.group)
+        if self.comm == "rccl":
+            rank = dist.get_rank(self.group) if w > 1 else 0
+            ids = [md.comm_unique_id() if rank == 0 else None]
+            if w > 1:
+                dist.broadcast_object_list(ids, src=0, group=self.group)
+            self.model.comm_init(rank, w, ids[0])
+            self.model.broadcast_state(0)
+        elif w > 1:
+            flat = self.model.param_buffer(); broadcast_params_(flat, 0, self.group)
+            # ADAM moments / BatchNorm statistics travel through the host copies (rare: construction only)
+            st = list(self.model._opt_and_bn_state())
+            obj = [st if dist.get_rank(self.group) == 0 else None]
+            dist.broadcast_object_list(obj, src=0, group=self.group)
+            self.model._restore_opt_and_bn_state(tuple(obj[0]))
+        self._ready = True
 
     def train_step(self, x, auto_loss, cache, parameters):
         from . import monodepth as md
+        if not self._ready:
+            self._setup(x, parameters, cache)
+        if self.comm == "rccl":
+            return md.train_step(self.model, x, auto_loss, cache, parameters, do_update=True)       # all-reduce + ADAM(1/world) inside the library
         loss = md.train_step(self.model, x, auto_loss, cache, parameters, do_update=False)
         self.allreduce_and_update()
         return loss
@@ -64,5 +104,8 @@ class DataParallel:
     def allreduce_and_update(self):
         """After a local `gradient(model)`: sum the gradient buffers over the ranks, then ADAM on the mean."""
         from . import monodepth as md
-        allreduce_sum_(self.model.grad_buffer(), self.group)
+        if self.comm == "rccl":
+            self.model.allreduce_grads()
+        else:
+            allreduce_sum_(self.model.grad_buffer(), self.group)
         md.update(md.ADAM(self.model.lr), self.model, grad_scale=1.0 / world_size(self.group))

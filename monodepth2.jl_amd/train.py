@@ -40,15 +40,17 @@ def train(datasets, log_dir, save_dir, batch_size=4, n_epochs=20, log_iter=50, s
                           dataset.target_id, list(dataset.source_ids), scales)
     if model is None:
         model = build_model(in_channels, lr=lr)
+    model.lr = lr                                             # ADAM's eta lives in the model's handle configuration: `lr` wins over a passed-in model's
     optimizer = md.ADAM(lr)
-    dp = par.DataParallel(model) if world > 1 else None
+    dp = None
     losses, it = [], 0
     for epoch in range(1, n_epochs + 1):
-        # every rank draws the same permutation (same seed) and takes its slice of each global batch
-        loader = D.DataLoader(dchain, batch_size * world, shuffle=True, seed=seed + epoch)
+        # every rank draws the same permutation (same seed) and decodes only its own slice of each global batch
+        loader = D.DataLoader(dchain, batch_size, shuffle=True, seed=seed + epoch, shard=(rank, world))
         for i, x_host in enumerate(loader, start=1):
-            lo, hi = par.shard_range(batch_size * world, rank, world)
-            x = x_host[lo:hi].cuda(non_blocking=True)
+            x = x_host.cuda(non_blocking=True)
+            if world > 1 and dp is None:                      # first batch: the handle exists now -> attach the communicator, make the replicas identical
+                dp = par.DataParallel(model, x_like=x, parameters=parameters, cache=cache)
             auto_loss = None
             if parameters.automasking:                      # computed outside AD (src/Monodepth.jl:159-164)
                 auto_loss = md.automasking_loss(cache.ssim, x, x[:, cache.target_id - 1].contiguous(), cache.source_ids)

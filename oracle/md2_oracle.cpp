@@ -147,6 +147,11 @@ O_API float o_net_train_loss(o_net* h, const float* x, const o_cfg* cfg, const f
     LossCfg c = to_cfg(cfg); return model_loss(h->net, x, c, auto_loss, do_bwd != 0, h->out);
 }
 O_API void o_net_adam_step(o_net* h, double eta, double grad_scale) { adam_step(h->net, eta, grad_scale); }
+// Flux.testmode! / the BatchNorm running statistics (mean[c], var[c] per BatchNorm in parameter order)
+O_API void o_net_set_testmode(o_net* h, int on) { h->net.testmode = on != 0; }
+O_API long o_net_bn_state_count(o_net* h) { return (long)h->net.nrs; }
+O_API void o_net_bn_state_get(o_net* h, float* p) { std::memcpy(p, h->net.rs.data(), sizeof(float) * h->net.nrs); }
+O_API void o_net_bn_state_set(o_net* h, const float* p) { std::memcpy(h->net.rs.data(), p, sizeof(float) * h->net.nrs); }
 O_API void o_net_eval_disparity(o_net* h, const float* x, int N, int C, int H, int W, float* d0, float* d1, float* d2, float* d3) {
     Tensor disp[4]; eval_disparity(h->net, x, N, C, H, W, disp);
     float* ds[4] = {d0, d1, d2, d3};

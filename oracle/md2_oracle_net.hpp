@@ -227,13 +227,16 @@ inline void t_frame_add(Tensor& df, const Tensor& dy, int L, int l) {
 // Conv weights in Flux layout (kW,kH,Cin,Cout) col-major.
 // ------------------------------------------------------------------------------------------------
 struct ConvP { int cin, cout, k, s, p; size_t w, b; bool has_b; };
-struct BNP { int c; size_t g, b; };
+struct BNP { int c; size_t g, b; size_t rs; };            // rs: offset of (running mean[c], running var[c]) in Net::rs
 
 struct Net {
     int C = 1;                         // image channels
     Vec<float> th, g, m, v;            // params, grads, Adam moments
     double beta1p = 1.0, beta2p = 1.0; // running beta powers (Flux ADAM state)
-    size_t np = 0;
+    size_t np = 0, nrs = 0;
+    // Flux BatchNorm state: tracked mu / sigma^2 (momentum 0.1, `_track_stats!`), used instead of the batch statistics under Flux.testmode!
+    // (the reference's eval_image / eval_video, src/Monodepth.jl:209,237).  For every BatchNorm in parameter order: mean[c], var[c].
+    mutable Vec<float> rs; bool testmode = false;
     ConvP stem; BNP stem_bn;
     struct Block { ConvP c1, c2, c3, cd; BNP b1, b2, b3, bd; bool down; bool bottleneck; bool stage_end; };
     int depth = 18, nblk = 8;
@@ -242,7 +245,7 @@ struct Net {
     int dec_ch[5] = {256, 128, 64, 32, 16}, in_ch[5] = {512, 256, 128, 64, 32}, skip_ch[5] = {256, 128, 64, 64, 0};
 
     ConvP mk(int cin, int cout, int k, int s, int p, bool bias) { ConvP c{cin, cout, k, s, p, np, 0, bias}; np += (size_t)cin * cout * k * k; if (bias) { c.b = np; np += cout; } return c; }
-    BNP mkbn(int c) { BNP b{c, np, np + (size_t)c}; np += 2 * (size_t)c; return b; }
+    BNP mkbn(int c) { BNP b{c, np, np + (size_t)c, nrs}; np += 2 * (size_t)c; nrs += 2 * (size_t)c; return b; }
     explicit Net(int C_, int depth_ = 18) : C(C_), depth(depth_) {
         stem = mk(C, 64, 7, 2, 3, false); stem_bn = mkbn(64);
         const int planes[4] = {64, 128, 256, 512}; int cin = 64;
@@ -266,6 +269,10 @@ struct Net {
         for (int l = 0; l < 4; ++l) head[l] = mk(dec_ch[l + 1], 1, 3, 1, 0, true);
         squeeze = mk(cin, 256, 1, 1, 0, true); pose[0] = mk(512, 256, 3, 1, 1, true); pose[1] = mk(256, 256, 3, 1, 1, true); pose[2] = mk(256, 6, 1, 1, 0, true);
         th.assign(np, 0); g.assign(np, 0); m.assign(np, 0); v.assign(np, 0);
+        rs.assign(nrs, 0);
+        auto init_rs = [&](const BNP& b) { for (int i = 0; i < b.c; ++i) rs[b.rs + b.c + i] = 1.f; };       // Flux: mu = 0, sigma^2 = 1
+        init_rs(stem_bn);
+        for (int i = 0; i < nblk; ++i) { init_rs(blk[i].b1); init_rs(blk[i].b2); if (blk[i].bottleneck) init_rs(blk[i].b3); if (blk[i].down) init_rs(blk[i].bd); }
     }
     const float* W(const ConvP& c) const { return th.data() + c.w; }
     const float* B(const ConvP& c) const { return c.has_b ? th.data() + c.b : nullptr; }
@@ -281,9 +288,25 @@ struct DecConv { Tensor xin, xpad, y; };                          // y = act(con
 struct DepthSave { DecConv c1[5], c2[5], head[4]; Tensor up[5], cat[5]; };
 struct PoseSave { Tensor f[2], sq[2], cat, y1, y2, y3; int order[2]; };   // f: the (first,second) feature pair
 
+// Flux BatchNorm under testmode!: (x - mu) / sqrt(sigma^2 + eps) with the tracked statistics
+inline void bn_test_fwd(const Tensor& x, const float* gamma, const float* beta, const float* rmean, const float* rvar, Tensor& y) {
+    const int C = x.c; const size_t P = x.plane();
+    y.reset(x.n, C, x.h, x.w);
+    for (int c = 0; c < C; ++c) {
+        const float is = 1.f / std::sqrt(rvar[c] + 1e-5f);
+        for (int n = 0; n < x.n; ++n) { const size_t o = ((size_t)n * C + c) * P; for (size_t i = 0; i < P; ++i) y.v[o + i] = gamma[c] * ((x.v[o + i] - rmean[c]) * is) + beta[c]; }
+    }
+}
 inline void convbn_fwd(const Net& N, const ConvP& c, const BNP& b, const Tensor& x, ConvBN& s, int act) {
     s.x = x; conv2d_fwd(x, N.W(c), nullptr, s.z, c.cout, c.k, c.s, c.p);
+    if (N.testmode) { bn_test_fwd(s.z, N.th.data() + b.g, N.th.data() + b.b, N.rs.data() + b.rs, N.rs.data() + b.rs + b.c, s.a); act_fwd(s.a, act); return; }
     bn_train_fwd(s.z, N.th.data() + b.g, N.th.data() + b.b, s.a, s.sv); act_fwd(s.a, act);
+    // Flux `_track_stats!`: mu <- 0.9 mu + 0.1 mean ; sigma^2 <- 0.9 sigma^2 + 0.1 * m/(m-1) * var (m = elements per channel)
+    const double m = (double)s.z.n * s.z.plane(); const float corr = m > 1 ? (float)(m / (m - 1)) : 1.f;
+    for (int i = 0; i < b.c; ++i) {
+        N.rs[b.rs + i] = 0.9f * N.rs[b.rs + i] + 0.1f * s.sv.mean[i];
+        N.rs[b.rs + b.c + i] = 0.9f * N.rs[b.rs + b.c + i] + 0.1f * corr * s.sv.var[i];
+    }
 }
 // d(out of bn, before act) -> dx ; accumulates dW, dgamma, dbeta
 inline void convbn_bwd(Net& N, const ConvP& c, const BNP& b, const ConvBN& s, const Tensor& da_preact, Tensor* dx) {
@@ -538,8 +561,8 @@ inline float model_loss(Net& net, const float* x, const LossCfg& c, const float*
 }
 
 // eval_disparity(m, x) = m.depth_decoder(m.encoder(x, Val(:stages))), src/model.jl:28.  x: [N][C][H][W] single frames.
-// BatchNorm runs in TRAIN mode (batch statistics): train() calls trainmode!(model) (src/Monodepth.jl:126) and the checkpoints it
-// saves (cpu(model), :191-194) carry that flag, which is how eval_image / eval_video (:201-248) end up running the loaded model.
+// BatchNorm follows the model's mode like Flux's: batch statistics under trainmode! (train(), src/Monodepth.jl:126), the tracked running statistics
+// under testmode! -- which eval_image / eval_video call explicitly (src/Monodepth.jl:209,237) -- see Net::testmode.
 inline void eval_disparity(Net& net, const float* x, int N, int C, int H, int W, Tensor disp[4]) {
     Tensor xf(N, C, H, W); std::memcpy(xf.p(), x, sizeof(float) * xf.size());
     auto enc = std::make_unique<EncSave>(); encoder_fwd(net, xf, *enc);

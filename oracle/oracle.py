@@ -35,6 +35,7 @@ def lib():
         _LIB.o_net_create.restype = C.c_void_p
         _LIB.o_net_create_depth.restype = C.c_void_p
         _LIB.o_net_nparams.restype = C.c_long
+        _LIB.o_net_bn_state_count.restype = C.c_long
         _LIB.o_net_train_loss.restype = C.c_float
         _LIB.o_loss_fwd_bwd.restype = C.c_float
     return _LIB
@@ -295,6 +296,16 @@ class OracleNet:
 
     def adam_step(self, eta=1e-4, grad_scale=1.0):
         lib().o_net_adam_step(self.h, C.c_double(eta), C.c_double(grad_scale))
+
+    def set_testmode(self, on=True):
+        """Flux.testmode!: BatchNorm normalises with its tracked running statistics."""
+        lib().o_net_set_testmode(self.h, int(bool(on)))
+
+    def bn_state(self):
+        n = lib().o_net_bn_state_count(self.h); p = np.zeros(n, np.float32); lib().o_net_bn_state_get(self.h, _p(p)); return p
+
+    def set_bn_state(self, st):
+        st = _c(st, np.float32); assert st.size == lib().o_net_bn_state_count(self.h); lib().o_net_bn_state_set(self.h, _p(st))
 
 
 def automasking_loss(x, cfg):

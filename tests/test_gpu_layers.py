@@ -100,3 +100,66 @@ def test_maxpool():
     assert np.array_equal(host(md().maxpool3s2(dev(x))), oracle.maxpool3s2_fwd(x))
     dy = rng.standard_normal((3, 64, 9, 13)).astype(np.float32)
     assert rel(host(md().maxpool3s2_pullback(dev(x), dev(dy))), oracle.maxpool3s2_bwd(x, dy)) < 1e-6
+
+
+# ---- the direct kernels the network uses besides the implicit GEMM (never reached through md2_conv2d_*) --------------------------------
+def _reflect_adjoint(dxpad, N, C, H, W):
+    t = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.pad(t, (1, 1, 1, 1), mode="reflect").backward(torch.tensor(dxpad, dtype=torch.float64))
+    return t.grad.numpy()
+
+
+@pytest.mark.parametrize("case", [(3, 1, 64, 96), (6, 3, 64, 96), (3, 1, 34, 70), (3, 3, 18, 130), (12, 1, 128, 416)])
+def test_stem_direct_kernels_vs_oracle(case):
+    """stem_fwd_kernel / stem_wgrad_kernel (7x7, stride 2, pad 3 on the boundary tensor) incl. the BatchNorm statistics of the epilogue:
+    C in {1,3}, B*3 images, ragged tiles (output 17x35, 9x65), and the headline frame size."""
+    N, C, H, W = case
+    x = rng.random((N, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((64, C, 7, 7)) / np.sqrt(49 * C)).astype(np.float32)
+    zo = oracle.conv2d_fwd(x, w, None, 2, 3)
+    z, mean, invstd = md().stem_conv(dev(x), dev(w))
+    assert z.shape == zo.shape and rel(host(z), zo) < 1e-4
+    m64 = zo.astype(np.float64).mean((0, 2, 3)); v64 = zo.astype(np.float64).var((0, 2, 3))
+    assert np.abs(host(mean) - m64).max() < 1e-4 * max(1.0, np.abs(m64).max()) and rel(host(invstd), 1.0 / np.sqrt(v64 + 1e-5)) < 1e-4
+    dz = rng.standard_normal(zo.shape).astype(np.float32)
+    _, dwo, _ = oracle.conv2d_bwd(x, w, dz, 2, 3)
+    dw = host(md().stem_conv_wgrad(dev(x), dev(dz)))
+    assert dw.shape == dwo.shape and rel(dw, dwo) < 1e-4          # max over ALL 64*C*49 weights: a wrong MFMA-layout index would move whole rows
+
+
+@pytest.mark.parametrize("case", [(2, 16, 20, 37, "elu"), (1, 32, 9, 21, "none"), (3, 64, 6, 11, "none"), (2, 128, 5, 7, "none"), (1, 16, 64, 208, "elu")])
+def test_disparity_head_direct_kernels_vs_oracle(case):
+    """head_fwd_kernel / head_bwd_kernel (reflect-pad 3x3 conv to one channel + sigmoid, src/depth_decoder.jl:43): all four channel counts,
+    ragged tiles, the ELU-derivative variant of the last branch."""
+    N, Cin, H, W, xact = case
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    if xact == "elu":
+        x = np.where(x > 0, x, np.expm1(x)).astype(np.float32)          # an ELU output
+    w = (rng.standard_normal((1, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32); b = rng.standard_normal(1).astype(np.float32)
+    xp = oracle.pad_reflect(x)
+    yo = 1.0 / (1.0 + np.exp(-oracle.conv2d_fwd(xp, w, b, 1, 0).astype(np.float64)))
+    y = md().head_conv(dev(x), dev(w), dev(b))
+    assert rel(host(y), yo) < 1e-5
+    dy = rng.standard_normal(yo.shape).astype(np.float32)
+    dzo = (dy * yo * (1 - yo)).astype(np.float32)
+    dxp, dwo, dbo = oracle.conv2d_bwd(xp, w, dzo, 1, 0)
+    dxo = _reflect_adjoint(dxp, N, Cin, H, W)
+    if xact == "elu":
+        dxo = dxo * np.where(x > 0, 1.0, x + 1.0)
+    dx, dw, db = md().head_conv_pullback(dev(x), dev(w), y, dev(dy), xact)
+    assert rel(host(dx), dxo) < 1e-4 and rel(host(dw), dwo) < 1e-4 and rel(host(db), dbo) < 1e-4
+
+
+@pytest.mark.parametrize("case", [(40, 64, 32, 52, 64, 3, 1, 1), (6, 64, 16, 26, 128, 3, 2, 1), (6, 64, 16, 26, 128, 1, 2, 0), (3, 128, 8, 13, 256, 3, 1, 1), (2, 256, 4, 13, 512, 3, 1, 1),
+                                  (2, 32, 9, 11, 16, 3, 1, 1)])
+def test_conv_bn_statistics_epilogue_vs_oracle(case):
+    """The BatchNorm batch statistics accumulated in the conv epilogue (128x64 and 64x64 tiles: butterfly + 8-slot double atomics; the
+    last case has 16 output channels and takes the separate statistics pass)."""
+    N, Cin, H, W, Cout, k, s, p = case
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    yo = oracle.conv2d_fwd(x, w, None, s, p)
+    y, mean, invstd = md().conv2d_bnstats(dev(x), dev(w), s, p)
+    assert rel(host(y), yo) < 1e-4
+    m64 = yo.astype(np.float64).mean((0, 2, 3)); v64 = yo.astype(np.float64).var((0, 2, 3))
+    assert np.abs(host(mean) - m64).max() < 1e-5 * max(1.0, np.abs(yo).max()) and rel(host(invstd), 1.0 / np.sqrt(v64 + 1e-5)) < 1e-4

@@ -33,6 +33,47 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
 
 
+# With the automask most pixels carry no photometric gradient; the few pixels whose mask / arg-min decision differs between two fp32 summation orders
+# then weigh visibly in the small arrays at the END of the chain (the full-resolution head and the last decoder branch).
+ALLOW_AUTOMASK = ("dec.head5", "dec.branch5")
+REPORT = os.environ.get("MD2_GRAD_REPORT")          # file that collects the per-array tables of every model test (diagnostics)
+
+
+def per_array(gh, go, C, depth=18):
+    """[(name, cosine, ||gh - go|| / ||go||, ||go||)] for every array of the flat parameter vector (syn.param_layout order)."""
+    out = []; off = 0
+    gh = np.asarray(gh, np.float64); go = np.asarray(go, np.float64)
+    for name, _, shape in syn.param_layout(C, depth):
+        n = int(np.prod(shape)); a = gh[off:off + n]; b = go[off:off + n]; off += n
+        na, nb = np.linalg.norm(a), np.linalg.norm(b)
+        out.append((name, float(a @ b / (na * nb + 1e-300)), float(np.linalg.norm(a - b) / (nb + 1e-300)), float(nb)))
+    assert off == gh.size == go.size
+    return out
+
+
+def assert_grads_match(gh, go, C, depth=18, cos_min=0.999, rel_max=1e-2, allow=(), tag=""):
+    """Gradient parity as a COMPARISON, array by array: every parameter array (conv weight, bias, BatchNorm gamma / beta — 3 136-element stem
+    included) must have cosine >= cos_min AND ||g_hip - g_oracle|| / ||g_oracle|| <= rel_max.  Arrays whose oracle gradient is numerically
+    zero (below 1e-7 of the largest array norm, e.g. biases in front of a BatchNorm-free mean) are compared absolutely.  `allow` lists name
+    prefixes with a documented reason for a looser bound (cos >= 0.99, rel <= 0.15): there the fp32 forward differs in a few ReLU / arg-min
+    decisions between two summation orders, which moves individual gradient entries by O(1) of their own size."""
+    tab = per_array(gh, go, C, depth)
+    top = max(t[3] for t in tab)
+    bad = []
+    for name, cos, rel_, nb in tab:
+        if nb < 1e-7 * top:
+            continue
+        loose = any(name.startswith(a) for a in allow)
+        if cos < (0.99 if loose else cos_min) or rel_ > (0.15 if loose else rel_max):
+            bad.append((name, cos, rel_, nb))
+    if REPORT:
+        with open(REPORT, "a") as f:
+            f.write("# %s: %d arrays, worst cos %.6f, worst rel %.3e\n" % (tag, len(tab), min(t[1] for t in tab if t[3] >= 1e-7 * top), max(t[2] for t in tab if t[3] >= 1e-7 * top)))
+            for t in sorted(tab, key=lambda t: -t[2])[:12]:
+                f.write("  %-28s cos %.6f rel %.3e norm %.3e\n" % t)
+    assert not bad, "gradient arrays outside the parity bound: " + ", ".join("%s (cos %.5f, rel %.2e)" % b[:3] for b in bad[:8])
+
+
 def host(t):
     return t.detach().cpu().numpy()
 
@@ -54,10 +95,7 @@ def test_loss_half_vs_oracle_and_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     N, C, H, W = int(g["N"]), int(g["C"]), int(g["H"]), int(g["W"])
     x = syn.synthetic_triplets(N, C, H, W, seed=int(g["seed"]))
-    Hm, Wm = max(H, 64), max(W, 64)
-    if (Hm, Wm) != (H, W):
-        pytest.skip("handle needs H,W >= 64")
-    model, params, cache, _, K, iK = make(N, C, H, W)
+    model, params, cache, _, K, iK = make(N, C, H, W)             # 32x64: a loss-only handle (the network needs >= 64)
     xd = dev(x); model._ensure(xd, params, cache)
     disps = [g["disp%d" % i] for i in range(4)]
     loss, dds, drv, dtv = md().loss_fwd_bwd(model, xd, [dev(d) for d in disps], dev(g["rvec"]), dev(g["tvec"]))
@@ -115,15 +153,10 @@ def test_model_and_train_step_vs_oracle_and_golden(name):
     assert abs(float(loss) - float(g["loss"])) / float(g["loss"]) < 1e-4
     md().gradient(model)
     gh = model.grads(); go = net.get_grads()
-    cos = float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go)))
-    assert cos > 0.9995                                          # fp32 ReLU / arg-min flips make element-wise equality impossible (see tests/test_oracle_vs_torch.py)
-    off = 0; nh = []; no = []
-    for _, _, shape in syn.param_layout(C):
-        n = int(np.prod(shape)); nh.append(np.linalg.norm(gh[off:off + n])); no.append(np.linalg.norm(go[off:off + n])); off += n
-    nh, no = np.array(nh), np.array(no); big = no > 1e-3 * no.max()
-    assert np.abs(nh[big] - no[big]).max() / no.max() < 2e-2
+    assert_grads_match(gh, go, C, allow=ALLOW_AUTOMASK if automask else (), tag=name)   # every parameter array against the oracle's
+    nh = np.array([t[3] for t in per_array(go, gh, C)])          # (norms of the HIP arrays)
     gn = g["grad_norms"]; bigg = gn > 1e-3 * gn.max()
-    assert np.abs(nh[bigg] - gn[bigg]).max() / gn.max() < 2e-2
+    assert np.abs(nh[bigg] - gn[bigg]).max() / gn.max() < 2e-2   # and the torch-derived golden norms
     # ---- ADAM (Flux.Optimise.update!)
     md().update(md().ADAM(1e-4), model)
     net.set_grads(gh); net.adam_step(1e-4)                        # same gradients in, so the update itself must agree tightly
@@ -311,12 +344,12 @@ def test_other_shapes_forward_loss_and_gradient_vs_oracle(shape):
     assert abs(float(loss) - lo) / lo < 1e-4
     gh = model.grads(); go = net.get_grads()
     assert np.isfinite(gh).all()
-    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+    assert_grads_match(gh, go, C, tag="shape %s" % (shape,))
 
 
 def test_config5_shape_1024x320_with_automasking_vs_oracle():
-    """BASELINE config #5's resolution (1024x320, RGB) with the min-reprojection automask, in fp32 (the build has no bf16 path): forward +
-    loss within 1e-4 of the oracle, gradient direction identical.  Exercises every kernel's tiling at 2.5x the headline width/height."""
+    """BASELINE config #5's resolution (1024x320, RGB) with the min-reprojection automask, in fp32 (the parity mode; the bf16 mixed-precision mode is
+    bounded separately below): forward + loss within 1e-4 of the oracle, every gradient array compared.  Exercises every kernel's tiling at 2.5x the headline width/height."""
     N, C, H, W = 1, 3, 320, 1024
     model, params, cache, theta, K, iK = make(N, C, H, W, automask=True, pseed=31)
     x = syn.synthetic_triplets(N, C, H, W, seed=32); xd = dev(x)
@@ -330,7 +363,7 @@ def test_config5_shape_1024x320_with_automasking_vs_oracle():
     assert abs(float(loss) - lo) / lo < 1e-4
     gh = model.grads(); go = net.get_grads()
     assert np.isfinite(gh).all()
-    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+    assert_grads_match(gh, go, C, allow=ALLOW_AUTOMASK, tag="config5 1024x320 automask")
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 64, 96), (1, 3, 96, 160)])
@@ -354,8 +387,7 @@ def test_resnet50_encoder_forward_loss_gradient_and_adam_vs_oracle(shape):
     assert abs(float(loss) - lo) / lo < 1e-4
     gh = model.grads(); go = net.get_grads()
     assert np.isfinite(gh).all()
-    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
-    assert abs(np.linalg.norm(gh) - np.linalg.norm(go)) / np.linalg.norm(go) < 2e-2
+    assert_grads_match(gh, go, C, depth=50, tag="resnet50 %s" % (shape,))
     md().update(md().ADAM(1e-4), model); net.adam_step(1e-4)
     assert np.abs(model.params() - net.get_params()).max() < 5e-3 * 1e-4 / 1e-4 * 1e-1     # |delta| <= lr per element; sign flips only on ~0 gradients
 
@@ -372,7 +404,7 @@ def test_config4_resnet50_640x192_vs_oracle():
     assert abs(float(loss) - lo) / lo < 1e-4
     gh = model.grads(); go = net.get_grads()
     assert np.isfinite(gh).all()
-    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
+    assert_grads_match(gh, go, C, depth=50, tag="config4 resnet50 640x192")
 
 
 @pytest.mark.parametrize("cfgd", [(2, 1, 128, 416, 18, False), (1, 3, 320, 1024, 18, True)])
@@ -432,5 +464,155 @@ def test_config2_full_size_parity_vs_oracle():
     lo = net.train_loss(x, cfg, None, True)
     assert abs(float(loss) - lo) / lo < 1e-4
     gh = model.grads(); go = net.get_grads()
-    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > 0.999
-    assert abs(np.linalg.norm(gh) - np.linalg.norm(go)) / np.linalg.norm(go) < 2e-2
+    assert_grads_match(gh, go, C, tag="config2 416x128 B=4")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# the reference's own real-image fixture: res/image.png, a Depth10k strip of 3 frames of 416x128 RGB (src/dtk.jl:29-46)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def _depth10k_triplet(grayscale):
+    from PIL import Image
+    strip = np.asarray(Image.open(os.path.join(GOLD, "depth10k_strip.png")).convert("RGB")).astype(np.float32) / np.float32(255.0)   # (128, 1248, 3)
+    assert strip.shape == (128, 1248, 3)
+    if grayscale:                                                  # Gray{Float32}.(frames), src/dtk.jl:33 (BT.601 luma)
+        strip = (np.float32(0.299) * strip[..., 0] + np.float32(0.587) * strip[..., 1] + np.float32(0.114) * strip[..., 2])[..., None]
+    frames = [strip[:, 416 * j:416 * (j + 1)] for j in range(3)]   # frames[:, (width*j+1):(width*(j+1))], src/dtk.jl:36
+    return np.ascontiguousarray(np.stack([f.transpose(2, 0, 1) for f in frames], 0)[None], np.float32)          # (1, 3, C, 128, 416)
+
+
+@pytest.mark.parametrize("grayscale", [False, True])
+def test_real_image_loss_half_vs_oracle(grayscale):
+    """Loss half on the reference-held real triplet with rough disparities and poses large enough to clamp against the border: real texture stresses the
+    arg-min ties, the SSIM clamps and the :border clamping far harder than the smooth synthetic frames."""
+    x = _depth10k_triplet(grayscale); N, _, C, H, W = x.shape
+    rng = np.random.default_rng(17)
+    model, params, cache, _, K, iK = make(N, C, H, W, automask=True)
+    xd = dev(x); model._ensure(xd, params, cache)
+    disps = [(rng.random((N, 1, H >> s, W >> s)) * 0.9 + 0.05).astype(np.float32) for s in (3, 2, 1, 0)]
+    rvec = ((rng.random((2, N, 3)) - 0.5) * 0.08).astype(np.float32); tvec = ((rng.random((2, N, 3)) - 0.5) * 1.0).astype(np.float32)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK, automasking=True)
+    al = oracle.automasking_loss(x, cfg)
+    ald = md().automasking_loss(md().SSIM(), xd, xd[:, 1].contiguous(), [1, 3])
+    assert np.abs(host(ald) - al).max() < 2e-5
+    for auto in (None, al):
+        loss, dds, drv, dtv = md().loss_fwd_bwd(model, xd, [dev(d) for d in disps], dev(rvec), dev(tvec), auto_loss=None if auto is None else dev(auto))
+        r = oracle.loss_fwd_bwd(x, cfg, disps, rvec, tvec, auto_loss=auto)
+        assert abs(float(loss) - r["loss"]) / r["loss"] < 1e-5
+        for i in range(4):
+            assert grad_close(host(dds[i]), r["ddisp"][i], tol=2e-4)
+        assert rel(host(drv), r["drvec"]) < 2e-3 and rel(host(dtv), r["dtvec"]) < 2e-3
+
+
+def test_real_image_full_step_vs_oracle():
+    """The whole training step (forward, loss, every gradient array) on the reference's real triplet, RGB, N = 1."""
+    x = _depth10k_triplet(False); N, _, C, H, W = x.shape
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=71)
+    xd = dev(x)
+    ds, poses = model(xd, [1, 3], 2)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK)
+    dso, rvo, tvo = net.model_forward(x, cfg)
+    for i in range(4):
+        assert rel(host(ds[i]), dso[i]) < 1e-4
+    loss = md().train_step(model, xd, None, cache, params, do_update=False)
+    lo = net.train_loss(x, cfg, None, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    assert_grads_match(model.grads(), net.get_grads(), C, tag="real image 416x128 RGB")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# deterministic mode, BatchNorm running statistics / test mode, handle management, the library's own RCCL path
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def test_deterministic_mode_is_bit_reproducible():
+    """MD2_DETERMINISTIC / md2_set_deterministic: two fresh handles, same inputs -> bit-identical loss, gradients and ADAM update (the default mode differs
+    in the last bits from run to run: fp32 atomics in the weight gradients, split-K, 8-slot BatchNorm sums)."""
+    N, C, H, W = 2, 3, 64, 96
+    x = dev(syn.synthetic_triplets(N, C, H, W, seed=81))
+    def run():
+        model, params, cache, theta, K, iK = make(N, C, H, W, automask=True, pseed=82)
+        al = md().automasking_loss(md().SSIM(), x, x[:, 1].contiguous(), [1, 3])
+        l = float(md().train_step(model, x, al, cache, params, do_update=True))
+        return l, model.grads(), model.params()
+    md().set_deterministic(True)
+    try:
+        a = run(); b = run()
+    finally:
+        md().set_deterministic(False)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    c = run()                                                      # and the ordered sums agree with the default mode to rounding
+    assert abs(c[0] - a[0]) < 1e-6 * abs(a[0])
+    assert np.linalg.norm(c[1] - a[1]) / np.linalg.norm(a[1]) < 2e-3
+
+
+def test_testmode_eval_and_bn_running_statistics_vs_oracle(tmp_path):
+    """Flux.testmode! (what eval_image / eval_video run, src/Monodepth.jl:209,237): train-mode passes track the BatchNorm mu / sigma^2, test-mode
+    eval_disparity normalises with them (n = 1 frame included), and the statistics travel with the checkpoint."""
+    N, C, H, W = 2, 1, 64, 96
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=91)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    for seed in (92, 93):
+        x = syn.synthetic_triplets(N, C, H, W, seed=seed)
+        md().train_loss(model, dev(x), None, cache, params, False); net.train_loss(x, oracle.make_cfg(N, C, H, W, K, iK), None, False)
+    so, sh = net.bn_state(), model.bn_state()
+    assert so.shape == sh.shape and np.abs(so - sh).max() / np.abs(so).max() < 1e-4
+    frame = syn.synthetic_triplets(1, C, H, W, seed=94)[:, 1]
+    md().testmode(model, True); net.set_testmode(True)
+    ds = md().eval_disparity(model, dev(frame)); do = net.eval_disparity(frame)
+    for i in range(4):
+        assert rel(host(ds[i]), do[i]) < 1e-4
+    with pytest.raises(RuntimeError):
+        md().train_loss(model, dev(x), None, cache, params, False)       # gradient needs trainmode!
+    md().save_checkpoint(model, tmp_path / "ck.npz")
+    other, _, _, _, _, _ = make(N, C, H, W, pseed=5)
+    other._ensure(dev(x), params, cache); md().load_checkpoint(other, str(tmp_path / "ck.npz")); md().testmode(other, True)
+    d2 = md().eval_disparity(other, dev(frame))
+    for i in range(4):
+        assert np.array_equal(host(d2[i]), host(ds[i]))
+    md().testmode(model, False)
+    dtr = md().eval_disparity(model, dev(frame))                          # batch statistics of ONE frame: a different answer
+    assert max(np.abs(host(a) - host(b)).max() for a, b in zip(ds, dtr)) > 1e-3
+
+
+def test_intrinsics_follow_the_cache_and_state_survives_a_handle_rebuild():
+    """TrainCache.K is read on every call (src/training.jl:48-57), and a change of batch size rebuilds the handle WITHOUT restarting ADAM."""
+    N, C, H, W = 2, 1, 64, 96
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=95)
+    x = syn.synthetic_triplets(N, C, H, W, seed=96); xd = dev(x)
+    l1 = float(md().train_loss(model, xd, None, cache, params, False)[0])
+    K2 = K.copy(); K2[0, 0] *= 1.3; K2[1, 1] *= 1.3
+    cache2 = md().TrainCache(cache.ssim, cache.backprojections, cache.projections, K2, np.linalg.inv(K2), 2, [1, 3], cache.scales)
+    l2 = float(md().train_loss(model, xd, None, cache2, params, False)[0])
+    net = oracle.OracleNet(C); net.set_params(theta)
+    lo2 = net.train_loss(x, oracle.make_cfg(N, C, H, W, K2, np.linalg.inv(K2)), None, False)
+    assert abs(l2 - lo2) / lo2 < 1e-4 and abs(l1 - l2) > 1e-6
+    # two ADAM steps at batch 2, then a batch-1 call (new handle): moments and beta powers must come along
+    for _ in range(2):
+        md().train_step(model, xd, None, cache, params, True)
+    m_before = model._opt_and_bn_state()
+    p1 = md().Params(target_size=(W, H), batch_size=1, automasking=False)
+    md().train_loss(model, xd[:1].contiguous(), None, cache, p1, False)
+    m_after = model._opt_and_bn_state()
+    assert np.array_equal(m_before[0], m_after[0]) and np.array_equal(m_before[1], m_after[1]) and m_before[2:4] == m_after[2:4]
+    assert abs(m_after[2] - 0.81) < 1e-12 and np.abs(m_after[0]).max() > 0
+
+
+def test_library_rccl_path_world1():
+    """md2_comm_*: the library's own RCCL communicator (what a Julia host uses), here with one rank (one GPU per box): bucketed all-reduce inside md2_backward
+    on the communication stream, ADAM on the mean.  With one rank every sum is the identity, so the step must equal the plain step."""
+    N, C, H, W = 2, 1, 64, 96
+    xd = dev(syn.synthetic_triplets(N, C, H, W, seed=97))
+    a, params, cache, theta, K, iK = make(N, C, H, W, pseed=98)
+    b, _, _, _, _, _ = make(N, C, H, W, pseed=98)
+    dp = md2amd.parallel.DataParallel(a, comm="rccl")
+    md().set_deterministic(True)
+    try:
+        la = float(dp.train_step(xd, None, cache, params)); lb = float(md().train_step(b, xd, None, cache, params, True))
+        la2 = float(dp.train_step(xd, None, cache, params)); lb2 = float(md().train_step(b, xd, None, cache, params, True))
+    finally:
+        md().set_deterministic(False)
+    assert la == lb and la2 == lb2 and np.array_equal(a.grads(), b.grads()) and np.array_equal(a.params(), b.params())
+    t = torch.arange(8, dtype=torch.float32, device="cuda")
+    assert torch.equal(a.comm_allreduce(t.clone()), t)
+    # the unbucketed route (explicit md2_allreduce_grads after a local gradient) gives the same buffer
+    md().train_loss(a, xd, None, cache, params, False); md().gradient(a); g1 = a.grads(); a.allreduce_grads(); torch.cuda.synchronize()
+    assert np.array_equal(a.grads(), g1)

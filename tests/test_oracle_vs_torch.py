@@ -168,3 +168,26 @@ def test_eval_disparity_vs_torch():
     dt = tr.eval_disparity(torch.tensor(theta, dtype=torch.float64), torch.tensor(x, dtype=torch.float64), C)
     for a, b in zip(ds, dt):
         assert rel(a, b.numpy()) < 1e-4
+
+
+def test_bn_running_statistics_and_testmode_vs_torch():
+    """Flux BatchNorm state: two train-mode passes track mu / sigma^2 (momentum 0.1, unbiased variance), then a test-mode pass
+    (Flux.testmode!, what eval_image / eval_video run, src/Monodepth.jl:209,237) normalises with them; n = 1 frame works there."""
+    C, H, W = 1, 64, 96
+    theta = syn.init_params(C, seed=13, randomize_affine=True)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    bn = tr.BNState(); tt = torch.tensor(theta, dtype=torch.float64)
+    for seed in (51, 52):
+        x = syn.synthetic_triplets(2, C, H, W, seed=seed)[:, 1]
+        net.eval_disparity(x); tr.eval_disparity(tt, torch.tensor(x, dtype=torch.float64), C, bn=bn)
+    st_o, st_t = net.bn_state(), bn.flat()
+    assert st_o.shape == st_t.shape and np.abs(st_o - st_t).max() / np.abs(st_t).max() < 1e-5
+    x1 = syn.synthetic_triplets(1, C, H, W, seed=53)[:, 1]
+    net.set_testmode(True); bn.test = True
+    do = net.eval_disparity(x1); dt = tr.eval_disparity(tt, torch.tensor(x1, dtype=torch.float64), C, bn=bn)
+    for a, b in zip(do, dt):
+        assert np.abs(a - b.numpy()).max() < 2e-5
+    assert np.array_equal(net.bn_state(), st_o)                     # test mode does not touch the statistics
+    net.set_testmode(False)
+    dtr = net.eval_disparity(x1)
+    assert max(np.abs(a - b).max() for a, b in zip(do, dtr)) > 1e-3  # and it really differs from batch statistics on one frame

@@ -90,8 +90,28 @@ def flux_conv(x, w, b, stride=1, pad=0):
     return F.conv2d(x, torch.flip(w, (2, 3)), b, stride=stride, padding=pad)
 
 
+class BNState:
+    """Tracked BatchNorm statistics in call order (torch's running_mean / running_var use Flux's convention: momentum 0.1 on the
+    new value, unbiased batch variance), and the train / test switch."""
+
+    def __init__(self):
+        self.stats, self.i, self.test = [], 0, False
+
+    def flat(self):
+        return torch.cat([torch.cat([m, v]) for m, v in self.stats]).numpy()
+
+
+_BN = None          # set by eval_disparity(..., bn=BNState) for the duration of one forward pass
+
+
 def bn_train(x, g, b):
-    return F.batch_norm(x, None, None, g, b, training=True, momentum=0.1, eps=1e-5)
+    if _BN is None:
+        return F.batch_norm(x, None, None, g, b, training=True, momentum=0.1, eps=1e-5)
+    i = _BN.i; _BN.i += 1
+    if i >= len(_BN.stats):
+        _BN.stats.append((torch.zeros(x.shape[1], dtype=x.dtype), torch.ones(x.shape[1], dtype=x.dtype)))
+    rm, rv = _BN.stats[i]
+    return F.batch_norm(x, rm, rv, g, b, training=not _BN.test, momentum=0.1, eps=1e-5)
 
 
 class Params:
@@ -220,7 +240,15 @@ def simple_depth_loss(x, disp, poses, K, invK, target_id=2, source_ids=(1, 3), m
     return prediction_loss(warped, tgt).mean() + smooth_loss(disp[:, 0], tgt)
 
 
-def eval_disparity(flat, x, C):
-    """eval_disparity (src/model.jl:28): encoder + depth decoder on single frames x (N,C,H,W); BN on batch statistics."""
-    disps, _ = model_forward(flat, x.unsqueeze(1), C, target_id=1, source_ids=())
+def eval_disparity(flat, x, C, bn=None):
+    """eval_disparity (src/model.jl:28): encoder + depth decoder on single frames x (N,C,H,W); BN on batch statistics, or with a BNState:
+    tracked statistics updated (train mode) / used (bn.test, Flux.testmode!)."""
+    global _BN
+    _BN = bn
+    if bn is not None:
+        bn.i = 0
+    try:
+        disps, _ = model_forward(flat, x.unsqueeze(1), C, target_id=1, source_ids=())
+    finally:
+        _BN = None
     return disps
