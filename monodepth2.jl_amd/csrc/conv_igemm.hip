@@ -41,8 +41,28 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const f32x4& lo, const f32x4& hi) {
     for (int i = 0; i < 4; ++i) { r[i] = (__bf16)lo[i]; r[4 + i] = (__bf16)hi[i]; }
     return r;
 }
-// BF: 0 fp32 MFMA, 1 bf16 operands (mixed precision)
-template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0>
+// 32 per-lane partial sums (value p = (g*4 + e)*2 + stat held for the lane's pixel column) -> totals over the 32 pixel lanes of each half-wave with a halving
+// butterfly (step b: exchange the half of the values whose index bit 0 differs from lane bit b: 16+8+4+2+1 shuffles), then pixel lane p adds value p with one
+// double atomic: dst[(p & 1) * C + channel(p >> 1)]
+__device__ __forceinline__ void stats_butterfly_atomic(float (&v)[32], double* __restrict__ dst, int C, int cbase, int lane) {
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        const bool up = (lane >> b) & 1;
+#pragma unroll
+        for (int k = 0; k < (16 >> b); ++k) {
+            const float lo = v[2 * k], hi = v[2 * k + 1];
+            v[k] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 1 << b);
+        }
+    }
+    const int p = lane & 31, r = p >> 1;                 // accumulator register r = 4g + e -> channel row 8g + 4*(lane>>5) + e
+    atomicAdd(dst + (p & 1) * C + cbase + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), (double)v[0]);
+}
+
+// BF: 0 fp32 MFMA, 1 bf16 operands (mixed precision).  XF: 1 = the pixel operand is relu(x * in_scale[ci] + in_shift[ci]) -- the producer's BatchNorm + ReLU
+// applied on the way from the global load into LDS, so that activation is never written to (or read from) HBM
+// BST: 1 = the epilogue also reduces the BatchNorm-pullback sums of its output (a.bst); a template parameter because its 48 partial-sum registers would otherwise
+// raise the register count of every instantiation
+template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0, int XF = 0, int BST = 0>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __restrict__ smem, const int block_x, const int nblocks_x) {
     constexpr int TP = BM / WP / MF, TC = BN / WC / MF;       // MFMA tiles per wave (pixels x channels)
     constexpr int NV = MF == 32 ? 4 : 1;                       // float4 groups per accumulator tile
@@ -129,7 +149,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const uint4 v = *reinterpret_cast<const uint4*>(xb + (a_off[t][j] + (unsigned)(ci0 * 4)));
-            const unsigned mk = 0u - ((a_mbits[j] >> t) & 1u);
+            const unsigned mk = XF ? 0xFFFFFFFFu : 0u - ((a_mbits[j] >> t) & 1u);          // XF: the mask is applied after the transform, in lstore
             ra[j] = make_float4(__uint_as_float(v.x & mk), __uint_as_float(v.y & mk), __uint_as_float(v.z & mk), __uint_as_float(v.w & mk));
         }
 #pragma unroll
@@ -139,6 +159,25 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     auto put_bf = [&](float* row, const float4& v) {        // 4 k-values (chunk q) of one row -> 4 bf16
         bf16x4 h; h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
         *reinterpret_cast<bf16x4*>(row + q * 2) = h;
+    };
+    // XF: per-channel scale / shift of the chunk whose data sits in ra[] (4 channels of this thread's k-quad); reloaded when the prefetch enters a new chunk
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto xf_load = [&](int chunk) {
+        if constexpr (XF != 0) {
+            const int ch = ((c_lo + chunk) << 4) + q * 4;
+            xsc = *reinterpret_cast<const float4*>(a.in_scale + ch); xsh = *reinterpret_cast<const float4*>(a.in_shift + ch);
+        }
+    };
+    auto xf_apply = [&](int tt) {               // tt: filter tap of the data in ra[] (its padding mask)
+        if constexpr (XF != 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const unsigned mk = 0u - ((a_mbits[j] >> tt) & 1u);
+                float4 v = ra[j];
+                v.x = fmaxf(fmaf(v.x, xsc.x, xsh.x), 0.f); v.y = fmaxf(fmaf(v.y, xsc.y, xsh.y), 0.f); v.z = fmaxf(fmaf(v.z, xsc.z, xsh.z), 0.f); v.w = fmaxf(fmaf(v.w, xsc.w, xsh.w), 0.f);
+                ra[j] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk), __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+            }
+        }
     };
     auto lstore = [&](int so) {                 // so: float offset of the stage
         if constexpr (BF != 0) {
@@ -220,8 +259,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     auto step_tc = [&](int sidx, int& t, int& ci0) { const int ss = min(sidx, nsteps - 1); const int c = ss / NT; t = ss - c * NT; ci0 = c << 4; };
     int o0 = 0, o1 = STAGE, o2 = 2 * STAGE;
     Ops cur, nxt;
-    gload(0, 0); lstore(o0);
-    { int t1, c1; step_tc(1, t1, c1); if (NT == 1) gload(0, c1); else gload(nsteps > 1 ? 1 : 0, 0); }
+    xf_load(0);
+    gload(0, 0); xf_apply(0); lstore(o0);
+    { int t1, c1; step_tc(1, t1, c1); if (NT == 1) { gload(0, c1); xf_load(c1 >> 4); xf_apply(0); } else { gload(nsteps > 1 ? 1 : 0, 0); xf_apply(nsteps > 1 ? 1 : 0); } }
     lstore(o1);
     __syncthreads();
     read_ops(o0, cur);
@@ -244,10 +284,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             continue;
 #endif
             gload(last2 ? NT - 1 : t2, c2 << 4);
+            if (XF != 0 && (t + 2) % NT == 0) xf_load(c2);          // the prefetch enters a new channel chunk (tap 0 of chunk c2; c2 is clamped like the loads)
             read_ops(o1, nxt);
             __builtin_amdgcn_s_setprio(1);          // raised priority around the MFMA cluster (also keeps hipcc from spreading it among the loads): -3 % class time;
             mfmas(cur);                             // the same pair in the all-taps weight-gradient loop was 3 % SLOWER
             __builtin_amdgcn_s_setprio(0);
+            xf_apply(last2 ? NT - 1 : t2);
             lstore(o2);
             __syncthreads();
             cur = nxt;
@@ -261,6 +303,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // epilogue: every (tile, register group) is 4 consecutive channels of one pixel -> one 16-B NHWC store
     //   16x16x4: D col = lane&15 (pixel), row = 4*(lane>>4) + e (channel)
     //   32x32x2: D col = lane&31 (pixel), row = 8*g + 4*(lane>>5) + e, register 4g+e
+    constexpr bool CAN_STAT = MF == 32 && TC == 1;          // tiles whose epilogue can reduce per-channel sums (a lane holds 16 channels of its pixel column)
+    constexpr bool DO_BST = CAN_STAT && BST != 0;
+    const bool want_bst = DO_BST && a.bst != nullptr && a.ksplit == 1;
+    float bs1[DO_BST ? 16 : 1], bsA[DO_BST ? 16 : 1], bsB[DO_BST ? 16 : 1];      // BatchNorm-pullback partial sums of this lane: sum g, sum g*xhatA, sum g*xhatB
+    if constexpr (DO_BST) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { bs1[r] = 0.f; bsA[r] = 0.f; bsB[r] = 0.f; }
+    }
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int m = m0 + wp * (BM / WP) + j * MF + (lane & (MF - 1));
@@ -279,8 +329,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                     const float4 rr = *reinterpret_cast<const float4*>(a.res + (long)n * a.res_bs + pix * a.res_ps + co);
                     v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                 }
+                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dp) {
+                    d = *reinterpret_cast<const float4*>(dp + co);
+                    if (a.dact_scale) {                 // dact_src is a raw conv output z: the activation it fed is relu(z * scale + shift)
+                        const float4 sc = *reinterpret_cast<const float4*>(a.dact_scale + co), sh = *reinterpret_cast<const float4*>(a.dact_shift + co);
+                        d.x = fmaf(d.x, sc.x, sh.x); d.y = fmaf(d.y, sc.y, sh.y); d.z = fmaf(d.z, sc.z, sh.z); d.w = fmaf(d.w, sc.w, sh.w);
+                    }
+                }
                 if (a.ksplit > 1) {            // partial sum: (x act') is linear, bias/activation are applied by the launcher's second pass
-                    if (dp) { const float4 d = *reinterpret_cast<const float4*>(dp + co); v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
+                    if (dp) { v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomicAdd(yp + co + e, v[e]);
                     continue;
@@ -290,19 +348,28 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
                 }
-                if (dp) {
-                    const float4 d = *reinterpret_cast<const float4*>(dp + co);
-                    v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact);
-                }
+                if (dp) { v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
                 if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
                 *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (DO_BST) {
+                    if (want_bst) {            // g = the final value just stored; xhat from the BatchNorm input(s) this gradient flows back into
+                        const float4 z = *reinterpret_cast<const float4*>(a.bz + (long)n * a.bz_bs + pix * a.bz_ps + co);
+                        const float4 mu = *reinterpret_cast<const float4*>(a.bstat + co), is = *reinterpret_cast<const float4*>(a.bstat + a.Cout + co);
+                        bs1[4 * g + 0] += v[0]; bs1[4 * g + 1] += v[1]; bs1[4 * g + 2] += v[2]; bs1[4 * g + 3] += v[3];
+                        bsA[4 * g + 0] += v[0] * ((z.x - mu.x) * is.x); bsA[4 * g + 1] += v[1] * ((z.y - mu.y) * is.y); bsA[4 * g + 2] += v[2] * ((z.z - mu.z) * is.z); bsA[4 * g + 3] += v[3] * ((z.w - mu.w) * is.w);
+                        if (a.bstB) {
+                            const float4 zb = *reinterpret_cast<const float4*>(a.bzB + (long)n * a.bzB_bs + pix * a.bzB_ps + co);
+                            const float4 mb = *reinterpret_cast<const float4*>(a.bstatB + co), ib = *reinterpret_cast<const float4*>(a.bstatB + a.Cout + co);
+                            bsB[4 * g + 0] += v[0] * ((zb.x - mb.x) * ib.x); bsB[4 * g + 1] += v[1] * ((zb.y - mb.y) * ib.y); bsB[4 * g + 2] += v[2] * ((zb.z - mb.z) * ib.z); bsB[4 * g + 3] += v[3] * ((zb.w - mb.w) * ib.w);
+                        }
+                    }
+                }
             }
     }
     // ---- optional BatchNorm statistics of this tile (the output rows past M were computed from masked loads and are exactly 0).
-    //      A lane holds 16 channels x (sum, sum of squares) over its TP pixels; the 32 pixel lanes of each half-wave are reduced with a
-    //      halving butterfly (step b: exchange the half of the values whose index bit 0 differs from lane bit b, 16+8+4+2+1 shuffles),
-    //      after which pixel lane p owns the total of value p = (g*4 + e)*2 + stat.
-    if constexpr (MF == 32 && TC == 1) {
+    //      A lane holds 16 channels x (sum, sum of squares) over its TP pixels; see stats_butterfly_atomic.  slot = block_x % BN_STAT_SLOTS spreads the double atomics.
+    if constexpr (CAN_STAT) {
+        const int cbase = c0 + wc * (BN / WC);
         if (a.stats) {
             float v[32];
 #pragma unroll
@@ -312,42 +379,50 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 for (int j = 0; j < TP; ++j) { const float z = acc[0][j][r]; s1 += z; s2 += z * z; }
                 v[2 * r] = s1; v[2 * r + 1] = s2;
             }
+            stats_butterfly_atomic(v, a.stats + (size_t)(block_x % BN_STAT_SLOTS) * 2 * a.Cout, a.Cout, cbase, lane);
+        }
+        if constexpr (DO_BST) if (want_bst) {                       // BatchNorm-pullback sums of the gradient this launch produced (replaces a separate read of dy and z)
+            float v[32];
 #pragma unroll
-            for (int b = 0; b < 5; ++b) {
-                const bool up = (lane >> b) & 1;
+            for (int r = 0; r < 16; ++r) { v[2 * r] = bs1[r]; v[2 * r + 1] = bsA[r]; }
+            stats_butterfly_atomic(v, a.bst + (size_t)(block_x % BN_STAT_SLOTS) * 2 * a.Cout, a.Cout, cbase, lane);
+            if (a.bstB) {
 #pragma unroll
-                for (int k = 0; k < (16 >> b); ++k) {
-                    const float lo = v[2 * k], hi = v[2 * k + 1];
-                    v[k] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, 1 << b);
-                }
+                for (int r = 0; r < 16; ++r) { v[2 * r] = bs1[r]; v[2 * r + 1] = bsB[r]; }
+                stats_butterfly_atomic(v, a.bstB + (size_t)(block_x % BN_STAT_SLOTS) * 2 * a.Cout, a.Cout, cbase, lane);
             }
-            const int p = lane & 31, r = p >> 1;                 // accumulator register r = 4g + e -> channel row 8g + 4*(lane>>5) + e
-            const int co = c0 + wc * (BN / WC) + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            atomicAdd(a.stats + (size_t)(block_x % BN_STAT_SLOTS) * 2 * a.Cout + (p & 1) * a.Cout + co, (double)v[0]);
         }
     }
 }
 
-template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0>
+template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0, int XF = 0, int BST = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * (BF == 0 ? LDK : 12)];
-    conv_igemm_body<BM, BN, WP, WC, MF, NT, BF>(a, smem, blockIdx.x, gridDim.x);
+    conv_igemm_body<BM, BN, WP, WC, MF, NT, BF, XF, BST>(a, smem, blockIdx.x, gridDim.x);
 }
 // The residue classes of a stride-2 input gradient (1, 2, 2 and 4 taps, a quarter of the output pixels each) in ONE launch: a block
 // picks its class from its index and runs that class's statically-unrolled tap loop.  As four launches every class paid its own
 // under-filled tail (312 blocks x 32..128 K-steps on 256 CUs at B=32; 40 blocks at B=4).
 struct ConvClasses { ConvArgs c[4]; int first[5]; };      // blocks [first[i], first[i+1]) belong to class i
-template <int BM, int BN, int WP, int WC, int MF, int BF = 0>
+template <int BM, int BN, int WP, int WC, int MF, int BF = 0, int BST = 0>
 __global__ __launch_bounds__(256) void conv_igemm_classes_kernel(ConvClasses k) {
     __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * (BF == 0 ? LDK : 12)];
     const int b = blockIdx.x;
     const int cls = b < k.first[1] ? 0 : (b < k.first[2] ? 1 : (b < k.first[3] ? 2 : 3));
     const int bx = b - k.first[cls], nb = k.first[cls + 1] - k.first[cls];
     switch (k.c[cls].nkh * k.c[cls].nkw) {
-        case 1: conv_igemm_body<BM, BN, WP, WC, MF, 1, BF>(k.c[cls], smem, bx, nb); break;
-        case 2: conv_igemm_body<BM, BN, WP, WC, MF, 2, BF>(k.c[cls], smem, bx, nb); break;
-        default: conv_igemm_body<BM, BN, WP, WC, MF, 4, BF>(k.c[cls], smem, bx, nb); break;
+        case 1: conv_igemm_body<BM, BN, WP, WC, MF, 1, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
+        case 2: conv_igemm_body<BM, BN, WP, WC, MF, 2, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
+        default: conv_igemm_body<BM, BN, WP, WC, MF, 4, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
     }
+}
+
+// BatchNorm-pullback sums that could not be fused into an epilogue (16-wide tiles, split-K, deterministic mode): one column pass over (g, z)
+static void bst_fallback(const ConvArgs& a, hipStream_t s) {
+    View g; g.p = a.y; g.N = a.N; g.H = a.Ho; g.W = a.Wo; g.C = a.Cout; g.bs = a.y_bs; g.ps = a.y_ps;
+    View z = g; z.p = const_cast<float*>(a.bz); z.bs = a.bz_bs; z.ps = a.bz_ps;
+    launch_bn_bwd_reduce(g, nullptr, ACT_NONE, z, a.bstat, a.bst, s);
+    if (a.bstB) { View zb = g; zb.p = const_cast<float*>(a.bzB); zb.bs = a.bzB_bs; zb.ps = a.bzB_ps; launch_bn_bwd_reduce(g, nullptr, ACT_NONE, zb, a.bstatB, a.bstB, s); }
 }
 
 template <int BM, int BN, int WP, int WC, int MF>
@@ -355,9 +430,22 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     static_assert((BM / WP) % MF == 0 && (BN / WC) % MF == 0, "wave tile must be a multiple of the MFMA tile");
     ConvArgs a = a_in;
     constexpr bool fuses_stats = MF == 32 && (BN / WC) == 32;
-    if (a.stats && (!fuses_stats || g_deterministic || a.ksplit > 1 || a.ostep != 1 || a.bias || a.act != ACT_NONE || a.accumulate || a.dact_src)) a.stats = nullptr;
+    const bool can_fuse = fuses_stats && !g_deterministic && a.ksplit == 1;
+    if (a.stats && (!can_fuse || a.ostep != 1 || a.bias || a.act != ACT_NONE || a.accumulate || a.dact_src)) a.stats = nullptr;
+    constexpr bool bst_tile = MF == 32 && BN == 64 && WP == 2;                 // the instantiations built with the BatchNorm-pullback sums in the epilogue (3x3 taps)
+    if (a.bst && !(can_fuse && bst_tile && a.nkh * a.nkw == 9 && !a.in_scale)) { a.bst = nullptr; a.bstB = nullptr; }
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
     const dim3 g(grid, a.ksplit);
+    if (a.in_scale) {                  // BatchNorm + ReLU of the producer folded into the loader: the encoder's second 3x3 convolutions (Cout % 64 == 0)
+        if constexpr (MF == 32 && BN == 64 && WP == 2) {
+            if (a.nkh * a.nkw != 9) { fprintf(stderr, "md2: conv_igemm: the input transform is built for 3x3 convolutions\n"); abort(); }
+            if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 1, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 0, 1>), g, dim3(256), 0, s, a);
+        } else { fprintf(stderr, "md2: conv_igemm: the input transform needs Cout %% 64 == 0\n"); abort(); }
+    } else if (a.bst) {
+        if constexpr (bst_tile) {
+            if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 1, 0, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 0, 0, 1>), g, dim3(256), 0, s, a);
+        }
+    } else
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
         case 9: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), g, dim3(256), 0, s, a); break;
         case 4: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), g, dim3(256), 0, s, a); break;
@@ -370,6 +458,7 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
         View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
         launch_colstats(yv, a_in.stats, s);
     }
+    if (a_in.bst && !a.bst && a.ksplit == 1 && a.ostep == 1) bst_fallback(a_in, s);       // (split-K: after the bias / activation pass, by launch_conv_igemm_one; sub-lattices: by launch_conv_igemm)
 }
 
 double conv_igemm_flops(const ConvArgs& a) {       // algorithmic: taps that can be non-zero
@@ -552,7 +641,10 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
     k.first[0] = 0;
     for (int i = 0; i < 4; ++i) k.first[i + 1] = k.first[i] + (i < n ? ((k.c[i].M + BM - 1) / BM) * (k.c[i].Cout / 64) : 0);
     for (int i = n; i < 4; ++i) k.c[i] = k.c[0];
-    if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+    if (k.c[0].bst) {
+        if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 0, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+    } else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32>), dim3(k.first[4]), dim3(256), 0, s, k);
 }
 static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
@@ -565,7 +657,7 @@ static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
 // sees the taps kh = (pad - ph) mod dil (+ multiples of dil), so the problem splits into dil^2 dense sub-convolutions on
 // output/tap lattices with no multiply-by-zero work (k=3, s=2: 1+2+2+4 = 9 taps over 4 quarter-size launches).
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
-    if (patch_eligible(a)) {
+    if (patch_eligible(a) && !a.in_scale && !a.bst) {
         if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || (a.dact_src && a.da_ps % 4 != 0)) { fprintf(stderr, "md2: conv3x3_patch: unaligned view\n"); abort(); }
         if (a.Cout == 16) launch_patch<16>(a, s); else launch_patch<32>(a, s);
         if (a.stats) { View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps; launch_colstats(yv, a.stats, s); }
@@ -575,23 +667,35 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     ConvClasses kc{}; int ncls = 0;
     static const bool merge_ok = !getenv("MD2_NO_CLASS_MERGE");
     const bool merge = merge_ok && a.dil == 2 && a.Cout % 64 == 0 && !a.stats;       // the encoder's stride-2 input gradients
+    // the BatchNorm-pullback sums are fused only when EVERY residue class runs in the merged launch (each output pixel is then written exactly once by a 32-wide tile)
+    bool all_merged = merge && !g_deterministic;
+    if (all_merged)
+        for (int ph = 0; ph < a.dil; ++ph) for (int pw = 0; pw < a.dil; ++pw) {
+            const int kh0 = ((a.pad - ph) % a.dil + a.dil) % a.dil, kw0 = ((a.pad - pw) % a.dil + a.dil) % a.dil;
+            const int nt = (kh0 < a.KH ? (a.KH - 1 - kh0) / a.dil + 1 : 0) * (kw0 < a.KW ? (a.KW - 1 - kw0) / a.dil + 1 : 0);
+            if (nt == 0 || nt > 4 || nt == 3) all_merged = false;
+        }
+    const bool fuse_bst = a.bst && all_merged;
     for (int ph = 0; ph < a.dil; ++ph)
         for (int pw = 0; pw < a.dil; ++pw) {
             ConvArgs b = a;
+            if (!fuse_bst) { b.bst = nullptr; b.bstB = nullptr; }
             b.oy0 = ph; b.ox0 = pw; b.ostep = a.dil;
             b.Hl = (a.Ho - ph + a.dil - 1) / a.dil; b.Wl = (a.Wo - pw + a.dil - 1) / a.dil;
             b.kh0 = ((a.pad - ph) % a.dil + a.dil) % a.dil; b.khs = a.dil; b.nkh = b.kh0 < a.KH ? (a.KH - 1 - b.kh0) / a.dil + 1 : 0;
             b.kw0 = ((a.pad - pw) % a.dil + a.dil) % a.dil; b.kws = a.dil; b.nkw = b.kw0 < a.KW ? (a.KW - 1 - b.kw0) / a.dil + 1 : 0;
             b.M = a.N * b.Hl * b.Wl;
+            if (ph == 0 && pw == 0 && a.accumulate_c00 >= 0) b.accumulate = a.accumulate_c00;
             if (b.M <= 0) continue;
             if (b.nkh == 0 || b.nkw == 0) {
-                if (a.accumulate != 1) { fprintf(stderr, "md2: conv_igemm: empty tap phase needs accumulate or a zeroed output\n"); abort(); }
+                if (a.accumulate != 1 && !a.skip_empty) { fprintf(stderr, "md2: conv_igemm: empty tap phase needs accumulate or a zeroed output\n"); abort(); }
                 continue;                                     // nothing to add for this residue class
             }
             if (merge && ncls < 4 && b.nkh * b.nkw <= 4 && b.nkh * b.nkw != 3) { b.ksplit = 1; kc.c[ncls++] = b; }
             else launch_conv_igemm_one(b, s);
         }
     if (ncls) launch_classes(kc, ncls, s);
+    if (a.bst && !fuse_bst) bst_fallback(a, s);
 }
 
 static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
@@ -641,6 +745,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
     if (a.ksplit > 1 && (bias2 || act2 != ACT_NONE)) launch_bias_act_view(yv, bias2, act2, s);
+    if (a.ksplit > 1 && a.bst && a.ostep == 1) bst_fallback(a, s);                         // split-K: the gradient is final only after every K slice has been added
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1034,6 +1139,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned okbits = 0;                           // bit i (patch rows), bit 16+i (dy rows): the load is inside the image, else it is committed as zero
     u32x4 pv[6], yv[4];
+    // x operand = relu(x * scale + shift): the producer's BatchNorm + ReLU applied on the way into LDS (this thread always commits the same 4 channels)
+    const bool xf = a.in_scale != nullptr;
+    f32x4 xsc = {1.f, 1.f, 1.f, 1.f}, xsh = {0.f, 0.f, 0.f, 0.f};
+    if (xf) { xsc = *reinterpret_cast<const f32x4*>(a.in_scale + cgi * 32 + q * 4); xsh = *reinterpret_cast<const f32x4*>(a.in_shift + cgi * 32 + q * 4); }
     const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 #ifdef MD2_ABLATE
     const int abl = a.ablate;      // tools/conv_bench only: 1 no global loads, 64 no LDS commit, 32 no LDS operand reads, 4 no MFMA, 16 no atomics tail, 8 no barriers
@@ -1045,6 +1154,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
             if (!(abl & 8)) __syncthreads();                         // the previous tile's MFMAs are done reading LDS
             // (okbits still describes the registers being committed: it is recomputed for the next tile below)
             if (col < PW && !(abl & 64)) {
+                if (xf) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        f32x4 v = __builtin_bit_cast(f32x4, pv[i]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], xsc[e], xsh[e]), 0.f);
+                        pv[i] = __builtin_bit_cast(u32x4, v);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(Xs + ((i * PW + col) * 8 + q) * 4) = pv[i] & (0u - ((okbits >> i) & 1u));
             }
@@ -1178,12 +1296,18 @@ static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<0>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
 }
 
+// can the weight gradient of a 3x3 / stride-1 / pad-1 convolution on an H x W image take its x operand through the BatchNorm + ReLU input transform?
+bool conv_wgrad_supports_in_transform(int H, int W, int Cin, int Cout) {
+    WgradArgs a{}; a.KH = a.KW = 3; a.stride = 1; a.pad = 1; a.H = a.Ho = H; a.W = a.Wo = W; a.Cin = Cin; a.Cout = Cout;
+    return wgrad_taps32_eligible(a) && Cout % 64 == 0 && Cin % 16 == 0;
+}
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || a.M <= 0 || a.M >= (1 << 24)) {
         fprintf(stderr, "md2: conv_wgrad: unsupported shape Cin=%d Cout=%d M=%d\n", a.Cin, a.Cout, a.M);
         abort();
     }
     static const int max_t = getenv("MD2_WGRAD_MAXT") ? atoi(getenv("MD2_WGRAD_MAXT")) : 128;
+    if (a.in_scale && !wgrad_taps32_eligible(a)) { fprintf(stderr, "md2: conv_wgrad: the input transform is built into the all-taps kernel only (3x3, stride 1, channels %% 32 == 0)\n"); abort(); }
     if (g_deterministic && a.db && (wgrad_taps32_eligible(a) || wgrad_patch_eligible(a))) {      // the fused bias gradient adds one atomic per wave: use the ordered column sum
         View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s);
         WgradArgs b = a; b.db = nullptr;

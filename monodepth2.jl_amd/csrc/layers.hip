@@ -100,7 +100,8 @@ void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View&
 
 // running (optional, [mean[C] | var[C]]): Flux BatchNorm's tracked statistics, mu = (1 - mtm) mu + mtm mean, sigma^2 = (1 - mtm) sigma^2 + mtm * m/(m-1) * var
 // (Flux `_track_stats!`, momentum 0.1, unbiased correction of the batch variance)
-__global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int C, double count, int slots, float* __restrict__ running, float momentum) {
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int C, double count, int slots, float* __restrict__ running, float momentum,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0, s2 = 0;
@@ -110,40 +111,53 @@ __global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __rest
     if (var < 0) var = 0;
     stats[c] = (float)mean;
     stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+    if (gamma) {                                       // y = z * scale + shift == gamma * (z - mean) * invstd + beta: what a consumer's loader applies on the fly
+        const float sc = gamma[c] * stats[C + c];
+        stats[2 * C + c] = sc; stats[3 * C + c] = beta[c] - stats[c] * sc;
+    }
     if (running) {
         const float corr = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
         running[c] = (1.f - momentum) * running[c] + momentum * (float)mean;
         running[C + c] = (1.f - momentum) * running[C + c] + momentum * corr * (float)var;
     }
 }
-void launch_bn_finalize(const double* acc, float* stats, int C, double count, int slots, float* running, float momentum, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, stats, C, count, slots, running, momentum);
+void launch_bn_finalize(const double* acc, float* stats, int C, double count, int slots, float* running, float momentum, hipStream_t s, const float* gamma, const float* beta) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, stats, C, count, slots, running, momentum, gamma, beta);
 }
 // Flux.testmode!: normalise with the tracked statistics, (x - mu) / sqrt(sigma^2 + eps)
-__global__ void bn_stats_from_running_kernel(const float* __restrict__ running, float* __restrict__ stats, int C) {
+__global__ void bn_stats_from_running_kernel(const float* __restrict__ running, float* __restrict__ stats, int C, const float* __restrict__ gamma, const float* __restrict__ beta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     stats[c] = running[c];
     stats[C + c] = 1.f / sqrtf(running[C + c] + 1e-5f);
+    if (gamma) { const float sc = gamma[c] * stats[C + c]; stats[2 * C + c] = sc; stats[3 * C + c] = beta[c] - stats[c] * sc; }
 }
-void launch_bn_stats_from_running(const float* running, float* stats, int C, hipStream_t s) {
-    hipLaunchKernelGGL(bn_stats_from_running_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running, stats, C);
+void launch_bn_stats_from_running(const float* running, float* stats, int C, hipStream_t s, const float* gamma, const float* beta) {
+    hipLaunchKernelGGL(bn_stats_from_running_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running, stats, C, gamma, beta);
 }
 
 // FAST: the channel-quad count Q is a power of two (it divides the grid stride, so a thread keeps ONE quad for its whole life and the
 // per-channel constants are loaded once) and every view is dense NHWC (element i of the [pixels][Q] float4 array is at float offset 4 i:
 // no per-element 64-bit divisions).  Every BatchNorm of the encoder qualifies; the generic path serves strided views.
+// rstats / rgamma / rbeta (optional): the residual is itself a BatchNorm output that is not materialised -- the 1x1 shortcut branch of a down-sampling block:
+// y = act(bn(z) + bn_r(res)) in ONE pass instead of bn_r -> buffer -> add
 template <bool FAST>
 __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       View res, int has_res, int act, View y) {
+                                                       View res, int has_res, int act, View y, const float* __restrict__ rstats, const float* __restrict__ rgamma, const float* __restrict__ rbeta) {
     const int Q = z.C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
     if (FAST) {
         const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
         const float4 m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
+        float4 rm = make_float4(0.f, 0.f, 0.f, 0.f), ris = rm, rg = rm, rb = rm;
+        if (rstats) { rm = ld4(rstats + q * 4); ris = ld4(rstats + z.C + q * 4); rg = ld4(rgamma + q * 4); rb = ld4(rbeta + q * 4); }
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
             const float4 v = ld4(z.p + i * 4);
             float4 o = make_float4(g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w);
-            if (has_res) { const float4 rr = ld4(res.p + i * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+            if (has_res) {
+                float4 rr = ld4(res.p + i * 4);
+                if (rstats) rr = make_float4(rg.x * ((rr.x - rm.x) * ris.x) + rb.x, rg.y * ((rr.y - rm.y) * ris.y) + rb.y, rg.z * ((rr.z - rm.z) * ris.z) + rb.z, rg.w * ((rr.w - rm.w) * ris.w) + rb.w);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+            }
             o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
             st4(y.p + i * 4, o);
         }
@@ -153,29 +167,39 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __re
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
         const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
         float4 o = make_float4(g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w);
-        if (has_res) { const float4 rr = ld4(vptr(res, n, r) + q * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+        if (has_res) {
+            float4 rr = ld4(vptr(res, n, r) + q * 4);
+            if (rstats) {
+                const float4 rm = ld4(rstats + q * 4), ris = ld4(rstats + z.C + q * 4), rg = ld4(rgamma + q * 4), rb = ld4(rbeta + q * 4);
+                rr = make_float4(rg.x * ((rr.x - rm.x) * ris.x) + rb.x, rg.y * ((rr.y - rm.y) * ris.y) + rb.y, rg.z * ((rr.z - rm.z) * ris.z) + rb.z, rg.w * ((rr.w - rm.w) * ris.w) + rb.w);
+            }
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
         o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
         st4(vptrw(y, n, r) + q * 4, o);
     }
 }
-void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s) {
+void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s,
+                     const float* rstats, const float* rgamma, const float* rbeta) {
     const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(y) && (!residual || dense_view_h(*residual));
     const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
-    if (fast) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y);
+    if (fast) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
 }
 
 template <bool FAST>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, int has_yact, int act, View z, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const double* __restrict__ acc, double count, View dz, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           const double* __restrict__ acc, double count, View dz, float* __restrict__ dgamma, float* __restrict__ dbeta, int slots) {
+    // acc: [slots][sum g | sum g*xhat][C] (the sums may come from a producer's epilogue, spread over BN_STAT_SLOTS to spread its atomics)
     const int C = z.C, Q = C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
+    auto asum = [&](int idx) { double t = 0; for (int k = 0; k < slots; ++k) t += acc[(size_t)k * 2 * C + idx]; return t; };
     if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += (float)acc[c]; dgamma[c] += (float)acc[C + c]; }
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += (float)asum(c); dgamma[c] += (float)asum(C + c); }
     if (FAST) {                                 // one channel quad per thread: the per-channel constants (incl. 8 double divisions) leave the loop
         const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
         const float4 m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4);
-        const float m1[4] = {(float)(acc[q * 4] / count), (float)(acc[q * 4 + 1] / count), (float)(acc[q * 4 + 2] / count), (float)(acc[q * 4 + 3] / count)};
-        const float m2[4] = {(float)(acc[C + q * 4] / count), (float)(acc[C + q * 4 + 1] / count), (float)(acc[C + q * 4 + 2] / count), (float)(acc[C + q * 4 + 3] / count)};
+        const float m1[4] = {(float)(asum(q * 4) / count), (float)(asum(q * 4 + 1) / count), (float)(asum(q * 4 + 2) / count), (float)(asum(q * 4 + 3) / count)};
+        const float m2[4] = {(float)(asum(C + q * 4) / count), (float)(asum(C + q * 4 + 1) / count), (float)(asum(C + q * 4 + 2) / count), (float)(asum(C + q * 4 + 3) / count)};
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
             float4 g = ld4(dy.p + i * 4);
             if (has_yact) { const float4 o = ld4(yact.p + i * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
@@ -194,8 +218,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
         float4 g = ld4(vptr(dy, n, r) + q * 4);
         if (has_yact) { const float4 o = ld4(vptr(yact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
         const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4);
-        const float m1[4] = {(float)(acc[q * 4] / count), (float)(acc[q * 4 + 1] / count), (float)(acc[q * 4 + 2] / count), (float)(acc[q * 4 + 3] / count)};
-        const float m2[4] = {(float)(acc[C + q * 4] / count), (float)(acc[C + q * 4 + 1] / count), (float)(acc[C + q * 4 + 2] / count), (float)(acc[C + q * 4 + 3] / count)};
+        const float m1[4] = {(float)(asum(q * 4) / count), (float)(asum(q * 4 + 1) / count), (float)(asum(q * 4 + 2) / count), (float)(asum(q * 4 + 3) / count)};
+        const float m2[4] = {(float)(asum(C + q * 4) / count), (float)(asum(C + q * 4 + 1) / count), (float)(asum(C + q * 4 + 2) / count), (float)(asum(C + q * 4 + 3) / count)};
         float4 o;
         o.x = ga.x * is.x * (g.x - m1[0] - (v.x - m.x) * is.x * m2[0]);
         o.y = ga.y * is.y * (g.y - m1[1] - (v.y - m.y) * is.y * m2[1]);
@@ -205,11 +229,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
     }
 }
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc, double count,
-                         const View& dz, float* dgamma, float* dbeta, hipStream_t s) {
+                         const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots) {
     const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(dy) && dense_view_h(dz) && (!yact || dense_view_h(*yact));
     const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
-    if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta);
+    if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta, slots);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta, slots);
 }
 
 // ---- MaxPool((3,3); pad=1, stride=2): first maximum in (kh,kw) scan order wins; the argmax tap (0..8) is kept ------------
@@ -237,6 +261,39 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(View x, View y, uint8_
 void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s) {
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(y.pixels() * (x.C / 4), 256, 4096)), dim3(256), 0, s, x, y, arg);
 }
+// Stem tail fused: a = relu(bn(z)) is never read back -- one pass computes the 3x3 / stride-2 max-pool of a on the fly from z, and writes a itself only for the
+// frames the depth decoder's skip connection needs (n % L == tgt; all frames when L == 1).  Replaces bn_apply (read z, write a) + maxpool_fwd (read a).
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              View a, int L, int tgt, View y, uint8_t* __restrict__ arg) {
+    const int Q = z.C / 4; const long total = y.pixels() * Q; const int HWo = y.H * y.W;
+    const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % Q);              // grid stride is a multiple of Q: one channel quad per thread
+    const float4 m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / Q; const int n = p / HWo; const int r = p - (long)n * HWo; const int oh = r / y.W, ow = r - oh * y.W;
+        const bool wa = (L == 1) || (n % L) == tgt;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; uint8_t bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh; if (ih < 0 || ih >= z.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw; if (iw < 0 || iw >= z.W) continue;
+                const float4 v = ld4(vptr(z, n, (long)ih * z.W + iw) + q * 4);
+                float vv[4] = {g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vv[e] = vv[e] > 0.f ? vv[e] : 0.f; if (vv[e] > best[e]) { best[e] = vv[e]; bi[e] = kh * 3 + kw; } }
+                if (wa && kh >= 1 && kw >= 1) st4(vptrw(a, n, (long)ih * z.W + iw) + q * 4, make_float4(vv[0], vv[1], vv[2], vv[3]));   // this output owns the 2x2 block (2oh.., 2ow..)
+            }
+        }
+        st4(vptrw(y, n, r) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
+        *reinterpret_cast<uchar4*>(arg + (p * z.C + q * 4)) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s) {
+    if ((z.H & 1) || (z.W & 1) || y.H != z.H / 2 || y.W != z.W / 2 || z.C % 4 != 0 || (256 % (z.C / 4)) != 0) { fprintf(stderr, "md2: bn_relu_maxpool: unsupported shape\n"); abort(); }
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(y.pixels() * (z.C / 4), 256, 4096)), dim3(256), 0, s, z, stats, gamma, beta, a, L, tgt, y, arg);
+}
+
 // gather form: input pixel (ih,iw) is covered by outputs oh in {(ih+1)/2 - (0|1)}...; no atomics, deterministic
 // yrelu: the pooled OUTPUT of a max-pool over post-ReLU activations; the ReLU derivative of the winning input equals (pooled value > 0),
 // so the mask is read from the 4x smaller pooled tensor instead of the activations themselves

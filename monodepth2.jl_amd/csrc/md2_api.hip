@@ -35,7 +35,9 @@ struct ConvL {
 struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; long rs = 0; float* stats = nullptr; double* acc = nullptr; double* acc_b = nullptr; };   // rs: offset of (running mean[c], running var[c]) in md2_handle::RS
 // BasicBlock (ResNet-18): c1 3x3(stride) - b1 - relu - c2 3x3 - b2 (+ shortcut) - relu
 // Bottleneck (ResNet-50): c1 1x1 - b1 - relu - c2 3x3(stride) - b2 - relu - c3 1x1 x4 - b3 (+ shortcut) - relu     (torchvision convention)
-struct Block { ConvL c1, c2, c3, cd; BNL b1, b2, b3, bd; bool down = false, bottleneck = false, stage_end = false; int stride = 1;
+// fuse (BasicBlocks whose kernels support it): a1 = relu(bn1(z1)) is never materialised -- conv2 and its weight gradient apply bn1 + ReLU in their loaders, the
+// BatchNorm-pullback sums come out of the input-gradient epilogues, and the shortcut BatchNorm is applied inside the block's final bn + add + ReLU pass
+struct Block { ConvL c1, c2, c3, cd; BNL b1, b2, b3, bd; bool down = false, bottleneck = false, stage_end = false, fuse = false; int stride = 1;
                View in, z1, a1, z2, a2, z3, zd, sd, out; View dz1, dz2, dz3, dzd; };
 struct ProfEvt { hipEvent_t a, b; int cls; double flops; char desc[112]; };
 enum { CLS_IGEMM = 0, CLS_WGRAD = 1, CLS_LOSS_FWD = 2, CLS_LOSS_BWD = 3, CLS_OTHER = 4 };
@@ -179,14 +181,17 @@ static void plan_buffers(md2_handle* h) {
         B.in = cur;
         if (!B.bottleneck) {
             const int co = B.c1.cout;
-            B.z1 = h->alloc_view(NL, hh, ww, co); B.a1 = h->alloc_view(NL, hh, ww, co); B.z2 = h->alloc_view(NL, hh, ww, co);
+            static const bool no_fuse = getenv("MD2_NO_BN_FUSE") != nullptr;
+            B.fuse = !no_fuse && conv_wgrad_supports_in_transform(hh, ww, co, co);        // conv2 and its weight gradient can fold bn1 + ReLU into their loaders at this size
+            B.z1 = h->alloc_view(NL, hh, ww, co); B.z2 = h->alloc_view(NL, hh, ww, co);
+            B.a1 = B.fuse ? make_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co);      // fused: never materialised (the view only carries the shape)
         } else {
             const int pl = B.c1.cout, co = B.c3.cout;
             B.z1 = h->alloc_view(NL, hi, wi, pl); B.a1 = h->alloc_view(NL, hi, wi, pl);
             B.z2 = h->alloc_view(NL, hh, ww, pl); B.a2 = h->alloc_view(NL, hh, ww, pl); B.z3 = h->alloc_view(NL, hh, ww, co);
         }
         const int co = B.bottleneck ? B.c3.cout : B.c1.cout;
-        if (B.down) { B.zd = h->alloc_view(NL, hh, ww, co); B.sd = h->alloc_view(NL, hh, ww, co); }
+        if (B.down) { B.zd = h->alloc_view(NL, hh, ww, co); B.sd = B.fuse ? make_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co); }
         B.out = h->alloc_view(NL, hh, ww, co);
         cur = B.out;
         if (B.stage_end) h->feat[stage++] = B.out;
@@ -209,16 +214,16 @@ static void plan_buffers(md2_handle* h) {
     h->totals = h->alloc<float>(16 * N); h->loss_dev = h->alloc<float>(4); h->ddisp_full = h->alloc<float>((size_t)4 * N * H * W);
     h->drvec = h->alloc<float>(6 * N); h->dtvec = h->alloc<float>(6 * N);
     h->loss_blk = h->alloc<double>((size_t)4 * N * ((W + 15) / 16) * ((H + 7) / 8) * 24);        // deterministic mode: [scale*N][block][24] partials (bound for loss tiles >= 16x8)
-    for (BNL* b : h->bns) b->stats = h->alloc<float>(2 * b->c);
+    for (BNL* b : h->bns) b->stats = h->alloc<float>(4 * b->c);                 // mean | invstd | scale | shift
     size_t nd = 0;
-    for (BNL* b : h->bns) nd += (size_t)(2 * BN_STAT_SLOTS + 2) * b->c;
+    for (BNL* b : h->bns) nd += (size_t)(4 * BN_STAT_SLOTS) * b->c;
     nd += (size_t)16 * N + 24 * N;
     h->acc_count = nd; h->acc_all = h->alloc<double>(nd);
     double* ap = h->acc_all;
     for (BNL* b : h->bns) { b->acc = ap; ap += (size_t)2 * BN_STAT_SLOTS * b->c; }      // [slot][sum | sum of squares][c]
     h->acc_fwd_count = ap - h->acc_all;
     h->acc_bwd = ap;
-    for (BNL* b : h->bns) { b->acc_b = ap; ap += 2 * b->c; }
+    for (BNL* b : h->bns) { b->acc_b = ap; ap += (size_t)2 * BN_STAT_SLOTS * b->c; }    // [slot][sum g | sum g*xhat][c]: filled by the producing input gradient's epilogue
     h->acc_bwd_count = ap - h->acc_bwd;
     h->loss_part = ap; ap += 16 * N; h->dRt_acc = ap; ap += 24 * N;
     // ---- backward: gradient accumulators, zeroed together at the start of every backward
@@ -259,6 +264,7 @@ static ConvArgs conv_args(const View& x, const float* w, const View& y, int KH, 
     a.bias = nullptr; a.act = ACT_NONE; a.accumulate = 0; a.dact_src = nullptr; a.da_bs = 0; a.da_ps = 0; a.dact = ACT_NONE;
     a.M = y.N * y.H * y.W;
     a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = y.H; a.Wl = y.W; a.kh0 = 0; a.khs = 1; a.nkh = KH; a.kw0 = 0; a.kws = 1; a.nkw = KH;
+    a.accumulate_c00 = -1;
     return a;
 }
 static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
@@ -275,12 +281,15 @@ static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y
     run_igemm(h, a);
 }
 // input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
-static void conv_dgrad(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact, const View* res = nullptr) {
+static ConvArgs dgrad_args(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact, const View* res = nullptr) {
     ConvArgs a = conv_args(dy, h->WD + c.w, dx, c.k, 1, c.k - 1 - pad_fwd, c.stride, PAD_ZERO);
     a.accumulate = accumulate;
     if (dact_src) { a.dact_src = dact_src->p; a.da_bs = dact_src->bs; a.da_ps = dact_src->ps; a.dact = dact; }
     if (res) { a.res = res->p; a.res_bs = res->bs; a.res_ps = res->ps; }
-    run_igemm(h, a);
+    return a;
+}
+static void conv_dgrad(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact, const View* res = nullptr) {
+    run_igemm(h, dgrad_args(h, c, dy, dx, pad_fwd, accumulate, dact_src, dact, res));
 }
 // stream a weight gradient is enqueued on: the side stream, forked by event from the chain at this point (its dy is complete)
 static hipStream_t wgrad_stream(md2_handle* h) {
@@ -293,8 +302,9 @@ static hipStream_t wgrad_stream(md2_handle* h) {
     }
     return st;
 }
-static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View& dy, int padmode) {
+static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View& dy, int padmode, const BNL* xbn = nullptr) {
     WgradArgs a{};
+    if (xbn) { a.in_scale = xbn->stats + 2 * xbn->c; a.in_shift = xbn->stats + 3 * xbn->c; }      // x is the raw conv output of the layer before: relu(bn(x)) on the fly
     a.x = x.p; a.x_bs = x.bs; a.x_ps = x.ps; a.H = x.H; a.W = x.W; a.Cin = x.C;
     a.dy = dy.p; a.dy_bs = dy.bs; a.dy_ps = dy.ps; a.Ho = dy.H; a.Wo = dy.W; a.Cout = dy.C;
     a.dw = h->G + c.w; a.N = dy.N; a.KH = c.kind == 1 ? 1 : c.k; a.KW = a.KH; a.stride = c.kind == 1 ? 1 : c.stride; a.pad = c.kind == 1 ? 0 : (padmode == PAD_REFLECT ? 1 : c.pad); a.padmode = padmode;
@@ -307,15 +317,24 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
 }
 // the batch statistics were accumulated into b.acc by the convolution that produced z (conv_fwd(..., b.acc))
 // (test mode, Flux.testmode!: the tracked running statistics instead; train mode also updates them, momentum 0.1)
+// b.stats = mean | invstd | scale | shift: the last two let a consumer apply y = z * scale + shift in its loader instead of reading a materialised y
+static void bn_stats(md2_handle* h, const BNL& b, const View& z) {
+    if (h->testmode) launch_bn_stats_from_running(h->RS + b.rs, b.stats, b.c, h->chain(), h->P + b.g, h->P + b.b);
+    else launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), BN_STAT_SLOTS, h->RS + b.rs, 0.1f, h->chain(), h->P + b.g, h->P + b.b);
+}
 static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* residual, int act, const View& y) {
-    if (h->testmode) launch_bn_stats_from_running(h->RS + b.rs, b.stats, b.c, h->chain());
-    else launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), BN_STAT_SLOTS, h->RS + b.rs, 0.1f, h->chain());
+    bn_stats(h, b, z);
     launch_bn_apply(z, b.stats, h->P + b.g, h->P + b.b, residual, act, y, h->chain());
 }
-// dy: gradient wrt the BN output (already masked by any following ReLU) -> dz
-static void bn_bwd(md2_handle* h, const BNL& b, const View& dy, const View& z, const View& dz) {
-    launch_bn_bwd_reduce(dy, nullptr, ACT_NONE, z, b.stats, b.acc_b, h->chain());
-    launch_bn_bwd_apply(dy, nullptr, ACT_NONE, z, b.stats, h->P + b.g, b.acc_b, (double)z.pixels(), dz, h->G + b.g, h->G + b.b, h->chain());
+// dy: gradient wrt the BN output (already masked by any following ReLU) -> dz.  have_sums: the producer of dy already accumulated sum dy / sum dy*xhat into b.acc_b
+static void bn_bwd(md2_handle* h, const BNL& b, const View& dy, const View& z, const View& dz, bool have_sums = false) {
+    if (!have_sums) launch_bn_bwd_reduce(dy, nullptr, ACT_NONE, z, b.stats, b.acc_b, h->chain());
+    launch_bn_bwd_apply(dy, nullptr, ACT_NONE, z, b.stats, h->P + b.g, b.acc_b, (double)z.pixels(), dz, h->G + b.g, h->G + b.b, h->chain(), BN_STAT_SLOTS);
+}
+// ask the launch that produces gradient `g` to also accumulate the BatchNorm-pullback sums of BatchNorm b (input z) -- and of a second one that consumes the same g
+static void want_bn_sums(ConvArgs& a, const BNL& b, const View& z, const BNL* b2 = nullptr, const View* z2 = nullptr) {
+    a.bst = b.acc_b; a.bz = z.p; a.bz_bs = z.bs; a.bz_ps = z.ps; a.bstat = b.stats;
+    if (b2) { a.bstB = b2->acc_b; a.bzB = z2->p; a.bzB_bs = z2->bs; a.bzB_ps = z2->ps; a.bstatB = b2->stats; }
 }
 
 static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp[4], const float* Rt, const float* auto_loss) {
@@ -367,10 +386,25 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
         if (g_deterministic && !h->testmode) launch_colstats(h->z0, h->stem_bn.acc, s);
         if (h->prof) h->prof_flops[CLS_IGEMM] += fl;
     }
-    bn_fwd(h, h->stem_bn, h->z0, nullptr, ACT_RELU, h->a0);
-    launch_maxpool_fwd(h->a0, h->p0, h->pool_arg, s);
+    // stem tail in one pass: BatchNorm + ReLU + max-pool; a0 is written only where the decoder's skip connection reads it (the target frames)
+    bn_stats(h, h->stem_bn, h->z0);
+    launch_bn_relu_maxpool(h->z0, h->stem_bn.stats, h->P + h->stem_bn.g, h->P + h->stem_bn.b, h->a0, L, tgt, h->p0, h->pool_arg, s);
     for (int i = 0; i < h->nblk; ++i) {
         Block& B = h->blk[i];
+        if (B.fuse) {
+            conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_stats(h, B.b1, B.z1);
+            {   // conv2 gathers relu(bn1(z1)) straight from z1
+                ConvArgs a = conv_args(B.z1, h->P + B.c2.w, B.z2, B.c2.k, B.c2.stride, B.c2.pad, 1, PAD_ZERO);
+                a.in_scale = B.b1.stats + 2 * B.b1.c; a.in_shift = B.b1.stats + 3 * B.b1.c; a.stats = h->testmode ? nullptr : B.b2.acc;
+                run_igemm(h, a);
+            }
+            bn_stats(h, B.b2, B.z2);
+            if (B.down) {                 // out = relu(bn2(z2) + bnd(zd)): the shortcut's BatchNorm output is never written
+                conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc); bn_stats(h, B.bd, B.zd);
+                launch_bn_apply(B.z2, B.b2.stats, h->P + B.b2.g, h->P + B.b2.b, &B.zd, ACT_RELU, B.out, s, B.bd.stats, h->P + B.bd.g, h->P + B.bd.b);
+            } else launch_bn_apply(B.z2, B.b2.stats, h->P + B.b2.g, h->P + B.b2.b, &B.in, ACT_RELU, B.out, s);
+            continue;
+        }
         conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_fwd(h, B.b1, B.z1, nullptr, ACT_RELU, B.a1);
         conv_fwd(h, B.c2, B.a1, B.z2, PAD_ZERO, ACT_NONE, B.b2.acc);
         if (B.bottleneck) { bn_fwd(h, B.b2, B.z2, nullptr, ACT_RELU, B.a2); conv_fwd(h, B.c3, B.a2, B.z3, PAD_ZERO, ACT_NONE, B.b3.acc); }
@@ -523,12 +557,42 @@ static int model_backward(md2_handle* h) {
     } else { pose_backward(h, N, 0); pose_backward(h, N, 1); }
     if (int r = comm_bucket(h, h->dc1[0].w, h->n_int)) return r;           // depth decoder, heads, pose decoder
     // ---- encoder
+    // BatchNorm pullbacks need sum g and sum g*xhat over the whole batch before the first dz can be formed.  Where the kernels allow it these sums are accumulated by
+    // the epilogue of the input-gradient launch that PRODUCES g (its last writer), so the separate reduction pass over (g, z) disappears; `sums_ready[i]` says whether
+    // block i's output-side BatchNorms (bn2 and the shortcut's) got theirs that way.
+    bool sums_ready[16]; for (int i = 0; i < 16; ++i) sums_ready[i] = false;
     for (int i = h->nblk - 1; i >= 0; --i) {
         Block& B = h->blk[i];
         const View& Gout = h->Gblk[i];                                  // d / d(pre-ReLU block output), already masked
         const View* Gin = (i == 0) ? &h->Gpool : &h->Gblk[i - 1];
         const View* in_act = (i == 0) ? nullptr : &B.in;                 // ReLU mask of the block input (stage 0: applied in the maxpool pullback)
         const View& dz1 = B.dz1; View da1 = make_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C);
+        // first encoder writer of Gin: own buffers (and the pool gradient) are overwritten; stage buffers already hold the decoder's contribution in the target frames
+        const int first_mode = (i == 0 || !h->blk[i - 1].stage_end) ? 0 : 2;
+        // the launch that completes Gin also reduces the BatchNorm-pullback sums of the block below (bn2 / bn3 and, for a down-sampling block, the shortcut's BatchNorm)
+        Block* Bp = (i > 0 && h->blk[i - 1].fuse) ? &h->blk[i - 1] : nullptr;
+        if (B.fuse) {
+            bn_bwd(h, B.b2, Gout, B.z2, B.dz2, sums_ready[i]);
+            conv_wgrad(h, B.c2, B.z1, B.dz2, PAD_ZERO, &B.b1);               // x = relu(bn1(z1)) formed in the loader
+            {   // da1 = (W2^T dz2) * relu'(bn1(z1)), and the sums of bn1's pullback from the same epilogue
+                ConvArgs a = dgrad_args(h, B.c2, B.dz2, da1, 1, 0, &B.z1, ACT_RELU);
+                a.dact_scale = B.b1.stats + 2 * B.b1.c; a.dact_shift = B.b1.stats + 3 * B.b1.c;
+                want_bn_sums(a, B.b1, B.z1);
+                run_igemm(h, a);
+            }
+            bn_bwd(h, B.b1, da1, B.z1, dz1, true);
+            conv_wgrad(h, B.c1, B.in, dz1, PAD_ZERO);
+            if (B.down) {           // the 1x1 / stride-2 shortcut writes its quarter of the pixels FIRST; the 3x3's residue classes then complete every pixel exactly once
+                bn_bwd(h, B.bd, Gout, B.zd, B.dzd, sums_ready[i]);
+                conv_wgrad(h, B.cd, B.in, B.dzd, PAD_ZERO);
+                ConvArgs ad = dgrad_args(h, B.cd, B.dzd, *Gin, 0, first_mode, in_act, ACT_RELU); ad.skip_empty = 1;
+                run_igemm(h, ad);
+            }
+            ConvArgs a = dgrad_args(h, B.c1, dz1, *Gin, B.c1.pad, first_mode, in_act, ACT_RELU, B.down ? nullptr : &Gout);
+            if (B.down) a.accumulate_c00 = 1;
+            if (Bp) { want_bn_sums(a, Bp->b2, Bp->z2, Bp->down ? &Bp->bd : nullptr, Bp->down ? &Bp->zd : nullptr); sums_ready[i - 1] = true; }
+            run_igemm(h, a);
+        } else {
         if (!B.bottleneck) {
             bn_bwd(h, B.b2, Gout, B.z2, B.dz2);
             conv_wgrad(h, B.c2, B.a1, B.dz2, PAD_ZERO);
@@ -544,16 +608,20 @@ static int model_backward(md2_handle* h) {
         }
         bn_bwd(h, B.b1, da1, B.z1, dz1);
         conv_wgrad(h, B.c1, B.in, dz1, PAD_ZERO);
-        // first encoder writer of Gin: own buffers (and the pool gradient) are overwritten; stage buffers already hold the decoder's
-        // contribution in the target frames
         // identity shortcut: d(block input) = relu'(in) * (conv1 pullback + Gout) -- Gout is added in the same epilogue (was an axpy pass)
-        const int first_mode = (i == 0 || !h->blk[i - 1].stage_end) ? 0 : 2;
-        conv_dgrad(h, B.c1, dz1, *Gin, B.c1.pad, first_mode, in_act, ACT_RELU, B.down ? nullptr : &Gout);
-        if (B.down) {
+        if (B.down) {           // (the last writer of Gin must be a launch that covers every pixel: the shortcut's input gradient goes first when the block below wants its sums)
             const View& dzd = B.dzd;
             bn_bwd(h, B.bd, Gout, B.zd, dzd);
             conv_wgrad(h, B.cd, B.in, dzd, PAD_ZERO);
-            conv_dgrad(h, B.cd, dzd, *Gin, 0, 1, in_act, ACT_RELU);
+            if (Bp) { ConvArgs ad = dgrad_args(h, B.cd, dzd, *Gin, 0, first_mode, in_act, ACT_RELU); ad.skip_empty = 1; run_igemm(h, ad); }
+        }
+        {
+            ConvArgs a = dgrad_args(h, B.c1, dz1, *Gin, B.c1.pad, first_mode, in_act, ACT_RELU, B.down ? nullptr : &Gout);
+            if (B.down && Bp) a.accumulate_c00 = 1;
+            if (Bp) { want_bn_sums(a, Bp->b2, Bp->z2, Bp->down ? &Bp->bd : nullptr, Bp->down ? &Bp->zd : nullptr); sums_ready[i - 1] = true; }
+            run_igemm(h, a);
+        }
+        if (B.down && !Bp) conv_dgrad(h, B.cd, B.dzd, *Gin, 0, 1, in_act, ACT_RELU);
         }
         if (i == stage_first[3]) { if (int r = comm_bucket(h, h->blk[i].c1.w, h->dc1[0].w)) return r; }                                  // encoder layer 4
         else if (i == stage_first[1] && stage_first[1] != stage_first[3]) { if (int r = comm_bucket(h, h->blk[i].c1.w, h->blk[stage_first[3]].c1.w)) return r; }   // layers 2-3

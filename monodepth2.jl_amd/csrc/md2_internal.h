@@ -72,6 +72,19 @@ struct ConvArgs {
     // bf16 mixed precision (md2_config.precision = 1): the operands of the 32x32 MFMA tiles are rounded to bf16 on their way from LDS to the
     // matrix pipe (v_cvt_pk_bf16_f32 + v_mfma_f32_32x32x16_bf16); accumulation, storage, weights and every other kernel stay fp32
     int bf16;
+    // ---- BatchNorm folded into the neighbouring convolutions (the activation a = relu(bn(z)) between two encoder convs is never materialised) ----
+    // input transform: the gathered operand is relu(x * in_scale[ci] + in_shift[ci]) (zero padding applies AFTER it); null = the raw tensor
+    const float* in_scale; const float* in_shift;
+    // the activation derivative is evaluated at dact_src * dact_scale[co] + dact_shift[co] (dact_src is then the producer's raw conv output z)
+    const float* dact_scale; const float* dact_shift;
+    // BatchNorm-pullback sums of THIS launch's final output g (after residual / act' / accumulate), fused into the 32x32 tiles' epilogue (a column pass otherwise):
+    //   bst[slot][0..Cout) += sum_px g ; bst[slot][Cout..2Cout) += sum_px g * xhat,  xhat = (bz - mean) * invstd with bstat = mean | invstd.
+    // A second (bstB, bzB, bstatB) serves a block output that feeds two BatchNorms (main branch and 1x1 shortcut).
+    double* bst; const float* bz; long bz_bs; int bz_ps; const float* bstat;
+    double* bstB; const float* bzB; long bzB_bs; int bzB_ps; const float* bstatB;
+    // stride-2 input gradient split into residue classes: accumulate mode of class (0,0) if >= 0 (the 1x1 shortcut's input gradient wrote exactly those pixels first);
+    // skip_empty: residue classes without a tap are left untouched instead of refusing a non-accumulating launch
+    int accumulate_c00, skip_empty;
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only
 #endif
@@ -88,11 +101,13 @@ struct WgradArgs {
     int M;
     int bf16;                     // same switch for the all-taps weight gradient (conv3x3_wgrad_taps32_kernel)
     float* db;                    // optional bias gradient: db[co] += sum_{n,oh,ow} dy (fused into the all-taps kernels, a colsum launch otherwise)
+    const float* in_scale; const float* in_shift;      // x operand = relu(x * in_scale[ci] + in_shift[ci]) applied on the way into LDS (all-taps kernel only); null = raw
 #ifdef MD2_ABLATE
     int ablate;
 #endif
 };
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
+bool conv_wgrad_supports_in_transform(int H, int W, int Cin, int Cout);
 
 // weight transforms between the three layouts
 //   flux   : [Cout][Cin][KH][KW], true convolution (kernel flipped)           (boundary)
@@ -117,15 +132,19 @@ void launch_nchw_to_view(const float* src, const View& v, hipStream_t s);
 // per-channel sum / sum of squares of a view -> double[2*C] (must be zeroed by caller)
 void launch_colstats(const View& z, double* acc, hipStream_t s);
 // mean/invstd from acc; also zeroes nothing.  stats: float[2*C] = mean, invstd
-void launch_bn_finalize(const double* acc /*[slots][2C]*/, float* stats, int C, double count, int slots, float* running /* [2C] or null */, float momentum, hipStream_t s);
-void launch_bn_stats_from_running(const float* running, float* stats, int C, hipStream_t s);
+// stats: float[4*C] = mean | invstd | scale | shift (the last two only when gamma / beta are given: y = z * scale + shift, what a consumer's loader applies)
+void launch_bn_finalize(const double* acc /*[slots][2C]*/, float* stats, int C, double count, int slots, float* running /* [2C] or null */, float momentum, hipStream_t s,
+                        const float* gamma = nullptr, const float* beta = nullptr);
+void launch_bn_stats_from_running(const float* running, float* stats, int C, hipStream_t s, const float* gamma = nullptr, const float* beta = nullptr);
+void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s);
 // y = act(gamma*(z-mean)*invstd + beta + residual)
-void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s);
+void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s,
+                     const float* rstats = nullptr, const float* rgamma = nullptr, const float* rbeta = nullptr);      // r*: the residual is a raw conv output, BatchNorm'ed on the fly
 // g = dy * act_deriv(yact) ; acc[0..C) += sum g ; acc[C..2C) += sum g*xhat          (acc double, zeroed by caller)
 void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View& z, const float* stats, double* acc, hipStream_t s);
 // dz = gamma*invstd*(g - s1/M - xhat*s2/M) ; dgamma += s2, dbeta += s1 (written by block 0)
-void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc,
-                         double count, const View& dz, float* dgamma, float* dbeta, hipStream_t s);
+void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc /* [slots][2C] */,
+                         double count, const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots = 1);
 void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s);
 // dx (+)= scatter of dy by arg, gather form; optional multiply by relu'(xact).  accumulate as in ConvArgs (0 / 1 / 2)
 void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu /* pooled output of a post-ReLU input, or null */, hipStream_t s);
