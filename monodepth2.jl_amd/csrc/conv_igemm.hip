@@ -31,6 +31,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
+#ifndef MD2_LATE_MASK
+#define MD2_LATE_MASK 1   // 1: zero-padding masks are applied when the gathered rows go to LDS (after the step's MFMAs) instead of right after the global loads
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -149,7 +152,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const uint4 v = *reinterpret_cast<const uint4*>(xb + (a_off[t][j] + (unsigned)(ci0 * 4)));
-            const unsigned mk = XF ? 0xFFFFFFFFu : 0u - ((a_mbits[j] >> t) & 1u);          // XF: the mask is applied after the transform, in lstore
+            const unsigned mk = (XF || MD2_LATE_MASK) ? 0xFFFFFFFFu : 0u - ((a_mbits[j] >> t) & 1u);          // late: the mask (and the XF transform) are applied in lstore, so the loads' wait sits behind the MFMAs
             ra[j] = make_float4(__uint_as_float(v.x & mk), __uint_as_float(v.y & mk), __uint_as_float(v.z & mk), __uint_as_float(v.w & mk));
         }
 #pragma unroll
@@ -169,10 +172,20 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         }
     };
     auto xf_apply = [&](int tt) {               // tt: filter tap of the data in ra[] (its padding mask)
+        if constexpr (XF == 0 && MD2_LATE_MASK != 0) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                unsigned mb = a_mbits[j]; asm volatile("" : "+v"(mb));            // keeps hipcc from hoisting NT x A_LD mask registers out of the loop
+                const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)mb, (unsigned)tt, 1u);
+                const float4 v = ra[j];
+                ra[j] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk), __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+            }
+        }
         if constexpr (XF != 0) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) {
-                const unsigned mk = 0u - ((a_mbits[j] >> tt) & 1u);
+                unsigned mb = a_mbits[j]; asm volatile("" : "+v"(mb));
+                const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)mb, (unsigned)tt, 1u);
                 float4 v = ra[j];
                 v.x = fmaxf(fmaf(v.x, xsc.x, xsh.x), 0.f); v.y = fmaxf(fmaf(v.y, xsc.y, xsh.y), 0.f); v.z = fmaxf(fmaf(v.z, xsc.z, xsh.z), 0.f); v.w = fmaxf(fmaf(v.w, xsc.w, xsh.w), 0.f);
                 ra[j] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk), __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
@@ -277,7 +290,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             if (!(abl & 1)) gload(last2 ? NT - 1 : t2, c2 << 4);
             if (!(abl & 2)) read_ops(o1, nxt);
             if (!(abl & 4)) mfmas(cur);
-            if (!(abl & 2)) lstore(o2);
+            if (!(abl & 2)) { xf_apply(last2 ? NT - 1 : t2); lstore(o2); }
             if (!(abl & 8)) __syncthreads();
             cur = nxt;
             { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
@@ -395,8 +408,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     }
 }
 
+// (the 128x64 tile runs 3 blocks per CU -- its 46 KB of LDS allow no more -- which needs <= 168 registers incl. the 32 accumulators: the variants with the input
+//  transform / the pullback sums must not fall to 2)
 template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0, int XF = 0, int BST = 0>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (XF || BST)) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * (BF == 0 ? LDK : 12)];
     conv_igemm_body<BM, BN, WP, WC, MF, NT, BF, XF, BST>(a, smem, blockIdx.x, gridDim.x);
 }
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 // under-filled tail (312 blocks x 32..128 K-steps on 256 CUs at B=32; 40 blocks at B=4).
 struct ConvClasses { ConvArgs c[4]; int first[5]; };      // blocks [first[i], first[i+1]) belong to class i
 template <int BM, int BN, int WP, int WC, int MF, int BF = 0, int BST = 0>
-__global__ __launch_bounds__(256) void conv_igemm_classes_kernel(ConvClasses k) {
+__global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_classes_kernel(ConvClasses k) {
     __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * (BF == 0 ? LDK : 12)];
     const int b = blockIdx.x;
     const int cls = b < k.first[1] ? 0 : (b < k.first[2] ? 1 : (b < k.first[3] ? 2 : 3));
@@ -650,7 +665,8 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
 static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
     long tiles128 = 0;
     for (int i = 0; i < n; ++i) { check_igemm_args(k.c[i]); tiles128 += (k.c[i].M + 127) / 128; }
-    if (tiles128 * (k.c[0].Cout / 64) >= 384) launch_classes_t<128>(k, n, s); else launch_classes_t<64>(k, n, s);
+    static const long big = getenv("MD2_IGEMM_BIG_TILES") ? atol(getenv("MD2_IGEMM_BIG_TILES")) : 3000;
+    if (tiles128 * (k.c[0].Cout / 64) >= big) launch_classes_t<128>(k, n, s); else launch_classes_t<64>(k, n, s);
 }
 
 // Input-gradient of a strided convolution (dil = forward stride): an output pixel of residue class (ph,pw) mod dil only
@@ -741,7 +757,10 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
         default: break;
     }
 #endif
-    if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= 384) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
+    // 64x64 tiles (5 blocks per CU) balance the 256 CUs better than 128x64 (3 per CU) on every encoder layer at batch 32 (624 .. 2496 tiles: 1.6 .. 3.25 rounds of 768
+    // resident 128x64 blocks) and are never slower there (tools/conv_bench, round 2: 87.8 / 92.5 / 93.5 / 81.2 vs 87.2 / 91.4 / 85.2 / 65.1 TFLOP/s on the four stage shapes)
+    static const long big = getenv("MD2_IGEMM_BIG_TILES") ? atol(getenv("MD2_IGEMM_BIG_TILES")) : 3000;
+    if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
     if (a.ksplit > 1 && (bias2 || act2 != ACT_NONE)) launch_bias_act_view(yv, bias2, act2, s);

@@ -187,28 +187,32 @@ void launch_bn_apply(const View& z, const float* stats, const float* gamma, cons
     else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
 }
 
+// sums -> per-channel coefficients, once per BatchNorm (it used to be redone by every thread of the apply kernel): coef = m1 | m2 = sum g / count | sum g*xhat / count;
+// also d gamma += sum g*xhat, d beta += sum g.  acc: [slots][sum g | sum g*xhat][C] (a producer's epilogue spreads its atomics over BN_STAT_SLOTS)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, int slots, int C, double count, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < slots; ++k) { s1 += acc[(size_t)k * 2 * C + c]; s2 += acc[(size_t)k * 2 * C + C + c]; }
+    coef[c] = (float)(s1 / count); coef[C + c] = (float)(s2 / count);
+    dbeta[c] += (float)s1; dgamma[c] += (float)s2;
+}
 template <bool FAST>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, int has_yact, int act, View z, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const double* __restrict__ acc, double count, View dz, float* __restrict__ dgamma, float* __restrict__ dbeta, int slots) {
-    // acc: [slots][sum g | sum g*xhat][C] (the sums may come from a producer's epilogue, spread over BN_STAT_SLOTS to spread its atomics)
+                                                           const float* __restrict__ coef, View dz) {
     const int C = z.C, Q = C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
-    auto asum = [&](int idx) { double t = 0; for (int k = 0; k < slots; ++k) t += acc[(size_t)k * 2 * C + idx]; return t; };
-    if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += (float)asum(c); dgamma[c] += (float)asum(C + c); }
-    if (FAST) {                                 // one channel quad per thread: the per-channel constants (incl. 8 double divisions) leave the loop
+    if (FAST) {                                 // one channel quad per thread: the per-channel constants leave the loop
         const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
-        const float4 m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4);
-        const float m1[4] = {(float)(asum(q * 4) / count), (float)(asum(q * 4 + 1) / count), (float)(asum(q * 4 + 2) / count), (float)(asum(q * 4 + 3) / count)};
-        const float m2[4] = {(float)(asum(C + q * 4) / count), (float)(asum(C + q * 4 + 1) / count), (float)(asum(C + q * 4 + 2) / count), (float)(asum(C + q * 4 + 3) / count)};
+        const float4 m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4), m1 = ld4(coef + q * 4), m2 = ld4(coef + C + q * 4);
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
             float4 g = ld4(dy.p + i * 4);
             if (has_yact) { const float4 o = ld4(yact.p + i * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
             const float4 v = ld4(z.p + i * 4);
             float4 o;
-            o.x = ga.x * is.x * (g.x - m1[0] - (v.x - m.x) * is.x * m2[0]);
-            o.y = ga.y * is.y * (g.y - m1[1] - (v.y - m.y) * is.y * m2[1]);
-            o.z = ga.z * is.z * (g.z - m1[2] - (v.z - m.z) * is.z * m2[2]);
-            o.w = ga.w * is.w * (g.w - m1[3] - (v.w - m.w) * is.w * m2[3]);
+            o.x = ga.x * is.x * (g.x - m1.x - (v.x - m.x) * is.x * m2.x);
+            o.y = ga.y * is.y * (g.y - m1.y - (v.y - m.y) * is.y * m2.y);
+            o.z = ga.z * is.z * (g.z - m1.z - (v.z - m.z) * is.z * m2.z);
+            o.w = ga.w * is.w * (g.w - m1.w - (v.w - m.w) * is.w * m2.w);
             st4(dz.p + i * 4, o);
         }
         return;
@@ -217,23 +221,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
         float4 g = ld4(vptr(dy, n, r) + q * 4);
         if (has_yact) { const float4 o = ld4(vptr(yact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4);
-        const float m1[4] = {(float)(asum(q * 4) / count), (float)(asum(q * 4 + 1) / count), (float)(asum(q * 4 + 2) / count), (float)(asum(q * 4 + 3) / count)};
-        const float m2[4] = {(float)(asum(C + q * 4) / count), (float)(asum(C + q * 4 + 1) / count), (float)(asum(C + q * 4 + 2) / count), (float)(asum(C + q * 4 + 3) / count)};
+        const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4), m1 = ld4(coef + q * 4), m2 = ld4(coef + C + q * 4);
         float4 o;
-        o.x = ga.x * is.x * (g.x - m1[0] - (v.x - m.x) * is.x * m2[0]);
-        o.y = ga.y * is.y * (g.y - m1[1] - (v.y - m.y) * is.y * m2[1]);
-        o.z = ga.z * is.z * (g.z - m1[2] - (v.z - m.z) * is.z * m2[2]);
-        o.w = ga.w * is.w * (g.w - m1[3] - (v.w - m.w) * is.w * m2[3]);
+        o.x = ga.x * is.x * (g.x - m1.x - (v.x - m.x) * is.x * m2.x);
+        o.y = ga.y * is.y * (g.y - m1.y - (v.y - m.y) * is.y * m2.y);
+        o.z = ga.z * is.z * (g.z - m1.z - (v.z - m.z) * is.z * m2.z);
+        o.w = ga.w * is.w * (g.w - m1.w - (v.w - m.w) * is.w * m2.w);
         st4(vptrw(dz, n, r) + q * 4, o);
     }
 }
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc, double count,
-                         const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots) {
+                         const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots, float* coef) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((z.C + 255) / 256), dim3(256), 0, s, acc, slots, z.C, count, coef, dgamma, dbeta);
     const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(dy) && dense_view_h(dz) && (!yact || dense_view_h(*yact));
     const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
-    if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta, slots);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, acc, count, dz, dgamma, dbeta, slots);
+    if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz);
 }
 
 // ---- MaxPool((3,3); pad=1, stride=2): first maximum in (kh,kw) scan order wins; the argmax tap (0..8) is kept ------------

@@ -214,7 +214,7 @@ static void plan_buffers(md2_handle* h) {
     h->totals = h->alloc<float>(16 * N); h->loss_dev = h->alloc<float>(4); h->ddisp_full = h->alloc<float>((size_t)4 * N * H * W);
     h->drvec = h->alloc<float>(6 * N); h->dtvec = h->alloc<float>(6 * N);
     h->loss_blk = h->alloc<double>((size_t)4 * N * ((W + 15) / 16) * ((H + 7) / 8) * 24);        // deterministic mode: [scale*N][block][24] partials (bound for loss tiles >= 16x8)
-    for (BNL* b : h->bns) b->stats = h->alloc<float>(4 * b->c);                 // mean | invstd | scale | shift
+    for (BNL* b : h->bns) b->stats = h->alloc<float>(6 * b->c);                 // mean | invstd | scale | shift | pullback m1 | m2
     size_t nd = 0;
     for (BNL* b : h->bns) nd += (size_t)(4 * BN_STAT_SLOTS) * b->c;
     nd += (size_t)16 * N + 24 * N;
@@ -329,7 +329,7 @@ static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* resid
 // dy: gradient wrt the BN output (already masked by any following ReLU) -> dz.  have_sums: the producer of dy already accumulated sum dy / sum dy*xhat into b.acc_b
 static void bn_bwd(md2_handle* h, const BNL& b, const View& dy, const View& z, const View& dz, bool have_sums = false) {
     if (!have_sums) launch_bn_bwd_reduce(dy, nullptr, ACT_NONE, z, b.stats, b.acc_b, h->chain());
-    launch_bn_bwd_apply(dy, nullptr, ACT_NONE, z, b.stats, h->P + b.g, b.acc_b, (double)z.pixels(), dz, h->G + b.g, h->G + b.b, h->chain(), BN_STAT_SLOTS);
+    launch_bn_bwd_apply(dy, nullptr, ACT_NONE, z, b.stats, h->P + b.g, b.acc_b, (double)z.pixels(), dz, h->G + b.g, h->G + b.b, h->chain(), BN_STAT_SLOTS, b.stats + 4 * b.c);
 }
 // ask the launch that produces gradient `g` to also accumulate the BatchNorm-pullback sums of BatchNorm b (input z) -- and of a second one that consumes the same g
 static void want_bn_sums(ConvArgs& a, const BNL& b, const View& z, const BNL* b2 = nullptr, const View* z2 = nullptr) {
@@ -1072,14 +1072,14 @@ int32_t md2_bn_train_bwd(const float* x, const float* gamma, const float* dy, fl
     hipStream_t s = (hipStream_t)stream;
     if (C % 4 || 256 % (C / 4)) return 2;
     const size_t n = (size_t)N * H * W * C;
-    float *xi = tmp_alloc(n, s), *di = tmp_alloc(n, s), *oi = tmp_alloc(n, s), *st = tmp_alloc(2 * C, s); double* acc = (double*)tmp_alloc(8 * C, s);
+    float *xi = tmp_alloc(n, s), *di = tmp_alloc(n, s), *oi = tmp_alloc(n, s), *st = tmp_alloc(4 * C, s); double* acc = (double*)tmp_alloc(8 * C, s);
     if (!xi || !di || !oi || !st || !acc) return 3;
     View v = make_view(xi, N, H, W, C), d = make_view(di, N, H, W, C), o = make_view(oi, N, H, W, C);
     launch_nchw_to_view(x, v, s); launch_nchw_to_view(dy, d, s);
     launch_colstats(v, acc, s); launch_bn_finalize(acc, st, C, (double)v.pixels(), 1, nullptr, 0.f, s);
     (void)hipMemsetAsync(dgamma, 0, C * sizeof(float), s); (void)hipMemsetAsync(dbeta, 0, C * sizeof(float), s);
     launch_bn_bwd_reduce(d, nullptr, ACT_NONE, v, st, acc + 2 * C, s);
-    launch_bn_bwd_apply(d, nullptr, ACT_NONE, v, st, gamma, acc + 2 * C, (double)v.pixels(), o, dgamma, dbeta, s);
+    launch_bn_bwd_apply(d, nullptr, ACT_NONE, v, st, gamma, acc + 2 * C, (double)v.pixels(), o, dgamma, dbeta, s, 1, st + 2 * C);
     launch_nhwc_to_nchw(nullptr, o, dx, s);
     (void)hipFreeAsync(xi, s); (void)hipFreeAsync(di, s); (void)hipFreeAsync(oi, s); (void)hipFreeAsync(st, s); (void)hipFreeAsync(acc, s);
     return hipGetLastError() != hipSuccess;

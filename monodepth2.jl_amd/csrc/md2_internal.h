@@ -144,7 +144,7 @@ void launch_bn_apply(const View& z, const float* stats, const float* gamma, cons
 void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View& z, const float* stats, double* acc, hipStream_t s);
 // dz = gamma*invstd*(g - s1/M - xhat*s2/M) ; dgamma += s2, dbeta += s1 (written by block 0)
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc /* [slots][2C] */,
-                         double count, const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots = 1);
+                         double count, const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots, float* coef /* float[2C] scratch: m1 | m2 */);
 void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s);
 // dx (+)= scatter of dy by arg, gather form; optional multiply by relu'(xact).  accumulate as in ConvArgs (0 / 1 / 2)
 void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu /* pooled output of a post-ReLU input, or null */, hipStream_t s);
