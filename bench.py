@@ -20,20 +20,29 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (--precision bf16 prices against this one)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-# HBM bytes per launch from the rocprofv3 PMC passes of THIS workload (B=32, C=1, 416x128), profiles/r01_pmc_hbm_traffic.md:
-# separate --pmc FETCH_SIZE / WRITE_SIZE runs, KiB units, FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE exact.
-# PMC counters cannot be collected from inside bench.py, so the committed measurement is reported (null for other workloads).
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {"conv_igemm": 108.1e6, "conv_wgrad": 119.4e6, "loss_fwd": 229.2e6, "loss_bwd": 300.3e6}
+# HBM bytes per launch come from the rocprofv3 PMC passes of THIS command (profiles/r02_pmc_hbm_traffic.json, written by tools/profile_summary.py from separate
+# --pmc FETCH_SIZE / WRITE_SIZE runs: KiB units, FETCH_SIZE x2 because gfx950 tallies 64 B per 128-B request, WRITE_SIZE exact).  PMC counters cannot be read
+# from inside bench.py, so the tracked measurement is reported when its workload equals the one being run, null otherwise.
+def pmc_traffic(B, C, H, W, depth, precision):
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
+    except Exception:
+        return {}
+    w = d.get("workload", {})
+    if (w.get("batch"), w.get("channels"), w.get("height"), w.get("width"), w.get("depth"), w.get("precision")) != (B, C, H, W, depth, precision):
+        return {}
+    return d.get("bytes_per_launch", {})
 
 
-def cpu_baseline(C, H, W, seconds_budget=25.0):
-    """The oracle (CPU restatement of the reference algorithm — not Flux itself) timed on this box's host cores: one
-    triplet per step (B=1), 416x128, forward + loss + backward + ADAM; 1 warm-up + as many timed steps as fit the budget."""
+def cpu_baseline(C, H, W, seconds_budget=75.0):
+    """The oracle (CPU restatement of the reference algorithm, op by op and unfused -- not Flux itself) timed on this box's host cores on the reference's own
+    training configuration, batch 4 (src/Monodepth.jl:104), 416x128, forward + loss + backward + ADAM; bounded: 1 warm-up, then timed steps (median) until the
+    budget is used (at most 10)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     import md2amd
     syn = md2amd.synthetic
-    B = 1
+    B = 4
     theta = syn.init_params(C, seed=42)
     x = syn.synthetic_triplets(B, C, H, W, seed=42)
     K, iK = syn.depth10k_intrinsics(W, H)
@@ -42,13 +51,11 @@ def cpu_baseline(C, H, W, seconds_budget=25.0):
     threads = oracle.num_threads()
     t0 = time.time(); net.train_loss(x, cfg, None, True); net.adam_step(1e-4); warm = time.time() - t0
     times = []
-    while sum(times) + warm < seconds_budget and len(times) < 5:
+    while (sum(times) + warm < seconds_budget and len(times) < 10) or len(times) < 2:
         t0 = time.time(); net.train_loss(x, cfg, None, True); net.adam_step(1e-4); times.append(time.time() - t0)
-    if not times:
-        times = [warm]
     med = sorted(times)[len(times) // 2]
     return {"value": B / med, "unit": "triplets/s", "cores": int(threads), "kind": "port",
-            "sample": "B=1 triplet, %dx%d, C=%d, fwd+loss+bwd+ADAM, 1 warm-up + %d timed steps, median (CPU restatement of the reference algorithm, OpenMP, not Flux itself)" % (W, H, C, len(times))}
+            "sample": "B=4 triplets (the reference's batch size), %dx%d, C=%d, fwd+loss+bwd+ADAM, 1 warm-up + %d timed steps (median %.2f s/step) on %d OpenMP threads; CPU restatement of the reference algorithm, op by op -- not Flux itself, and not the optimisation target" % (W, H, C, len(times), med, int(threads))}
 
 
 def main():
@@ -95,7 +102,33 @@ def main():
         return model, params, cache, x
 
     model, params, cache, x = setup(B)
+    # N > 1: the library's own RCCL communicator (md2_comm_*: bucketed all-reduce overlapped with the pullback, ADAM on the mean) -- the path a Julia host uses.
+    # It is checked on a known pattern before the timed region; if it cannot be brought up the step falls back to torch.distributed's RCCL all-reduce of the same
+    # buffer, and says so in the JSON line.
+    comm_note = "single rank"
     dp = par.DataParallel(model)
+    if world > 1 and dp.comm == "rccl":
+        try:
+            dp._setup(x, params, cache)
+            t = torch.full((8,), float(rank + 1), device="cuda")
+            model.comm_allreduce(t); torch.cuda.synchronize()
+            if abs(float(t[0]) - world * (world + 1) / 2.0) > 1e-3:
+                raise RuntimeError("self-check sum %.3f != %.3f" % (float(t[0]), world * (world + 1) / 2.0))
+            comm_note = "libmd2hip RCCL communicator (md2_comm_init), 4 buckets overlapped with the pullback"
+        except Exception as e:                      # noqa: BLE001
+            comm_note = "torch.distributed RCCL all-reduce of the library's gradient buffer (md2_comm_init failed: %s)" % str(e)[:200]
+            try:
+                model.comm_destroy()
+            except Exception:                       # noqa: BLE001
+                model._comm_spec = None
+            dp = par.DataParallel(model, comm="torch")
+        # every rank must take the same branch
+        flag = torch.tensor([1.0 if dp.comm == "rccl" else 0.0], device="cuda"); torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if float(flag.item()) < 0.5 and dp.comm == "rccl":
+            model.comm_destroy()
+            dp = par.DataParallel(model, comm="torch"); comm_note = "torch.distributed RCCL all-reduce (another rank could not initialise md2_comm)"
+    elif world > 1:
+        comm_note = "torch.distributed all-reduce (%s backend)" % os.environ.get("MD2_BENCH_BACKEND", "nccl")
 
     def sync():
         if world > 1:
@@ -121,28 +154,32 @@ def main():
     out = {"metric": "self-sup training imgs/sec, 416x128 ResNet-18 (1 img = 1 triplet: 3 frames through the encoder)", "value": value, "unit": "triplets/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-           "config": {"workload": "ResNet-%d depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, fp32 fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4 and configs[3] ResNet-50 640x192 batch=16 under extra)" % (args.depth, W, H, C, B),
-                      "global_batch": world * B, "parallelism": "dp%d" % world, "loss": final_loss}}
+           "config": {"workload": "ResNet-%d depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, %s fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4, configs[3] ResNet-50 640x192 batch=16 and configs[4] 1024x320 bf16 automask under extra)" % (
+                          args.depth, W, H, C, B, "fp32" if args.precision == "f32" else "bf16 MFMA operands / fp32 accumulate"),
+                      "global_batch": world * B, "parallelism": "dp%d" % world, "gradient_exchange": comm_note, "loss": final_loss}}
 
+    # ---- roofline of the dominant kernel class, measured live with HIP events on the launch stream (3 profiled steps)
+    # The timed region above overlaps the weight-gradient kernels with the rest of the backward pass on a second stream; overlapped
+    # launches inflate each other's duration, so the per-kernel roofline is timed with the overlap switched off (same kernels, same
+    # data, one at a time).  profiles/ holds the rocprofv3 summaries of both modes.  Every rank runs these steps (the gradient exchange is
+    # a collective), rank 0 reports its own kernels.
+    md.set_two_streams(model, False)
+    md.profile(model, rank == 0)
+    for _ in range(3):
+        dp.train_step(x, None, cache, params)
+    sync()
     if rank == 0:
-        # ---- roofline of the dominant kernel class, measured live with HIP events on the launch stream (3 profiled steps)
-        # The timed region above overlaps the weight-gradient kernels with the rest of the backward pass on a second stream; overlapped
-        # launches inflate each other's duration, so the per-kernel roofline is timed with the overlap switched off (same kernels, same
-        # data, one at a time).  profiles/ holds the rocprofv3 summaries of both modes.
-        md.set_two_streams(model, False)
-        md.profile(model, True)
-        for _ in range(3):
-            md.train_step(model, x, None, cache, params, do_update=True)
-        torch.cuda.synchronize()
         ig, wg, lf, lb = (md.profile_get(model, c) for c in range(4))
         md.profile(model, False)
-        md.set_two_streams(model, True)
+    md.set_two_streams(model, True)
+    if rank == 0:
+        traffic = pmc_traffic(B, C, H, W, args.depth, args.precision)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
                            "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
-                           "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH["conv_igemm"] if (B, C, H, W, args.depth, args.precision) == (32, 1, 128, 416, 18, "f32") else None,
-                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
+                           "traffic": traffic.get("conv_igemm"),
+                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, profiles/r02_pmc_hbm_traffic.md)",
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1),
                            "timing": "HIP events per launch on the launch stream, 3 steps with the second (weight-gradient) stream disabled; `value` is measured with it enabled"}
         extra = {"frames_per_s": 3.0 * value}         # one triplet = 3 frames through the encoder
@@ -154,8 +191,7 @@ def main():
                 a = p["bytes"] / (p["ms"] * 1e-3) / 1e9
                 extra[nm] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "ms_per_step": p["ms"] / 3,
                              "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1),
-                             "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH[nm[len("roofline_"):]] if (B, C, H, W, args.depth, args.precision) == (32, 1, 128, 416, 18, "f32") else None,
-                             "note": "instruction-bound, not HBM-bound: 541 (fwd) / 1490 (bwd) VALU lane-instructions per pixel and scale (rocprofv3 SQ_INSTS_VALU) = 48 % / 37 % of the VALU issue peak (DESIGN.md section 4)"}
+                             "traffic": traffic.get(nm[len("roofline_"):])}
         if world == 1 and not args.no_extra and B != 4:
             # BASELINE.json configs[1]: batch = 4 on one MI355X
             del dp, model

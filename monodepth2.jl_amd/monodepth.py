@@ -327,6 +327,11 @@ class Model:
         _check(_lib.lib().md2_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p)), self._h, "comm_init")
         self._comm_spec = (rank, world)
 
+    def comm_destroy(self):
+        if self._h is not None and self._comm_spec is not None:
+            _check(_lib.lib().md2_comm_destroy(self._h), self._h, "comm_destroy")
+        self._comm_spec = None
+
     def broadcast_state(self, root=0):
         _lib.lib().md2_set_stream(self._h, _stream())
         _check(_lib.lib().md2_broadcast_state(self._h, int(root)), self._h, "broadcast_state")

@@ -1,7 +1,7 @@
 """Turn rocprofv3 CSV output into the markdown summaries kept under profiles/.
 
   kernel stats :  profile_summary.py stats  <dir with *_kernel_stats.csv>  <steps in trace>  <title line>  > profiles/rNN_..._kernel_stats.md
-  HBM traffic  :  profile_summary.py pmc    <dir of the FETCH_SIZE pass>  <dir of the WRITE_SIZE pass>  <steps in trace>  > profiles/rNN_pmc_hbm_traffic.md
+  HBM traffic  :  profile_summary.py pmc    <dir of the FETCH_SIZE pass>  <dir of the WRITE_SIZE pass>  <steps in trace>  [out.json B C H W depth precision]  > profiles/rNN_pmc_hbm_traffic.md
 
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE tallies a 128-B request of a wide coalesced read as 64 B, so reads are
 doubled (MI355X_MICROARCH.md, "HBM" section); the two counters do not fit one pass, hence two runs of the same command.
@@ -65,7 +65,16 @@ def pmc(df, dw, steps):
         w = wr[k][1] * 1024 / 1e6 / steps
         print("| %s | %.1f | %.0f | %.1f | %.1f | %.2f |" % (k, n, fe[k][1] / steps, rd, w, (rd + w) / max(n, 1e-9)))
     print()
-    print("bench.py table (bytes per launch):", {k: round((2 * fe[k][1] * 1024 + wr[k][1] * 1024) / max(fe[k][0], 1), -5) for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd")})
+    tab = {k: round((2 * fe[k][1] * 1024 + wr[k][1] * 1024) / max(fe[k][0], 1), -5) for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd")}
+    print("bench.py table (bytes per launch):", tab)
+    if len(sys.argv) > 5:                       # machine-readable copy that bench.py reads for `roofline.traffic`
+        import json
+        w = [int(v) for v in sys.argv[6:11]]
+        json.dump({"command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
+                   "workload": {"batch": w[0], "channels": w[1], "height": w[2], "width": w[3], "depth": w[4], "precision": sys.argv[11]},
+                   "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 64 B per 128-B request) + WRITE_SIZE KiB x 1024, per launch", "bytes_per_launch": tab,
+                   "bytes_per_step": {k: 2 * fe[k][1] * 1024 / steps + wr[k][1] * 1024 / steps for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd", "other")}},
+                  open(sys.argv[5], "w"), indent=1)
 
 
 if __name__ == "__main__":
