@@ -31,6 +31,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
+#ifndef MD2_DUAL_ACC
+#define MD2_DUAL_ACC 0    // experiment: even / odd k-pairs of a K-step accumulate into two independent register sets (breaks the 8-deep dependent MFMA chain of the 1x1-tile waves)
+#endif
+#ifndef MD2_SETPRIO
+#define MD2_SETPRIO 1
+#endif
+#ifndef MD2_PF3
+#define MD2_PF3 0         // 1: the global loads run THREE steps ahead of the MFMAs (one step in flight in registers before they are written to LDS), not two.
+                          // Measured (tools/conv_bench, round 2): 4 - 8 % SLOWER on the encoder shapes -- the loads' latency is already covered, what costs is their issue
+#endif
 #ifndef MD2_LATE_MASK
 #define MD2_LATE_MASK 1   // 1: zero-padding masks are applied when the gathered rows go to LDS (after the step's MFMAs) instead of right after the global loads
 #endif
@@ -113,6 +123,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #pragma unroll
             for (int e = 0; e < 4 * NV; ++e) acc[i][j][e] = 0.f;
 
+    acc_t acc2[MD2_DUAL_ACC ? TC : 1][MD2_DUAL_ACC ? TP : 1];
+    if constexpr (MD2_DUAL_ACC != 0) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4 * NV; ++e) acc2[i][j][e] = 0.f;
+    }
     float4 ra[A_LD], rb[B_LD];
     // split-K (small grids only): this block covers channel chunks [c_lo, c_hi) of every tap
     const int cpt_all = a.Cin >> 4;             // 16-channel chunks per tap
@@ -171,14 +190,22 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             xsc = *reinterpret_cast<const float4*>(a.in_scale + ch); xsh = *reinterpret_cast<const float4*>(a.in_shift + ch);
         }
     };
-    auto xf_apply = [&](int tt) {               // tt: filter tap of the data in ra[] (its padding mask)
+    // sa / sb: the register set being written to LDS -- the loads of the PREVIOUS step when the global loads run three steps ahead (MD2_PF3), else this step's
+    float4 sa[A_LD], sb[B_LD];
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) sa[j] = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) sb[j] = rb[j];
+    };
+    auto xf_apply = [&](int tt) {               // tt: filter tap of the data in sa[] (its padding mask)
         if constexpr (XF == 0 && MD2_LATE_MASK != 0) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) {
                 unsigned mb = a_mbits[j]; asm volatile("" : "+v"(mb));            // keeps hipcc from hoisting NT x A_LD mask registers out of the loop
                 const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)mb, (unsigned)tt, 1u);
-                const float4 v = ra[j];
-                ra[j] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk), __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+                const float4 v = sa[j];
+                sa[j] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk), __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
             }
         }
         if constexpr (XF != 0) {
@@ -186,24 +213,24 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             for (int j = 0; j < A_LD; ++j) {
                 unsigned mb = a_mbits[j]; asm volatile("" : "+v"(mb));
                 const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)mb, (unsigned)tt, 1u);
-                float4 v = ra[j];
+                float4 v = sa[j];
                 v.x = fmaxf(fmaf(v.x, xsc.x, xsh.x), 0.f); v.y = fmaxf(fmaf(v.y, xsc.y, xsh.y), 0.f); v.z = fmaxf(fmaf(v.z, xsc.z, xsh.z), 0.f); v.w = fmaxf(fmaf(v.w, xsc.w, xsh.w), 0.f);
-                ra[j] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk), __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+                sa[j] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk), __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
             }
         }
     };
     auto lstore = [&](int so) {                 // so: float offset of the stage
         if constexpr (BF != 0) {
 #pragma unroll
-            for (int j = 0; j < A_LD; ++j) put_bf(smem + so + ((tid + 256 * j) >> 2) * ROWF, ra[j]);
+            for (int j = 0; j < A_LD; ++j) put_bf(smem + so + ((tid + 256 * j) >> 2) * ROWF, sa[j]);
 #pragma unroll
-            for (int j = 0; j < B_LD; ++j) put_bf(smem + so + XS + (((tid + 256 * j) >> 2) & (BN - 1)) * ROWF, rb[j]);
+            for (int j = 0; j < B_LD; ++j) put_bf(smem + so + XS + (((tid + 256 * j) >> 2) & (BN - 1)) * ROWF, sb[j]);
             return;
         }
 #pragma unroll
-        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4*>(smem + so + ((tid + 256 * j) >> 2) * LDK + q * 4) = ra[j];
+        for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4*>(smem + so + ((tid + 256 * j) >> 2) * LDK + q * 4) = sa[j];
 #pragma unroll
-        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(smem + so + XS + (((tid + 256 * j) >> 2) & (BN - 1)) * LDK + q * 4) = rb[j];   // BN < 64: duplicate rows, same data
+        for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(smem + so + XS + (((tid + 256 * j) >> 2) & (BN - 1)) * LDK + q * 4) = sb[j];   // BN < 64: duplicate rows, same data
     };
     // operand fragments of one K-step
     //   16x16x4: lane (row l&15, k-quad l>>4), one ds_read_b128 per 16-row tile; MFMA r contracts k in {r, 4+r, 8+r, 12+r}
@@ -255,7 +282,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
                     for (int j = 0; j < TP; ++j) {
-                        if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.w[i][jj][r], o.x[j][jj][r], acc[i][j], 0, 0, 0);
+                        if constexpr (MF == 32 && MD2_DUAL_ACC != 0) {
+                            if (r & 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.w[i][jj][r], o.x[j][jj][r], acc2[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.w[i][jj][r], o.x[j][jj][r], acc[i][j], 0, 0, 0);
+                        } else if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.w[i][jj][r], o.x[j][jj][r], acc[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.w[i][jj][r], o.x[j][jj][r], acc[i][j], 0, 0, 0);
                     }
         }
@@ -273,9 +303,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     int o0 = 0, o1 = STAGE, o2 = 2 * STAGE;
     Ops cur, nxt;
     xf_load(0);
-    gload(0, 0); xf_apply(0); lstore(o0);
-    { int t1, c1; step_tc(1, t1, c1); if (NT == 1) { gload(0, c1); xf_load(c1 >> 4); xf_apply(0); } else { gload(nsteps > 1 ? 1 : 0, 0); xf_apply(nsteps > 1 ? 1 : 0); } }
+    gload(0, 0); stage(); xf_apply(0); lstore(o0);
+    { int t1, c1; step_tc(1, t1, c1); if (NT == 1) { gload(0, c1); stage(); xf_load(c1 >> 4); xf_apply(0); } else { gload(nsteps > 1 ? 1 : 0, 0); stage(); xf_apply(nsteps > 1 ? 1 : 0); } }
     lstore(o1);
+    if constexpr (MD2_PF3 != 0) {               // step 2's loads go in flight before the loop; every loop step then stages the previous step's loads and issues the next
+        if constexpr (NT >= 3) gload(2, 0); else if constexpr (NT == 2) gload(0, min(1, cpt - 1) << 4); else gload(0, min(2, cpt - 1) << 4);
+    }
     __syncthreads();
     read_ops(o0, cur);
     for (int c = 0; c < cpt; ++c) {
@@ -286,8 +319,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             const int t2 = (t + 2) % NT;
             const int c2 = min(c + (t + 2) / NT, cpt - 1);
             const bool last2 = (c + (t + 2) / NT) > cpt - 1;          // beyond the end: reload the final step (harmless)
+            const int t3 = (t + 3) % NT;
+            const int c3 = min(c + (t + 3) / NT, cpt - 1);
+            const bool last3 = (c + (t + 3) / NT) > cpt - 1;
 #ifdef MD2_ABLATE
-            if (!(abl & 1)) gload(last2 ? NT - 1 : t2, c2 << 4);
+            if (MD2_PF3) { stage(); if (!(abl & 1)) gload(last3 ? NT - 1 : t3, c3 << 4); }
+            else { if (!(abl & 1)) gload(last2 ? NT - 1 : t2, c2 << 4); stage(); }
             if (!(abl & 2)) read_ops(o1, nxt);
             if (!(abl & 4)) mfmas(cur);
             if (!(abl & 2)) { xf_apply(last2 ? NT - 1 : t2); lstore(o2); }
@@ -296,12 +333,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
             continue;
 #endif
-            gload(last2 ? NT - 1 : t2, c2 << 4);
-            if (XF != 0 && (t + 2) % NT == 0) xf_load(c2);          // the prefetch enters a new channel chunk (tap 0 of chunk c2; c2 is clamped like the loads)
+            if (MD2_PF3) { stage(); gload(last3 ? NT - 1 : t3, c3 << 4); }          // sa/sb <- the loads issued one step ago (step s+2's data); step s+3's go in flight
+            else { gload(last2 ? NT - 1 : t2, c2 << 4); stage(); }
+            if (XF != 0 && (t + 2) % NT == 0) xf_load(c2);          // the data being staged enters a new channel chunk (tap 0 of chunk c2; c2 is clamped like the loads)
             read_ops(o1, nxt);
-            __builtin_amdgcn_s_setprio(1);          // raised priority around the MFMA cluster (also keeps hipcc from spreading it among the loads): -3 % class time;
+            if (MD2_SETPRIO) __builtin_amdgcn_s_setprio(1);          // raised priority around the MFMA cluster (also keeps hipcc from spreading it among the loads): -3 % class time;
             mfmas(cur);                             // the same pair in the all-taps weight-gradient loop was 3 % SLOWER
-            __builtin_amdgcn_s_setprio(0);
+            if (MD2_SETPRIO) __builtin_amdgcn_s_setprio(0);
             xf_apply(last2 ? NT - 1 : t2);
             lstore(o2);
             __syncthreads();
@@ -313,6 +351,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #ifdef MD2_ABLATE
     if (abl & 16) { if (acc[0][0][0] == 123.456f) a.y[0] = 1.f; return; }      // skip the epilogue stores
 #endif
+    if constexpr (MD2_DUAL_ACC != 0) {
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4 * NV; ++e) acc[i][j][e] += acc2[i][j][e];
+    }
     // epilogue: every (tile, register group) is 4 consecutive channels of one pixel -> one 16-B NHWC store
     //   16x16x4: D col = lane&15 (pixel), row = 4*(lane>>4) + e (channel)
     //   32x32x2: D col = lane&31 (pixel), row = 8*g + 4*(lane>>5) + e, register 4g+e
