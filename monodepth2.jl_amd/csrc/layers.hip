@@ -189,13 +189,24 @@ void launch_bn_apply(const View& z, const float* stats, const float* gamma, cons
 
 // sums -> per-channel coefficients, once per BatchNorm (it used to be redone by every thread of the apply kernel): coef = m1 | m2 = sum g / count | sum g*xhat / count;
 // also d gamma += sum g*xhat, d beta += sum g.  acc: [slots][sum g | sum g*xhat][C] (a producer's epilogue spreads its atomics over BN_STAT_SLOTS)
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, int slots, int C, double count, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// With stats / gamma given, coef[2C..5C) also holds the pullback as an affine map of (g, z): dz = A g + B z + C0, for consumers that form dz in their loader
+// (the stem's weight gradient) instead of reading a materialised dz.
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, int slots, int C, double count, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       const float* __restrict__ stats, const float* __restrict__ gamma) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0, s2 = 0;
     for (int k = 0; k < slots; ++k) { s1 += acc[(size_t)k * 2 * C + c]; s2 += acc[(size_t)k * 2 * C + C + c]; }
-    coef[c] = (float)(s1 / count); coef[C + c] = (float)(s2 / count);
+    const float m1 = (float)(s1 / count), m2 = (float)(s2 / count);
+    coef[c] = m1; coef[C + c] = m2;
     dbeta[c] += (float)s1; dgamma[c] += (float)s2;
+    if (stats) {
+        const float mean = stats[c], is = stats[C + c], k = gamma[c] * is;
+        coef[2 * C + c] = k; coef[3 * C + c] = -k * is * m2; coef[4 * C + c] = k * (mean * is * m2 - m1);
+    }
+}
+void launch_bn_bwd_finalize(const double* acc, int slots, int C, double count, float* coef, float* dgamma, float* dbeta, const float* stats, const float* gamma, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, slots, C, count, coef, dgamma, dbeta, stats, gamma);
 }
 template <bool FAST>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, int has_yact, int act, View z, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
 }
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc, double count,
                          const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots, float* coef) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((z.C + 255) / 256), dim3(256), 0, s, acc, slots, z.C, count, coef, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((z.C + 255) / 256), dim3(256), 0, s, acc, slots, z.C, count, coef, dgamma, dbeta, (const float*)nullptr, (const float*)nullptr);
     const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(dy) && dense_view_h(dz) && (!yact || dense_view_h(*yact));
     const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
     if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz);
@@ -300,8 +311,13 @@ void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamm
 // gather form: input pixel (ih,iw) is covered by outputs oh in {(ih+1)/2 - (0|1)}...; no atomics, deterministic
 // yrelu: the pooled OUTPUT of a max-pool over post-ReLU activations; the ReLU derivative of the winning input equals (pooled value > 0),
 // so the mask is read from the 4x smaller pooled tensor instead of the activations themselves
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View yrelu, int has_yrelu) {
+// bz / bstat / bacc (optional): dx is the gradient of a BatchNorm output whose input is bz -- the kernel also accumulates that BatchNorm's pullback sums
+// (sum g, sum g*xhat per channel; needs 256 % (C/4) == 0 so that a thread keeps one channel quad) and the separate reduction pass over (g, z) goes away
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View yrelu, int has_yrelu,
+                                                          View bz, const float* __restrict__ bstat, double* __restrict__ bacc) {
     const int Q = dx.C / 4; const long total = dx.pixels() * Q; const int HW = dx.H * dx.W, HWo = dy.H * dy.W;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1;
+    if (bacc) { const int q0 = threadIdx.x % Q; mu = ld4(bstat + q0 * 4); is = ld4(bstat + dx.C + q0 * 4); }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int ih = r / dx.W, iw = r - ih * dx.W;
         float g[4] = {0.f, 0.f, 0.f, 0.f};
@@ -321,10 +337,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t
         if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1)) {      // earlier contributions are already masked
             const float4 o = ld4(dp); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
         st4(dp, make_float4(g[0], g[1], g[2], g[3]));
+        if (bacc) {
+            const float4 z = ld4(vptr(bz, n, r) + q * 4);
+            s1.x += g[0]; s1.y += g[1]; s1.z += g[2]; s1.w += g[3];
+            s2.x += g[0] * ((z.x - mu.x) * is.x); s2.y += g[1] * ((z.y - mu.y) * is.y); s2.z += g[2] * ((z.z - mu.z) * is.z); s2.w += g[3] * ((z.w - mu.w) * is.w);
+        }
+    }
+    if (bacc) {                                   // block reduction over the 256 / Q threads that share a channel quad, then one double atomic per channel and block
+        __shared__ float red[8 * 256];
+        const float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[e * 256 + threadIdx.x] = v[e];
+        __syncthreads();
+        const int C = dx.C, RG = 256 / Q;
+        for (int c = threadIdx.x; c < 2 * C; c += 256) {
+            const int which = c / C, ch = c % C, qq = ch / 4, e = ch % 4;
+            float t = 0.f;
+            for (int gI = 0; gI < RG; ++gI) t += red[(which * 4 + e) * 256 + gI * Q + qq];
+            atomicAdd(bacc + (size_t)(blockIdx.x % BN_STAT_SLOTS) * 2 * C + which * C + ch, (double)t);
+        }
     }
 }
-void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu, hipStream_t s) {
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(dx.pixels() * (dx.C / 4), 256, 4096)), dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0);
+void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu, hipStream_t s, const View* bz, const float* bstat, double* bacc) {
+    const int Q = dx.C / 4;
+    if (bacc && (256 % Q != 0 || !bz)) { fprintf(stderr, "md2: maxpool_bwd: the fused BatchNorm sums need 256 %% (C/4) == 0\n"); abort(); }
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(dx.pixels() * Q, 256, bacc ? 1024 : 4096)), dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0,
+                       bz ? *bz : dx, bstat, bacc);
 }
 
 // ---- NNlib.upsample_bilinear(x, (2,2)) (src/depth_decoder.jl:18-19), align-corners mapping --------------------------------
@@ -453,6 +491,31 @@ void launch_colsum(const View& v, float* out, hipStream_t s) {
     if (g_deterministic) rpb = (int)std::min<long>(P, 1 << 30);
     hipLaunchKernelGGL(colsum_kernel, dim3((int)((P + rpb - 1) / rpb)), dim3(256), 0, s, v, out, rpb);
 }
+
+// ---- pose squeezer bookkeeping (src/model.jl:30-35, src/pose_decoder.jl:23-25): the 1x1 squeezer runs ONCE over all 3N frames (sq3 [3N][hw][256]); the pose decoder's input
+//      for source s is cat(frame fr[s][0], frame fr[s][1]) with (fr) = ((0,1),(1,2)): sqcat [2][N][hw][512].  Forward = gather, pullback = scatter-add (frame 1 is used twice).
+__global__ __launch_bounds__(256) void pose_pairs_fwd_kernel(const float* __restrict__ sq3, float* __restrict__ sqcat, int N, int hw) {
+    const long total = (long)2 * N * hw * 128;                        // float4 slots of sqcat
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = i % 128; const long r = i / 128; const int px = r % hw; const long sn = r / hw; const int n = sn % N, s = sn / N;
+        const int j = c4 >> 6, fr = s + j;                             // frames (0,1) for source 0, (1,2) for source 1
+        st4(sqcat + i * 4, ld4(sq3 + (((long)(n * 3 + fr) * hw + px) * 64 + (c4 & 63)) * 4));
+    }
+}
+__global__ __launch_bounds__(256) void pose_pairs_bwd_kernel(const float* __restrict__ dsqcat, float* __restrict__ dsq3, int N, int hw) {
+    const long total = (long)3 * N * hw * 64;                          // float4 slots of dsq3
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = i % 64; const long r = i / 64; const int px = r % hw; const long nf = r / hw; const int fr = nf % 3, n = nf / 3;
+        auto at = [&](int s, int j) { return ld4(dsqcat + ((((long)(s * N + n) * hw + px) * 128) + j * 64 + c4) * 4); };
+        float4 g;
+        if (fr == 0) g = at(0, 0);
+        else if (fr == 2) g = at(1, 1);
+        else { const float4 a = at(0, 1), b = at(1, 0); g = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+        st4(dsq3 + i * 4, g);
+    }
+}
+void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, hipStream_t s) { hipLaunchKernelGGL(pose_pairs_fwd_kernel, dim3(grid_for((long)2 * N * hw * 128, 256, 2048)), dim3(256), 0, s, sq3, sqcat, N, hw); }
+void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, hipStream_t s) { hipLaunchKernelGGL(pose_pairs_bwd_kernel, dim3(grid_for((long)3 * N * hw * 64, 256, 2048)), dim3(256), 0, s, dsqcat, dsq3, N, hw); }
 
 // ---- pose head tail: mean over (W,H) * 0.01 (src/pose_decoder.jl:29-31); y view [B][h*w][>=6 channels] -------------------------
 __global__ void pose_mean_fwd_kernel(View y, float* __restrict__ rvec, float* __restrict__ tvec) {

@@ -61,7 +61,7 @@ struct md2_handle {
     int Kpad = 64;
     View z0, a0, p0; uint8_t* pool_arg = nullptr;
     View feat[5], y1[5], cat[5], y2[5], dispv[4];
-    View sqcat, py1, py2, py3; float *rvec = nullptr, *tvec = nullptr, *Rt = nullptr;
+    View sq3, dsq3; View sqcat, py1, py2, py3; float *rvec = nullptr, *tvec = nullptr, *Rt = nullptr;
     double *loss_part = nullptr, *dRt_acc = nullptr; float *totals = nullptr, *loss_dev = nullptr, *ddisp_full = nullptr, *drvec = nullptr, *dtvec = nullptr;
     const float* x_last = nullptr; const float* auto_last = nullptr; bool have_fwd = false;
     View Gfeat[5], Gblk[16], Gpool; char* gzero_begin = nullptr; size_t gzero_bytes = 0;
@@ -209,12 +209,13 @@ static void plan_buffers(md2_handle* h) {
         if (b >= 1) h->dispv[b - 1] = h->alloc_view(N, dh, dw, 1);
     }
     const int ph = H / 32, pw = W / 32;
+    h->sq3 = h->alloc_view(3 * N, ph, pw, 256); h->dsq3 = h->alloc_view(3 * N, ph, pw, 256);
     h->sqcat = h->alloc_view(2 * N, ph, pw, 512); h->py1 = h->alloc_view(2 * N, ph, pw, 256); h->py2 = h->alloc_view(2 * N, ph, pw, 256); h->py3 = h->alloc_view(2 * N, ph, pw, 16);
     h->rvec = h->alloc<float>(6 * N); h->tvec = h->alloc<float>(6 * N); h->Rt = h->alloc<float>(24 * N);
     h->totals = h->alloc<float>(16 * N); h->loss_dev = h->alloc<float>(4); h->ddisp_full = h->alloc<float>((size_t)4 * N * H * W);
     h->drvec = h->alloc<float>(6 * N); h->dtvec = h->alloc<float>(6 * N);
     h->loss_blk = h->alloc<double>((size_t)4 * N * ((W + 15) / 16) * ((H + 7) / 8) * 24);        // deterministic mode: [scale*N][block][24] partials (bound for loss tiles >= 16x8)
-    for (BNL* b : h->bns) b->stats = h->alloc<float>(6 * b->c);                 // mean | invstd | scale | shift | pullback m1 | m2
+    for (BNL* b : h->bns) b->stats = h->alloc<float>(9 * b->c);                 // mean | invstd | scale | shift | pullback m1 | m2 | A | B | C0 (dz = A g + B z + C0)
     size_t nd = 0;
     for (BNL* b : h->bns) nd += (size_t)(4 * BN_STAT_SLOTS) * b->c;
     nd += (size_t)16 * N + 24 * N;
@@ -362,12 +363,11 @@ static void set_batch(md2_handle* h, int n_enc, int n_dec) {
 
 // pose decoder, both sources batched (src/model.jl:22-35, src/pose_decoder.jl:23-32); enqueued on h->chain()
 static void pose_forward(md2_handle* h, int N) {
-    const int fr[2][2] = {{0, 1}, {1, 2}};     // (first, second) frame of the temporally ordered pair for source 1 and source 3
-    for (int sidx = 0; sidx < 2; ++sidx)
-        for (int j = 0; j < 2; ++j) {
-            View sq = h->sqcat; sq.p += (long)sidx * N * sq.bs; sq.N = N;
-            conv_fwd(h, h->squeeze, frame_view(h->feat[4], 3, fr[sidx][j]), chan_slice(sq, j * 256, 256), PAD_ZERO, ACT_RELU);
-        }
+    // the squeezer (1x1 conv + ReLU) runs once over all 3N frames -- frame 2's features feed both pairs, the reference squeezes them twice (src/pose_decoder.jl:23-25) --
+    // then the two temporally ordered pairs are gathered: (f1, f2) for source 1, (f2, f3) for source 3 (src/model.jl:30-35)
+    View sq3 = h->sq3; sq3.N = 3 * N;
+    conv_fwd(h, h->squeeze, h->feat[4], sq3, PAD_ZERO, ACT_RELU);
+    launch_pose_pairs_fwd(h->sq3.p, h->sqcat.p, N, h->sq3.H * h->sq3.W, h->chain());
     conv_fwd(h, h->pose[0], h->sqcat, h->py1, PAD_ZERO, ACT_RELU);
     conv_fwd(h, h->pose[1], h->py1, h->py2, PAD_ZERO, ACT_RELU);
     conv_fwd(h, h->pose[2], h->py2, h->py3, PAD_ZERO, ACT_NONE);
@@ -481,14 +481,11 @@ static void pose_backward(md2_handle* h, int N, int part) {
         conv_dgrad(h, h->pose[0], h->dpy1, h->dsq, 1, 0, &h->sqcat, ACT_RELU);
         return;
     }
-    const int fr[2][2] = {{0, 1}, {1, 2}};
-    for (int sidx = 0; sidx < 2; ++sidx)
-        for (int j = 0; j < 2; ++j) {
-            View d = h->dsq; d.p += (long)sidx * N * d.bs; d.N = N; d = chan_slice(d, j * 256, 256);
-            View fv = frame_view(h->feat[4], 3, fr[sidx][j]), gv = frame_view(h->Gfeat[4], 3, fr[sidx][j]);
-            conv_wgrad(h, h->squeeze, fv, d, PAD_ZERO);
-            conv_dgrad(h, h->squeeze, d, gv, 0, fr[sidx][j] == 1 ? 1 : 0, &fv, ACT_RELU);   // frames 0 and 2 get exactly one contribution; frame 1 adds to the depth decoder's
-        }
+    // squeezer: scatter-add the pair gradients back onto the 3N frames (frame 2 collects both of its uses), then ONE weight gradient and ONE input gradient.
+    // Gfeat[4]: frames 1 and 3 get exactly this contribution (overwrite), frame 2 adds to the depth decoder's (accumulate mode 2)
+    launch_pose_pairs_bwd(h->dsq.p, h->dsq3.p, N, h->dsq3.H * h->dsq3.W, h->chain());
+    conv_wgrad(h, h->squeeze, h->feat[4], h->dsq3, PAD_ZERO);
+    conv_dgrad(h, h->squeeze, h->dsq3, h->Gfeat[4], 0, 2, &h->feat[4], ACT_RELU);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -626,12 +623,18 @@ static int model_backward(md2_handle* h) {
         if (i == stage_first[3]) { if (int r = comm_bucket(h, h->blk[i].c1.w, h->dc1[0].w)) return r; }                                  // encoder layer 4
         else if (i == stage_first[1] && stage_first[1] != stage_first[3]) { if (int r = comm_bucket(h, h->blk[i].c1.w, h->blk[stage_first[3]].c1.w)) return r; }   // layers 2-3
     }
-    launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s);        // Gfeat[0]: decoder skip gradient in the target frames only; ReLU mask from the pooled output
-    {
-        bn_bwd(h, h->stem_bn, h->Gfeat[0], h->z0, h->dz0);
+    {   // stem tail pullback: the max-pool pullback also reduces the stem BatchNorm's sums, and the stem's weight gradient forms dz = A g + B z + C0 in its loader:
+        // no reduction pass, no dz tensor (Gfeat[0]: decoder skip gradient in the target frames only; ReLU mask from the pooled output)
+        const BNL& b = h->stem_bn;
+        const bool fuse = !g_deterministic && !getenv("MD2_NO_BN_FUSE");
+        if (fuse) launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, &h->z0, b.stats, b.acc_b);
+        else { launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s); launch_bn_bwd_reduce(h->Gfeat[0], nullptr, ACT_NONE, h->z0, b.stats, b.acc_b, s); }
+        launch_bn_bwd_finalize(b.acc_b, BN_STAT_SLOTS, b.c, (double)h->z0.pixels(), b.stats + 4 * b.c, h->G + b.g, h->G + b.b, b.stats, h->P + b.g, s);
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
         hipStream_t st = wgrad_stream(h);
-        h->pbegin(CLS_WGRAD, fl, "stem wgrad 7x7 s2 (direct)", st, true); launch_stem_wgrad(h->x_last, NL, h->C, H, W, h->dz0, h->G + h->stem.w, h->Kpad, st); h->pend(st, true);
+        h->pbegin(CLS_WGRAD, fl, "stem wgrad 7x7 s2 (direct, BatchNorm pullback in the loader)", st, true);
+        launch_stem_wgrad(h->x_last, NL, h->C, H, W, h->Gfeat[0], h->G + h->stem.w, h->Kpad, st, &h->z0, b.stats + 6 * b.c);
+        h->pend(st, true);
         if (h->prof) h->prof_flops[CLS_WGRAD] += fl;
     }
     if (h->n_bucket_done >= 0) {            // last bucket (layer 1 + stem), then the caller's stream waits for the communication stream

@@ -125,7 +125,9 @@ void launch_head_bwd(const View& x, const float* w, const View& y, const View& d
 // ---- layer kernels (layers.hip) ----------------------------------------------------------------
 // ---- ResNet stem, 7x7 stride 2 pad 3 on the boundary tensor x [NL][C][H][W] (stem.hip); w / dw: [64][Kpad], k = (kh*7+kw)*C + c
 void launch_stem_fwd(const float* x, int NL, int C, int H, int W, const float* w, int Kpad, const View& z, double* bn_stats /*[BN_STAT_SLOTS][128] or null*/, hipStream_t s);
-void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& dz, float* dw, int Kpad, hipStream_t s);
+// zbn / coef (optional): dz is not materialised -- the view passed as dz holds g (the gradient of the BatchNorm OUTPUT), zbn the BatchNorm input, and the kernel forms
+// dz = coef[0..64) g + coef[64..128) z + coef[128..192) per channel on the way into LDS
+void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& dz, float* dw, int Kpad, hipStream_t s, const View* zbn = nullptr, const float* coef = nullptr);
 void launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 void launch_nhwc_to_nchw(const float* src, const View& v, float* dst, hipStream_t s);
 void launch_nchw_to_view(const float* src, const View& v, hipStream_t s);
@@ -147,7 +149,10 @@ void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& 
                          double count, const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots, float* coef /* float[2C] scratch: m1 | m2 */);
 void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s);
 // dx (+)= scatter of dy by arg, gather form; optional multiply by relu'(xact).  accumulate as in ConvArgs (0 / 1 / 2)
-void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu /* pooled output of a post-ReLU input, or null */, hipStream_t s);
+void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu /* pooled output of a post-ReLU input, or null */, hipStream_t s,
+                        const View* bz = nullptr, const float* bstat = nullptr, double* bacc = nullptr);       // optional: BatchNorm-pullback sums of dx w.r.t. BatchNorm input bz
+// sums -> coef = m1 | m2 [| A | B | C0 with stats / gamma: dz = A g + B z + C0], d gamma / d beta accumulated
+void launch_bn_bwd_finalize(const double* acc, int slots, int C, double count, float* coef, float* dgamma, float* dbeta, const float* stats, const float* gamma, hipStream_t s);
 void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s);
 // dx = adjoint(up2)(dy) * act_deriv(xact)
 void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int act, hipStream_t s);
@@ -157,6 +162,9 @@ void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, c
 void launch_axpy_view(const View& src, const View& dst, float a, int accumulate, const View* actsrc, int act, hipStream_t s);
 // out[c] (+)= sum over pixels of v[.,c]   (float atomics)
 void launch_colsum(const View& v, float* out, hipStream_t s);
+// pose squeezer: sq3 [3N][hw][256] (all frames, squeezed once) <-> sqcat [2][N][hw][512] (the temporally ordered pairs of both sources); the pullback adds frame 1's two uses
+void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, hipStream_t s);
+void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, hipStream_t s);
 // pose head: y [B][HW][16] -> rvec/tvec [B][3] = 0.01 * mean ; and its adjoint
 void launch_pose_mean_fwd(const View& y, float* rvec, float* tvec, hipStream_t s);
 void launch_pose_mean_bwd(const float* drvec, const float* dtvec, const View& dy, hipStream_t s);

@@ -170,9 +170,9 @@ void launch_stem_fwd(const float* x, int NL, int C, int H, int W, const float* w
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient: persistent blocks walk 4 x 32 pixel tiles; wave w contracts tile row w (16 steps of 2 pixels); blockIdx.y selects 64 k's
 // ------------------------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool FUSE>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, View dz, float* __restrict__ dw, int H, int W, int Kpad,
-                                                         int tiles_x, int tiles_y, int total_tiles) {
+                                                         int tiles_x, int tiles_y, int total_tiles, View zbn, const float* __restrict__ coef) {
     constexpr int K = 49 * C, TH = 4, PR = 2 * TH + 5, NP = (C * PR * S_PC + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float ssm[];
     float* Ps = ssm;                           // [C][PR][72]
@@ -198,6 +198,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     float pv[NP]; u32x4 yv[8]; unsigned yok = 0;                        // next tile's patch / dz in flight; bit i of yok: dz slot i is inside the image
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v zv[FUSE ? 8 : 1];                                              // FUSE: the BatchNorm input of the same positions; dz = cA * g + cB * z + cC (this thread's 4 channels never change)
+    f32x4v cA = {0.f, 0.f, 0.f, 0.f}, cB = cA, cC = cA;
+    if constexpr (FUSE) { const int q4 = (tid & 15) * 4; cA = *reinterpret_cast<const f32x4v*>(coef + q4); cB = *reinterpret_cast<const f32x4v*>(coef + 64 + q4); cC = *reinterpret_cast<const f32x4v*>(coef + 128 + q4); }
     const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const float* yrow = Ys + (wave * 32) * 64;
     const float* prow = Ps + (2 * wave) * S_PC;
@@ -209,6 +213,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 8; ++i) {                               // dz slot f = tid + 256 i: pixel f/16, float4 f%16
                 const int f = tid + 256 * i, px = f >> 4, q = f & 15;
+                if constexpr (FUSE) {
+                    const f32x4v g = __builtin_bit_cast(f32x4v, yv[i]);
+                    yv[i] = __builtin_bit_cast(u32x4, cA * g + cB * zv[i] + cC);
+                }
                 *reinterpret_cast<u32x4*>(Ys + px * 64 + ((q * 4) ^ ((px & 1) * 32))) = yv[i] & (0u - ((yok >> i) & 1u));
             }
             __syncthreads();
@@ -232,6 +240,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
                 const int f = tid + 256 * i, px = f >> 4, q = f & 15, oy = ty * TH + (px >> 5), ox = tx * S_TW + (px & 31);
                 yok |= ((oy < dz.H && ox < dz.W) ? 1u : 0u) << i;
                 yv[i] = *reinterpret_cast<const u32x4*>(dn + ((long)min(oy, dz.H - 1) * dz.W + min(ox, dz.W - 1)) * dz.ps + q * 4);
+                if constexpr (FUSE) zv[i] = *reinterpret_cast<const f32x4v*>(zbn.p + (long)n * zbn.bs + ((long)min(oy, dz.H - 1) * dz.W + min(ox, dz.W - 1)) * zbn.ps + q * 4);
             }
         }
         if (s < 0) continue;
@@ -270,23 +279,29 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     }
 }
 
-void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& dz, float* dw, int Kpad, hipStream_t s) {
+void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& dz, float* dw, int Kpad, hipStream_t s, const View* zbn, const float* coef) {
     if ((C != 1 && C != 3) || dz.C != 64 || dz.H != H / 2 || dz.W != W / 2 || dz.N != NL || (H & 1) || (W & 1) || dz.ps % 4 != 0) {
         fprintf(stderr, "md2: stem_wgrad: unsupported shape C=%d %dx%d\n", C, H, W); abort();
     }
     const int tiles_x = (dz.W + S_TW - 1) / S_TW, tiles_y = (dz.H + 3) / 4, total = tiles_x * tiles_y * NL;
     const int kgroups = (49 * C + 63) / 64;
     const size_t lds = (size_t)std::max(C * 13 * S_PC + 128 * 64, 4 * 16 * 64) * sizeof(float);
-    static int per_cu[2] = {0, 0};
-    int& pc = per_cu[C == 3];
+    const bool fuse = zbn != nullptr;
+    static int per_cu[4] = {0, 0, 0, 0};
+    int& pc = per_cu[(C == 3) + 2 * fuse];
     if (!pc) {
-        const void* fn = C == 1 ? reinterpret_cast<const void*>(&stem_wgrad_kernel<1>) : reinterpret_cast<const void*>(&stem_wgrad_kernel<3>);
+        const void* fn = C == 1 ? (fuse ? reinterpret_cast<const void*>(&stem_wgrad_kernel<1, true>) : reinterpret_cast<const void*>(&stem_wgrad_kernel<1, false>))
+                                : (fuse ? reinterpret_cast<const void*>(&stem_wgrad_kernel<3, true>) : reinterpret_cast<const void*>(&stem_wgrad_kernel<3, false>));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, 256, lds) != hipSuccess || pc < 1) pc = 1;
         pc = std::min(pc, 3);
     }
     const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * pc / kgroups));       // persistent: the co-resident blocks, shared by the k groups
-    if (C == 1) hipLaunchKernelGGL(stem_wgrad_kernel<1>, dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total);
-    else hipLaunchKernelGGL(stem_wgrad_kernel<3>, dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total);
+    const View zz = fuse ? *zbn : dz;
+    if (fuse && (zz.C != 64 || zz.H != dz.H || zz.W != dz.W || zz.N != dz.N || zz.ps % 4 != 0)) { fprintf(stderr, "md2: stem_wgrad: BatchNorm input view mismatch\n"); abort(); }
+    if (C == 1) { if (fuse) hipLaunchKernelGGL((stem_wgrad_kernel<1, true>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef);
+                  else hipLaunchKernelGGL((stem_wgrad_kernel<1, false>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef); }
+    else { if (fuse) hipLaunchKernelGGL((stem_wgrad_kernel<3, true>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef);
+           else hipLaunchKernelGGL((stem_wgrad_kernel<3, false>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef); }
 }
 
 }  // namespace md2
