@@ -3,17 +3,25 @@
 // Replaces the cuDNN kernels the reference reaches through Flux `Conv` (src/depth_decoder.jl:13-14,43,
 // src/pose_decoder.jl:15-19, ResNet.jl via src/model.jl:14) and their Zygote pullbacks (SURVEY.md §2a k1,k4,k6,k9).
 //
-// Design (MI355X-first, not a cuDNN translation):
+// Design (MI355X-first, not a cuDNN translation; DESIGN.md §4 has the measurements):
 //  * NHWC views, so one GEMM-K step of 16 input channels of one filter tap is one contiguous 64-B run per
 //    output pixel: global loads are 16-B per lane, 4 lanes per pixel.
-//  * v_mfma_f32_16x16x4_f32 (exact fp32, the only fp32 matrix op on gfx950; 1e-4 parity forces fp32).
-//    D rows = output channels, D cols = pixels, so each lane ends up with 4 consecutive channels of one
-//    pixel -> one 16-B store per MFMA tile.
-//  * LDS tiles [row][16+4] floats: ds_read_b128 per lane gives 4 consecutive k of its row = the operand
-//    of 4 MFMAs; the +4 pad makes the 16-lane groups of ds_read_b128 conflict-free (80-B row stride).
-//  * register-staged double buffering: global loads of step s+1 are in flight while step s runs on MFMA.
-//  * input-gradient = the same kernel on dY with the transposed/flipped weights (dil = forward stride).
-//  * weight-gradient: D rows = cout, cols = cin, K = pixels; split over pixel ranges, fp32 atomics.
+//  * v_mfma_f32_32x32x2_f32 on the wide tiles (128x64 / 64x64 per 256-thread block), v_mfma_f32_16x16x4_f32 on the
+//    narrow-channel ones -- exact fp32, the only fp32 matrix ops on gfx950 (1e-4 parity forces fp32); the optional
+//    mixed-precision mode converts on the way into LDS and issues v_mfma_f32_32x32x16_bf16.
+//    D rows = output channels, D cols = pixels, so a lane ends up with 4 consecutive channels of one pixel
+//    -> one 16-B store per accumulator quad.
+//  * LDS tiles [row][16+4] floats, three stages, ONE barrier per K-step: the loads of step s+2 are issued
+//    before the MFMA cluster of step s; ds_read_b128 per lane = the operands of 4 MFMAs, the +4 pad keeps the
+//    16-lane groups conflict-free (80-B row stride).  K order is chunk-major (all taps of 16 channels, then the next 16).
+//  * loader transform XF: the producer's BatchNorm + ReLU (y = max(scale*z + shift, 0)) is applied to the A operand
+//    between the global load and the LDS write, with the zero-padding mask applied AFTER it -- a1 = relu(bn1(z1)) never exists in HBM.
+//  * epilogue options: bias, ELU / sigmoid, residual add, dact (ReLU / BN-ReLU mask of the pullback), per-channel
+//    sum / sum-of-squares (BatchNorm statistics of the output) and BST (the three sums the BatchNorm pullback needs: sum g, sum g*z ...).
+//  * input-gradient = the same kernel on dY with the transposed/flipped weights (dil = forward stride); stride-2
+//    layers run their 4 residue classes in one launch (conv_igemm_classes_kernel).
+//  * weight-gradient: D rows = cout, cols = cin, K = pixels; all-taps kernel for the 3x3 layers, split over pixel
+//    ranges with fp32 atomics (or ordered partials in deterministic mode).
 //  * workgroup id remap so tiles that share the same pixel tile run on one XCD (shared L2).
 #include "md2_internal.h"
 #include <algorithm>
