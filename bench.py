@@ -186,7 +186,8 @@ def main():
         if wg["ms"] > 0:
             a = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
             extra["roofline_conv_wgrad"] = {"bound": "mfma", "achieved": a, "peak": peak_tf, "unit": "TFLOP/s", "frac": a / peak_tf, "ms_per_step": wg["ms"] / 3}
-        for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_bwd", lb)):
+        # the training step runs the loss as ONE class: smoothness sums + the fused value-and-pullback kernel ("loss_train"); "loss_fwd" only exists in forward-only calls
+        for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_train", lb)):
             if p["ms"] > 0:
                 a = p["bytes"] / (p["ms"] * 1e-3) / 1e9
                 extra[nm] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "ms_per_step": p["ms"] / 3,

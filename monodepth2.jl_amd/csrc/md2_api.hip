@@ -245,7 +245,11 @@ static void plan_buffers(md2_handle* h) {
         h->dupv[b] = h->alloc_view(h->y2[b].N, h->y2[b].H, h->y2[b].W, h->y2[b].C);
     }
     h->dxpad = h->alloc<float>(dxpad_max);
-    for (int l = 0; l < 4; ++l) h->ddisp_lo[l] = h->alloc<float>((size_t)N * h->dispv[l].H * h->dispv[l].W);
+    {   // one block, coarse scales first: the fused loss kernel accumulates into levels 0..2 with atomics, so they are zeroed by a single memset
+        size_t tot = 0; for (int l = 0; l < 4; ++l) tot += (size_t)N * h->dispv[l].H * h->dispv[l].W;
+        float* base = h->alloc<float>(tot);
+        for (int l = 0; l < 4; ++l) { h->ddisp_lo[l] = base; base += (size_t)N * h->dispv[l].H * h->dispv[l].W; }
+    }
     const size_t emax = (size_t)NL * (H / 2) * (W / 2) * 64;
     h->E1 = h->alloc<float>(emax); h->E2 = h->alloc<float>(emax); h->E3 = h->alloc<float>(emax);
     // pre-activation gradients of every encoder conv: NOT shared scratch, the weight-gradient stream reads them while the main stream moves on
@@ -463,6 +467,38 @@ static int loss_backward(md2_handle* h, const float* x, const float* const disp[
     if (h->prof) h->prof_bytes[CLS_LOSS_BWD] += 4.0 * h->H * h->W * (2 + 3 * h->C) * 4 * h->N;
     const size_t P = (size_t)h->H * h->W;
     if (!simple) for (int i = 0; i < 4; ++i) launch_upsample_planar_bwd(h->ddisp_full + (size_t)i * h->N * P, h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
+    launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, 1, 0, s);
+    KCHK();
+    return 0;
+}
+
+// loss value and its pullback in one pass (training): fills the loss, ddisp_lo[4], drvec, dtvec
+static int loss_train(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
+    static const bool split = getenv("MD2_LOSS_SPLIT") && atoi(getenv("MD2_LOSS_SPLIT")) != 0;       // cross-check: the separate forward and pullback kernels
+    if (split) { if (int r = loss_forward(h, x, disp, rvec, tvec, auto_loss, loss_out, simple)) return r; return loss_backward(h, x, disp, rvec, tvec, auto_loss, simple); }
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)40 * h->N * sizeof(double), s));           // loss_part [16N] and dRt_acc [24N] are adjacent
+    launch_pose_compose(rvec, tvec, h->Rt, h->N, 1, 0, s);
+    LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
+    if (simple) simple_mode(h, a);
+    const size_t P = (size_t)h->H * h->W;
+    // gradient wrt the disparity maps: the full-resolution scale is written directly; the coarse scales receive the adjoint of the bilinear resize from inside the
+    // kernel (per-tile partial sums, float atomics) -- or, in deterministic mode, full-resolution maps that the ordered adjoint kernel reduces afterwards
+    float *dd[4], *dlo[4];
+    static const bool no_scatter = getenv("MD2_LOSS_NOSCATTER") && atoi(getenv("MD2_LOSS_NOSCATTER")) != 0;
+    const bool scatter = !simple && !g_deterministic && !no_scatter;
+    for (int i = 0; i < 4; ++i) {
+        const bool full = !simple && a.dh[i] == h->H && a.dw[i] == h->W;
+        dd[i] = full ? h->ddisp_lo[i] : h->ddisp_full + (size_t)i * h->N * P;
+        dlo[i] = (scatter && !full) ? h->ddisp_lo[i] : nullptr;
+    }
+    if (scatter) HIPCHK(hipMemsetAsync(h->ddisp_lo[0], 0, (size_t)((char*)h->ddisp_lo[3] - (char*)h->ddisp_lo[0]), s));
+    launch_loss_smooth_sums(a, h->loss_part, g_deterministic ? h->loss_blk : nullptr, s);
+    h->pbegin(CLS_LOSS_BWD); launch_loss_train(a, h->loss_part, dd, dlo, h->dRt_acc, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
+    if (h->prof) h->prof_bytes[CLS_LOSS_BWD] += 4.0 * h->H * h->W * (2 + 3 * h->C) * a.nscales * h->N;
+    launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
+    if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!simple) for (int i = 0; i < 4; ++i) if (!dlo[i] && dd[i] != h->ddisp_lo[i]) launch_upsample_planar_bwd(dd[i], h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
     launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, 1, 0, s);
     KCHK();
     return 0;
@@ -849,15 +885,13 @@ int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, fl
     }
     if (int r = model_forward(h, x)) return r;
     const float* disp[4] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p};
-    if (int r = loss_forward(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;
+    if (int r = loss_train(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;          // the loss pullback comes out of the same pass: md2_backward starts at the network
     h->x_last = x; h->auto_last = auto_loss; h->have_fwd = true;
     return 0;
 }
 int32_t md2_backward(md2_handle* h) {
     if (!h->have_fwd) { h->err = "md2_backward: call md2_train_loss first"; return 2; }
-    const float* disp[4] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p};
-    if (int r = loss_backward(h, h->x_last, disp, h->rvec, h->tvec, h->auto_last)) return r;
-    return model_backward(h);
+    return model_backward(h);                   // ddisp_lo / drvec / dtvec were filled by md2_train_loss
 }
 int32_t md2_adam_step(md2_handle* h, float grad_scale) {
     h->beta1p *= 0.9; h->beta2p *= 0.999;
@@ -881,9 +915,8 @@ int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const f
                          const float* auto_loss, float* loss, float* dd0, float* dd1, float* dd2, float* dd3, float* drvec, float* dtvec) {
     const float* disp[4] = {d0, d1, d2, d3};
     h->have_fwd = false;                    // overwrites Rt / totals of a pending md2_train_loss
-    if (int r = loss_forward(h, x, disp, rvec, tvec, auto_loss, loss)) return r;
-    if (!(dd0 || dd1 || dd2 || dd3 || drvec || dtvec)) return 0;
-    if (int r = loss_backward(h, x, disp, rvec, tvec, auto_loss)) return r;
+    if (!(dd0 || dd1 || dd2 || dd3 || drvec || dtvec)) return loss_forward(h, x, disp, rvec, tvec, auto_loss, loss);
+    if (int r = loss_train(h, x, disp, rvec, tvec, auto_loss, loss)) return r;
     float* dds[4] = {dd0, dd1, dd2, dd3};
     for (int i = 0; i < 4; ++i)
         if (dds[i]) HIPCHK(hipMemcpyAsync(dds[i], h->ddisp_lo[i], (size_t)h->N * h->dispv[i].H * h->dispv[i].W * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
@@ -895,9 +928,8 @@ int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const f
 int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, const float* rvec, const float* tvec, float* loss, float* ddisp, float* drvec, float* dtvec) {
     const float* d4[4] = {disp, disp, disp, disp};
     h->have_fwd = false;
-    if (int r = loss_forward(h, x, d4, rvec, tvec, nullptr, loss, true)) return r;
-    if (!(ddisp || drvec || dtvec)) return 0;
-    if (int r = loss_backward(h, x, d4, rvec, tvec, nullptr, true)) return r;
+    if (!(ddisp || drvec || dtvec)) return loss_forward(h, x, d4, rvec, tvec, nullptr, loss, true);
+    if (int r = loss_train(h, x, d4, rvec, tvec, nullptr, loss, true)) return r;
     if (ddisp) HIPCHK(hipMemcpyAsync(ddisp, h->ddisp_full, (size_t)h->N * h->H * h->W * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (drvec) HIPCHK(hipMemcpyAsync(drvec, h->drvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (dtvec) HIPCHK(hipMemcpyAsync(dtvec, h->dtvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));

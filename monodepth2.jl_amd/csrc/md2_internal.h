@@ -196,6 +196,11 @@ int loss_blocks_per_image(const LossArgs& a);
 void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, float* loss, hipStream_t s);
 // backward: ddisp_full[scale][N][H][W] ; dRt partials -> dRt_acc double [2][N][12] (zeroed by caller)
 void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, double* blk /* [nscales*N][blocks][24] or null */, hipStream_t s);
+// training: smoothness sums, then loss value + pullback from one pass over the warp.  part / dRt_acc zeroed by the caller; dd[sc] = [N][H][W] gradient wrt the
+// full-resolution disparity of scale sc, or -- where dlo[sc] is not null -- dlo[sc] = [N][dh][dw] (zeroed by the caller) receives the adjoint of the bilinear resize
+// of that gradient instead (float atomics); blk as above (needs >= max(N*tiles32*12, nscales*N*blocks*25) doubles)
+void launch_loss_smooth_sums(const LossArgs& a, double* part, double* blk, hipStream_t s);      // first: part slots 1..3 (sum d, Sx, Sy per scale and sample)
+void launch_loss_train(const LossArgs& a, double* part, float* const dd[4], float* const dlo[4], double* dRt_acc, double* blk, hipStream_t s);
 void launch_automask(const float* x, float* out, int N, int C, int H, int W, int src0, int src1, int tgt, hipStream_t s);
 // planar bilinear (align-corners) upsample adjoint, gather form: [planes][Ho][Wo] -> [planes][H][W]
 void launch_upsample_planar_bwd(const float* dout, float* dx, int planes, int H, int W, int Ho, int Wo, hipStream_t s);

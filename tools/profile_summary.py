@@ -17,8 +17,8 @@ def klass(name):
         return "conv_wgrad"
     if "loss_fwd_kernel" in name:
         return "loss_fwd"
-    if "loss_bwd_kernel" in name:
-        return "loss_bwd"
+    if "loss_train_kernel" in name or "loss_bwd_kernel" in name:
+        return "loss_train"
     return "other"
 
 
@@ -42,7 +42,7 @@ def stats(d, steps, title):
     print()
     print("| class | launches/step | ms/step | avg us |")
     print("|---|---|---|---|")
-    for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd", "other"):
+    for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_train", "other"):
         n, t = agg[k]
         print("| %s | %.1f | %.3f | %.1f |" % (k, n / steps, t / 1e6 / steps, t / 1e3 / max(n, 1)))
 
@@ -59,13 +59,13 @@ def pmc(df, dw, steps):
     fe, wr = load(df, "FETCH_SIZE"), load(dw, "WRITE_SIZE")
     print("| kernel class | launches/step | FETCH_SIZE KiB/step (raw) | read MB/step (x2 corrected) | WRITE_SIZE MB/step | read+write MB per launch |")
     print("|---|---|---|---|---|---|")
-    for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd", "other"):
+    for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_train", "other"):
         n = fe[k][0] / steps
         rd = 2 * fe[k][1] * 1024 / 1e6 / steps
         w = wr[k][1] * 1024 / 1e6 / steps
         print("| %s | %.1f | %.0f | %.1f | %.1f | %.2f |" % (k, n, fe[k][1] / steps, rd, w, (rd + w) / max(n, 1e-9)))
     print()
-    tab = {k: round((2 * fe[k][1] * 1024 + wr[k][1] * 1024) / max(fe[k][0], 1), -5) for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd")}
+    tab = {k: round((2 * fe[k][1] * 1024 + wr[k][1] * 1024) / max(fe[k][0], 1), -5) for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_train")}
     print("bench.py table (bytes per launch):", tab)
     if len(sys.argv) > 5:                       # machine-readable copy that bench.py reads for `roofline.traffic`
         import json
@@ -73,7 +73,7 @@ def pmc(df, dw, steps):
         json.dump({"command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
                    "workload": {"batch": w[0], "channels": w[1], "height": w[2], "width": w[3], "depth": w[4], "precision": sys.argv[11]},
                    "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 64 B per 128-B request) + WRITE_SIZE KiB x 1024, per launch", "bytes_per_launch": tab,
-                   "bytes_per_step": {k: 2 * fe[k][1] * 1024 / steps + wr[k][1] * 1024 / steps for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_bwd", "other")}},
+                   "bytes_per_step": {k: 2 * fe[k][1] * 1024 / steps + wr[k][1] * 1024 / steps for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_train", "other")}},
                   open(sys.argv[5], "w"), indent=1)
 
 
