@@ -406,8 +406,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 }
                 if (a.ksplit > 1) {            // partial sum: (x act') is linear, bias/activation are applied by the launcher's second pass
                     if (dp) { v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
+                    if (a.ws) *reinterpret_cast<float4*>(a.ws + ((long)blockIdx.y * a.M + m) * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);   // dense launch: row m of slice blockIdx.y
+                    else {                     // (64 lanes = 64 different pixels: 64 cache lines per atomic instruction -- the workspace path exists because of this)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(yp + co + e, v[e]);
+                        for (int e = 0; e < 4; ++e) atomicAdd(yp + co + e, v[e]);
+                    }
                     continue;
                 }
                 if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + co); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
@@ -484,6 +487,53 @@ __global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_cl
         case 2: conv_igemm_body<BM, BN, WP, WC, MF, 2, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
         default: conv_igemm_body<BM, BN, WP, WC, MF, 4, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
     }
+}
+
+// split-K second pass: y = act(sum_k ws[k] + bias) [+ y]; with `stats` also the BatchNorm statistics of the (linear, bias-free) result.
+// block = 256 threads = RG row groups x Q channel quads (the colstats layout); ws rows are dense [ksplit][M][C], y is addressed through its strides.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int M, int C, float* __restrict__ y, long y_bs, int y_ps, int HW,
+                                                            const float* __restrict__ bias, int act, int accumulate, double* __restrict__ stats, int rows_per_block) {
+    const int Qall = C / 4, qoff = blockIdx.y * 256, Q = min(Qall - qoff, 256), RG = 256 / Q;
+    const int q = qoff + threadIdx.x % Q, rg = threadIdx.x / Q;
+    __shared__ float red[2 * 4 * 256];
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const int p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, M);
+    const float4 b = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long slice = (long)M * C;
+    if (rg < RG)
+        for (int p = p0 + rg; p < p1; p += RG) {
+            const float* wp = ws + (long)p * C + q * 4;
+            float4 v = *reinterpret_cast<const float4*>(wp);
+            for (int k = 1; k < ksplit; ++k) { const float4 t = *reinterpret_cast<const float4*>(wp + k * slice); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            if (act != ACT_NONE) { v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act); }
+            const int n = p / HW, r = p - n * HW;
+            float* yp = y + (long)n * y_bs + (long)r * y_ps + q * 4;
+            if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4*>(yp) = v;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+        }
+    if (!stats) return;
+    float* r1 = red; float* r2 = red + 4 * 256;
+    r1[0 * 256 + threadIdx.x] = s1.x; r1[1 * 256 + threadIdx.x] = s1.y; r1[2 * 256 + threadIdx.x] = s1.z; r1[3 * 256 + threadIdx.x] = s1.w;
+    r2[0 * 256 + threadIdx.x] = s2.x; r2[1 * 256 + threadIdx.x] = s2.y; r2[2 * 256 + threadIdx.x] = s2.z; r2[3 * 256 + threadIdx.x] = s2.w;
+    __syncthreads();
+    double* acc = stats + (size_t)(blockIdx.x % BN_STAT_SLOTS) * 2 * C;
+    for (int c = threadIdx.x; c < 2 * 4 * Q; c += 256) {
+        const int which = c / (4 * Q), ch = c % (4 * Q), qq = ch / 4, e = ch % 4;
+        const float* rr = which ? r2 : r1;
+        float sum = 0.f;
+        for (int g = 0; g < RG; ++g) sum += rr[e * 256 + g * Q + qq];
+        atomicAdd(acc + which * C + qoff * 4 + ch, (double)sum);
+    }
+}
+static bool splitk_ws_shape_ok(int C) { const int Q = C / 4; return C % 64 == 0 && (Q <= 256 ? 256 % Q == 0 : Q % 256 == 0); }
+static void launch_splitk_reduce(const ConvArgs& a, const float* bias, int act, int accumulate, double* stats, hipStream_t s) {
+    const int Q = a.Cout / 4, RG = std::max(1, 256 / std::min(Q, 256));
+    int rpb = (a.M + 511) / 512; rpb = std::max(RG, (rpb + RG - 1) / RG * RG);
+    const dim3 grid((a.M + rpb - 1) / rpb, (Q + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, stats, rpb);
 }
 
 // BatchNorm-pullback sums that could not be fused into an epilogue (16-wide tiles, split-K, deterministic mode): one column pass over (g, z)
@@ -772,34 +822,48 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     a.ksplit = 1;
     check_igemm_args(a);
-    // Small pixel counts (batch 4: M = 208 ... 2496) give only tens of tiles with a serial K loop of up to 288 steps.  Split the
-    // channel chunks over gridDim.y (>= 2 chunks per split), sum with fp32 atomics into a zeroed output and apply bias /
-    // activation in a second elementwise pass.
-    {
-        const long tiles64 = (long)((a.M + 63) / 64) * (a.Cout / (a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : 16)));
-        const int cpt = a.Cin / 16;
+    // Few tiles with a long serial K loop (batch 4: M = 208 ... 2496 pixels give tens of tiles and up to 288 K-steps; batch 32: the 512-channel layers put
+    // 2.4 blocks on a CU, i.e. 3 on some and 2 on others): split the channel chunks over gridDim.y.
+    const long tiles64 = (long)((a.M + 63) / 64) * (a.Cout / (a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : 16)));
+    const int cpt = a.Cin / 16;
+    const long steps = (long)cpt * a.nkh * a.nkw;
+    static const bool no_ws = getenv("MD2_IGEMM_NO_WS") && atoi(getenv("MD2_IGEMM_NO_WS")) != 0;
+    const bool use_ws = a.ws && !no_ws && a.ostep == 1 && splitk_ws_shape_ok(a.Cout) && !g_deterministic;
+    double* ws_stats = nullptr;
+    if (use_ws) {
+        // With the workspace the partial tiles are plain 16-B stores and one cheap pass sums them, so the split pays as soon as it balances the CUs better:
+        // cost(k) ~ (blocks per CU, rounded up) x (K-steps per block + prologue / epilogue), with a penalty while a SIMD has fewer than 3 waves to hide latency behind.
+        auto cost = [&](int k) { const long per_cu = (tiles64 * k + 255) / 256; return (double)per_cu * ((double)steps / k + 10.0) * (per_cu == 1 ? 1.5 : (per_cu == 2 ? 1.15 : 1.0)); };
+        int best = 1; double cb = cost(1);
+        for (int k = 2; k <= 8 && steps / k >= 16 && (long)k * a.M * a.Cout <= a.ws_cap && k <= cpt; ++k) { const double c = cost(k); if (c < 0.95 * cb) { cb = c; best = k; } }
+        if (cb <= 0.9 * cost(1)) a.ksplit = best;
+        if (a.ksplit > 1) { ws_stats = a.stats; a.stats = nullptr; }          // the statistics come out of the reduce pass
+    } else {
+        // no workspace (op-level calls): sum with fp32 atomics into a zeroed output and apply bias / activation in a second elementwise pass.
         static const int want = getenv("MD2_IGEMM_SPLIT_BLOCKS") ? atoi(getenv("MD2_IGEMM_SPLIT_BLOCKS")) : 512;
         // ... and the same for up to one tile per CU when the serial K loop is very long (>= 256 steps: the 512-channel 3x3 layers at 1/32 scale;
         // measured: 0.175 -> 0.106 ms and 0.179 -> 0.138 ms there, but 0.092 -> 0.105 ms for the 256-channel layers with 144 steps)
         static const int mid = getenv("MD2_IGEMM_SPLIT_MID") ? atoi(getenv("MD2_IGEMM_SPLIT_MID")) : 256;
         static const int long_k = getenv("MD2_IGEMM_SPLIT_KSTEPS") ? atoi(getenv("MD2_IGEMM_SPLIT_KSTEPS")) : 256;
-        const bool few = tiles64 < 100 || (tiles64 < mid && (long)cpt * a.nkh * a.nkw >= long_k);
+        const bool few = tiles64 < 100 || (tiles64 < mid && steps >= long_k);
         // (a serial K loop of fewer than 64 steps -- the 1x1 convolutions -- is cheaper than the fill + atomics + bias/activation passes of a split)
-        if (few && cpt >= 4 && (long)cpt * a.nkh * a.nkw >= 64 && want > 0 && !g_deterministic) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
+        if (few && cpt >= 4 && steps >= 64 && want > 0 && !g_deterministic) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
+        a.ws = nullptr;
     }
     View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
-    const float* bias2 = nullptr; int act2 = ACT_NONE;
+    const float* bias2 = nullptr; int act2 = ACT_NONE, acc2 = 0;
     if (a.ksplit > 1) {
         if (a.ostep != 1) a.ksplit = 1;                      // residue-class launches write a sub-lattice: keep them single-pass
         else {
-            if (!a.accumulate) launch_fill_view(yv, 0.f, s);
+            if (a.ws) { acc2 = a.accumulate; a.accumulate = 0; }
+            else if (!a.accumulate) launch_fill_view(yv, 0.f, s);
             else if (a.accumulate == 2) {                    // only the middle frame of every triplet holds earlier contributions
                 if (a.N % 3) { fprintf(stderr, "md2: conv_igemm: accumulate mode 2 needs a 3-frame batch\n"); abort(); }
                 for (int l = 0; l < 3; l += 2) { View f = yv; f.p = yv.p + (long)l * yv.bs; f.N = yv.N / 3; f.bs = yv.bs * 3; launch_fill_view(f, 0.f, s); }
             }
             bias2 = a.bias; act2 = a.act; a.bias = nullptr; a.act = ACT_NONE;
         }
-    }
+    } else a.ws = nullptr;
     const long tiles128 = (long)((a.M + 127) / 128);
 #ifdef MD2_ABLATE
     switch (a.force_tile) {
@@ -817,7 +881,8 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
-    if (a.ksplit > 1 && (bias2 || act2 != ACT_NONE)) launch_bias_act_view(yv, bias2, act2, s);
+    if (a.ksplit > 1 && a.ws) launch_splitk_reduce(a, bias2, act2, acc2, ws_stats, s);
+    else if (a.ksplit > 1 && (bias2 || act2 != ACT_NONE)) launch_bias_act_view(yv, bias2, act2, s);
     if (a.ksplit > 1 && a.bst && a.ostep == 1) bst_fallback(a, s);                         // split-K: the gradient is final only after every K slice has been added
 }
 

@@ -7,8 +7,8 @@
 // (+1 px halo, reflect-mapped like pad_reflect) of both warped sources and the target is built in LDS, the 3x3
 // window statistics are read from LDS, and only per-(scale,sample) partial sums leave the block.
 // Algorithmic HBM bytes per sample per scale (fwd): 4P(1+3C).
-// The backward recomputes the warp (reads the same bytes) and writes d loss / d disparity (4P per scale) plus
-// 24 pose-gradient partials per block (wave shuffle + LDS reduction, no per-pixel atomics).
+// Training uses loss_train_kernel instead: the same tile (+2 px halo) built once, loss value AND pullback out of it -- d loss / d disparity
+// (4P per scale, the coarse scales already resized to their own resolution) plus 24 pose-gradient partials per block (DPP + LDS reduction, no per-pixel atomics).
 #include "md2_internal.h"
 #include <algorithm>
 
@@ -16,7 +16,6 @@ namespace md2 {
 
 constexpr int TW = 32, TH = 16;           // tile
 constexpr int FW = TW + 2, FH = TH + 2;   // fwd region (halo 1)
-constexpr int BW2 = TW + 4, BH2 = TH + 4; // bwd value region (halo 2)
 constexpr int MAXC = 3;
 
 struct Pose12 { float R[9]; float t[3]; };   // column-major R
@@ -253,217 +252,6 @@ __global__ void loss_finalize_kernel(LossArgs a, const double* __restrict__ part
 }
 void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, float* loss, hipStream_t s) {
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, a, part, totals, loss);
-}
-
-// =====================================================================================================================
-// backward
-// =====================================================================================================================
-template <int C>
-__global__ __launch_bounds__(256) void loss_bwd_kernel(LossArgs a, const float* __restrict__ totals, float* __restrict__ ddisp_full, double* __restrict__ dRt_acc, double* __restrict__ blk) {
-    __shared__ float wv[2][C][BH2 * BW2];        // warped sources at padded positions of tile + 2
-    __shared__ float tg[C][BH2 * BW2];
-    __shared__ float dl[BH2 * BW2];
-    __shared__ float coef[C][3][FH * FW];        // d photometric_{s*} / d (pool x, pool x^2, pool xy) at q in tile + 1, pre-scaled
-    __shared__ signed char amin[FH * FW];        // winning source at q, -1: none (outside / masked)
-    __shared__ float red[4][24];
-    const int zi = blockIdx.z, sc = zi / a.N, n = zi % a.N;
-    const int H = a.H, W = a.W;
-    const long P = (long)H * W;
-    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
-    const float* xn = a.x + (long)n * 3 * C * P;
-    const float* tgt = xn + (long)a.tgt * C * P;
-    const float* srcs[2] = {xn + (long)a.src0 * C * P, xn + (long)a.src1 * C * P};
-    const float* dsp = a.disp[sc] + (long)n * a.dh[sc] * a.dw[sc];
-    Pose12 T[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const float* rt = a.Rt + ((long)s * a.N + n) * 12;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) T[s].R[i] = rt[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) T[s].t[i] = rt[9 + i];
-    }
-    const float alpha = 0.85f, beta = 1.f - alpha, invC = 1.f / (float)C;
-    const float wpix = 1.f / ((float)a.nscales * (float)a.N * (float)P);      // d loss / d warp_loss[q]
-    // ---- phase 1: values at padded positions u in tile + 2 (u clamped into the padded domain [-1, size])
-    for (int i = threadIdx.x; i < BH2 * BW2; i += 256) {
-        const int ry = i / BW2, rx = i - ry * BW2;
-        const int uy = max(-1, min(ty0 - 2 + ry, H)), ux = max(-1, min(tx0 - 2 + rx, W));
-        const int py = refl_idx(uy, H), px = refl_idx(ux, W);
-        const float d = disp_at(dsp, a.dh[sc], a.dw[sc], H, W, py, px);
-        dl[i] = d;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            Proj pr; project_px(d, py, px, a.K, a.invK, T[s], a.min_disp, a.max_disp, H, W, pr);
-            Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
-            for (int c = 0; c < C; ++c) wv[s][c][i] = sample_val(srcs[s] + (long)c * P, sm);
-        }
-        for (int c = 0; c < C; ++c) tg[c][i] = tgt[(long)c * P + (long)py * W + px];
-    }
-    __syncthreads();
-    // ---- phase 2: window owners q in tile + 1: photometric of both sources, arg-min, SSIM pullback coefficients
-    for (int i = threadIdx.x; i < FH * FW; i += 256) {
-        const int ry = i / FW, rx = i - ry * FW;
-        const int qy = ty0 - 1 + ry, qx = tx0 - 1 + rx;
-        signed char win = -1;
-        if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
-            const int ctr = (ry + 1) * BW2 + rx + 1;
-            float pl[2] = {0.f, 0.f}; SsimOut so[2][C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float yw[9], sy = 0.f, syy = 0.f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { yw[k] = tg[c][ctr + (k / 3 - 1) * BW2 + (k % 3 - 1)]; sy += yw[k]; syy += yw[k] * yw[k]; }
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float sx = 0.f, sxx = 0.f, sxy = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) { const float xv = wv[s][c][ctr + (k / 3 - 1) * BW2 + (k % 3 - 1)]; sx += xv; sxx += xv * xv; sxy += xv * yw[k]; }
-                    ssim_from_sums(sx, sy, sxx, syy, sxy, true, so[s][c]);
-                    pl[s] += alpha * invC * so[s][c].val + beta * invC * fabsf(yw[4] - wv[s][c][ctr]);
-                }
-            }
-            win = pl[1] < pl[0] ? 1 : 0;                                             // first arg-min (Zygote `minimum`)
-            if (a.auto_loss && !(pl[win] < a.auto_loss[(long)n * P + (long)qy * W + qx])) win = -1;   // mask wins ties -> no gradient
-            const float g = wpix * alpha * invC * (1.f / 9.f);                       // through mean_c, alpha, and the /9 of MeanPool
-#pragma unroll
-            for (int c = 0; c < C; ++c) {                                            // select by value: a runtime index into so[][] would put it in scratch
-                const bool w1 = win == 1;
-                const float m = win < 0 ? 0.f : g;
-                coef[c][0][i] = m * (w1 ? so[1][c].g_mx : so[0][c].g_mx);
-                coef[c][1][i] = m * (w1 ? so[1][c].g_pxx : so[0][c].g_pxx);
-                coef[c][2][i] = m * (w1 ? so[1][c].g_pxy : so[0][c].g_pxy);
-            }
-        } else
-            for (int c = 0; c < C; ++c) { coef[c][0][i] = 0.f; coef[c][1][i] = 0.f; coef[c][2][i] = 0.f; }
-        amin[i] = win;
-    }
-    __syncthreads();
-    // ---- phase 3: per tile pixel r: gather d loss / d warped_s[r], pull back through grid_sample, Project, Backproject, depth
-    const float* tt = totals + ((long)sc * a.N + n) * 4;
-    const float den = a.normalize ? tt[1] + 1e-7f : 1.f;
-    const double cntx = (double)(W - 1) * H * a.N, cnty = (double)W * (H - 1) * a.N;
-    const float sw = a.smooth_w[sc] / (float)a.nscales;
-    const float ax = sw / den / (float)cntx, ay = sw / den / (float)cnty;
-    const float corr = a.normalize ? sw * (float)((double)tt[2] / cntx + (double)tt[3] / cnty) / (den * den) / (float)P : 0.f;
-    float acc[24];
-#pragma unroll
-    for (int k = 0; k < 24; ++k) acc[k] = 0.f;
-    for (int i = threadIdx.x; i < TH * TW; i += 256) {
-        const int ly = i / TW, lx = i - ly * TW, py = ty0 + ly, px = tx0 + lx;
-        if (py >= H || px >= W) continue;
-        const int cb = (ly + 2) * BW2 + lx + 2;          // r in the value region
-        // padded positions that alias r under pad_reflect
-        int uys[3], uxs[3], ny = 0, nx = 0;
-        uys[ny++] = py; if (py == 1) uys[ny++] = -1; if (py == H - 2) uys[ny++] = H;
-        uxs[nx++] = px; if (px == 1) uxs[nx++] = -1; if (px == W - 2) uxs[nx++] = W;
-        const float d = dl[cb];
-        float gd = 0.f;                                   // d loss / d disparity[r]
-        const int rwin = amin[(ly + 1) * FW + lx + 1];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float gw[C];
-            bool any = false;
-            for (int c = 0; c < C; ++c) {
-                float g = 0.f;
-                for (int iy = 0; iy < ny; ++iy)
-                    for (int ix = 0; ix < nx; ++ix) {
-                        const int uy = uys[iy], ux = uxs[ix];
-                        const int vb = (uy - ty0 + 2) * BW2 + (ux - tx0 + 2);   // value-region index of u (within tile + 2)
-                        const float xu = wv[s][c][vb], yu = tg[c][vb];
-#pragma unroll
-                        for (int dy = -1; dy <= 1; ++dy) {
-                            const int qy = uy + dy; if (qy < 0 || qy >= H) continue;
-#pragma unroll
-                            for (int dx = -1; dx <= 1; ++dx) {
-                                const int qx = ux + dx; if (qx < 0 || qx >= W) continue;
-                                const int qi = (qy - ty0 + 1) * FW + (qx - tx0 + 1);
-                                if (amin[qi] != s) continue;
-                                g += coef[c][0][qi] + 2.f * xu * coef[c][1][qi] + yu * coef[c][2][qi];
-                            }
-                        }
-                    }
-                if (rwin == s) { const float df = tg[c][cb] - wv[s][c][cb]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
-                gw[c] = g; any = any || g != 0.f;
-            }
-            if (!any) continue;
-            // grid_sample pullback wrt the sampling coordinate
-            Proj pr; project_px(d, py, px, a.K, a.invK, T[s], a.min_disp, a.max_disp, H, W, pr);
-            Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
-            float ggx = 0.f, ggy = 0.f;
-            for (int c = 0; c < C; ++c) {
-                const float* im = srcs[s] + (long)c * P;
-                const float v00 = im[sm.i00], v01 = sm.v01 ? im[sm.i01] : 0.f, v10 = sm.v10 ? im[sm.i10] : 0.f, v11 = sm.v11 ? im[sm.i11] : 0.f;   // NNlib: outside corners read as 0 in the coordinate pullback
-                ggx += gw[c] * ((v01 - v00) * sm.wy0 + (v11 - v10) * sm.wy1);
-                ggy += gw[c] * ((v10 - v00) * sm.wx0 + (v11 - v01) * sm.wx1);
-            }
-            ggx *= pr.mx; ggy *= pr.my;                  // unnormalise: (size-1)/2, 0 where clamped
-            // Project pullback (normalise: *2/(size-1))
-            const float gu = ggx * (2.f / (float)(W - 1)), gv = ggy * (2.f / (float)(H - 1));
-            const float gc[3] = {gu * pr.denom, gv * pr.denom, -(gu * pr.c[0] + gv * pr.c[1]) * pr.denom * pr.denom};
-            float gr[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) gr[j] = a.K[j * 3 + 0] * gc[0] + a.K[j * 3 + 1] * gc[1] + a.K[j * 3 + 2] * gc[2];
-            float gP[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                gP[j] = T[s].R[j * 3 + 0] * gr[0] + T[s].R[j * 3 + 1] * gr[1] + T[s].R[j * 3 + 2] * gr[2];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc[s * 12 + j * 3 + k] += gr[k] * pr.P[j];
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) acc[s * 12 + 9 + k] += gr[k];
-            // Backproject + disparity_to_depth pullback
-            const float cx = (float)(px + 1), cy = (float)(py + 1);
-            float gdepth = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) gdepth += gP[k] * (a.invK[k] * cx + a.invK[3 + k] * cy + a.invK[6 + k]);
-            const float dd = d * (a.max_disp - a.min_disp) + a.min_disp;
-            const float rdd = frcp(dd);
-            gd += -gdepth * (a.max_disp - a.min_disp) * rdd * rdd;
-        }
-        // smooth_loss(d / (mean + eps)) pullback
-        float gs = -corr;
-        auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
-        auto ex = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + 1]); if (C > 1) gi *= invC; return fexp(-gi); };
-        auto ey = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + BW2]); if (C > 1) gi *= invC; return fexp(-gi); };
-        if (px + 1 < W) gs += ax * sgn(d - dl[cb + 1]) * ex(cb);
-        if (px >= 1) gs -= ax * sgn(dl[cb - 1] - d) * ex(cb - 1);
-        if (py + 1 < H) gs += ay * sgn(d - dl[cb + BW2]) * ey(cb);
-        if (py >= 1) gs -= ay * sgn(dl[cb - BW2] - d) * ey(cb - BW2);
-        ddisp_full[((long)sc * a.N + n) * P + (long)py * W + px] = gd + gs;
-    }
-    // ---- pose-gradient partials: wave shuffle, then LDS across the 4 waves, one double atomic per value per block
-#pragma unroll
-    for (int k = 0; k < 24; ++k) acc[k] = wave_sum(acc[k]);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 24; ++k) red[wave][k] = acc[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 24) {
-        const int s = threadIdx.x / 12, k = threadIdx.x % 12;
-        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (blk) blk[((long)zi * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 24 + threadIdx.x] = (double)v;
-        else if (v != 0.f) atomicAdd(dRt_acc + ((long)s * a.N + n) * 12 + k, (double)v);
-    }
-}
-// deterministic mode: dRt_acc[(s*N+n)*12+k] = sum over scales, then blocks, in order
-__global__ void loss_dRt_reduce_kernel(const double* __restrict__ blk, double* __restrict__ dRt_acc, int N, int nscales, int nb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= 24 * N) return;
-    const int k = i % 12, n = (i / 12) % N, s = i / (12 * N);
-    double acc = 0;
-    for (int sc = 0; sc < nscales; ++sc)
-        for (int b = 0; b < nb; ++b) acc += blk[(((long)sc * N + n) * nb + b) * 24 + s * 12 + k];
-    dRt_acc[((long)s * N + n) * 12 + k] = acc;
-}
-void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, double* blk, hipStream_t s) {
-    if ((a.C != 1 && a.C != 3) || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_bwd: unsupported shape\n"); abort(); }
-    dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N * a.nscales);
-    if (a.C == 1) hipLaunchKernelGGL(loss_bwd_kernel<1>, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc, blk);
-    else hipLaunchKernelGGL(loss_bwd_kernel<3>, grid, dim3(256), 0, s, a, totals, ddisp_full, dRt_acc, blk);
-    if (blk) hipLaunchKernelGGL(loss_dRt_reduce_kernel, dim3((24 * a.N + 63) / 64), dim3(64), 0, s, blk, dRt_acc, a.N, a.nscales, (int)(grid.x * grid.y));
 }
 
 // =====================================================================================================================

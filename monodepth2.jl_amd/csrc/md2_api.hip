@@ -76,6 +76,7 @@ struct md2_handle {
     bool net_ok = true;                 // false: the image is too small for the network (H or W < 64): only the loss-half entry points work
     float* RS = nullptr; long n_rs = 0; bool testmode = false;     // BatchNorm running mean / variance (Flux BatchNorm mu, sigma^2; momentum 0.1) and Flux.testmode!
     double* loss_blk = nullptr;         // deterministic mode: per-block partial sums of the loss kernels
+    float* ws_main = nullptr; float* ws_pose = nullptr; long ws_cap = 0;   // split-K workspaces of the implicit GEMM: one per stream that runs convolutions concurrently
     // data parallelism: RCCL communicator + bucketed all-reduce of the flat gradient buffer, overlapped with the rest of the pullback
     void* comm = nullptr; int rank = 0, world = 1; hipStream_t scomm = nullptr; hipEvent_t ev_cm[8], ev_cs[8], ev_cdone = nullptr; bool grads_reduced = false; long bucket_lo[8]; int n_bucket_done = 0;
     bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
@@ -213,6 +214,7 @@ static void plan_buffers(md2_handle* h) {
     h->sqcat = h->alloc_view(2 * N, ph, pw, 512); h->py1 = h->alloc_view(2 * N, ph, pw, 256); h->py2 = h->alloc_view(2 * N, ph, pw, 256); h->py3 = h->alloc_view(2 * N, ph, pw, 16);
     h->rvec = h->alloc<float>(6 * N); h->tvec = h->alloc<float>(6 * N); h->Rt = h->alloc<float>(24 * N);
     h->totals = h->alloc<float>(16 * N); h->loss_dev = h->alloc<float>(4); h->ddisp_full = h->alloc<float>((size_t)4 * N * H * W);
+    h->ws_cap = 8L << 20; h->ws_main = h->alloc<float>((size_t)h->ws_cap); h->ws_pose = h->alloc<float>((size_t)h->ws_cap);      // 2 x 32 MB
     h->drvec = h->alloc<float>(6 * N); h->dtvec = h->alloc<float>(6 * N);
     h->loss_blk = h->alloc<double>((size_t)4 * N * ((W + 15) / 16) * ((H + 7) / 8) * 24);        // deterministic mode: [scale*N][block][24] partials (bound for loss tiles >= 16x8)
     for (BNL* b : h->bns) b->stats = h->alloc<float>(9 * b->c);                 // mean | invstd | scale | shift | pullback m1 | m2 | A | B | C0 (dz = A g + B z + C0)
@@ -274,6 +276,7 @@ static ConvArgs conv_args(const View& x, const float* w, const View& y, int KH, 
 }
 static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
     ConvArgs a = a_in; a.bf16 = h->bf16;
+    a.ws = (h->cur && h->cur == h->s3) ? h->ws_pose : h->ws_main; a.ws_cap = h->ws_cap;
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W);
     h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
@@ -457,25 +460,8 @@ static int loss_forward(md2_handle* h, const float* x, const float* const disp[4
     KCHK();
     return 0;
 }
-// pullback of the loss half: fills ddisp_lo[4] (scale resolution), drvec, dtvec
-static int loss_backward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, bool simple = false) {
-    hipStream_t s = h->stream;
-    LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
-    if (simple) simple_mode(h, a);
-    HIPCHK(hipMemsetAsync(h->dRt_acc, 0, (size_t)24 * h->N * sizeof(double), s));
-    h->pbegin(CLS_LOSS_BWD); launch_loss_bwd(a, h->totals, h->ddisp_full, h->dRt_acc, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
-    if (h->prof) h->prof_bytes[CLS_LOSS_BWD] += 4.0 * h->H * h->W * (2 + 3 * h->C) * 4 * h->N;
-    const size_t P = (size_t)h->H * h->W;
-    if (!simple) for (int i = 0; i < 4; ++i) launch_upsample_planar_bwd(h->ddisp_full + (size_t)i * h->N * P, h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
-    launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, 1, 0, s);
-    KCHK();
-    return 0;
-}
-
 // loss value and its pullback in one pass (training): fills the loss, ddisp_lo[4], drvec, dtvec
 static int loss_train(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
-    static const bool split = getenv("MD2_LOSS_SPLIT") && atoi(getenv("MD2_LOSS_SPLIT")) != 0;       // cross-check: the separate forward and pullback kernels
-    if (split) { if (int r = loss_forward(h, x, disp, rvec, tvec, auto_loss, loss_out, simple)) return r; return loss_backward(h, x, disp, rvec, tvec, auto_loss, simple); }
     hipStream_t s = h->stream;
     HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)40 * h->N * sizeof(double), s));           // loss_part [16N] and dRt_acc [24N] are adjacent
     launch_pose_compose(rvec, tvec, h->Rt, h->N, 1, 0, s);

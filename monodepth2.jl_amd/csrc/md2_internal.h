@@ -65,7 +65,9 @@ struct ConvArgs {
     int oy0, ox0, ostep, Hl, Wl;
     // tap lattice: taps kh = kh0 + a*khs (a < nkh), kw = kw0 + b*kws (b < nkw)   (dense: 0,1,KH / 0,1,KW)
     int kh0, khs, nkh, kw0, kws, nkw;
-    int ksplit;                   // set by the launcher: >1 = the channel chunks are split over gridDim.y and summed with fp32 atomics
+    int ksplit;                   // set by the launcher: >1 = the channel chunks are split over gridDim.y; the partial sums go to ws[ksplit][M][Cout] and a second pass
+                                  // (splitk_reduce_kernel: + bias, activation, accumulate, BatchNorm statistics) writes y -- or, without a workspace, fp32 atomics into y
+    float* ws; long ws_cap;       // optional split-K workspace of the calling stream (floats); null = atomics
     // optional training-BatchNorm statistics of the OUTPUT (no bias / activation): stats[slot][0..Cout) += sum_pixels y, stats[slot][Cout..2Cout) += sum y^2,
     // slot = blockIdx.x % BN_STAT_SLOTS spreads the double atomics; fused into the 32x32 tiles' epilogue, a colstats launch (slot 0) otherwise
     double* stats;
@@ -194,8 +196,6 @@ void launch_loss_fwd(const LossArgs& a, double* part, double* blk, hipStream_t s
 int loss_blocks_per_image(const LossArgs& a);
 // totals[(scale*N+n)*4+..] float copy + scalar loss
 void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, float* loss, hipStream_t s);
-// backward: ddisp_full[scale][N][H][W] ; dRt partials -> dRt_acc double [2][N][12] (zeroed by caller)
-void launch_loss_bwd(const LossArgs& a, const float* totals, float* ddisp_full, double* dRt_acc, double* blk /* [nscales*N][blocks][24] or null */, hipStream_t s);
 // training: smoothness sums, then loss value + pullback from one pass over the warp.  part / dRt_acc zeroed by the caller; dd[sc] = [N][H][W] gradient wrt the
 // full-resolution disparity of scale sc, or -- where dlo[sc] is not null -- dlo[sc] = [N][dh][dw] (zeroed by the caller) receives the adjoint of the bilinear resize
 // of that gradient instead (float atomics); blk as above (needs >= max(N*tiles32*12, nscales*N*blocks*25) doubles)

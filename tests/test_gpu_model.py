@@ -430,7 +430,7 @@ def test_config4_resnet50_640x192_vs_oracle():
 def test_bf16_mixed_precision_tracks_the_fp32_oracle(cfgd):
     """BASELINE config #5's "bf16 mixed precision": only the MFMA operands are bf16 (8 mantissa bits), accumulation / activations /
     master weights / BatchNorm / loss / ADAM stay fp32.  Not a parity mode: the loss must stay within 2 % of the fp32 oracle and the
-    gradient must point the same way (cosine > 0.9 without the automask; measured 0.97 at 416x128, 0.91 at 1024x320); the fp32 mode on the same handle class stays at 1e-4 (the other tests)."""
+    gradient must point the same way (without the automask: cosine > 0.95 at 416x128, measured 0.97; > 0.85 at 1024x320, measured 0.90 .. 0.91); the fp32 mode on the same handle class stays at 1e-4 (the other tests)."""
     N, C, H, W, depth, automask = cfgd
     model, params, cache, theta, K, iK = make(N, C, H, W, automask=automask, pseed=61, depth=depth, precision="bf16")
     x = syn.synthetic_triplets(N, C, H, W, seed=62); xd = dev(x)
@@ -445,7 +445,7 @@ def test_bf16_mixed_precision_tracks_the_fp32_oracle(cfgd):
     # with the automask most pixels carry no gradient and the few mask / arg-min decisions that flip under the bf16 perturbation of the
     # disparities dominate the difference (measured 0.68 .. 0.81 from run to run: the atomics' summation order decides a few of them), without it the
     # directions agree to 0.97 at 416x128 and 0.91 at 1024x320
-    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > (0.6 if automask else 0.9)
+    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > (0.6 if automask else (0.95 if W <= 416 else 0.85))
     # and it trains: a few ADAM steps reduce the loss
     l0 = float(md().train_step(model, xd, al, cache, params, do_update=True))
     for _ in range(8):
