@@ -367,6 +367,89 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #pragma unroll
                 for (int e = 0; e < 4 * NV; ++e) acc[i][j][e] += acc2[i][j][e];
     }
+    // ---- epilogue of the one-tap (1x1) launches: their K loop is a handful of steps, so they live or die by how the output tile (and the residual / activation /
+    //      BatchNorm-input tensors read beside it) meets HBM.  The accumulators go through LDS once and come back transposed: 16 lanes own the 64 channels (256 B)
+    //      of one pixel, so every global access of a wave is four full 256-B rows instead of 64 scattered 16-B pieces.
+    if constexpr (NT == 1 && MF == 32 && TC == 1 && BN == 64 && WC == 2) {
+        constexpr int TLD = BN + 4;
+        __syncthreads();                                   // every wave is done with the operand stages
+        float* T = smem;
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int g = 0; g < NV; ++g)
+                *reinterpret_cast<float4*>(T + (wp * (BM / WP) + j * MF + (lane & 31)) * TLD + wc * 32 + 8 * g + 4 * (lane >> 5)) = make_float4(acc[0][j][4 * g], acc[0][j][4 * g + 1], acc[0][j][4 * g + 2], acc[0][j][4 * g + 3]);
+        __syncthreads();
+        const int q4 = (tid & 15) * 4, rr = tid >> 4, co = c0 + q4;
+        const bool want_st = a.stats != nullptr, want_b = BST != 0 && a.bst != nullptr && a.ksplit == 1;
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;       // statistics: (sum z, sum z^2) -- or the pullback sums (sum g, sum g*xhatA, sum g*xhatB)
+        float4 bias4 = s1, dsc = s1, dsh = s1, muA = s1, isA = s1, muB = s1, isB = s1;
+        if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + co);
+        if (a.dact_scale) { dsc = *reinterpret_cast<const float4*>(a.dact_scale + co); dsh = *reinterpret_cast<const float4*>(a.dact_shift + co); }
+        if (want_b) {
+            muA = *reinterpret_cast<const float4*>(a.bstat + co); isA = *reinterpret_cast<const float4*>(a.bstat + a.Cout + co);
+            if (a.bstB) { muB = *reinterpret_cast<const float4*>(a.bstatB + co); isB = *reinterpret_cast<const float4*>(a.bstatB + a.Cout + co); }
+        }
+#pragma unroll 2
+        for (int p = 0; p < BM / 16; ++p) {
+            const int pr = p * 16 + rr, m = m0 + pr;
+            if (m >= a.M) continue;
+            const int n = m / HlWl, r = m - n * HlWl, li = r / a.Wl, lj = r - li * a.Wl;
+            const int oy = a.oy0 + li * a.ostep, ox = a.ox0 + lj * a.ostep;
+            const long pix = (long)oy * a.Wo + ox;
+            float4 v = *reinterpret_cast<const float4*>(T + pr * TLD + q4);
+            if (a.res && (a.ksplit == 1 || blockIdx.y == 0)) { const float4 t = *reinterpret_cast<const float4*>(a.res + (long)n * a.res_bs + pix * a.res_ps + co); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.dact_src) {
+                d = *reinterpret_cast<const float4*>(a.dact_src + (long)n * a.da_bs + pix * a.da_ps + co);
+                if (a.dact_scale) { d.x = fmaf(d.x, dsc.x, dsh.x); d.y = fmaf(d.y, dsc.y, dsh.y); d.z = fmaf(d.z, dsc.z, dsh.z); d.w = fmaf(d.w, dsc.w, dsh.w); }
+            }
+            if (a.ksplit > 1) {                            // partial sum (see the register epilogue below)
+                if (a.dact_src) { v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact); }
+                if (a.ws) *reinterpret_cast<float4*>(a.ws + ((long)blockIdx.y * a.M + m) * a.Cout + co) = v;
+                else { float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co; atomicAdd(yp, v.x); atomicAdd(yp + 1, v.y); atomicAdd(yp + 2, v.z); atomicAdd(yp + 3, v.w); }
+                continue;
+            }
+            v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+            if (a.act != ACT_NONE) { v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act); }
+            if (a.dact_src) { v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact); }
+            float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co;
+            if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1) || (a.acc_lat && oy % a.acc_lat == 0 && ox % a.acc_lat == 0)) {
+                const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(yp) = v;
+            if (want_st) { s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
+            if constexpr (BST != 0) if (want_b) {
+                const float4 z = *reinterpret_cast<const float4*>(a.bz + (long)n * a.bz_bs + pix * a.bz_ps + co);
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x += v.x * ((z.x - muA.x) * isA.x); s2.y += v.y * ((z.y - muA.y) * isA.y); s2.z += v.z * ((z.z - muA.z) * isA.z); s2.w += v.w * ((z.w - muA.w) * isA.w);
+                if (a.bstB) {
+                    const float4 zb = *reinterpret_cast<const float4*>(a.bzB + (long)n * a.bzB_bs + pix * a.bzB_ps + co);
+                    s3.x += v.x * ((zb.x - muB.x) * isB.x); s3.y += v.y * ((zb.y - muB.y) * isB.y); s3.z += v.z * ((zb.z - muB.z) * isB.z); s3.w += v.w * ((zb.w - muB.w) * isB.w);
+                }
+            }
+        }
+        if (!(want_st || want_b)) return;                  // block-uniform
+        // column sums: the 16 threads that share a channel quad meet in LDS; thread (k, ch) then adds the block's total with one double atomic
+        __syncthreads();
+        float* R = smem;                                   // [3][4][256]
+        R[0 * 256 + tid] = s1.x; R[1 * 256 + tid] = s1.y; R[2 * 256 + tid] = s1.z; R[3 * 256 + tid] = s1.w;
+        R[1024 + 0 * 256 + tid] = s2.x; R[1024 + 1 * 256 + tid] = s2.y; R[1024 + 2 * 256 + tid] = s2.z; R[1024 + 3 * 256 + tid] = s2.w;
+        R[2048 + 0 * 256 + tid] = s3.x; R[2048 + 1 * 256 + tid] = s3.y; R[2048 + 2 * 256 + tid] = s3.z; R[2048 + 3 * 256 + tid] = s3.w;
+        __syncthreads();
+        if (tid < 192) {
+            const int k = tid >> 6, ch = tid & 63, qq = ch >> 2, e = ch & 3;
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sum += R[k * 1024 + e * 256 + g * 16 + qq];
+            const size_t slot = (size_t)(block_x % BN_STAT_SLOTS) * 2 * a.Cout;
+            if (want_st) { if (k < 2) atomicAdd(a.stats + slot + k * a.Cout + c0 + ch, (double)sum); }
+            else if (k == 0) { atomicAdd(a.bst + slot + c0 + ch, (double)sum); if (a.bstB) atomicAdd(a.bstB + slot + c0 + ch, (double)sum); }
+            else if (k == 1) atomicAdd(a.bst + slot + a.Cout + c0 + ch, (double)sum);
+            else if (a.bstB) atomicAdd(a.bstB + slot + a.Cout + c0 + ch, (double)sum);
+        }
+        return;
+    }
     // epilogue: every (tile, register group) is 4 consecutive channels of one pixel -> one 16-B NHWC store
     //   16x16x4: D col = lane&15 (pixel), row = 4*(lane>>4) + e (channel)
     //   32x32x2: D col = lane&31 (pixel), row = 8*g + 4*(lane>>5) + e, register 4g+e
@@ -419,7 +502,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
                 }
                 if (dp) { v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
-                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1) || (a.acc_lat && (a.oy0 + li * a.ostep) % a.acc_lat == 0 && (a.ox0 + lj * a.ostep) % a.acc_lat == 0)) {
+                    const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                }
                 *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
                 if constexpr (DO_BST) {
                     if (want_bst) {            // g = the final value just stored; xhat from the BatchNorm input(s) this gradient flows back into
@@ -465,11 +550,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     }
 }
 
+// three pipeline stages of (pixel tile + weight tile) rows; the one-tap launches reuse it for their transposed output tile [BM][BN + 4] (or [3][4][256] column sums)
+constexpr int igemm_smem_floats(int BM, int BN, int BF) {
+    const int pipe = 3 * (BM + BN) * (BF == 0 ? LDK : 12), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
+    return pipe > tile ? pipe : tile;
+}
 // (the 128x64 tile runs 3 blocks per CU -- its 46 KB of LDS allow no more -- which needs <= 168 registers incl. the 32 accumulators: the variants with the input
 //  transform / the pullback sums must not fall to 2)
 template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0, int XF = 0, int BST = 0>
 __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (XF || BST)) ? 3 : 1) void conv_igemm_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * (BF == 0 ? LDK : 12)];
+    __shared__ __attribute__((aligned(16))) float smem[igemm_smem_floats(BM, BN, BF)];
     conv_igemm_body<BM, BN, WP, WC, MF, NT, BF, XF, BST>(a, smem, blockIdx.x, gridDim.x);
 }
 // The residue classes of a stride-2 input gradient (1, 2, 2 and 4 taps, a quarter of the output pixels each) in ONE launch: a block
@@ -478,7 +568,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BN == 64 && (XF || BST)) ? 3 : 1
 struct ConvClasses { ConvArgs c[4]; int first[5]; };      // blocks [first[i], first[i+1]) belong to class i
 template <int BM, int BN, int WP, int WC, int MF, int BF = 0, int BST = 0>
 __global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_classes_kernel(ConvClasses k) {
-    __shared__ __attribute__((aligned(16))) float smem[3 * (BM + BN) * (BF == 0 ? LDK : 12)];
+    __shared__ __attribute__((aligned(16))) float smem[igemm_smem_floats(BM, BN, BF)];
     const int b = blockIdx.x;
     const int cls = b < k.first[1] ? 0 : (b < k.first[2] ? 1 : (b < k.first[3] ? 2 : 3));
     const int bx = b - k.first[cls], nb = k.first[cls + 1] - k.first[cls];
@@ -492,7 +582,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_cl
 // split-K second pass: y = act(sum_k ws[k] + bias) [+ y]; with `stats` also the BatchNorm statistics of the (linear, bias-free) result.
 // block = 256 threads = RG row groups x Q channel quads (the colstats layout); ws rows are dense [ksplit][M][C], y is addressed through its strides.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int M, int C, float* __restrict__ y, long y_bs, int y_ps, int HW,
-                                                            const float* __restrict__ bias, int act, int accumulate, double* __restrict__ stats, int rows_per_block) {
+                                                            const float* __restrict__ bias, int act, int accumulate, int acc_lat, int Wo, double* __restrict__ stats, int rows_per_block) {
     const int Qall = C / 4, qoff = blockIdx.y * 256, Q = min(Qall - qoff, 256), RG = 256 / Q;
     const int q = qoff + threadIdx.x % Q, rg = threadIdx.x / Q;
     __shared__ float red[2 * 4 * 256];
@@ -509,7 +599,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             if (act != ACT_NONE) { v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act); }
             const int n = p / HW, r = p - n * HW;
             float* yp = y + (long)n * y_bs + (long)r * y_ps + q * 4;
-            if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1) || (acc_lat && (r / Wo) % acc_lat == 0 && (r % Wo) % acc_lat == 0)) {
+                const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
             *reinterpret_cast<float4*>(yp) = v;
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
             s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
@@ -533,7 +625,7 @@ static void launch_splitk_reduce(const ConvArgs& a, const float* bias, int act, 
     const int Q = a.Cout / 4, RG = std::max(1, 256 / std::min(Q, 256));
     int rpb = (a.M + 511) / 512; rpb = std::max(RG, (rpb + RG - 1) / RG * RG);
     const dim3 grid((a.M + rpb - 1) / rpb, (Q + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, stats, rpb);
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, a.acc_lat, a.Wo, stats, rpb);
 }
 
 // BatchNorm-pullback sums that could not be fused into an epilogue (16-wide tiles, split-K, deterministic mode): one column pass over (g, z)
@@ -552,17 +644,20 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     const bool can_fuse = fuses_stats && !g_deterministic && a.ksplit == 1;
     if (a.stats && (!can_fuse || a.ostep != 1 || a.bias || a.act != ACT_NONE || a.accumulate || a.dact_src)) a.stats = nullptr;
     constexpr bool bst_tile = MF == 32 && BN == 64 && WP == 2;                 // the instantiations built with the BatchNorm-pullback sums in the epilogue (3x3 taps)
-    if (a.bst && !(can_fuse && bst_tile && a.nkh * a.nkw == 9 && !a.in_scale)) { a.bst = nullptr; a.bstB = nullptr; }
+    const int ntaps = a.nkh * a.nkw;
+    if (a.bst && !(can_fuse && bst_tile && (ntaps == 9 || ntaps == 1) && !a.in_scale)) { a.bst = nullptr; a.bstB = nullptr; }
     const int grid = ((a.M + BM - 1) / BM) * (a.Cout / BN);
     const dim3 g(grid, a.ksplit);
     if (a.in_scale) {                  // BatchNorm + ReLU of the producer folded into the loader: the encoder's second 3x3 convolutions (Cout % 64 == 0)
         if constexpr (MF == 32 && BN == 64 && WP == 2) {
-            if (a.nkh * a.nkw != 9) { fprintf(stderr, "md2: conv_igemm: the input transform is built for 3x3 convolutions\n"); abort(); }
-            if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 1, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 0, 1>), g, dim3(256), 0, s, a);
+            if (ntaps == 9) { if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 1, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 0, 1>), g, dim3(256), 0, s, a); }
+            else if (ntaps == 1) { if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, 1, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, 0, 1>), g, dim3(256), 0, s, a); }
+            else { fprintf(stderr, "md2: conv_igemm: the input transform is built for 3x3 and 1x1 convolutions\n"); abort(); }
         } else { fprintf(stderr, "md2: conv_igemm: the input transform needs Cout %% 64 == 0\n"); abort(); }
     } else if (a.bst) {
         if constexpr (bst_tile) {
-            if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 1, 0, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 0, 0, 1>), g, dim3(256), 0, s, a);
+            if (ntaps == 9) { if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 1, 0, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 0, 0, 1>), g, dim3(256), 0, s, a); }
+            else { if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, 1, 0, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, 0, 0, 1>), g, dim3(256), 0, s, a); }
         }
     } else
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
@@ -891,7 +986,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 // REFLECT / FAST are compile-time so that the steady-state loop is ONE basic block (uniform branches would split it and the ~180
 // address/carry VALU instructions of the loader would run ahead of, instead of between, the 32 MFMAs of a step)
-template <int T, int BKP, int MF, bool REFLECT, bool FAST>
+template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {
     // LDS tiles [pixel][channel]: A operand lane (row = channel, k = pixel) reads consecutive channels of one pixel row.
     // 32x32x2: the two 32-lane halves are separate ds_read_b32 groups -> conflict-free for any row length.
@@ -927,6 +1022,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
     // exact floor(m / d) for 0 <= m < 2^24 from the float reciprocal (+-1 correction): integer division costs ~40 VALU ops, this ~8
     auto fdiv = [](int m, int d, float rcp) { int qq = (int)((float)m * rcp); const int r = m - qq * d; qq += (r >= d) ? 1 : 0; qq -= (r < 0) ? 1 : 0; return qq; };
     float4 rd[NLD], rx[NLD];
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (XF) { const int lc = (tid % LPP) * 4; xsc = *reinterpret_cast<const float4*>(a.in_scale + i0 + lc); xsh = *reinterpret_cast<const float4*>(a.in_shift + i0 + lc); }   // 256 % LPP == 0: one channel quad per thread
     // Per-load pixel state (n, oh, ow, m), advanced incrementally: consecutive loads of one slot are BKP pixels apart, so the
     // (n, oh, ow) split is a carry update (a few VALU ops) instead of two divisions per load per step.
     int p_m[NLD], p_n[NLD], p_oh[NLD], p_ow[NLD];
@@ -953,6 +1050,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
             const uint4 vx = *reinterpret_cast<const uint4*>(a.x + (long)n * a.x_bs + ((long)ih * a.W + iw) * a.x_ps + i0 + lc);
             const unsigned md = in ? 0xFFFFFFFFu : 0u, mx = ok ? 0xFFFFFFFFu : 0u;       // integer masks keep the loop branch-free
             rd[j] = make_float4(__uint_as_float(vd.x & md), __uint_as_float(vd.y & md), __uint_as_float(vd.z & md), __uint_as_float(vd.w & md));
+            if constexpr (XF) {
+                const float tx = fmaxf(fmaf(__uint_as_float(vx.x), xsc.x, xsh.x), 0.f), ty = fmaxf(fmaf(__uint_as_float(vx.y), xsc.y, xsh.y), 0.f);
+                const float tz = fmaxf(fmaf(__uint_as_float(vx.z), xsc.z, xsh.z), 0.f), tw = fmaxf(fmaf(__uint_as_float(vx.w), xsc.w, xsh.w), 0.f);
+                rx[j] = make_float4(__uint_as_float(__float_as_uint(tx) & mx), __uint_as_float(__float_as_uint(ty) & mx), __uint_as_float(__float_as_uint(tz) & mx), __uint_as_float(__float_as_uint(tw) & mx));
+            } else
             rx[j] = make_float4(__uint_as_float(vx.x & mx), __uint_as_float(vx.y & mx), __uint_as_float(vx.z & mx), __uint_as_float(vx.w & mx));
             // advance; positions past the end stay clamped to a valid pixel (their loads are masked by `in`)
             p_m[j] += BKP;
@@ -1094,6 +1196,14 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     const int sps = (steps_total + splitk - 1) / splitk;
     splitk = (steps_total + sps - 1) / sps;
     const dim3 g(tiles * taps * splitk);
+    if (a.in_scale) {
+        if constexpr (T >= 64) {
+            if (refl) { fprintf(stderr, "md2: conv_wgrad: the input transform is for zero-padded convolutions\n"); abort(); }
+            if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            return;
+        } else { fprintf(stderr, "md2: conv_wgrad: the input transform needs channel counts that are multiples of 64\n"); abort(); }
+    }
     if (fast && refl) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
     else if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
     else if (refl) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, true, false>), g, dim3(256), 0, s, a, sps, steps_total);
@@ -1445,7 +1555,9 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
         abort();
     }
     static const int max_t = getenv("MD2_WGRAD_MAXT") ? atoi(getenv("MD2_WGRAD_MAXT")) : 128;
-    if (a.in_scale && !wgrad_taps32_eligible(a)) { fprintf(stderr, "md2: conv_wgrad: the input transform is built into the all-taps kernel only (3x3, stride 1, channels %% 32 == 0)\n"); abort(); }
+    if (a.in_scale && !wgrad_taps32_eligible(a) && !(a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.padmode != PAD_REFLECT)) {
+        fprintf(stderr, "md2: conv_wgrad: the input transform is built into the all-taps kernel (3x3, stride 1) and the 64- / 128-wide tile kernels only\n"); abort();
+    }
     if (g_deterministic && a.db && (wgrad_taps32_eligible(a) || wgrad_patch_eligible(a))) {      // the fused bias gradient adds one atomic per wave: use the ordered column sum
         View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s);
         WgradArgs b = a; b.db = nullptr;

@@ -188,8 +188,10 @@ static void plan_buffers(md2_handle* h) {
             B.a1 = B.fuse ? make_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co);      // fused: never materialised (the view only carries the shape)
         } else {
             const int pl = B.c1.cout, co = B.c3.cout;
-            B.z1 = h->alloc_view(NL, hi, wi, pl); B.a1 = h->alloc_view(NL, hi, wi, pl);
-            B.z2 = h->alloc_view(NL, hh, ww, pl); B.a2 = h->alloc_view(NL, hh, ww, pl); B.z3 = h->alloc_view(NL, hh, ww, co);
+            static const bool no_fuse = getenv("MD2_NO_BN_FUSE") != nullptr;
+            B.fuse = !no_fuse;                // 1x1 and 3x3 loaders (forward and weight gradient) all take the BatchNorm + ReLU transform at these channel counts (multiples of 64)
+            B.z1 = h->alloc_view(NL, hi, wi, pl); B.a1 = B.fuse ? make_view(nullptr, NL, hi, wi, pl) : h->alloc_view(NL, hi, wi, pl);
+            B.z2 = h->alloc_view(NL, hh, ww, pl); B.a2 = B.fuse ? make_view(nullptr, NL, hh, ww, pl) : h->alloc_view(NL, hh, ww, pl); B.z3 = h->alloc_view(NL, hh, ww, co);
         }
         const int co = B.bottleneck ? B.c3.cout : B.c1.cout;
         if (B.down) { B.zd = h->alloc_view(NL, hh, ww, co); B.sd = B.fuse ? make_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co); }
@@ -406,10 +408,17 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
                 run_igemm(h, a);
             }
             bn_stats(h, B.b2, B.z2);
-            if (B.down) {                 // out = relu(bn2(z2) + bnd(zd)): the shortcut's BatchNorm output is never written
+            if (B.bottleneck) {           // ... and the 1x1 conv3 gathers relu(bn2(z2)) from z2
+                ConvArgs a = conv_args(B.z2, h->P + B.c3.w, B.z3, B.c3.k, B.c3.stride, B.c3.pad, 1, PAD_ZERO);
+                a.in_scale = B.b2.stats + 2 * B.b2.c; a.in_shift = B.b2.stats + 3 * B.b2.c; a.stats = h->testmode ? nullptr : B.b3.acc;
+                run_igemm(h, a);
+                bn_stats(h, B.b3, B.z3);
+            }
+            const BNL& bo = B.bottleneck ? B.b3 : B.b2; const View& zo = B.bottleneck ? B.z3 : B.z2;
+            if (B.down) {                 // out = relu(bn(z) + bnd(zd)): the shortcut's BatchNorm output is never written
                 conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc); bn_stats(h, B.bd, B.zd);
-                launch_bn_apply(B.z2, B.b2.stats, h->P + B.b2.g, h->P + B.b2.b, &B.zd, ACT_RELU, B.out, s, B.bd.stats, h->P + B.bd.g, h->P + B.bd.b);
-            } else launch_bn_apply(B.z2, B.b2.stats, h->P + B.b2.g, h->P + B.b2.b, &B.in, ACT_RELU, B.out, s);
+                launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.zd, ACT_RELU, B.out, s, B.bd.stats, h->P + B.bd.g, h->P + B.bd.b);
+            } else launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.in, ACT_RELU, B.out, s);
             continue;
         }
         conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_fwd(h, B.b1, B.z1, nullptr, ACT_RELU, B.a1);
@@ -591,6 +600,16 @@ static int model_backward(md2_handle* h) {
         // the launch that completes Gin also reduces the BatchNorm-pullback sums of the block below (bn2 / bn3 and, for a down-sampling block, the shortcut's BatchNorm)
         Block* Bp = (i > 0 && h->blk[i - 1].fuse) ? &h->blk[i - 1] : nullptr;
         if (B.fuse) {
+            if (B.bottleneck) {
+                View da2 = make_view(h->E3, NL, B.a2.H, B.a2.W, B.a2.C);
+                bn_bwd(h, B.b3, Gout, B.z3, B.dz3, sums_ready[i]);
+                conv_wgrad(h, B.c3, B.z2, B.dz3, PAD_ZERO, &B.b2);           // x = relu(bn2(z2)) formed in the loader
+                ConvArgs a = dgrad_args(h, B.c3, B.dz3, da2, 0, 0, &B.z2, ACT_RELU);       // da2 = (W3^T dz3) * relu'(bn2(z2)) + the sums of bn2's pullback
+                a.dact_scale = B.b2.stats + 2 * B.b2.c; a.dact_shift = B.b2.stats + 3 * B.b2.c;
+                want_bn_sums(a, B.b2, B.z2);
+                run_igemm(h, a);
+                bn_bwd(h, B.b2, da2, B.z2, B.dz2, true);
+            } else
             bn_bwd(h, B.b2, Gout, B.z2, B.dz2, sums_ready[i]);
             conv_wgrad(h, B.c2, B.z1, B.dz2, PAD_ZERO, &B.b1);               // x = relu(bn1(z1)) formed in the loader
             {   // da1 = (W2^T dz2) * relu'(bn1(z1)), and the sums of bn1's pullback from the same epilogue
@@ -608,8 +627,8 @@ static int model_backward(md2_handle* h) {
                 run_igemm(h, ad);
             }
             ConvArgs a = dgrad_args(h, B.c1, dz1, *Gin, B.c1.pad, first_mode, in_act, ACT_RELU, B.down ? nullptr : &Gout);
-            if (B.down) a.accumulate_c00 = 1;
-            if (Bp) { want_bn_sums(a, Bp->b2, Bp->z2, Bp->down ? &Bp->bd : nullptr, Bp->down ? &Bp->zd : nullptr); sums_ready[i - 1] = true; }
+            if (B.down) { if (B.bottleneck) a.acc_lat = B.cd.stride; else a.accumulate_c00 = 1; }      // (the bottleneck's conv1 is a dense 1x1: it adds on the shortcut's pixel lattice)
+            if (Bp) { want_bn_sums(a, Bp->bottleneck ? Bp->b3 : Bp->b2, Bp->bottleneck ? Bp->z3 : Bp->z2, Bp->down ? &Bp->bd : nullptr, Bp->down ? &Bp->zd : nullptr); sums_ready[i - 1] = true; }
             run_igemm(h, a);
         } else {
         if (!B.bottleneck) {
@@ -637,7 +656,7 @@ static int model_backward(md2_handle* h) {
         {
             ConvArgs a = dgrad_args(h, B.c1, dz1, *Gin, B.c1.pad, first_mode, in_act, ACT_RELU, B.down ? nullptr : &Gout);
             if (B.down && Bp) a.accumulate_c00 = 1;
-            if (Bp) { want_bn_sums(a, Bp->b2, Bp->z2, Bp->down ? &Bp->bd : nullptr, Bp->down ? &Bp->zd : nullptr); sums_ready[i - 1] = true; }
+            if (Bp) { want_bn_sums(a, Bp->bottleneck ? Bp->b3 : Bp->b2, Bp->bottleneck ? Bp->z3 : Bp->z2, Bp->down ? &Bp->bd : nullptr, Bp->down ? &Bp->zd : nullptr); sums_ready[i - 1] = true; }
             run_igemm(h, a);
         }
         if (B.down && !Bp) conv_dgrad(h, B.cd, B.dzd, *Gin, 0, 1, in_act, ACT_RELU);

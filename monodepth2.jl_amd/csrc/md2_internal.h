@@ -87,6 +87,9 @@ struct ConvArgs {
     // stride-2 input gradient split into residue classes: accumulate mode of class (0,0) if >= 0 (the 1x1 shortcut's input gradient wrote exactly those pixels first);
     // skip_empty: residue classes without a tap are left untouched instead of refusing a non-accumulating launch
     int accumulate_c00, skip_empty;
+    // dense launch: output pixels on the lattice (oy % acc_lat == 0 && ox % acc_lat == 0) ADD to y whatever `accumulate` says (a strided 1x1 shortcut's input gradient
+    // wrote exactly those pixels first); 0 = off
+    int acc_lat;
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only
 #endif
