@@ -663,8 +663,8 @@ def _hip_and_oracle_grads(N, C, H, W, sd, depth=18, automask=False):
     return loss, gh, theta, x, (host(al) if automask else None), K, iK
 
 
-@pytest.mark.parametrize("case", [(1, 1, 64, 96, 100, False), (2, 1, 64, 96, 41, False), (2, 3, 64, 96, 102, True), (3, 1, 96, 160, 106, False), (5, 3, 64, 64, 21, False),
-                                  (1, 1, 64, 256, 203, False), (2, 3, 64, 256, 202, False)])
+@pytest.mark.parametrize("case", [(1, 1, 64, 96, 101, False), (2, 1, 64, 96, 109, False), (2, 3, 64, 96, 100, True), (3, 1, 96, 160, 107, False), (5, 3, 64, 64, 109, False),
+                                  (1, 1, 64, 256, 108, False), (2, 3, 64, 256, 104, False)])
 def test_gradient_parity_tight_on_kink_free_seeds(case):
     """Inputs on which no ReLU / max-pool / arg-min / clamp decision differs between the HIP and the oracle arithmetic (found with tools/seed_scan.py): there EVERY
     parameter array must agree with the oracle to 4e-3 relative, cosine >= 0.9999 (measured 2e-5 .. 2e-3) -- C = 1 and 3, automask on / off, batch 1 .. 5, a
