@@ -581,14 +581,18 @@ __global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_cl
 
 // split-K second pass: y = act(sum_k ws[k] + bias) [+ y]; with `stats` also the BatchNorm statistics of the (linear, bias-free) result.
 // block = 256 threads = RG row groups x Q channel quads (the colstats layout); ws rows are dense [ksplit][M][C], y is addressed through its strides.
+struct SplitkBst { double* acc; const float* z; long z_bs; int z_ps; const float* stat; };       // BatchNorm-pullback sums of the final gradient: acc = sum g | sum g*xhat, xhat from (z, mean | invstd)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int M, int C, float* __restrict__ y, long y_bs, int y_ps, int HW,
-                                                            const float* __restrict__ bias, int act, int accumulate, int acc_lat, int Wo, double* __restrict__ stats, int rows_per_block) {
+                                                            const float* __restrict__ bias, int act, int accumulate, int acc_lat, int Wo, double* __restrict__ stats, int rows_per_block, SplitkBst bA, SplitkBst bB) {
     const int Qall = C / 4, qoff = blockIdx.y * 256, Q = min(Qall - qoff, 256), RG = 256 / Q;
     const int q = qoff + threadIdx.x % Q, rg = threadIdx.x / Q;
     __shared__ float red[2 * 4 * 256];
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;
     const int p0 = blockIdx.x * rows_per_block, p1 = min(p0 + rows_per_block, M);
     const float4 b = bias ? *reinterpret_cast<const float4*>(bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 muA = s1, isA = s1, muB = s1, isB = s1;
+    if (bA.acc && rg < RG) { muA = *reinterpret_cast<const float4*>(bA.stat + q * 4); isA = *reinterpret_cast<const float4*>(bA.stat + C + q * 4); }
+    if (bB.acc && rg < RG) { muB = *reinterpret_cast<const float4*>(bB.stat + q * 4); isB = *reinterpret_cast<const float4*>(bB.stat + C + q * 4); }
     const long slice = (long)M * C;
     if (rg < RG)
         for (int p = p0 + rg; p < p1; p += RG) {
@@ -604,8 +608,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             }
             *reinterpret_cast<float4*>(yp) = v;
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+            if (bA.acc) {
+                const float4 z = *reinterpret_cast<const float4*>(bA.z + (long)n * bA.z_bs + (long)r * bA.z_ps + q * 4);
+                s2.x += v.x * ((z.x - muA.x) * isA.x); s2.y += v.y * ((z.y - muA.y) * isA.y); s2.z += v.z * ((z.z - muA.z) * isA.z); s2.w += v.w * ((z.w - muA.w) * isA.w);
+                if (bB.acc) {
+                    const float4 zb = *reinterpret_cast<const float4*>(bB.z + (long)n * bB.z_bs + (long)r * bB.z_ps + q * 4);
+                    s3.x += v.x * ((zb.x - muB.x) * isB.x); s3.y += v.y * ((zb.y - muB.y) * isB.y); s3.z += v.z * ((zb.z - muB.z) * isB.z); s3.w += v.w * ((zb.w - muB.w) * isB.w);
+                }
+            } else { s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
         }
+    if (bA.acc) {                 // pullback sums: sum g shared, sum g*xhat per BatchNorm
+        float* r1 = red; float* r2 = red + 4 * 256;
+        for (int pass = 0; pass < (bB.acc ? 2 : 1); ++pass) {
+            const float4 t2 = pass ? s3 : s2; double* dst = (pass ? bB.acc : bA.acc) + (size_t)(blockIdx.x % BN_STAT_SLOTS) * 2 * C;
+            if (pass) __syncthreads();
+            r1[0 * 256 + threadIdx.x] = s1.x; r1[1 * 256 + threadIdx.x] = s1.y; r1[2 * 256 + threadIdx.x] = s1.z; r1[3 * 256 + threadIdx.x] = s1.w;
+            r2[0 * 256 + threadIdx.x] = t2.x; r2[1 * 256 + threadIdx.x] = t2.y; r2[2 * 256 + threadIdx.x] = t2.z; r2[3 * 256 + threadIdx.x] = t2.w;
+            __syncthreads();
+            for (int c = threadIdx.x; c < 2 * 4 * Q; c += 256) {
+                const int which = c / (4 * Q), ch = c % (4 * Q), qq = ch / 4, e = ch % 4;
+                const float* rr = which ? r2 : r1;
+                float sum = 0.f;
+                for (int g = 0; g < RG; ++g) sum += rr[e * 256 + g * Q + qq];
+                atomicAdd(dst + which * C + qoff * 4 + ch, (double)sum);
+            }
+        }
+        return;
+    }
     if (!stats) return;
     float* r1 = red; float* r2 = red + 4 * 256;
     r1[0 * 256 + threadIdx.x] = s1.x; r1[1 * 256 + threadIdx.x] = s1.y; r1[2 * 256 + threadIdx.x] = s1.z; r1[3 * 256 + threadIdx.x] = s1.w;
@@ -621,11 +650,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 static bool splitk_ws_shape_ok(int C) { const int Q = C / 4; return C % 64 == 0 && (Q <= 256 ? 256 % Q == 0 : Q % 256 == 0); }
-static void launch_splitk_reduce(const ConvArgs& a, const float* bias, int act, int accumulate, double* stats, hipStream_t s) {
+static void launch_splitk_reduce(const ConvArgs& a, const float* bias, int act, int accumulate, double* stats, bool with_bst, hipStream_t s) {
     const int Q = a.Cout / 4, RG = std::max(1, 256 / std::min(Q, 256));
     int rpb = (a.M + 511) / 512; rpb = std::max(RG, (rpb + RG - 1) / RG * RG);
     const dim3 grid((a.M + rpb - 1) / rpb, (Q + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, a.acc_lat, a.Wo, stats, rpb);
+    SplitkBst bA{}, bB{};
+    if (with_bst && a.bst) { bA.acc = a.bst; bA.z = a.bz; bA.z_bs = a.bz_bs; bA.z_ps = a.bz_ps; bA.stat = a.bstat; if (a.bstB) { bB.acc = a.bstB; bB.z = a.bzB; bB.z_bs = a.bzB_bs; bB.z_ps = a.bzB_ps; bB.stat = a.bstatB; } }
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, a.acc_lat, a.Wo, stats, rpb, bA, bB);
 }
 
 // BatchNorm-pullback sums that could not be fused into an epilogue (16-wide tiles, split-K, deterministic mode): one column pass over (g, z)
@@ -976,9 +1007,9 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
-    if (a.ksplit > 1 && a.ws) launch_splitk_reduce(a, bias2, act2, acc2, ws_stats, s);
+    if (a.ksplit > 1 && a.ws) launch_splitk_reduce(a, bias2, act2, acc2, ws_stats, a.ostep == 1, s);      // (also the BatchNorm-pullback sums of the now final gradient)
     else if (a.ksplit > 1 && (bias2 || act2 != ACT_NONE)) launch_bias_act_view(yv, bias2, act2, s);
-    if (a.ksplit > 1 && a.bst && a.ostep == 1) bst_fallback(a, s);                         // split-K: the gradient is final only after every K slice has been added
+    if (a.ksplit > 1 && !a.ws && a.bst && a.ostep == 1) bst_fallback(a, s);                         // split-K: the gradient is final only after every K slice has been added
 }
 
 // ------------------------------------------------------------------------------------------------------------
