@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round-2 profile set, run on the GPU box from the repo root (tools/make_profiles.sh); raw output under gpurun_out/prof_final/, summaries by tools/profile_summary.py.
+# One rocprofv3 pass per purpose: kernel trace + stats (both stream modes, batch 32 and batch 4), then the two HBM counters in separate --pmc passes (never with other trace domains).
+set -e
+R=$PWD; O=$R/gpurun_out/prof_final; mkdir -p $O; export TMPDIR=/tmp
+cd /tmp
+MD2_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/one -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/one.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/two -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/two.log 2>&1
+MD2_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b4 -o t -- python3 $R/tools/prof_config.py 4 18 1 128 416 f32 10 > $O/b4.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/write.log 2>&1
+cd $R
+tail -1 $O/one.log | cut -c1-300; tail -1 $O/two.log | cut -c1-300; grep ms/step $O/b4.log
