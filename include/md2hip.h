@@ -69,7 +69,8 @@ int32_t md2_param_buffer(md2_handle* h, void** dev_ptr, int64_t* count);
 int32_t md2_model_forward(md2_handle* h, const float* x, float* disp0, float* disp1, float* disp2, float* disp3,
                           float* rvec, float* tvec);
 /* ---- train_loss forward (src/training.jl:21-78): model + loss.  auto_loss may be NULL.
- *      loss: device scalar.  Keeps activations for md2_backward. ------------------------------- */
+ *      loss: device scalar.  Keeps activations for md2_backward.  The loss kernel produces the loss value and its pullback
+ *      (d loss / d disparities, d loss / d poses) in the same pass over the warp, so md2_backward starts at the network. --- */
 int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, float* loss);
 /* ---- Zygote pullback of the last md2_train_loss into the gradient buffer --------------------- */
 int32_t md2_backward(md2_handle* h);
