@@ -32,6 +32,8 @@ namespace md2 {
 
 int g_deterministic = 0;
 
+__device__ float g_zero_row[16];          // what a direct-to-LDS load of a zero-padded (masked) row reads
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous range of logical ids.
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -48,6 +50,11 @@ constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
 #ifndef MD2_PF3
 #define MD2_PF3 0         // 1: the global loads run THREE steps ahead of the MFMAs (one step in flight in registers before they are written to LDS), not two.
                           // Measured (tools/conv_bench, round 2): 4 - 8 % SLOWER on the encoder shapes -- the loads' latency is already covered, what costs is their issue
+#endif
+#ifndef MD2_GLDS
+#define MD2_GLDS 0        // experiment: the plain fp32 variant stages both operand tiles with global_load_lds_dwordx4 (swizzled source address, unpadded 64-B rows, loads three
+                          // steps ahead with a counted vmcnt and a raw s_barrier) -- no VGPR round trip, no mask ANDs, no ds_write.  Correct (the layer tests pass with it) but
+                          // within +-1.5 % of the register-staged pipeline on all four encoder stage shapes at 5 blocks per CU (tools/conv_bench), with distance 2 as well
 #endif
 #ifndef MD2_LATE_MASK
 #define MD2_LATE_MASK 1   // 1: zero-padding masks are applied when the gathered rows go to LDS (after the step's MFMAs) instead of right after the global loads
@@ -92,7 +99,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     static_assert(WP * WC == 4 && TP >= 1 && TC >= 1 && A_LD >= 1, "bad tile");
     // LDS row of a tile: fp32 -> 16 k-values + 4 pad floats; bf16 mode -> the row is converted ONCE on its way into LDS: 16 bf16 (32 B)
     // padded to a 48-B stride that keeps 16 consecutive rows' 16-B reads on distinct banks
-    constexpr int ROWF = BF == 0 ? LDK : 12;
+    // DL (direct load): global_load_lds writes a wave's 64 x 16 B linearly, so the rows are 16 floats without padding and the bank spread comes from an XOR swizzle of the
+    // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
+    constexpr bool DL = MD2_GLDS != 0 && XF == 0 && BF == 0 && BN == 64;
+    constexpr int ROWF = BF == 0 ? (DL ? 16 : LDK) : 12;
     constexpr int XS = BM * ROWF, STAGE = (BM + BN) * ROWF;    // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,14 +123,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         a_ok[j] = m < a.M;
         const int mm = a_ok[j] ? m : 0;
         const int n = mm / HlWl, r = mm - n * HlWl, li = r / a.Wl, lj = r - li * a.Wl;
-        a_base[j] = ((unsigned)((long)n * a.x_bs) + q * 4) * 4u;      // BYTE offsets: one VGPR per address (SGPR base + 32-bit offset)
+        a_base[j] = ((unsigned)((long)n * a.x_bs) + (DL ? (q ^ ((tid >> 4) & 3)) : q) * 4) * 4u;      // BYTE offsets: one VGPR per address (SGPR base + 32-bit offset); DL: swizzled chunk
         a_ih[j] = (a.oy0 + li * a.ostep) * a.stride - a.pad;
         a_iw[j] = (a.ox0 + lj * a.ostep) * a.stride - a.pad;
     }
     // weights: row (c0 + f>>2), k runs linearly when the tap lattice is dense; per-tap base otherwise
     unsigned b_row[B_LD];
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) b_row[j] = ((unsigned)((c0 + (((tid + 256 * j) >> 2) & (BN - 1))) * Ktot) + q * 4) * 4u;
+    for (int j = 0; j < B_LD; ++j) b_row[j] = ((unsigned)((c0 + (((tid + 256 * j) >> 2) & (BN - 1))) * Ktot) + (DL ? (q ^ ((tid >> 4) & 3)) : q) * 4) * 4u;
 
     using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
     acc_t acc[TC][TP];
@@ -167,7 +177,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
             else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
             a_mbits[j] |= ok ? (1u << t) : 0u;
-            a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * 4u : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address
+            a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * 4u : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address (DL: g_zero_row instead)
         }
         b_tap[t] = (unsigned)((kh * a.KW + kw) * a.Cin) * 4u + (unsigned)(c_lo * 64);
     }
@@ -184,6 +194,22 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         }
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) rb[j] = *reinterpret_cast<const float4*>(wb + (b_row[j] + b_tap[t] + (unsigned)(ci0 * 4)));
+    };
+    // DL: one global_load_lds_dwordx4 per operand row slot; LDS destination = wave-uniform base + lane * 16 B = row (16 * wave + lane / 4 + 64 j), chunk lane % 4
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    auto gload_dl = [&](int t, int ci0, int so) {
+        if constexpr (DL) {
+            const char* zero = reinterpret_cast<const char*>(g_zero_row) + q * 16;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const char* src = ((a_mbits[j] >> t) & 1u) ? xb + (a_off[t][j] + (unsigned)(ci0 * 4)) : zero;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + so + (wave * 16 + 64 * j) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + (b_row[j] + b_tap[t] + (unsigned)(ci0 * 4))), (lds_ptr_t)(smem + so + XS + (wave * 16 + 64 * j) * 16), 16, 0, 0);
+        }
     };
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     auto put_bf = [&](float* row, const float4& v) {        // 4 k-values (chunk q) of one row -> 4 bf16
@@ -263,6 +289,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) o.x[j][pl] = *reinterpret_cast<const bf16x8*>(smem + so + (wp * (BM / WP) + j * MF + lrow) * ROWF + 8 * pl + lh);
             return;
+        } else if constexpr (DL) {
+            const int sw = (lrow >> 2) & 3;             // the tile offsets added to lrow are multiples of 16 rows: the swizzle depends on lrow alone
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) o.w[i][jj] = *reinterpret_cast<const f32x4*>(smem + so + XS + (wc * (BN / WC) + i * MF + lrow) * 16 + (((2 * jj + lk4 / 4) ^ sw) << 2));
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) o.x[j][jj] = *reinterpret_cast<const f32x4*>(smem + so + (wp * (BM / WP) + j * MF + lrow) * 16 + (((2 * jj + lk4 / 4) ^ sw) << 2));
         } else {
 #pragma unroll
         for (int i = 0; i < TC; ++i)
@@ -311,14 +347,30 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     int o0 = 0, o1 = STAGE, o2 = 2 * STAGE;
     Ops cur, nxt;
     xf_load(0);
+    if constexpr (DL) {
+        // three stages, loads THREE steps ahead: the tile of step s+3 is issued at the top of step s into the stage step s was read from, and only the loads issued
+        // one step earlier are waited for before the barrier (counted vmcnt, raw s_barrier) -- a global load has two MFMA clusters to land instead of one
+        gload_dl(0, 0, o0);                                  // (static tap indices: a runtime index into a_off[][] would put it in scratch)
+        if constexpr (NT >= 3) { gload_dl(1, 0, o1); gload_dl(2, 0, o2); }
+        else if constexpr (NT == 2) { gload_dl(1, 0, o1); gload_dl(0, min(1, cpt - 1) << 4, o2); }
+        else { gload_dl(0, min(1, cpt - 1) << 4, o1); gload_dl(0, min(2, cpt - 1) << 4, o2); }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD + B_LD) : "memory");      // steps 0 and 1 have landed, step 2 may still be in flight
+        __builtin_amdgcn_s_barrier();
+        read_ops(o0, cur);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // everybody has read stage 0 before step 0 re-targets it
+    } else {
     gload(0, 0); stage(); xf_apply(0); lstore(o0);
     { int t1, c1; step_tc(1, t1, c1); if (NT == 1) { gload(0, c1); stage(); xf_load(c1 >> 4); xf_apply(0); } else { gload(nsteps > 1 ? 1 : 0, 0); stage(); xf_apply(nsteps > 1 ? 1 : 0); } }
     lstore(o1);
+    }
     if constexpr (MD2_PF3 != 0) {               // step 2's loads go in flight before the loop; every loop step then stages the previous step's loads and issues the next
         if constexpr (NT >= 3) gload(2, 0); else if constexpr (NT == 2) gload(0, min(1, cpt - 1) << 4); else gload(0, min(2, cpt - 1) << 4);
     }
+    if constexpr (!DL) {
     __syncthreads();
     read_ops(o0, cur);
+    }
     for (int c = 0; c < cpt; ++c) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -331,16 +383,44 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             const int c3 = min(c + (t + 3) / NT, cpt - 1);
             const bool last3 = (c + (t + 3) / NT) > cpt - 1;
 #ifdef MD2_ABLATE
+            if constexpr (DL) {
+                if (!(abl & 1)) gload_dl(last3 ? NT - 1 : t3, c3 << 4, o0);
+                if (!(abl & 2)) read_ops(o1, nxt);
+                if (!(abl & 4)) mfmas(cur);
+                if (!(abl & 8)) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD + B_LD) : "memory"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                cur = nxt;
+                { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
+                continue;
+            }
             if (MD2_PF3) { stage(); if (!(abl & 1)) gload(last3 ? NT - 1 : t3, c3 << 4); }
             else { if (!(abl & 1)) gload(last2 ? NT - 1 : t2, c2 << 4); stage(); }
             if (!(abl & 2)) read_ops(o1, nxt);
             if (!(abl & 4)) mfmas(cur);
+            if (abl & 64) {                        // upper bound of a direct-to-LDS load path: the loads stay (kept alive), the mask / LDS-store work goes
+#pragma unroll
+                for (int j = 0; j < A_LD; ++j) asm volatile("" :: "v"(sa[j].x), "v"(sa[j].y), "v"(sa[j].z), "v"(sa[j].w));
+#pragma unroll
+                for (int j = 0; j < B_LD; ++j) asm volatile("" :: "v"(sb[j].x), "v"(sb[j].y), "v"(sb[j].z), "v"(sb[j].w));
+            } else
             if (!(abl & 2)) { xf_apply(last2 ? NT - 1 : t2); lstore(o2); }
             if (!(abl & 8)) __syncthreads();
             cur = nxt;
             { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
             continue;
 #endif
+            if constexpr (DL) {                     // step s+3's tiles go straight into the stage of step s (free since the last barrier)
+                gload_dl(last3 ? NT - 1 : t3, c3 << 4, o0);
+                read_ops(o1, nxt);
+                if (MD2_SETPRIO) __builtin_amdgcn_s_setprio(1);
+                mfmas(cur);
+                if (MD2_SETPRIO) __builtin_amdgcn_s_setprio(0);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD + B_LD) : "memory");          // step s+2's tiles (issued one step ago) have landed; step s+3's stay in flight
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                cur = nxt;
+                { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
+                continue;
+            }
             if (MD2_PF3) { stage(); gload(last3 ? NT - 1 : t3, c3 << 4); }          // sa/sb <- the loads issued one step ago (step s+2's data); step s+3's go in flight
             else { gload(last2 ? NT - 1 : t2, c2 << 4); stage(); }
             if (XF != 0 && (t + 2) % NT == 0) xf_load(c2);          // the data being staged enters a new channel chunk (tap 0 of chunk c2; c2 is clamped like the loads)
