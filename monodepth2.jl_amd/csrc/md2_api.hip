@@ -1029,7 +1029,12 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* b, float
     if (b) (void)hipMemcpyAsync(bi, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s);
     ConvArgs a = conv_args(xv, wi, yv, k, stride, p_eff, 1, pad_mode);
     a.bias = b ? bi : nullptr; a.act = act; a.stats = acc;          // stats: fused into the epilogue of the 32-wide tiles, a column-statistics pass otherwise
+    // a split-K workspace like a handle's, so that the op-level tests drive the same reduce pass (bias / activation / statistics) the training step uses on small maps
+    const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
+    float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
+    a.ws = ws; a.ws_cap = ws_cap;
     launch_conv_igemm(a, s);
+    (void)hipFreeAsync(ws, s);
     if (bn_mean) {
         launch_bn_finalize(acc, st, coutP, (double)yv.pixels(), BN_STAT_SLOTS, nullptr, 0.f, s);
         (void)hipMemcpyAsync(bn_mean, st, Cout * sizeof(float), hipMemcpyDeviceToDevice, s); (void)hipMemcpyAsync(bn_invstd, st + coutP, Cout * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -1069,7 +1074,11 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         View dxp = make_view(dxi, N, Hp, Wp, cinP);
         ConvArgs a = conv_args(dyv, wd, dxp, k, 1, k - 1 - (pad_mode == PAD_REFLECT ? 0 : pad), stride, PAD_ZERO);
         a.accumulate = 1;                                   // dxi is zero-initialised; strided pullbacks may have tap-free residue classes
+        const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
+        float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
+        a.ws = ws; a.ws_cap = ws_cap;
         launch_conv_igemm(a, s);
+        (void)hipFreeAsync(ws, s);
         if (pad_mode == PAD_REFLECT) {
             float* dxf = tmp_alloc((size_t)N * H * W * cinP, s); if (!dxf) return 3;
             View dv = make_view(dxf, N, H, W, cinP);

@@ -50,6 +50,11 @@ CONV_CASES = [
     # all-taps weight gradient (every 3x3 / stride-1 layer with Cin, Cout % 32 == 0): odd sizes -> partial tile rows, a masked last column
     (3, 32, 5, 9, 64, 3, 1, 1, "zeros"),          # Ho = 5: second tile row has one valid row; Wo = 9 -> TW = 10
     (2, 64, 7, 33, 32, 3, 1, 0, "reflect"),       # Wo = 33 -> two tiles of 18 columns, the second ragged; reflected halo
+    # one-tap launches (LDS-transposed epilogue) and split-K through the workspace (few tiles, long K loop)
+    (3, 256, 12, 20, 64, 1, 1, 0, "zeros"),       # ResNet-50 bottleneck conv1: 1x1, Cout 64
+    (48, 64, 24, 40, 256, 1, 1, 0, "zeros"),      # ... conv3: enough pixels for the 128-wide 1x1 tile; its input gradient contracts 256 channels into 64
+    (2, 1024, 3, 5, 512, 1, 1, 0, "zeros"),       # 1x1 with 64 K-steps on 30 pixels: split over the channel chunks
+    (1, 512, 4, 13, 512, 3, 1, 1, "zeros"),       # the 1/32-scale 3x3 at batch 1: 8 tiles, 288 K-steps -> split 8 ways
 ]
 
 
