@@ -347,7 +347,8 @@ struct LossTrainOut { double* part; float* dd[4]; float* dlo[4]; double* dRt_acc
 #endif
 template <int C, int TH>
 __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArgs a, LossTrainOut o, int tpb, int ntx) {
-    constexpr int VW = TW + 4, VH = TH + 4, OW = TW + 2, OH = TH + 2, SH = TH / 8, NSR = (OH + 2) / 3;
+    constexpr int OSH = C == 1 ? 3 : 2;          // window owners per thread in phase 2 (three colour channels keep 2 x 3 x OSH coefficient triples alive: two owners fit the registers)
+    constexpr int VW = TW + 4, VH = TH + 4, OW = TW + 2, OH = TH + 2, SH = TH / 8, NSR = (OH + OSH - 1) / OSH;
     __shared__ float wv[2][C][VH * VW];          // warped sources at the padded positions of tile + 2
     __shared__ float tg[C][VH * VW];
     __shared__ float dl[VH * VW];
@@ -436,17 +437,17 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
             for (int c = 0; c < C; ++c) tg[c][i] = tgt[(long)c * P + (long)py * W + px];
         }
         __syncthreads();
-        // ---- phase 2: window owners q in tile + 1, three vertically adjacent ones per thread
+        // ---- phase 2: window owners q in tile + 1, OSH vertically adjacent ones per thread
         for (int st = threadIdx.x; st < OW * NSR; st += 256) {
-            const int k3 = st / OW, rx = st - k3 * OW, ry0 = k3 * 3;
-            float pl[3][2], gmx[3][2][C], gpxx[3][2][C], gpxy[3][2][C];
+            const int k3 = st / OW, rx = st - k3 * OW, ry0 = k3 * OSH;
+            float pl[OSH][2], gmx[OSH][2][C], gpxx[OSH][2][C], gpxy[OSH][2][C];
 #pragma unroll
-            for (int oo = 0; oo < 3; ++oo) { pl[oo][0] = 0.f; pl[oo][1] = 0.f; }
+            for (int oo = 0; oo < OSH; ++oo) { pl[oo][0] = 0.f; pl[oo][1] = 0.f; }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                float Ry[5], Ryy[5], yc[5], Rx[2][5], Rxx[2][5], Rxy[2][5], xc[2][5];
+                float Ry[OSH + 2], Ryy[OSH + 2], yc[OSH + 2], Rx[2][OSH + 2], Rxx[2][OSH + 2], Rxy[2][OSH + 2], xc[2][OSH + 2];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
+                for (int j = 0; j < OSH + 2; ++j) {
                     const int b = min(ry0 + j, VH - 1) * VW + rx;       // rows past the value region belong to owners that are never stored
                     const float y0 = tg[c][b], y1 = tg[c][b + 1], y2 = tg[c][b + 2];
                     Ry[j] = y0 + y1 + y2; Ryy[j] = y0 * y0 + y1 * y1 + y2 * y2; yc[j] = y1;
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                     }
                 }
 #pragma unroll
-                for (int oo = 0; oo < 3; ++oo) {
+                for (int oo = 0; oo < OSH; ++oo) {
                     const float sy = Ry[oo] + Ry[oo + 1] + Ry[oo + 2], syy = Ryy[oo] + Ryy[oo + 1] + Ryy[oo + 2];
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                 }
             }
 #pragma unroll
-            for (int oo = 0; oo < 3; ++oo) {
+            for (int oo = 0; oo < OSH; ++oo) {
                 const int ry = ry0 + oo;
                 if (ry >= OH) break;
                 const int qi = ry * OW + rx, qy = ty0 - 1 + ry, qx = tx0 - 1 + rx;

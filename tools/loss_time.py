@@ -1,11 +1,11 @@
 """Times md2_loss_fwd_bwd (the loss half alone: smoothness sums + fused value-and-pullback kernel + finalize + pose pullback) on random disparities / poses.
-usage: python tools/loss_time.py N C  -- also the target of tools/pmc_kernel.sh for the loss-kernel counters in profiles/r02_loss_train_pmc.md"""
+usage: python tools/loss_time.py N C [H W]  -- also the target of tools/pmc_kernel.sh for the loss-kernel counters in profiles/r02_loss_train_pmc.md"""
 import sys, os, time
 sys.path[:0] = ["/root/repo", "/root/repo/tests", "/root/repo/oracle"]
 import numpy as np, torch
 import md2amd
 from test_gpu_model import make, dev, md, syn, host
-N, C, H, W = int(sys.argv[1]), int(sys.argv[2]), 128, 416
+N, C = int(sys.argv[1]), int(sys.argv[2]); H, W = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (128, 416)
 model, params, cache, theta, K, iK = make(N, C, H, W)
 x = syn.synthetic_triplets(N, C, H, W, seed=3); xd = dev(x); model._ensure(xd, params, cache)
 rng = np.random.default_rng(1)
