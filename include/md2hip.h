@@ -141,10 +141,17 @@ int32_t md2_profile_dump(md2_handle* h, const char* path);
 /* ---- op-level entry points (stateless; `stream` = hipStream_t or NULL), reference layout ------ */
 /* SSIM()(x, y), src/utils.jl:25-39.  [planes][H][W] */
 int32_t md2_ssim_fwd(const float* x, const float* y, float* out, int32_t planes, int32_t H, int32_t W, void* stream);
+/* ... and its pullback: dout [planes][H][W] -> dx, dy (either may be NULL).  With the other *_bwd entry points below this is what a ChainRulesCore.rrule of the
+ * L2 functions calls when Zygote stays in charge of the step (src/Monodepth.jl:170) instead of md2_train_step (monodepth2.jl_amd/julia/Monodepth2HIP.jl). */
+int32_t md2_ssim_bwd(const float* x, const float* y, const float* dout, float* dx, float* dy, int32_t planes, int32_t H, int32_t W, void* stream);
 /* photometric_loss(ssim, predicted, target), src/training.jl:1-7 -> [N][1][H][W] */
 int32_t md2_photometric_loss_fwd(const float* pred, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* pullback wrt `predicted` (the target is data): dout [N][1][H][W] -> dpred [N][C][H][W] */
+int32_t md2_photometric_loss_bwd(const float* pred, const float* target, const float* dout, float* dpred, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 /* prediction_loss(ssim, predictions, target), src/training.jl:13-15; preds [k][N][C][H][W] */
 int32_t md2_prediction_loss_fwd(const float* preds, int32_t k, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* pullback wrt the k predictions: the gradient of `minimum` goes to the first arg-min; dpreds [k][N][C][H][W] */
+int32_t md2_prediction_loss_bwd(const float* preds, int32_t k, const float* target, const float* dout, float* dpreds, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 /* disparity_to_depth, src/utils.jl:175-179 */
 int32_t md2_disparity_to_depth(const float* d, float* out, int64_t n, double min_depth, double max_depth, void* stream);
 /* Backproject(depth, invK), src/utils.jl:63-65: depth [N][P] -> [N][P][3] */
@@ -157,6 +164,9 @@ int32_t md2_grid_sample_bwd_grid(const float* in, const float* grid, const float
 /* fused disparity -> depth -> Backproject -> Project -> grid_sample(:border)  (src/training.jl:48-57) */
 int32_t md2_warp_fwd(const float* disp, const float* src, const float* K_dev, const float* invK_dev, const float* R, const float* t,
                      float* out, int32_t N, int32_t C, int32_t H, int32_t W, double min_depth, double max_depth, void* stream);
+/* pullback of md2_warp_fwd wrt the disparity and the pose (the source image is data): dout [N][C][H][W] -> ddisp [N][H][W], dR [N][9] (column-major), dt [N][3] */
+int32_t md2_warp_bwd(const float* disp, const float* src, const float* K_dev, const float* invK_dev, const float* R, const float* t, const float* dout,
+                     float* ddisp, float* dR, float* dt, int32_t N, int32_t C, int32_t H, int32_t W, double min_depth, double max_depth, void* stream);
 /* NNlib.upsample_bilinear(x; size), src/training.jl:45 */
 int32_t md2_upsample_bilinear_fwd(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, void* stream);
 int32_t md2_upsample_bilinear_bwd(const float* dout, float* dx, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, void* stream);
@@ -167,6 +177,11 @@ int32_t md2_so3_exp_map_bwd(const float* rvec, const float* dR, float* drvec, in
 int32_t md2_composeT(const float* rvec, const float* t, int32_t invert, float* R, float* tout, int32_t N, void* stream);
 /* smooth_loss(disparity, image), src/utils.jl:159-173 -> device scalar */
 int32_t md2_smooth_loss(const float* disp, const float* image, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* pullback wrt the disparity (the image is data): dloss = upstream scalar on the device -> ddisp [N][H][W] */
+int32_t md2_smooth_loss_bwd(const float* disp, const float* image, const float* dloss, float* ddisp, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* device memory for callers without an array package of their own ("device pointers it obtained from md2_alloc / md2_free") */
+int32_t md2_alloc(void** ptr, int64_t bytes);
+int32_t md2_free(void* ptr);
 /* Flux Conv (true convolution, weights (kW,kH,Cin,Cout)) on NCHW tensors through the MFMA implicit-GEMM kernels.
  * pad_mode 0 = zeros, 1 = reflect-pad(1) then valid conv (DecoderBlock, src/depth_decoder.jl:1-5); act: 0 none 1 relu 2 elu 3 sigmoid */
 int32_t md2_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W,

@@ -60,7 +60,14 @@ _SIGS = {
     "md2_profile_get": (I32, [P, I32, C.POINTER(F64), C.POINTER(I64), C.POINTER(F64), C.POINTER(F64)]),
     "md2_profile_dump": (I32, [P, C.c_char_p]),
     "md2_ssim_fwd": (I32, [P, P, P, I32, I32, I32, P]),
+    "md2_ssim_bwd": (I32, [P, P, P, P, P, I32, I32, I32, P]),
     "md2_photometric_loss_fwd": (I32, [P, P, P, I32, I32, I32, I32, P]),
+    "md2_photometric_loss_bwd": (I32, [P, P, P, P, I32, I32, I32, I32, P]),
+    "md2_prediction_loss_bwd": (I32, [P, I32, P, P, P, I32, I32, I32, I32, P]),
+    "md2_warp_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, F64, F64, P]),
+    "md2_smooth_loss_bwd": (I32, [P, P, P, P, I32, I32, I32, I32, P]),
+    "md2_alloc": (I32, [P, I64]),
+    "md2_free": (I32, [P]),
     "md2_prediction_loss_fwd": (I32, [P, I32, P, P, I32, I32, I32, I32, P]),
     "md2_disparity_to_depth": (I32, [P, P, I64, F64, F64, P]),
     "md2_backproject": (I32, [P, P, P, I32, I32, I32, P]),

@@ -912,6 +912,152 @@ __global__ void op_smooth_kernel(const float* __restrict__ d, const float* __res
 }
 __global__ void op_smooth_final(const double* __restrict__ part, float* __restrict__ out, double cntx, double cnty) { if (threadIdx.x == 0 && blockIdx.x == 0) *out = (float)(part[0] / cntx + part[1] / cnty); }
 
+// ---- op-level pullbacks (reference layout): what a ChainRules `rrule` of the L2 functions calls when Zygote stays in charge of the step --------------------------
+// d out / d x of SSIM (and of photometric_loss: scale_ssim = alpha / C, scale_l1 = (1 - alpha) / C), gather form: pixel p collects from every window q that holds one of
+// its pad_reflect aliases u.  x / y: [planes][H][W]; dout: [planes / cd][H][W] (cd = 1: one map per plane; cd = C: one map per sample, shared by its channels);
+// win / wj (optional): only pixels q with win[q] == wj pass their dout (the arg-min of prediction_loss)
+__global__ void op_ssim_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dout, float* __restrict__ dx, int planes, int cd, int H, int W,
+                                   float scale_ssim, float scale_l1, const float* __restrict__ win, float wj) {
+    FOR1D(i, (long)planes * H * W) {
+        const int w = i % W; const long t = i / W; const int h = t % H; const long pl = t / H;
+        const float* xp = x + pl * H * W; const float* yp = y + pl * H * W;
+        const long dbase = (pl / cd) * (long)H * W;
+        const float xv = xp[(long)h * W + w], yv = yp[(long)h * W + w];
+        int uys[3], uxs[3], ny = 0, nx = 0;
+        uys[ny++] = h; if (h == 1) uys[ny++] = -1; if (h == H - 2) uys[ny++] = H;
+        uxs[nx++] = w; if (w == 1) uxs[nx++] = -1; if (w == W - 2) uxs[nx++] = W;
+        float g = 0.f;
+        for (int iy = 0; iy < ny; ++iy)
+            for (int ix = 0; ix < nx; ++ix)
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const int qy = uys[iy] + dy; if (qy < 0 || qy >= H) continue;
+                    for (int dxx = -1; dxx <= 1; ++dxx) {
+                        const int qx = uxs[ix] + dxx; if (qx < 0 || qx >= W) continue;
+                        const long qo = (long)qy * W + qx;
+                        float d = dout[dbase + qo];
+                        if (win && win[dbase + qo] != wj) d = 0.f;
+                        if (d == 0.f) continue;
+                        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+                        for (int a = -1; a <= 1; ++a)
+                            for (int b = -1; b <= 1; ++b) {
+                                const int o = refl_idx(qy + a, H) * W + refl_idx(qx + b, W);
+                                const float xa = xp[o], ya = yp[o];
+                                sx += xa; sy += ya; sxx += xa * xa; syy += ya * ya; sxy += xa * ya;
+                            }
+                        SsimOut so; ssim_from_sums(sx, sy, sxx, syy, sxy, true, so);
+                        g += d * (1.f / 9.f) * (so.g_mx + 2.f * xv * so.g_pxx + yv * so.g_pxy);
+                    }
+                }
+        float out = scale_ssim * g;
+        if (scale_l1 != 0.f) {
+            float d = dout[dbase + (long)h * W + w];
+            if (win && win[dbase + (long)h * W + w] != wj) d = 0.f;
+            const float df = yv - xv;
+            out += scale_l1 * d * -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+        }
+        dx[i] = out;
+    }
+}
+// index (as float) of the first minimum over the k photometric losses of prediction_loss
+__global__ void op_prediction_argmin_kernel(const float* __restrict__ preds, int k, const float* __restrict__ tgt, float* __restrict__ win, int N, int C, int H, int W, long pj, long pn, long tn) {
+    const long P = (long)H * W;
+    FOR1D(i, (long)N * P) {
+        const int w = i % W; const long t = i / W; const int h = t % H; const int n = t / H;
+        float best = 0.f; int bj = 0;
+        for (int j = 0; j < k; ++j) {
+            float ss = 0.f, l1 = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float* xp = preds + (long)j * pj + (long)n * pn + (long)c * P; const float* yp = tgt + (long)n * tn + (long)c * P;
+                float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int o = refl_idx(h + dy, H) * W + refl_idx(w + dx, W);
+                        const float xv = xp[o], yv = yp[o];
+                        sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+                    }
+                SsimOut so; ssim_from_sums(sx, sy, sxx, syy, sxy, false, so);
+                ss += so.val; l1 += fabsf(yp[(long)h * W + w] - xp[(long)h * W + w]);
+            }
+            const float pl = 0.85f * (ss / (float)C) + (1.f - 0.85f) * (l1 / (float)C);
+            if (j == 0 || pl < best) { best = pl; bj = j; }
+        }
+        win[i] = (float)bj;
+    }
+}
+// d smooth_loss / d disparity (the image is data): dl = upstream scalar (device)
+__global__ void op_smooth_bwd_kernel(const float* __restrict__ d, const float* __restrict__ img, const float* __restrict__ dl, float* __restrict__ dd, int N, int C, int H, int W) {
+    const long P = (long)H * W;
+    const float gx = dl[0] / (float)((double)(W - 1) * H * N), gy = dl[0] / (float)((double)W * (H - 1) * N);
+    auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+    FOR1D(i, (long)N * P) {
+        const int n = i / P; const long p = i - (long)n * P; const int h = p / W, w = p - (long)h * W;
+        auto ex = [&](long q) { float gi = 0.f; for (int c = 0; c < C; ++c) { const float* im = img + ((long)n * C + c) * P; gi += fabsf(im[q] - im[q + 1]); } if (C > 1) gi /= (float)C; return expf(-gi); };
+        auto ey = [&](long q) { float gi = 0.f; for (int c = 0; c < C; ++c) { const float* im = img + ((long)n * C + c) * P; gi += fabsf(im[q] - im[q + W]); } if (C > 1) gi /= (float)C; return expf(-gi); };
+        float g = 0.f;
+        if (w + 1 < W) g += gx * sgn(d[i] - d[i + 1]) * ex(p);
+        if (w >= 1) g -= gx * sgn(d[i - 1] - d[i]) * ex(p - 1);
+        if (h + 1 < H) g += gy * sgn(d[i] - d[i + W]) * ey(p);
+        if (h >= 1) g -= gy * sgn(d[i - W] - d[i]) * ey(p - W);
+        dd[i] = g;
+    }
+}
+// pullback of the fused warp (md2_warp_fwd) wrt disparity, R (column-major 3x3) and t; the source image is data.  dR / dt: [N][9] / [N][3], zeroed by the caller, float atomics
+__global__ __launch_bounds__(256) void op_warp_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ src, const float* __restrict__ K, const float* __restrict__ invK,
+                                                         const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ dout, float* __restrict__ ddisp,
+                                                         float* __restrict__ dR, float* __restrict__ dt, int C, int H, int W, float min_disp, float max_disp) {
+    const long P = (long)H * W; const int n = blockIdx.y;
+    Pose12 T; for (int k = 0; k < 9; ++k) T.R[k] = R[n * 9 + k]; for (int k = 0; k < 3; ++k) T.t[k] = t[n * 3 + k];
+    float Kl[9], iK[9]; for (int k = 0; k < 9; ++k) { Kl[k] = K[k]; iK[k] = invK[k]; }
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        const int py = p / W, px = p - (long)py * W;
+        const float d = disp[(long)n * P + p];
+        Proj pr; project_px(d, py, px, Kl, iK, T, min_disp, max_disp, H, W, pr);
+        Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
+        float ggx = 0.f, ggy = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* im = src + ((long)n * C + c) * P; const float g = dout[((long)n * C + c) * P + p];
+            const float v00 = im[sm.i00], v01 = sm.v01 ? im[sm.i01] : 0.f, v10 = sm.v10 ? im[sm.i10] : 0.f, v11 = sm.v11 ? im[sm.i11] : 0.f;
+            ggx += g * ((v01 - v00) * sm.wy0 + (v11 - v10) * sm.wy1);
+            ggy += g * ((v10 - v00) * sm.wx0 + (v11 - v01) * sm.wx1);
+        }
+        ggx *= pr.mx; ggy *= pr.my;
+        const float gu = ggx * (2.f / (float)(W - 1)), gv = ggy * (2.f / (float)(H - 1));
+        const float gc[3] = {gu * pr.denom, gv * pr.denom, -(gu * pr.c[0] + gv * pr.c[1]) * pr.denom * pr.denom};
+        float gr[3], gP[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gr[j] = Kl[j * 3 + 0] * gc[0] + Kl[j * 3 + 1] * gc[1] + Kl[j * 3 + 2] * gc[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            gP[j] = T.R[j * 3 + 0] * gr[0] + T.R[j * 3 + 1] * gr[1] + T.R[j * 3 + 2] * gr[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[j * 3 + k] += gr[k] * pr.P[j];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[9 + k] += gr[k];
+        const float cx = (float)(px + 1), cy = (float)(py + 1);
+        float gdepth = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gdepth += gP[k] * (iK[k] * cx + iK[3 + k] * cy + iK[6 + k]);
+        const float ddn = d * (max_disp - min_disp) + min_disp, rdd = frcp(ddn);
+        ddisp[(long)n * P + p] = -gdepth * (max_disp - min_disp) * rdd * rdd;
+    }
+    __shared__ float red[4][12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) red[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < 9) atomicAdd(dR + n * 9 + threadIdx.x, v); else atomicAdd(dt + n * 3 + threadIdx.x - 9, v);
+    }
+}
+
 // automasking_loss (src/training.jl:9-11) on the triplet tensor x [N][3][C][H][W] in place: predictions = frames src0, src1, target = frame tgt
 void launch_automask(const float* x, float* out, int N, int C, int H, int W, int src0, int src1, int tgt, hipStream_t s) {
     const long CP = (long)C * H * W;
@@ -938,6 +1084,42 @@ int32_t md2_prediction_loss_fwd(const float* preds, int32_t k, const float* targ
     if (H < 2 || W < 2 || k < 1) return 2;
     hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, S_(stream), preds, k, target, out, N, C, H, W, (long)N * C * H * W, (long)C * H * W, (long)C * H * W); return chk();
 }
+int32_t md2_ssim_bwd(const float* x, const float* y, const float* dout, float* dx, float* dy, int32_t planes, int32_t H, int32_t W, void* stream) {
+    if (H < 2 || W < 2) return 2;
+    if (dx) hipLaunchKernelGGL(op_ssim_bwd_kernel, GRID1D((long)planes * H * W), 0, S_(stream), x, y, dout, dx, planes, 1, H, W, 1.f, 0.f, (const float*)nullptr, 0.f);
+    if (dy) hipLaunchKernelGGL(op_ssim_bwd_kernel, GRID1D((long)planes * H * W), 0, S_(stream), y, x, dout, dy, planes, 1, H, W, 1.f, 0.f, (const float*)nullptr, 0.f);      // SSIM is symmetric in its arguments
+    return chk();
+}
+int32_t md2_photometric_loss_bwd(const float* pred, const float* target, const float* dout, float* dpred, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (H < 2 || W < 2) return 2;
+    hipLaunchKernelGGL(op_ssim_bwd_kernel, GRID1D((long)N * C * H * W), 0, S_(stream), pred, target, dout, dpred, N * C, C, H, W, 0.85f / (float)C, (1.f - 0.85f) / (float)C, (const float*)nullptr, 0.f);
+    return chk();
+}
+int32_t md2_prediction_loss_bwd(const float* preds, int32_t k, const float* target, const float* dout, float* dpreds, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (H < 2 || W < 2 || k < 1) return 2;
+    float* win = nullptr;
+    if (hipMallocAsync((void**)&win, (size_t)N * H * W * sizeof(float), S_(stream)) != hipSuccess) return 3;
+    const long NC = (long)N * C * H * W;
+    hipLaunchKernelGGL(op_prediction_argmin_kernel, GRID1D((long)N * H * W), 0, S_(stream), preds, k, target, win, N, C, H, W, NC, (long)C * H * W, (long)C * H * W);
+    for (int j = 0; j < k; ++j)        // the gradient of the minimum goes to the first arg-min (Zygote `minimum`)
+        hipLaunchKernelGGL(op_ssim_bwd_kernel, GRID1D(NC), 0, S_(stream), preds + j * NC, target, dout, dpreds + j * NC, N * C, C, H, W, 0.85f / (float)C, (1.f - 0.85f) / (float)C, win, (float)j);
+    (void)hipFreeAsync(win, S_(stream));
+    return chk();
+}
+int32_t md2_smooth_loss_bwd(const float* disp, const float* image, const float* dloss, float* ddisp, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
+    if (H < 2 || W < 2) return 2;
+    hipLaunchKernelGGL(op_smooth_bwd_kernel, GRID1D((long)N * H * W), 0, S_(stream), disp, image, dloss, ddisp, N, C, H, W); return chk();
+}
+int32_t md2_warp_bwd(const float* disp, const float* src, const float* K, const float* invK, const float* R, const float* t, const float* dout, float* ddisp, float* dR, float* dt,
+                     int32_t N, int32_t C, int32_t H, int32_t W, double min_depth, double max_depth, void* stream) {
+    if (H < 2 || W < 2) return 2;
+    (void)hipMemsetAsync(dR, 0, (size_t)N * 9 * sizeof(float), S_(stream)); (void)hipMemsetAsync(dt, 0, (size_t)N * 3 * sizeof(float), S_(stream));
+    const int gx = (int)std::max<long>(1, std::min<long>(((long)H * W + 255) / 256, 512));
+    hipLaunchKernelGGL(op_warp_bwd_kernel, dim3(gx, N), dim3(256), 0, S_(stream), disp, src, K, invK, R, t, dout, ddisp, dR, dt, C, H, W, (float)(1.0 / max_depth), (float)(1.0 / min_depth));
+    return chk();
+}
+int32_t md2_alloc(void** ptr, int64_t bytes) { return (ptr && bytes >= 0 && hipMalloc(ptr, (size_t)bytes) == hipSuccess) ? 0 : 3; }
+int32_t md2_free(void* ptr) { return hipFree(ptr) == hipSuccess ? 0 : 1; }
 int32_t md2_disparity_to_depth(const float* d, float* out, int64_t n, double min_depth, double max_depth, void* stream) {
     hipLaunchKernelGGL(op_d2d_kernel, GRID1D(n), 0, S_(stream), d, out, (long)n, (float)(1.0 / max_depth), (float)(1.0 / min_depth)); return chk();
 }

@@ -9,7 +9,8 @@ module Monodepth2HIP
 
 using AMDGPU
 using LinearAlgebra: I
-import ChainRulesCore: @non_differentiable
+import ChainRulesCore
+import ChainRulesCore: @non_differentiable, NoTangent, unthunk
 
 const LIB = get(ENV, "MD2HIP_LIB", joinpath(@__DIR__, "..", "libmd2hip.so"))
 
@@ -222,16 +223,33 @@ ok(rc, what) = rc == 0 ? nothing : error("libmd2hip $what failed ($rc)")
 function ssim(x::ROCArray{Float32,4}, y::ROCArray{Float32,4})
     W, H, C, N = size(x); out = similar(x); ok(md2_ssim_fwd(dptr(x), dptr(y), dptr(out), Int32(C * N), Int32(H), Int32(W), NOSTREAM), "ssim_fwd"); out
 end
+function ∇ssim(x::ROCArray{Float32,4}, y::ROCArray{Float32,4}, Δ::ROCArray{Float32,4})
+    W, H, C, N = size(x); dx = similar(x); dy = similar(y)
+    ok(md2_ssim_bwd(dptr(x), dptr(y), dptr(Δ), dptr(dx), dptr(dy), Int32(C * N), Int32(H), Int32(W), NOSTREAM), "ssim_bwd"); dx, dy
+end
+ChainRulesCore.rrule(::typeof(ssim), x::ROCArray{Float32,4}, y::ROCArray{Float32,4}) = ssim(x, y), Δ -> (NoTangent(), ∇ssim(x, y, ROCArray{Float32}(unthunk(Δ)))...)
 # photometric_loss(ssim, predicted, target), src/training.jl:1-7
 function photometric_loss(pred::ROCArray{Float32,4}, target::ROCArray{Float32,4})
     W, H, C, N = size(pred); out = ROCArray{Float32}(undef, W, H, 1, N)
     ok(md2_photometric_loss_fwd(dptr(pred), dptr(target), dptr(out), Int32(N), Int32(C), Int32(H), Int32(W), NOSTREAM), "photometric_loss_fwd"); out
 end
+function ∇photometric_loss(pred::ROCArray{Float32,4}, target::ROCArray{Float32,4}, Δ::ROCArray{Float32,4})       # wrt `pred` (the target is data)
+    W, H, C, N = size(pred); dp = similar(pred)
+    ok(md2_photometric_loss_bwd(dptr(pred), dptr(target), dptr(Δ), dptr(dp), Int32(N), Int32(C), Int32(H), Int32(W), NOSTREAM), "photometric_loss_bwd"); dp
+end
+ChainRulesCore.rrule(::typeof(photometric_loss), pred::ROCArray{Float32,4}, target::ROCArray{Float32,4}) =
+    photometric_loss(pred, target), Δ -> (NoTangent(), ∇photometric_loss(pred, target, ROCArray{Float32}(unthunk(Δ))), NoTangent())
 # prediction_loss(ssim, predictions, target), src/training.jl:13-15; predictions stacked (W,H,C,N,k)
 function prediction_loss(preds::ROCArray{Float32,5}, target::ROCArray{Float32,4})
     W, H, C, N, k = size(preds); out = ROCArray{Float32}(undef, W, H, 1, N)
     ok(md2_prediction_loss_fwd(dptr(preds), Int32(k), dptr(target), dptr(out), Int32(N), Int32(C), Int32(H), Int32(W), NOSTREAM), "prediction_loss_fwd"); out
 end
+function ∇prediction_loss(preds::ROCArray{Float32,5}, target::ROCArray{Float32,4}, Δ::ROCArray{Float32,4})         # the gradient of `minimum` goes to the first arg-min
+    W, H, C, N, k = size(preds); dp = similar(preds)
+    ok(md2_prediction_loss_bwd(dptr(preds), Int32(k), dptr(target), dptr(Δ), dptr(dp), Int32(N), Int32(C), Int32(H), Int32(W), NOSTREAM), "prediction_loss_bwd"); dp
+end
+ChainRulesCore.rrule(::typeof(prediction_loss), preds::ROCArray{Float32,5}, target::ROCArray{Float32,4}) =
+    prediction_loss(preds, target), Δ -> (NoTangent(), ∇prediction_loss(preds, target, ROCArray{Float32}(unthunk(Δ))), NoTangent())
 # disparity_to_depth, src/utils.jl:175-179
 function disparity_to_depth(d::ROCArray{Float32}, min_depth, max_depth)
     out = similar(d); ok(md2_disparity_to_depth(dptr(d), dptr(out), length(d), Float64(min_depth), Float64(max_depth), NOSTREAM), "disparity_to_depth"); out
@@ -260,6 +278,19 @@ function warp(disp::ROCArray{Float32,4}, src::ROCArray{Float32,4}, K::ROCArray{F
     W, H, C, N = size(src); out = similar(src)
     ok(md2_warp_fwd(dptr(disp), dptr(src), dptr(K), dptr(invK), dptr(R), dptr(t), dptr(out), Int32(N), Int32(C), Int32(H), Int32(W), Float64(min_depth), Float64(max_depth), NOSTREAM), "warp_fwd"); out
 end
+# its pullback wrt the disparity and the pose (the source image is data): dR (9,N) column-major 3x3 per sample, dt (3,N)
+function ∇warp(disp::ROCArray{Float32,4}, src::ROCArray{Float32,4}, K::ROCArray{Float32,2}, invK::ROCArray{Float32,2}, R::ROCArray{Float32,3}, t::ROCArray{Float32,3}, min_depth, max_depth, Δ::ROCArray{Float32,4})
+    W, H, C, N = size(src); dd = similar(disp); dR = ROCArray{Float32}(undef, 3, 3, N); dt = similar(t)
+    ok(md2_warp_bwd(dptr(disp), dptr(src), dptr(K), dptr(invK), dptr(R), dptr(t), dptr(Δ), dptr(dd), dptr(dR), dptr(dt), Int32(N), Int32(C), Int32(H), Int32(W), Float64(min_depth), Float64(max_depth), NOSTREAM), "warp_bwd"); dd, dR, dt
+end
+function ChainRulesCore.rrule(::typeof(warp), disp::ROCArray{Float32,4}, src::ROCArray{Float32,4}, K, invK, R::ROCArray{Float32,3}, t::ROCArray{Float32,3}, min_depth, max_depth)
+    out = warp(disp, src, K, invK, R, t, min_depth, max_depth)
+    function warp_pullback(Δ)
+        dd, dR, dt = ∇warp(disp, src, K, invK, R, t, min_depth, max_depth, ROCArray{Float32}(unthunk(Δ)))
+        NoTangent(), dd, NoTangent(), NoTangent(), NoTangent(), dR, dt, NoTangent(), NoTangent()
+    end
+    out, warp_pullback
+end
 # NNlib.upsample_bilinear(x; size), src/training.jl:45, and its pullback
 function upsample_bilinear(x::ROCArray{Float32,4}; size)
     W, H, C, N = Base.size(x); Wo, Ho = size; out = ROCArray{Float32}(undef, Wo, Ho, C, N)
@@ -282,6 +313,15 @@ function smooth_loss(disp::ROCArray{Float32,3}, image::ROCArray{Float32,4})
     W, H, C, N = size(image); out = ROCArray{Float32}(undef, 1)
     ok(md2_smooth_loss(dptr(disp), dptr(image), dptr(out), Int32(N), Int32(C), Int32(H), Int32(W), NOSTREAM), "smooth_loss"); out
 end
+function ∇smooth_loss(disp::ROCArray{Float32,3}, image::ROCArray{Float32,4}, Δ::ROCArray{Float32,1})                 # wrt the disparity (the image is data); Δ: upstream scalar on the device
+    W, H, C, N = size(image); dd = similar(disp)
+    ok(md2_smooth_loss_bwd(dptr(disp), dptr(image), dptr(Δ), dptr(dd), Int32(N), Int32(C), Int32(H), Int32(W), NOSTREAM), "smooth_loss_bwd"); dd
+end
+ChainRulesCore.rrule(::typeof(smooth_loss), disp::ROCArray{Float32,3}, image::ROCArray{Float32,4}) =
+    smooth_loss(disp, image), Δ -> (NoTangent(), ∇smooth_loss(disp, image, ROCArray{Float32}(collect(Float32, unthunk(Δ)))), NoTangent())
+# device memory for hosts without an array package: md2_alloc / md2_free (SURVEY.md section 8b ownership rule)
+function alloc(bytes::Integer); p = Ref{Ptr{Cvoid}}(C_NULL); GC.@preserve p ok(md2_alloc(Base.unsafe_convert(Ptr{Ptr{Cvoid}}, p), Int64(bytes)), "alloc"); p[]; end
+free(p::Ptr{Cvoid}) = ok(md2_free(p), "free")
 # Flux Conv / BatchNorm / MaxPool / ADAM as the network uses them (parity tests): weights (kW,kH,Cin,Cout), pad_mode 0 zeros / 1 reflect, act 0 none 1 relu 2 elu 3 σ
 function conv2d(x::ROCArray{Float32,4}, w::ROCArray{Float32,4}, b; stride=1, pad=0, pad_mode=0, act=0)
     W, H, Cin, N = size(x); k, _, _, Cout = size(w); pe = pad_mode == 1 ? 1 : pad

@@ -180,6 +180,41 @@ def warp(disparity, source, K, invK, R, t, min_depth, max_depth):
 # --------------------------------------------------------------------------------------------
 # losses (src/training.jl:1-19)
 # --------------------------------------------------------------------------------------------
+def ssim_pullback(x, y, dout):
+    """Pullback of SSIM()(x, y): dout (N,C,H,W) -> (dx, dy)."""
+    x, y, g = _f32(x), _f32(y), _f32(dout); N, Cc, H, W = x.shape; dx, dy = torch.empty_like(x), torch.empty_like(x)
+    _check(_lib.lib().md2_ssim_bwd(_dev(x), _dev(y), _dev(g), _dev(dx), _dev(dy), N * Cc, H, W, _stream())); return dx, dy
+
+
+def photometric_loss_pullback(predicted, target, dout):
+    """Pullback of photometric_loss wrt `predicted` (the target is data): dout (N,1,H,W) -> (N,C,H,W)."""
+    p, t, g = _f32(predicted), _f32(target), _f32(dout); N, Cc, H, W = p.shape; dp = torch.empty_like(p)
+    _check(_lib.lib().md2_photometric_loss_bwd(_dev(p), _dev(t), _dev(g), _dev(dp), N, Cc, H, W, _stream())); return dp
+
+
+def prediction_loss_pullback(predictions, target, dout):
+    """Pullback of prediction_loss wrt its predictions: the gradient of the minimum goes to the first arg-min."""
+    preds = _f32(torch.stack([_f32(p) for p in predictions], 0)); t, g = _f32(target), _f32(dout); k, N, Cc, H, W = preds.shape; dp = torch.empty_like(preds)
+    _check(_lib.lib().md2_prediction_loss_bwd(_dev(preds), k, _dev(t), _dev(g), _dev(dp), N, Cc, H, W, _stream())); return [dp[j] for j in range(k)]
+
+
+def smooth_loss_pullback(disparity, image, dloss=1.0):
+    """Pullback of smooth_loss wrt the disparity (the image is data)."""
+    d, im = _f32(disparity), _f32(image); N, H, W = d.shape; dd = torch.empty_like(d)
+    g = _f32(dloss) if torch.is_tensor(dloss) else torch.full((1,), float(dloss), device=d.device)
+    _check(_lib.lib().md2_smooth_loss_bwd(_dev(d), _dev(im), _dev(g), _dev(dd), N, im.shape[1], H, W, _stream())); return dd
+
+
+def warp_pullback(disparity, source, K, invK, R, t, min_depth, max_depth, dout):
+    """Pullback of `warp` wrt the disparity and the pose: -> (ddisparity like disparity, dR (N,9) column-major, dt (N,3))."""
+    d, s, g = _f32(disparity), _f32(source), _f32(dout); N, Cc, H, W = s.shape
+    Kd = K if torch.is_tensor(K) else _dev_mat(K); iK = invK if torch.is_tensor(invK) else _dev_mat(invK)
+    dd = torch.empty_like(d); dR = torch.empty(N, 9, device=d.device); dt = torch.empty(N, 3, device=d.device)
+    _check(_lib.lib().md2_warp_bwd(_dev(d), _dev(s), _dev(Kd), _dev(iK), _dev(_f32(R)), _dev(_f32(t).reshape(N, 3)), _dev(g), _dev(dd), _dev(dR), _dev(dt), N, Cc, H, W,
+                                   float(min_depth), float(max_depth), _stream()))
+    return dd, dR, dt
+
+
 def photometric_loss(ssim, predicted, target, alpha=0.85):
     if abs(alpha - 0.85) > 1e-12:
         raise ValueError("the HIP kernel implements the reference's alpha = 0.85")

@@ -144,6 +144,57 @@ def test_fused_warp_matches_unfused_sequence():                 # src/training.j
     assert np.abs(out - ref).max() < 1e-4
 
 
+def test_l2_op_pullbacks_vs_oracle():
+    """The op-level pullbacks a Julia `rrule` of SSIM / photometric_loss / prediction_loss / smooth_loss / warp would call (include/md2hip.h `*_bwd`), against the
+    oracle's pullbacks of the same functions; shapes with reflect-pad aliases on every border (H, W small) and C = 1 / 3."""
+    for (N, C, H, W) in [(2, 3, 20, 30), (1, 1, 5, 7)]:
+        x = rng.random((N, C, H, W)).astype(np.float32); y = np.clip(x + 0.1 * rng.standard_normal(x.shape), 0, 1).astype(np.float32)
+        g = rng.standard_normal((N, C, H, W)).astype(np.float32)
+        dx, dy = md().ssim_pullback(dev(x), dev(y), dev(g)); dxo, dyo = oracle.ssim_bwd(x, y, g)
+        assert rel(host(dx), dxo) < 2e-4 and rel(host(dy), dyo) < 2e-4
+        g1 = rng.standard_normal((N, 1, H, W)).astype(np.float32)
+        dp = md().photometric_loss_pullback(dev(x), dev(y), dev(g1))
+        assert rel(host(dp), oracle.photometric_loss_bwd(x, y, g1)) < 2e-4
+        # prediction_loss: the arg-min routes the upstream gradient to one prediction per pixel
+        p2 = np.clip(y + 0.1 * rng.standard_normal(x.shape), 0, 1).astype(np.float32)
+        _, arg = oracle.prediction_loss([x, p2], y)
+        dps = md().prediction_loss_pullback([dev(x), dev(p2)], dev(y), dev(g1))
+        for j, pj in enumerate([x, p2]):
+            ref = oracle.photometric_loss_bwd(pj, y, g1 * (arg == j))
+            assert rel(host(dps[j]), ref) < 2e-4
+        d = rng.random((N, H, W)).astype(np.float32)
+        dd = md().smooth_loss_pullback(dev(d), dev(x), 0.7)
+        assert rel(host(dd), oracle.smooth_loss_bwd(d, x, 0.7)) < 1e-4
+
+
+def test_fused_warp_pullback_vs_unfused_oracle_chain():
+    """md2_warp_bwd against the oracle's chain grid_sample_bwd -> project_bwd -> backproject / disparity_to_depth pullbacks (src/training.jl:48-57)."""
+    N, C, H, W = 2, 3, 48, 64
+    x = syn.synthetic_triplets(N, C, H, W, seed=8); K, iK = syn.depth10k_intrinsics(W, H)
+    d = (rng.random((N, 1, H, W)) * 0.8 + 0.1).astype(np.float32)
+    r = ((rng.random((N, 3)) - 0.5) * 0.02).astype(np.float32); t = ((rng.random((N, 3)) - 0.5) * 0.2).astype(np.float32)
+    R, to = oracle.composeT(r, t, False)
+    g = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    dd, dR, dt = md().warp_pullback(dev(d), dev(x[:, 0]), K, iK, dev(colmajor(R)), dev(to), 0.1, 100.0, dev(g))
+    # reference: the oracle's pullbacks of the unfused chain, in float64 (grid_sample -> Project -> Backproject -> disparity_to_depth)
+    d64, R64, t64 = d.astype(np.float64), R.astype(np.float64), to.astype(np.float64)
+    depth = oracle.disparity_to_depth(d64, 0.1, 100.0)
+    pts = oracle.backproject(depth.reshape(N, -1), iK.astype(np.float64), H, W)
+    uv = oracle.project(pts, K.astype(np.float64), R64, t64, H, W)
+    dgrid, _ = oracle.grid_sample_bwd(x[:, 0].astype(np.float64), uv.reshape(N, H, W, 2), g.astype(np.float64), True)
+    dpts, dRo, dto = oracle.project_bwd(pts, K.astype(np.float64), R64, t64, dgrid.reshape(N, H * W, 2), H, W)
+    ys, xs = np.meshgrid(np.arange(1, H + 1, dtype=np.float64), np.arange(1, W + 1, dtype=np.float64), indexing="ij")
+    rays = np.stack([xs.ravel(), ys.ravel(), np.ones(H * W)], 0)                     # pixel coordinates are 1-based (src/utils.jl:50-60)
+    rays = (iK.astype(np.float64) @ rays).T                                           # (P, 3)
+    ddepth = (dpts * rays[None]).sum(-1).reshape(N, 1, H, W)
+    mn, mx = 1.0 / 100.0, 1.0 / 0.1
+    ddo = -ddepth * (mx - mn) / (d64 * (mx - mn) + mn) ** 2
+    assert rel(host(dd), ddo) < 2e-4
+    assert rel(host(dt), dto) < 2e-4
+    dRh = host(dR).reshape(N, 3, 3).transpose(0, 2, 1)                                # column-major [n][j][i] -> R[i][j]
+    assert rel(dRh, dRo) < 2e-4
+
+
 def test_adam_raw_matches_oracle():
     n = 4096; p = rng.standard_normal(n).astype(np.float32)
     net = oracle.OracleNet(1); theta = np.zeros(net.nparams, np.float32); theta[:n] = p; net.set_params(theta)
