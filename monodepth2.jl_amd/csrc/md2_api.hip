@@ -40,7 +40,7 @@ struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; long rs = 0; float* s
 struct Block { ConvL c1, c2, c3, cd; BNL b1, b2, b3, bd; bool down = false, bottleneck = false, stage_end = false, fuse = false; int stride = 1;
                View in, z1, a1, z2, a2, z3, zd, sd, out; View dz1, dz2, dz3, dzd; };
 struct ProfEvt { hipEvent_t a, b; int cls; double flops; char desc[112]; };
-enum { CLS_IGEMM = 0, CLS_WGRAD = 1, CLS_LOSS_FWD = 2, CLS_LOSS_BWD = 3, CLS_OTHER = 4 };
+enum { CLS_IGEMM = 0, CLS_WGRAD = 1, CLS_LOSS_FWD = 2, CLS_LOSS_BWD = 3, CLS_OTHER = 4 };      // CLS_LOSS_BWD: the training step's fused loss value + pullback kernel (bench.py: roofline_loss_train)
 
 }  // namespace
 
