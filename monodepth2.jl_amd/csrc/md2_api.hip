@@ -211,6 +211,8 @@ static void plan_buffers(md2_handle* h) {
         dxpad_max = std::max(dxpad_max, (size_t)N * (dh + 2) * (dw + 2) * (dec[b] + skc[b]));
         if (b >= 1) h->dispv[b - 1] = h->alloc_view(N, dh, dw, 1);
     }
+    // a loss-only handle (H, W multiples of 8 but not of 32) has no decoder to derive the disparity sizes from: the loss reads / writes H >> (3 - l) x W >> (3 - l)
+    if (!h->net_ok) for (int l = 0; l < 4; ++l) h->dispv[l] = h->alloc_view(N, H >> (3 - l), W >> (3 - l), 1);
     const int ph = H / 32, pw = W / 32;
     h->sq3 = h->alloc_view(3 * N, ph, pw, 256); h->dsq3 = h->alloc_view(3 * N, ph, pw, 256);
     h->sqcat = h->alloc_view(2 * N, ph, pw, 512); h->py1 = h->alloc_view(2 * N, ph, pw, 256); h->py2 = h->alloc_view(2 * N, ph, pw, 256); h->py3 = h->alloc_view(2 * N, ph, pw, 16);
