@@ -169,6 +169,21 @@ def test_loss_half_ragged_tiles_vs_oracle(case):
     # forward-only call (separate kernel) agrees with the fused value
     l2, _, _, _ = md().loss_fwd_bwd(model, xd, [dev(d) for d in disps], dev(rvec), dev(tvec), want_grads=False)
     assert abs(float(l2) - float(loss)) / float(loss) < 1e-6
+    # deterministic mode (ordered partial sums, full-resolution maps + the ordered resize adjoint): bit-reproducible, and the same numbers to rounding
+    md().set_deterministic(True)
+    try:
+        la, da, ra, ta = md().loss_fwd_bwd(model, xd, [dev(d) for d in disps], dev(rvec), dev(tvec))
+        lb, db, rb, tb = md().loss_fwd_bwd(model, xd, [dev(d) for d in disps], dev(rvec), dev(tvec))
+    finally:
+        md().set_deterministic(False)
+    assert float(la) == float(lb) and all(torch.equal(p, q) for p, q in zip(da, db)) and torch.equal(ra, rb) and torch.equal(ta, tb)
+    assert abs(float(la) - float(loss)) / float(loss) < 1e-6 and all(rel(host(p), host(q)) < 1e-5 for p, q in zip(da, dds))
+    # the slow_depth objective (one full-resolution disparity, un-normalised smoothness) on the same ragged frame
+    d1 = disps[3]
+    ls, dd1, dr1, dt1 = md().simple_depth_loss(model, xd, dev(d1), dev(rvec), dev(tvec))
+    rs = oracle.loss_fwd_bwd(x, oracle.make_cfg(N, C, H, W, K, iK, simple=True), [d1], rvec, tvec)
+    assert abs(float(ls) - rs["loss"]) / rs["loss"] < 1e-5 and grad_close(host(dd1), rs["ddisp"][0], tol=5e-4)
+    assert rel(host(dr1), rs["drvec"]) < 5e-3 and rel(host(dt1), rs["dtvec"]) < 5e-3
 
 
 @pytest.mark.parametrize("name", ["net_c1_64x96", "net_c3_64x96_automask"])
