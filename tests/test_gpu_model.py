@@ -597,13 +597,15 @@ def test_real_image_full_step_vs_oracle():
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # deterministic mode, BatchNorm running statistics / test mode, handle management, the library's own RCCL path
 # ---------------------------------------------------------------------------------------------------------------------------------------
-def test_deterministic_mode_is_bit_reproducible():
+@pytest.mark.parametrize("depth", [18, 50])
+def test_deterministic_mode_is_bit_reproducible(depth):
     """MD2_DETERMINISTIC / md2_set_deterministic: two fresh handles, same inputs -> bit-identical loss, gradients and ADAM update (the default mode differs
-    in the last bits from run to run: fp32 atomics in the weight gradients, split-K, 8-slot BatchNorm sums)."""
+    in the last bits from run to run: fp32 atomics in the weight gradients, split-K, 8-slot BatchNorm sums).  Both trunks: the ResNet-50 bottlenecks take the
+    folded-BatchNorm kernels with their ordered fallbacks (column passes instead of epilogue sums, no split-K workspace)."""
     N, C, H, W = 2, 3, 64, 96
     x = dev(syn.synthetic_triplets(N, C, H, W, seed=81))
     def run():
-        model, params, cache, theta, K, iK = make(N, C, H, W, automask=True, pseed=82)
+        model, params, cache, theta, K, iK = make(N, C, H, W, automask=True, pseed=82, depth=depth)
         al = md().automasking_loss(md().SSIM(), x, x[:, 1].contiguous(), [1, 3])
         l = float(md().train_step(model, x, al, cache, params, do_update=True))
         return l, model.grads(), model.params()
@@ -614,8 +616,8 @@ def test_deterministic_mode_is_bit_reproducible():
         md().set_deterministic(False)
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     c = run()                                                      # and the ordered sums agree with the default mode to rounding
-    assert abs(c[0] - a[0]) < 1e-6 * abs(a[0])
-    assert np.linalg.norm(c[1] - a[1]) / np.linalg.norm(a[1]) < 2e-3
+    assert abs(c[0] - a[0]) < (1e-6 if depth == 18 else 2e-5) * abs(a[0])
+    assert np.linalg.norm(c[1] - a[1]) / np.linalg.norm(a[1]) < (2e-3 if depth == 18 else 5e-2)      # (ResNet-50: kink noise, see the fp64 criterion test)
 
 
 def test_testmode_eval_and_bn_running_statistics_vs_oracle(tmp_path):
