@@ -672,13 +672,15 @@ def test_intrinsics_follow_the_cache_and_state_survives_a_handle_rebuild():
     assert abs(m_after[2] - 0.81) < 1e-12 and np.abs(m_after[0]).max() > 0
 
 
-def test_library_rccl_path_world1():
+@pytest.mark.parametrize("depth", [18, 50])
+def test_library_rccl_path_world1(depth):
     """md2_comm_*: the library's own RCCL communicator (what a Julia host uses), here with one rank (one GPU per box): bucketed all-reduce inside md2_backward
-    on the communication stream, ADAM on the mean.  With one rank every sum is the identity, so the step must equal the plain step."""
+    on the communication stream, ADAM on the mean.  With one rank every sum is the identity, so the step must equal the plain step -- which also checks that the
+    four buckets tile the gradient buffer of either trunk exactly once (a gap or an overlap would leave / double a slice)."""
     N, C, H, W = 2, 1, 64, 96
     xd = dev(syn.synthetic_triplets(N, C, H, W, seed=97))
-    a, params, cache, theta, K, iK = make(N, C, H, W, pseed=98)
-    b, _, _, _, _, _ = make(N, C, H, W, pseed=98)
+    a, params, cache, theta, K, iK = make(N, C, H, W, pseed=98, depth=depth)
+    b, _, _, _, _, _ = make(N, C, H, W, pseed=98, depth=depth)
     dp = md2amd.parallel.DataParallel(a, comm="rccl")
     md().set_deterministic(True)
     try:
