@@ -68,6 +68,9 @@ int32_t md2_param_buffer(md2_handle* h, void** dev_ptr, int64_t* count);
  *      x [N][3][C][H][W]; disp_i [N][1][H>>(3-i)][W>>(3-i)]; rvec,tvec [2][N][3] (source-major) --- */
 int32_t md2_model_forward(md2_handle* h, const float* x, float* disp0, float* disp1, float* disp2, float* disp3,
                           float* rvec, float* tvec);
+/* eval_poses(m, features, source_ids, target_id), src/model.jl:22-35, on the frames themselves (the stage features live in the handle):
+ * encoder + pose decoder only, for both (source, target) pairs -> rvec, tvec [2][N][3] */
+int32_t md2_eval_poses(md2_handle* h, const float* x, float* rvec, float* tvec);
 /* ---- train_loss forward (src/training.jl:21-78): model + loss.  auto_loss may be NULL.
  *      loss: device scalar.  Keeps activations for md2_backward.  The loss kernel produces the loss value and its pullback
  *      (d loss / d disparities, d loss / d poses) in the same pass over the warp, so md2_backward starts at the network. --- */

@@ -52,6 +52,7 @@ _SIGS = {
     "md2_eval_disparity": (I32, [P, P, I32, P, P, P, P]),
     "md2_opt_state_get": (I32, [P, P, P, I64, C.POINTER(F64), C.POINTER(F64)]),
     "md2_opt_state_set": (I32, [P, P, P, I64, F64, F64]),
+    "md2_eval_poses": (I32, [P, P, P, P]),
     "md2_loss_fwd_bwd": (I32, [P] * 16),
     "md2_simple_depth_loss": (I32, [P] * 9),
     "md2_set_two_streams": (I32, [P, I32]),

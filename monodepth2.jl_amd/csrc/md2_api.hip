@@ -386,7 +386,7 @@ static void pose_forward(md2_handle* h, int N) {
 }
 
 // L frames per sample (3 for training, 1 for eval_disparity); tgt = index of the frame the depth decoder sees
-static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, bool with_pose = true) {
+static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, bool with_pose = true, bool with_depth = true) {
     hipStream_t s = h->stream;
     const int NL = h->z0.N, N = NL / L, H = h->H, W = h->W;
     HIPCHK(hipMemsetAsync(h->acc_all, 0, h->acc_fwd_count * sizeof(double), s));
@@ -442,7 +442,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
     }
     // ---- depth decoder on the target-frame features (src/model.jl:16-17, src/depth_decoder.jl:49-65)
     View x5 = frame_view(h->feat[4], L, tgt);
-    for (int b = 0; b < 5; ++b) {
+    for (int b = 0; b < (with_depth ? 5 : 0); ++b) {
         const View& in = (b == 0) ? x5 : h->y2[b - 1];
         conv_fwd(h, h->dc1[b], in, h->y1[b], PAD_REFLECT, ACT_ELU);
         launch_upsample2x_fwd(h->y1[b], chan_slice(h->cat[b], 0, h->y1[b].C), s);
@@ -879,6 +879,12 @@ int32_t md2_model_forward(md2_handle* h, const float* x, float* d0, float* d1, f
     h->have_fwd = false;                    // overwrites the activations a pending md2_backward would need
     if (int r = model_forward(h, x)) return r;
     return copy_outputs(h, d0, d1, d2, d3, rvec, tvec);
+}
+int32_t md2_eval_poses(md2_handle* h, const float* x, float* rvec, float* tvec) {
+    if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
+    h->have_fwd = false;
+    if (int r = model_forward(h, x, 3, 1, true, false)) return r;          // encoder + pose decoder; the depth decoder is skipped
+    return copy_outputs(h, nullptr, nullptr, nullptr, nullptr, rvec, tvec);
 }
 int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, float* loss) {
     if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }

@@ -156,6 +156,11 @@ function model_forward(h, x::ROCArray{Float32,5})
     disps, rvec, tvec
 end
 # train_loss(model, x, auto_loss, cache, parameters, false)[1], src/training.jl:21-78 -> device scalar
+# eval_poses(m, features, source_ids, target_id), src/model.jl:22-35, from the frames (the stage features live in the handle): encoder + pose decoder only
+function eval_poses(h, x::ROCArray{Float32,5})
+    N = size(x, 5); rvec = ROCArray{Float32}(undef, 3, N, 2); tvec = ROCArray{Float32}(undef, 3, N, 2)
+    check(h, md2_eval_poses(h.ptr, dptr(x), dptr(rvec), dptr(tvec)), "eval_poses"); rvec, tvec
+end
 function train_loss(h, x::ROCArray{Float32,5}, auto_loss)
     loss = ROCArray{Float32}(undef, 1)
     check(h, md2_train_loss(h.ptr, dptr(x), dptr(auto_loss), dptr(loss)), "train_loss"); loss

@@ -433,6 +433,18 @@ class Model:
         return ds, [Pose(rvec[0], tvec[0]), Pose(rvec[1], tvec[1])]
 
 
+def eval_poses(m: Model, x, source_ids=(1, 3), target_id=2):
+    """eval_poses(m, features, source_ids, target_id), src/model.jl:22-35, from the frames x (N,3,C,H,W): the encoder and the pose decoder only (the stage features
+    stay in the handle).  Returns [Pose(source 1 -> target), Pose(target -> source 3)] like the model call."""
+    if list(source_ids) != [1, 3] or target_id != 2:
+        raise NotImplementedError("hot path implements source_ids=[1,3], target_id=2 (src/kitty.jl, src/dtk.jl)")
+    x = _f32(x); m._ensure(x); N = x.shape[0]
+    L = _lib.lib(); L.md2_set_stream(m._h, _stream())
+    rvec = torch.empty(2, N, 3, device=x.device); tvec = torch.empty(2, N, 3, device=x.device)
+    _check(L.md2_eval_poses(m._h, _dev(x), _dev(rvec), _dev(tvec)), m._h, "eval_poses")
+    return [Pose(rvec[0], tvec[0]), Pose(rvec[1], tvec[1])]
+
+
 def eval_disparity(m: Model, x):
     """eval_disparity(m, x) = m.depth_decoder(m.encoder(x, Val(:stages))), src/model.jl:28.  x (n,C,H,W) single frames; the model's
     handle must exist (n <= its batch) or is created for batch n.  Returns the 4 disparities, coarse -> fine."""

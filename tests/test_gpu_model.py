@@ -491,6 +491,20 @@ def test_bf16_mixed_precision_tracks_the_fp32_oracle(cfgd):
     assert np.isfinite(l1) and l1 < l0
 
 
+def test_eval_poses_matches_the_model_call():
+    """eval_poses (src/model.jl:22-35): encoder + pose decoder alone give the poses of the full model call."""
+    N, C, H, W = 2, 1, 64, 96
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=17)
+    xd = dev(syn.synthetic_triplets(N, C, H, W, seed=18))
+    _, poses = model(xd, [1, 3], 2)
+    p2 = md().eval_poses(model, xd)
+    for a, b in zip(poses, p2):
+        assert rel(host(a.rvec), host(b.rvec)) < 1e-5 and rel(host(a.tvec), host(b.tvec)) < 1e-5
+    net = oracle.OracleNet(C); net.set_params(theta)
+    _, rvo, tvo = net.model_forward(host(xd), oracle.make_cfg(N, C, H, W, K, iK))
+    assert rel(np.stack([host(p.rvec) for p in p2]), rvo) < 1e-4 and rel(np.stack([host(p.tvec) for p in p2]), tvo) < 1e-4
+
+
 def test_backward_requires_a_training_forward():
     """md2_backward after a plain model forward (which overwrites the activations) must fail loudly, not return stale gradients."""
     N, C, H, W = 1, 1, 64, 96
