@@ -398,8 +398,9 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(View dy, View dx, V
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int h = r / dx.W, w = r - h * dx.W;
         // outputs oh with source index in (h-1, h+1): oh in [ (h-1)*(Ho-1)/(H-1) , (h+1)*(Ho-1)/(H-1) ]
         const float rh = dx.H > 1 ? (float)(dy.H - 1) / (float)(dx.H - 1) : 0.f, rw = dx.W > 1 ? (float)(dy.W - 1) / (float)(dx.W - 1) : 0.f;
-        const int oh_lo = max(0, (int)floorf((h - 1) * rh) - 1), oh_hi = min(dy.H - 1, (int)ceilf((h + 1) * rh) + 1);
-        const int ow_lo = max(0, (int)floorf((w - 1) * rw) - 1), ow_hi = min(dy.W - 1, (int)ceilf((w + 1) * rw) + 1);
+        // (a candidate just outside the open interval has weight 0 or a rounding-sized one: no +-1 safety margin, which was 2 of 7 candidates per axis)
+        const int oh_lo = max(0, (int)floorf((h - 1) * rh)), oh_hi = min(dy.H - 1, (int)ceilf((h + 1) * rh));
+        const int ow_lo = max(0, (int)floorf((w - 1) * rw)), ow_hi = min(dy.W - 1, (int)ceilf((w + 1) * rw));
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int oh = oh_lo; oh <= oh_hi; ++oh) {
             int h0, h1; float fh; up_src(oh, dx.H, dy.H, h0, h1, fh);
