@@ -1,0 +1,905 @@
+// conv_winograd.hip — fused Winograd F(2x2, 3x3) convolution on the fp32 matrix cores of gfx950 (CDNA4).
+//
+// Serves every 3x3 / stride-1 convolution with Cout % 32 == 0 (forward AND input gradient -- the latter is the same kernel on dY with the
+// transposed / flipped weights): the encoder's BasicBlock convs (ResNet.jl via src/model.jl:14), DecoderBlock (src/depth_decoder.jl:13-14) and the
+// PoseDecoder's 3x3 layers (src/pose_decoder.jl:15-19).  The reference gets the same algorithmic cut from cuDNN's algorithm choice.
+//
+// Why: the direct implicit GEMM (conv_igemm.hip) sits at ~0.62 of the fp32 MFMA peak with a measured ceiling of ~0.75; these layers are 85-90 % of the
+// step's FLOPs and F(2x2,3x3) needs 16 instead of 36 multiplies per 2x2 output tile (2.25x fewer MFMA cycles).  Nothing transformed ever touches HBM
+// except the weights (once per step, 16/9 of their size).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      d: 4x4 input patch of a 2x2 output tile, g: 3x3 taps (cross-correlation form)
+//
+// Block = 256 threads = 4 waves; block tile = 32 Winograd tiles (128 output pixels, flattened over (n, ty, tx) so that 13x4 maps pack like 104x32 ones)
+// x 32*NS output channels.  Wave i owns Winograd row i: the four positions (i, j), j = 0..3, i.e. acc[j][s] = U_(i,j)[32 couts s][K] . V_(i,j)[K][32 tiles].
+//   * input: the raw 4x4 patches of the 32 tiles for a 16-channel chunk are staged in LDS ([16 patch slots][32 tiles][16 ch], 32 KB, double buffered);
+//     BatchNorm + ReLU of the producer (XF) and the zero-padding mask are applied on the way in, exactly as in the implicit GEMM.  Wave i reads only the two
+//     patch rows its B^T row needs (ds_read_b128, XOR-swizzled 16-B chunks: conflict-free) and forms V_(i,0..3) in registers directly in MFMA B-operand
+//     layout (lane = tile, k-half): 32 VALU instructions per 8 channels against 32 MFMAs of 64 cycles.
+//   * weights: U = G g G^T is precomputed once per step (wino_weights_kernel) in MFMA A-operand FRAGMENT order, so a wave streams its operands with
+//     fully coalesced 1-KB global_load_dwordx4 straight into registers -- every U element is used by exactly one wave of the block: LDS would add nothing.
+//   * output: each wave applies the column half of A^T . A in registers (4 positions -> 2), the row half goes through LDS ([4][2][32 tiles][couts], 68 KB
+//     reusing the stages); then 16 lanes own the 64 channels of one pixel (256-B rows to HBM) and run the same epilogue contract as conv_igemm_kernel:
+//     bias, ELU / ReLU, residual, activation-derivative mask (incl. BatchNorm-folded), accumulate modes, BatchNorm statistics / pullback sums.
+#include "md2_internal.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace md2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+constexpr int WT = 32;                       // Winograd tiles per block
+constexpr int W_STAGE = 16 * WT * 16;        // floats per LDS stage (32 KB)
+
+// ---- weights: w [Cout][9][Cin] (cross-correlation taps, tap = kh*3 + kw) -> U fragments [Cout/32][4 (i)][Cin/8][4 (j)][64 lanes][4]:
+//      lane l, element e of fragment (ct, i, c8, j) = (G g G^T)[i][j] of (co = 32 ct + (l & 31), ci = 8 c8 + 4 (l >> 5) + e)
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;          // (ci quad, co): co fastest within 32 so that the 16-B stores of a half-wave are contiguous
+    const int co_lo = gid & 31, rest = gid >> 5;
+    const int nq = Cin >> 2;
+    const int cq = rest % nq, ct = rest / nq;
+    if (ct >= (Cout >> 5)) return;
+    const int co = ct * 32 + co_lo, ci = cq * 4;
+    float4 g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = *reinterpret_cast<const float4*>(w + ((long)co * 9 + t) * Cin + ci);
+    // Gg: rows i of G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+    float4 gg[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float4 a = g[c], b = g[3 + c], d = g[6 + c];
+        gg[0][c] = a; gg[3][c] = d;
+        gg[1][c] = make_float4(0.5f * (a.x + b.x + d.x), 0.5f * (a.y + b.y + d.y), 0.5f * (a.z + b.z + d.z), 0.5f * (a.w + b.w + d.w));
+        gg[2][c] = make_float4(0.5f * (a.x - b.x + d.x), 0.5f * (a.y - b.y + d.y), 0.5f * (a.z - b.z + d.z), 0.5f * (a.w - b.w + d.w));
+    }
+    const int c8 = ci >> 3, h = (ci >> 2) & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a = gg[i][0], b = gg[i][1], d = gg[i][2];
+        float4 u[4];
+        u[0] = a; u[3] = d;
+        u[1] = make_float4(0.5f * (a.x + b.x + d.x), 0.5f * (a.y + b.y + d.y), 0.5f * (a.z + b.z + d.z), 0.5f * (a.w + b.w + d.w));
+        u[2] = make_float4(0.5f * (a.x - b.x + d.x), 0.5f * (a.y - b.y + d.y), 0.5f * (a.z - b.z + d.z), 0.5f * (a.w - b.w + d.w));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(U + ((((long)(ct * 4 + i) * (Cin >> 3) + c8) * 4 + j) * 64 + (co_lo + 32 * h)) * 4) = u[j];
+    }
+}
+void launch_wino_weights(const float* w, float* U, int Cout, int Cin, hipStream_t s) {
+    const long n = (long)(Cout / 32) * (Cin / 4) * 32;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, U, Cout, Cin);
+}
+// all eligible layers of a handle in one launch: desc = {w offset, U offset, Cout, Cin} per layer, block ranges by prefix sums in `first`
+__global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* __restrict__ wbase, float* __restrict__ Ubase, const long* __restrict__ desc, int nlayers) {
+    int b = blockIdx.x, l = 0;
+    for (; l < nlayers; ++l) { const long nb = desc[l * 5 + 4]; if (b < nb) break; b -= (int)nb; }
+    if (l >= nlayers) return;
+    const float* w = wbase + desc[l * 5 + 0]; float* U = Ubase + desc[l * 5 + 1];
+    const int Cout = (int)desc[l * 5 + 2], Cin = (int)desc[l * 5 + 3];
+    const int gid = b * 256 + threadIdx.x;
+    const int co_lo = gid & 31, rest = gid >> 5;
+    const int nq = Cin >> 2;
+    const int cq = rest % nq, ct = rest / nq;
+    if (ct >= (Cout >> 5)) return;
+    const int co = ct * 32 + co_lo, ci = cq * 4;
+    float4 g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = *reinterpret_cast<const float4*>(w + ((long)co * 9 + t) * Cin + ci);
+    float4 gg[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float4 a = g[c], bb = g[3 + c], d = g[6 + c];
+        gg[0][c] = a; gg[3][c] = d;
+        gg[1][c] = make_float4(0.5f * (a.x + bb.x + d.x), 0.5f * (a.y + bb.y + d.y), 0.5f * (a.z + bb.z + d.z), 0.5f * (a.w + bb.w + d.w));
+        gg[2][c] = make_float4(0.5f * (a.x - bb.x + d.x), 0.5f * (a.y - bb.y + d.y), 0.5f * (a.z - bb.z + d.z), 0.5f * (a.w - bb.w + d.w));
+    }
+    const int c8 = ci >> 3, h = (ci >> 2) & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a = gg[i][0], bb = gg[i][1], d = gg[i][2];
+        float4 u[4];
+        u[0] = a; u[3] = d;
+        u[1] = make_float4(0.5f * (a.x + bb.x + d.x), 0.5f * (a.y + bb.y + d.y), 0.5f * (a.z + bb.z + d.z), 0.5f * (a.w + bb.w + d.w));
+        u[2] = make_float4(0.5f * (a.x - bb.x + d.x), 0.5f * (a.y - bb.y + d.y), 0.5f * (a.z - bb.z + d.z), 0.5f * (a.w - bb.w + d.w));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(U + ((((long)(ct * 4 + i) * (Cin >> 3) + c8) * 4 + j) * 64 + (co_lo + 32 * h)) * 4) = u[j];
+    }
+}
+void launch_wino_weights_batched(const float* wbase, float* Ubase, const long* desc_dev, int nlayers, int total_blocks, hipStream_t s) {
+    if (nlayers <= 0 || total_blocks <= 0) return;
+    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, s, wbase, Ubase, desc_dev, nlayers);
+}
+long wino_weight_blocks(int Cout, int Cin) { return ((long)(Cout / 32) * (Cin / 4) * 32 + 255) / 256; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NS, int XF, int BST>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int TH, int TW, int Mt, int ntp) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int COB = 32 * NS;                 // output channels per block
+    constexpr int F = 8 * NS;                    // U fragments per 16-channel chunk and wave
+    constexpr int R = 2 * NS;                    // fragment ring: loads run two j-steps (8 NS MFMAs) ahead of their use
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    // pixel tile fastest inside an XCD's contiguous id range: the blocks running together on one XCD share a cout tile, so its U slice (2 MB at Cin = 512) stays in that L2
+    const int tile_p = bid % ntp, tile_c = bid / ntp;
+    const int m0 = tile_p * WT, c0 = tile_c * COB;
+    const int THW = TH * TW;
+
+    // ---- loader constants: thread = (tile t, 16-B chunk q, column pair w2); 8 patch slots ab = w2 + 2 jj : row a = jj >> 1, column b = w2 + 2 (jj & 1)
+    const int lt = (tid >> 2) & 31, q = tid & 3, w2 = tid >> 7;
+    unsigned l_off[8], l_mask = 0;
+    {
+        const int m = m0 + lt;
+        const bool tv = m < Mt;
+        const int mm = tv ? m : 0;
+        const int n = mm / THW, r = mm - n * THW, ty = r / TW, tx = r - ty * TW;
+        const unsigned base = (unsigned)((long)n * a.x_bs) + (unsigned)(q * 4);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            int ih = 2 * ty - a.pad + (jj >> 1), iw = 2 * tx - a.pad + w2 + 2 * (jj & 1);
+            bool ok = tv;
+            if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+            else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            l_mask |= ok ? (1u << jj) : 0u;
+            l_off[jj] = ok ? (base + (unsigned)((ih * a.W + iw) * a.x_ps)) * 4u : (unsigned)(q * 16);       // masked slots read a valid dummy address
+        }
+    }
+    const int l_dst = ((w2 * 32 + lt) * 16) + ((q ^ ((lt >> 2) & 3)) << 2);        // + jj * 2 * 32 * 16 floats
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    uint4 ra[8];
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) ra[jj] = *reinterpret_cast<const uint4*>(xb + (l_off[jj] + (unsigned)(c * 64)));
+        if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 16 + q * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 16 + q * 4); }
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const unsigned mk = 0u - ((l_mask >> jj) & 1u);
+            uint4 v = ra[jj];
+            if constexpr (XF != 0) {
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
+            }
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + l_dst + jj * (2 * 32 * 16)) = v;
+        }
+    };
+
+    // ---- consumer constants: wave i = Winograd row; B^T row i combines patch rows (r1, r2): d[r1] + sg * d[r2]
+    const int wi = wave;
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int ct = lane & 31, ch = lane >> 5;
+    const int p0 = ((ch ^ ((ct >> 2) & 3)) << 2);                       // swizzled 16-B chunk of k-half ch, first 8 channels of the chunk; second 8: ^ 8 floats
+    const int rd1 = (r1 * 4 * 32 + ct) * 16, rd2 = (r2 * 4 * 32 + ct) * 16;
+
+    f32x16 acc[4][NS];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][s][e] = 0.f;
+
+    // U streams of this wave: fragment (c8, j) of cout sub-tile s at ub[s] + (c8 * 4 + j) * 256 floats
+    const int nchunks = a.Cin >> 4;
+    const int nfr = nchunks * 8;                    // fragments per stream
+    const float* ub[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ub[s] = a.wino_u + ((long)((tile_c * NS + s) * 4 + wi) * (a.Cin >> 3)) * 4 * 256 + lane * 4;
+    float4 ring[R];
+    // ring slot g % R holds fragment step g of the chunk: (fragment index fi = g / NS within the chunk, sub-tile s = g % NS)
+#pragma unroll
+    for (int g = 0; g < R; ++g) ring[g] = *reinterpret_cast<const float4*>(ub[g % NS] + (long)min(g / NS, nfr - 1) * 256);
+
+#ifdef MD2_ABLATE
+    const int abl = a.ablate;                    // tools/conv_bench: 1 = no patch loads after the first chunk, 2 = no U refills, 4 = no MFMAs, 8 = no V transform reads
+#else
+    constexpr int abl = 0;
+#endif
+    gload(0); lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int so = (c & 1) * W_STAGE;
+        if (c + 1 < nchunks && !(abl & 1)) gload(c + 1);
+        float4 V[4];
+#pragma unroll
+        for (int g = 0; g < F; ++g) {
+            const int fi = g / NS, s = g % NS, c8l = fi >> 2, j = fi & 3;
+            if (s == 0 && j == 0 && !(abl & 8 && c > 0)) {
+                // V_(i, 0..3) for this lane's tile and k-half: row combine, then the B^T column combine
+                const int pp = c8l ? (p0 ^ 8) : p0;
+                float4 rr[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + rd1 + b * (32 * 16) + pp);
+                    const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + rd2 + b * (32 * 16) + pp);
+                    rr[b] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+                }
+                V[0] = make_float4(rr[0].x - rr[2].x, rr[0].y - rr[2].y, rr[0].z - rr[2].z, rr[0].w - rr[2].w);
+                V[1] = make_float4(rr[1].x + rr[2].x, rr[1].y + rr[2].y, rr[1].z + rr[2].z, rr[1].w + rr[2].w);
+                V[2] = make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w);
+                V[3] = make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w);
+            }
+            const float4 u = ring[g % R];
+            if (!(abl & 4)) {
+            acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, V[j].x, acc[j][s], 0, 0, 0);
+            acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, V[j].y, acc[j][s], 0, 0, 0);
+            acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, V[j].z, acc[j][s], 0, 0, 0);
+            acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, V[j].w, acc[j][s], 0, 0, 0);
+            } else asm volatile("" :: "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w), "v"(V[j].x));
+            // refill this ring slot with fragment step g + R (of this or the next chunk; past the end: the last fragment again, never used)
+            const int gn = g + R, fn = c * 8 + gn / NS;
+            if (!(abl & 2)) ring[g % R] = *reinterpret_cast<const float4*>(ub[gn % NS] + (long)min(fn, nfr - 1) * 256);
+        }
+        if (c + 1 < nchunks && !(abl & 1)) lstore(W_STAGE - so);
+        __syncthreads();
+    }
+
+    // ---- output transform.  Column half in registers: R_b = sum_j M[i][j] A^T[b][j]  (A^T = [1 1 1 0; 0 1 -1 -1])
+    constexpr int RLD = COB + 4;
+    float* Rl = wsm;                             // [4 (i)][2 (b)][32 tiles][RLD]
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 o0, o1;
+            o0.x = acc[0][s][4 * g + 0] + acc[1][s][4 * g + 0] + acc[2][s][4 * g + 0]; o1.x = acc[1][s][4 * g + 0] - acc[2][s][4 * g + 0] - acc[3][s][4 * g + 0];
+            o0.y = acc[0][s][4 * g + 1] + acc[1][s][4 * g + 1] + acc[2][s][4 * g + 1]; o1.y = acc[1][s][4 * g + 1] - acc[2][s][4 * g + 1] - acc[3][s][4 * g + 1];
+            o0.z = acc[0][s][4 * g + 2] + acc[1][s][4 * g + 2] + acc[2][s][4 * g + 2]; o1.z = acc[1][s][4 * g + 2] - acc[2][s][4 * g + 2] - acc[3][s][4 * g + 2];
+            o0.w = acc[0][s][4 * g + 3] + acc[1][s][4 * g + 3] + acc[2][s][4 * g + 3]; o1.w = acc[1][s][4 * g + 3] - acc[2][s][4 * g + 3] - acc[3][s][4 * g + 3];
+            const int col = s * 32 + 8 * g + 4 * ch;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * 32 + ct) * RLD + col) = o0;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * 32 + ct) * RLD + col) = o1;
+        }
+    __syncthreads();
+    // ---- row half + epilogue: QN lanes own the COB channels of one pixel
+    constexpr int QN = COB / 4, RP = 256 / QN;
+    const int q4 = (tid % QN) * 4, rr0 = tid / QN, co = c0 + q4;
+    const bool want_st = a.stats != nullptr, want_b = BST != 0 && a.bst != nullptr;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;
+    float4 bias4 = s1, dsc = s1, dsh = s1, muA = s1, isA = s1, muB = s1, isB = s1;
+    if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + co);
+    if (a.dact_scale) { dsc = *reinterpret_cast<const float4*>(a.dact_scale + co); dsh = *reinterpret_cast<const float4*>(a.dact_shift + co); }
+    if constexpr (BST != 0) if (want_b) {
+        muA = *reinterpret_cast<const float4*>(a.bstat + co); isA = *reinterpret_cast<const float4*>(a.bstat + a.Cout + co);
+        if (a.bstB) { muB = *reinterpret_cast<const float4*>(a.bstatB + co); isB = *reinterpret_cast<const float4*>(a.bstatB + a.Cout + co); }
+    }
+#pragma unroll 1
+    for (int p = 0; p < WT / RP; ++p) {
+        const int t = p * RP + rr0, m = m0 + t;
+        if (m >= Mt) continue;
+        const int n = m / THW, r = m - n * THW, ty = r / TW, tx = r - ty * TW;
+        float4 Rv[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) Rv[i][b] = *reinterpret_cast<const float4*>(Rl + ((i * 2 + b) * 32 + t) * RLD + q4);
+#pragma unroll
+        for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const int oy = 2 * ty + oa, ox = 2 * tx + ob;
+                if (oy >= a.Ho || ox >= a.Wo) continue;
+                float4 v;
+                if (oa == 0) { v.x = Rv[0][ob].x + Rv[1][ob].x + Rv[2][ob].x; v.y = Rv[0][ob].y + Rv[1][ob].y + Rv[2][ob].y; v.z = Rv[0][ob].z + Rv[1][ob].z + Rv[2][ob].z; v.w = Rv[0][ob].w + Rv[1][ob].w + Rv[2][ob].w; }
+                else { v.x = Rv[1][ob].x - Rv[2][ob].x - Rv[3][ob].x; v.y = Rv[1][ob].y - Rv[2][ob].y - Rv[3][ob].y; v.z = Rv[1][ob].z - Rv[2][ob].z - Rv[3][ob].z; v.w = Rv[1][ob].w - Rv[2][ob].w - Rv[3][ob].w; }
+                const long pix = (long)oy * a.Wo + ox;
+                if (a.res) { const float4 tt = *reinterpret_cast<const float4*>(a.res + (long)n * a.res_bs + pix * a.res_ps + co); v.x += tt.x; v.y += tt.y; v.z += tt.z; v.w += tt.w; }
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if (a.act != ACT_NONE) { v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act); }
+                if (a.dact_src) {
+                    float4 d = *reinterpret_cast<const float4*>(a.dact_src + (long)n * a.da_bs + pix * a.da_ps + co);
+                    if (a.dact_scale) { d.x = fmaf(d.x, dsc.x, dsh.x); d.y = fmaf(d.y, dsc.y, dsh.y); d.z = fmaf(d.z, dsc.z, dsh.z); d.w = fmaf(d.w, dsc.w, dsh.w); }
+                    v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact);
+                }
+                float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co;
+                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *reinterpret_cast<float4*>(yp) = v;
+                if (want_st) { s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
+                if constexpr (BST != 0) if (want_b) {
+                    const float4 z = *reinterpret_cast<const float4*>(a.bz + (long)n * a.bz_bs + pix * a.bz_ps + co);
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                    s2.x += v.x * ((z.x - muA.x) * isA.x); s2.y += v.y * ((z.y - muA.y) * isA.y); s2.z += v.z * ((z.z - muA.z) * isA.z); s2.w += v.w * ((z.w - muA.w) * isA.w);
+                    if (a.bstB) {
+                        const float4 zb = *reinterpret_cast<const float4*>(a.bzB + (long)n * a.bzB_bs + pix * a.bzB_ps + co);
+                        s3.x += v.x * ((zb.x - muB.x) * isB.x); s3.y += v.y * ((zb.y - muB.y) * isB.y); s3.z += v.z * ((zb.z - muB.z) * isB.z); s3.w += v.w * ((zb.w - muB.w) * isB.w);
+                    }
+                }
+            }
+    }
+    if (!(want_st || want_b)) return;                  // block-uniform
+    // column sums: the RP threads that share a channel quad meet in LDS; thread (k, channel) then adds the block's total with one double atomic
+    __syncthreads();
+    float* Rs = wsm;                                   // [3][4][256]
+    Rs[0 * 256 + tid] = s1.x; Rs[1 * 256 + tid] = s1.y; Rs[2 * 256 + tid] = s1.z; Rs[3 * 256 + tid] = s1.w;
+    Rs[1024 + 0 * 256 + tid] = s2.x; Rs[1024 + 1 * 256 + tid] = s2.y; Rs[1024 + 2 * 256 + tid] = s2.z; Rs[1024 + 3 * 256 + tid] = s2.w;
+    Rs[2048 + 0 * 256 + tid] = s3.x; Rs[2048 + 1 * 256 + tid] = s3.y; Rs[2048 + 2 * 256 + tid] = s3.z; Rs[2048 + 3 * 256 + tid] = s3.w;
+    __syncthreads();
+    if (tid < 3 * COB) {
+        const int k = tid / COB, chn = tid % COB, qq = chn >> 2, e = chn & 3;
+        float sum = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < RP; ++g) sum += Rs[k * 1024 + e * 256 + g * QN + qq];
+        const size_t slot = (size_t)(blockIdx.x % BN_STAT_SLOTS) * 2 * a.Cout;
+        if (want_st) { if (k < 2) atomicAdd(a.stats + slot + k * a.Cout + c0 + chn, (double)sum); }
+        else if (k == 0) { atomicAdd(a.bst + slot + c0 + chn, (double)sum); if (a.bstB) atomicAdd(a.bstB + slot + c0 + chn, (double)sum); }
+        else if (k == 1) atomicAdd(a.bst + slot + a.Cout + c0 + chn, (double)sum);
+        else if (a.bstB) atomicAdd(a.bstB + slot + a.Cout + c0 + chn, (double)sum);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second-generation kernel for the layers with many tiles (Cin % 8 == 0, Cout % 64 == 0): 512 threads = 8 waves, block tile = 64 Winograd tiles x 64 output
+// channels, 8-channel K chunks.  Measured on the first kernel (tools/conv_bench ablations, 96x32x104, 512 -> 64): MFMAs alone 0.68 ms, operand loads alone 0.88 ms
+// (the U fragments 0.65 of it, at 4 KB in flight per wave) -- it is bound by L2 -> CU operand traffic, not by the matrix pipe.  So, per multiply:
+//   * U: half the traffic -- the two waves (i, tile half 0 / 1) that need the same fragments share them.  The 32 fragments of a chunk (32 KB, fragment order = lane-linear
+//     1-KB pieces) are copied into an LDS double buffer one whole chunk ahead, 4 per wave: no per-fragment waits.
+//   * patches: horizontally adjacent tiles share two of their four columns.  The block's 64 consecutive tiles are cut into row segments; a segment of L tiles stages
+//     4 rows x (2 L + 2) pixels once instead of 16 L pixel slots (~1.9x fewer gathered bytes and LDS).
+//   * everything a chunk needs is loaded to registers at the top of the previous chunk and committed to LDS right before that chunk's single barrier.
+// One workgroup per CU (139 KB of LDS in the epilogue, 256 registers): the layers with few tiles (1/16, 1/32 scale) stay on the 256-thread kernel above.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int W2_T = 64, W2_NLI = 4;
+struct Wino2Geo { int TH, TW, Mt, ntp, nslots; };      // nslots: patch slots allocated per stage (host: worst case over the blocks), multiple of 16
+
+template <int NTHR, int COB, int BST>
+__device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __restrict__ wsm, const int m0, const int ntile, const int Mt, const int THW, const int TW, const int c0, const int tid) {
+    // R[i][b][tile][COB + 4] holds the column-transformed sums; QN lanes own the COB channels of one pixel.  Same contract as conv_igemm_kernel's epilogue.
+    constexpr int RLD = COB + 4, QN = COB / 4, RP = NTHR / QN;
+    const float* Rl = wsm;
+    const int q4 = (tid % QN) * 4, rr0 = tid / QN, co = c0 + q4;
+    const bool want_st = a.stats != nullptr, want_b = BST != 0 && a.bst != nullptr;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;
+    float4 bias4 = s1, dsc = s1, dsh = s1, muA = s1, isA = s1, muB = s1, isB = s1;
+    if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + co);
+    if (a.dact_scale) { dsc = *reinterpret_cast<const float4*>(a.dact_scale + co); dsh = *reinterpret_cast<const float4*>(a.dact_shift + co); }
+    if constexpr (BST != 0) if (want_b) {
+        muA = *reinterpret_cast<const float4*>(a.bstat + co); isA = *reinterpret_cast<const float4*>(a.bstat + a.Cout + co);
+        if (a.bstB) { muB = *reinterpret_cast<const float4*>(a.bstatB + co); isB = *reinterpret_cast<const float4*>(a.bstatB + a.Cout + co); }
+    }
+#pragma unroll 1
+    for (int p = 0; p < ntile / RP; ++p) {
+        const int t = p * RP + rr0, m = m0 + t;
+        if (m >= Mt) continue;
+        const int n = m / THW, r = m - n * THW, ty = r / TW, tx = r - ty * TW;
+        float4 Rv[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) Rv[i][b] = *reinterpret_cast<const float4*>(Rl + ((i * 2 + b) * ntile + t) * RLD + q4);
+#pragma unroll
+        for (int oa = 0; oa < 2; ++oa)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const int oy = 2 * ty + oa, ox = 2 * tx + ob;
+                if (oy >= a.Ho || ox >= a.Wo) continue;
+                float4 v;
+                if (oa == 0) { v.x = Rv[0][ob].x + Rv[1][ob].x + Rv[2][ob].x; v.y = Rv[0][ob].y + Rv[1][ob].y + Rv[2][ob].y; v.z = Rv[0][ob].z + Rv[1][ob].z + Rv[2][ob].z; v.w = Rv[0][ob].w + Rv[1][ob].w + Rv[2][ob].w; }
+                else { v.x = Rv[1][ob].x - Rv[2][ob].x - Rv[3][ob].x; v.y = Rv[1][ob].y - Rv[2][ob].y - Rv[3][ob].y; v.z = Rv[1][ob].z - Rv[2][ob].z - Rv[3][ob].z; v.w = Rv[1][ob].w - Rv[2][ob].w - Rv[3][ob].w; }
+                const long pix = (long)oy * a.Wo + ox;
+                if (a.res) { const float4 tt = *reinterpret_cast<const float4*>(a.res + (long)n * a.res_bs + pix * a.res_ps + co); v.x += tt.x; v.y += tt.y; v.z += tt.z; v.w += tt.w; }
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if (a.act != ACT_NONE) { v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act); }
+                if (a.dact_src) {
+                    float4 d = *reinterpret_cast<const float4*>(a.dact_src + (long)n * a.da_bs + pix * a.da_ps + co);
+                    if (a.dact_scale) { d.x = fmaf(d.x, dsc.x, dsh.x); d.y = fmaf(d.y, dsc.y, dsh.y); d.z = fmaf(d.z, dsc.z, dsh.z); d.w = fmaf(d.w, dsc.w, dsh.w); }
+                    v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact);
+                }
+                float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co;
+                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *reinterpret_cast<float4*>(yp) = v;
+                if (want_st) { s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
+                if constexpr (BST != 0) if (want_b) {
+                    const float4 z = *reinterpret_cast<const float4*>(a.bz + (long)n * a.bz_bs + pix * a.bz_ps + co);
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                    s2.x += v.x * ((z.x - muA.x) * isA.x); s2.y += v.y * ((z.y - muA.y) * isA.y); s2.z += v.z * ((z.z - muA.z) * isA.z); s2.w += v.w * ((z.w - muA.w) * isA.w);
+                    if (a.bstB) {
+                        const float4 zb = *reinterpret_cast<const float4*>(a.bzB + (long)n * a.bzB_bs + pix * a.bzB_ps + co);
+                        s3.x += v.x * ((zb.x - muB.x) * isB.x); s3.y += v.y * ((zb.y - muB.y) * isB.y); s3.z += v.z * ((zb.z - muB.z) * isB.z); s3.w += v.w * ((zb.w - muB.w) * isB.w);
+                    }
+                }
+            }
+    }
+    if (!(want_st || want_b)) return;                  // block-uniform
+    __syncthreads();
+    float* Rs = wsm;                                   // [3][4][NTHR]
+    Rs[0 * NTHR + tid] = s1.x; Rs[1 * NTHR + tid] = s1.y; Rs[2 * NTHR + tid] = s1.z; Rs[3 * NTHR + tid] = s1.w;
+    Rs[4 * NTHR + 0 * NTHR + tid] = s2.x; Rs[4 * NTHR + 1 * NTHR + tid] = s2.y; Rs[4 * NTHR + 2 * NTHR + tid] = s2.z; Rs[4 * NTHR + 3 * NTHR + tid] = s2.w;
+    Rs[8 * NTHR + 0 * NTHR + tid] = s3.x; Rs[8 * NTHR + 1 * NTHR + tid] = s3.y; Rs[8 * NTHR + 2 * NTHR + tid] = s3.z; Rs[8 * NTHR + 3 * NTHR + tid] = s3.w;
+    __syncthreads();
+    if (tid < 3 * COB) {
+        const int k = tid / COB, chn = tid % COB, qq = chn >> 2, e = chn & 3;
+        float sum = 0.f;
+#pragma unroll 4
+        for (int g = 0; g < RP; ++g) sum += Rs[k * 4 * NTHR + e * NTHR + g * QN + qq];
+        const size_t slot = (size_t)(blockIdx.x % BN_STAT_SLOTS) * 2 * a.Cout;
+        if (want_st) { if (k < 2) atomicAdd(a.stats + slot + k * a.Cout + c0 + chn, (double)sum); }
+        else if (k == 0) { atomicAdd(a.bst + slot + c0 + chn, (double)sum); if (a.bstB) atomicAdd(a.bstB + slot + c0 + chn, (double)sum); }
+        else if (k == 1) atomicAdd(a.bst + slot + a.Cout + c0 + chn, (double)sum);
+        else if (a.bstB) atomicAdd(a.bstB + slot + a.Cout + c0 + chn, (double)sum);
+    }
+}
+
+template <int XF, int BST>
+__global__ __launch_bounds__(512, 2) void conv_wino64_kernel(ConvArgs a, Wino2Geo geo) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int COB = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
+    const int PST = geo.nslots * 8 + 256;            // floats per patch stage: [slot][8 channels] + a 1-KB dummy row for the loader's inactive items
+    float* const Ubuf = wsm + 2 * PST;               // [2][32 fragments][256 floats]
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_p = bid % ntp, tile_c = bid / ntp;
+    const int m0 = tile_p * W2_T, c0 = tile_c * COB;
+    const int THW = TH * TW;
+    // ---- row segments of the block's 64 consecutive tiles: segment 0 = tiles up to the end of the first tile row, then whole rows
+    const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
+    const int L0 = min(TW - tx0, W2_T);
+    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, W2_T), S = 4 * (2 * Lf + 2);
+    const int n_rows_total = a.N * TH;
+
+    // ---- loader: item f = tid + 512 li = (slot f >> 1, 16-B half f & 1) of a stage; pixel address, validity and LDS position are fixed for the whole K loop
+    unsigned l_off[W2_NLI]; int l_dst[W2_NLI]; unsigned l_ok = 0;
+    const int h2 = tid & 1;
+#pragma unroll
+    for (int li = 0; li < W2_NLI; ++li) {
+        const int slot = (tid + 512 * li) >> 1;
+        int k, r, WP, txa, Lk;
+        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
+        else { const int s2 = slot - S0; k = 1 + s2 / S; r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, W2_T - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
+        const int pa = r / WP, pc = r - pa * WP;
+        const int rr = rr_first + k;
+        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+        const int rrc = act ? rr : 0;
+        const int n = rrc / TH, ty = rrc - n * TH;
+        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+        bool ok = act;
+        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        l_ok |= ok ? (1u << li) : 0u;
+        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(h2 * 4)) * 4u : (unsigned)(h2 * 16);
+        // inactive items store into a per-lane dummy row behind the stage instead of branching around the store: with conditional stores hipcc sinks each prefetch
+        // load into the branch of its store (load -> wait -> store at the bottom of the chunk: no prefetch at all)
+        l_dst[li] = act ? slot * 8 + ((h2 ^ ((slot >> 3) & 1)) << 2) : geo.nslots * 8 + lane * 4;
+    }
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    uint4 ra[W2_NLI];
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int li = 0; li < W2_NLI; ++li) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 32)));
+        if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 8 + h2 * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 8 + h2 * 4); }
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < W2_NLI; ++li) {
+            const unsigned mk = 0u - ((l_ok >> li) & 1u);
+            uint4 v = ra[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));          // pins the mask / transform arithmetic (and the loads' wait) here: instruction selection
+                                                                                    // otherwise floats these pure ALU nodes to the top of the block, above both sched_barriers
+            if constexpr (XF != 0) {
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
+            }
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + l_dst[li]) = v;
+        }
+    };
+    // ---- U: fragment fidx = (i * 4 + j) * 2 + s of chunk c8 -> Ubuf[c8 & 1][fidx]; wave w copies fragments 4 w .. 4 w + 3
+    const int nchunks = a.Cin >> 3;
+    const float* usrc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int fidx = wave * 4 + e, fi = fidx >> 3, fj = (fidx >> 1) & 3, fs = fidx & 1;
+        usrc[e] = a.wino_u + (((long)((tile_c * 2 + fs) * 4 + fi) * nchunks) * 4 + fj) * 256 + lane * 4;          // + c8 * 1024 floats
+    }
+    // (register-staged like the patches: with global_load_lds hipcc drains vmcnt(0) before the first ds_read of every chunk -- an LDS-DMA may alias any LDS read --
+    //  which serialises the prefetch with the chunk it was meant to overlap; ordinary loads get counted waits at their use, the ds_write at the bottom of the chunk)
+    f32x4 uv0, uv1, uv2, uv3;
+#define W2_ULOAD(c_) do { const long o_ = (long)(c_) * 1024; uv0 = *reinterpret_cast<const f32x4*>(usrc[0] + o_); uv1 = *reinterpret_cast<const f32x4*>(usrc[1] + o_); \
+                          uv2 = *reinterpret_cast<const f32x4*>(usrc[2] + o_); uv3 = *reinterpret_cast<const f32x4*>(usrc[3] + o_); } while (0)
+#define W2_USTORE(c_) do { float* d_ = Ubuf + ((c_) & 1) * 8192 + wave * 4 * 256 + lane * 4; *reinterpret_cast<f32x4*>(d_) = uv0; *reinterpret_cast<f32x4*>(d_ + 256) = uv1; \
+                           *reinterpret_cast<f32x4*>(d_ + 512) = uv2; *reinterpret_cast<f32x4*>(d_ + 768) = uv3; } while (0)
+
+    // ---- consumer: wave = (Winograd row i, tile half th); lane = (tile, k-half)
+    const int wi = wave & 3, th = wave >> 2;
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int ct = th * 32 + (lane & 31), ch = lane >> 5;
+    int c_off1[4], c_off2[4];
+    {
+        const int u = tx0 + ct, k = u / TW;
+        const int lc = (k == 0) ? ct : (u - k * TW);
+        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, W2_T - L0 - (k - 1) * TW) + 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
+            c_off1[b] = sl1 * 8 + ((ch ^ ((sl1 >> 3) & 1)) << 2);
+            c_off2[b] = sl2 * 8 + ((ch ^ ((sl2 >> 3) & 1)) << 2);
+        }
+    }
+    const int u_rd = (wi * 4) * 2 * 256 + lane * 4;             // + (j * 2 + s) * 256
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][s][e] = 0.f;
+
+#ifdef MD2_ABLATE
+    const int abl = a.ablate;
+#else
+    constexpr int abl = 0;
+#endif
+    W2_ULOAD(0);
+    gload(0);
+    W2_USTORE(0); lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int so = (c & 1) * PST;
+        const float* ub = Ubuf + (c & 1) * 8192 + u_rd;
+        const int cn = min(c + 1, nchunks - 1);          // past the end: the last chunk again, into the stage nobody reads any more (keeps the loop body branch-free)
+        if (!(abl & 2)) W2_ULOAD(cn);
+        if (!(abl & 1)) gload(cn);
+        __builtin_amdgcn_sched_barrier(0);             // the prefetch is issued here, before the chunk's arithmetic
+        float4 V[4];
+        {
+            float4 rr[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + c_off1[b]);
+                const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + c_off2[b]);
+                rr[b] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+            }
+            V[0] = make_float4(rr[0].x - rr[2].x, rr[0].y - rr[2].y, rr[0].z - rr[2].z, rr[0].w - rr[2].w);
+            V[1] = make_float4(rr[1].x + rr[2].x, rr[1].y + rr[2].y, rr[1].z + rr[2].z, rr[1].w + rr[2].w);
+            V[2] = make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w);
+            V[3] = make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float4 u = *reinterpret_cast<const float4*>(ub + (j * 2 + s) * 256);
+                if (!(abl & 4)) {
+                acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, V[j].x, acc[j][s], 0, 0, 0);
+                acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, V[j].y, acc[j][s], 0, 0, 0);
+                acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, V[j].z, acc[j][s], 0, 0, 0);
+                acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, V[j].w, acc[j][s], 0, 0, 0);
+                } else asm volatile("" :: "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w), "v"(V[j].x));
+            }
+        __builtin_amdgcn_sched_barrier(0);             // ... and committed here, behind it (hipcc otherwise hoists the padding masks, and with them the loads' wait, to the top)
+        if (!(abl & 2)) W2_USTORE(c + 1);          // (the loads of chunk c + 1 are waited for here, at their use)
+        if (!(abl & 1)) lstore(PST - so);
+        __syncthreads();
+    }
+
+    // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4], 139 KB: the pipeline buffers are dead)
+    constexpr int RLD = COB + 4;
+    float* Rl = wsm;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 o0, o1;
+            o0.x = acc[0][s][4 * g + 0] + acc[1][s][4 * g + 0] + acc[2][s][4 * g + 0]; o1.x = acc[1][s][4 * g + 0] - acc[2][s][4 * g + 0] - acc[3][s][4 * g + 0];
+            o0.y = acc[0][s][4 * g + 1] + acc[1][s][4 * g + 1] + acc[2][s][4 * g + 1]; o1.y = acc[1][s][4 * g + 1] - acc[2][s][4 * g + 1] - acc[3][s][4 * g + 1];
+            o0.z = acc[0][s][4 * g + 2] + acc[1][s][4 * g + 2] + acc[2][s][4 * g + 2]; o1.z = acc[1][s][4 * g + 2] - acc[2][s][4 * g + 2] - acc[3][s][4 * g + 2];
+            o0.w = acc[0][s][4 * g + 3] + acc[1][s][4 * g + 3] + acc[2][s][4 * g + 3]; o1.w = acc[1][s][4 * g + 3] - acc[2][s][4 * g + 3] - acc[3][s][4 * g + 3];
+            const int col = s * 32 + 8 * g + 4 * ch;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * W2_T + ct) * RLD + col) = o0;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * W2_T + ct) * RLD + col) = o1;
+        }
+    __syncthreads();
+    wino_final_epilogue<512, COB, BST>(a, wsm, m0, W2_T, Mt, THW, TW, c0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Third kernel: what the two above taught, combined.  256 threads (wave = Winograd row i), TWO independent workgroups per CU -- one workgroup's MFMAs run under the other's
+// LDS / transform / commit phases, which a single lockstep 8-wave workgroup cannot do (conv_wino64_kernel: skeleton without MFMAs and loads = 0.28 of 1.02 ms).
+// Block tile = 64 tiles x 32 output channels, 8-channel chunks:
+//   * a wave contracts BOTH 32-tile halves against the same U fragment (8 MFMAs per 1-KB fragment: half the U traffic per multiply of conv_wino_kernel), and the
+//     fragment is private to the wave, so it goes global -> registers with no LDS round trip.  Ring of 4 fragments refilled IN PLACE: slot j is reloaded with chunk c + 1's
+//     fragment right after chunk c's last use -- a full chunk of prefetch distance for 16 registers, and every U load is older than the patch loads issued after it, so its
+//     counted wait never waits for them;
+//   * row-segment patch staging as in conv_wino64_kernel (each staged pixel serves two tiles), branch-free loader, commit pinned behind the chunk's MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NLI, int XF, int BST>
+__global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo geo) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int COB = 32;
+    constexpr int PST = 128 * NLI * 8;               // floats per patch stage: every (slot, half) item of the loader has a real slot (those past geo.nslots are never read)
+    const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_p = bid % ntp, tile_c = bid / ntp;
+    const int m0 = tile_p * W2_T, c0 = tile_c * COB;
+    const int THW = TH * TW;
+    const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
+    const int L0 = min(TW - tx0, W2_T);
+    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, W2_T), S = 4 * (2 * Lf + 2);
+    const int n_rows_total = a.N * TH;
+
+    // ---- loader: item f = tid + 256 li = (slot f >> 1, 16-B half f & 1); LDS position = slot * 8 + swizzled half, i.e. l_dst0 + li * 1024 floats
+    unsigned l_off[NLI]; unsigned l_ok = 0;
+    const int h2 = tid & 1;
+    const int l_dst0 = (tid >> 1) * 8 + ((h2 ^ ((tid >> 4) & 1)) << 2);
+#pragma unroll
+    for (int li = 0; li < NLI; ++li) {
+        const int slot = (tid + 256 * li) >> 1;
+        int k, r, WP, txa, Lk;
+        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
+        else { const int s2 = slot - S0; k = 1 + s2 / S; r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, W2_T - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
+        const int pa = r / WP, pc = r - pa * WP;
+        const int rr = rr_first + k;
+        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+        const int rrc = act ? rr : 0;
+        const int n = rrc / TH, ty = rrc - n * TH;
+        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+        bool ok = act;
+        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        l_ok |= ok ? (1u << li) : 0u;
+        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(h2 * 4)) * 4u : (unsigned)(h2 * 16);
+    }
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    uint4 ra[NLI];
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 32)));
+        if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 8 + h2 * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 8 + h2 * 4); }
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            const unsigned mk = 0u - ((l_ok >> li) & 1u);
+            uint4 v = ra[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));          // pins the mask / transform arithmetic (and the loads' wait) at the commit point
+            if constexpr (XF != 0) {
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
+            }
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 1024) = v;
+        }
+    };
+
+    // ---- consumer: lane = (tile within a 32-tile half, k-half); B^T row i combines patch rows (r1, r2)
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int tl = lane & 31, ch = lane >> 5;
+    int c_off1[2][4], c_off2[2][4];
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+        const int ct = th * 32 + tl;
+        const int u = tx0 + ct, k = u / TW;
+        const int lc = (k == 0) ? ct : (u - k * TW);
+        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, W2_T - L0 - (k - 1) * TW) + 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
+            c_off1[th][b] = sl1 * 8 + ((ch ^ ((sl1 >> 3) & 1)) << 2);
+            c_off2[th][b] = sl2 * 8 + ((ch ^ ((sl2 >> 3) & 1)) << 2);
+        }
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][t][e] = 0.f;
+
+    // U stream of this wave: fragment (c8, j) of cout sub-tile tile_c at ub + (c8 * 4 + j) * 256 floats
+    const int nchunks = a.Cin >> 3;
+    const float* ub = a.wino_u + ((long)(tile_c * 4 + wi) * nchunks) * 4 * 256 + lane * 4;
+    f32x4 uf0 = *reinterpret_cast<const f32x4*>(ub), uf1 = *reinterpret_cast<const f32x4*>(ub + 256), uf2 = *reinterpret_cast<const f32x4*>(ub + 512), uf3 = *reinterpret_cast<const f32x4*>(ub + 768);
+
+#ifdef MD2_ABLATE
+    const int abl = a.ablate;
+#else
+    constexpr int abl = 0;
+#endif
+    gload(0); lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int so = (c & 1) * PST;
+        const int cn = min(c + 1, nchunks - 1);          // past the end: the last chunk again, into the stage nobody reads any more (keeps the loop body branch-free)
+        const float* un = ub + (long)cn * 1024;
+        if (!(abl & 1)) gload(cn);
+        __builtin_amdgcn_sched_barrier(0);
+#define W3_MFMA(th_, j_, uf_) do { if (!(abl & 4)) { \
+                acc[j_][th_] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf_[0], V[j_].x, acc[j_][th_], 0, 0, 0); \
+                acc[j_][th_] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf_[1], V[j_].y, acc[j_][th_], 0, 0, 0); \
+                acc[j_][th_] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf_[2], V[j_].z, acc[j_][th_], 0, 0, 0); \
+                acc[j_][th_] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf_[3], V[j_].w, acc[j_][th_], 0, 0, 0); \
+            } else asm volatile("" :: "v"(uf_[0]), "v"(uf_[1]), "v"(uf_[2]), "v"(uf_[3]), "v"(V[j_].x)); } while (0)
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+            float4 V[4];
+            {
+                float4 rr[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + c_off1[th][b]);
+                    const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + c_off2[th][b]);
+                    rr[b] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+                }
+                V[0] = make_float4(rr[0].x - rr[2].x, rr[0].y - rr[2].y, rr[0].z - rr[2].z, rr[0].w - rr[2].w);
+                V[1] = make_float4(rr[1].x + rr[2].x, rr[1].y + rr[2].y, rr[1].z + rr[2].z, rr[1].w + rr[2].w);
+                V[2] = make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w);
+                V[3] = make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w);
+            }
+            W3_MFMA(th, 0, uf0); W3_MFMA(th, 1, uf1); W3_MFMA(th, 2, uf2); W3_MFMA(th, 3, uf3);
+        }
+        if (!(abl & 2)) {          // in-place refill: chunk c + 1's fragments, a full chunk before their use
+            uf0 = *reinterpret_cast<const f32x4*>(un); uf1 = *reinterpret_cast<const f32x4*>(un + 256); uf2 = *reinterpret_cast<const f32x4*>(un + 512); uf3 = *reinterpret_cast<const f32x4*>(un + 768);
+        }
+#undef W3_MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 1)) lstore(PST - so);
+        __syncthreads();
+    }
+
+    // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4])
+    constexpr int RLD = COB + 4;
+    float* Rl = wsm;
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 o0, o1;
+            o0.x = acc[0][th][4 * g + 0] + acc[1][th][4 * g + 0] + acc[2][th][4 * g + 0]; o1.x = acc[1][th][4 * g + 0] - acc[2][th][4 * g + 0] - acc[3][th][4 * g + 0];
+            o0.y = acc[0][th][4 * g + 1] + acc[1][th][4 * g + 1] + acc[2][th][4 * g + 1]; o1.y = acc[1][th][4 * g + 1] - acc[2][th][4 * g + 1] - acc[3][th][4 * g + 1];
+            o0.z = acc[0][th][4 * g + 2] + acc[1][th][4 * g + 2] + acc[2][th][4 * g + 2]; o1.z = acc[1][th][4 * g + 2] - acc[2][th][4 * g + 2] - acc[3][th][4 * g + 2];
+            o0.w = acc[0][th][4 * g + 3] + acc[1][th][4 * g + 3] + acc[2][th][4 * g + 3]; o1.w = acc[1][th][4 * g + 3] - acc[2][th][4 * g + 3] - acc[3][th][4 * g + 3];
+            const int col = 8 * g + 4 * ch, ct = th * 32 + tl;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * W2_T + ct) * RLD + col) = o0;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * W2_T + ct) * RLD + col) = o1;
+        }
+    __syncthreads();
+    wino_final_epilogue<256, COB, BST>(a, wsm, m0, W2_T, Mt, THW, TW, c0, tid);
+}
+
+// patch slots a block can need at tile-row width TW: worst case over the position of its first tile
+static int wino2_slots(int TW) {
+    const int Lf = std::min(TW, W2_T), S = 4 * (2 * Lf + 2);
+    int worst = 0;
+    for (int tx0 = 0; tx0 < TW; ++tx0) {
+        const int L0 = std::min(TW - tx0, W2_T);
+        const int rest = W2_T - L0, nfull = rest / TW, Lr = rest - nfull * TW;          // whole rows, then a short last segment with rows as wide as it needs
+        worst = std::max(worst, 4 * (2 * L0 + 2) + nfull * S + (Lr ? 4 * (2 * Lr + 2) : 0));
+    }
+    return (worst + 15) / 16 * 16;
+}
+static long g_wino2_min_tiles = getenv("MD2_WINO2_MIN_TILES") ? atol(getenv("MD2_WINO2_MIN_TILES")) : (1L << 40);          // (measured slower than the third kernel everywhere: only on request)
+
+static bool wino2_eligible(const ConvArgs& a, Wino2Geo& g) {
+    static const bool off = getenv("MD2_NO_WINO2") != nullptr;
+    if (off || g_wino_on == 2 || a.Cout % 64 != 0 || a.Cin % 8 != 0) return false;
+    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW; g.ntp = (g.Mt + W2_T - 1) / W2_T;
+    g.nslots = wino2_slots(g.TW);
+    if (g.nslots * 2 > 512 * W2_NLI) return false;                // more (slot, half) items than the loader's 4 per thread
+    return g_wino_on == 3 || (long)g.Mt * (a.Cout / 64) >= g_wino2_min_tiles;
+}
+// third kernel: Cout % 32 == 0, Cin % 8 == 0, up to 640 patch slots per stage (tile rows of at least 4 tiles)
+static long g_wino3_min_tiles = getenv("MD2_WINO3_MIN_TILES") ? atol(getenv("MD2_WINO3_MIN_TILES")) : 8192;
+static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g) {
+    static const bool off = getenv("MD2_NO_WINO3") != nullptr;
+    if (off || g_wino_on == 2 || g_wino_on == 3 || a.Cout % 32 != 0 || a.Cin % 8 != 0) return false;
+    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW; g.ntp = (g.Mt + W2_T - 1) / W2_T;
+    g.nslots = wino2_slots(g.TW);
+    if (g.nslots > 128 * 5) return false;
+    return g_wino_on == 4 || (long)g.Mt * (a.Cout / 32) >= g_wino3_min_tiles;
+}
+template <int NLI>
+static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
+    constexpr size_t lds_pipe = (size_t)2 * 128 * NLI * 8 * sizeof(float), lds_epi = (size_t)8 * W2_T * (32 + 4) * sizeof(float);
+    constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = g.ntp * (a.Cout / 32);
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 1, 0>), dim3(grid), dim3(256), lds, s, a, g);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 1>), dim3(grid), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0>), dim3(grid), dim3(256), lds, s, a, g);
+}
+static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) { launch_wino3_t<5>(a, g, s); }
+static void launch_wino2(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
+    const size_t lds_pipe = ((size_t)2 * (g.nslots * 8 + 256) + 2 * 8192) * sizeof(float), lds_epi = (size_t)8 * W2_T * (64 + 4) * sizeof(float);
+    const size_t lds = std::max(lds_pipe, lds_epi);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino64_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino64_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino64_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = g.ntp * (a.Cout / 64);
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino64_kernel<1, 0>), dim3(grid), dim3(512), lds, s, a, g);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino64_kernel<0, 1>), dim3(grid), dim3(512), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino64_kernel<0, 0>), dim3(grid), dim3(512), lds, s, a, g);
+}
+
+int g_wino_on = getenv("MD2_NO_WINO") ? 0 : (getenv("MD2_WINO_MODE") ? atoi(getenv("MD2_WINO_MODE")) : 1);          // MD2_WINO_MODE=2/3/4: pin one kernel (md2_set_winograd)
+int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 96;
+
+// 3x3, stride 1, dense output lattice, no split-K, fp32; Cin % 16, Cout % 32
+bool conv_wino_eligible(const ConvArgs& a) {
+    if (!g_wino_on || !a.wino_u || a.bf16) return false;
+    if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.oy0 == 0 && a.ox0 == 0 && a.Hl == a.Ho && a.Wl == a.Wo)) return false;
+    if (a.Cin % 16 != 0 || a.Cout % 32 != 0 || a.acc_lat) return false;
+    if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
+    if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
+    const long tiles = (long)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2);
+    const int cob = a.Cout % 64 == 0 ? 64 : 32;
+    return ((tiles + WT - 1) / WT) * (a.Cout / cob) >= g_wino_min_blocks;
+}
+size_t conv_wino_u_floats(int Cout, int Cin) { return (size_t)16 * Cout * Cin; }
+
+template <int NS>
+static void launch_wino_t(const ConvArgs& a, hipStream_t s) {
+    const int TH = (a.Ho + 1) / 2, TW = (a.Wo + 1) / 2, Mt = a.N * TH * TW, ntp = (Mt + WT - 1) / WT;
+    const int grid = ntp * (a.Cout / (32 * NS));
+    constexpr size_t lds_pipe = 2 * W_STAGE * sizeof(float), lds_epi = (size_t)8 * 32 * (32 * NS + 4) * sizeof(float);
+    constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<NS, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino_kernel<NS, 1, 0>), dim3(grid), dim3(256), lds, s, a, TH, TW, Mt, ntp);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino_kernel<NS, 0, 1>), dim3(grid), dim3(256), lds, s, a, TH, TW, Mt, ntp);
+    else hipLaunchKernelGGL((conv_wino_kernel<NS, 0, 0>), dim3(grid), dim3(256), lds, s, a, TH, TW, Mt, ntp);
+}
+
+// the caller (launch_conv_igemm) has checked conv_wino_eligible(a)
+void launch_conv_wino(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    const long x_bytes = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps);
+    if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || (a.dact_src && a.da_ps % 4 != 0) || (a.res && a.res_ps % 4 != 0) || x_bytes >= (1L << 32) || (a.in_scale && a.bst)) {
+        fprintf(stderr, "md2: conv_wino: unsupported view (x_ps=%d y_ps=%d)\n", a.x_ps, a.y_ps); abort();
+    }
+    // statistics / pullback sums are fused unless the run must be bit-reproducible (double atomics): then the separate column passes
+    const bool fuse = !g_deterministic;
+    const bool stats_ok = fuse && !a.bias && a.act == ACT_NONE && !a.accumulate && !a.dact_src;
+    if (a.stats && !stats_ok) a.stats = nullptr;
+    if (a.bst && !fuse) { a.bst = nullptr; a.bstB = nullptr; }
+    Wino2Geo g2;
+    if (wino3_eligible(a, g2)) launch_wino3(a, g2, s);
+    else if (wino2_eligible(a, g2)) launch_wino2(a, g2, s);
+    else if (a.Cout % 64 == 0) launch_wino_t<2>(a, s); else launch_wino_t<1>(a, s);
+    View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
+    if (a_in.stats && !a.stats) {
+        if (a_in.bias || a_in.act != ACT_NONE) { fprintf(stderr, "md2: conv_wino: BatchNorm statistics need a bias-free, linear output\n"); abort(); }
+        launch_colstats(yv, a_in.stats, s);
+    }
+    if (a_in.bst && !a.bst) {
+        View z = yv; z.p = const_cast<float*>(a_in.bz); z.bs = a_in.bz_bs; z.ps = a_in.bz_ps;
+        launch_bn_bwd_reduce(yv, nullptr, ACT_NONE, z, a_in.bstat, a_in.bst, s);
+        if (a_in.bstB) { View zb = yv; zb.p = const_cast<float*>(a_in.bzB); zb.bs = a_in.bzB_bs; zb.ps = a_in.bzB_ps; launch_bn_bwd_reduce(yv, nullptr, ACT_NONE, zb, a_in.bstatB, a_in.bstB, s); }
+    }
+}
+
+}  // namespace md2

@@ -30,6 +30,7 @@ struct ConvL {
     int kind = 0;                        // 0 igemm, 1 stem (direct 7x7 kernels, weights [64][Kpad]: taps=1, cinP=Kpad), 2 head (cout 1, direct kernel)
     long w = 0, b = 0;                   // offsets (floats) into the internal flat buffers
     long fw = 0, fb = 0;                 // offsets into the Flux-layout flat vector
+    long uf = -1, ud = -1;               // offsets of the layer's Winograd operands (forward / input gradient) in md2_handle::UF / UD; -1 = the layer never takes the Winograd kernel
     long wn() const { return (long)coutP * taps * cinP; }
 };
 struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; long rs = 0; float* stats = nullptr; double* acc = nullptr; double* acc_b = nullptr; };   // rs: offset of (running mean[c], running var[c]) in md2_handle::RS
@@ -69,6 +70,8 @@ struct md2_handle {
     float *E1 = nullptr, *E2 = nullptr, *E3 = nullptr;
     View dpy3, dpy2, dpy1, dsq;
     long* wdesc_dev = nullptr; int n_wdesc = 0;
+    // Winograd operands U = G g G^T of every 3x3 / stride-1 layer, refreshed once per step from P (forward) and WD (input gradient)
+    float *UF = nullptr, *UD = nullptr; long n_uf = 0, n_ud = 0; long *udesc_f = nullptr, *udesc_d = nullptr; int n_udf = 0, n_udd = 0, ublk_f = 0, ublk_d = 0; hipEvent_t ev_uf = nullptr;
     // weight gradients run on a second stream, concurrently with the input-gradient / BN-pullback chain of the main stream
     hipStream_t s3 = nullptr; hipStream_t cur = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // pose branch stream; `cur` = stream of the chain being enqueued
     hipStream_t s4 = nullptr; int wg_rr = 0; int n_wg_streams = 1; hipEvent_t ev_join4 = nullptr;
@@ -290,12 +293,14 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
 static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act, double* bn_stats = nullptr) {
     ConvArgs a = conv_args(x, h->P + c.w, y, c.k, c.stride, padmode == PAD_REFLECT ? 1 : c.pad, 1, padmode);
     a.bias = c.bias ? h->P + c.b : nullptr; a.act = act; a.stats = h->testmode ? nullptr : bn_stats;
+    a.wino_u = c.uf >= 0 ? h->UF + c.uf : nullptr;
     run_igemm(h, a);
 }
 // input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
 static ConvArgs dgrad_args(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact, const View* res = nullptr) {
     ConvArgs a = conv_args(dy, h->WD + c.w, dx, c.k, 1, c.k - 1 - pad_fwd, c.stride, PAD_ZERO);
     a.accumulate = accumulate;
+    a.wino_u = c.ud >= 0 ? h->UD + c.ud : nullptr;
     if (dact_src) { a.dact_src = dact_src->p; a.da_bs = dact_src->bs; a.da_ps = dact_src->ps; a.dact = dact; }
     if (res) { a.res = res->p; a.res_bs = res->bs; a.res_ps = res->ps; }
     return a;
@@ -386,9 +391,12 @@ static void pose_forward(md2_handle* h, int N) {
 }
 
 // L frames per sample (3 for training, 1 for eval_disparity); tgt = index of the frame the depth decoder sees
-static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, bool with_pose = true, bool with_depth = true) {
+// Winograd operands of the forward convolutions from the current parameters (one launch; ~16/9 of the 3x3 weights are written)
+static void refresh_wino_fwd(md2_handle* h, hipStream_t s) { launch_wino_weights_batched(h->P, h->UF, h->udesc_f, h->n_udf, h->ublk_f, s); }
+static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, bool with_pose = true, bool with_depth = true, bool wino_on_side = false) {
     hipStream_t s = h->stream;
     const int NL = h->z0.N, N = NL / L, H = h->H, W = h->W;
+    if (!wino_on_side) refresh_wino_fwd(h, s);          // (md2_train_loss runs it on the side stream, overlapping the stem)
     HIPCHK(hipMemsetAsync(h->acc_all, 0, h->acc_fwd_count * sizeof(double), s));
     // ---- encoder: stem + BN + ReLU, maxpool, 8 basic blocks
     {   // direct 7x7 stride-2 convolution on the boundary tensor (+ its BatchNorm statistics)
@@ -400,6 +408,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
     // stem tail in one pass: BatchNorm + ReLU + max-pool; a0 is written only where the decoder's skip connection reads it (the target frames)
     bn_stats(h, h->stem_bn, h->z0);
     launch_bn_relu_maxpool(h->z0, h->stem_bn.stats, h->P + h->stem_bn.g, h->P + h->stem_bn.b, h->a0, L, tgt, h->p0, h->pool_arg, s);
+    if (wino_on_side) (void)hipStreamWaitEvent(s, h->ev_uf, 0);          // the first Winograd convolution is block 0's conv1
     for (int i = 0; i < h->nblk; ++i) {
         Block& B = h->blk[i];
         if (B.fuse) {
@@ -407,6 +416,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
             {   // conv2 gathers relu(bn1(z1)) straight from z1
                 ConvArgs a = conv_args(B.z1, h->P + B.c2.w, B.z2, B.c2.k, B.c2.stride, B.c2.pad, 1, PAD_ZERO);
                 a.in_scale = B.b1.stats + 2 * B.b1.c; a.in_shift = B.b1.stats + 3 * B.b1.c; a.stats = h->testmode ? nullptr : B.b2.acc;
+                a.wino_u = B.c2.uf >= 0 ? h->UF + B.c2.uf : nullptr;
                 run_igemm(h, a);
             }
             bn_stats(h, B.b2, B.z2);
@@ -531,6 +541,7 @@ static int backward_prepare(md2_handle* h, hipStream_t s) {
     HIPCHK(hipMemsetAsync(h->G, 0, (size_t)h->n_int * sizeof(float), s));
     HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
     launch_weight_to_dgrad_batched(h->P, h->WD, h->wdesc_dev, h->n_wdesc, s);
+    launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, s);          // Winograd operands of the input-gradient convolutions
     KCHK(); return 0;
 }
 static int model_backward(md2_handle* h) {
@@ -799,6 +810,19 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
         if (hipMalloc((void**)&h->wdesc_dev, d.size() * sizeof(long)) != hipSuccess) return fail("hipMalloc(wdesc) failed");
         (void)hipMemcpy(h->wdesc_dev, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice);
     }
+    {   // Winograd operand tables: forward U from P [coutP][9][cinP], input-gradient U from WD [cinP][9][coutP] (the same transform with the channel roles swapped)
+        std::vector<long> df, dd; long of = 0, od = 0;
+        for (ConvL* c : h->convs) if (c->kind == 0 && c->k == 3 && c->stride == 1) {
+            if (c->coutP % 32 == 0 && c->cinP % 16 == 0) { c->uf = of; const long nb = wino_weight_blocks(c->coutP, c->cinP); df.insert(df.end(), {c->w, of, (long)c->coutP, (long)c->cinP, nb}); h->ublk_f += (int)nb; of += (long)conv_wino_u_floats(c->coutP, c->cinP); }
+            if (c->cinP % 32 == 0 && c->coutP % 16 == 0) { c->ud = od; const long nb = wino_weight_blocks(c->cinP, c->coutP); dd.insert(dd.end(), {c->w, od, (long)c->cinP, (long)c->coutP, nb}); h->ublk_d += (int)nb; od += (long)conv_wino_u_floats(c->cinP, c->coutP); }
+        }
+        h->n_uf = of; h->n_ud = od; h->n_udf = (int)df.size() / 5; h->n_udd = (int)dd.size() / 5;
+        if (hipMalloc((void**)&h->UF, std::max<long>(of, 4) * sizeof(float)) != hipSuccess || hipMalloc((void**)&h->UD, std::max<long>(od, 4) * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&h->udesc_f, std::max<size_t>(df.size(), 5) * sizeof(long)) != hipSuccess || hipMalloc((void**)&h->udesc_d, std::max<size_t>(dd.size(), 5) * sizeof(long)) != hipSuccess) return fail("hipMalloc(winograd operands) failed");
+        if (!df.empty()) (void)hipMemcpy(h->udesc_f, df.data(), df.size() * sizeof(long), hipMemcpyHostToDevice);
+        if (!dd.empty()) (void)hipMemcpy(h->udesc_d, dd.data(), dd.size() * sizeof(long), hipMemcpyHostToDevice);
+        if (hipEventCreateWithFlags(&h->ev_uf, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
+    }
     // default intrinsics: Depth10k (src/dtk.jl:16-22) scaled to the image size
     const double f = 2648.0 / 4.63461538462 * (h->W / 416.0), cx = h->W / 2.0, cy = h->H / 2.0;
     const float Kc[9] = {(float)f, 0, 0, 0, (float)f, 0, (float)cx, (float)cy, 1};
@@ -826,11 +850,12 @@ static void destroy_handle(md2_handle* h) {          // also the failure path of
     for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (int i = 0; i < 64; ++i) if (h->ev_pool[i]) (void)hipEventDestroy(h->ev_pool[i]);
     for (int i = 0; i < 8; ++i) { if (h->ev_cm[i]) (void)hipEventDestroy(h->ev_cm[i]); if (h->ev_cs[i]) (void)hipEventDestroy(h->ev_cs[i]); }
-    hipEvent_t evs[] = {h->ev_join, h->ev_p0, h->ev_p1, h->ev_a, h->ev_b, h->ev_c, h->ev_join4, h->ev_cdone};
+    hipEvent_t evs[] = {h->ev_join, h->ev_p0, h->ev_p1, h->ev_a, h->ev_b, h->ev_c, h->ev_join4, h->ev_cdone, h->ev_uf};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     hipStream_t sts[] = {h->s2, h->s3, h->s4, h->scomm};
     for (hipStream_t st : sts) if (st) (void)hipStreamDestroy(st);
     (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD); (void)hipFree(h->RS);
+    (void)hipFree(h->UF); (void)hipFree(h->UD); (void)hipFree(h->udesc_f); (void)hipFree(h->udesc_d);
     delete h;
 }
 int32_t md2_destroy(md2_handle* h) {
@@ -893,10 +918,11 @@ int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, fl
     h->have_fwd = false; h->prep_done = false;
     if (h->two_streams && h->s2) {          // ordered after everything already on the caller's stream (the previous ADAM step reads G and writes P)
         (void)hipEventRecord(h->ev_p0, h->stream); (void)hipStreamWaitEvent(h->s2, h->ev_p0, 0);
+        refresh_wino_fwd(h, h->s2); (void)hipEventRecord(h->ev_uf, h->s2);
         if (int r = backward_prepare(h, h->s2)) return r;
         (void)hipEventRecord(h->ev_p1, h->s2); h->prep_done = true;
     }
-    if (int r = model_forward(h, x)) return r;
+    if (int r = model_forward(h, x, 3, 1, true, true, h->prep_done)) return r;
     const float* disp[4] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p};
     if (int r = loss_train(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;          // the loss pullback comes out of the same pass: md2_backward starts at the network
     h->x_last = x; h->auto_last = auto_loss; h->have_fwd = true;
@@ -1037,12 +1063,14 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* b, float
     if (b) (void)hipMemcpyAsync(bi, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s);
     ConvArgs a = conv_args(xv, wi, yv, k, stride, p_eff, 1, pad_mode);
     a.bias = b ? bi : nullptr; a.act = act; a.stats = acc;          // stats: fused into the epilogue of the 32-wide tiles, a column-statistics pass otherwise
+    float* uw = nullptr;                                            // 3x3 / stride 1: the Winograd operand, as a handle keeps it per layer
+    if (k == 3 && stride == 1 && coutP % 32 == 0) { uw = tmp_alloc(conv_wino_u_floats(coutP, cinP), s); if (!uw) return 3; launch_wino_weights(wi, uw, coutP, cinP, s); a.wino_u = uw; }
     // a split-K workspace like a handle's, so that the op-level tests drive the same reduce pass (bias / activation / statistics) the training step uses on small maps
     const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
     float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
     a.ws = ws; a.ws_cap = ws_cap;
     launch_conv_igemm(a, s);
-    (void)hipFreeAsync(ws, s);
+    (void)hipFreeAsync(ws, s); if (uw) (void)hipFreeAsync(uw, s);
     if (bn_mean) {
         launch_bn_finalize(acc, st, coutP, (double)yv.pixels(), BN_STAT_SLOTS, nullptr, 0.f, s);
         (void)hipMemcpyAsync(bn_mean, st, Cout * sizeof(float), hipMemcpyDeviceToDevice, s); (void)hipMemcpyAsync(bn_invstd, st + coutP, Cout * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -1085,8 +1113,10 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
         float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
         a.ws = ws; a.ws_cap = ws_cap;
+        float* uw = nullptr;
+        if (k == 3 && stride == 1 && cinP % 32 == 0) { uw = tmp_alloc(conv_wino_u_floats(cinP, coutP), s); if (!uw) return 3; launch_wino_weights(wd, uw, cinP, coutP, s); a.wino_u = uw; }
         launch_conv_igemm(a, s);
-        (void)hipFreeAsync(ws, s);
+        (void)hipFreeAsync(ws, s); if (uw) (void)hipFreeAsync(uw, s);
         if (pad_mode == PAD_REFLECT) {
             float* dxf = tmp_alloc((size_t)N * H * W * cinP, s); if (!dxf) return 3;
             View dv = make_view(dxf, N, H, W, cinP);
@@ -1184,6 +1214,7 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host, int64_t n) {
     HIPCHK(hipMemcpy(h->RS, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); return 0;
 }
 int32_t md2_set_deterministic(int32_t on) { g_deterministic = on != 0; return 0; }
+int32_t md2_set_winograd(int32_t on, int32_t min_blocks) { g_wino_on = on < 0 || on > 4 ? 1 : on; if (min_blocks >= 0) g_wino_min_blocks = min_blocks; return 0; }
 int32_t md2_set_lr(md2_handle* h, double lr) { if (!(lr > 0)) { h->err = "md2_set_lr: lr must be positive"; return 2; } h->cfg.lr = lr; return 0; }
 
 // ---- op-level hooks for the direct kernels the network uses besides the implicit GEMM (parity tests) ------------------------------------

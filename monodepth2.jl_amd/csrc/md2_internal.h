@@ -16,6 +16,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // one workgroup per weight-gradient tile, BatchNorm / bias sums by a single workgroup per channel group, per-block loss partials summed
 // sequentially -- so two runs on the same inputs are bit-identical.  Much slower; exists to bisect parity failures.
 extern int g_deterministic;
+// md2_set_winograd(): the 3x3 / stride-1 layers take the fused Winograd F(2x2,3x3) kernel when the launch has at least g_wino_min_blocks workgroups (MD2_NO_WINO=1 /
+// MD2_WINO_MIN_BLOCKS override the defaults at load time); off = the direct implicit GEMM everywhere
+extern int g_wino_on, g_wino_min_blocks;
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
@@ -90,12 +93,22 @@ struct ConvArgs {
     // dense launch: output pixels on the lattice (oy % acc_lat == 0 && ox % acc_lat == 0) ADD to y whatever `accumulate` says (a strided 1x1 shortcut's input gradient
     // wrote exactly those pixels first); 0 = off
     int acc_lat;
+    // Winograd F(2x2,3x3) operand of this layer (conv_winograd.hip): U = G g G^T of `w` in MFMA fragment order, refreshed once per step; null = direct convolution only
+    const float* wino_u;
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only
 #endif
 };
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 double conv_igemm_flops(const ConvArgs& a);
+// fused Winograd F(2x2,3x3) for the 3x3 / stride-1 layers (conv_winograd.hip); launch_conv_igemm routes to it when a.wino_u is set and the shape qualifies
+bool conv_wino_eligible(const ConvArgs& a);
+void launch_conv_wino(const ConvArgs& a, hipStream_t s);
+size_t conv_wino_u_floats(int Cout, int Cin);
+void launch_wino_weights(const float* w /*[Cout][9][Cin]*/, float* U, int Cout, int Cin, hipStream_t s);
+long wino_weight_blocks(int Cout, int Cin);
+// desc (device): {w offset, U offset, Cout, Cin, blocks} per layer
+void launch_wino_weights_batched(const float* wbase, float* Ubase, const long* desc_dev, int nlayers, int total_blocks, hipStream_t s);
 
 // dw[co][(kh*KW+kw)*Cin+ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, ih, iw, ci]   (atomic accumulation, split over pixels)
 struct WgradArgs {

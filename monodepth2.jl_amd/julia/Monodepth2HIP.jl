@@ -68,6 +68,7 @@ set_lr!(h, eta) = check(h, md2_set_lr(h.ptr, Float64(eta)), "set_lr")
 testmode!(h, on::Bool=true) = check(h, md2_set_testmode(h.ptr, Int32(on)), "set_testmode")       # Flux.testmode! / trainmode!, src/Monodepth.jl:126,209,237
 trainmode!(h) = testmode!(h, false)
 set_deterministic!(on::Bool) = md2_set_deterministic(Int32(on))
+set_winograd!(on::Bool, min_blocks::Integer=-1) = md2_set_winograd(Int32(on), Int32(min_blocks))     # algorithm choice of the 3x3 / stride-1 convolutions (cuDNN's job behind Flux `Conv`)
 set_two_streams!(h, on::Bool) = check(h, md2_set_two_streams(h.ptr, Int32(on)), "set_two_streams")
 
 # ---- Flux.params(model) <-> the library's flat vector ----------------------------------------------------------------------------------------

@@ -168,3 +168,65 @@ def test_conv_bn_statistics_epilogue_vs_oracle(case):
     assert rel(host(y), yo) < 1e-4
     m64 = yo.astype(np.float64).mean((0, 2, 3)); v64 = yo.astype(np.float64).var((0, 2, 3))
     assert np.abs(host(mean) - m64).max() < 1e-5 * max(1.0, np.abs(yo).max()) and rel(host(invstd), 1.0 / np.sqrt(v64 + 1e-5)) < 1e-4
+
+
+# ---- fused Winograd F(2x2,3x3) kernel (conv_winograd.hip): every 3x3 / stride-1 layer with Cout % 32 == 0, forward and input gradient ---------------------
+WINO_CASES = [
+    # N, Cin, H, W, Cout, pad, pad_mode, act
+    (2, 64, 16, 26, 64, 1, "zeros", "none"),        # encoder layer 1 shape family
+    (3, 128, 8, 13, 128, 1, "zeros", "none"),       # odd width: half-empty last tile column
+    (2, 256, 4, 13, 512, 1, "zeros", "none"),       # 1/32-scale map: 7x2 tiles per image, blocks span images
+    (5, 512, 4, 13, 256, 0, "reflect", "elu"),      # decoder branch 1 conv 1 (reflect pad, bias + ELU)
+    (2, 96, 12, 20, 32, 0, "reflect", "elu"),       # Cout 32: one 32-channel sub-tile per block; Cin 96 (6 chunks)
+    (1, 32, 7, 9, 96, 1, "zeros", "relu"),          # Cout 96 = 3 sub-tile blocks; odd height AND width, a single partly filled block
+    (3, 16, 5, 33, 64, 1, "zeros", "none"),         # one channel chunk (no steady-state loop iteration after the prologue)
+    (1, 64, 2, 2, 64, 0, "reflect", "none"),        # the smallest reflect-padded map: every patch row / column is a mirror
+    (7, 128, 16, 13, 64, 0, "reflect", "sigmoid"),
+    (2, 8, 6, 140, 64, 1, "zeros", "none"),         # tile rows wider than a block (70 tiles): blocks start mid-row; one 8-channel chunk
+    (1, 24, 40, 6, 128, 1, "zeros", "relu"),        # 3 tiles per row: a block spans 22 row segments
+]
+
+
+@pytest.fixture(params=[2, 3, 4], ids=["tile32", "tile64x64", "tile64x32"])
+def forced_winograd(request):
+    md().set_winograd(request.param, 1)          # every eligible launch takes the Winograd kernel, however small its grid: the 256-thread / 32-tile one, or the
+    yield request.param                           # 512-thread 64-tile x 64-channel one, or the 256-thread 64-tile x 32-channel one (row-segment patches), wherever they apply
+    md().set_winograd(True, 96)
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv_fwd_and_input_gradient_vs_oracle(case, forced_winograd):
+    """conv_wino_kernel against the oracle's direct convolution (1e-4 like every other layer kernel), and bit-for-bit agreement of the layer's OTHER outputs with the
+    direct implicit GEMM is NOT expected (different summation order) -- so the direct path is checked against the same oracle numbers in the same test."""
+    N, Cin, H, W, Cout, p, mode, act = case
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xin = oracle.pad_reflect(x) if mode == "reflect" else x
+    zo = oracle.conv2d_fwd(xin, w, b, 1, 0 if mode == "reflect" else p)
+    ref = {"none": zo, "relu": np.maximum(zo, 0), "elu": np.where(zo > 0, zo, np.expm1(zo)), "sigmoid": 1 / (1 + np.exp(-zo))}[act]
+    y = host(md().conv2d(dev(x), dev(w), dev(b), 1, p, mode, act))
+    assert y.shape == ref.shape and rel(y, ref) < 1e-4
+    md().set_winograd(False)
+    y_direct = host(md().conv2d(dev(x), dev(w), dev(b), 1, p, mode, act))
+    md().set_winograd(forced_winograd, 1)
+    assert rel(y_direct, ref) < 1e-4 and not np.array_equal(y, y_direct)          # the two algorithms really are different code paths
+    dy = rng.standard_normal(zo.shape).astype(np.float32)
+    dxo, dwo, dbo = oracle.conv2d_bwd(xin, w, dy, 1, 0 if mode == "reflect" else p)
+    if mode == "reflect":
+        dxo = _reflect_adjoint(dxo, N, Cin, H, W)
+    dx, dw, db = md().conv2d_pullback(dev(x), dev(w), dev(dy), 1, p, mode)          # the input gradient is the same kernel with the channel roles swapped (Cin % 32 == 0 cases)
+    assert rel(host(dx), dxo) < 1e-4 and rel(host(dw), dwo) < 1e-4 and rel(host(db), dbo) < 1e-4
+
+
+@pytest.mark.parametrize("case", [(40, 64, 32, 52, 64), (3, 128, 8, 13, 256), (2, 256, 4, 13, 512), (4, 64, 7, 9, 32)])
+def test_winograd_bn_statistics_epilogue_vs_oracle(case, forced_winograd):
+    """BatchNorm batch statistics out of the Winograd epilogue (column sums through LDS + 8-slot double atomics), incl. partly filled blocks and odd maps."""
+    N, Cin, H, W, Cout = case
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    yo = oracle.conv2d_fwd(x, w, None, 1, 1)
+    y, mean, invstd = md().conv2d_bnstats(dev(x), dev(w), 1, 1)
+    assert rel(host(y), yo) < 1e-4
+    m64 = yo.astype(np.float64).mean((0, 2, 3)); v64 = yo.astype(np.float64).var((0, 2, 3))
+    assert np.abs(host(mean) - m64).max() < 1e-5 * max(1.0, np.abs(yo).max()) and rel(host(invstd), 1.0 / np.sqrt(v64 + 1e-5)) < 1e-4
