@@ -745,15 +745,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
                 V[2] = make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w);
                 V[3] = make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w);
             }
-            W3_MFMA(th, 0, uf0); W3_MFMA(th, 1, uf1); W3_MFMA(th, 2, uf2); W3_MFMA(th, 3, uf3);
-        }
-        if (!(abl & 2)) {          // in-place refill: chunk c + 1's fragments, a full chunk before their use
-            uf0 = *reinterpret_cast<const f32x4*>(un); uf1 = *reinterpret_cast<const f32x4*>(un + 256); uf2 = *reinterpret_cast<const f32x4*>(un + 512); uf3 = *reinterpret_cast<const f32x4*>(un + 768);
+            // in-place refill right behind a fragment's last use in this chunk (tile half 1): the next use is three MFMA groups, the commit, the barrier and a transform
+            // phase later -- for every j alike
+            // (the sched_barriers keep hipcc from collecting the four loads behind the last MFMA)
+            W3_MFMA(th, 0, uf0); if (th == 1 && !(abl & 2)) { uf0 = *reinterpret_cast<const f32x4*>(un); __builtin_amdgcn_sched_barrier(0); }
+            W3_MFMA(th, 1, uf1); if (th == 1 && !(abl & 2)) { uf1 = *reinterpret_cast<const f32x4*>(un + 256); __builtin_amdgcn_sched_barrier(0); }
+            W3_MFMA(th, 2, uf2); if (th == 1 && !(abl & 2)) { uf2 = *reinterpret_cast<const f32x4*>(un + 512); __builtin_amdgcn_sched_barrier(0); }
+            W3_MFMA(th, 3, uf3); if (th == 1 && !(abl & 2)) uf3 = *reinterpret_cast<const f32x4*>(un + 768);
         }
 #undef W3_MFMA
         __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 1)) lstore(PST - so);
-        __syncthreads();
+        if (!(abl & 8)) __syncthreads();
     }
 
     // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4])
@@ -798,14 +801,13 @@ static bool wino2_eligible(const ConvArgs& a, Wino2Geo& g) {
     return g_wino_on == 3 || (long)g.Mt * (a.Cout / 64) >= g_wino2_min_tiles;
 }
 // third kernel: Cout % 32 == 0, Cin % 8 == 0, up to 640 patch slots per stage (tile rows of at least 4 tiles)
-static long g_wino3_min_tiles = getenv("MD2_WINO3_MIN_TILES") ? atol(getenv("MD2_WINO3_MIN_TILES")) : 8192;
 static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g) {
     static const bool off = getenv("MD2_NO_WINO3") != nullptr;
     if (off || g_wino_on == 2 || g_wino_on == 3 || a.Cout % 32 != 0 || a.Cin % 8 != 0) return false;
     g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW; g.ntp = (g.Mt + W2_T - 1) / W2_T;
     g.nslots = wino2_slots(g.TW);
     if (g.nslots > 128 * 5) return false;
-    return g_wino_on == 4 || (long)g.Mt * (a.Cout / 32) >= g_wino3_min_tiles;
+    return g_wino_on == 4 || (long)g.ntp * (a.Cout / 32) >= g_wino_min_blocks;
 }
 template <int NLI>
 static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
@@ -841,15 +843,21 @@ static void launch_wino2(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
 }
 
 int g_wino_on = getenv("MD2_NO_WINO") ? 0 : (getenv("MD2_WINO_MODE") ? atoi(getenv("MD2_WINO_MODE")) : 1);          // MD2_WINO_MODE=2/3/4: pin one kernel (md2_set_winograd)
-int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 96;
+int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 160;
 
-// 3x3, stride 1, dense output lattice, no split-K, fp32; Cin % 16, Cout % 32
+// 3x3, stride 1, dense output lattice, no split-K, fp32; Cin % 16, Cout % 32.  Automatic choice (md2_set_winograd(1, n)): the 64-tile x 32-channel kernel when it
+// launches at least n workgroups (default 160: in-model per-launch timings at batch 32, tools/run_layer_compare.sh -- below that the direct implicit GEMM with its split-K
+// wins), the direct convolution otherwise; the other two kernels only when pinned (modes 2 / 3).
+static bool wino2_eligible(const ConvArgs& a, Wino2Geo& g);
+static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g);
 bool conv_wino_eligible(const ConvArgs& a) {
     if (!g_wino_on || !a.wino_u || a.bf16) return false;
     if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.oy0 == 0 && a.ox0 == 0 && a.Hl == a.Ho && a.Wl == a.Wo)) return false;
     if (a.Cin % 16 != 0 || a.Cout % 32 != 0 || a.acc_lat) return false;
     if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
     if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
+    Wino2Geo g;
+    if (g_wino_on == 1) return wino3_eligible(a, g);
     const long tiles = (long)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2);
     const int cob = a.Cout % 64 == 0 ? 64 : 32;
     return ((tiles + WT - 1) / WT) * (a.Cout / cob) >= g_wino_min_blocks;

@@ -191,7 +191,7 @@ WINO_CASES = [
 def forced_winograd(request):
     md().set_winograd(request.param, 1)          # every eligible launch takes the Winograd kernel, however small its grid: the 256-thread / 32-tile one, or the
     yield request.param                           # 512-thread 64-tile x 64-channel one, or the 256-thread 64-tile x 32-channel one (row-segment patches), wherever they apply
-    md().set_winograd(True, 96)
+    md().set_winograd(True, 160)
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
