@@ -983,7 +983,7 @@ static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
 // sees the taps kh = (pad - ph) mod dil (+ multiples of dil), so the problem splits into dil^2 dense sub-convolutions on
 // output/tap lattices with no multiply-by-zero work (k=3, s=2: 1+2+2+4 = 9 taps over 4 quarter-size launches).
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
-    if (conv_wino_eligible(a) && !(patch_eligible(a) && !a.in_scale && !a.bst)) { launch_conv_wino(a, s); return; }
+    if (conv_wino_eligible(a) && !(patch_eligible(a) && !a.in_scale && !a.bst && a.Cout == 16)) { launch_conv_wino(a, s); return; }          // (32 output channels: Winograd beats the LDS-patch kernel)
     if (patch_eligible(a) && !a.in_scale && !a.bst) {
         if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || (a.dact_src && a.da_ps % 4 != 0)) { fprintf(stderr, "md2: conv3x3_patch: unaligned view\n"); abort(); }
         if (a.Cout == 16) launch_patch<16>(a, s); else launch_patch<32>(a, s);
