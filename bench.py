@@ -2,7 +2,8 @@
 """bench.py — self-supervised training throughput (triplets/s) of the MI355X training step.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run with one
-rank per GPU (RCCL).  W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize, MAX over
+rank per GPU (RCCL) -- or, started plainly with --gpus N > 1 and no WORLD_SIZE in the environment, it starts its own N ranks (child processes, before this
+process touches a GPU) and relays rank 0's line.  W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize, MAX over
 ranks, rank 0 prints ONE JSON line.  A step = forward + loss + backward + (all-reduce) + ADAM over one batch of synthetic
 416x128 triplets already resident in HBM (src/Monodepth.jl:156-176).  Weak scaling: every GPU gets `--batch` triplets
 (default 32 = BASELINE.json configs[2]'s per-GPU batch, so that N=1 and N=8 do the same per-GPU work; configs[1]'s
@@ -20,12 +21,13 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (--precision bf16 prices against this one)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-# HBM bytes per launch come from the rocprofv3 PMC passes of THIS command (profiles/r02_pmc_hbm_traffic.json, written by tools/profile_summary.py from separate
+VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s (a wave64 VALU instruction takes 2 cycles of its SIMD)
+# HBM bytes per launch come from the rocprofv3 PMC passes of THIS command (profiles/r03_pmc_hbm_traffic.json, written by tools/profile_summary.py from separate
 # --pmc FETCH_SIZE / WRITE_SIZE runs: KiB units, FETCH_SIZE x2 because gfx950 tallies 64 B per 128-B request, WRITE_SIZE exact).  PMC counters cannot be read
 # from inside bench.py, so the tracked measurement is reported when its workload equals the one being run, null otherwise.
 def pmc_traffic(B, C, H, W, depth, precision):
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))
     except Exception:
         return {}
     w = d.get("workload", {})
@@ -34,10 +36,23 @@ def pmc_traffic(B, C, H, W, depth, precision):
     return d.get("bytes_per_launch", {})
 
 
-def cpu_baseline(C, H, W, seconds_budget=75.0):
+def valu_insts(kernel, B, C, H, W):
+    """SQ_INSTS_VALU per launch of a loss kernel from the committed PMC summary (profiles/r03_loss_pmc.json: {"workload": {...}, "loss_train": n, ...}); None when
+    the workload differs from the one measured."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_loss_pmc.json")))
+    except Exception:
+        return None
+    w = d.get("workload", {})
+    if (w.get("batch"), w.get("channels"), w.get("height"), w.get("width")) != (B, C, H, W):
+        return None
+    return d.get(kernel)
+
+
+def cpu_baseline(C, H, W):
     """The oracle (CPU restatement of the reference algorithm, op by op and unfused -- not Flux itself) timed on this box's host cores on the reference's own
-    training configuration, batch 4 (src/Monodepth.jl:104), 416x128, forward + loss + backward + ADAM; bounded: 1 warm-up, then timed steps (median) until the
-    budget is used (at most 10)."""
+    training configuration, batch 4 (src/Monodepth.jl:104), 416x128, forward + loss + backward + ADAM: 3 warm-up steps, then 10 timed steps, median
+    (~7 s per step on the GPU box's 128 threads, so this leg takes ~1.5 min)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     import md2amd
@@ -49,13 +64,30 @@ def cpu_baseline(C, H, W, seconds_budget=75.0):
     cfg = oracle.make_cfg(B, C, H, W, K, iK)
     net = oracle.OracleNet(C); net.set_params(theta)
     threads = oracle.num_threads()
-    t0 = time.time(); net.train_loss(x, cfg, None, True); net.adam_step(1e-4); warm = time.time() - t0
+    for _ in range(3):
+        net.train_loss(x, cfg, None, True); net.adam_step(1e-4)
     times = []
-    while (sum(times) + warm < seconds_budget and len(times) < 10) or len(times) < 2:
+    for _ in range(10):
         t0 = time.time(); net.train_loss(x, cfg, None, True); net.adam_step(1e-4); times.append(time.time() - t0)
     med = sorted(times)[len(times) // 2]
     return {"value": B / med, "unit": "triplets/s", "cores": int(threads), "kind": "port",
-            "sample": "B=4 triplets (the reference's batch size), %dx%d, C=%d, fwd+loss+bwd+ADAM, 1 warm-up + %d timed steps (median %.2f s/step) on %d OpenMP threads; CPU restatement of the reference algorithm, op by op -- not Flux itself, and not the optimisation target" % (W, H, C, len(times), med, int(threads))}
+            "sample": "B=4 triplets (the reference's batch size), %dx%d, C=%d, fwd+loss+bwd+ADAM, 3 warm-up + %d timed steps (median %.2f s/step) on %d OpenMP threads; CPU restatement of the reference algorithm, op by op -- not Flux itself, and not the optimisation target" % (W, H, C, len(times), med, int(threads))}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent never touches a GPU), relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL)))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode()); sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -72,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -106,17 +140,26 @@ def main():
     # It is checked on a known pattern before the timed region; if it cannot be brought up the step falls back to torch.distributed's RCCL all-reduce of the same
     # buffer, and says so in the JSON line.
     comm_note = "single rank"
-    dp = par.DataParallel(model)
-    if world > 1 and dp.comm == "rccl":
+    backend = os.environ.get("MD2_BENCH_BACKEND", "nccl")
+    dp = par.DataParallel(model, comm="torch")
+    rccl_ranks = 1
+    if world > 1 and backend == "nccl":
+        # the library's communicator is VERIFIED before it is timed: every rank steps once on the same batch, first alone (local gradient), then with the communicator
+        # attached -- the bucketed, overlapped all-reduce inside md2_backward must return world x the local gradient on every rank (parallel.verify_rccl)
         try:
-            dp._setup(x, params, cache)
-            t = torch.full((8,), float(rank + 1), device="cuda")
-            model.comm_allreduce(t); torch.cuda.synchronize()
-            if abs(float(t[0]) - world * (world + 1) / 2.0) > 1e-3:
-                raise RuntimeError("self-check sum %.3f != %.3f" % (float(t[0]), world * (world + 1) / 2.0))
-            comm_note = "libmd2hip RCCL communicator (md2_comm_init), 4 buckets overlapped with the pullback"
+            xc = torch.from_numpy(syn.synthetic_triplets(min(B, 8), C, H, W, seed=7)).cuda().repeat((B + 7) // 8, 1, 1, 1, 1)[:B].contiguous()
+            md.train_step(model, xc, None, cache, params, do_update=False)
+            g_local = model.grad_buffer().float().clone()
+            dpr = par.DataParallel(model, comm="rccl")
+            dpr._setup(x, params, cache)
+            ok, err = par.verify_rccl(dpr, xc, cache, params, g_local)
+            rccl_ranks = model.comm_world()[1]
+            if not ok or rccl_ranks != world:
+                raise RuntimeError("reduced gradient differs from world x local gradient (rel %.2e) or communicator has %d ranks" % (err, rccl_ranks))
+            dp = dpr
+            comm_note = "libmd2hip RCCL communicator (md2_comm_init), 4 buckets overlapped with the pullback; verified against the local gradient before timing (rel %.1e)" % err
         except Exception as e:                      # noqa: BLE001
-            comm_note = "torch.distributed RCCL all-reduce of the library's gradient buffer (md2_comm_init failed: %s)" % str(e)[:200]
+            comm_note = "torch.distributed RCCL all-reduce of the library's gradient buffer (library communicator not used: %s)" % str(e)[:200]
             try:
                 model.comm_destroy()
             except Exception:                       # noqa: BLE001
@@ -126,9 +169,12 @@ def main():
         flag = torch.tensor([1.0 if dp.comm == "rccl" else 0.0], device="cuda"); torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         if float(flag.item()) < 0.5 and dp.comm == "rccl":
             model.comm_destroy()
-            dp = par.DataParallel(model, comm="torch"); comm_note = "torch.distributed RCCL all-reduce (another rank could not initialise md2_comm)"
+            dp = par.DataParallel(model, comm="torch"); comm_note = "torch.distributed RCCL all-reduce (another rank could not verify md2_comm)"
+        if dp.comm != "rccl":
+            rccl_ranks = 0
     elif world > 1:
-        comm_note = "torch.distributed all-reduce (%s backend)" % os.environ.get("MD2_BENCH_BACKEND", "nccl")
+        comm_note = "torch.distributed all-reduce (%s backend)" % backend
+        rccl_ranks = 0
 
     def sync():
         if world > 1:
@@ -156,7 +202,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
            "config": {"workload": "ResNet-%d depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, %s fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4, configs[3] ResNet-50 640x192 batch=16 and configs[4] 1024x320 bf16 automask under extra)" % (
                           args.depth, W, H, C, B, "fp32" if args.precision == "f32" else "bf16 MFMA operands / fp32 accumulate"),
-                      "global_batch": world * B, "parallelism": "dp%d" % world, "gradient_exchange": comm_note, "loss": final_loss}}
+                      "global_batch": world * B, "parallelism": "dp%d" % world, "gradient_exchange": comm_note, "rccl_ranks": rccl_ranks, "loss": final_loss}}
 
     # ---- roofline of the dominant kernel class, measured live with HIP events on the launch stream (3 profiled steps)
     # The timed region above overlaps the weight-gradient kernels with the rest of the backward pass on a second stream; overlapped
@@ -176,10 +222,14 @@ def main():
         traffic = pmc_traffic(B, C, H, W, args.depth, args.precision)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+        ach_x = ig["flops_executed"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_wino*_kernel (fused Winograd F(2x2,3x3): the 3x3 stride-1 layers) + conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
                            "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
+                           "algorithmic": "achieved / frac count the direct-convolution FLOPs of the layers (SURVEY.md section 8d: 2 M Cout taps Cin), whatever algorithm ran",
+                           "executed_achieved": ach_x, "executed_frac": ach_x / peak_tf,
+                           "executed": "FLOPs the matrix cores really issued: Winograd launches multiply 16 instead of 36 times per 2x2 output tile -- this is the MFMA pipe utilisation",
                            "traffic": traffic.get("conv_igemm"),
-                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, profiles/r02_pmc_hbm_traffic.md)",
+                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, profiles/r03_pmc_hbm_traffic.md)",
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1),
                            "timing": "HIP events per launch on the launch stream, 3 steps with the second (weight-gradient) stream disabled; `value` is measured with it enabled"}
         extra = {"frames_per_s": 3.0 * value}         # one triplet = 3 frames through the encoder
@@ -190,9 +240,17 @@ def main():
         for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_train", lb)):
             if p["ms"] > 0:
                 a = p["bytes"] / (p["ms"] * 1e-3) / 1e9
-                extra[nm] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "ms_per_step": p["ms"] / 3,
-                             "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1),
-                             "traffic": traffic.get(nm[len("roofline_"):])}
+                ent = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "ms_per_step": p["ms"] / 3,
+                       "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1),
+                       "traffic": traffic.get(nm[len("roofline_"):])}
+                vi = valu_insts(nm[len("roofline_"):], B, C, H, W)
+                if vi:          # the kernel is bound by vector-instruction issue, not by HBM (profiles/r0x_loss_train_pmc.md): report that roofline, keep the HBM fraction beside it
+                    rate = vi * 64.0 / (p["ms"] / max(p["launches"], 1) * 1e-3) / 1e12          # T lane-instructions / s
+                    ent = {"bound": "valu", "achieved": rate, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": rate / VALU_PEAK_TLANE,
+                           "valu_wave_instructions_per_launch": vi, "counter": "SQ_INSTS_VALU of this kernel at this workload (rocprofv3 --pmc, profiles/)",
+                           "ms_per_step": p["ms"] / 3, "hbm": {"achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                                                               "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1), "traffic": traffic.get(nm[len("roofline_"):])}}
+                extra[nm] = ent
         if world == 1 and not args.no_extra and B != 4:
             # BASELINE.json configs[1]: batch = 4 on one MI355X
             del dp, model

@@ -142,6 +142,9 @@ int32_t md2_profile_enable(md2_handle* h, int32_t on);
 int32_t md2_profile_reset(md2_handle* h);
 /* classes: 0 conv_igemm (fwd+dgrad), 1 conv_wgrad, 2 loss_fwd, 3 loss_bwd, 4 other */
 int32_t md2_profile_get(md2_handle* h, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
+/* FLOPs the matrix cores executed in class `cls` since md2_profile_reset: equals the algorithmic count of md2_profile_get except for the convolutions that took the
+ * Winograd F(2x2,3x3) route (16 instead of 36 multiplies per 2x2 output tile) -- bench.py reports both fractions of the MFMA peak. */
+int32_t md2_profile_get_executed(md2_handle* h, int32_t cls, double* flops_executed);
 
 /* per-launch table of the profiled kernels (csv: class, ms, GFLOP, TFLOP/s, shape) */
 int32_t md2_profile_dump(md2_handle* h, const char* path);

@@ -59,6 +59,7 @@ _SIGS = {
     "md2_profile_enable": (I32, [P, I32]),
     "md2_profile_reset": (I32, [P]),
     "md2_profile_get": (I32, [P, I32, C.POINTER(F64), C.POINTER(I64), C.POINTER(F64), C.POINTER(F64)]),
+    "md2_profile_get_executed": (I32, [P, I32, C.POINTER(F64)]),
     "md2_profile_dump": (I32, [P, C.c_char_p]),
     "md2_ssim_fwd": (I32, [P, P, P, I32, I32, I32, P]),
     "md2_ssim_bwd": (I32, [P, P, P, P, P, I32, I32, I32, P]),

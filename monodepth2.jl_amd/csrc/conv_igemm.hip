@@ -786,6 +786,13 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     if (a_in.bst && !a.bst && a.ksplit == 1 && a.ostep == 1) bst_fallback(a_in, s);       // (split-K: after the bias / activation pass, by launch_conv_igemm_one; sub-lattices: by launch_conv_igemm)
 }
 
+static bool patch_eligible(const ConvArgs& a);
+// FLOPs the matrix cores execute for this launch: the Winograd route multiplies 16 instead of 36 times per 2x2 output tile (partly filled tiles count in full)
+double conv_igemm_executed_flops(const ConvArgs& a) {
+    if (conv_wino_eligible(a) && !(patch_eligible(a) && !a.in_scale && !a.bst && a.Cout == 16))
+        return 2.0 * 16.0 * (double)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2) * a.Cout * a.Cin;
+    return conv_igemm_flops(a);
+}
 double conv_igemm_flops(const ConvArgs& a) {       // algorithmic: taps that can be non-zero
     const double taps = a.dil > 1 && a.ostep == 1 ? (double)a.KH * a.KW / ((double)a.dil * a.dil) : (double)a.nkh * a.nkw;
     return 2.0 * (double)a.M * a.Cout * taps * a.Cin;

@@ -694,6 +694,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
             const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
             c_off1[th][b] = sl1 * 8 + ((ch ^ ((sl1 >> 3) & 1)) << 2);
             c_off2[th][b] = sl2 * 8 + ((ch ^ ((sl2 >> 3) & 1)) << 2);
+#ifdef MD2_ABLATE
+            if (a.ablate & 16) { c_off1[th][b] = tl * 4 + ch * 128 + th * 256 + b * 512; c_off2[th][b] = c_off1[th][b] + 2048; }      // timing experiment: conflict-free (wrong) read addresses
+#endif
         }
     }
 

@@ -82,7 +82,7 @@ struct md2_handle {
     float* ws_main = nullptr; float* ws_pose = nullptr; long ws_cap = 0;   // split-K workspaces of the implicit GEMM: one per stream that runs convolutions concurrently
     // data parallelism: RCCL communicator + bucketed all-reduce of the flat gradient buffer, overlapped with the rest of the pullback
     void* comm = nullptr; int rank = 0, world = 1; hipStream_t scomm = nullptr; hipEvent_t ev_cm[8], ev_cs[8], ev_cdone = nullptr; bool grads_reduced = false; long bucket_lo[8]; int n_bucket_done = 0;
-    bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0};
+    bool prof = false; std::vector<ProfEvt> evts; double prof_flops[5] = {0, 0, 0, 0, 0}, prof_bytes[5] = {0, 0, 0, 0, 0}, prof_exec[5] = {0, 0, 0, 0, 0};
 
     template <class T> T* alloc(size_t count) {
         arena_off = (arena_off + 255) / 256 * 256;
@@ -287,7 +287,7 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W);
     h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
-    if (h->prof) h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a);
+    if (h->prof) { h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a); h->prof_exec[CLS_IGEMM] += conv_igemm_executed_flops(a); }
 }
 // forward conv (kind 0) on views.  x.C must equal c.cinP, y.C == c.coutP
 static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act, double* bn_stats = nullptr) {
@@ -403,7 +403,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, 
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
         h->pbegin(CLS_IGEMM, fl, "stem fwd 7x7 s2 (direct)"); launch_stem_fwd(x, NL, h->C, H, W, h->P + h->stem.w, h->Kpad, h->z0, (h->testmode || g_deterministic) ? nullptr : h->stem_bn.acc, s); h->pend();
         if (g_deterministic && !h->testmode) launch_colstats(h->z0, h->stem_bn.acc, s);
-        if (h->prof) h->prof_flops[CLS_IGEMM] += fl;
+        if (h->prof) { h->prof_flops[CLS_IGEMM] += fl; h->prof_exec[CLS_IGEMM] += fl; }
     }
     // stem tail in one pass: BatchNorm + ReLU + max-pool; a0 is written only where the decoder's skip connection reads it (the target frames)
     bn_stats(h, h->stem_bn, h->z0);
@@ -1017,7 +1017,7 @@ int32_t md2_profile_reset(md2_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     for (auto& e : h->evts) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     h->evts.clear();
-    for (int i = 0; i < 5; ++i) { h->prof_flops[i] = 0; h->prof_bytes[i] = 0; }
+    for (int i = 0; i < 5; ++i) { h->prof_flops[i] = 0; h->prof_bytes[i] = 0; h->prof_exec[i] = 0; }
     return 0;
 }
 int32_t md2_profile_get(md2_handle* h, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes) {
@@ -1029,6 +1029,10 @@ int32_t md2_profile_get(md2_handle* h, int32_t cls, double* total_ms, int64_t* l
     return 0;
 }
 
+int32_t md2_profile_get_executed(md2_handle* h, int32_t cls, double* flops_executed) {
+    if (flops_executed) *flops_executed = (cls == CLS_IGEMM) ? h->prof_exec[cls] : ((cls >= 0 && cls < 5) ? h->prof_flops[cls] : 0);
+    return 0;
+}
 int32_t md2_profile_dump(md2_handle* h, const char* path) {
     HIPCHK(hipStreamSynchronize(h->stream));
     FILE* f = fopen(path, "w"); if (!f) { h->err = "md2_profile_dump: cannot open file"; return 2; }

@@ -101,6 +101,7 @@ struct ConvArgs {
 };
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 double conv_igemm_flops(const ConvArgs& a);
+double conv_igemm_executed_flops(const ConvArgs& a);      // what the matrix cores really multiply (Winograd launches: 16/36 of the algorithmic count)
 // fused Winograd F(2x2,3x3) for the 3x3 / stride-1 layers (conv_winograd.hip); launch_conv_igemm routes to it when a.wino_u is set and the shape qualifies
 bool conv_wino_eligible(const ConvArgs& a);
 void launch_conv_wino(const ConvArgs& a, hipStream_t s);

@@ -219,7 +219,9 @@ profile_reset!(h) = check(h, md2_profile_reset(h.ptr), "profile_reset")
 function profile_get(h, cls)
     ms = Ref(0.0); n = Ref(Int64(0)); fl = Ref(0.0); by = Ref(0.0)
     GC.@preserve ms n fl by check(h, md2_profile_get(h.ptr, Int32(cls), Base.unsafe_convert(Ptr{Float64}, ms), Base.unsafe_convert(Ptr{Int64}, n), Base.unsafe_convert(Ptr{Float64}, fl), Base.unsafe_convert(Ptr{Float64}, by)), "profile_get")
-    (ms = ms[], launches = n[], flops = fl[], bytes = by[])
+    ex = Ref(0.0)
+    GC.@preserve ex check(h, md2_profile_get_executed(h.ptr, Int32(cls), Base.unsafe_convert(Ptr{Float64}, ex)), "profile_get_executed")
+    (ms = ms[], launches = n[], flops = fl[], bytes = by[], flops_executed = ex[])       # executed < algorithmic where the Winograd kernels ran
 end
 profile_dump(h, path::String) = check(h, md2_profile_dump(h.ptr, path), "profile_dump")
 

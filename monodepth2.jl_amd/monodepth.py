@@ -284,14 +284,26 @@ class Model:
             raise ValueError("decoder channels do not match the encoder's stages")
         if precision not in ("f32", "bf16"):
             raise ValueError("precision must be 'f32' (the reference's) or 'bf16' (mixed: bf16 MFMA operands, fp32 everything else)")
-        self.lr, self.precision = lr, precision
         self._h = None
+        self.lr, self.precision = lr, precision
         self._shape = None
         self._params_host = None
         self._cfg_extra = dict(min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, automasking=False)
         self._K = None
         self._testmode = False
         self._comm_spec = None
+
+    # ADAM's eta lives in the handle (md2_config.lr, read by md2_adam_step / md2_train_step): assigning model.lr must reach it, also on a handle that already exists
+    # (train(model=resumed, lr=new) used to keep stepping at the handle's creation-time rate)
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if getattr(self, "_h", None) is not None:
+            _check(_lib.lib().md2_set_lr(self._h, self._lr), self._h, "set_lr")
 
     # -- handle management --------------------------------------------------------------------
     def _ensure(self, x, parameters: Optional[Params] = None, cache: Optional[TrainCache] = None):
@@ -308,9 +320,11 @@ class Model:
                 self.set_intrinsics(cache.K, cache.invK)
             return
         # a new shape / Params needs a new handle: carry the weights AND the optimiser / BatchNorm state across, or training would silently restart ADAM
+        if self._h is not None and self._comm_spec is not None:
+            # refuse BEFORE tearing anything down: destroying this rank's communicator alone would leave the other ranks hanging in their next collective
+            raise RuntimeError("a new batch / resolution / Params needs a new handle, but an RCCL communicator is attached: comm_destroy() on every rank first, then comm_init again")
         saved = self.params() if self._h is not None else self._params_host
         state = self._opt_and_bn_state() if self._h is not None else None
-        comm = self._comm_spec
         self.close()
         cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr,
                              self.encoder.depth, 1 if self.precision == "bf16" else 0)
@@ -323,8 +337,6 @@ class Model:
             self._restore_opt_and_bn_state(state)
         if self._testmode:
             _check(_lib.lib().md2_set_testmode(self._h, 1), self._h)
-        if comm is not None:
-            raise RuntimeError("the handle had to be rebuilt (new batch / resolution / Params) while an RCCL communicator was attached: call comm_init again on every rank")
         if cache is not None:
             self.set_intrinsics(cache.K, cache.invK)
         elif self._K is not None:
@@ -361,6 +373,13 @@ class Model:
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         _check(_lib.lib().md2_comm_init(self._h, int(rank), int(world), C.cast(buf, C.c_void_p)), self._h, "comm_init")
         self._comm_spec = (rank, world)
+
+    def comm_world(self):
+        """(rank, world) of the library's communicator as the library sees it (md2_comm_world); (0, 1) without one."""
+        r = C.c_int32(0); w = C.c_int32(1)
+        if self._h is not None:
+            _check(_lib.lib().md2_comm_world(self._h, C.byref(r), C.byref(w)), self._h, "comm_world")
+        return int(r.value), int(w.value)
 
     def comm_destroy(self):
         if self._h is not None and self._comm_spec is not None:
@@ -530,7 +549,9 @@ def train_loss(model: Model, x, auto_loss, cache: TrainCache, parameters: Params
         raise ValueError("parameters.automasking is set but auto_loss is None")
     vis_disparity = vis_warped = vis_loss = None
     if do_visualization:                      # src/training.jl:34-37, 72-75: host copies of the last scale's disparity / warps / loss map
+        bn = model.bn_state()                                         # this extra train-mode forward must not track the BatchNorm statistics a second time with the same batch
         ds, poses = model(x, cache.source_ids, cache.target_id)       # BEFORE the training forward: it reuses the activation buffers
+        model.load_bn_state(bn)
         vis_disparity = ds[-1].cpu()
         target_x = x[:, cache.target_id - 1].contiguous()
         warped = []
@@ -565,8 +586,7 @@ def update(optimizer: ADAM, model: Model, grad_scale=1.0):
     """Flux.Optimise.update!(optimizer, theta, grads) — the step size is the optimiser's eta."""
     _lib.lib().md2_set_stream(model._h, _stream())
     if optimizer is not None and optimizer.eta != model.lr:
-        model.lr = optimizer.eta
-        _check(_lib.lib().md2_set_lr(model._h, float(optimizer.eta)), model._h, "set_lr")
+        model.lr = optimizer.eta                      # (the property setter calls md2_set_lr)
     _check(_lib.lib().md2_adam_step(model._h, float(grad_scale)), model._h, "adam_step")
 
 
@@ -657,7 +677,9 @@ def profile_dump(model: Model, path):
 def profile_get(model: Model, cls):
     ms = C.c_double(); n = C.c_int64(); fl = C.c_double(); by = C.c_double()
     _check(_lib.lib().md2_profile_get(model._h, cls, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), model._h)
-    return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    ex = C.c_double()
+    _check(_lib.lib().md2_profile_get_executed(model._h, cls, C.byref(ex)), model._h)
+    return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value, flops_executed=ex.value)
 
 
 # --------------------------------------------------------------------------------------------

@@ -52,10 +52,10 @@ def broadcast_params_(flat, src=0, group=None):
 class DataParallel:
     """Wraps a Model for data-parallel training.
 
-    comm="rccl" (default when torch.distributed runs on the nccl backend): the LIBRARY's own RCCL communicator (md2_comm_init) — the same path a Julia
+    comm="rccl" (opt-in): the LIBRARY's own RCCL communicator (md2_comm_init) — the same path a Julia
     host uses: md2_backward all-reduces the flat gradient buffer bucket by bucket on a communication stream while the rest of the pullback computes, and
     md2_train_step applies ADAM to the mean.  torch.distributed only carries the 128-byte RCCL id from rank 0 to the others.
-    comm="torch": local fwd+bwd -> torch.distributed all-reduce(sum) of the wrapped gradient buffer -> ADAM(grad_scale = 1/world); the cross-check, and the only
+    comm="torch" (default): local fwd+bwd -> torch.distributed all-reduce(sum) of the wrapped gradient buffer -> ADAM(grad_scale = 1/world); the cross-check, and the only
     choice on a gloo group (CPU transport, e.g. two ranks rehearsing on one card).
 
     Construction makes the replicas identical: parameters, ADAM moments, beta powers and BatchNorm running statistics of rank 0 are broadcast."""
@@ -64,7 +64,9 @@ class DataParallel:
         self.model, self.group = model, group
         w = world_size(group)
         if comm is None:
-            comm = "rccl" if (w > 1 and dist.get_backend(group) == "nccl") else "torch"
+            # default: the torch.distributed all-reduce.  The library's own communicator (bucketed, overlapped) is opt-in until a run on a multi-GPU node has
+            # verified it -- bench.py asks for it and checks the reduced gradient against a local one before timing anything (verify_rccl)
+            comm = "torch"
         self.comm = comm
         self._ready = False
         if x_like is not None:
@@ -109,3 +111,18 @@ class DataParallel:
         else:
             allreduce_sum_(self.model.grad_buffer(), self.group)
         md.update(md.ADAM(self.model.lr), self.model, grad_scale=1.0 / world_size(self.group))
+
+
+def verify_rccl(dp, x_common, cache, parameters, g_local, tol=2e-4):
+    """Hardware check of the library communicator at world > 1, run before anything is timed: every rank steps on the SAME batch with identical weights, so the bucketed,
+    overlapped all-reduce inside md2_backward must return world x the local gradient `g_local` (taken before the communicator was attached) on every rank.
+    Returns (ok, worst relative error over the ranks)."""
+    from . import monodepth as md
+    w = world_size(dp.group)
+    md.train_step(dp.model, x_common, None, cache, parameters, do_update=False)
+    g = dp.model.grad_buffer().float()
+    err = (g / float(w) - g_local).norm() / (g_local.norm() + 1e-30)
+    t = torch.tensor([float(err)], device=g.device)
+    if w > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=dp.group)
+    return bool(float(t.item()) < tol), float(t.item())

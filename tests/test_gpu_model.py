@@ -444,7 +444,7 @@ def test_resnet50_encoder_forward_loss_gradient_and_adam_vs_oracle(shape):
     gh = model.grads(); go = net.get_grads()
     assert np.isfinite(gh).all()
     # (ill-conditioned at fp32 resolution: see test_resnet50_gradients_are_as_close_to_fp64_as_the_fp32_oracle, which is the tight statement for this trunk)
-    assert_grads_match(gh, go, C, depth=50, cos_min=0.995, rel_max=1e-1, tag="resnet50 %s" % (shape,))
+    assert_grads_match(gh, go, C, depth=50, cos_min=0.997, rel_max=6e-2, tag="resnet50 %s" % (shape,))
     md().update(md().ADAM(1e-4), model); net.adam_step(1e-4)
     assert np.abs(model.params() - net.get_params()).max() < 5e-3 * 1e-4 / 1e-4 * 1e-1     # |delta| <= lr per element; sign flips only on ~0 gradients
 
@@ -461,7 +461,7 @@ def test_config4_resnet50_640x192_vs_oracle():
     assert abs(float(loss) - lo) / lo < 1e-4
     gh = model.grads(); go = net.get_grads()
     assert np.isfinite(gh).all()
-    assert_grads_match(gh, go, C, depth=50, cos_min=0.995, rel_max=1e-1, tag="config4 resnet50 640x192")
+    assert_grads_match(gh, go, C, depth=50, cos_min=0.997, rel_max=6e-2, tag="config4 resnet50 640x192")
 
 
 @pytest.mark.parametrize("cfgd", [(2, 1, 128, 416, 18, False), (1, 3, 320, 1024, 18, False), (1, 3, 320, 1024, 18, True)])
@@ -483,7 +483,18 @@ def test_bf16_mixed_precision_tracks_the_fp32_oracle(cfgd):
     # with the automask most pixels carry no gradient and the few mask / arg-min decisions that flip under the bf16 perturbation of the
     # disparities dominate the difference (measured 0.68 .. 0.81 from run to run: the atomics' summation order decides a few of them), without it the
     # directions agree to 0.97 at 416x128 and 0.91 at 1024x320
-    assert float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go))) > (0.6 if automask else (0.95 if W <= 416 else 0.85))
+    cos_all = float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go)))
+    if not automask:
+        assert cos_all > (0.95 if W <= 416 else 0.85)
+    else:
+        # the mask decisions are taken on bf16-perturbed disparities: a handful flip against the fp32 oracle and dominate the small masked gradient.  So the
+        # statement is made per array on the part of the network the mask does NOT reach through a few pixels -- the encoder trunk and the pose decoder, whose
+        # gradients are sums over every pixel -- and the whole vector only has to keep its direction
+        assert cos_all > 0.55
+        tab = per_array(gh, go, C, depth)
+        top = max(t[3] for t in tab)
+        worst = min(t[1] for t in tab if (t[0].startswith("enc.layer") or t[0].startswith("pose.")) and t[0].endswith(".W") and t[3] > 1e-3 * top)
+        assert worst > 0.5, "bf16 + automask: an encoder / pose weight gradient lost its direction (worst per-array cosine %.3f)" % worst
     # and it trains: a few ADAM steps reduce the loss
     l0 = float(md().train_step(model, xd, al, cache, params, do_update=True))
     for _ in range(8):
@@ -719,26 +730,33 @@ def _hip_and_oracle_grads(N, C, H, W, sd, depth=18, automask=False):
     return loss, gh, theta, x, (host(al) if automask else None), K, iK
 
 
-@pytest.mark.parametrize("case", [(1, 1, 64, 96, 101, False), (2, 1, 64, 96, 109, False), (2, 3, 64, 96, 100, True), (3, 1, 96, 160, 107, False), (5, 3, 64, 64, 109, False),
-                                  (1, 1, 64, 256, 108, False), (2, 3, 64, 256, 104, False)])
+# seeds from tools/run_seed_scan.sh (round 3: Winograd kernels, deterministic AND default mode within 2.5e-3 of the oracle in every array)
+TIGHT_CASES = [(1, 1, 64, 96, 101, False), (2, 1, 64, 96, 107, False), (2, 3, 64, 96, 110, True), (3, 1, 96, 160, 108, False), (5, 3, 64, 64, 105, False),
+               (1, 1, 64, 256, 108, False), (2, 3, 64, 256, 106, False)]
+
+
+@pytest.mark.parametrize("case", TIGHT_CASES)
 def test_gradient_parity_tight_on_kink_free_seeds(case):
     """Inputs on which no ReLU / max-pool / arg-min / clamp decision differs between the HIP and the oracle arithmetic (found with tools/seed_scan.py): there EVERY
     parameter array must agree with the oracle to 4e-3 relative, cosine >= 0.9999 (measured 2e-5 .. 2e-3) -- C = 1 and 3, automask on / off, batch 1 .. 5, a
-    ragged 160x96 frame, and two 256-wide cases in which all four encoder stages take the BatchNorm-folded convolutions (layer4 is 8 wide there).  The default (atomics, split-K) kernels run here; up to three attempts, because a reordered fp32 sum can flip a near-tie (the 160x96 case
-    was seen at 8e-3 once and 2e-3 the next run)."""
+    ragged 160x96 frame, and two 256-wide cases in which all four encoder stages take the BatchNorm-folded convolutions (layer4 is 8 wide there).
+    The statement is made ONCE, in deterministic mode (ordered reductions: the same bits every run), with no retry; the default mode (fp32 atomics, split-K, 8-slot
+    statistics) is then held against the deterministic gradient, array by array."""
     N, C, H, W, sd, automask = case
-    last = None
-    for attempt in range(3):
+    md().set_deterministic(True)
+    try:
         loss, gh, theta, x, al, K, iK = _hip_and_oracle_grads(N, C, H, W, sd, automask=automask)
-        if attempt == 0:
-            net = oracle.OracleNet(C); net.set_params(theta)
-            lo = net.train_loss(x, oracle.make_cfg(N, C, H, W, K, iK, automasking=automask), al, True); go = net.get_grads()
-        assert abs(loss - lo) / lo < 1e-4
-        try:
-            assert_grads_match(gh, go, C, cos_min=0.9999, rel_max=4e-3, tag="tight %s attempt %d" % (case, attempt)); return
-        except AssertionError as e:
-            last = e
-    raise last
+    finally:
+        md().set_deterministic(False)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    lo = net.train_loss(x, oracle.make_cfg(N, C, H, W, K, iK, automasking=automask), al, True); go = net.get_grads()
+    assert abs(loss - lo) / lo < 1e-4
+    assert_grads_match(gh, go, C, cos_min=0.9999, rel_max=4e-3, tag="tight deterministic %s" % (case,))
+    loss_d, gd, _, _, _, _, _ = _hip_and_oracle_grads(N, C, H, W, sd, automask=automask)          # default mode, same inputs
+    assert abs(loss_d - loss) / loss < 1e-5
+    # (a reordered fp32 sum may flip a near-tie in the default mode -- ~1e-2 in the arrays upstream of it, profiles/r02_grad_diag.md -- so this leg carries the general
+    #  bound: what it must catch is a default-mode kernel that computes something else than its ordered twin, which shows as O(1))
+    assert_grads_match(gd, gh, C, tag="default vs deterministic %s" % (case,))
 
 
 def test_resnet50_gradients_are_as_close_to_fp64_as_the_fp32_oracle():
@@ -771,3 +789,95 @@ def _slices(C, depth):
     off = 0
     for _, _, shape in syn.param_layout(C, depth):
         n = int(np.prod(shape)); yield off, n; off += n
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# the configurations bench.py measures, at their FULL batch
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def test_config3_b32_full_parity_vs_oracle():
+    """BASELINE.json configs[2]'s per-GPU shape, the one `bench.py` reports `value` on: ResNet-18, 416x128, C=1, batch 32 (96 frames through the encoder).  Batch 32
+    selects other launches than batch 4 (Winograd instead of split-K direct convolutions on most layers, other tile / grid choices, the 8192-block max-pool pullback):
+    disparities, poses and loss within 1e-4 of the oracle (the north-star tolerance), every gradient array compared.  (~1.5 min of oracle time on the GPU box's host cores.)"""
+    N, C, H, W = 32, 1, 128, 416
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=42)
+    x = syn.synthetic_triplets(N, C, H, W, seed=43); xd = dev(x)
+    ds, poses = model(xd, [1, 3], 2)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK)
+    dso, rvo, tvo = net.model_forward(x, cfg)
+    for i in range(4):
+        assert rel(host(ds[i]), dso[i]) < 1e-4
+    for s_ in range(2):
+        assert rel(host(poses[s_].rvec), rvo[s_]) < 1e-4 and rel(host(poses[s_].tvec), tvo[s_]) < 1e-4
+    loss = md().train_step(model, xd, None, cache, params, do_update=False)
+    lo = net.train_loss(x, cfg, None, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    gh = model.grads(); go = net.get_grads()
+    assert np.isfinite(gh).all()
+    assert_grads_match(gh, go, C, tag="config3 416x128 B=32")
+
+
+@pytest.mark.parametrize("cfgd", [(16, 3, 192, 640, 50, "f32", False), (8, 3, 320, 1024, 18, "bf16", True)], ids=["config4_resnet50_640x192_b16", "config5_1024x320_bf16_automask_b8"])
+def test_full_batch_properties_of_configs_4_and_5(cfgd):
+    """BASELINE.json configs[3] / [4] at the per-GPU batch bench.py runs them at (the oracle would need many minutes there; their N = 1 parity tests are above): finite
+    loss / gradients, a deterministic forward, batch-permutation invariance of the loss half, sample 0's loss half equal to the one-sample handle's, and a loss that
+    comes down under ADAM on a fixed batch."""
+    N, C, H, W, depth, precision, automask = cfgd
+    model, params, cache, theta, K, iK = make(N, C, H, W, automask=automask, pseed=71, depth=depth, precision=precision)
+    x = syn.synthetic_triplets(N, C, H, W, seed=72); xd = dev(x)
+    al = md().automasking_loss(md().SSIM(), xd, xd[:, 1].contiguous(), [1, 3]) if automask else None
+    l1, _, _, _ = md().train_loss(model, xd, al, cache, params, False)
+    l2, _, _, _ = md().train_loss(model, xd, al, cache, params, False)
+    assert np.isfinite(float(l1)) and abs(float(l1) - float(l2)) < 1e-6 * abs(float(l1))
+    md().gradient(model); g = model.grads()
+    assert np.isfinite(g).all() and np.linalg.norm(g) > 0
+    ds, poses = model(xd, [1, 3], 2)
+    rvec = torch.stack([poses[0].rvec, poses[1].rvec]); tvec = torch.stack([poses[0].tvec, poses[1].tvec])
+    la, _, _, _ = md().loss_fwd_bwd(model, xd, ds, rvec, tvec, auto_loss=al, want_grads=False)
+    perm = torch.randperm(N, device="cuda")
+    lb, _, _, _ = md().loss_fwd_bwd(model, xd[perm].contiguous(), [d[perm].contiguous() for d in ds], rvec[:, perm].contiguous(), tvec[:, perm].contiguous(),
+                                    auto_loss=(al[perm].contiguous() if automask else None), want_grads=False)
+    assert abs(float(la) - float(lb)) < 2e-6 * abs(float(la))
+    # sample 0 alone: the oracle's loss half on the GPU's own disparities / poses (seconds), and the mean of the per-sample values
+    cfg1 = oracle.make_cfg(1, C, H, W, K, iK, automasking=automask)
+    r = oracle.loss_fwd_bwd(x[:1], cfg1, [host(d[:1]) for d in ds], np.stack([host(poses[0].rvec[:1]), host(poses[1].rvec[:1])]), np.stack([host(poses[0].tvec[:1]), host(poses[1].tvec[:1])]),
+                            auto_loss=(host(al[:1]) if automask else None), do_bwd=False)
+    m1, p1, c1, _, _, _ = make(1, C, H, W, automask=automask, pseed=71, depth=depth, precision=precision)
+    x1 = dev(x[:1]); m1._ensure(x1, p1, c1)
+    lg, _, _, _ = md().loss_fwd_bwd(m1, x1, [d[:1].contiguous() for d in ds], torch.stack([poses[0].rvec[:1], poses[1].rvec[:1]]).contiguous(),
+                                    torch.stack([poses[0].tvec[:1], poses[1].tvec[:1]]).contiguous(), auto_loss=(al[:1].contiguous() if automask else None), want_grads=False)
+    assert abs(float(lg) - r["loss"]) / r["loss"] < 1e-5
+    losses = [float(md().train_step(model, xd, al, cache, params, True)) for _ in range(10)]
+    assert np.isfinite(losses).all() and losses[-1] < max(losses[:3]) and min(losses[5:]) < losses[1]
+
+
+def test_lr_assignment_reaches_an_existing_handle():
+    """ADAM's eta lives in the handle: `model.lr = x` on a model whose handle already exists (train(model=resumed, lr=new), src/Monodepth.jl:125) must change the step the
+    NEXT update takes.  First ADAM step: |delta| = eta |g| / (|g| + eps), i.e. eta wherever the gradient is not tiny."""
+    N, C, H, W = 1, 1, 64, 96
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=5, lr=1e-4)
+    xd = dev(syn.synthetic_triplets(N, C, H, W, seed=6))
+    md().train_step(model, xd, None, cache, params, do_update=False)          # the handle exists and holds a gradient
+    g = model.grads(); p0 = model.params()
+    model.lr = 1e-2
+    md().update(None, model)
+    d = np.abs(model.params() - p0)[np.abs(g) > 1e-6]
+    assert d.size > 1000 and abs(float(np.median(d)) - 1e-2) < 2e-4 and float(d.max()) < 1.01e-2
+
+
+def test_library_rccl_on_every_gpu_of_the_box():
+    """N > 1 on the real transport, whenever the box has more than one GPU (the driver's scaling node; skipped on the one-GPU boxes): `bench.py --gpus N` starts its own N
+    ranks, verifies the library's bucketed RCCL all-reduce against world x the local gradient before timing, and must report n_gpus = rccl_ranks = N."""
+    import json
+    import subprocess
+    import sys
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU on this box: the world > 1 RCCL path needs the multi-GPU node")
+    n = min(n, 4)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "64", "--width", "96",
+                        "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["config"]["rccl_ranks"] == n and "verified" in line["config"]["gradient_exchange"]

@@ -77,8 +77,38 @@ def pmc(df, dw, steps):
                   open(sys.argv[5], "w"), indent=1)
 
 
+def valu(d, steps, out_json, B, C, H, W):
+    """SQ counters of the loss kernels (and the per-class totals) from a --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY pass."""
+    import json
+    f = glob.glob(d + "/*counter_collection.csv")[0]
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        key = "loss_train" if "loss_train_kernel" in k else ("loss_smooth_sums" if "loss_smooth_sums" in k else klass(k))
+        a = per[key][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    print("# SQ counters per launch (rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra; B=%d C=%d %dx%d)" % (B, C, W, H))
+    print("# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles (MI355X_MICROARCH.md); a wave64 VALU instruction occupies its SIMD-32 for 2 cycles.")
+    print()
+    print("| kernel / class | launches | SQ_INSTS_VALU per launch | SQ_WAVE_CYCLES | SQ_WAIT_INST_ANY | SQ_ACTIVE_INST_ANY |")
+    print("|---|---|---|---|---|---|")
+    out = {"workload": {"batch": B, "channels": C, "height": H, "width": W}}
+    for key in sorted(per):
+        c = per[key]
+        n = c["SQ_INSTS_VALU"][0]
+        row = [c[x][1] / max(c[x][0], 1) for x in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")]
+        print("| %s | %d | %.4g | %.4g | %.4g | %.4g |" % (key, n, *row))
+        out[key] = row[0]
+    px = 4 * B * H * W * (1 + 0.25 + 0.0625 + 0.015625) / 1.328125          # pixel-scales of the four-scale loss (every scale is evaluated at full resolution)
+    if "loss_train" in out:
+        print()
+        print("loss_train_kernel: %.0f lane-instructions per pixel and scale (4 scales x B x H x W = %.3g pixel-scales per launch)" % (out["loss_train"] * 64 / (4 * B * H * W), 4 * B * H * W))
+    json.dump(out, open(out_json, "w"), indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == "valu":
+        valu(sys.argv[2], int(sys.argv[3]), sys.argv[4], *[int(v) for v in sys.argv[5:9]])
     else:
         pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]))
