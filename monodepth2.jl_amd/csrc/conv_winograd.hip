@@ -782,6 +782,189 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
     wino_final_epilogue<256, COB, BST>(a, wsm, m0, W2_T, Mt, THW, TW, c0, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fourth kernel, for the layers with enough tiles to fill the chip with 64 x 64 blocks: ONE wave per SIMD (256 threads, one workgroup per CU) so that a wave owns 512
+// registers -- 256 accumulators (64 tiles x 64 output channels x 4 positions) and a second register set for the U fragments of the next chunk.  Per multiply it moves the
+// least data of the four kernels (each U fragment feeds 8 MFMAs and is loaded once per CU, each staged pixel serves 64 channels), needs no LDS for U and shares a barrier
+// among four waves only; what it gives up is a second workgroup to hide its own transform phases behind.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NLI, int XF, int BST>
+__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs a, Wino2Geo geo) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int COB = 64;
+    constexpr int PST = 128 * NLI * 8;               // floats per patch stage: every (slot, half) item of the loader has a real slot (those past geo.nslots are never read)
+    const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_p = bid % ntp, tile_c = bid / ntp;
+    const int m0 = tile_p * W2_T, c0 = tile_c * COB;
+    const int THW = TH * TW;
+    const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
+    const int L0 = min(TW - tx0, W2_T);
+    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, W2_T), S = 4 * (2 * Lf + 2);
+    const int n_rows_total = a.N * TH;
+
+    // ---- loader: item f = tid + 256 li = (slot f >> 1, 16-B half f & 1); LDS position = slot * 8 + swizzled half, i.e. l_dst0 + li * 1024 floats
+    unsigned l_off[NLI]; unsigned l_ok = 0;
+    const int h2 = tid & 1;
+    const int l_dst0 = (tid >> 1) * 8 + ((h2 ^ ((tid >> 4) & 1)) << 2);
+#pragma unroll
+    for (int li = 0; li < NLI; ++li) {
+        const int slot = (tid + 256 * li) >> 1;
+        int k, r, WP, txa, Lk;
+        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
+        else { const int s2 = slot - S0; k = 1 + s2 / S; r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, W2_T - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
+        const int pa = r / WP, pc = r - pa * WP;
+        const int rr = rr_first + k;
+        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+        const int rrc = act ? rr : 0;
+        const int n = rrc / TH, ty = rrc - n * TH;
+        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+        bool ok = act;
+        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        l_ok |= ok ? (1u << li) : 0u;
+        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(h2 * 4)) * 4u : (unsigned)(h2 * 16);
+    }
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    uint4 ra[NLI];
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 32)));
+        if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 8 + h2 * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 8 + h2 * 4); }
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            const unsigned mk = 0u - ((l_ok >> li) & 1u);
+            uint4 v = ra[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));          // pins the mask / transform arithmetic (and the loads' wait) at the commit point
+            if constexpr (XF != 0) {
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
+            }
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 1024) = v;
+        }
+    };
+
+    // ---- consumer: lane = (tile within a 32-tile half, k-half); B^T row i combines patch rows (r1, r2)
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int tl = lane & 31, ch = lane >> 5;
+    int c_off1[2][4], c_off2[2][4];
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+        const int ct = th * 32 + tl;
+        const int u = tx0 + ct, k = u / TW;
+        const int lc = (k == 0) ? ct : (u - k * TW);
+        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, W2_T - L0 - (k - 1) * TW) + 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
+            c_off1[th][b] = sl1 * 8 + ((ch ^ ((sl1 >> 3) & 1)) << 2);
+            c_off2[th][b] = sl2 * 8 + ((ch ^ ((sl2 >> 3) & 1)) << 2);
+#ifdef MD2_ABLATE
+            if (a.ablate & 16) { c_off1[th][b] = tl * 4 + ch * 128 + th * 256 + b * 512; c_off2[th][b] = c_off1[th][b] + 2048; }      // timing experiment: conflict-free (wrong) read addresses
+#endif
+        }
+    }
+
+    f32x16 acc[4][2][2];          // [j][tile half][cout sub-tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][t][s2][e] = 0.f;
+
+    // U streams of this wave (two 32-channel sub-tiles): fragment (c8, j) of sub-tile s at ub[s] + (c8 * 4 + j) * 256 floats.  One wave per SIMD owns 512 registers:
+    // the 8 fragments of chunk c + 1 are loaded into a second register set at the top of chunk c -- a full chunk of prefetch distance, no LDS, no sharing needed
+    const int nchunks = a.Cin >> 3;
+    const float* ub0 = a.wino_u + ((long)((tile_c * 2 + 0) * 4 + wi) * nchunks) * 4 * 256 + lane * 4;
+    const float* ub1 = a.wino_u + ((long)((tile_c * 2 + 1) * 4 + wi) * nchunks) * 4 * 256 + lane * 4;
+    f32x4 uf[2][4], un[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { uf[0][j] = *reinterpret_cast<const f32x4*>(ub0 + j * 256); uf[1][j] = *reinterpret_cast<const f32x4*>(ub1 + j * 256); }
+
+#ifdef MD2_ABLATE
+    const int abl = a.ablate;
+#else
+    constexpr int abl = 0;
+#endif
+    gload(0); lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int so = (c & 1) * PST;
+        const int cn = min(c + 1, nchunks - 1);          // past the end: the last chunk again, into the stage nobody reads any more (keeps the loop body branch-free)
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { un[0][j] = *reinterpret_cast<const f32x4*>(ub0 + (long)cn * 1024 + j * 256); un[1][j] = *reinterpret_cast<const f32x4*>(ub1 + (long)cn * 1024 + j * 256); }
+        }
+        if (!(abl & 1)) gload(cn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+            float4 V[4];
+            {
+                float4 rr[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + c_off1[th][b]);
+                    const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + c_off2[th][b]);
+                    rr[b] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+                }
+                V[0] = make_float4(rr[0].x - rr[2].x, rr[0].y - rr[2].y, rr[0].z - rr[2].z, rr[0].w - rr[2].w);
+                V[1] = make_float4(rr[1].x + rr[2].x, rr[1].y + rr[2].y, rr[1].z + rr[2].z, rr[1].w + rr[2].w);
+                V[2] = make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w);
+                V[3] = make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w);
+            }
+            if (!(abl & 4)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        acc[j][th][s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s2][j][0], V[j].x, acc[j][th][s2], 0, 0, 0);
+                        acc[j][th][s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s2][j][1], V[j].y, acc[j][th][s2], 0, 0, 0);
+                        acc[j][th][s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s2][j][2], V[j].z, acc[j][th][s2], 0, 0, 0);
+                        acc[j][th][s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s2][j][3], V[j].w, acc[j][th][s2], 0, 0, 0);
+                    }
+            } else asm volatile("" :: "v"(V[0].x), "v"(V[1].x), "v"(V[2].x), "v"(V[3].x), "v"(uf[0][0][0]), "v"(uf[1][3][3]));
+        }
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { uf[0][j] = un[0][j]; uf[1][j] = un[1][j]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 1)) lstore(PST - so);
+        if (!(abl & 8)) __syncthreads();
+    }
+
+    // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4], 139 KB: this workgroup has the CU's LDS to itself)
+    constexpr int RLD = COB + 4;
+    float* Rl = wsm;
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 o0, o1;
+                o0.x = acc[0][th][s2][4 * g + 0] + acc[1][th][s2][4 * g + 0] + acc[2][th][s2][4 * g + 0]; o1.x = acc[1][th][s2][4 * g + 0] - acc[2][th][s2][4 * g + 0] - acc[3][th][s2][4 * g + 0];
+                o0.y = acc[0][th][s2][4 * g + 1] + acc[1][th][s2][4 * g + 1] + acc[2][th][s2][4 * g + 1]; o1.y = acc[1][th][s2][4 * g + 1] - acc[2][th][s2][4 * g + 1] - acc[3][th][s2][4 * g + 1];
+                o0.z = acc[0][th][s2][4 * g + 2] + acc[1][th][s2][4 * g + 2] + acc[2][th][s2][4 * g + 2]; o1.z = acc[1][th][s2][4 * g + 2] - acc[2][th][s2][4 * g + 2] - acc[3][th][s2][4 * g + 2];
+                o0.w = acc[0][th][s2][4 * g + 3] + acc[1][th][s2][4 * g + 3] + acc[2][th][s2][4 * g + 3]; o1.w = acc[1][th][s2][4 * g + 3] - acc[2][th][s2][4 * g + 3] - acc[3][th][s2][4 * g + 3];
+                const int col = s2 * 32 + 8 * g + 4 * ch, ct = th * 32 + tl;
+                *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * W2_T + ct) * RLD + col) = o0;
+                *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * W2_T + ct) * RLD + col) = o1;
+            }
+    __syncthreads();
+    wino_final_epilogue<256, COB, BST>(a, wsm, m0, W2_T, Mt, THW, TW, c0, tid);
+}
+
 // patch slots a block can need at tile-row width TW: worst case over the position of its first tile
 static int wino2_slots(int TW) {
     const int Lf = std::min(TW, W2_T), S = 4 * (2 * Lf + 2);
@@ -829,6 +1012,30 @@ static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) 
     else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0>), dim3(grid), dim3(256), lds, s, a, g);
 }
 static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) { launch_wino3_t<5>(a, g, s); }
+static bool wino4_eligible(const ConvArgs& a, Wino2Geo& g) {
+    static const bool off = getenv("MD2_NO_WINO4") != nullptr;
+    static const long minb = getenv("MD2_WINO4_MIN_BLOCKS") ? atol(getenv("MD2_WINO4_MIN_BLOCKS")) : (1L << 40);
+    if (off || (g_wino_on != 1 && g_wino_on != 5) || a.Cout % 64 != 0 || a.Cin % 8 != 0) return false;
+    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW; g.ntp = (g.Mt + W2_T - 1) / W2_T;
+    g.nslots = wino2_slots(g.TW);
+    if (g.nslots > 128 * 5) return false;
+    return g_wino_on == 5 || (long)g.ntp * (a.Cout / 64) >= minb;
+}
+static void launch_wino4(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
+    constexpr size_t lds_pipe = (size_t)2 * 128 * 5 * 8 * sizeof(float), lds_epi = (size_t)8 * W2_T * (64 + 4) * sizeof(float);
+    constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<5, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<5, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<5, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = g.ntp * (a.Cout / 64);
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino4_kernel<5, 1, 0>), dim3(grid), dim3(256), lds, s, a, g);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino4_kernel<5, 0, 1>), dim3(grid), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino4_kernel<5, 0, 0>), dim3(grid), dim3(256), lds, s, a, g);
+}
 static void launch_wino2(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
     const size_t lds_pipe = ((size_t)2 * (g.nslots * 8 + 256) + 2 * 8192) * sizeof(float), lds_epi = (size_t)8 * W2_T * (64 + 4) * sizeof(float);
     const size_t lds = std::max(lds_pipe, lds_epi);
@@ -898,7 +1105,8 @@ void launch_conv_wino(const ConvArgs& a_in, hipStream_t s) {
     if (a.stats && !stats_ok) a.stats = nullptr;
     if (a.bst && !fuse) { a.bst = nullptr; a.bstB = nullptr; }
     Wino2Geo g2;
-    if (wino3_eligible(a, g2)) launch_wino3(a, g2, s);
+    if (wino4_eligible(a, g2)) launch_wino4(a, g2, s);
+    else if (wino3_eligible(a, g2)) launch_wino3(a, g2, s);
     else if (wino2_eligible(a, g2)) launch_wino2(a, g2, s);
     else if (a.Cout % 64 == 0) launch_wino_t<2>(a, s); else launch_wino_t<1>(a, s);
     View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
