@@ -235,7 +235,9 @@ def main():
         extra = {"frames_per_s": 3.0 * value}         # one triplet = 3 frames through the encoder
         if wg["ms"] > 0:
             a = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
-            extra["roofline_conv_wgrad"] = {"bound": "mfma", "achieved": a, "peak": peak_tf, "unit": "TFLOP/s", "frac": a / peak_tf, "ms_per_step": wg["ms"] / 3}
+            ax = wg["flops_executed"] / (wg["ms"] * 1e-3) / 1e12
+            extra["roofline_conv_wgrad"] = {"bound": "mfma", "kernel": "conv_wino_wgrad_kernel (Winograd domain: the 3x3 stride-1 layers) + conv_wgrad_kernel<*> + conv3x3_wgrad_*_kernel + stem_wgrad_kernel",
+                                            "achieved": a, "peak": peak_tf, "unit": "TFLOP/s", "frac": a / peak_tf, "executed_achieved": ax, "executed_frac": ax / peak_tf, "ms_per_step": wg["ms"] / 3}
         # the training step runs the loss as ONE class: smoothness sums + the fused value-and-pullback kernel ("loss_train"); "loss_fwd" only exists in forward-only calls
         for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_train", lb)):
             if p["ms"] > 0:

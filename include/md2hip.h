@@ -99,7 +99,7 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host_state, int64_t n);
 int32_t md2_set_deterministic(int32_t on);
 /* Algorithm choice for the 3x3 / stride-1 convolutions (the reference leaves it to cuDNN behind Flux `Conv`, src/depth_decoder.jl:13-14): on = 1 (default) routes launches
  * with at least min_blocks workgroups (default 160; < 0 keeps the current value) to the fused Winograd F(2x2,3x3) kernels, on = 0 forces the direct implicit GEMM;
- * on = 2 / 3 / 4 pin one of the three Winograd kernels (32 tiles x 64 channels; 64 x 64, 512 threads; 64 x 32) wherever it applies (tests, tuning).
+ * on = 2 / 3 pin one of the two Winograd kernels (32 tiles x 64 channels per workgroup; 64 tiles x 32 channels) wherever it applies (tests, tuning).
  * Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MIN_BLOCKS in the environment at load time. */
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks);
 /* ADAM moments (Flux parameter layout, host) + running beta powers: the optimiser state the reference's BSON checkpoints

@@ -1683,6 +1683,7 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
         if (wgrad_taps32_eligible(b)) launch_wgrad_taps32(b, s); else if (b.Cout == 16) launch_wgrad_patch<1>(b, s); else launch_wgrad_patch<2>(b, s);
         return;
     }
+    if (conv_wino_wgrad_eligible(a)) { launch_conv_wino_wgrad(a, s); return; }
     if (wgrad_taps32_eligible(a)) { launch_wgrad_taps32(a, s); return; }
     if (wgrad_patch_eligible(a)) { if (a.Cout == 16) launch_wgrad_patch<1>(a, s); else launch_wgrad_patch<2>(a, s); return; }
     if (a.db) { View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s); }

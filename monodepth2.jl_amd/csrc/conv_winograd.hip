@@ -10,6 +10,8 @@
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      d: 4x4 input patch of a 2x2 output tile, g: 3x3 taps (cross-correlation form)
 //
+// Two kernels: conv_wino3_kernel (64 tiles x 32 channels per block, further down) is the one the training step takes; conv_wino_kernel (first version, described here)
+// stays for shapes the other cannot stage (tile rows shorter than 4 tiles) and as the pinned alternative of the tests.
 // Block = 256 threads = 4 waves; block tile = 32 Winograd tiles (128 output pixels, flattened over (n, ty, tx) so that 13x4 maps pack like 104x32 ones)
 // x 32*NS output channels.  Wave i owns Winograd row i: the four positions (i, j), j = 0..3, i.e. acc[j][s] = U_(i,j)[32 couts s][K] . V_(i,j)[K][32 tiles].
 //   * input: the raw 4x4 patches of the 32 tiles for a 16-channel chunk are staged in LDS ([16 patch slots][32 tiles][16 ch], 32 KB, double buffered);
@@ -340,17 +342,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int TH, i
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Second-generation kernel for the layers with many tiles (Cin % 8 == 0, Cout % 64 == 0): 512 threads = 8 waves, block tile = 64 Winograd tiles x 64 output
-// channels, 8-channel K chunks.  Measured on the first kernel (tools/conv_bench ablations, 96x32x104, 512 -> 64): MFMAs alone 0.68 ms, operand loads alone 0.88 ms
-// (the U fragments 0.65 of it, at 4 KB in flight per wave) -- it is bound by L2 -> CU operand traffic, not by the matrix pipe.  So, per multiply:
-//   * U: half the traffic -- the two waves (i, tile half 0 / 1) that need the same fragments share them.  The 32 fragments of a chunk (32 KB, fragment order = lane-linear
-//     1-KB pieces) are copied into an LDS double buffer one whole chunk ahead, 4 per wave: no per-fragment waits.
-//   * patches: horizontally adjacent tiles share two of their four columns.  The block's 64 consecutive tiles are cut into row segments; a segment of L tiles stages
-//     4 rows x (2 L + 2) pixels once instead of 16 L pixel slots (~1.9x fewer gathered bytes and LDS).
-//   * everything a chunk needs is loaded to registers at the top of the previous chunk and committed to LDS right before that chunk's single barrier.
-// One workgroup per CU (139 KB of LDS in the epilogue, 256 registers): the layers with few tiles (1/16, 1/32 scale) stay on the 256-thread kernel above.
+// What the first kernel is bound by (tools/conv_bench ablations, 96 x 32x104, 512 -> 64 channels): MFMAs alone 0.68 ms, operand loads alone 0.88 ms -- the U fragments
+// 0.65 of it at 4 KB in flight per wave, the 16 patch slots per tile the rest -- i.e. L2 -> CU operand traffic and its latency, not the matrix pipe.  The kernel below
+// moves less per multiply.  Shared pieces first: the geometry of row-segment patch staging and the epilogue.
+//   Patches: horizontally adjacent tiles share two of their four columns.  A block's 64 consecutive (flattened) tiles are cut into row segments; a segment of L tiles stages
+//   4 rows x (2 L + 2) pixels once instead of 16 L pixel slots (~1.9x fewer gathered bytes and LDS); slot = segment base + row * (2 L + 2) + column.
+// Measured and rejected on the way (same shape; kept out of the source): 512 threads per 64 x 64 block with the U fragments shared through an LDS double buffer (1.02 ms: one
+// lockstep workgroup per CU overlaps nothing -- its skeleton without MFMAs and loads is 0.28 ms; filled by global_load_lds it was slower still, because hipcc drains
+// vmcnt(0) before the first ds_read of every chunk, an LDS-DMA may alias any LDS read); one wave per SIMD with 512 registers and 256 accumulators (64 x 64 per wave,
+// 5.1 ms: nothing hides that wave's own LDS / transform latency).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int W2_T = 64, W2_NLI = 4;
+constexpr int W2_T = 64;
 struct Wino2Geo { int TH, TW, Mt, ntp, nslots; };      // nslots: patch slots allocated per stage (host: worst case over the blocks), multiple of 16
 
 template <int NTHR, int COB, int BST>
@@ -431,191 +433,16 @@ __device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __
     }
 }
 
-template <int XF, int BST>
-__global__ __launch_bounds__(512, 2) void conv_wino64_kernel(ConvArgs a, Wino2Geo geo) {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];
-    constexpr int COB = 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
-    const int PST = geo.nslots * 8 + 256;            // floats per patch stage: [slot][8 channels] + a 1-KB dummy row for the loader's inactive items
-    float* const Ubuf = wsm + 2 * PST;               // [2][32 fragments][256 floats]
-    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_p = bid % ntp, tile_c = bid / ntp;
-    const int m0 = tile_p * W2_T, c0 = tile_c * COB;
-    const int THW = TH * TW;
-    // ---- row segments of the block's 64 consecutive tiles: segment 0 = tiles up to the end of the first tile row, then whole rows
-    const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
-    const int L0 = min(TW - tx0, W2_T);
-    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, W2_T), S = 4 * (2 * Lf + 2);
-    const int n_rows_total = a.N * TH;
-
-    // ---- loader: item f = tid + 512 li = (slot f >> 1, 16-B half f & 1) of a stage; pixel address, validity and LDS position are fixed for the whole K loop
-    unsigned l_off[W2_NLI]; int l_dst[W2_NLI]; unsigned l_ok = 0;
-    const int h2 = tid & 1;
-#pragma unroll
-    for (int li = 0; li < W2_NLI; ++li) {
-        const int slot = (tid + 512 * li) >> 1;
-        int k, r, WP, txa, Lk;
-        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
-        else { const int s2 = slot - S0; k = 1 + s2 / S; r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, W2_T - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
-        const int pa = r / WP, pc = r - pa * WP;
-        const int rr = rr_first + k;
-        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
-        const int rrc = act ? rr : 0;
-        const int n = rrc / TH, ty = rrc - n * TH;
-        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
-        bool ok = act;
-        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
-        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        l_ok |= ok ? (1u << li) : 0u;
-        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(h2 * 4)) * 4u : (unsigned)(h2 * 16);
-        // inactive items store into a per-lane dummy row behind the stage instead of branching around the store: with conditional stores hipcc sinks each prefetch
-        // load into the branch of its store (load -> wait -> store at the bottom of the chunk: no prefetch at all)
-        l_dst[li] = act ? slot * 8 + ((h2 ^ ((slot >> 3) & 1)) << 2) : geo.nslots * 8 + lane * 4;
-    }
-    const char* xb = reinterpret_cast<const char*>(a.x);
-    uint4 ra[W2_NLI];
-    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto gload = [&](int c) {
-#pragma unroll
-        for (int li = 0; li < W2_NLI; ++li) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 32)));
-        if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 8 + h2 * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 8 + h2 * 4); }
-    };
-    auto lstore = [&](int so) {
-#pragma unroll
-        for (int li = 0; li < W2_NLI; ++li) {
-            const unsigned mk = 0u - ((l_ok >> li) & 1u);
-            uint4 v = ra[li];
-            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));          // pins the mask / transform arithmetic (and the loads' wait) here: instruction selection
-                                                                                    // otherwise floats these pure ALU nodes to the top of the block, above both sched_barriers
-            if constexpr (XF != 0) {
-                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
-                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
-            }
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
-            *reinterpret_cast<uint4*>(wsm + so + l_dst[li]) = v;
-        }
-    };
-    // ---- U: fragment fidx = (i * 4 + j) * 2 + s of chunk c8 -> Ubuf[c8 & 1][fidx]; wave w copies fragments 4 w .. 4 w + 3
-    const int nchunks = a.Cin >> 3;
-    const float* usrc[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int fidx = wave * 4 + e, fi = fidx >> 3, fj = (fidx >> 1) & 3, fs = fidx & 1;
-        usrc[e] = a.wino_u + (((long)((tile_c * 2 + fs) * 4 + fi) * nchunks) * 4 + fj) * 256 + lane * 4;          // + c8 * 1024 floats
-    }
-    // (register-staged like the patches: with global_load_lds hipcc drains vmcnt(0) before the first ds_read of every chunk -- an LDS-DMA may alias any LDS read --
-    //  which serialises the prefetch with the chunk it was meant to overlap; ordinary loads get counted waits at their use, the ds_write at the bottom of the chunk)
-    f32x4 uv0, uv1, uv2, uv3;
-#define W2_ULOAD(c_) do { const long o_ = (long)(c_) * 1024; uv0 = *reinterpret_cast<const f32x4*>(usrc[0] + o_); uv1 = *reinterpret_cast<const f32x4*>(usrc[1] + o_); \
-                          uv2 = *reinterpret_cast<const f32x4*>(usrc[2] + o_); uv3 = *reinterpret_cast<const f32x4*>(usrc[3] + o_); } while (0)
-#define W2_USTORE(c_) do { float* d_ = Ubuf + ((c_) & 1) * 8192 + wave * 4 * 256 + lane * 4; *reinterpret_cast<f32x4*>(d_) = uv0; *reinterpret_cast<f32x4*>(d_ + 256) = uv1; \
-                           *reinterpret_cast<f32x4*>(d_ + 512) = uv2; *reinterpret_cast<f32x4*>(d_ + 768) = uv3; } while (0)
-
-    // ---- consumer: wave = (Winograd row i, tile half th); lane = (tile, k-half)
-    const int wi = wave & 3, th = wave >> 2;
-    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
-    const float sg = (wi == 1) ? 1.f : -1.f;
-    const int ct = th * 32 + (lane & 31), ch = lane >> 5;
-    int c_off1[4], c_off2[4];
-    {
-        const int u = tx0 + ct, k = u / TW;
-        const int lc = (k == 0) ? ct : (u - k * TW);
-        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, W2_T - L0 - (k - 1) * TW) + 2;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
-            c_off1[b] = sl1 * 8 + ((ch ^ ((sl1 >> 3) & 1)) << 2);
-            c_off2[b] = sl2 * 8 + ((ch ^ ((sl2 >> 3) & 1)) << 2);
-        }
-    }
-    const int u_rd = (wi * 4) * 2 * 256 + lane * 4;             // + (j * 2 + s) * 256
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][s][e] = 0.f;
-
-#ifdef MD2_ABLATE
-    const int abl = a.ablate;
-#else
-    constexpr int abl = 0;
-#endif
-    W2_ULOAD(0);
-    gload(0);
-    W2_USTORE(0); lstore(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int so = (c & 1) * PST;
-        const float* ub = Ubuf + (c & 1) * 8192 + u_rd;
-        const int cn = min(c + 1, nchunks - 1);          // past the end: the last chunk again, into the stage nobody reads any more (keeps the loop body branch-free)
-        if (!(abl & 2)) W2_ULOAD(cn);
-        if (!(abl & 1)) gload(cn);
-        __builtin_amdgcn_sched_barrier(0);             // the prefetch is issued here, before the chunk's arithmetic
-        float4 V[4];
-        {
-            float4 rr[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + c_off1[b]);
-                const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + c_off2[b]);
-                rr[b] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
-            }
-            V[0] = make_float4(rr[0].x - rr[2].x, rr[0].y - rr[2].y, rr[0].z - rr[2].z, rr[0].w - rr[2].w);
-            V[1] = make_float4(rr[1].x + rr[2].x, rr[1].y + rr[2].y, rr[1].z + rr[2].z, rr[1].w + rr[2].w);
-            V[2] = make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w);
-            V[3] = make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const float4 u = *reinterpret_cast<const float4*>(ub + (j * 2 + s) * 256);
-                if (!(abl & 4)) {
-                acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.x, V[j].x, acc[j][s], 0, 0, 0);
-                acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.y, V[j].y, acc[j][s], 0, 0, 0);
-                acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.z, V[j].z, acc[j][s], 0, 0, 0);
-                acc[j][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(u.w, V[j].w, acc[j][s], 0, 0, 0);
-                } else asm volatile("" :: "v"(u.x), "v"(u.y), "v"(u.z), "v"(u.w), "v"(V[j].x));
-            }
-        __builtin_amdgcn_sched_barrier(0);             // ... and committed here, behind it (hipcc otherwise hoists the padding masks, and with them the loads' wait, to the top)
-        if (!(abl & 2)) W2_USTORE(c + 1);          // (the loads of chunk c + 1 are waited for here, at their use)
-        if (!(abl & 1)) lstore(PST - so);
-        __syncthreads();
-    }
-
-    // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4], 139 KB: the pipeline buffers are dead)
-    constexpr int RLD = COB + 4;
-    float* Rl = wsm;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 o0, o1;
-            o0.x = acc[0][s][4 * g + 0] + acc[1][s][4 * g + 0] + acc[2][s][4 * g + 0]; o1.x = acc[1][s][4 * g + 0] - acc[2][s][4 * g + 0] - acc[3][s][4 * g + 0];
-            o0.y = acc[0][s][4 * g + 1] + acc[1][s][4 * g + 1] + acc[2][s][4 * g + 1]; o1.y = acc[1][s][4 * g + 1] - acc[2][s][4 * g + 1] - acc[3][s][4 * g + 1];
-            o0.z = acc[0][s][4 * g + 2] + acc[1][s][4 * g + 2] + acc[2][s][4 * g + 2]; o1.z = acc[1][s][4 * g + 2] - acc[2][s][4 * g + 2] - acc[3][s][4 * g + 2];
-            o0.w = acc[0][s][4 * g + 3] + acc[1][s][4 * g + 3] + acc[2][s][4 * g + 3]; o1.w = acc[1][s][4 * g + 3] - acc[2][s][4 * g + 3] - acc[3][s][4 * g + 3];
-            const int col = s * 32 + 8 * g + 4 * ch;
-            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * W2_T + ct) * RLD + col) = o0;
-            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * W2_T + ct) * RLD + col) = o1;
-        }
-    __syncthreads();
-    wino_final_epilogue<512, COB, BST>(a, wsm, m0, W2_T, Mt, THW, TW, c0, tid);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// Third kernel: what the two above taught, combined.  256 threads (wave = Winograd row i), TWO independent workgroups per CU -- one workgroup's MFMAs run under the other's
-// LDS / transform / commit phases, which a single lockstep 8-wave workgroup cannot do (conv_wino64_kernel: skeleton without MFMAs and loads = 0.28 of 1.02 ms).
-// Block tile = 64 tiles x 32 output channels, 8-channel chunks:
+// The kernel the step uses: 256 threads (wave = Winograd row i), TWO independent workgroups per CU, block tile = 64 tiles x 32 output channels, 8-channel chunks:
 //   * a wave contracts BOTH 32-tile halves against the same U fragment (8 MFMAs per 1-KB fragment: half the U traffic per multiply of conv_wino_kernel), and the
-//     fragment is private to the wave, so it goes global -> registers with no LDS round trip.  Ring of 4 fragments refilled IN PLACE: slot j is reloaded with chunk c + 1's
-//     fragment right after chunk c's last use -- a full chunk of prefetch distance for 16 registers, and every U load is older than the patch loads issued after it, so its
-//     counted wait never waits for them;
-//   * row-segment patch staging as in conv_wino64_kernel (each staged pixel serves two tiles), branch-free loader, commit pinned behind the chunk's MFMAs.
+//     fragment is private to the wave, so it goes global -> registers with no LDS round trip.  Four fragment registers refilled IN PLACE right behind a fragment's last use
+//     in the chunk: three MFMA groups, the commit, the barrier and a transform phase of prefetch distance for 16 registers, and every U load is older than the patch loads
+//     issued after it, so its counted wait never waits for them;
+//   * row-segment patch staging (each staged pixel serves two tiles), branch-free loader (conditional stores make hipcc sink every prefetch load into the branch of its
+//     store), commit pinned behind the chunk's MFMAs with sched_barrier + an empty asm on the loaded registers (instruction selection otherwise floats the padding masks,
+//     and with them the loads' wait, to the top of the block).
+// In-model at batch 32 (tools/run_layer_compare.sh): 0.215 -> 0.153 ms on the 64-channel layers, 0.217 -> 0.141 (128), 0.211 -> 0.160 (256), 0.218 -> 0.188 (512).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NLI, int XF, int BST>
 __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo geo) {
@@ -782,189 +609,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
     wino_final_epilogue<256, COB, BST>(a, wsm, m0, W2_T, Mt, THW, TW, c0, tid);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Fourth kernel, for the layers with enough tiles to fill the chip with 64 x 64 blocks: ONE wave per SIMD (256 threads, one workgroup per CU) so that a wave owns 512
-// registers -- 256 accumulators (64 tiles x 64 output channels x 4 positions) and a second register set for the U fragments of the next chunk.  Per multiply it moves the
-// least data of the four kernels (each U fragment feeds 8 MFMAs and is loaded once per CU, each staged pixel serves 64 channels), needs no LDS for U and shares a barrier
-// among four waves only; what it gives up is a second workgroup to hide its own transform phases behind.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int NLI, int XF, int BST>
-__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs a, Wino2Geo geo) {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];
-    constexpr int COB = 64;
-    constexpr int PST = 128 * NLI * 8;               // floats per patch stage: every (slot, half) item of the loader has a real slot (those past geo.nslots are never read)
-    const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
-    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
-    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_p = bid % ntp, tile_c = bid / ntp;
-    const int m0 = tile_p * W2_T, c0 = tile_c * COB;
-    const int THW = TH * TW;
-    const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
-    const int L0 = min(TW - tx0, W2_T);
-    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, W2_T), S = 4 * (2 * Lf + 2);
-    const int n_rows_total = a.N * TH;
-
-    // ---- loader: item f = tid + 256 li = (slot f >> 1, 16-B half f & 1); LDS position = slot * 8 + swizzled half, i.e. l_dst0 + li * 1024 floats
-    unsigned l_off[NLI]; unsigned l_ok = 0;
-    const int h2 = tid & 1;
-    const int l_dst0 = (tid >> 1) * 8 + ((h2 ^ ((tid >> 4) & 1)) << 2);
-#pragma unroll
-    for (int li = 0; li < NLI; ++li) {
-        const int slot = (tid + 256 * li) >> 1;
-        int k, r, WP, txa, Lk;
-        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
-        else { const int s2 = slot - S0; k = 1 + s2 / S; r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, W2_T - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
-        const int pa = r / WP, pc = r - pa * WP;
-        const int rr = rr_first + k;
-        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
-        const int rrc = act ? rr : 0;
-        const int n = rrc / TH, ty = rrc - n * TH;
-        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
-        bool ok = act;
-        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
-        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        l_ok |= ok ? (1u << li) : 0u;
-        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(h2 * 4)) * 4u : (unsigned)(h2 * 16);
-    }
-    const char* xb = reinterpret_cast<const char*>(a.x);
-    uint4 ra[NLI];
-    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto gload = [&](int c) {
-#pragma unroll
-        for (int li = 0; li < NLI; ++li) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 32)));
-        if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 8 + h2 * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 8 + h2 * 4); }
-    };
-    auto lstore = [&](int so) {
-#pragma unroll
-        for (int li = 0; li < NLI; ++li) {
-            const unsigned mk = 0u - ((l_ok >> li) & 1u);
-            uint4 v = ra[li];
-            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));          // pins the mask / transform arithmetic (and the loads' wait) at the commit point
-            if constexpr (XF != 0) {
-                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
-                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
-            }
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
-            *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 1024) = v;
-        }
-    };
-
-    // ---- consumer: lane = (tile within a 32-tile half, k-half); B^T row i combines patch rows (r1, r2)
-    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
-    const float sg = (wi == 1) ? 1.f : -1.f;
-    const int tl = lane & 31, ch = lane >> 5;
-    int c_off1[2][4], c_off2[2][4];
-#pragma unroll
-    for (int th = 0; th < 2; ++th) {
-        const int ct = th * 32 + tl;
-        const int u = tx0 + ct, k = u / TW;
-        const int lc = (k == 0) ? ct : (u - k * TW);
-        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, W2_T - L0 - (k - 1) * TW) + 2;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
-            c_off1[th][b] = sl1 * 8 + ((ch ^ ((sl1 >> 3) & 1)) << 2);
-            c_off2[th][b] = sl2 * 8 + ((ch ^ ((sl2 >> 3) & 1)) << 2);
-#ifdef MD2_ABLATE
-            if (a.ablate & 16) { c_off1[th][b] = tl * 4 + ch * 128 + th * 256 + b * 512; c_off2[th][b] = c_off1[th][b] + 2048; }      // timing experiment: conflict-free (wrong) read addresses
-#endif
-        }
-    }
-
-    f32x16 acc[4][2][2];          // [j][tile half][cout sub-tile]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[j][t][s2][e] = 0.f;
-
-    // U streams of this wave (two 32-channel sub-tiles): fragment (c8, j) of sub-tile s at ub[s] + (c8 * 4 + j) * 256 floats.  One wave per SIMD owns 512 registers:
-    // the 8 fragments of chunk c + 1 are loaded into a second register set at the top of chunk c -- a full chunk of prefetch distance, no LDS, no sharing needed
-    const int nchunks = a.Cin >> 3;
-    const float* ub0 = a.wino_u + ((long)((tile_c * 2 + 0) * 4 + wi) * nchunks) * 4 * 256 + lane * 4;
-    const float* ub1 = a.wino_u + ((long)((tile_c * 2 + 1) * 4 + wi) * nchunks) * 4 * 256 + lane * 4;
-    f32x4 uf[2][4], un[2][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { uf[0][j] = *reinterpret_cast<const f32x4*>(ub0 + j * 256); uf[1][j] = *reinterpret_cast<const f32x4*>(ub1 + j * 256); }
-
-#ifdef MD2_ABLATE
-    const int abl = a.ablate;
-#else
-    constexpr int abl = 0;
-#endif
-    gload(0); lstore(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int so = (c & 1) * PST;
-        const int cn = min(c + 1, nchunks - 1);          // past the end: the last chunk again, into the stage nobody reads any more (keeps the loop body branch-free)
-        if (!(abl & 2)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { un[0][j] = *reinterpret_cast<const f32x4*>(ub0 + (long)cn * 1024 + j * 256); un[1][j] = *reinterpret_cast<const f32x4*>(ub1 + (long)cn * 1024 + j * 256); }
-        }
-        if (!(abl & 1)) gload(cn);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int th = 0; th < 2; ++th) {
-            float4 V[4];
-            {
-                float4 rr[4];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + c_off1[th][b]);
-                    const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + c_off2[th][b]);
-                    rr[b] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
-                }
-                V[0] = make_float4(rr[0].x - rr[2].x, rr[0].y - rr[2].y, rr[0].z - rr[2].z, rr[0].w - rr[2].w);
-                V[1] = make_float4(rr[1].x + rr[2].x, rr[1].y + rr[2].y, rr[1].z + rr[2].z, rr[1].w + rr[2].w);
-                V[2] = make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w);
-                V[3] = make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w);
-            }
-            if (!(abl & 4)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        acc[j][th][s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s2][j][0], V[j].x, acc[j][th][s2], 0, 0, 0);
-                        acc[j][th][s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s2][j][1], V[j].y, acc[j][th][s2], 0, 0, 0);
-                        acc[j][th][s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s2][j][2], V[j].z, acc[j][th][s2], 0, 0, 0);
-                        acc[j][th][s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[s2][j][3], V[j].w, acc[j][th][s2], 0, 0, 0);
-                    }
-            } else asm volatile("" :: "v"(V[0].x), "v"(V[1].x), "v"(V[2].x), "v"(V[3].x), "v"(uf[0][0][0]), "v"(uf[1][3][3]));
-        }
-        if (!(abl & 2)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { uf[0][j] = un[0][j]; uf[1][j] = un[1][j]; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(abl & 1)) lstore(PST - so);
-        if (!(abl & 8)) __syncthreads();
-    }
-
-    // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4], 139 KB: this workgroup has the CU's LDS to itself)
-    constexpr int RLD = COB + 4;
-    float* Rl = wsm;
-#pragma unroll
-    for (int th = 0; th < 2; ++th)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 o0, o1;
-                o0.x = acc[0][th][s2][4 * g + 0] + acc[1][th][s2][4 * g + 0] + acc[2][th][s2][4 * g + 0]; o1.x = acc[1][th][s2][4 * g + 0] - acc[2][th][s2][4 * g + 0] - acc[3][th][s2][4 * g + 0];
-                o0.y = acc[0][th][s2][4 * g + 1] + acc[1][th][s2][4 * g + 1] + acc[2][th][s2][4 * g + 1]; o1.y = acc[1][th][s2][4 * g + 1] - acc[2][th][s2][4 * g + 1] - acc[3][th][s2][4 * g + 1];
-                o0.z = acc[0][th][s2][4 * g + 2] + acc[1][th][s2][4 * g + 2] + acc[2][th][s2][4 * g + 2]; o1.z = acc[1][th][s2][4 * g + 2] - acc[2][th][s2][4 * g + 2] - acc[3][th][s2][4 * g + 2];
-                o0.w = acc[0][th][s2][4 * g + 3] + acc[1][th][s2][4 * g + 3] + acc[2][th][s2][4 * g + 3]; o1.w = acc[1][th][s2][4 * g + 3] - acc[2][th][s2][4 * g + 3] - acc[3][th][s2][4 * g + 3];
-                const int col = s2 * 32 + 8 * g + 4 * ch, ct = th * 32 + tl;
-                *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * W2_T + ct) * RLD + col) = o0;
-                *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * W2_T + ct) * RLD + col) = o1;
-            }
-    __syncthreads();
-    wino_final_epilogue<256, COB, BST>(a, wsm, m0, W2_T, Mt, THW, TW, c0, tid);
-}
-
 // patch slots a block can need at tile-row width TW: worst case over the position of its first tile
 static int wino2_slots(int TW) {
     const int Lf = std::min(TW, W2_T), S = 4 * (2 * Lf + 2);
@@ -976,24 +620,14 @@ static int wino2_slots(int TW) {
     }
     return (worst + 15) / 16 * 16;
 }
-static long g_wino2_min_tiles = getenv("MD2_WINO2_MIN_TILES") ? atol(getenv("MD2_WINO2_MIN_TILES")) : (1L << 40);          // (measured slower than the third kernel everywhere: only on request)
-
-static bool wino2_eligible(const ConvArgs& a, Wino2Geo& g) {
-    static const bool off = getenv("MD2_NO_WINO2") != nullptr;
-    if (off || g_wino_on == 2 || a.Cout % 64 != 0 || a.Cin % 8 != 0) return false;
-    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW; g.ntp = (g.Mt + W2_T - 1) / W2_T;
-    g.nslots = wino2_slots(g.TW);
-    if (g.nslots * 2 > 512 * W2_NLI) return false;                // more (slot, half) items than the loader's 4 per thread
-    return g_wino_on == 3 || (long)g.Mt * (a.Cout / 64) >= g_wino2_min_tiles;
-}
 // third kernel: Cout % 32 == 0, Cin % 8 == 0, up to 640 patch slots per stage (tile rows of at least 4 tiles)
 static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g) {
     static const bool off = getenv("MD2_NO_WINO3") != nullptr;
-    if (off || g_wino_on == 2 || g_wino_on == 3 || a.Cout % 32 != 0 || a.Cin % 8 != 0) return false;
+    if (off || g_wino_on == 2 || a.Cout % 32 != 0 || a.Cin % 8 != 0) return false;
     g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW; g.ntp = (g.Mt + W2_T - 1) / W2_T;
     g.nslots = wino2_slots(g.TW);
     if (g.nslots > 128 * 5) return false;
-    return g_wino_on == 4 || (long)g.ntp * (a.Cout / 32) >= g_wino_min_blocks;
+    return g_wino_on == 3 || (long)g.ntp * (a.Cout / 32) >= g_wino_min_blocks;
 }
 template <int NLI>
 static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
@@ -1012,53 +646,218 @@ static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) 
     else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0>), dim3(grid), dim3(256), lds, s, a, g);
 }
 static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) { launch_wino3_t<5>(a, g, s); }
-static bool wino4_eligible(const ConvArgs& a, Wino2Geo& g) {
-    static const bool off = getenv("MD2_NO_WINO4") != nullptr;
-    static const long minb = getenv("MD2_WINO4_MIN_BLOCKS") ? atol(getenv("MD2_WINO4_MIN_BLOCKS")) : (1L << 40);
-    if (off || (g_wino_on != 1 && g_wino_on != 5) || a.Cout % 64 != 0 || a.Cin % 8 != 0) return false;
-    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW; g.ntp = (g.Mt + W2_T - 1) / W2_T;
-    g.nslots = wino2_slots(g.TW);
-    if (g.nslots > 128 * 5) return false;
-    return g_wino_on == 5 || (long)g.ntp * (a.Cout / 64) >= minb;
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient in the Winograd domain (cuDNN's algorithm choice for Flux's conv filter pullback, src/depth_decoder.jl:13-14 / ResNet.jl):
+//   dU_(i,j)[co][ci] = sum over tiles  dM_(i,j)[tile][co] * V_(i,j)[tile][ci],   dM = A dY A^T (2x2 output-gradient tile -> 4x4),  V = B^T d B (as in the forward kernel),
+//   dw = G^T dU G  (4x4 -> the 3x3 taps).  16 multiplies per tile and channel pair instead of 36.
+// GEMM-K = tiles.  Block = 256 threads (wave = Winograd row i), 64 output channels x 32 input channels x all 16 positions, a contiguous range of K batches; a batch = up to 16
+// tiles of ONE tile row, so its patch is a single row segment (4 rows x (2 L + 2) pixels) and its geometry is scalar work.  Per k-step (two tiles, MFMA k = lane half):
+//   A operand: lane (channel pair 2r, 2r+1 ; tile) reads the tile's 4 dy pixels as ds_read_b64, forms dM_(i,0..3) for both channels -> two 32-row MFMA tiles (even / odd
+//              channels), B operand: lane (channel r ; tile) reads 2 patch rows x 4 columns as ds_read_b32 and forms V_(i,0..3); 8 MFMAs per k-step and wave.
+// The block's 16 x 64 x 32 sums leave through LDS (G^T . G: column half in registers, row half across the four waves) as one fp32 atomic per weight; the block column with
+// input-channel tile 0 also produces the bias gradient (sum of dy).  Two workgroups per CU (68 KB of LDS, 128 accumulator registers).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WG_TB = 16, WG_WP = 2 * WG_TB + 2, WG_XSLOTS = 160;          // tiles per batch, patch row stride (slots), slots allocated (>= 4 * WG_WP = 136: every loader item has a real slot)
+constexpr int WG_XF = WG_XSLOTS * 32, WG_DYF = WG_TB * 4 * 64, WG_STAGE = WG_XF + WG_DYF;      // floats per stage: x [slot][32 ci] | dy [tile][4 px][64 co]
+struct WinoWgGeo { int TH, TW, BPR, nb, bpb, nco, nci; };              // BPR batches per tile row, nb batches in all, bpb batches per block
+
+template <int XF>
+__global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, WinoWgGeo geo) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_co = bid % geo.nco, tile_ci = (bid / geo.nco) % geo.nci, ks = bid / (geo.nco * geo.nci);
+    const int co0 = tile_co * 64, ci0 = tile_ci * 32;
+    const int b_lo = ks * geo.bpb, b_hi = min(b_lo + geo.bpb, geo.nb);
+    const int TW = geo.TW, TH = geo.TH;
+
+    // ---- loader items (fixed per thread; the pixel they address changes with the batch)
+    //   x : item f = tid + 256 li (li < 5) = (slot f >> 3 = row pa * 34 + column pc, 16-B piece f & 7 of the 32 channels)
+    //   dy: item f = tid + 256 li (li < 4) = (pixel slot f >> 4 = tile * 4 + (oa * 2 + ob), 16-B piece f & 15 of the 64 channels)
+    int x_pa[5], x_pc[5];
+#pragma unroll
+    for (int li = 0; li < 5; ++li) { const int slot = (tid + 256 * li) >> 3; x_pa[li] = slot / WG_WP; x_pc[li] = slot - x_pa[li] * WG_WP; }
+    const int xq = tid & 7, dq = tid & 15;
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + ci0 + xq * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + ci0 + xq * 4); }
+    uint4 rx[5], rd[4]; unsigned okx = 0, okd = 0;
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    const char* db_ = reinterpret_cast<const char*>(a.dy);
+    auto gload = [&](int b) {              // batch b -> registers (+ validity bits); b is block-uniform
+        const int rr = b / geo.BPR, bq = b - rr * geo.BPR;
+        const int n = rr / TH, ty = rr - n * TH, tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
+        okx = 0; okd = 0;
+#pragma unroll
+        for (int li = 0; li < 5; ++li) {
+            int ih = 2 * ty - a.pad + x_pa[li], iw = 2 * tx0 - a.pad + x_pc[li];
+            bool ok = x_pa[li] < 4 && x_pc[li] < 2 * L + 2;
+            if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+            else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            const unsigned off = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(ci0 + xq * 4)) * 4u : (unsigned)(xq * 16);
+            rx[li] = *reinterpret_cast<const uint4*>(xb + off);
+            okx |= ok ? (1u << li) : 0u;
+        }
+#pragma unroll
+        for (int li = 0; li < 4; ++li) {
+            const int ps = (tid + 256 * li) >> 4, t = ps >> 2, oy = 2 * ty + ((ps >> 1) & 1), ox = 2 * (tx0 + t) + (ps & 1);
+            const bool ok = t < L && oy < a.Ho && ox < a.Wo;
+            const unsigned off = ok ? ((unsigned)((long)n * a.dy_bs) + (unsigned)((oy * a.Wo + ox) * a.dy_ps) + (unsigned)(co0 + dq * 4)) * 4u : (unsigned)(dq * 16);
+            rd[li] = *reinterpret_cast<const uint4*>(db_ + off);
+            okd |= ok ? (1u << li) : 0u;
+        }
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < 5; ++li) {
+            const unsigned mk = 0u - ((okx >> li) & 1u);
+            uint4 v = rx[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            if constexpr (XF != 0) {
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
+            }
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + ((tid + 256 * li) >> 3) * 32 + xq * 4) = v;
+        }
+#pragma unroll
+        for (int li = 0; li < 4; ++li) {
+            const unsigned mk = 0u - ((okd >> li) & 1u);
+            uint4 v = rd[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + WG_XF + ((tid + 256 * li) >> 4) * 64 + dq * 4) = v;
+        }
+    };
+
+    // ---- consumer constants: wave i.  A (dM) row combine: r_b = ca * dY[0][b] + cb * dY[1][b]; B (V) row combine: d[r1] + sg * d[r2]
+    const float ca = (wi == 3) ? 0.f : 1.f, cb = (wi == 0) ? 0.f : (wi == 1 ? 1.f : -1.f);
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int xo1 = (r1 * WG_WP + 2 * lh) * 32 + lr, xo2 = (r2 * WG_WP + 2 * lh) * 32 + lr;          // + k-step * 4 slots (two tiles) + column b
+    const int dyo = WG_XF + (lh * 4) * 64 + 2 * lr;                                                  // + k-step * 8 pixel rows + px * 64
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][m][e] = 0.f;
+    float2 bsum = make_float2(0.f, 0.f);
+
+    if (b_lo < b_hi) {
+        gload(b_lo); lstore(0);
+        __syncthreads();
+        for (int b = b_lo; b < b_hi; ++b) {
+            const int so = ((b - b_lo) & 1) * WG_STAGE;
+            const int bn = min(b + 1, b_hi - 1);
+            gload(bn);
+            __builtin_amdgcn_sched_barrier(0);
+            const int bq = b % geo.BPR, L = min(WG_TB, TW - bq * WG_TB), nk = (L + 1) >> 1;
+            for (int k = 0; k < nk; ++k) {
+                const float* xs = wsm + so + k * (4 * 32);
+                const float* ds = wsm + so + dyo + k * (8 * 64);
+                const float2 y00 = *reinterpret_cast<const float2*>(ds), y01 = *reinterpret_cast<const float2*>(ds + 64), y10 = *reinterpret_cast<const float2*>(ds + 128), y11 = *reinterpret_cast<const float2*>(ds + 192);
+                float xv1[4], xv2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { xv1[c] = xs[xo1 + c * 32]; xv2[c] = xs[xo2 + c * 32]; }
+                bsum.x += (y00.x + y01.x) + (y10.x + y11.x); bsum.y += (y00.y + y01.y) + (y10.y + y11.y);
+                // dM_(i, 0..3) of both channels
+                const float p0x = ca * y00.x + cb * y10.x, p1x = ca * y01.x + cb * y11.x, p0y = ca * y00.y + cb * y10.y, p1y = ca * y01.y + cb * y11.y;
+                const float mx[4] = {p0x, p0x + p1x, p0x - p1x, -p1x}, my[4] = {p0y, p0y + p1y, p0y - p1y, -p1y};
+                // V_(i, 0..3)
+                float rr[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rr[c] = fmaf(sg, xv2[c], xv1[c]);
+                const float V[4] = {rr[0] - rr[2], rr[1] + rr[2], rr[2] - rr[1], rr[1] - rr[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(mx[j], V[j], acc[j][0], 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(my[j], V[j], acc[j][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(WG_STAGE - so);
+            __syncthreads();
+        }
+    }
+
+    // ---- dw = G^T dU G.  Column half in registers: T_q = sum_j dU_(i,j) G[j][q], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; row half across the waves through LDS
+    //      (T[i][q][32 rows][33]), one pass per channel parity m; row r of pass m is output channel co0 + 2 r + m
+    float* T = wsm;
+    constexpr int TLD = 33;
+    const int ci = tid & 31, rw = tid >> 5;                  // combine: thread -> input channel ci, rows rw + 8 k
+    for (int m = 0; m < 2; ++m) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float a0 = acc[0][m][e], a1 = acc[1][m][e], a2 = acc[2][m][e], a3 = acc[3][m][e];
+            const int row = 8 * (e >> 2) + 4 * lh + (e & 3);
+            T[((wi * 3 + 0) * 32 + row) * TLD + lr] = a0 + 0.5f * (a1 + a2);
+            T[((wi * 3 + 1) * 32 + row) * TLD + lr] = 0.5f * (a1 - a2);
+            T[((wi * 3 + 2) * 32 + row) * TLD + lr] = 0.5f * (a1 + a2) + a3;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = rw + 8 * k;
+            float* dst = a.dw + ((long)(co0 + 2 * row + m) * 9) * a.Cin + ci0 + ci;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float t0 = T[((0 * 3 + q) * 32 + row) * TLD + ci], t1 = T[((1 * 3 + q) * 32 + row) * TLD + ci], t2 = T[((2 * 3 + q) * 32 + row) * TLD + ci], t3 = T[((3 * 3 + q) * 32 + row) * TLD + ci];
+                atomicAdd(dst + (0 * 3 + q) * a.Cin, t0 + 0.5f * (t1 + t2));
+                atomicAdd(dst + (1 * 3 + q) * a.Cin, 0.5f * (t1 - t2));
+                atomicAdd(dst + (2 * 3 + q) * a.Cin, 0.5f * (t1 + t2) + t3);
+            }
+        }
+    }
+    // bias gradient: wave 0 of the block column with input-channel tile 0 (every wave read the same dy)
+    if (a.db && tile_ci == 0 && wi == 0) {
+        bsum.x += __shfl_xor(bsum.x, 32); bsum.y += __shfl_xor(bsum.y, 32);
+        if (lh == 0) { atomicAdd(a.db + co0 + 2 * lr, bsum.x); atomicAdd(a.db + co0 + 2 * lr + 1, bsum.y); }
+    }
 }
-static void launch_wino4(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
-    constexpr size_t lds_pipe = (size_t)2 * 128 * 5 * 8 * sizeof(float), lds_epi = (size_t)8 * W2_T * (64 + 4) * sizeof(float);
+
+bool conv_wino_wgrad_eligible(const WgradArgs& a) {
+    static const bool off = getenv("MD2_NO_WINO_WGRAD") != nullptr;
+    static const long min_m = getenv("MD2_WINO_WGRAD_MIN_M") ? atol(getenv("MD2_WINO_WGRAD_MIN_M")) : 1024;          // (in-model, batch 32: ahead of the all-taps kernel from the 1/32-scale layers up)
+    if (off || !g_wino_on || g_deterministic || a.bf16) return false;
+    if (!(a.KH == 3 && a.KW == 3 && a.stride == 1) || a.Cout % 64 != 0 || a.Cin % 32 != 0) return false;
+    if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
+    if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
+    const long x_bytes = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), dy_bytes = 4 * ((long)a.N * a.dy_bs + (long)a.Ho * a.Wo * a.dy_ps);
+    if (a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || x_bytes >= (1L << 32) || dy_bytes >= (1L << 32)) return false;
+    return g_wino_on >= 2 || a.M >= min_m;
+}
+void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
+    WinoWgGeo g;
+    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.BPR = (g.TW + WG_TB - 1) / WG_TB; g.nb = a.N * g.TH * g.BPR;
+    g.nco = a.Cout / 64; g.nci = a.Cin / 32;
+    static const int want = getenv("MD2_WINO_WGRAD_BLOCKS") ? atoi(getenv("MD2_WINO_WGRAD_BLOCKS")) : 512;
+    int ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));
+    g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
+    constexpr size_t lds_pipe = (size_t)2 * WG_STAGE * sizeof(float), lds_epi = (size_t)12 * 32 * 33 * sizeof(float);
     constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<5, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<5, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<5, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int grid = g.ntp * (a.Cout / 64);
-    if (a.in_scale) hipLaunchKernelGGL((conv_wino4_kernel<5, 1, 0>), dim3(grid), dim3(256), lds, s, a, g);
-    else if (a.bst) hipLaunchKernelGGL((conv_wino4_kernel<5, 0, 1>), dim3(grid), dim3(256), lds, s, a, g);
-    else hipLaunchKernelGGL((conv_wino4_kernel<5, 0, 0>), dim3(grid), dim3(256), lds, s, a, g);
-}
-static void launch_wino2(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
-    const size_t lds_pipe = ((size_t)2 * (g.nslots * 8 + 256) + 2 * 8192) * sizeof(float), lds_epi = (size_t)8 * W2_T * (64 + 4) * sizeof(float);
-    const size_t lds = std::max(lds_pipe, lds_epi);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino64_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino64_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino64_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    const int grid = g.ntp * (a.Cout / 64);
-    if (a.in_scale) hipLaunchKernelGGL((conv_wino64_kernel<1, 0>), dim3(grid), dim3(512), lds, s, a, g);
-    else if (a.bst) hipLaunchKernelGGL((conv_wino64_kernel<0, 1>), dim3(grid), dim3(512), lds, s, a, g);
-    else hipLaunchKernelGGL((conv_wino64_kernel<0, 0>), dim3(grid), dim3(512), lds, s, a, g);
+    const int grid = g.nco * g.nci * ksn;
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino_wgrad_kernel<1>), dim3(grid), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino_wgrad_kernel<0>), dim3(grid), dim3(256), lds, s, a, g);
 }
 
-int g_wino_on = getenv("MD2_NO_WINO") ? 0 : (getenv("MD2_WINO_MODE") ? atoi(getenv("MD2_WINO_MODE")) : 1);          // MD2_WINO_MODE=2/3/4: pin one kernel (md2_set_winograd)
+int g_wino_on = getenv("MD2_NO_WINO") ? 0 : (getenv("MD2_WINO_MODE") ? atoi(getenv("MD2_WINO_MODE")) : 1);          // MD2_WINO_MODE=2/3: pin one kernel (md2_set_winograd)
 int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 160;
 
 // 3x3, stride 1, dense output lattice, no split-K, fp32; Cin % 16, Cout % 32.  Automatic choice (md2_set_winograd(1, n)): the 64-tile x 32-channel kernel when it
 // launches at least n workgroups (default 160: in-model per-launch timings at batch 32, tools/run_layer_compare.sh -- below that the direct implicit GEMM with its split-K
-// wins), the direct convolution otherwise; the other two kernels only when pinned (modes 2 / 3).
-static bool wino2_eligible(const ConvArgs& a, Wino2Geo& g);
+// wins), the direct convolution otherwise; the 32-tile kernel only when pinned (mode 2; mode 3 pins the 64-tile one).
 static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g);
 bool conv_wino_eligible(const ConvArgs& a) {
     if (!g_wino_on || !a.wino_u || a.bf16) return false;
@@ -1105,9 +904,7 @@ void launch_conv_wino(const ConvArgs& a_in, hipStream_t s) {
     if (a.stats && !stats_ok) a.stats = nullptr;
     if (a.bst && !fuse) { a.bst = nullptr; a.bstB = nullptr; }
     Wino2Geo g2;
-    if (wino4_eligible(a, g2)) launch_wino4(a, g2, s);
-    else if (wino3_eligible(a, g2)) launch_wino3(a, g2, s);
-    else if (wino2_eligible(a, g2)) launch_wino2(a, g2, s);
+    if (wino3_eligible(a, g2)) launch_wino3(a, g2, s);
     else if (a.Cout % 64 == 0) launch_wino_t<2>(a, s); else launch_wino_t<1>(a, s);
     View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
     if (a_in.stats && !a.stats) {

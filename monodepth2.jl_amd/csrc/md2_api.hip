@@ -330,7 +330,11 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode);
     hipStream_t st = wgrad_stream(h);
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
-    if (h->prof) h->prof_flops[CLS_WGRAD] += 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
+    if (h->prof) {
+        const double fl = 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;
+        h->prof_flops[CLS_WGRAD] += fl;
+        h->prof_exec[CLS_WGRAD] += conv_wino_wgrad_eligible(a) ? 2.0 * 16.0 * (double)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2) * a.Cout * a.Cin : fl;      // Winograd route: 16 instead of 36 multiplies per tile
+    }
 }
 // the batch statistics were accumulated into b.acc by the convolution that produced z (conv_fwd(..., b.acc))
 // (test mode, Flux.testmode!: the tracked running statistics instead; train mode also updates them, momentum 0.1)
@@ -689,7 +693,7 @@ static int model_backward(md2_handle* h) {
         h->pbegin(CLS_WGRAD, fl, "stem wgrad 7x7 s2 (direct, BatchNorm pullback in the loader)", st, true);
         launch_stem_wgrad(h->x_last, NL, h->C, H, W, h->Gfeat[0], h->G + h->stem.w, h->Kpad, st, &h->z0, b.stats + 6 * b.c);
         h->pend(st, true);
-        if (h->prof) h->prof_flops[CLS_WGRAD] += fl;
+        if (h->prof) { h->prof_flops[CLS_WGRAD] += fl; h->prof_exec[CLS_WGRAD] += fl; }
     }
     if (h->n_bucket_done >= 0) {            // last bucket (layer 1 + stem), then the caller's stream waits for the communication stream
         if (int r = comm_bucket(h, 0, h->blk[stage_first[1]].c1.w)) return r;
@@ -1030,7 +1034,7 @@ int32_t md2_profile_get(md2_handle* h, int32_t cls, double* total_ms, int64_t* l
 }
 
 int32_t md2_profile_get_executed(md2_handle* h, int32_t cls, double* flops_executed) {
-    if (flops_executed) *flops_executed = (cls == CLS_IGEMM) ? h->prof_exec[cls] : ((cls >= 0 && cls < 5) ? h->prof_flops[cls] : 0);
+    if (flops_executed) *flops_executed = (cls == CLS_IGEMM || cls == CLS_WGRAD) ? h->prof_exec[cls] : ((cls >= 0 && cls < 5) ? h->prof_flops[cls] : 0);
     return 0;
 }
 int32_t md2_profile_dump(md2_handle* h, const char* path) {
@@ -1218,7 +1222,7 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host, int64_t n) {
     HIPCHK(hipMemcpy(h->RS, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); return 0;
 }
 int32_t md2_set_deterministic(int32_t on) { g_deterministic = on != 0; return 0; }
-int32_t md2_set_winograd(int32_t on, int32_t min_blocks) { g_wino_on = on < 0 || on > 5 ? 1 : on; if (min_blocks >= 0) g_wino_min_blocks = min_blocks; return 0; }
+int32_t md2_set_winograd(int32_t on, int32_t min_blocks) { g_wino_on = on < 0 || on > 3 ? 1 : on; if (min_blocks >= 0) g_wino_min_blocks = min_blocks; return 0; }
 int32_t md2_set_lr(md2_handle* h, double lr) { if (!(lr > 0)) { h->err = "md2_set_lr: lr must be positive"; return 2; } h->cfg.lr = lr; return 0; }
 
 // ---- op-level hooks for the direct kernels the network uses besides the implicit GEMM (parity tests) ------------------------------------

@@ -127,6 +127,9 @@ struct WgradArgs {
 };
 void launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 bool conv_wgrad_supports_in_transform(int H, int W, int Cin, int Cout);
+// weight gradient in the Winograd domain (conv_winograd.hip); launch_conv_wgrad routes the 3x3 / stride-1 layers with Cout % 64 == 0, Cin % 32 == 0 to it
+bool conv_wino_wgrad_eligible(const WgradArgs& a);
+void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s);
 
 // weight transforms between the three layouts
 //   flux   : [Cout][Cin][KH][KW], true convolution (kernel flipped)           (boundary)

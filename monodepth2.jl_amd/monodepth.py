@@ -526,7 +526,7 @@ def set_deterministic(on=True):
 def set_winograd(on=True, min_blocks=-1):
     """Algorithm choice for the 3x3 / stride-1 convolutions: fused Winograd F(2x2,3x3) for launches of at least `min_blocks` workgroups (default policy: 160), or the direct
     implicit GEMM everywhere (on=False).  What cuDNN's heuristics decide for the reference's Flux `Conv` layers."""
-    _check(_lib.lib().md2_set_winograd(int(on), int(min_blocks)), None, "set_winograd")          # on: False / True, or 2 / 3 / 4 = pin one of the three kernels
+    _check(_lib.lib().md2_set_winograd(int(on), int(min_blocks)), None, "set_winograd")          # on: False / True, or 2 / 3 = pin one of the two kernels
 
 
 class _DevBuf:

@@ -4,6 +4,5 @@ for shape in "96 32 104 64 64" "96 16 52 128 128" "96 8 26 256 256" "96 4 13 512
   ./tools/conv_bench $shape 3 || exit 1
   WINO=1 WMODE=2 ./tools/conv_bench $shape 3 || exit 1
   WINO=1 WMODE=3 ./tools/conv_bench $shape 3 || exit 1
-  WINO=1 WMODE=4 ./tools/conv_bench $shape 3 || exit 1
-  WINO=1 WMODE=4 XF=1 ./tools/conv_bench $shape 3 || exit 1
+  WINO=1 WMODE=3 XF=1 ./tools/conv_bench $shape 3 || exit 1
 done
