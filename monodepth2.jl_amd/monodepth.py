@@ -234,6 +234,8 @@ def automasking_loss(ssim, inputs, target, source_ids):
 
 
 def _apply_mask(mask, warp_loss):
+    """`_apply_mask` (src/training.jl:17-19) for the op-level call surface only (the visualization map): an elementwise minimum of two device tensors, host glue through torch.
+    The training step never comes here -- the fused loss kernel applies the mask itself (md2_train_loss, ties -> mask)."""
     return torch.minimum(mask, warp_loss)
 
 
