@@ -39,6 +39,9 @@ typedef struct md2_config {
     int32_t precision;    /* 0: fp32 everywhere (parity mode, the reference's precision = f32, src/Monodepth.jl:72);
                              1: bf16 mixed precision -- the MFMA operands of the 32-wide conv / weight-gradient tiles are rounded to
                                 bf16, accumulation, activations, master weights, BatchNorm, loss and ADAM stay fp32          */
+    int32_t target_id;    /* TrainCache.target_id, 1-based frame of the triplet the depth decoder sees (src/model.jl:16, src/training.jl:25); 0 = the default 2 */
+    int32_t source_ids[2];/* TrainCache.source_ids, 1-based, two distinct frames other than target_id in the caller's order (src/model.jl:22-35: a source before the
+                             target is paired (source, target) and its pose inverted, src/training.jl:29); {0, 0} = the default {1, 3} (src/dtk.jl, src/kitty.jl)     */
 } md2_config;
 
 /* ---- handle ------------------------------------------------------------------------------- */

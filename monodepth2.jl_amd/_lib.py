@@ -13,7 +13,7 @@ class Md2Config(C.Structure):
     _fields_ = [("batch", C.c_int32), ("channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
                 ("automasking", C.c_int32), ("device", C.c_int32),
                 ("min_depth", C.c_double), ("max_depth", C.c_double), ("disparity_smoothness", C.c_double), ("lr", C.c_double),
-                ("encoder_depth", C.c_int32), ("precision", C.c_int32)]
+                ("encoder_depth", C.c_int32), ("precision", C.c_int32), ("target_id", C.c_int32), ("source_ids", C.c_int32 * 2)]
 
 
 def build(force=False):

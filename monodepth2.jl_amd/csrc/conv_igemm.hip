@@ -494,7 +494,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             if (a.act != ACT_NONE) { v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act); }
             if (a.dact_src) { v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact); }
             float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co;
-            if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1) || (a.acc_lat && oy % a.acc_lat == 0 && ox % a.acc_lat == 0)) {
+            if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame) || (a.acc_lat && oy % a.acc_lat == 0 && ox % a.acc_lat == 0)) {
                 const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             *reinterpret_cast<float4*>(yp) = v;
@@ -582,7 +582,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
                 }
                 if (dp) { v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
-                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1) || (a.acc_lat && (a.oy0 + li * a.ostep) % a.acc_lat == 0 && (a.ox0 + lj * a.ostep) % a.acc_lat == 0)) {
+                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame) || (a.acc_lat && (a.oy0 + li * a.ostep) % a.acc_lat == 0 && (a.ox0 + lj * a.ostep) % a.acc_lat == 0)) {
                     const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
                 }
                 *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_cl
 // block = 256 threads = RG row groups x Q channel quads (the colstats layout); ws rows are dense [ksplit][M][C], y is addressed through its strides.
 struct SplitkBst { double* acc; const float* z; long z_bs; int z_ps; const float* stat; };       // BatchNorm-pullback sums of the final gradient: acc = sum g | sum g*xhat, xhat from (z, mean | invstd)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int M, int C, float* __restrict__ y, long y_bs, int y_ps, int HW,
-                                                            const float* __restrict__ bias, int act, int accumulate, int acc_lat, int Wo, double* __restrict__ stats, int rows_per_block, SplitkBst bA, SplitkBst bB) {
+                                                            const float* __restrict__ bias, int act, int accumulate, int acc_lat, int Wo, double* __restrict__ stats, int rows_per_block, SplitkBst bA, SplitkBst bB, int acc_frame) {
     const int Qall = C / 4, qoff = blockIdx.y * 256, Q = min(Qall - qoff, 256), RG = 256 / Q;
     const int q = qoff + threadIdx.x % Q, rg = threadIdx.x / Q;
     __shared__ float red[2 * 4 * 256];
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             if (act != ACT_NONE) { v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act); }
             const int n = p / HW, r = p - n * HW;
             float* yp = y + (long)n * y_bs + (long)r * y_ps + q * 4;
-            if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1) || (acc_lat && (r / Wo) % acc_lat == 0 && (r % Wo) % acc_lat == 0)) {
+            if (accumulate == 1 || (accumulate == 2 && (n % 3) == acc_frame) || (acc_lat && (r / Wo) % acc_lat == 0 && (r % Wo) % acc_lat == 0)) {
                 const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
             *reinterpret_cast<float4*>(yp) = v;
@@ -736,7 +736,7 @@ static void launch_splitk_reduce(const ConvArgs& a, const float* bias, int act, 
     const dim3 grid((a.M + rpb - 1) / rpb, (Q + 255) / 256);
     SplitkBst bA{}, bB{};
     if (with_bst && a.bst) { bA.acc = a.bst; bA.z = a.bz; bA.z_bs = a.bz_bs; bA.z_ps = a.bz_ps; bA.stat = a.bstat; if (a.bstB) { bB.acc = a.bstB; bB.z = a.bzB; bB.z_bs = a.bzB_bs; bB.z_ps = a.bzB_ps; bB.stat = a.bstatB; } }
-    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, a.acc_lat, a.Wo, stats, rpb, bA, bB);
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, a.acc_lat, a.Wo, stats, rpb, bA, bB, a.acc_frame);
 }
 
 // BatchNorm-pullback sums that could not be fused into an epilogue (16-wide tiles, split-K, deterministic mode): one column pass over (g, z)
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
                         for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
                     }
                     if (dp) { const float4 d = *reinterpret_cast<const float4*>(dp + co); v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
-                    if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                    if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame)) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
                     *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -1073,7 +1073,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
             else if (!a.accumulate) launch_fill_view(yv, 0.f, s);
             else if (a.accumulate == 2) {                    // only the middle frame of every triplet holds earlier contributions
                 if (a.N % 3) { fprintf(stderr, "md2: conv_igemm: accumulate mode 2 needs a 3-frame batch\n"); abort(); }
-                for (int l = 0; l < 3; l += 2) { View f = yv; f.p = yv.p + (long)l * yv.bs; f.N = yv.N / 3; f.bs = yv.bs * 3; launch_fill_view(f, 0.f, s); }
+                for (int l = 0; l < 3; ++l) if (l != a.acc_frame) { View f = yv; f.p = yv.p + (long)l * yv.bs; f.N = yv.N / 3; f.bs = yv.bs * 3; launch_fill_view(f, 0.f, s); }
             }
             bias2 = a.bias; act2 = a.act; a.bias = nullptr; a.act = ACT_NONE;
         }

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int TH, i
                     v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact);
                 }
                 float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co;
-                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
                 *reinterpret_cast<float4*>(yp) = v;
                 if (want_st) { s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
                 if constexpr (BST != 0) if (want_b) {
@@ -399,7 +399,7 @@ __device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __
                     v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact);
                 }
                 float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co;
-                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == 1)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
                 *reinterpret_cast<float4*>(yp) = v;
                 if (want_st) { s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
                 if constexpr (BST != 0) if (want_b) {

@@ -314,7 +314,7 @@ void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamm
 // bz / bstat / bacc (optional): dx is the gradient of a BatchNorm output whose input is bz -- the kernel also accumulates that BatchNorm's pullback sums
 // (sum g, sum g*xhat per channel; needs 256 % (C/4) == 0 so that a thread keeps one channel quad) and the separate reduction pass over (g, z) goes away
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View yrelu, int has_yrelu,
-                                                          View bz, const float* __restrict__ bstat, double* __restrict__ bacc) {
+                                                          View bz, const float* __restrict__ bstat, double* __restrict__ bacc, int acc_frame) {
     const int Q = dx.C / 4; const long total = dx.pixels() * Q; const int HW = dx.H * dx.W, HWo = dy.H * dy.W;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1;
     if (bacc) { const int q0 = threadIdx.x % Q; mu = ld4(bstat + q0 * 4); is = ld4(bstat + dx.C + q0 * 4); }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t
             }
         }
         float* dp = vptrw(dx, n, r) + q * 4;
-        if (accumulate == 1 || (accumulate == 2 && (n % 3) == 1)) {      // earlier contributions are already masked
+        if (accumulate == 1 || (accumulate == 2 && (n % 3) == acc_frame)) {      // earlier contributions are already masked
             const float4 o = ld4(dp); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
         st4(dp, make_float4(g[0], g[1], g[2], g[3]));
         if (bacc) {
@@ -358,12 +358,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t
         }
     }
 }
-void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu, hipStream_t s, const View* bz, const float* bstat, double* bacc) {
+void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu, hipStream_t s, const View* bz, const float* bstat, double* bacc, int acc_frame) {
     const int Q = dx.C / 4;
     if (bacc && (256 % Q != 0 || !bz)) { fprintf(stderr, "md2: maxpool_bwd: the fused BatchNorm sums need 256 %% (C/4) == 0\n"); abort(); }
     // (with the fused sums every block ends in 2 C double atomics: measured 371 / 341 / 291 / 277 / 271 us at caps of 1024 / 2048 / 4096 / 8192 / 16384 blocks, B=32)
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(dx.pixels() * Q, 256, 8192)), dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0,
-                       bz ? *bz : dx, bstat, bacc);
+                       bz ? *bz : dx, bstat, bacc, acc_frame);
 }
 
 // ---- NNlib.upsample_bilinear(x, (2,2)) (src/depth_decoder.jl:18-19), align-corners mapping --------------------------------
@@ -496,28 +496,28 @@ void launch_colsum(const View& v, float* out, hipStream_t s) {
 
 // ---- pose squeezer bookkeeping (src/model.jl:30-35, src/pose_decoder.jl:23-25): the 1x1 squeezer runs ONCE over all 3N frames (sq3 [3N][hw][256]); the pose decoder's input
 //      for source s is cat(frame fr[s][0], frame fr[s][1]) with (fr) = ((0,1),(1,2)): sqcat [2][N][hw][512].  Forward = gather, pullback = scatter-add (frame 1 is used twice).
-__global__ __launch_bounds__(256) void pose_pairs_fwd_kernel(const float* __restrict__ sq3, float* __restrict__ sqcat, int N, int hw) {
+struct PoseFrames { int f[4]; };              // (first, second) frame of the pair of source 0, of source 1
+__global__ __launch_bounds__(256) void pose_pairs_fwd_kernel(const float* __restrict__ sq3, float* __restrict__ sqcat, int N, int hw, PoseFrames pf) {
     const long total = (long)2 * N * hw * 128;                        // float4 slots of sqcat
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = i % 128; const long r = i / 128; const int px = r % hw; const long sn = r / hw; const int n = sn % N, s = sn / N;
-        const int j = c4 >> 6, fr = s + j;                             // frames (0,1) for source 0, (1,2) for source 1
+        const int j = c4 >> 6, fr = pf.f[2 * s + j];                  // default frames (0,1) for source 0, (1,2) for source 1
         st4(sqcat + i * 4, ld4(sq3 + (((long)(n * 3 + fr) * hw + px) * 64 + (c4 & 63)) * 4));
     }
 }
-__global__ __launch_bounds__(256) void pose_pairs_bwd_kernel(const float* __restrict__ dsqcat, float* __restrict__ dsq3, int N, int hw) {
+__global__ __launch_bounds__(256) void pose_pairs_bwd_kernel(const float* __restrict__ dsqcat, float* __restrict__ dsq3, int N, int hw, PoseFrames pf) {
     const long total = (long)3 * N * hw * 64;                          // float4 slots of dsq3
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = i % 64; const long r = i / 64; const int px = r % hw; const long nf = r / hw; const int fr = nf % 3, n = nf / 3;
-        auto at = [&](int s, int j) { return ld4(dsqcat + ((((long)(s * N + n) * hw + px) * 128) + j * 64 + c4) * 4); };
-        float4 g;
-        if (fr == 0) g = at(0, 0);
-        else if (fr == 2) g = at(1, 1);
-        else { const float4 a = at(0, 1), b = at(1, 0); g = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);                    // a frame collects every use of it (the target frame is used by both pairs)
+#pragma unroll
+        for (int sj = 0; sj < 4; ++sj)
+            if (pf.f[sj] == fr) { const float4 t = ld4(dsqcat + ((((long)((sj >> 1) * N + n) * hw + px) * 128) + (sj & 1) * 64 + c4) * 4); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
         st4(dsq3 + i * 4, g);
     }
 }
-void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, hipStream_t s) { hipLaunchKernelGGL(pose_pairs_fwd_kernel, dim3(grid_for((long)2 * N * hw * 128, 256, 2048)), dim3(256), 0, s, sq3, sqcat, N, hw); }
-void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, hipStream_t s) { hipLaunchKernelGGL(pose_pairs_bwd_kernel, dim3(grid_for((long)3 * N * hw * 64, 256, 2048)), dim3(256), 0, s, dsqcat, dsq3, N, hw); }
+void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, const int fr[4], hipStream_t s) { PoseFrames pf{{fr[0], fr[1], fr[2], fr[3]}}; hipLaunchKernelGGL(pose_pairs_fwd_kernel, dim3(grid_for((long)2 * N * hw * 128, 256, 2048)), dim3(256), 0, s, sq3, sqcat, N, hw, pf); }
+void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, const int fr[4], hipStream_t s) { PoseFrames pf{{fr[0], fr[1], fr[2], fr[3]}}; hipLaunchKernelGGL(pose_pairs_bwd_kernel, dim3(grid_for((long)3 * N * hw * 64, 256, 2048)), dim3(256), 0, s, dsqcat, dsq3, N, hw, pf); }
 
 // ---- pose head tail: mean over (W,H) * 0.01 (src/pose_decoder.jl:29-31); y view [B][h*w][>=6 channels] -------------------------
 __global__ void pose_mean_fwd_kernel(View y, float* __restrict__ rvec, float* __restrict__ tvec) {

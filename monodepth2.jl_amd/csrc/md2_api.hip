@@ -50,6 +50,8 @@ struct md2_handle {
     std::string err;
     hipStream_t stream = nullptr;
     int N = 0, NL = 0, C = 1, H = 0, W = 0;
+    int tgt = 1, src[2] = {0, 2};            // 0-based target / source frames of the triplet (md2_config.target_id / source_ids; src/training.jl:25-32)
+    int pose_fr[4] = {0, 1, 1, 2};           // temporally ordered (first, second) frames of the two pose pairs (src/model.jl:30-35)
     float K[9], invK[9];
     long n_int = 0, n_flux = 0;
     float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *WD = nullptr;
@@ -278,7 +280,7 @@ static ConvArgs conv_args(const View& x, const float* w, const View& y, int KH, 
     a.bias = nullptr; a.act = ACT_NONE; a.accumulate = 0; a.dact_src = nullptr; a.da_bs = 0; a.da_ps = 0; a.dact = ACT_NONE;
     a.M = y.N * y.H * y.W;
     a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = y.H; a.Wl = y.W; a.kh0 = 0; a.khs = 1; a.nkh = KH; a.kw0 = 0; a.kws = 1; a.nkw = KH;
-    a.accumulate_c00 = -1;
+    a.accumulate_c00 = -1; a.acc_frame = 1;
     return a;
 }
 static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
@@ -299,7 +301,7 @@ static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y
 // input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
 static ConvArgs dgrad_args(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact, const View* res = nullptr) {
     ConvArgs a = conv_args(dy, h->WD + c.w, dx, c.k, 1, c.k - 1 - pad_fwd, c.stride, PAD_ZERO);
-    a.accumulate = accumulate;
+    a.accumulate = accumulate; a.acc_frame = h->tgt;
     a.wino_u = c.ud >= 0 ? h->UD + c.ud : nullptr;
     if (dact_src) { a.dact_src = dact_src->p; a.da_bs = dact_src->bs; a.da_ps = dact_src->ps; a.dact = dact; }
     if (res) { a.res = res->p; a.res_bs = res->bs; a.res_ps = res->ps; }
@@ -366,7 +368,7 @@ static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp
     a.Rt = Rt; a.auto_loss = h->cfg.automasking ? auto_loss : nullptr;
     std::memcpy(a.K, h->K, sizeof(a.K)); std::memcpy(a.invK, h->invK, sizeof(a.invK));
     a.min_disp = (float)(1.0 / h->cfg.max_depth); a.max_disp = (float)(1.0 / h->cfg.min_depth);
-    a.tgt = 1; a.src0 = 0; a.src1 = 2; a.normalize = 1;
+    a.tgt = h->tgt; a.src0 = h->src[0]; a.src1 = h->src[1]; a.normalize = 1;
     return a;
 }
 
@@ -387,7 +389,7 @@ static void pose_forward(md2_handle* h, int N) {
     // then the two temporally ordered pairs are gathered: (f1, f2) for source 1, (f2, f3) for source 3 (src/model.jl:30-35)
     View sq3 = h->sq3; sq3.N = 3 * N;
     conv_fwd(h, h->squeeze, h->feat[4], sq3, PAD_ZERO, ACT_RELU);
-    launch_pose_pairs_fwd(h->sq3.p, h->sqcat.p, N, h->sq3.H * h->sq3.W, h->chain());
+    launch_pose_pairs_fwd(h->sq3.p, h->sqcat.p, N, h->sq3.H * h->sq3.W, h->pose_fr, h->chain());
     conv_fwd(h, h->pose[0], h->sqcat, h->py1, PAD_ZERO, ACT_RELU);
     conv_fwd(h, h->pose[1], h->py1, h->py2, PAD_ZERO, ACT_RELU);
     conv_fwd(h, h->pose[2], h->py2, h->py3, PAD_ZERO, ACT_NONE);
@@ -397,8 +399,9 @@ static void pose_forward(md2_handle* h, int N) {
 // L frames per sample (3 for training, 1 for eval_disparity); tgt = index of the frame the depth decoder sees
 // Winograd operands of the forward convolutions from the current parameters (one launch; ~16/9 of the 3x3 weights are written)
 static void refresh_wino_fwd(md2_handle* h, hipStream_t s) { launch_wino_weights_batched(h->P, h->UF, h->udesc_f, h->n_udf, h->ublk_f, s); }
-static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = 1, bool with_pose = true, bool with_depth = true, bool wino_on_side = false) {
+static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1, bool with_pose = true, bool with_depth = true, bool wino_on_side = false) {
     hipStream_t s = h->stream;
+    if (tgt < 0) tgt = h->tgt;                  // triplets: the configured target frame
     const int NL = h->z0.N, N = NL / L, H = h->H, W = h->W;
     if (!wino_on_side) refresh_wino_fwd(h, s);          // (md2_train_loss runs it on the side stream, overlapping the stem)
     HIPCHK(hipMemsetAsync(h->acc_all, 0, h->acc_fwd_count * sizeof(double), s));
@@ -475,7 +478,7 @@ static void simple_mode(md2_handle* h, LossArgs& a) {      // slow_depth objecti
 static int loss_forward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
     hipStream_t s = h->stream;
     HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)16 * h->N * sizeof(double), s));
-    launch_pose_compose(rvec, tvec, h->Rt, h->N, 1, 0, s);       // inverse_transform = source_ids .< target_id = [true, false] (src/training.jl:29)
+    launch_pose_compose(rvec, tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);       // inverse_transform = source_ids .< target_id = [true, false] (src/training.jl:29)
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
     if (simple) simple_mode(h, a);
     h->pbegin(CLS_LOSS_FWD); launch_loss_fwd(a, h->loss_part, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
@@ -489,7 +492,7 @@ static int loss_forward(md2_handle* h, const float* x, const float* const disp[4
 static int loss_train(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
     hipStream_t s = h->stream;
     HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)40 * h->N * sizeof(double), s));           // loss_part [16N] and dRt_acc [24N] are adjacent
-    launch_pose_compose(rvec, tvec, h->Rt, h->N, 1, 0, s);
+    launch_pose_compose(rvec, tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
     if (simple) simple_mode(h, a);
     const size_t P = (size_t)h->H * h->W;
@@ -510,7 +513,7 @@ static int loss_train(md2_handle* h, const float* x, const float* const disp[4],
     launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
     if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!simple) for (int i = 0; i < 4; ++i) if (!dlo[i] && dd[i] != h->ddisp_lo[i]) launch_upsample_planar_bwd(dd[i], h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
-    launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, 1, 0, s);
+    launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
     KCHK();
     return 0;
 }
@@ -530,7 +533,7 @@ static void pose_backward(md2_handle* h, int N, int part) {
     }
     // squeezer: scatter-add the pair gradients back onto the 3N frames (frame 2 collects both of its uses), then ONE weight gradient and ONE input gradient.
     // Gfeat[4]: frames 1 and 3 get exactly this contribution (overwrite), frame 2 adds to the depth decoder's (accumulate mode 2)
-    launch_pose_pairs_bwd(h->dsq.p, h->dsq3.p, N, h->dsq3.H * h->dsq3.W, h->chain());
+    launch_pose_pairs_bwd(h->dsq.p, h->dsq3.p, N, h->dsq3.H * h->dsq3.W, h->pose_fr, h->chain());
     conv_wgrad(h, h->squeeze, h->feat[4], h->dsq3, PAD_ZERO);
     conv_dgrad(h, h->squeeze, h->dsq3, h->Gfeat[4], 0, 2, &h->feat[4], ACT_RELU);
 }
@@ -583,15 +586,15 @@ static int model_backward(md2_handle* h) {
         const int dc = h->y1[b].C;
         launch_fold_reflect(chan_slice(dcp, 0, dc), h->dupv[b], 0, nullptr, ACT_NONE, s);
         if (b < 4) {
-            View fv = frame_view(h->feat[3 - b], 3, 1), gv = frame_view(h->Gfeat[3 - b], 3, 1);
+            View fv = frame_view(h->feat[3 - b], 3, h->tgt), gv = frame_view(h->Gfeat[3 - b], 3, h->tgt);
             launch_fold_reflect(chan_slice(dcp, dc, fv.C), gv, 0, &fv, ACT_RELU, s);      // first writer of this stage's target frames
         }
         launch_upsample2x_bwd(h->dupv[b], h->dZ1[b], &h->y1[b], ACT_ELU, s);
-        const View& in = (b == 0) ? frame_view(h->feat[4], 3, 1) : h->y2[b - 1];
+        const View& in = (b == 0) ? frame_view(h->feat[4], 3, h->tgt) : h->y2[b - 1];
         conv_wgrad(h, h->dc1[b], in, h->dZ1[b], PAD_REFLECT);
         View dip = make_view(h->dxpad, N, in.H + 2, in.W + 2, in.C);
         conv_dgrad(h, h->dc1[b], h->dZ1[b], dip, 0, 0, nullptr, ACT_NONE);
-        if (b == 0) { View fv = frame_view(h->feat[4], 3, 1), gv = frame_view(h->Gfeat[4], 3, 1); launch_fold_reflect(dip, gv, 0, &fv, ACT_RELU, s); }   // first writer of Gfeat[4] frame 1
+        if (b == 0) { View fv = frame_view(h->feat[4], 3, h->tgt), gv = frame_view(h->Gfeat[4], 3, h->tgt); launch_fold_reflect(dip, gv, 0, &fv, ACT_RELU, s); }   // first writer of Gfeat[4] frame 1
         else launch_fold_reflect(dip, h->gA[b - 1], (b - 1) >= 1 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);
     }
     // ---- pose branch, second half: accumulate into Gfeat[4] after the depth decoder's write; then join (the encoder pullback reads Gfeat[4])
@@ -685,8 +688,8 @@ static int model_backward(md2_handle* h) {
         // no reduction pass, no dz tensor (Gfeat[0]: decoder skip gradient in the target frames only; ReLU mask from the pooled output)
         const BNL& b = h->stem_bn;
         const bool fuse = !g_deterministic && !getenv("MD2_NO_BN_FUSE");
-        if (fuse) launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, &h->z0, b.stats, b.acc_b);
-        else { launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s); launch_bn_bwd_reduce(h->Gfeat[0], nullptr, ACT_NONE, h->z0, b.stats, b.acc_b, s); }
+        if (fuse) launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, &h->z0, b.stats, b.acc_b, h->tgt);
+        else { launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, nullptr, nullptr, nullptr, h->tgt); launch_bn_bwd_reduce(h->Gfeat[0], nullptr, ACT_NONE, h->z0, b.stats, b.acc_b, s); }
         launch_bn_bwd_finalize(b.acc_b, BN_STAT_SLOTS, b.c, (double)h->z0.pixels(), b.stats + 4 * b.c, h->G + b.g, h->G + b.b, b.stats, h->P + b.g, s);
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
         hipStream_t st = wgrad_stream(h);
@@ -788,6 +791,12 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     md2_handle* h = new md2_handle();
     h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width; h->net_ok = net_ok;
     h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision == 1;
+    {   // TrainCache.target_id / source_ids (1-based at the boundary)
+        const int t = cfg->target_id ? cfg->target_id : 2, s0 = cfg->source_ids[0] ? cfg->source_ids[0] : (cfg->source_ids[1] ? 0 : 1), s1 = cfg->source_ids[1] ? cfg->source_ids[1] : (cfg->source_ids[0] ? 0 : 3);
+        if (t < 1 || t > 3 || s0 < 1 || s0 > 3 || s1 < 1 || s1 > 3 || s0 == s1 || s0 == t || s1 == t) { g_create_err = "md2_create: target_id / source_ids must be three distinct frames of the triplet (1..3), two of them sources"; delete h; return 2; }
+        h->tgt = t - 1; h->src[0] = s0 - 1; h->src[1] = s1 - 1;
+        for (int k = 0; k < 2; ++k) { const bool before = h->src[k] < h->tgt; h->pose_fr[2 * k] = before ? h->src[k] : h->tgt; h->pose_fr[2 * k + 1] = before ? h->tgt : h->src[k]; }
+    }
     for (int i = 0; i < 64; ++i) h->ev_pool[i] = nullptr;
     for (int i = 0; i < 8; ++i) { h->ev_cm[i] = nullptr; h->ev_cs[i] = nullptr; }
     build_layers(h);
@@ -912,7 +921,7 @@ int32_t md2_model_forward(md2_handle* h, const float* x, float* d0, float* d1, f
 int32_t md2_eval_poses(md2_handle* h, const float* x, float* rvec, float* tvec) {
     if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
     h->have_fwd = false;
-    if (int r = model_forward(h, x, 3, 1, true, false)) return r;          // encoder + pose decoder; the depth decoder is skipped
+    if (int r = model_forward(h, x, 3, -1, true, false)) return r;          // encoder + pose decoder; the depth decoder is skipped
     return copy_outputs(h, nullptr, nullptr, nullptr, nullptr, rvec, tvec);
 }
 int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, float* loss) {
@@ -926,7 +935,7 @@ int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, fl
         if (int r = backward_prepare(h, h->s2)) return r;
         (void)hipEventRecord(h->ev_p1, h->s2); h->prep_done = true;
     }
-    if (int r = model_forward(h, x, 3, 1, true, true, h->prep_done)) return r;
+    if (int r = model_forward(h, x, 3, -1, true, true, h->prep_done)) return r;
     const float* disp[4] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p};
     if (int r = loss_train(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;          // the loss pullback comes out of the same pass: md2_backward starts at the network
     h->x_last = x; h->auto_last = auto_loss; h->have_fwd = true;
@@ -951,7 +960,7 @@ int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, fl
 int32_t md2_automasking_loss(md2_handle* h, const float* x, float* out) {
     // photometric of the UNWARPED sources vs the target, min over sources (src/training.jl:9-11); the frames are read in place
     if (h->H < 2 || h->W < 2) { h->err = "md2_automasking_loss: image too small"; return 2; }
-    launch_automask(x, out, h->N, h->C, h->H, h->W, 0, 2, 1, h->stream);
+    launch_automask(x, out, h->N, h->C, h->H, h->W, h->src[0], h->src[1], h->tgt, h->stream);
     KCHK(); return 0;
 }
 int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const float* d1, const float* d2, const float* d3, const float* rvec, const float* tvec,

@@ -60,7 +60,8 @@ struct ConvArgs {
     const float* w;
     float* y; long y_bs; int y_ps; int Ho, Wo, Cout;
     int N, KH, KW, stride, pad, dil, padmode;
-    const float* bias; int act; int accumulate;               // accumulate: 0 overwrite, 1 add to y, 2 add only where (batch index % 3) == 1 (target frames)
+    const float* bias; int act; int accumulate;               // accumulate: 0 overwrite, 1 add to y, 2 add only where (batch index % 3) == acc_frame (the target frames)
+    int acc_frame;                                            // frame of the triplet that already holds a contribution in accumulate mode 2 (0-based target frame)
     const float* dact_src; long da_bs; int da_ps; int dact;   // optional: multiply by act_deriv(dact_src[n,oh,ow,co])
     const float* res; long res_bs; int res_ps;                // optional residual gradient added BEFORE the act_deriv factor: y = (conv + res) * act'(dact_src) [+ y]
     int M;                                                    // N*Hl*Wl
@@ -172,7 +173,7 @@ void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& 
 void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s);
 // dx (+)= scatter of dy by arg, gather form; optional multiply by relu'(xact).  accumulate as in ConvArgs (0 / 1 / 2)
 void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu /* pooled output of a post-ReLU input, or null */, hipStream_t s,
-                        const View* bz = nullptr, const float* bstat = nullptr, double* bacc = nullptr);       // optional: BatchNorm-pullback sums of dx w.r.t. BatchNorm input bz
+                        const View* bz = nullptr, const float* bstat = nullptr, double* bacc = nullptr, int acc_frame = 1);       // optional: BatchNorm-pullback sums of dx w.r.t. BatchNorm input bz
 // sums -> coef = m1 | m2 [| A | B | C0 with stats / gamma: dz = A g + B z + C0], d gamma / d beta accumulated
 void launch_bn_bwd_finalize(const double* acc, int slots, int C, double count, float* coef, float* dgamma, float* dbeta, const float* stats, const float* gamma, hipStream_t s);
 void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s);
@@ -185,8 +186,9 @@ void launch_axpy_view(const View& src, const View& dst, float a, int accumulate,
 // out[c] (+)= sum over pixels of v[.,c]   (float atomics)
 void launch_colsum(const View& v, float* out, hipStream_t s);
 // pose squeezer: sq3 [3N][hw][256] (all frames, squeezed once) <-> sqcat [2][N][hw][512] (the temporally ordered pairs of both sources); the pullback adds frame 1's two uses
-void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, hipStream_t s);
-void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, hipStream_t s);
+// fr[4] = the two (first, second) frame pairs, temporally ordered: {a0, b0, a1, b1} (0-based; src/model.jl:30-35)
+void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, const int fr[4], hipStream_t s);
+void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, const int fr[4], hipStream_t s);
 // pose head: y [B][HW][16] -> rvec/tvec [B][3] = 0.01 * mean ; and its adjoint
 void launch_pose_mean_fwd(const View& y, float* rvec, float* tvec, hipStream_t s);
 void launch_pose_mean_bwd(const float* drvec, const float* dtvec, const View& dy, hipStream_t s);

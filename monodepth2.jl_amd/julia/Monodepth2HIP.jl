@@ -19,6 +19,7 @@ struct MD2Config
     automasking::Int32; device::Int32
     min_depth::Float64; max_depth::Float64; disparity_smoothness::Float64; lr::Float64
     encoder_depth::Int32; precision::Int32       # ResidualNetwork(18 | 50); 0 = f32, 1 = bf16 MFMA operands
+    target_id::Int32; source_id1::Int32; source_id2::Int32      # TrainCache.target_id / source_ids (1-based; 0 = the defaults 2 / (1, 3))
 end
 
 include("md2_ccall.jl")        # raw wrappers: md2_create(...), md2_train_step(...), ... one per export
@@ -51,8 +52,9 @@ ones_like(::ROCArray{T}, shape) where T = AMDGPU.ones(T, shape)
 
 # ---- handle: Params (src/Monodepth.jl:32-42) + the shapes TrainCache is built for ------------------------------------------------------------
 function Handle(; batch, channels, width, height, automasking=false, device=0,
-                min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, lr=1e-4, encoder_depth=18, precision=0)
-    cfg = Ref(MD2Config(batch, channels, height, width, automasking, device, min_depth, max_depth, disparity_smoothness, lr, encoder_depth, precision))
+                min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, lr=1e-4, encoder_depth=18, precision=0, target_id=2, source_ids=[1, 3])
+    cfg = Ref(MD2Config(batch, channels, height, width, automasking, device, min_depth, max_depth, disparity_smoothness, lr, encoder_depth, precision,
+                        target_id, source_ids[1], source_ids[2]))          # TrainCache.target_id / source_ids (src/Monodepth.jl:44-55), 1-based like the reference
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve out begin
         rc = md2_create(cfg, Base.unsafe_convert(Ptr{Ptr{Cvoid}}, out))

@@ -290,7 +290,7 @@ class Model:
         self.lr, self.precision = lr, precision
         self._shape = None
         self._params_host = None
-        self._cfg_extra = dict(min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, automasking=False)
+        self._cfg_extra = dict(min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, automasking=False, target_id=2, source_ids=(1, 3))
         self._K = None
         self._testmode = False
         self._comm_spec = None
@@ -308,14 +308,21 @@ class Model:
             _check(_lib.lib().md2_set_lr(self._h, self._lr), self._h, "set_lr")
 
     # -- handle management --------------------------------------------------------------------
-    def _ensure(self, x, parameters: Optional[Params] = None, cache: Optional[TrainCache] = None):
+    def _ensure(self, x, parameters: Optional[Params] = None, cache: Optional[TrainCache] = None, frames=None):
         N, L, Cc, H, W = x.shape
         if L != 3 or Cc != self.encoder.in_channels:
             raise ValueError("x must be (N,3,C,H,W) with C == encoder.in_channels")
         extra = dict(self._cfg_extra)
         if parameters is not None:
-            extra = dict(min_depth=parameters.min_depth, max_depth=parameters.max_depth,
+            extra.update(min_depth=parameters.min_depth, max_depth=parameters.max_depth,
                          disparity_smoothness=parameters.disparity_smoothness, automasking=bool(parameters.automasking))
+        if cache is not None:                      # TrainCache.target_id / source_ids (src/Monodepth.jl:44-55)
+            frames = (cache.source_ids, cache.target_id)
+        if frames is not None:
+            sids, tid = [int(v) for v in frames[0]], int(frames[1])
+            if len(sids) != 2 or sorted(sids + [tid]) != [1, 2, 3]:
+                raise NotImplementedError("the hot path takes triplets: target_id and two source_ids, three distinct frames in 1..3 (any order; src/model.jl:22-35)")
+            extra.update(target_id=tid, source_ids=tuple(sids))
         key = (N, Cc, H, W, tuple(sorted(extra.items())), x.device.index)
         if self._h is not None and key == self._shape:
             if cache is not None:                 # the reference reads cache.K / cache.invK on every call (src/training.jl:48-57)
@@ -329,7 +336,7 @@ class Model:
         state = self._opt_and_bn_state() if self._h is not None else None
         self.close()
         cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr,
-                             self.encoder.depth, 1 if self.precision == "bf16" else 0)
+                             self.encoder.depth, 1 if self.precision == "bf16" else 0, int(extra["target_id"]), (C.c_int32 * 2)(*extra["source_ids"]))
         h = C.c_void_p()
         _check(_lib.lib().md2_create(C.byref(cfg), C.byref(h)), None, "md2_create")
         self._h, self._shape, self._cfg_extra = h, key, extra
@@ -443,9 +450,7 @@ class Model:
 
     # -- forward --------------------------------------------------------------------------------
     def __call__(self, x, source_ids, target_id):
-        if list(source_ids) != [1, 3] or target_id != 2:
-            raise NotImplementedError("hot path implements source_ids=[1,3], target_id=2 (src/kitty.jl, src/dtk.jl)")
-        x = _f32(x); self._ensure(x)
+        x = _f32(x); self._ensure(x, frames=(source_ids, target_id))
         N, _, _, H, W = x.shape
         L = _lib.lib(); L.md2_set_stream(self._h, _stream())
         ds = [torch.empty(N, 1, H >> s, W >> s, device=x.device) for s in (3, 2, 1, 0)]
@@ -457,9 +462,7 @@ class Model:
 def eval_poses(m: Model, x, source_ids=(1, 3), target_id=2):
     """eval_poses(m, features, source_ids, target_id), src/model.jl:22-35, from the frames x (N,3,C,H,W): the encoder and the pose decoder only (the stage features
     stay in the handle).  Returns [Pose(source 1 -> target), Pose(target -> source 3)] like the model call."""
-    if list(source_ids) != [1, 3] or target_id != 2:
-        raise NotImplementedError("hot path implements source_ids=[1,3], target_id=2 (src/kitty.jl, src/dtk.jl)")
-    x = _f32(x); m._ensure(x); N = x.shape[0]
+    x = _f32(x); m._ensure(x, frames=(source_ids, target_id)); N = x.shape[0]
     L = _lib.lib(); L.md2_set_stream(m._h, _stream())
     rvec = torch.empty(2, N, 3, device=x.device); tvec = torch.empty(2, N, 3, device=x.device)
     _check(L.md2_eval_poses(m._h, _dev(x), _dev(rvec), _dev(tvec)), m._h, "eval_poses")
@@ -630,13 +633,11 @@ def slow_depth(x, K, invK, target_id=2, source_ids=(1, 3), min_depth=0.1, max_de
     """slow_depth (src/simple_depth.jl:1-62): optimise a raw disparity map (init 0.5) and two poses (rvec=[0,0,0.01], tvec=0) for ONE
     triplet with ADAM(3e-4).  The reference calls an undefined `warp`; the sequence it stands for is fused in the loss kernel.
     x (1,3,C,H,W).  Returns (disp (1,1,H,W), [Pose, Pose], losses)."""
-    if list(source_ids) != [1, 3] or target_id != 2:
-        raise NotImplementedError("hot path implements source_ids=[1,3], target_id=2")
     x = _f32(x); N, _, Cc, H, W = x.shape
     enc = ResidualNetwork(18, in_channels=Cc)
     model = Model(enc, DepthDecoder(list(enc.stages), [2, 3, 4, 5]), PoseDecoder(512))
     params = Params(target_size=(W, H), batch_size=N, min_depth=min_depth, max_depth=max_depth, automasking=False)
-    model._ensure(x, params); model.set_intrinsics(K, invK)
+    model._ensure(x, params, frames=(list(source_ids), target_id)); model.set_intrinsics(K, invK)
     dev = x.device
     disp = torch.full((N, 1, H, W), 0.5, device=dev)
     rvec = torch.zeros(2, N, 3, device=dev); rvec[:, :, 2] = 0.01

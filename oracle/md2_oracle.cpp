@@ -96,9 +96,11 @@ struct o_cfg {
     int N, C, H, W, automasking, simple;
     double min_depth, max_depth, smoothness;
     float K[9], invK[9];
+    int target_id, source_ids[2];          // TrainCache.target_id / source_ids (1-based, src/Monodepth.jl:44-55); 0 = the defaults 2 / {1, 3}
 };
 static LossCfg to_cfg(const o_cfg* c) {
     LossCfg l; l.N = c->N; l.C = c->C; l.H = c->H; l.W = c->W; l.automasking = c->automasking; l.simple = c->simple; if (c->simple) l.nscales = 1;
+    if (c->target_id) { l.target_id = c->target_id; l.source_ids[0] = c->source_ids[0]; l.source_ids[1] = c->source_ids[1]; }
     l.min_depth = c->min_depth; l.max_depth = c->max_depth; l.smoothness = c->smoothness;
     std::memcpy(l.K, c->K, sizeof(l.K)); std::memcpy(l.invK, c->invK, sizeof(l.invK)); return l;
 }

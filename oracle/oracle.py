@@ -44,12 +44,13 @@ def lib():
 class OCfg(C.Structure):
     _fields_ = [("N", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("automasking", C.c_int), ("simple", C.c_int),
                 ("min_depth", C.c_double), ("max_depth", C.c_double), ("smoothness", C.c_double),
-                ("K", C.c_float * 9), ("invK", C.c_float * 9)]
+                ("K", C.c_float * 9), ("invK", C.c_float * 9), ("target_id", C.c_int), ("source_ids", C.c_int * 2)]
 
 
-def make_cfg(N, Cc, H, W, K, invK, automasking=False, min_depth=0.1, max_depth=100.0, smoothness=1e-3, simple=False):
-    """K, invK: 3x3 numpy matrices (mathematical row/col indexing); stored column-major like Julia."""
+def make_cfg(N, Cc, H, W, K, invK, automasking=False, min_depth=0.1, max_depth=100.0, smoothness=1e-3, simple=False, target_id=2, source_ids=(1, 3)):
+    """K, invK: 3x3 numpy matrices (mathematical row/col indexing); stored column-major like Julia.  target_id / source_ids: TrainCache's, 1-based."""
     c = OCfg()
+    c.target_id = int(target_id); c.source_ids[0], c.source_ids[1] = int(source_ids[0]), int(source_ids[1])
     c.N, c.C, c.H, c.W, c.automasking, c.simple = N, Cc, H, W, int(automasking), int(simple)
     c.min_depth, c.max_depth, c.smoothness = min_depth, max_depth, smoothness
     Kc = np.asarray(K, np.float32).T.reshape(-1)       # column-major flatten

@@ -325,6 +325,10 @@ def test_simple_depth_loss_and_driver():
     d0 = np.full((N, 1, H, W), 0.5, np.float32); r0 = np.zeros((2, N, 3), np.float32); r0[:, :, 2] = 0.01
     l0 = oracle.loss_fwd_bwd(x, oracle.make_cfg(N, C, H, W, K, iK, simple=True), [d0], r0, np.zeros((2, N, 3), np.float32), do_bwd=False)["loss"]
     assert abs(losses[0] - l0) / l0 < 1e-5
+    # slow_depth(x, ...; target_id, source_ids) with other frame roles (src/simple_depth.jl:1-6): the poses are optimised directly, so nothing is inverted
+    _, _, l31 = md().slow_depth(xd, K, iK, target_id=3, source_ids=(2, 1), iters=1, log_every=1)
+    l0 = oracle.loss_fwd_bwd(x, oracle.make_cfg(N, C, H, W, K, iK, simple=True, target_id=3, source_ids=(2, 1)), [d0], r0, np.zeros((2, N, 3), np.float32), do_bwd=False)["loss"]
+    assert abs(l31[0] - l0) / l0 < 1e-5 and abs(l31[0] - losses[0]) / l0 > 1e-3
 
 
 @pytest.mark.parametrize("C,automask", [(1, False), (3, True)])
@@ -881,3 +885,39 @@ def test_library_rccl_on_every_gpu_of_the_box():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == n and line["config"]["rccl_ranks"] == n and "verified" in line["config"]["gradient_exchange"]
+
+
+@pytest.mark.parametrize("frames", [([2, 3], 1), ([2, 1], 3), ([3, 1], 2), ([1, 3], 2)], ids=["target1", "target3_reversed_sources", "sources_swapped", "default"])
+@pytest.mark.parametrize("automask", [False, True])
+def test_target_and_source_frames_are_the_callers_choice(frames, automask):
+    """TrainCache.target_id / source_ids (src/Monodepth.jl:44-55): which frame of the triplet the depth decoder sees, which two are warped onto it, in which order.  A source
+    before the target is paired (source, target) and its pose inverted (src/model.jl:30-35, src/training.jl:29); the pose outputs follow the order of source_ids.  Forward,
+    loss and every gradient array against the oracle for the non-default roles (and the default as the control)."""
+    sids, tid = frames
+    N, C, H, W = 2, 1, 64, 96
+    m = md()
+    K, iK = syn.depth10k_intrinsics(W, H)
+    params = m.Params(target_size=(W, H), batch_size=N, automasking=automask)
+    cache = m.TrainCache(m.SSIM(), m.Backproject(W, H), m.Project(W, H), K, iK, tid, list(sids), [0.125, 0.25, 0.5, 1.0])
+    enc = m.ResidualNetwork(18, in_channels=C)
+    model = m.Model(enc, m.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), m.PoseDecoder(enc.stages[-1]))
+    theta = syn.init_params(C, seed=91, randomize_affine=True); model.load_params(theta)
+    x = syn.synthetic_triplets(N, C, H, W, seed=92); xd = dev(x)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK, automasking=automask, target_id=tid, source_ids=sids)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    ds, poses = model(xd, sids, tid)
+    dso, rvo, tvo = net.model_forward(x, cfg)
+    for i in range(4):
+        assert rel(host(ds[i]), dso[i]) < 1e-4
+    for s_ in range(2):
+        assert rel(host(poses[s_].rvec), rvo[s_]) < 1e-4 and rel(host(poses[s_].tvec), tvo[s_]) < 1e-4
+    al = m.automasking_loss(m.SSIM(), xd, xd[:, tid - 1].contiguous(), sids) if automask else None
+    alo = oracle.automasking_loss(x, cfg) if automask else None
+    if automask:
+        assert np.abs(host(al) - alo).max() < 1e-4
+    loss = m.train_step(model, xd, al, cache, params, do_update=False)
+    lo = net.train_loss(x, cfg, alo, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    assert_grads_match(model.grads(), net.get_grads(), C, allow=ALLOW_AUTOMASK if automask else (), tag="frames %s" % (frames,))
+    with pytest.raises(NotImplementedError):
+        model(xd, [1, 2, 3], 2)
