@@ -42,6 +42,10 @@ typedef struct md2_config {
     int32_t target_id;    /* TrainCache.target_id, 1-based frame of the triplet the depth decoder sees (src/model.jl:16, src/training.jl:25); 0 = the default 2 */
     int32_t source_ids[2];/* TrainCache.source_ids, 1-based, two distinct frames other than target_id in the caller's order (src/model.jl:22-35: a source before the
                              target is paired (source, target) and its pose inverted, src/training.jl:29); {0, 0} = the default {1, 3} (src/dtk.jl, src/kitty.jl)     */
+    int32_t scale_levels[5]; /* DepthDecoder(; scale_levels) (src/depth_decoder.jl:26-47): ascending levels in 1..5, 0-terminated when fewer than five; output i has the resolution
+                             H >> (5 - level_i); branches 1..max level are built, a head after each listed level.  All zero = the default 2:5 (src/Monodepth.jl:106)            */
+    double scales[5];     /* TrainCache.scales (src/Monodepth.jl:54,107): the smoothness weight of output i is disparity_smoothness * scales[i] (src/training.jl:67);
+                             0 = the reference's 1 / 2^(5 - level_i)                                                                                                      */
 } md2_config;
 
 /* ---- handle ------------------------------------------------------------------------------- */
@@ -68,8 +72,9 @@ int32_t md2_grad_buffer(md2_handle* h, void** dev_ptr, int64_t* count);
 int32_t md2_param_buffer(md2_handle* h, void** dev_ptr, int64_t* count);
 
 /* ---- model: (m::Model)(x, source_ids, target_id), src/model.jl:8-20 (source_ids=[1,3], target_id=2)
- *      x [N][3][C][H][W]; disp_i [N][1][H>>(3-i)][W>>(3-i)]; rvec,tvec [2][N][3] (source-major) --- */
-int32_t md2_model_forward(md2_handle* h, const float* x, float* disp0, float* disp1, float* disp2, float* disp3,
+ *      x [N][3][C][H][W]; disp_i [N][1][H>>(5-level_i)][W>>(5-level_i)] for the configured scale levels (2:5 by default: H>>(3-i)), the pointers past the last
+ *      level are ignored (NULL); rvec,tvec [2][N][3] (source-major) --- */
+int32_t md2_model_forward(md2_handle* h, const float* x, float* disp0, float* disp1, float* disp2, float* disp3, float* disp4,
                           float* rvec, float* tvec);
 /* eval_poses(m, features, source_ids, target_id), src/model.jl:22-35, on the frames themselves (the stage features live in the handle):
  * encoder + pose decoder only, for both (source, target) pairs -> rvec, tvec [2][N][3] */
@@ -88,7 +93,7 @@ int32_t md2_set_lr(md2_handle* h, double lr);
 int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, float* loss, int32_t do_update);
 /* eval_disparity(m, x), src/model.jl:28: n single frames x [n][C][H][W] (n <= batch) -> the 4 disparities [n][1][h][w].
  * BatchNorm follows the handle's mode (md2_set_testmode): batch statistics under trainmode! (default), tracked statistics under testmode!. */
-int32_t md2_eval_disparity(md2_handle* h, const float* x, int32_t n, float* disp0, float* disp1, float* disp2, float* disp3);
+int32_t md2_eval_disparity(md2_handle* h, const float* x, int32_t n, float* disp0, float* disp1, float* disp2, float* disp3, float* disp4);
 /* Flux.testmode!(model) / trainmode!(model) (src/Monodepth.jl:126,209,237): on = 1 makes every BatchNorm normalise with its tracked running mean /
  * variance (momentum 0.1, updated by every train-mode forward pass like Flux's `_track_stats!`); md2_train_loss needs train mode. */
 int32_t md2_set_testmode(md2_handle* h, int32_t on);
@@ -127,8 +132,8 @@ int32_t md2_broadcast_state(md2_handle* h, int32_t root);   /* parameters, ADAM 
 /* The loss half alone (src/training.jl:28-77) given disparities and poses; pullbacks may be NULL.
  * ddisp_i like disp_i; drvec/dtvec [2][N][3]. */
 int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* disp0, const float* disp1, const float* disp2,
-                         const float* disp3, const float* rvec, const float* tvec, const float* auto_loss, float* loss,
-                         float* ddisp0, float* ddisp1, float* ddisp2, float* ddisp3, float* drvec, float* dtvec);
+                         const float* disp3, const float* disp4, const float* rvec, const float* tvec, const float* auto_loss, float* loss,
+                         float* ddisp0, float* ddisp1, float* ddisp2, float* ddisp3, float* ddisp4, float* drvec, float* dtvec);
 
 /* slow_depth's objective (src/simple_depth.jl:25-42, BASELINE config #1): mean(prediction_loss(warp(disp, x, Ps))) +
  * smooth_loss(disp) on ONE full-resolution disparity disp [N][1][H][W] (no sigmoid, no mean-normalisation, weight 1) and its
@@ -211,7 +216,7 @@ int32_t md2_conv2d_bnstats_fwd(const float* x, const float* w, float* y, float* 
  * -> z [N][64][H/2][W/2] (+ the BatchNorm statistics of z, optional); and its weight gradient from dz */
 int32_t md2_stem_conv_fwd(const float* x, const float* w, float* z, float* bn_mean, float* bn_invstd, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 int32_t md2_stem_conv_wgrad(const float* x, const float* dz, float* dw, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
-/* The disparity heads (src/depth_decoder.jl:43): reflect-pad + 3x3 conv to ONE channel + sigmoid, Cin in {16,32,64,128}; x [N][Cin][H][W], w Flux [1][Cin][3][3],
+/* The disparity heads (src/depth_decoder.jl:43): reflect-pad + 3x3 conv to ONE channel + sigmoid, Cin in {16,32,64,128,256}; x [N][Cin][H][W], w Flux [1][Cin][3][3],
  * b [1] -> y [N][1][H][W]; pullback of dy -> dx, dw, db (x_act = 2: x is an ELU output and dx is taken w.r.t. its pre-activation, as the last branch does) */
 int32_t md2_head_conv_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream);
 int32_t md2_head_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin, int32_t H,

@@ -13,7 +13,8 @@ class Md2Config(C.Structure):
     _fields_ = [("batch", C.c_int32), ("channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
                 ("automasking", C.c_int32), ("device", C.c_int32),
                 ("min_depth", C.c_double), ("max_depth", C.c_double), ("disparity_smoothness", C.c_double), ("lr", C.c_double),
-                ("encoder_depth", C.c_int32), ("precision", C.c_int32), ("target_id", C.c_int32), ("source_ids", C.c_int32 * 2)]
+                ("encoder_depth", C.c_int32), ("precision", C.c_int32), ("target_id", C.c_int32), ("source_ids", C.c_int32 * 2),
+                ("scale_levels", C.c_int32 * 5), ("scales", C.c_double * 5)]
 
 
 def build(force=False):
@@ -43,17 +44,17 @@ _SIGS = {
     "md2_grads_get": (I32, [P, P, I64]),
     "md2_grad_buffer": (I32, [P, C.POINTER(P), C.POINTER(I64)]),
     "md2_param_buffer": (I32, [P, C.POINTER(P), C.POINTER(I64)]),
-    "md2_model_forward": (I32, [P] * 8),
+    "md2_model_forward": (I32, [P] * 9),
     "md2_train_loss": (I32, [P, P, P, P]),
     "md2_backward": (I32, [P]),
     "md2_adam_step": (I32, [P, C.c_float]),
     "md2_train_step": (I32, [P, P, P, P, I32]),
     "md2_automasking_loss": (I32, [P, P, P]),
-    "md2_eval_disparity": (I32, [P, P, I32, P, P, P, P]),
+    "md2_eval_disparity": (I32, [P, P, I32, P, P, P, P, P]),
     "md2_opt_state_get": (I32, [P, P, P, I64, C.POINTER(F64), C.POINTER(F64)]),
     "md2_opt_state_set": (I32, [P, P, P, I64, F64, F64]),
     "md2_eval_poses": (I32, [P, P, P, P]),
-    "md2_loss_fwd_bwd": (I32, [P] * 16),
+    "md2_loss_fwd_bwd": (I32, [P] * 18),
     "md2_simple_depth_loss": (I32, [P] * 9),
     "md2_set_two_streams": (I32, [P, I32]),
     "md2_profile_enable": (I32, [P, I32]),

@@ -1762,6 +1762,7 @@ void launch_head_fwd(const View& x, const float* w, const float* b, const View& 
         case 8: hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
         case 16: hipLaunchKernelGGL(head_fwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
         case 32: hipLaunchKernelGGL(head_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
+        case 64: hipLaunchKernelGGL(head_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;          // a head on the first branch (scale level 1, 256 channels)
         default: fprintf(stderr, "md2: head_fwd: unsupported Cin=%d\n", x.C); abort();
     }
 }
@@ -1885,6 +1886,7 @@ void launch_head_bwd(const View& x, const float* w, const View& y, const View& d
         case 8: launch_head_bwd_t<8>(x, w, y, dy, dx, accumulate, x_act, dw, db, s); break;
         case 16: launch_head_bwd_t<16>(x, w, y, dy, dx, accumulate, x_act, dw, db, s); break;
         case 32: launch_head_bwd_t<32>(x, w, y, dy, dx, accumulate, x_act, dw, db, s); break;
+        case 64: launch_head_bwd_t<64>(x, w, y, dy, dx, accumulate, x_act, dw, db, s); break;
         default: fprintf(stderr, "md2: head_bwd: unsupported Cin=%d\n", x.C); abort();
     }
 }

@@ -272,15 +272,15 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int C>
 __global__ __launch_bounds__(256) void loss_smooth_sums_kernel(LossArgs a, double* __restrict__ part, double* __restrict__ blk) {
     __shared__ float dt[33 * 33];
-    __shared__ float red[16][12];
+    __shared__ float red[16][3 * MD2_MAX_SCALES];
     const int n = blockIdx.z, H = a.H, W = a.W;
     const long P = (long)H * W;
     const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5, tx0 = blockIdx.x * 32, ty0 = blockIdx.y * 32, px = tx0 + lx;
     const float* tgt = a.x + ((long)n * 3 + a.tgt) * C * P;
     const float invC = 1.f / (float)C;
-    float v[12], ex[4], ey[4];
+    float v[3 * MD2_MAX_SCALES], ex[4], ey[4];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) v[k] = 0.f;
+    for (int k = 0; k < 3 * MD2_MAX_SCALES; ++k) v[k] = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int py = ty0 + ly0 + r * 8;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void loss_smooth_sums_kernel(LossArgs a, doubl
         if (py + 1 < H) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tgt[c * P + p] - tgt[c * P + p + W]); if (C > 1) gi *= invC; ey[r] = fexp(-gi); }
     }
 #pragma unroll
-    for (int sc = 0; sc < 4; ++sc) {
+    for (int sc = 0; sc < MD2_MAX_SCALES; ++sc) {
         if (sc >= a.nscales) break;
         const int dh = a.dh[sc], dw = a.dw[sc];
         const float* dsp = a.disp[sc] + (long)n * dh * dw;
@@ -310,14 +310,14 @@ __global__ __launch_bounds__(256) void loss_smooth_sums_kernel(LossArgs a, doubl
     }
     const int row = threadIdx.x >> 4;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) { const float r = row16_sum(v[k]); if ((threadIdx.x & 15) == 0) red[row][k] = r; }
+    for (int k = 0; k < 3 * MD2_MAX_SCALES; ++k) { const float r = row16_sum(v[k]); if ((threadIdx.x & 15) == 0) red[row][k] = r; }
     __syncthreads();
     if (threadIdx.x < 3 * a.nscales) {
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
         const int sc = threadIdx.x / 3, k = threadIdx.x - sc * 3;
-        if (blk) blk[((long)n * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = (double)t;
+        if (blk) blk[((long)n * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * (3 * MD2_MAX_SCALES) + threadIdx.x] = (double)t;
         else atomicAdd(part + ((long)sc * a.N + n) * 4 + 1 + k, (double)t);
     }
 }
@@ -326,11 +326,11 @@ __global__ void loss_smooth_reduce_kernel(const double* __restrict__ blk, double
     const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= N * nscales * 3) return;
     const int k = i % 3, sc = (i / 3) % nscales, n = i / (3 * nscales);
     double s = 0;
-    for (int b = 0; b < nb; ++b) s += blk[((long)n * nb + b) * 12 + sc * 3 + k];
+    for (int b = 0; b < nb; ++b) s += blk[((long)n * nb + b) * (3 * MD2_MAX_SCALES) + sc * 3 + k];
     part[((long)sc * N + n) * 4 + 1 + k] = s;
 }
 
-struct LossTrainOut { double* part; float* dd[4]; float* dlo[4]; double* dRt_acc; double* blk; };
+struct LossTrainOut { double* part; float* dd[MD2_MAX_SCALES]; float* dlo[MD2_MAX_SCALES]; double* dRt_acc; double* blk; };
 // One block = `tpb` consecutive TW x TH tiles of one (scale, sample).  Per tile:
 //  1. warped sources / target / disparity at the padded positions of tile + 2 -> LDS                           (the only global gathers of the forward)
 //  2. window owners q in tile + 1, three per thread in a column (row sums of the five window moments shared between them):
@@ -653,10 +653,10 @@ void launch_loss_smooth_sums(const LossArgs& a, double* part, double* blk, hipSt
     else hipLaunchKernelGGL(loss_smooth_sums_kernel<3>, grid, dim3(256), 0, s, a, part, blk);
     if (blk) hipLaunchKernelGGL(loss_smooth_reduce_kernel, dim3((a.N * a.nscales * 3 + 63) / 64), dim3(64), 0, s, blk, part, a.N, a.nscales, (int)(grid.x * grid.y));
 }
-void launch_loss_train(const LossArgs& a, double* part, float* const dd[4], float* const dlo[4], double* dRt_acc, double* blk, hipStream_t s) {
+void launch_loss_train(const LossArgs& a, double* part, float* const dd[MD2_MAX_SCALES], float* const dlo[MD2_MAX_SCALES], double* dRt_acc, double* blk, hipStream_t s) {
     if ((a.C != 1 && a.C != 3) || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_train: unsupported C=%d H=%d W=%d\n", a.C, a.H, a.W); abort(); }
     LossTrainOut o; o.part = part; o.dRt_acc = dRt_acc; o.blk = blk;
-    for (int i = 0; i < 4; ++i) { o.dd[i] = dd[i]; o.dlo[i] = dlo[i]; }
+    for (int i = 0; i < MD2_MAX_SCALES; ++i) { o.dd[i] = dd[i]; o.dlo[i] = dlo[i]; }
     static const int tpb_env = getenv("MD2_LOSS_TPB") ? atoi(getenv("MD2_LOSS_TPB")) : 0;
     const int ntx = (a.W + TW - 1) / TW, tpb = tpb_env > 0 ? tpb_env : 2;
     const int th = a.C == 1 ? 32 : 16;

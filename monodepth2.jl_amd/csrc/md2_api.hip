@@ -57,18 +57,21 @@ struct md2_handle {
     float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *WD = nullptr;
     double beta1p = 1.0, beta2p = 1.0;
     ConvL stem; BNL stem_bn; Block blk[16]; int nblk = 8, depth = 18, bf16 = 0; int stages[5] = {64, 64, 128, 256, 512};
-    ConvL dc1[5], dc2[5], head[4], squeeze, pose[3];
+    ConvL dc1[5], dc2[5], head[5], squeeze, pose[3];
+    // DepthDecoder(; scale_levels) (src/depth_decoder.jl:26-47): ns outputs at levels lv[0] < ... < lv[ns-1] (1..5), branches 1..nbr = lv[ns-1]; out_of[b] = output index of
+    // the head on branch b (0-based) or -1; scl[i] = TrainCache.scales[i] (the smoothness weight of output i, src/training.jl:67)
+    int ns = 4, lv[5] = {2, 3, 4, 5, 0}, nbr = 5, out_of[5] = {-1, 0, 1, 2, 3}; double scl[5] = {0.125, 0.25, 0.5, 1.0, 0.0};
     std::vector<ConvL*> convs; std::vector<BNL*> bns;
     char* arena = nullptr; size_t arena_off = 0;
     double* acc_all = nullptr; size_t acc_count = 0; double* acc_bwd = nullptr; size_t acc_fwd_count = 0, acc_bwd_count = 0;
     int Kpad = 64;
     View z0, a0, p0; uint8_t* pool_arg = nullptr;
-    View feat[5], y1[5], cat[5], y2[5], dispv[4];
+    View feat[5], y1[5], cat[5], y2[5], dispv[5];
     View sq3, dsq3; View sqcat, py1, py2, py3; float *rvec = nullptr, *tvec = nullptr, *Rt = nullptr;
-    double *loss_part = nullptr, *dRt_acc = nullptr; float *totals = nullptr, *loss_dev = nullptr, *ddisp_full = nullptr, *drvec = nullptr, *dtvec = nullptr;
+    double *loss_part = nullptr, *dRt_acc = nullptr; size_t ddisp_lo_count = 0; float *totals = nullptr, *loss_dev = nullptr, *ddisp_full = nullptr, *drvec = nullptr, *dtvec = nullptr;
     const float* x_last = nullptr; const float* auto_last = nullptr; bool have_fwd = false;
     View Gfeat[5], Gblk[16], Gpool; char* gzero_begin = nullptr; size_t gzero_bytes = 0;
-    View gA[5], dZ1[5], dupv[5]; float* dxpad = nullptr; float* ddisp_lo[4] = {nullptr, nullptr, nullptr, nullptr};
+    View gA[5], dZ1[5], dupv[5]; float* dxpad = nullptr; float* ddisp_lo[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float *E1 = nullptr, *E2 = nullptr, *E3 = nullptr;
     View dpy3, dpy2, dpy1, dsq;
     long* wdesc_dev = nullptr; int n_wdesc = 0;
@@ -140,8 +143,8 @@ static void build_layers(md2_handle* h) {
     // DepthDecoder channel arithmetic from the encoder stages (src/depth_decoder.jl:31-35)
     const int dec[5] = {256, 128, 64, 32, 16};
     const int inc[5] = {h->stages[4], 256, 128, 64, 32}, skc[5] = {h->stages[3], h->stages[2], h->stages[1], h->stages[0], 0};
-    for (int b = 0; b < 5; ++b) { mk(h->dc1[b], inc[b], dec[b], 3, 1, 0, true, 0); mk(h->dc2[b], dec[b] + skc[b], dec[b], 3, 1, 0, true, 0); }
-    for (int l = 0; l < 4; ++l) mk(h->head[l], dec[l + 1], 1, 3, 1, 0, true, 2);
+    for (int b = 0; b < h->nbr; ++b) { mk(h->dc1[b], inc[b], dec[b], 3, 1, 0, true, 0); mk(h->dc2[b], dec[b] + skc[b], dec[b], 3, 1, 0, true, 0); }
+    for (int i = 0; i < h->ns; ++i) mk(h->head[i], dec[h->lv[i] - 1], 1, 3, 1, 0, true, 2);          // Flux.params order: all branches, then the decoders (heads)
     mk(h->squeeze, h->stages[4], 256, 1, 1, 0, true, 0); mk(h->pose[0], 512, 256, 3, 1, 1, true, 0); mk(h->pose[1], 256, 256, 3, 1, 1, true, 0); mk(h->pose[2], 256, 6, 1, 1, 0, true, 0);
     h->n_int = io; h->n_flux = fo; h->n_rs = ro;
 }
@@ -207,29 +210,29 @@ static void plan_buffers(md2_handle* h) {
     const int dec[5] = {256, 128, 64, 32, 16}, skc[5] = {h->stages[3], h->stages[2], h->stages[1], h->stages[0], 0}, inc[5] = {h->stages[4], 256, 128, 64, 32};
     int dh = H / 32, dw = W / 32;
     size_t dxpad_max = 0;
-    for (int b = 0; b < 5; ++b) {
+    for (int b = 0; b < h->nbr; ++b) {
         h->y1[b] = h->alloc_view(N, dh, dw, dec[b]);
         dxpad_max = std::max(dxpad_max, (size_t)N * (dh + 2) * (dw + 2) * inc[b]);
         dh *= 2; dw *= 2;
         h->cat[b] = h->alloc_view(N, dh, dw, dec[b] + skc[b]);
         h->y2[b] = h->alloc_view(N, dh, dw, dec[b]);
         dxpad_max = std::max(dxpad_max, (size_t)N * (dh + 2) * (dw + 2) * (dec[b] + skc[b]));
-        if (b >= 1) h->dispv[b - 1] = h->alloc_view(N, dh, dw, 1);
+        if (h->out_of[b] >= 0) h->dispv[h->out_of[b]] = h->alloc_view(N, dh, dw, 1);
     }
     // a loss-only handle (H, W multiples of 8 but not of 32) has no decoder to derive the disparity sizes from: the loss reads / writes H >> (3 - l) x W >> (3 - l)
-    if (!h->net_ok) for (int l = 0; l < 4; ++l) h->dispv[l] = h->alloc_view(N, H >> (3 - l), W >> (3 - l), 1);
+    if (!h->net_ok) for (int l = 0; l < h->ns; ++l) h->dispv[l] = h->alloc_view(N, H >> (5 - h->lv[l]), W >> (5 - h->lv[l]), 1);
     const int ph = H / 32, pw = W / 32;
     h->sq3 = h->alloc_view(3 * N, ph, pw, 256); h->dsq3 = h->alloc_view(3 * N, ph, pw, 256);
     h->sqcat = h->alloc_view(2 * N, ph, pw, 512); h->py1 = h->alloc_view(2 * N, ph, pw, 256); h->py2 = h->alloc_view(2 * N, ph, pw, 256); h->py3 = h->alloc_view(2 * N, ph, pw, 16);
     h->rvec = h->alloc<float>(6 * N); h->tvec = h->alloc<float>(6 * N); h->Rt = h->alloc<float>(24 * N);
-    h->totals = h->alloc<float>(16 * N); h->loss_dev = h->alloc<float>(4); h->ddisp_full = h->alloc<float>((size_t)4 * N * H * W);
+    h->totals = h->alloc<float>(4 * MD2_MAX_SCALES * N); h->loss_dev = h->alloc<float>(4); h->ddisp_full = h->alloc<float>((size_t)h->ns * N * H * W);
     h->ws_cap = 8L << 20; h->ws_main = h->alloc<float>((size_t)h->ws_cap); h->ws_pose = h->alloc<float>((size_t)h->ws_cap);      // 2 x 32 MB
     h->drvec = h->alloc<float>(6 * N); h->dtvec = h->alloc<float>(6 * N);
-    h->loss_blk = h->alloc<double>((size_t)4 * N * ((W + 15) / 16) * ((H + 7) / 8) * 24);        // deterministic mode: [scale*N][block][24] partials (bound for loss tiles >= 16x8)
+    h->loss_blk = h->alloc<double>((size_t)MD2_MAX_SCALES * N * ((W + 15) / 16) * ((H + 7) / 8) * 25);        // deterministic mode: [scale*N][block][24] partials (bound for loss tiles >= 16x8)
     for (BNL* b : h->bns) b->stats = h->alloc<float>(9 * b->c);                 // mean | invstd | scale | shift | pullback m1 | m2 | A | B | C0 (dz = A g + B z + C0)
     size_t nd = 0;
     for (BNL* b : h->bns) nd += (size_t)(4 * BN_STAT_SLOTS) * b->c;
-    nd += (size_t)16 * N + 24 * N;
+    nd += (size_t)4 * MD2_MAX_SCALES * N + 24 * N;
     h->acc_count = nd; h->acc_all = h->alloc<double>(nd);
     double* ap = h->acc_all;
     for (BNL* b : h->bns) { b->acc = ap; ap += (size_t)2 * BN_STAT_SLOTS * b->c; }      // [slot][sum | sum of squares][c]
@@ -237,7 +240,7 @@ static void plan_buffers(md2_handle* h) {
     h->acc_bwd = ap;
     for (BNL* b : h->bns) { b->acc_b = ap; ap += (size_t)2 * BN_STAT_SLOTS * b->c; }    // [slot][sum g | sum g*xhat][c]: filled by the producing input gradient's epilogue
     h->acc_bwd_count = ap - h->acc_bwd;
-    h->loss_part = ap; ap += 16 * N; h->dRt_acc = ap; ap += 24 * N;
+    h->loss_part = ap; ap += 4 * MD2_MAX_SCALES * N; h->dRt_acc = ap; ap += 24 * N;
     // ---- backward: gradient accumulators, zeroed together at the start of every backward
     h->arena_off = (h->arena_off + 255) / 256 * 256;
     const size_t gz0 = h->arena_off;
@@ -250,16 +253,16 @@ static void plan_buffers(md2_handle* h) {
     h->arena_off = (h->arena_off + 255) / 256 * 256;
     h->gzero_begin = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(h->arena) + gz0); h->gzero_bytes = h->arena_off - gz0;
     // ---- backward scratch
-    for (int b = 0; b < 5; ++b) {
+    for (int b = 0; b < h->nbr; ++b) {
         h->gA[b] = h->alloc_view(h->y2[b].N, h->y2[b].H, h->y2[b].W, h->y2[b].C);
         h->dZ1[b] = h->alloc_view(h->y1[b].N, h->y1[b].H, h->y1[b].W, h->y1[b].C);
         h->dupv[b] = h->alloc_view(h->y2[b].N, h->y2[b].H, h->y2[b].W, h->y2[b].C);
     }
     h->dxpad = h->alloc<float>(dxpad_max);
     {   // one block, coarse scales first: the fused loss kernel accumulates into levels 0..2 with atomics, so they are zeroed by a single memset
-        size_t tot = 0; for (int l = 0; l < 4; ++l) tot += (size_t)N * h->dispv[l].H * h->dispv[l].W;
-        float* base = h->alloc<float>(tot);
-        for (int l = 0; l < 4; ++l) { h->ddisp_lo[l] = base; base += (size_t)N * h->dispv[l].H * h->dispv[l].W; }
+        size_t tot = 0; for (int l = 0; l < h->ns; ++l) tot += (size_t)N * h->dispv[l].H * h->dispv[l].W;
+        float* base = h->alloc<float>(tot); h->ddisp_lo_count = tot;
+        for (int l = 0; l < h->ns; ++l) { h->ddisp_lo[l] = base; base += (size_t)N * h->dispv[l].H * h->dispv[l].W; }
     }
     const size_t emax = (size_t)NL * (H / 2) * (W / 2) * 64;
     h->E1 = h->alloc<float>(emax); h->E2 = h->alloc<float>(emax); h->E3 = h->alloc<float>(emax);
@@ -360,11 +363,10 @@ static void want_bn_sums(ConvArgs& a, const BNL& b, const View& z, const BNL* b2
     if (b2) { a.bstB = b2->acc_b; a.bzB = z2->p; a.bzB_bs = z2->bs; a.bzB_ps = z2->ps; a.bstatB = b2->stats; }
 }
 
-static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp[4], const float* Rt, const float* auto_loss) {
+static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp[MD2_MAX_SCALES], const float* Rt, const float* auto_loss) {
     LossArgs a{};
-    a.x = x; a.N = h->N; a.C = h->C; a.H = h->H; a.W = h->W; a.nscales = 4;
-    const double scales[4] = {0.125, 0.25, 0.5, 1.0};
-    for (int i = 0; i < 4; ++i) { a.disp[i] = disp[i]; a.dh[i] = h->H >> (3 - i); a.dw[i] = h->W >> (3 - i); a.smooth_w[i] = (float)h->cfg.disparity_smoothness * (float)scales[i]; }
+    a.x = x; a.N = h->N; a.C = h->C; a.H = h->H; a.W = h->W; a.nscales = h->ns;
+    for (int i = 0; i < h->ns; ++i) { a.disp[i] = disp[i]; a.dh[i] = h->H >> (5 - h->lv[i]); a.dw[i] = h->W >> (5 - h->lv[i]); a.smooth_w[i] = (float)h->cfg.disparity_smoothness * (float)h->scl[i]; }
     a.Rt = Rt; a.auto_loss = h->cfg.automasking ? auto_loss : nullptr;
     std::memcpy(a.K, h->K, sizeof(a.K)); std::memcpy(a.invK, h->invK, sizeof(a.invK));
     a.min_disp = (float)(1.0 / h->cfg.max_depth); a.max_disp = (float)(1.0 / h->cfg.min_depth);
@@ -380,7 +382,7 @@ static void set_batch(md2_handle* h, int n_enc, int n_dec) {
     h->z0.N = h->a0.N = h->p0.N = n_enc;
     for (int i = 0; i < h->nblk; ++i) { Block& B = h->blk[i]; B.in.N = B.z1.N = B.a1.N = B.z2.N = B.out.N = n_enc; if (B.bottleneck) B.a2.N = B.z3.N = n_enc; if (B.down) B.zd.N = B.sd.N = n_enc; }
     for (int i = 0; i < 5; ++i) { h->feat[i].N = n_enc; h->y1[i].N = h->cat[i].N = h->y2[i].N = n_dec; }
-    for (int i = 0; i < 4; ++i) h->dispv[i].N = n_dec;
+    for (int i = 0; i < h->ns; ++i) h->dispv[i].N = n_dec;
 }
 
 // pose decoder, both sources batched (src/model.jl:22-35, src/pose_decoder.jl:23-32); enqueued on h->chain()
@@ -459,13 +461,13 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
     }
     // ---- depth decoder on the target-frame features (src/model.jl:16-17, src/depth_decoder.jl:49-65)
     View x5 = frame_view(h->feat[4], L, tgt);
-    for (int b = 0; b < (with_depth ? 5 : 0); ++b) {
+    for (int b = 0; b < (with_depth ? h->nbr : 0); ++b) {
         const View& in = (b == 0) ? x5 : h->y2[b - 1];
         conv_fwd(h, h->dc1[b], in, h->y1[b], PAD_REFLECT, ACT_ELU);
         launch_upsample2x_fwd(h->y1[b], chan_slice(h->cat[b], 0, h->y1[b].C), s);
         if (b < 4) { View sk = frame_view(h->feat[3 - b], L, tgt); launch_axpy_view(sk, chan_slice(h->cat[b], h->y1[b].C, sk.C), 1.f, 0, nullptr, ACT_NONE, s); }
         conv_fwd(h, h->dc2[b], h->cat[b], h->y2[b], PAD_REFLECT, ACT_ELU);
-        if (b >= 1) launch_head_fwd(h->y2[b], h->P + h->head[b - 1].w, h->P + h->head[b - 1].b, h->dispv[b - 1], s);
+        if (const int o = h->out_of[b]; o >= 0) launch_head_fwd(h->y2[b], h->P + h->head[o].w, h->P + h->head[o].b, h->dispv[o], s);
     }
     if (pose_async) (void)hipStreamWaitEvent(h->stream, h->ev_b, 0);       // join: the loss needs the poses
     KCHK();
@@ -475,44 +477,46 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
 static void simple_mode(md2_handle* h, LossArgs& a) {      // slow_depth objective, src/simple_depth.jl:25-42
     a.nscales = 1; a.dh[0] = h->H; a.dw[0] = h->W; a.smooth_w[0] = 1.f; a.normalize = 0; a.auto_loss = nullptr;
 }
-static int loss_forward(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
+static int loss_forward(md2_handle* h, const float* x, const float* const disp[MD2_MAX_SCALES], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
     hipStream_t s = h->stream;
-    HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)16 * h->N * sizeof(double), s));
+    HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)4 * MD2_MAX_SCALES * h->N * sizeof(double), s));
     launch_pose_compose(rvec, tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);       // inverse_transform = source_ids .< target_id = [true, false] (src/training.jl:29)
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
     if (simple) simple_mode(h, a);
     h->pbegin(CLS_LOSS_FWD); launch_loss_fwd(a, h->loss_part, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
-    if (h->prof) h->prof_bytes[CLS_LOSS_FWD] += 4.0 * h->H * h->W * (1 + 3 * h->C) * 4 * h->N;
+    if (h->prof) h->prof_bytes[CLS_LOSS_FWD] += 4.0 * h->H * h->W * (1 + 3 * h->C) * a.nscales * h->N;
     launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
     if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
     KCHK();
     return 0;
 }
 // loss value and its pullback in one pass (training): fills the loss, ddisp_lo[4], drvec, dtvec
-static int loss_train(md2_handle* h, const float* x, const float* const disp[4], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
+static int loss_train(md2_handle* h, const float* x, const float* const disp[MD2_MAX_SCALES], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
     hipStream_t s = h->stream;
-    HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)40 * h->N * sizeof(double), s));           // loss_part [16N] and dRt_acc [24N] are adjacent
+    HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)(4 * MD2_MAX_SCALES + 24) * h->N * sizeof(double), s));           // loss_part [20N] and dRt_acc [24N] are adjacent
     launch_pose_compose(rvec, tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
     if (simple) simple_mode(h, a);
     const size_t P = (size_t)h->H * h->W;
     // gradient wrt the disparity maps: the full-resolution scale is written directly; the coarse scales receive the adjoint of the bilinear resize from inside the
     // kernel (per-tile partial sums, float atomics) -- or, in deterministic mode, full-resolution maps that the ordered adjoint kernel reduces afterwards
-    float *dd[4], *dlo[4];
+    float *dd[MD2_MAX_SCALES] = {}, *dlo[MD2_MAX_SCALES] = {};
     static const bool no_scatter = getenv("MD2_LOSS_NOSCATTER") && atoi(getenv("MD2_LOSS_NOSCATTER")) != 0;
     const bool scatter = !simple && !g_deterministic && !no_scatter;
-    for (int i = 0; i < 4; ++i) {
+    bool any_lo = false;
+    for (int i = 0; i < a.nscales; ++i) {
         const bool full = !simple && a.dh[i] == h->H && a.dw[i] == h->W;
         dd[i] = full ? h->ddisp_lo[i] : h->ddisp_full + (size_t)i * h->N * P;
-        dlo[i] = (scatter && !full) ? h->ddisp_lo[i] : nullptr;
+        dlo[i] = (scatter && !full) ? h->ddisp_lo[i] : nullptr; any_lo |= dlo[i] != nullptr;
     }
-    if (scatter) HIPCHK(hipMemsetAsync(h->ddisp_lo[0], 0, (size_t)((char*)h->ddisp_lo[3] - (char*)h->ddisp_lo[0]), s));
+    // (the coarse levels come first in the block; a full-resolution last level is written, not accumulated)
+    if (any_lo) HIPCHK(hipMemsetAsync(h->ddisp_lo[0], 0, dlo[h->ns - 1] ? h->ddisp_lo_count * sizeof(float) : (size_t)((char*)h->ddisp_lo[h->ns - 1] - (char*)h->ddisp_lo[0]), s));
     launch_loss_smooth_sums(a, h->loss_part, g_deterministic ? h->loss_blk : nullptr, s);
     h->pbegin(CLS_LOSS_BWD); launch_loss_train(a, h->loss_part, dd, dlo, h->dRt_acc, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
     if (h->prof) h->prof_bytes[CLS_LOSS_BWD] += 4.0 * h->H * h->W * (2 + 3 * h->C) * a.nscales * h->N;
     launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
     if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (!simple) for (int i = 0; i < 4; ++i) if (!dlo[i] && dd[i] != h->ddisp_lo[i]) launch_upsample_planar_bwd(dd[i], h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
+    if (!simple) for (int i = 0; i < a.nscales; ++i) if (!dlo[i] && dd[i] != h->ddisp_lo[i]) launch_upsample_planar_bwd(dd[i], h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
     launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
     KCHK();
     return 0;
@@ -571,13 +575,14 @@ static int model_backward(md2_handle* h) {
     const bool pose_async = h->two_streams && h->s3;
     if (pose_async) { (void)hipEventRecord(h->ev_a, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_a, 0); h->cur = h->s3; pose_backward(h, N, 0); h->cur = nullptr; }
     // ---- depth decoder
-    for (int l = 0; l < 4; ++l) {
-        const int b = l + 1;
+    const int nbr = h->nbr;
+    for (int l = 0; l < h->ns; ++l) {
+        const int b = h->lv[l] - 1;
         View dyv = make_view(h->ddisp_lo[l], N, h->dispv[l].H, h->dispv[l].W, 1);
-        // last branch (b == 4): only its head consumes it, so the ELU derivative of y2[4] is applied right there
-        launch_head_bwd(h->y2[b], h->P + h->head[l].w, h->dispv[l], dyv, h->gA[b], 0, b == 4 ? ACT_ELU : ACT_NONE, h->G + h->head[l].w, h->G + h->head[l].b, s);
+        // last branch: only its head consumes it, so the ELU derivative of its y2 is applied right there
+        launch_head_bwd(h->y2[b], h->P + h->head[l].w, h->dispv[l], dyv, h->gA[b], 0, b == nbr - 1 ? ACT_ELU : ACT_NONE, h->G + h->head[l].w, h->G + h->head[l].b, s);
     }
-    for (int b = 4; b >= 0; --b) {
+    for (int b = nbr - 1; b >= 0; --b) {
         // gA[b] now holds d loss / d (pre-ELU output of c2[b])
         const View& dZ2 = h->gA[b];
         conv_wgrad(h, h->dc2[b], h->cat[b], dZ2, PAD_REFLECT);
@@ -595,7 +600,7 @@ static int model_backward(md2_handle* h) {
         View dip = make_view(h->dxpad, N, in.H + 2, in.W + 2, in.C);
         conv_dgrad(h, h->dc1[b], h->dZ1[b], dip, 0, 0, nullptr, ACT_NONE);
         if (b == 0) { View fv = frame_view(h->feat[4], 3, h->tgt), gv = frame_view(h->Gfeat[4], 3, h->tgt); launch_fold_reflect(dip, gv, 0, &fv, ACT_RELU, s); }   // first writer of Gfeat[4] frame 1
-        else launch_fold_reflect(dip, h->gA[b - 1], (b - 1) >= 1 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);
+        else launch_fold_reflect(dip, h->gA[b - 1], h->out_of[b - 1] >= 0 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);        // (adds to the head's contribution where branch b-1 has one)
     }
     // ---- pose branch, second half: accumulate into Gfeat[4] after the depth decoder's write; then join (the encoder pullback reads Gfeat[4])
     if (pose_async) {
@@ -609,6 +614,9 @@ static int model_backward(md2_handle* h) {
     // the epilogue of the input-gradient launch that PRODUCES g (its last writer), so the separate reduction pass over (g, z) disappears; `sums_ready[i]` says whether
     // block i's output-side BatchNorms (bn2 and the shortcut's) got theirs that way.
     bool sums_ready[16]; for (int i = 0; i < 16; ++i) sums_ready[i] = false;
+    // stage_below[i]: index of the stage feature that is block i's input when block i-1 ends a stage; stage_used[j]: the decoder wrote Gfeat[j] (skip of branch 3-j, head feature 4)
+    int stage_below[16]; { int st = 1; for (int i = 0; i < h->nblk; ++i) { stage_below[i] = st - 1; if (h->blk[i].stage_end) ++st; } }
+    bool stage_used[5]; for (int j = 0; j < 5; ++j) stage_used[j] = (j == 4) || (3 - j) < nbr;
     for (int i = h->nblk - 1; i >= 0; --i) {
         Block& B = h->blk[i];
         const View& Gout = h->Gblk[i];                                  // d / d(pre-ReLU block output), already masked
@@ -616,7 +624,8 @@ static int model_backward(md2_handle* h) {
         const View* in_act = (i == 0) ? nullptr : &B.in;                 // ReLU mask of the block input (stage 0: applied in the maxpool pullback)
         const View& dz1 = B.dz1; View da1 = make_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C);
         // first encoder writer of Gin: own buffers (and the pool gradient) are overwritten; stage buffers already hold the decoder's contribution in the target frames
-        const int first_mode = (i == 0 || !h->blk[i - 1].stage_end) ? 0 : 2;
+        // (a stage whose skip connection the decoder does not reach -- scale_levels ending below 5 -- has no such contribution: plain overwrite)
+        const int first_mode = (i == 0 || !h->blk[i - 1].stage_end || !stage_used[stage_below[i]]) ? 0 : 2;
         // the launch that completes Gin also reduces the BatchNorm-pullback sums of the block below (bn2 / bn3 and, for a down-sampling block, the shortcut's BatchNorm)
         Block* Bp = (i > 0 && h->blk[i - 1].fuse) ? &h->blk[i - 1] : nullptr;
         if (B.fuse) {
@@ -688,8 +697,9 @@ static int model_backward(md2_handle* h) {
         // no reduction pass, no dz tensor (Gfeat[0]: decoder skip gradient in the target frames only; ReLU mask from the pooled output)
         const BNL& b = h->stem_bn;
         const bool fuse = !g_deterministic && !getenv("MD2_NO_BN_FUSE");
-        if (fuse) launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, &h->z0, b.stats, b.acc_b, h->tgt);
-        else { launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, nullptr, nullptr, nullptr, h->tgt); launch_bn_bwd_reduce(h->Gfeat[0], nullptr, ACT_NONE, h->z0, b.stats, b.acc_b, s); }
+        const int acc_frame = stage_used[0] ? h->tgt : -1;           // no decoder skip gradient in Gfeat[0] when the fifth branch is absent
+        if (fuse) launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, &h->z0, b.stats, b.acc_b, acc_frame);
+        else { launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, nullptr, nullptr, nullptr, acc_frame); launch_bn_bwd_reduce(h->Gfeat[0], nullptr, ACT_NONE, h->z0, b.stats, b.acc_b, s); }
         launch_bn_bwd_finalize(b.acc_b, BN_STAT_SLOTS, b.c, (double)h->z0.pixels(), b.stats + 4 * b.c, h->G + b.g, h->G + b.b, b.stats, h->P + b.g, s);
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
         hipStream_t st = wgrad_stream(h);
@@ -795,6 +805,17 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
         const int t = cfg->target_id ? cfg->target_id : 2, s0 = cfg->source_ids[0] ? cfg->source_ids[0] : (cfg->source_ids[1] ? 0 : 1), s1 = cfg->source_ids[1] ? cfg->source_ids[1] : (cfg->source_ids[0] ? 0 : 3);
         if (t < 1 || t > 3 || s0 < 1 || s0 > 3 || s1 < 1 || s1 > 3 || s0 == s1 || s0 == t || s1 == t) { g_create_err = "md2_create: target_id / source_ids must be three distinct frames of the triplet (1..3), two of them sources"; delete h; return 2; }
         h->tgt = t - 1; h->src[0] = s0 - 1; h->src[1] = s1 - 1;
+        // DepthDecoder scale_levels / TrainCache.scales (all zero: 2:5 and 1 / 2^(5 - level), src/Monodepth.jl:106-107)
+        if (cfg->scale_levels[0]) {
+            h->ns = 0; for (int b = 0; b < 5; ++b) h->out_of[b] = -1;
+            for (int i = 0; i < 5 && cfg->scale_levels[i]; ++i) {
+                const int l = cfg->scale_levels[i];
+                if (l < 1 || l > 5 || (i && l <= h->lv[i - 1])) { g_create_err = "md2_create: `scale_levels` should be at most of length 5, ascending, with values in [1, 5]"; delete h; return 2; }
+                h->lv[i] = l; h->out_of[l - 1] = i; h->ns = i + 1;
+            }
+            h->nbr = h->lv[h->ns - 1];
+        }
+        for (int i = 0; i < h->ns; ++i) h->scl[i] = cfg->scales[i] != 0.0 ? cfg->scales[i] : 1.0 / (double)(1 << (5 - h->lv[i]));
         for (int k = 0; k < 2; ++k) { const bool before = h->src[k] < h->tgt; h->pose_fr[2 * k] = before ? h->src[k] : h->tgt; h->pose_fr[2 * k + 1] = before ? h->tgt : h->src[k]; }
     }
     for (int i = 0; i < 64; ++i) h->ev_pool[i] = nullptr;
@@ -904,25 +925,25 @@ int32_t md2_grads_get(md2_handle* h, float* host, int64_t n) { return get_flat(h
 int32_t md2_grad_buffer(md2_handle* h, void** p, int64_t* count) { *p = h->G; *count = h->n_int; return 0; }
 int32_t md2_param_buffer(md2_handle* h, void** p, int64_t* count) { *p = h->P; *count = h->n_int; return 0; }
 
-static int copy_outputs(md2_handle* h, float* d0, float* d1, float* d2, float* d3, float* rvec, float* tvec) {
-    float* ds[4] = {d0, d1, d2, d3};
-    for (int i = 0; i < 4; ++i)
+static int copy_outputs(md2_handle* h, float* d0, float* d1, float* d2, float* d3, float* d4, float* rvec, float* tvec) {
+    float* ds[MD2_MAX_SCALES] = {d0, d1, d2, d3, d4};
+    for (int i = 0; i < h->ns; ++i)
         if (ds[i]) HIPCHK(hipMemcpyAsync(ds[i], h->dispv[i].p, (size_t)h->N * h->dispv[i].H * h->dispv[i].W * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (rvec) HIPCHK(hipMemcpyAsync(rvec, h->rvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (tvec) HIPCHK(hipMemcpyAsync(tvec, h->tvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
-int32_t md2_model_forward(md2_handle* h, const float* x, float* d0, float* d1, float* d2, float* d3, float* rvec, float* tvec) {
+int32_t md2_model_forward(md2_handle* h, const float* x, float* d0, float* d1, float* d2, float* d3, float* d4, float* rvec, float* tvec) {
     if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
     h->have_fwd = false;                    // overwrites the activations a pending md2_backward would need
     if (int r = model_forward(h, x)) return r;
-    return copy_outputs(h, d0, d1, d2, d3, rvec, tvec);
+    return copy_outputs(h, d0, d1, d2, d3, d4, rvec, tvec);
 }
 int32_t md2_eval_poses(md2_handle* h, const float* x, float* rvec, float* tvec) {
     if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
     h->have_fwd = false;
     if (int r = model_forward(h, x, 3, -1, true, false)) return r;          // encoder + pose decoder; the depth decoder is skipped
-    return copy_outputs(h, nullptr, nullptr, nullptr, nullptr, rvec, tvec);
+    return copy_outputs(h, nullptr, nullptr, nullptr, nullptr, nullptr, rvec, tvec);
 }
 int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, float* loss) {
     if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
@@ -936,7 +957,7 @@ int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, fl
         (void)hipEventRecord(h->ev_p1, h->s2); h->prep_done = true;
     }
     if (int r = model_forward(h, x, 3, -1, true, true, h->prep_done)) return r;
-    const float* disp[4] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p};
+    const float* disp[MD2_MAX_SCALES] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p, h->dispv[4].p};
     if (int r = loss_train(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;          // the loss pullback comes out of the same pass: md2_backward starts at the network
     h->x_last = x; h->auto_last = auto_loss; h->have_fwd = true;
     return 0;
@@ -963,14 +984,15 @@ int32_t md2_automasking_loss(md2_handle* h, const float* x, float* out) {
     launch_automask(x, out, h->N, h->C, h->H, h->W, h->src[0], h->src[1], h->tgt, h->stream);
     KCHK(); return 0;
 }
-int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const float* d1, const float* d2, const float* d3, const float* rvec, const float* tvec,
-                         const float* auto_loss, float* loss, float* dd0, float* dd1, float* dd2, float* dd3, float* drvec, float* dtvec) {
-    const float* disp[4] = {d0, d1, d2, d3};
+int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const float* d1, const float* d2, const float* d3, const float* d4, const float* rvec, const float* tvec,
+                         const float* auto_loss, float* loss, float* dd0, float* dd1, float* dd2, float* dd3, float* dd4, float* drvec, float* dtvec) {
+    const float* disp[MD2_MAX_SCALES] = {d0, d1, d2, d3, d4};
+    for (int i = 0; i < h->ns; ++i) if (!disp[i]) { h->err = "md2_loss_fwd_bwd: a disparity of a configured scale level is NULL"; return 2; }
     h->have_fwd = false;                    // overwrites Rt / totals of a pending md2_train_loss
-    if (!(dd0 || dd1 || dd2 || dd3 || drvec || dtvec)) return loss_forward(h, x, disp, rvec, tvec, auto_loss, loss);
+    if (!(dd0 || dd1 || dd2 || dd3 || dd4 || drvec || dtvec)) return loss_forward(h, x, disp, rvec, tvec, auto_loss, loss);
     if (int r = loss_train(h, x, disp, rvec, tvec, auto_loss, loss)) return r;
-    float* dds[4] = {dd0, dd1, dd2, dd3};
-    for (int i = 0; i < 4; ++i)
+    float* dds[MD2_MAX_SCALES] = {dd0, dd1, dd2, dd3, dd4};
+    for (int i = 0; i < h->ns; ++i)
         if (dds[i]) HIPCHK(hipMemcpyAsync(dds[i], h->ddisp_lo[i], (size_t)h->N * h->dispv[i].H * h->dispv[i].W * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (drvec) HIPCHK(hipMemcpyAsync(drvec, h->drvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     if (dtvec) HIPCHK(hipMemcpyAsync(dtvec, h->dtvec, 6 * h->N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
@@ -978,7 +1000,7 @@ int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* d0, const f
 }
 
 int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, const float* rvec, const float* tvec, float* loss, float* ddisp, float* drvec, float* dtvec) {
-    const float* d4[4] = {disp, disp, disp, disp};
+    const float* d4[MD2_MAX_SCALES] = {disp, disp, disp, disp, disp};
     h->have_fwd = false;
     if (!(ddisp || drvec || dtvec)) return loss_forward(h, x, d4, rvec, tvec, nullptr, loss, true);
     if (int r = loss_train(h, x, d4, rvec, tvec, nullptr, loss, true)) return r;
@@ -991,14 +1013,14 @@ int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, 
 // eval_disparity(m, x), src/model.jl:28: encoder + depth decoder on n single frames x [n][C][H][W], n <= batch.
 // BatchNorm follows the handle's mode like Flux's: batch statistics under trainmode! (the default, src/Monodepth.jl:126), the tracked running
 // statistics after md2_set_testmode(h, 1) -- what the reference's eval_image / eval_video do (testmode!, src/Monodepth.jl:209,237).
-int32_t md2_eval_disparity(md2_handle* h, const float* x, int32_t n, float* d0, float* d1, float* d2, float* d3) {
+int32_t md2_eval_disparity(md2_handle* h, const float* x, int32_t n, float* d0, float* d1, float* d2, float* d3, float* d4) {
     if (n < 1 || n > h->N) { h->err = "md2_eval_disparity: need 1 <= n <= batch"; return 2; }
     if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
     set_batch(h, n, n);
     int r = model_forward(h, x, 1, 0, false);
     if (!r) {
-        float* ds[4] = {d0, d1, d2, d3};
-        for (int i = 0; i < 4 && !r; ++i)
+        float* ds[MD2_MAX_SCALES] = {d0, d1, d2, d3, d4};
+        for (int i = 0; i < h->ns && !r; ++i)
             if (ds[i] && hipMemcpyAsync(ds[i], h->dispv[i].p, (size_t)n * h->dispv[i].H * h->dispv[i].W * sizeof(float), hipMemcpyDeviceToDevice, h->stream) != hipSuccess) { h->err = "md2_eval_disparity: copy failed"; r = 1; }
     }
     set_batch(h, h->NL, h->N);
@@ -1286,7 +1308,7 @@ static int head_weights(const float* w_dev, float* w_int, int Cin, hipStream_t s
 }
 int32_t md2_head_conv_fwd(const float* x, const float* w, const float* b, float* y, int32_t N, int32_t Cin, int32_t H, int32_t W, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if ((Cin != 16 && Cin != 32 && Cin != 64 && Cin != 128) || H < 3 || W < 3) return 2;
+    if ((Cin != 16 && Cin != 32 && Cin != 64 && Cin != 128 && Cin != 256) || H < 3 || W < 3) return 2;
     float *xi = tmp_alloc((size_t)N * H * W * Cin, s), *wi = tmp_alloc((size_t)9 * Cin, s);
     if (!xi || !wi) return 3;
     View xv = make_view(xi, N, H, W, Cin); launch_nchw_to_view(x, xv, s);
@@ -1299,7 +1321,7 @@ int32_t md2_head_conv_fwd(const float* x, const float* w, const float* b, float*
 // dx is wanted with respect to the pre-activation (how the last decoder branch uses it)
 int32_t md2_head_conv_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t x_act, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if ((Cin != 16 && Cin != 32 && Cin != 64 && Cin != 128) || H < 3 || W < 3) return 2;
+    if ((Cin != 16 && Cin != 32 && Cin != 64 && Cin != 128 && Cin != 256) || H < 3 || W < 3) return 2;
     const size_t n = (size_t)N * H * W * Cin;
     float *xi = tmp_alloc(n, s), *oi = tmp_alloc(n, s), *wi = tmp_alloc((size_t)9 * Cin, s), *gi = tmp_alloc((size_t)9 * Cin, s), *gb = tmp_alloc(4, s);
     if (!xi || !oi || !wi || !gi || !gb) return 3;

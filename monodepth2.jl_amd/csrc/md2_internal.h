@@ -199,16 +199,17 @@ void launch_fill_view(const View& v, float val, hipStream_t s);
 void launch_bias_act_view(const View& y, const float* bias, int act, hipStream_t s);
 
 // ---- loss kernels (loss.hip) --------------------------------------------------------------------
+#define MD2_MAX_SCALES 5     // DepthDecoder scale_levels has at most 5 entries (src/depth_decoder.jl:27-29)
 struct LossArgs {
     const float* x;            // [N][3][C][H][W]
-    const float* disp[4];      // [N][h_i][w_i]
-    int dh[4], dw[4];
+    const float* disp[MD2_MAX_SCALES];      // [N][h_i][w_i]
+    int dh[MD2_MAX_SCALES], dw[MD2_MAX_SCALES];
     const float* Rt;           // [2][N][12] : R (col-major 9) + t (3), after composeT
     const float* auto_loss;    // [N][H][W] or null
     float K[9], invK[9];       // column-major
     int N, C, H, W, nscales;
     float min_disp, max_disp;  // 1/max_depth, 1/min_depth
-    float smooth_w[4];         // disparity_smoothness * scale_i
+    float smooth_w[MD2_MAX_SCALES];         // disparity_smoothness * scale_i
     int tgt, src0, src1;       // 0-based frame indices
     int normalize;             // 1: smooth_loss(d / (mean(d)+1e-7)) (train_loss, src/training.jl:64-67); 0: smooth_loss(d) (slow_depth, src/simple_depth.jl:39)
 };
@@ -222,7 +223,7 @@ void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, 
 // full-resolution disparity of scale sc, or -- where dlo[sc] is not null -- dlo[sc] = [N][dh][dw] (zeroed by the caller) receives the adjoint of the bilinear resize
 // of that gradient instead (float atomics); blk as above (needs >= max(N*tiles32*12, nscales*N*blocks*25) doubles)
 void launch_loss_smooth_sums(const LossArgs& a, double* part, double* blk, hipStream_t s);      // first: part slots 1..3 (sum d, Sx, Sy per scale and sample)
-void launch_loss_train(const LossArgs& a, double* part, float* const dd[4], float* const dlo[4], double* dRt_acc, double* blk, hipStream_t s);
+void launch_loss_train(const LossArgs& a, double* part, float* const dd[MD2_MAX_SCALES], float* const dlo[MD2_MAX_SCALES], double* dRt_acc, double* blk, hipStream_t s);
 void launch_automask(const float* x, float* out, int N, int C, int H, int W, int src0, int src1, int tgt, hipStream_t s);
 // planar bilinear (align-corners) upsample adjoint, gather form: [planes][Ho][Wo] -> [planes][H][W]
 void launch_upsample_planar_bwd(const float* dout, float* dx, int planes, int H, int W, int Ho, int Wo, hipStream_t s);

@@ -20,6 +20,8 @@ struct MD2Config
     min_depth::Float64; max_depth::Float64; disparity_smoothness::Float64; lr::Float64
     encoder_depth::Int32; precision::Int32       # ResidualNetwork(18 | 50); 0 = f32, 1 = bf16 MFMA operands
     target_id::Int32; source_id1::Int32; source_id2::Int32      # TrainCache.target_id / source_ids (1-based; 0 = the defaults 2 / (1, 3))
+    scale_levels::NTuple{5, Int32}                               # DepthDecoder(; scale_levels), ascending, 0-terminated (all 0 = 2:5, src/Monodepth.jl:106)
+    scales::NTuple{5, Float64}                                   # TrainCache.scales (0 = 1 / 2^(5 - level), src/Monodepth.jl:107)
 end
 
 include("md2_ccall.jl")        # raw wrappers: md2_create(...), md2_train_step(...), ... one per export
@@ -29,7 +31,10 @@ mutable struct Handle
     ptr::Ptr{Cvoid}
     channels::Int
     depth::Int
+    scale_levels::Vector{Int}
 end
+pad5(v, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), 5)
+disp5(d) = ntuple(i -> i <= length(d) ? dptr(d[i]) : C_NULL, 5)      # the C ABI takes one pointer per possible scale level
 
 function check(h, rc, what)
     rc == 0 && return
@@ -52,15 +57,17 @@ ones_like(::ROCArray{T}, shape) where T = AMDGPU.ones(T, shape)
 
 # ---- handle: Params (src/Monodepth.jl:32-42) + the shapes TrainCache is built for ------------------------------------------------------------
 function Handle(; batch, channels, width, height, automasking=false, device=0,
-                min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, lr=1e-4, encoder_depth=18, precision=0, target_id=2, source_ids=[1, 3])
+                min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, lr=1e-4, encoder_depth=18, precision=0, target_id=2, source_ids=[1, 3],
+                scale_levels=collect(2:5), scales=Float64[])
     cfg = Ref(MD2Config(batch, channels, height, width, automasking, device, min_depth, max_depth, disparity_smoothness, lr, encoder_depth, precision,
-                        target_id, source_ids[1], source_ids[2]))          # TrainCache.target_id / source_ids (src/Monodepth.jl:44-55), 1-based like the reference
+                        target_id, source_ids[1], source_ids[2],           # TrainCache.target_id / source_ids (src/Monodepth.jl:44-55), 1-based like the reference
+                        pad5(scale_levels, Int32), pad5(scales, Float64)))
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve out begin
         rc = md2_create(cfg, Base.unsafe_convert(Ptr{Ptr{Cvoid}}, out))
     end
     check(nothing, rc, "md2_create")
-    h = Handle(out[], channels, encoder_depth); finalizer(x -> md2_destroy(x.ptr), h); h
+    h = Handle(out[], channels, encoder_depth, collect(Int, scale_levels)); finalizer(x -> md2_destroy(x.ptr), h); h
 end
 set_stream!(h, stream::Ptr{Cvoid}) = check(h, md2_set_stream(h.ptr, stream), "set_stream")
 synchronize(h) = check(h, md2_synchronize(h.ptr), "synchronize")
@@ -89,13 +96,39 @@ load_opt_state!(h, m::Vector{Float32}, v::Vector{Float32}, b1, b2) = GC.@preserv
 
 # The trainable arrays of `Model(encoder, depth_decoder, pose_decoder)` (src/model.jl:1-6) in the library's flat order (param_table.jl).
 #  * depth_decoder.branches is a Vector of Vectors of BranchBlock (src/depth_decoder.jl:36-44): branches 1..5 in order, each c1.d.weight, c1.d.bias, c2.d.weight,
-#    c2.d.bias; then depth_decoder.decoders[l].d.(weight, bias) for levels 2..5; pose_decoder.squeezer, pose_decoder.pose[1..3] (src/pose_decoder.jl:13-21).
+#    c2.d.bias; then depth_decoder.decoders[l].d.(weight, bias) for the scale levels (2..5 by default); pose_decoder.squeezer, pose_decoder.pose[1..3] (src/pose_decoder.jl:13-21).
 #    This is exactly the order `Flux.params` walks these structs in.
 #  * encoder: ResNet.jl is not vendored with the reference, so its field names are not relied on: `Flux.params(m.encoder)` is walked in order and every array's
 #    size is checked against the table.  Flux's BatchNorm yields (β, γ) — `trainable(bn) = (β, γ)` — while the table holds (γ, β): the pair is swapped here.
 #    A ResNet.jl that orders its layers differently (e.g. the shortcut before conv1) fails the size check with the entry it stopped at; adapt the walk there.
-function ordered_params(m, channels::Int, depth::Int, params_of=x -> collect(Flux_params(x)))
-    tab = PARAM_TABLE[(channels, depth)]
+# The table for a DepthDecoder built with other scale_levels (src/depth_decoder.jl:38-46): branches 1..max level, one head per level (decoder_channels[level] => 1),
+# offsets recomputed.  param_table.jl holds the default 2:5.
+function param_table(channels::Int, depth::Int, scale_levels=2:5)
+    base = PARAM_TABLE[(channels, depth)]
+    collect(scale_levels) == collect(2:5) && return base
+    dec = (256, 128, 64, 32, 16)
+    rows = Tuple{String,Symbol,Tuple}[]
+    for (name, kind, shape, _) in base
+        startswith(name, "pose.") && continue
+        startswith(name, "dec.head") && continue
+        m = match(r"^dec\.branch(\d)", name)
+        m !== nothing && parse(Int, m.captures[1]) > maximum(scale_levels) && continue
+        push!(rows, (name, kind, shape))
+    end
+    for l in scale_levels
+        push!(rows, ("dec.head$l.W", :W, (3, 3, dec[l], 1))); push!(rows, ("dec.head$l.b", :b, (1,)))
+    end
+    for (name, kind, shape, _) in base
+        startswith(name, "pose.") && push!(rows, (name, kind, shape))
+    end
+    out = Tuple{String,Symbol,Tuple,Int}[]; off = 0
+    for (name, kind, shape) in rows
+        push!(out, (name, kind, shape, off)); off += prod(shape)
+    end
+    out
+end
+function ordered_params(m, channels::Int, depth::Int, params_of=x -> collect(Flux_params(x)); scale_levels=2:5)
+    tab = param_table(channels, depth, scale_levels)
     out = Vector{Any}(undef, length(tab))
     enc = params_of(m.encoder); ei = 1; i = 1
     while i <= length(tab) && startswith(tab[i][1], "enc.")
@@ -130,11 +163,11 @@ end
 Flux_params(x) = Main.Flux.params(x)          # resolved in the host module, which has Flux loaded (src/Monodepth.jl:13)
 
 # Flux.params(model) -> the flat host vector md2_params_set takes (src/Monodepth.jl:124)
-flatten_flux_params(m, channels, depth=18) = reduce(vcat, (vec(Float32.(Array(a))) for a in ordered_params(m, channels, depth)))
+flatten_flux_params(m, channels, depth=18; scale_levels=2:5) = reduce(vcat, (vec(Float32.(Array(a))) for a in ordered_params(m, channels, depth; scale_levels)))
 # the reverse, in place, for `model_host = cpu(model); @save ... model_host` (src/Monodepth.jl:191-194)
-function unflatten_flux_params!(m, θ::Vector{Float32}, channels, depth=18)
-    tab = PARAM_TABLE[(channels, depth)]
-    for (a, (_, _, shape, off)) in zip(ordered_params(m, channels, depth), tab)
+function unflatten_flux_params!(m, θ::Vector{Float32}, channels, depth=18; scale_levels=2:5)
+    tab = param_table(channels, depth, scale_levels)
+    for (a, (_, _, shape, off)) in zip(ordered_params(m, channels, depth; scale_levels), tab)
         copyto!(a, reshape(θ[off + 1:off + prod(shape)], shape))
     end
     m
@@ -153,9 +186,9 @@ end
 # (m::Model)(x, source_ids, target_id), src/model.jl:8-20.  x: ROCArray (W,H,C,3,N)
 function model_forward(h, x::ROCArray{Float32,5})
     W, H, C, L, N = size(x)
-    disps = [ROCArray{Float32}(undef, W >> s, H >> s, 1, N) for s in (3, 2, 1, 0)]
+    disps = [ROCArray{Float32}(undef, W >> (5 - l), H >> (5 - l), 1, N) for l in h.scale_levels]
     rvec = ROCArray{Float32}(undef, 3, N, 2); tvec = ROCArray{Float32}(undef, 3, N, 2)       # Julia (3,N,2) == C [2][N][3]
-    check(h, md2_model_forward(h.ptr, dptr(x), dptr(disps[1]), dptr(disps[2]), dptr(disps[3]), dptr(disps[4]), dptr(rvec), dptr(tvec)), "model_forward")
+    check(h, md2_model_forward(h.ptr, dptr(x), disp5(disps)..., dptr(rvec), dptr(tvec)), "model_forward")
     disps, rvec, tvec
 end
 # train_loss(model, x, auto_loss, cache, parameters, false)[1], src/training.jl:21-78 -> device scalar
@@ -185,14 +218,13 @@ end
 # eval_disparity(m, x), src/model.jl:28.  x: ROCArray (W,H,C,n) single frames, n <= batch
 function eval_disparity(h, x::ROCArray{Float32,4})
     W, H, C, n = size(x)
-    disps = [ROCArray{Float32}(undef, W >> s, H >> s, 1, n) for s in (3, 2, 1, 0)]
-    check(h, md2_eval_disparity(h.ptr, dptr(x), Int32(n), dptr(disps[1]), dptr(disps[2]), dptr(disps[3]), dptr(disps[4])), "eval_disparity"); disps
+    disps = [ROCArray{Float32}(undef, W >> (5 - l), H >> (5 - l), 1, n) for l in h.scale_levels]
+    check(h, md2_eval_disparity(h.ptr, dptr(x), Int32(n), disp5(disps)...), "eval_disparity"); disps
 end
 # the loss half on given disparities / poses and its pullbacks (src/training.jl:28-77)
 function loss_fwd_bwd(h, x, disps, rvec, tvec, auto_loss=nothing)
     loss = ROCArray{Float32}(undef, 1); dd = similar.(disps); dr = similar(rvec); dt = similar(tvec)
-    check(h, md2_loss_fwd_bwd(h.ptr, dptr(x), dptr(disps[1]), dptr(disps[2]), dptr(disps[3]), dptr(disps[4]), dptr(rvec), dptr(tvec), dptr(auto_loss), dptr(loss),
-                              dptr(dd[1]), dptr(dd[2]), dptr(dd[3]), dptr(dd[4]), dptr(dr), dptr(dt)), "loss_fwd_bwd")
+    check(h, md2_loss_fwd_bwd(h.ptr, dptr(x), disp5(disps)..., dptr(rvec), dptr(tvec), dptr(auto_loss), dptr(loss), disp5(dd)..., dptr(dr), dptr(dt)), "loss_fwd_bwd")
     loss, dd, dr, dt
 end
 # slow_depth's objective + pullbacks (src/simple_depth.jl:25-42): disp (1,W,H,N) == [N][1][H][W]

@@ -263,8 +263,10 @@ class DepthDecoder:
         scale_levels = list(scale_levels)
         if len(scale_levels) > 5 or min(scale_levels) < 1 or max(scale_levels) > 5:
             raise ValueError("`scale_levels` should be at most of length 5 and have values in [1, 5] range.")   # src/depth_decoder.jl:27-29
-        if tuple(encoder_channels) not in (synthetic.stages(18), synthetic.stages(50)) or scale_levels != [2, 3, 4, 5]:
-            raise NotImplementedError("hot path implements the ResNet-18 / ResNet-50 stage channels and scale_levels=2:5 (src/Monodepth.jl:106,118)")
+        if any(b <= a for a, b in zip(scale_levels, scale_levels[1:])):
+            raise ValueError("`scale_levels` must be ascending: branch i of the reference's constructor starts where level i-1 ended (src/depth_decoder.jl:38-46)")
+        if tuple(encoder_channels) not in (synthetic.stages(18), synthetic.stages(50)):
+            raise NotImplementedError("hot path implements the ResNet-18 / ResNet-50 stage channels (src/Monodepth.jl:117-118)")
         self.encoder_channels, self.scale_levels = list(encoder_channels), scale_levels
 
 
@@ -290,7 +292,7 @@ class Model:
         self.lr, self.precision = lr, precision
         self._shape = None
         self._params_host = None
-        self._cfg_extra = dict(min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, automasking=False, target_id=2, source_ids=(1, 3))
+        self._cfg_extra = dict(min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, automasking=False, target_id=2, source_ids=(1, 3), scales=None)
         self._K = None
         self._testmode = False
         self._comm_spec = None
@@ -316,8 +318,11 @@ class Model:
         if parameters is not None:
             extra.update(min_depth=parameters.min_depth, max_depth=parameters.max_depth,
                          disparity_smoothness=parameters.disparity_smoothness, automasking=bool(parameters.automasking))
-        if cache is not None:                      # TrainCache.target_id / source_ids (src/Monodepth.jl:44-55)
+        if cache is not None:                      # TrainCache.target_id / source_ids / scales (src/Monodepth.jl:44-55)
             frames = (cache.source_ids, cache.target_id)
+            if len(cache.scales) != len(self.depth_decoder.scale_levels):
+                raise ValueError("TrainCache.scales needs one entry per DepthDecoder scale level (zip(disparities, cache.scales), src/training.jl:42)")
+            extra.update(scales=tuple(float(v) for v in cache.scales))
         if frames is not None:
             sids, tid = [int(v) for v in frames[0]], int(frames[1])
             if len(sids) != 2 or sorted(sids + [tid]) != [1, 2, 3]:
@@ -336,7 +341,8 @@ class Model:
         state = self._opt_and_bn_state() if self._h is not None else None
         self.close()
         cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr,
-                             self.encoder.depth, 1 if self.precision == "bf16" else 0, int(extra["target_id"]), (C.c_int32 * 2)(*extra["source_ids"]))
+                             self.encoder.depth, 1 if self.precision == "bf16" else 0, int(extra["target_id"]), (C.c_int32 * 2)(*extra["source_ids"]),
+                             (C.c_int32 * 5)(*self.depth_decoder.scale_levels), (C.c_double * 5)(*(extra["scales"] or ())))
         h = C.c_void_p()
         _check(_lib.lib().md2_create(C.byref(cfg), C.byref(h)), None, "md2_create")
         self._h, self._shape, self._cfg_extra = h, key, extra
@@ -453,10 +459,15 @@ class Model:
         x = _f32(x); self._ensure(x, frames=(source_ids, target_id))
         N, _, _, H, W = x.shape
         L = _lib.lib(); L.md2_set_stream(self._h, _stream())
-        ds = [torch.empty(N, 1, H >> s, W >> s, device=x.device) for s in (3, 2, 1, 0)]
+        ds = [torch.empty(N, 1, H >> (5 - l), W >> (5 - l), device=x.device) for l in self.depth_decoder.scale_levels]
         rvec = torch.empty(2, N, 3, device=x.device); tvec = torch.empty(2, N, 3, device=x.device)
-        _check(L.md2_model_forward(self._h, _dev(x), _dev(ds[0]), _dev(ds[1]), _dev(ds[2]), _dev(ds[3]), _dev(rvec), _dev(tvec)), self._h, "model_forward")
+        _check(L.md2_model_forward(self._h, _dev(x), *_pad5(ds), _dev(rvec), _dev(tvec)), self._h, "model_forward")
         return ds, [Pose(rvec[0], tvec[0]), Pose(rvec[1], tvec[1])]
+
+
+def _pad5(tensors):
+    """The C ABI takes one pointer per possible scale level (five); the ones past the configured levels are NULL."""
+    return [_dev(t) if t is not None else None for t in tensors] + [None] * (5 - len(tensors))
 
 
 def eval_poses(m: Model, x, source_ids=(1, 3), target_id=2):
@@ -471,13 +482,13 @@ def eval_poses(m: Model, x, source_ids=(1, 3), target_id=2):
 
 def eval_disparity(m: Model, x):
     """eval_disparity(m, x) = m.depth_decoder(m.encoder(x, Val(:stages))), src/model.jl:28.  x (n,C,H,W) single frames; the model's
-    handle must exist (n <= its batch) or is created for batch n.  Returns the 4 disparities, coarse -> fine."""
+    handle must exist (n <= its batch) or is created for batch n.  Returns the disparities of the decoder's scale levels, coarse -> fine."""
     x = _f32(x); n, Cc, H, W = x.shape
     if m._h is None or m._shape[1:4] != (Cc, H, W) or m._shape[0] < n:
         m._ensure(x.new_zeros((n, 3, Cc, H, W)))
     L = _lib.lib(); L.md2_set_stream(m._h, _stream())
-    ds = [torch.empty(n, 1, H >> s, W >> s, device=x.device) for s in (3, 2, 1, 0)]
-    _check(L.md2_eval_disparity(m._h, _dev(x), n, _dev(ds[0]), _dev(ds[1]), _dev(ds[2]), _dev(ds[3])), m._h, "eval_disparity")
+    ds = [torch.empty(n, 1, H >> (5 - l), W >> (5 - l), device=x.device) for l in m.depth_decoder.scale_levels]
+    _check(L.md2_eval_disparity(m._h, _dev(x), n, *_pad5(ds)), m._h, "eval_disparity")
     return ds
 
 
@@ -557,12 +568,13 @@ def train_loss(model: Model, x, auto_loss, cache: TrainCache, parameters: Params
         bn = model.bn_state()                                         # this extra train-mode forward must not track the BatchNorm statistics a second time with the same batch
         ds, poses = model(x, cache.source_ids, cache.target_id)       # BEFORE the training forward: it reuses the activation buffers
         model.load_bn_state(bn)
-        vis_disparity = ds[-1].cpu()
+        dlast = ds[-1] if tuple(ds[-1].shape[-2:]) == tuple(x.shape[-2:]) else upsample_bilinear(ds[-1], (x.shape[-1], x.shape[-2]))     # src/training.jl:45
+        vis_disparity = dlast.cpu()
         target_x = x[:, cache.target_id - 1].contiguous()
         warped = []
         for pose, sid in zip(poses, cache.source_ids):
             R, t = composeT(pose.rvec, pose.tvec, sid < cache.target_id)
-            warped.append(warp(ds[-1], x[:, sid - 1].contiguous(), cache.K, cache.invK, R, t, parameters.min_depth, parameters.max_depth))
+            warped.append(warp(dlast, x[:, sid - 1].contiguous(), cache.K, cache.invK, R, t, parameters.min_depth, parameters.max_depth))
         wl = prediction_loss(cache.ssim, warped, target_x)
         if parameters.automasking and auto_loss is not None:
             wl = _apply_mask(_f32(auto_loss), wl)
@@ -611,11 +623,10 @@ def loss_fwd_bwd(model: Model, x, disps, rvec, tvec, auto_loss=None, want_grads=
     x = _f32(x); L = _lib.lib(); L.md2_set_stream(model._h, _stream())
     ds = [_f32(d) for d in disps]; rvec, tvec = _f32(rvec), _f32(tvec)
     loss = torch.empty((), device=x.device)
-    dds = [torch.empty_like(d) for d in ds] if want_grads else [None] * 4
+    dds = [torch.empty_like(d) for d in ds] if want_grads else [None] * len(ds)
     drv = torch.empty_like(rvec) if want_grads else None; dtv = torch.empty_like(tvec) if want_grads else None
     al = _f32(auto_loss) if auto_loss is not None else None
-    _check(L.md2_loss_fwd_bwd(model._h, _dev(x), _dev(ds[0]), _dev(ds[1]), _dev(ds[2]), _dev(ds[3]), _dev(rvec), _dev(tvec), _dev(al), _dev(loss),
-                              _dev(dds[0]), _dev(dds[1]), _dev(dds[2]), _dev(dds[3]), _dev(drv), _dev(dtv)), model._h, "loss_fwd_bwd")
+    _check(L.md2_loss_fwd_bwd(model._h, _dev(x), *_pad5(ds), _dev(rvec), _dev(tvec), _dev(al), _dev(loss), *_pad5(dds), _dev(drv), _dev(dtv)), model._h, "loss_fwd_bwd")
     return loss, dds, drv, dtv
 
 

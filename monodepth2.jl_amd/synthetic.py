@@ -22,7 +22,7 @@ def decoder_channels(depth=18):
     return [st[4]] + DEC_CH[:4], list(DEC_CH), [st[3], st[2], st[1], st[0], 0]
 
 
-def param_layout(C=1, depth=18):
+def param_layout(C=1, depth=18, scale_levels=(2, 3, 4, 5)):
     """Flat parameter order shared by the oracle and the HIP library (documented in DESIGN.md).
     Returns a list of (name, kind, shape) with kind in {"W","b","gamma","beta"}; conv weights are in
     Flux layout (kW,kH,Cin,Cout) column-major == numpy (Cout,Cin,KH,KW)."""
@@ -57,26 +57,26 @@ def param_layout(C=1, depth=18):
                 conv(p + ".down", cin, co, 1, False); bn(p + ".down.bn", co)
             cin = co
     inc, dec, skc = decoder_channels(depth)
-    for b in range(5):
+    for b in range(max(scale_levels)):             # DepthDecoder builds branches 1..max(scale_levels) and one head per listed level (src/depth_decoder.jl:38-46)
         conv("dec.branch%d.c1" % (b + 1), inc[b], dec[b], 3, True)
         conv("dec.branch%d.c2" % (b + 1), dec[b] + skc[b], dec[b], 3, True)
-    for l in range(4):
-        conv("dec.head%d" % (l + 2), dec[l + 1], 1, 3, True)
+    for l in scale_levels:
+        conv("dec.head%d" % l, dec[l - 1], 1, 3, True)
     top = stages(depth)[4]
     conv("pose.squeezer", top, 256, 1, True); conv("pose.pose1", 512, 256, 3, True); conv("pose.pose2", 256, 256, 3, True); conv("pose.pose3", 256, 6, 1, True)
     return out
 
 
-def num_params(C=1, depth=18):
-    return int(sum(int(np.prod(s)) for _, _, s in param_layout(C, depth)))
+def num_params(C=1, depth=18, scale_levels=(2, 3, 4, 5)):
+    return int(sum(int(np.prod(s)) for _, _, s in param_layout(C, depth, scale_levels)))
 
 
-def init_params(C=1, seed=42, randomize_affine=False, depth=18):
+def init_params(C=1, seed=42, randomize_affine=False, depth=18, scale_levels=(2, 3, 4, 5)):
     """Flux defaults: conv W Glorot-uniform, bias 0, BN gamma 1 / beta 0.  With
     randomize_affine the biases/gamma/beta are perturbed so tests exercise those gradients."""
     rng = np.random.default_rng(seed)
     parts = []
-    for name, kind, shape in param_layout(C, depth):
+    for name, kind, shape in param_layout(C, depth, scale_levels):
         if kind == "W":
             cout, cin, kh, kw = shape
             lim = np.sqrt(24.0 / (kh * kw * cin + kh * kw * cout))

@@ -97,17 +97,22 @@ struct o_cfg {
     double min_depth, max_depth, smoothness;
     float K[9], invK[9];
     int target_id, source_ids[2];          // TrainCache.target_id / source_ids (1-based, src/Monodepth.jl:44-55); 0 = the defaults 2 / {1, 3}
+    int scale_levels[5]; double scales[5]; // DepthDecoder scale_levels (0-terminated; all 0 = 2:5) and TrainCache.scales (0 = 1 / 2^(5 - level))
 };
 static LossCfg to_cfg(const o_cfg* c) {
     LossCfg l; l.N = c->N; l.C = c->C; l.H = c->H; l.W = c->W; l.automasking = c->automasking; l.simple = c->simple; if (c->simple) l.nscales = 1;
     if (c->target_id) { l.target_id = c->target_id; l.source_ids[0] = c->source_ids[0]; l.source_ids[1] = c->source_ids[1]; }
+    if (c->scale_levels[0] && !c->simple) { l.nscales = 0; for (int i = 0; i < 5 && c->scale_levels[i]; ++i) { l.levels[i] = c->scale_levels[i]; l.nscales = i + 1; } }
+    if (!c->simple) for (int i = 0; i < l.nscales; ++i) l.scales[i] = c->scales[i] != 0.0 ? c->scales[i] : 1.0 / (double)(1 << (5 - l.levels[i]));
     l.min_depth = c->min_depth; l.max_depth = c->max_depth; l.smoothness = c->smoothness;
     std::memcpy(l.K, c->K, sizeof(l.K)); std::memcpy(l.invK, c->invK, sizeof(l.invK)); return l;
 }
-struct o_net { Net net; StepOut out; explicit o_net(int C, int depth = 18) : net(C, depth) {} };
+struct o_net { Net net; StepOut out; explicit o_net(int C, int depth = 18, const int* levels = nullptr) : net(C, depth, levels) {} };
 
 O_API o_net* o_net_create(int C) { return new o_net(C); }
 O_API o_net* o_net_create_depth(int C, int depth) { return (depth == 18 || depth == 50) ? new o_net(C, depth) : nullptr; }
+// DepthDecoder(; scale_levels): ascending levels in 1..5, 0-terminated
+O_API o_net* o_net_create_levels(int C, int depth, const int* levels) { return (depth == 18 || depth == 50) ? new o_net(C, depth, levels) : nullptr; }
 O_API void o_net_destroy(o_net* h) { delete h; }
 O_API long o_net_nparams(o_net* h) { return (long)h->net.np; }
 O_API void o_net_params_set(o_net* h, const float* p) { std::memcpy(h->net.th.data(), p, sizeof(float) * h->net.np); }
@@ -121,8 +126,8 @@ O_API int o_net_layout(o_net* h, long* offs, long* counts, int* kinds, int cap) 
     auto bn = [&](const BNP& b) { if (n < cap) { offs[n] = (long)b.g; counts[n] = b.c; kinds[n] = 2; } ++n; if (n < cap) { offs[n] = (long)b.b; counts[n] = b.c; kinds[n] = 3; } ++n; };
     conv(N.stem); bn(N.stem_bn);
     for (int i = 0; i < N.nblk; ++i) { conv(N.blk[i].c1); bn(N.blk[i].b1); conv(N.blk[i].c2); bn(N.blk[i].b2); if (N.blk[i].bottleneck) { conv(N.blk[i].c3); bn(N.blk[i].b3); } if (N.blk[i].down) { conv(N.blk[i].cd); bn(N.blk[i].bd); } }
-    for (int b = 0; b < 5; ++b) { conv(N.dc1[b]); conv(N.dc2[b]); }
-    for (int l = 0; l < 4; ++l) conv(N.head[l]);
+    for (int b = 0; b < N.nbr; ++b) { conv(N.dc1[b]); conv(N.dc2[b]); }
+    for (int l = 0; l < N.ns; ++l) conv(N.head[l]);
     conv(N.squeeze); for (int i = 0; i < 3; ++i) conv(N.pose[i]);
     return n;
 }
@@ -132,16 +137,16 @@ O_API int o_net_convs(o_net* h, int* desc, int cap) {
     auto conv = [&](const ConvP& c) { if (n < cap) { desc[n * 6 + 0] = c.cin; desc[n * 6 + 1] = c.cout; desc[n * 6 + 2] = c.k; desc[n * 6 + 3] = c.s; desc[n * 6 + 4] = c.p; desc[n * 6 + 5] = c.has_b; } ++n; };
     conv(N.stem);
     for (int i = 0; i < N.nblk; ++i) { conv(N.blk[i].c1); conv(N.blk[i].c2); if (N.blk[i].bottleneck) conv(N.blk[i].c3); if (N.blk[i].down) conv(N.blk[i].cd); }
-    for (int b = 0; b < 5; ++b) { conv(N.dc1[b]); conv(N.dc2[b]); }
-    for (int l = 0; l < 4; ++l) conv(N.head[l]);
+    for (int b = 0; b < N.nbr; ++b) { conv(N.dc1[b]); conv(N.dc2[b]); }
+    for (int l = 0; l < N.ns; ++l) conv(N.head[l]);
     conv(N.squeeze); for (int i = 0; i < 3; ++i) conv(N.pose[i]);
     return n;
 }
 // Model forward: disparities (4 buffers [N][1][h][w] coarse->fine), rvec/tvec [2][N][3]
-O_API void o_net_model_forward(o_net* h, const float* x, const o_cfg* cfg, float* d0, float* d1, float* d2, float* d3, float* rvec, float* tvec) {
+O_API void o_net_model_forward(o_net* h, const float* x, const o_cfg* cfg, float* d0, float* d1, float* d2, float* d3, float* d4, float* rvec, float* tvec) {
     LossCfg c = to_cfg(cfg); model_loss(h->net, x, c, nullptr, false, h->out, true);
-    float* ds[4] = {d0, d1, d2, d3};
-    for (int i = 0; i < 4; ++i) if (ds[i]) std::memcpy(ds[i], h->out.disp[i].p(), sizeof(float) * h->out.disp[i].size());
+    float* ds[5] = {d0, d1, d2, d3, d4};
+    for (int i = 0; i < h->net.ns; ++i) if (ds[i]) std::memcpy(ds[i], h->out.disp[i].p(), sizeof(float) * h->out.disp[i].size());
     for (int s = 0; s < 2; ++s) { if (rvec) std::memcpy(rvec + (size_t)s * c.N * 3, h->out.rvec[s].data(), sizeof(float) * c.N * 3); if (tvec) std::memcpy(tvec + (size_t)s * c.N * 3, h->out.tvec[s].data(), sizeof(float) * c.N * 3); }
 }
 // train_loss forward (+ pullback into the handle's gradient buffer when do_bwd)
@@ -154,10 +159,10 @@ O_API void o_net_set_testmode(o_net* h, int on) { h->net.testmode = on != 0; }
 O_API long o_net_bn_state_count(o_net* h) { return (long)h->net.nrs; }
 O_API void o_net_bn_state_get(o_net* h, float* p) { std::memcpy(p, h->net.rs.data(), sizeof(float) * h->net.nrs); }
 O_API void o_net_bn_state_set(o_net* h, const float* p) { std::memcpy(h->net.rs.data(), p, sizeof(float) * h->net.nrs); }
-O_API void o_net_eval_disparity(o_net* h, const float* x, int N, int C, int H, int W, float* d0, float* d1, float* d2, float* d3) {
-    Tensor disp[4]; eval_disparity(h->net, x, N, C, H, W, disp);
-    float* ds[4] = {d0, d1, d2, d3};
-    for (int i = 0; i < 4; ++i) if (ds[i]) std::memcpy(ds[i], disp[i].p(), sizeof(float) * disp[i].size());
+O_API void o_net_eval_disparity(o_net* h, const float* x, int N, int C, int H, int W, float* d0, float* d1, float* d2, float* d3, float* d4) {
+    Tensor disp[5]; eval_disparity(h->net, x, N, C, H, W, disp);
+    float* ds[5] = {d0, d1, d2, d3, d4};
+    for (int i = 0; i < h->net.ns; ++i) if (ds[i]) std::memcpy(ds[i], disp[i].p(), sizeof(float) * disp[i].size());
 }
 O_API void o_net_opt_state_get(o_net* h, float* m, float* v, double* b1p, double* b2p) {
     std::memcpy(m, h->net.m.data(), sizeof(float) * h->net.np); std::memcpy(v, h->net.v.data(), sizeof(float) * h->net.np); *b1p = h->net.beta1p; *b2p = h->net.beta2p;
@@ -165,18 +170,18 @@ O_API void o_net_opt_state_get(o_net* h, float* m, float* v, double* b1p, double
 O_API void o_automasking_loss(const float* x, const o_cfg* cfg, float* out) { LossCfg c = to_cfg(cfg); Tensor t = automasking_loss(x, c); std::memcpy(out, t.p(), sizeof(float) * t.size()); }
 
 // The loss half alone: disparities + poses in, loss (+ pullbacks) out.  Any output pointer may be null.
-O_API float o_loss_fwd_bwd(const float* x, const o_cfg* cfg, const float* d0, const float* d1, const float* d2, const float* d3,
+O_API float o_loss_fwd_bwd(const float* x, const o_cfg* cfg, const float* d0, const float* d1, const float* d2, const float* d3, const float* d4,
                            const float* rvec, const float* tvec, const float* auto_loss, int do_bwd,
-                           float* dd0, float* dd1, float* dd2, float* dd3, float* drvec, float* dtvec, float* warped_out, float* warp_loss_out) {
+                           float* dd0, float* dd1, float* dd2, float* dd3, float* dd4, float* drvec, float* dtvec, float* warped_out, float* warp_loss_out) {
     LossCfg c = to_cfg(cfg);
-    const float* ds[4] = {d0, d1, d2, d3}; Tensor disp[4], ddisp[4];
-    for (int i = 0; i < c.nscales; ++i) { const int sh = c.simple ? 0 : 3 - i; disp[i] = wrap(ds[i], c.N, 1, c.H >> sh, c.W >> sh); }
+    const float* ds[5] = {d0, d1, d2, d3, d4}; Tensor disp[5], ddisp[5];
+    for (int i = 0; i < c.nscales; ++i) { const int sh = c.simple ? 0 : 5 - c.levels[i]; disp[i] = wrap(ds[i], c.N, 1, c.H >> sh, c.W >> sh); }
     const float* rv[2] = {rvec, rvec + (size_t)c.N * 3}; const float* tv[2] = {tvec, tvec + (size_t)c.N * 3};
     Vec<float> drv((size_t)2 * c.N * 3, 0.f), dtv((size_t)2 * c.N * 3, 0.f);
     float* drp[2] = {drv.data(), drv.data() + (size_t)c.N * 3}; float* dtp[2] = {dtv.data(), dtv.data() + (size_t)c.N * 3};
     const float loss = loss_fwd_bwd(x, c, disp, rv, tv, auto_loss, do_bwd != 0, ddisp, drp, dtp, warped_out, warp_loss_out);
     if (do_bwd) {
-        float* dds[4] = {dd0, dd1, dd2, dd3};
+        float* dds[5] = {dd0, dd1, dd2, dd3, dd4};
         for (int i = 0; i < c.nscales; ++i) if (dds[i]) std::memcpy(dds[i], ddisp[i].p(), sizeof(float) * ddisp[i].size());
         if (drvec) std::memcpy(drvec, drv.data(), sizeof(float) * drv.size());
         if (dtvec) std::memcpy(dtvec, dtv.data(), sizeof(float) * dtv.size());

@@ -222,7 +222,7 @@ inline void t_frame_add(Tensor& df, const Tensor& dy, int L, int l) {
 // ------------------------------------------------------------------------------------------------
 // Parameter table.  Flat order (documented in DESIGN.md, mirrored by the HIP library):
 //   encoder: stem.W, stem.bn(g,b); layer{1..4}.block{0,1}: conv1.W, bn1(g,b), conv2.W, bn2(g,b)[, down.W, down.bn(g,b)]
-//   depth decoder (src/depth_decoder.jl:26-47): branches 1..5: c1.W, c1.b, c2.W, c2.b ; heads for levels 2..5: W, b
+//   depth decoder (src/depth_decoder.jl:26-47): branches 1..max(scale_levels): c1.W, c1.b, c2.W, c2.b ; one head per scale level (2..5 by default): W, b
 //   pose decoder (src/pose_decoder.jl:13-21): squeezer W,b ; pose[1] W,b ; pose[2] W,b ; pose[3] W,b
 // Conv weights in Flux layout (kW,kH,Cin,Cout) col-major.
 // ------------------------------------------------------------------------------------------------
@@ -241,12 +241,15 @@ struct Net {
     struct Block { ConvP c1, c2, c3, cd; BNP b1, b2, b3, bd; bool down; bool bottleneck; bool stage_end; };
     int depth = 18, nblk = 8;
     Block blk[16];
-    ConvP dc1[5], dc2[5], head[4], squeeze, pose[3];
+    ConvP dc1[5], dc2[5], head[5], squeeze, pose[3];
+    // DepthDecoder(; scale_levels): ns outputs at ascending levels lv[i] in 1..5; branches 1..nbr = lv[ns-1]; out_of[b] = output index of the head after branch b, or -1
+    int ns = 4, lv[5] = {2, 3, 4, 5, 0}, nbr = 5, out_of[5] = {-1, 0, 1, 2, 3};
     int dec_ch[5] = {256, 128, 64, 32, 16}, in_ch[5] = {512, 256, 128, 64, 32}, skip_ch[5] = {256, 128, 64, 64, 0};
 
     ConvP mk(int cin, int cout, int k, int s, int p, bool bias) { ConvP c{cin, cout, k, s, p, np, 0, bias}; np += (size_t)cin * cout * k * k; if (bias) { c.b = np; np += cout; } return c; }
     BNP mkbn(int c) { BNP b{c, np, np + (size_t)c, nrs}; np += 2 * (size_t)c; nrs += 2 * (size_t)c; return b; }
-    explicit Net(int C_, int depth_ = 18) : C(C_), depth(depth_) {
+    explicit Net(int C_, int depth_ = 18, const int* levels = nullptr) : C(C_), depth(depth_) {
+        if (levels && levels[0]) { ns = 0; for (int b = 0; b < 5; ++b) out_of[b] = -1; for (int i = 0; i < 5 && levels[i]; ++i) { lv[i] = levels[i]; out_of[levels[i] - 1] = i; ns = i + 1; } nbr = lv[ns - 1]; }
         stem = mk(C, 64, 7, 2, 3, false); stem_bn = mkbn(64);
         const int planes[4] = {64, 128, 256, 512}; int cin = 64;
         const int nb18[4] = {2, 2, 2, 2}, nb50[4] = {3, 4, 6, 3};
@@ -265,8 +268,8 @@ struct Net {
                 cin = co;
             }
         if (depth == 50) { const int st[5] = {64, 256, 512, 1024, 2048}; in_ch[0] = st[4]; skip_ch[0] = st[3]; skip_ch[1] = st[2]; skip_ch[2] = st[1]; skip_ch[3] = st[0]; }
-        for (int b = 0; b < 5; ++b) { dc1[b] = mk(in_ch[b], dec_ch[b], 3, 1, 0, true); dc2[b] = mk(dec_ch[b] + skip_ch[b], dec_ch[b], 3, 1, 0, true); }
-        for (int l = 0; l < 4; ++l) head[l] = mk(dec_ch[l + 1], 1, 3, 1, 0, true);
+        for (int b = 0; b < nbr; ++b) { dc1[b] = mk(in_ch[b], dec_ch[b], 3, 1, 0, true); dc2[b] = mk(dec_ch[b] + skip_ch[b], dec_ch[b], 3, 1, 0, true); }
+        for (int i = 0; i < ns; ++i) head[i] = mk(dec_ch[lv[i] - 1], 1, 3, 1, 0, true);
         squeeze = mk(cin, 256, 1, 1, 0, true); pose[0] = mk(512, 256, 3, 1, 1, true); pose[1] = mk(256, 256, 3, 1, 1, true); pose[2] = mk(256, 6, 1, 1, 0, true);
         th.assign(np, 0); g.assign(np, 0); m.assign(np, 0); v.assign(np, 0);
         rs.assign(nrs, 0);
@@ -285,7 +288,7 @@ struct ConvBN { Tensor x, z, a; BNSave sv; };                     // a = act(bn(
 struct BlockSave { ConvBN c1, c2, c3, cd; Tensor out; };
 struct EncSave { ConvBN stem; Tensor pooled; Vec<int32_t> arg; BlockSave blk[16]; Tensor feat[5]; };
 struct DecConv { Tensor xin, xpad, y; };                          // y = act(conv(pad_reflect(xin)))
-struct DepthSave { DecConv c1[5], c2[5], head[4]; Tensor up[5], cat[5]; };
+struct DepthSave { DecConv c1[5], c2[5], head[5]; Tensor up[5], cat[5]; };
 struct PoseSave { Tensor f[2], sq[2], cat, y1, y2, y3; int order[2]; };   // f: the (first,second) feature pair
 
 // Flux BatchNorm under testmode!: (x - mu) / sqrt(sigma^2 + eps) with the tracked statistics
@@ -363,23 +366,23 @@ inline Tensor decconv_bwd(Net& N, const ConvP& c, const DecConv& s, Tensor dy, i
     act_bwd(s.y, dy, act); Tensor dxp; conv2d_bwd(s.xpad, N.W(c), dy, &dxp, N.gW(c), N.gB(c), c.k, 1, 0);
     return t_pad_reflect_bwd(dxp, s.xin.h, s.xin.w);
 }
-// DepthDecoder forward, src/depth_decoder.jl:49-65 with scale_levels = 2:5.  feat: the 5 TARGET-frame features.
-inline void depth_fwd(const Net& N, const Tensor feat[5], DepthSave& S, Tensor disp[4]) {
+// DepthDecoder forward, src/depth_decoder.jl:49-65.  feat: the 5 TARGET-frame features; disp[i] = output of scale level lv[i].
+inline void depth_fwd(const Net& N, const Tensor feat[5], DepthSave& S, Tensor disp[5]) {
     Tensor x = feat[4];
-    for (int b = 0; b < 5; ++b) {
+    for (int b = 0; b < N.nbr; ++b) {
         decconv_fwd(N, N.dc1[b], x, S.c1[b], ACT_ELU);
         S.up[b] = t_up2(S.c1[b].y);
         S.cat[b] = (b < 4) ? t_cat(S.up[b], feat[3 - b]) : S.up[b];
         decconv_fwd(N, N.dc2[b], S.cat[b], S.c2[b], ACT_ELU);
         x = S.c2[b].y;
-        if (b >= 1) { decconv_fwd(N, N.head[b - 1], x, S.head[b - 1], ACT_SIGMOID); disp[b - 1] = S.head[b - 1].y; }
+        if (const int o = N.out_of[b]; o >= 0) { decconv_fwd(N, N.head[o], x, S.head[o], ACT_SIGMOID); disp[o] = S.head[o].y; }
     }
 }
-inline void depth_bwd(Net& N, DepthSave& S, const Tensor ddisp[4], Tensor dfeat[5]) {   // dfeat: target-frame feature grads (output)
+inline void depth_bwd(Net& N, DepthSave& S, const Tensor ddisp[5], Tensor dfeat[5]) {   // dfeat: target-frame feature grads (output; empty where the decoder does not read the stage)
     Tensor dx;   // gradient wrt the running x (output of branch b)
-    for (int b = 4; b >= 0; --b) {
+    for (int b = N.nbr - 1; b >= 0; --b) {
         Tensor dout;
-        if (b >= 1) dout = decconv_bwd(N, N.head[b - 1], S.head[b - 1], ddisp[b - 1], ACT_SIGMOID);
+        if (const int o = N.out_of[b]; o >= 0) dout = decconv_bwd(N, N.head[o], S.head[o], ddisp[o], ACT_SIGMOID);
         if (dx.size()) { if (dout.size()) for (size_t j = 0; j < dout.size(); ++j) dout.v[j] += dx.v[j]; else dout = dx; }
         Tensor dcat = decconv_bwd(N, N.dc2[b], S.c2[b], dout, ACT_ELU);
         Tensor dup;
@@ -427,7 +430,7 @@ inline void pose_bwd(Net& N, PoseSave& S, const float* drvec, const float* dtvec
 struct LossCfg {
     int N, C, H, W, L = 3, target_id = 2, nsrc = 2; int source_ids[2] = {1, 3};
     double min_depth = 0.1, max_depth = 100.0, smoothness = 1e-3; int automasking = 0;
-    double scales[4] = {0.125, 0.25, 0.5, 1.0}; int nscales = 4;
+    double scales[5] = {0.125, 0.25, 0.5, 1.0, 0.0}; int nscales = 4; int levels[5] = {2, 3, 4, 5, 0};      // TrainCache.scales; the DepthDecoder's scale levels (output i is H >> (5 - level))
     // mode 1 = slow_depth (src/simple_depth.jl:25-42): ONE full-resolution scale, smooth_loss on the raw disparity (no mean
     // normalisation) with weight 1
     int simple = 0;
@@ -445,8 +448,8 @@ inline Tensor automasking_loss(const float* x, const LossCfg& c) {
     for (int s = 0; s < c.nsrc; ++s) { Tensor src = x_frame(x, c, c.source_ids[s]); photometric_fwd_bwd<float>(src.p(), tgt.p(), stack.data() + s * NP, nullptr, nullptr, c.N, c.C, c.H, c.W); }
     Tensor out(c.N, 1, c.H, c.W); min_stack<float>(stack.data(), c.nsrc, NP, out.p(), nullptr); return out;
 }
-inline float loss_fwd_bwd(const float* x, const LossCfg& c, const Tensor disp[4], const float* const rvec[2], const float* const tvec[2],
-                          const float* auto_loss, bool do_bwd, Tensor ddisp[4], float* drvec[2], float* dtvec[2],
+inline float loss_fwd_bwd(const float* x, const LossCfg& c, const Tensor disp[5], const float* const rvec[2], const float* const tvec[2],
+                          const float* auto_loss, bool do_bwd, Tensor ddisp[5], float* drvec[2], float* dtvec[2],
                           float* warped_out /* optional [nscales][nsrc][N][C][H][W] */, float* warp_loss_out /* optional [nscales][N][H][W] */) {
     const int N = c.N, C = c.C, H = c.H, W = c.W; const size_t P = (size_t)H * W, NP = N * P;
     Tensor tgt = x_frame(x, c, c.target_id);
@@ -528,7 +531,7 @@ inline float loss_fwd_bwd(const float* x, const LossCfg& c, const Tensor disp[4]
 // ------------------------------------------------------------------------------------------------
 // Model forward (src/model.jl:8-20) + train_loss (src/training.jl:21-78) + pullback into N.g.
 // ------------------------------------------------------------------------------------------------
-struct StepOut { Tensor disp[4]; Vec<float> rvec[2], tvec[2]; float loss = 0; };
+struct StepOut { Tensor disp[5]; Vec<float> rvec[2], tvec[2]; float loss = 0; };
 inline float model_loss(Net& net, const float* x, const LossCfg& c, const float* auto_loss, bool do_bwd, StepOut& out, bool model_only = false) {
     const int N = c.N, L = c.L;
     Tensor xf(N * L, c.C, c.H, c.W); std::memcpy(xf.p(), x, sizeof(float) * xf.size());   // reshape (w,h,c,l*n): frame fastest
@@ -544,14 +547,14 @@ inline float model_loss(Net& net, const float* x, const LossCfg& c, const float*
     }
     if (model_only) return 0.f;
     const float* rv[2] = {out.rvec[0].data(), out.rvec[1].data()}; const float* tv[2] = {out.tvec[0].data(), out.tvec[1].data()};
-    Tensor ddisp[4]; Vec<float> drv[2], dtv[2]; float* drp[2]; float* dtp[2];
+    Tensor ddisp[5]; Vec<float> drv[2], dtv[2]; float* drp[2]; float* dtp[2];
     for (int s = 0; s < 2; ++s) { drv[s].assign((size_t)N * 3, 0); dtv[s].assign((size_t)N * 3, 0); drp[s] = drv[s].data(); dtp[s] = dtv[s].data(); }
     out.loss = loss_fwd_bwd(x, c, out.disp, rv, tv, auto_loss, do_bwd, ddisp, drp, dtp, nullptr, nullptr);
     if (!do_bwd) return out.loss;
     std::fill(net.g.begin(), net.g.end(), 0.f);
     Tensor dfeat[5]; for (int i = 0; i < 5; ++i) dfeat[i].reset(enc->feat[i].n, enc->feat[i].c, enc->feat[i].h, enc->feat[i].w);
     Tensor dtf[5]; depth_bwd(net, *dep, ddisp, dtf);
-    for (int i = 0; i < 5; ++i) t_frame_add(dfeat[i], dtf[i], L, c.target_id - 1);
+    for (int i = 0; i < 5; ++i) if (dtf[i].size()) t_frame_add(dfeat[i], dtf[i], L, c.target_id - 1);
     for (int s = 0; s < c.nsrc; ++s) {
         Tensor df0, df1; pose_bwd(net, ps[s], drp[s], dtp[s], df0, df1);
         t_frame_add(dfeat[4], df0, L, ps[s].order[0] - 1); t_frame_add(dfeat[4], df1, L, ps[s].order[1] - 1);
@@ -563,7 +566,7 @@ inline float model_loss(Net& net, const float* x, const LossCfg& c, const float*
 // eval_disparity(m, x) = m.depth_decoder(m.encoder(x, Val(:stages))), src/model.jl:28.  x: [N][C][H][W] single frames.
 // BatchNorm follows the model's mode like Flux's: batch statistics under trainmode! (train(), src/Monodepth.jl:126), the tracked running statistics
 // under testmode! -- which eval_image / eval_video call explicitly (src/Monodepth.jl:209,237) -- see Net::testmode.
-inline void eval_disparity(Net& net, const float* x, int N, int C, int H, int W, Tensor disp[4]) {
+inline void eval_disparity(Net& net, const float* x, int N, int C, int H, int W, Tensor disp[5]) {
     Tensor xf(N, C, H, W); std::memcpy(xf.p(), x, sizeof(float) * xf.size());
     auto enc = std::make_unique<EncSave>(); encoder_fwd(net, xf, *enc);
     auto dep = std::make_unique<DepthSave>(); depth_fwd(net, enc->feat, *dep, disp);

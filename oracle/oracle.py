@@ -34,6 +34,7 @@ def lib():
         _LIB.o_smooth_loss_bwd_f64.restype = C.c_double
         _LIB.o_net_create.restype = C.c_void_p
         _LIB.o_net_create_depth.restype = C.c_void_p
+        _LIB.o_net_create_levels.restype = C.c_void_p
         _LIB.o_net_nparams.restype = C.c_long
         _LIB.o_net_bn_state_count.restype = C.c_long
         _LIB.o_net_train_loss.restype = C.c_float
@@ -44,12 +45,18 @@ def lib():
 class OCfg(C.Structure):
     _fields_ = [("N", C.c_int), ("C", C.c_int), ("H", C.c_int), ("W", C.c_int), ("automasking", C.c_int), ("simple", C.c_int),
                 ("min_depth", C.c_double), ("max_depth", C.c_double), ("smoothness", C.c_double),
-                ("K", C.c_float * 9), ("invK", C.c_float * 9), ("target_id", C.c_int), ("source_ids", C.c_int * 2)]
+                ("K", C.c_float * 9), ("invK", C.c_float * 9), ("target_id", C.c_int), ("source_ids", C.c_int * 2),
+                ("scale_levels", C.c_int * 5), ("scales", C.c_double * 5)]
 
 
-def make_cfg(N, Cc, H, W, K, invK, automasking=False, min_depth=0.1, max_depth=100.0, smoothness=1e-3, simple=False, target_id=2, source_ids=(1, 3)):
-    """K, invK: 3x3 numpy matrices (mathematical row/col indexing); stored column-major like Julia.  target_id / source_ids: TrainCache's, 1-based."""
+def make_cfg(N, Cc, H, W, K, invK, automasking=False, min_depth=0.1, max_depth=100.0, smoothness=1e-3, simple=False, target_id=2, source_ids=(1, 3), scale_levels=None, scales=None):
+    """K, invK: 3x3 numpy matrices (mathematical row/col indexing); stored column-major like Julia.  target_id / source_ids: TrainCache's, 1-based.
+    scale_levels: the DepthDecoder's (None = 2:5); scales: TrainCache.scales (None = 1 / 2^(5 - level))."""
     c = OCfg()
+    for i, l in enumerate(scale_levels or ()):
+        c.scale_levels[i] = int(l)
+    for i, v in enumerate(scales or ()):
+        c.scales[i] = float(v)
     c.target_id = int(target_id); c.source_ids[0], c.source_ids[1] = int(source_ids[0]), int(source_ids[1])
     c.N, c.C, c.H, c.W, c.automasking, c.simple = N, Cc, H, W, int(automasking), int(simple)
     c.min_depth, c.max_depth, c.smoothness = min_depth, max_depth, smoothness
@@ -241,9 +248,14 @@ def maxpool3s2_bwd(x, dy):
 
 
 # ---------------- network handle ----------------
+def _pad5(arrays):
+    return [_p(a) for a in arrays] + [None] * (5 - len(arrays))
+
+
 class OracleNet:
-    def __init__(self, channels=1, depth=18):
-        self.h = C.c_void_p(lib().o_net_create_depth(channels, depth)); self.C = channels; self.depth = depth
+    def __init__(self, channels=1, depth=18, scale_levels=(2, 3, 4, 5)):
+        self.levels = [int(l) for l in scale_levels]
+        self.h = C.c_void_p(lib().o_net_create_levels(channels, depth, (C.c_int * 6)(*self.levels))); self.C = channels; self.depth = depth
         if not self.h:
             raise ValueError("encoder depth must be 18 or 50")
         self.nparams = lib().o_net_nparams(self.h)
@@ -277,9 +289,9 @@ class OracleNet:
 
     def model_forward(self, x, cfg):
         x = _c(x, np.float32); N, H, W = cfg.N, cfg.H, cfg.W
-        ds = [np.zeros((N, 1, H >> s, W >> s), np.float32) for s in (3, 2, 1, 0)]
+        ds = [np.zeros((N, 1, H >> (5 - l), W >> (5 - l)), np.float32) for l in self.levels]
         rvec = np.zeros((2, N, 3), np.float32); tvec = np.zeros((2, N, 3), np.float32)
-        lib().o_net_model_forward(self.h, _p(x), C.byref(cfg), _p(ds[0]), _p(ds[1]), _p(ds[2]), _p(ds[3]), _p(rvec), _p(tvec))
+        lib().o_net_model_forward(self.h, _p(x), C.byref(cfg), *_pad5(ds), _p(rvec), _p(tvec))
         return ds, rvec, tvec
 
     def train_loss(self, x, cfg, auto_loss=None, do_bwd=False):
@@ -288,8 +300,8 @@ class OracleNet:
 
     def eval_disparity(self, x):
         x = _c(x, np.float32); N, Cc, H, W = x.shape
-        ds = [np.zeros((N, 1, H >> s, W >> s), np.float32) for s in (3, 2, 1, 0)]
-        lib().o_net_eval_disparity(self.h, _p(x), N, Cc, H, W, _p(ds[0]), _p(ds[1]), _p(ds[2]), _p(ds[3])); return ds
+        ds = [np.zeros((N, 1, H >> (5 - l), W >> (5 - l)), np.float32) for l in self.levels]
+        lib().o_net_eval_disparity(self.h, _p(x), N, Cc, H, W, *_pad5(ds)); return ds
 
     def opt_state(self):
         m = np.zeros(self.nparams, np.float32); v = np.zeros(self.nparams, np.float32); b1 = C.c_double(); b2 = C.c_double()
@@ -315,18 +327,18 @@ def automasking_loss(x, cfg):
 
 
 def loss_fwd_bwd(x, cfg, disps, rvec, tvec, auto_loss=None, do_bwd=True, want_warped=False):
-    """disps: 4 arrays (N,1,h,w) coarse->fine (cfg.simple: ONE full-resolution array); rvec,tvec (2,N,3).  Returns dict."""
+    """disps: one array (N,1,h,w) per scale level, coarse->fine (cfg.simple: ONE full-resolution array); rvec,tvec (2,N,3).  Returns dict."""
     x = _c(x, np.float32); ds = [_c(d, np.float32) for d in disps]; rvec = _c(rvec, np.float32); tvec = _c(tvec, np.float32)
     nreal = len(ds)
-    while len(ds) < 4:
+    while len(ds) < 5:
         ds.append(np.zeros((1,), np.float32))
     al = None if auto_loss is None else _c(auto_loss, np.float32)
     dds = [np.zeros_like(d) for d in ds]; drv = np.zeros_like(rvec); dtv = np.zeros_like(tvec)
     N, Cc, H, W = cfg.N, cfg.C, cfg.H, cfg.W
-    warped = np.zeros((4, 2, N, Cc, H, W), np.float32) if want_warped else None
-    wl = np.zeros((4, N, H, W), np.float32) if want_warped else None
-    loss = lib().o_loss_fwd_bwd(_p(x), C.byref(cfg), _p(ds[0]), _p(ds[1]), _p(ds[2]), _p(ds[3]), _p(rvec), _p(tvec), _p(al), int(do_bwd),
-                                _p(dds[0]), _p(dds[1]), _p(dds[2]), _p(dds[3]), _p(drv), _p(dtv), _p(warped), _p(wl))
+    warped = np.zeros((5, 2, N, Cc, H, W), np.float32) if want_warped else None
+    wl = np.zeros((5, N, H, W), np.float32) if want_warped else None
+    loss = lib().o_loss_fwd_bwd(_p(x), C.byref(cfg), _p(ds[0]), _p(ds[1]), _p(ds[2]), _p(ds[3]), _p(ds[4]), _p(rvec), _p(tvec), _p(al), int(do_bwd),
+                                _p(dds[0]), _p(dds[1]), _p(dds[2]), _p(dds[3]), _p(dds[4]), _p(drv), _p(dtv), _p(warped), _p(wl))
     return dict(loss=float(loss), ddisp=dds[:nreal], drvec=drv, dtvec=dtv, warped=warped, warp_loss=wl)
 
 

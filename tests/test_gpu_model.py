@@ -39,11 +39,11 @@ ALLOW_AUTOMASK = ("dec.head5", "dec.branch5")
 REPORT = os.environ.get("MD2_GRAD_REPORT")          # file that collects the per-array tables of every model test (diagnostics)
 
 
-def per_array(gh, go, C, depth=18):
+def per_array(gh, go, C, depth=18, levels=(2, 3, 4, 5)):
     """[(name, cosine, ||gh - go|| / ||go||, ||go||)] for every array of the flat parameter vector (syn.param_layout order)."""
     out = []; off = 0
     gh = np.asarray(gh, np.float64); go = np.asarray(go, np.float64)
-    for name, _, shape in syn.param_layout(C, depth):
+    for name, _, shape in syn.param_layout(C, depth, levels):
         n = int(np.prod(shape)); a = gh[off:off + n]; b = go[off:off + n]; off += n
         na, nb = np.linalg.norm(a), np.linalg.norm(b)
         out.append((name, float(a @ b / (na * nb + 1e-300)), float(np.linalg.norm(a - b) / (nb + 1e-300)), float(nb)))
@@ -51,7 +51,7 @@ def per_array(gh, go, C, depth=18):
     return out
 
 
-def assert_grads_match(gh, go, C, depth=18, cos_min=0.998, rel_max=5e-2, allow=(), tag=""):
+def assert_grads_match(gh, go, C, depth=18, cos_min=0.998, rel_max=5e-2, allow=(), tag="", levels=(2, 3, 4, 5)):
     """Gradient parity as a COMPARISON, array by array: every parameter array (conv weight, bias, BatchNorm gamma / beta -- the 3 136-element stem included)
     must have cosine >= cos_min AND ||g_hip - g_oracle|| / ||g_oracle|| <= rel_max.  Arrays whose oracle gradient is numerically zero (below 1e-7 of the
     largest array norm) are skipped.
@@ -62,15 +62,15 @@ def assert_grads_match(gh, go, C, depth=18, cos_min=0.998, rel_max=5e-2, allow=(
     ~1e-2, in both implementations alike when measured against an fp64 computation, and the fp32 oracle itself moves by that much under a 1-ulp
     perturbation of its input.  A wrong index / layout / boundary in a kernel shows as O(1) in at least one array and fails this bound.
     `allow`: name prefixes with a documented reason for a looser bound (cos >= 0.99, rel <= 0.15)."""
-    tab = per_array(gh, go, C, depth)
+    tab = per_array(gh, go, C, depth, levels)
     top = max(t[3] for t in tab)
     # an array whose gradient is a near-complete cancellation (e.g. one scalar bias summing signed per-pixel terms to 1e-6 of its siblings' size) has no
     # meaningful RELATIVE error: skip arrays 100x below the median norm of their kind (W / b / gamma / beta)
     kinds = {}
-    for (name, _, _, nb), (_, kind, _) in zip(tab, syn.param_layout(C, depth)):
+    for (name, _, _, nb), (_, kind, _) in zip(tab, syn.param_layout(C, depth, levels)):
         kinds.setdefault(kind, []).append(nb)
     med = {k: float(np.median(v)) for k, v in kinds.items()}
-    kind_of = {name: kind for name, kind, _ in syn.param_layout(C, depth)}
+    kind_of = {name: kind for name, kind, _ in syn.param_layout(C, depth, levels)}
     bad = []
     for name, cos, rel_, nb in tab:
         if nb < 1e-7 * top or nb < 1e-2 * med[kind_of[name]]:
@@ -921,3 +921,59 @@ def test_target_and_source_frames_are_the_callers_choice(frames, automask):
     assert_grads_match(model.grads(), net.get_grads(), C, allow=ALLOW_AUTOMASK if automask else (), tag="frames %s" % (frames,))
     with pytest.raises(NotImplementedError):
         model(xd, [1, 2, 3], 2)
+
+
+@pytest.mark.parametrize("levels,scales,automask", [((1, 3, 4), (0.3, 0.7, 1.1), False), ((1, 2, 3, 4, 5), None, True), ((5,), None, False), ((2, 3), None, False), ((4,), (1.0,), True)],
+                         ids=["l134_own_scales", "l12345_automask", "l5", "l23", "l4_automask"])
+def test_depth_decoder_scale_levels_vs_oracle(levels, scales, automask):
+    """DepthDecoder(; scale_levels) / TrainCache.scales (src/depth_decoder.jl:26-47, src/Monodepth.jl:106-107, src/training.jl:42-67): any ascending subset of 1:5 -- fewer
+    branches when the last level is below 5 (encoder stages without a skip consumer get no decoder gradient), a 256-channel head at level 1, a loss without a
+    full-resolution level, five loss terms.  Parameter count and order, forward, loss, every gradient array and one ADAM step against the oracle."""
+    N, C, H, W = 2, 1, 64, 96
+    m = md()
+    K, iK = syn.depth10k_intrinsics(W, H)
+    sc = list(scales) if scales else [1.0 / 2 ** (5 - l) for l in levels]
+    params = m.Params(target_size=(W, H), batch_size=N, automasking=automask)
+    cache = m.TrainCache(m.SSIM(), m.Backproject(W, H), m.Project(W, H), K, iK, 2, [1, 3], sc)
+    enc = m.ResidualNetwork(18, in_channels=C)
+    model = m.Model(enc, m.DepthDecoder(list(enc.stages), list(levels)), m.PoseDecoder(enc.stages[-1]), lr=1e-3)
+    theta = syn.init_params(C, seed=31, randomize_affine=True, scale_levels=levels); model.load_params(theta)
+    x = syn.synthetic_triplets(N, C, H, W, seed=93); xd = dev(x)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK, automasking=automask, scale_levels=levels, scales=sc)
+    net = oracle.OracleNet(C, scale_levels=levels); net.set_params(theta)
+    model._ensure(xd, params, cache)                             # (TrainCache.scales reach the handle with the cache)
+    ds, poses = model(xd, [1, 3], 2)
+    assert len(ds) == len(levels) and model.params().size == theta.size == net.nparams
+    assert np.array_equal(model.params(), theta)                 # Flux order in, Flux order out, through the internal layout
+    dso, rvo, tvo = net.model_forward(x, cfg)
+    for i, l in enumerate(levels):
+        assert tuple(ds[i].shape) == (N, 1, H >> (5 - l), W >> (5 - l)) and rel(host(ds[i]), dso[i]) < 1e-4
+    assert rel(host(poses[0].rvec), rvo[0]) < 1e-4 and rel(host(poses[1].tvec), tvo[1]) < 1e-4
+    al = m.automasking_loss(m.SSIM(), xd, xd[:, 1].contiguous(), [1, 3]) if automask else None
+    alo = oracle.automasking_loss(x, cfg) if automask else None
+    # the loss half on the oracle's disparities and poses, with its pullbacks (a loss without a full-resolution level; five levels)
+    # (without the mask here -- it multiplies the pixels whose decision flips between two fp32 summation orders; the training step below runs with it)
+    def close(a, b):                              # an arg-min flip of ONE pixel moves a 3x3 window, i.e. up to 4 entries of a coarse level by up to ~0.1 of the largest
+        d = np.abs(a.astype(np.float64) - b) / np.abs(b).max(); return (d > 2e-4).sum() <= max(0.03 * d.size, 8) and d.max() < 0.15
+    loss, dds, drv, dtv = m.loss_fwd_bwd(model, xd, [dev(d) for d in dso], dev(rvo), dev(tvo))
+    cfg0 = oracle.make_cfg(N, C, H, W, K, iK, scale_levels=levels, scales=sc)
+    r = oracle.loss_fwd_bwd(x, cfg0, dso, rvo, tvo)
+    assert abs(float(loss) - r["loss"]) / r["loss"] < 1e-5
+    for i in range(len(levels)):
+        assert close(host(dds[i]), r["ddisp"][i]), i
+    assert rel(host(drv), r["drvec"]) < 5e-3 and rel(host(dtv), r["dtvec"]) < 5e-3
+    # deterministic mode takes the other reduction path of the coarse levels (full-resolution maps + ordered resize adjoint)
+    m.set_deterministic(True)
+    try:
+        _, dd2, _, _ = m.loss_fwd_bwd(model, xd, [dev(d) for d in dso], dev(rvo), dev(tvo))
+        for i in range(len(levels)):
+            assert close(host(dd2[i]), r["ddisp"][i]), i
+    finally:
+        m.set_deterministic(False)
+    loss = m.train_step(model, xd, al, cache, params, do_update=False)
+    lo = net.train_loss(x, cfg, alo, True)
+    assert abs(float(loss) - lo) / lo < 1e-4
+    last = ("dec.head%d" % levels[-1], "dec.branch%d" % levels[-1])
+    assert_grads_match(model.grads(), net.get_grads(), C, allow=last if automask else (), tag="levels %s" % (levels,), levels=levels)
+    gh = model.grads(); m.update(m.ADAM(1e-3), model); net.set_grads(gh); net.adam_step(1e-3)          # same gradients in: the update over this parameter layout must agree tightly
+    assert rel(model.params() - theta, net.get_params() - theta) < 5e-3

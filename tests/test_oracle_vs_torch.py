@@ -191,3 +191,35 @@ def test_bn_running_statistics_and_testmode_vs_torch():
     net.set_testmode(False)
     dtr = net.eval_disparity(x1)
     assert max(np.abs(a - b).max() for a, b in zip(do, dtr)) > 1e-3  # and it really differs from batch statistics on one frame
+
+
+@pytest.mark.parametrize("levels", [(1, 3, 4), (1, 2, 3, 4, 5), (5,), (2, 3)])
+def test_depth_decoder_scale_levels_vs_torch_live(levels):
+    """DepthDecoder(; scale_levels) (src/depth_decoder.jl:26-47): branches 1..max level, a head after each listed level (level 1: 256 channels at H/16), one loss term per
+    output with TrainCache.scales[i] (src/training.jl:42-67).  The oracle's generalisation against the torch implementation: forward, loss, gradients -- including the
+    encoder stages the decoder no longer reads (their skip gradient is absent, not zero-filled garbage)."""
+    N, C, H, W = 1, 1, 64, 96
+    theta = syn.init_params(C, seed=31, randomize_affine=True, scale_levels=levels)      # (seed 21 puts a ReLU / max-pool input of levels (1,3,4) on a kink: 8 % on layer1-2 arrays between fp32 and fp64)
+    x = syn.synthetic_triplets(N, C, H, W, seed=22)
+    K, iK = syn.depth10k_intrinsics(W, H)
+    scales = [1.0 / 2 ** (5 - l) for l in levels]
+    if len(levels) == 3:
+        scales = [0.3, 0.7, 1.1]                       # TrainCache.scales are the caller's numbers
+    cfg = oracle.make_cfg(N, C, H, W, K, iK, scale_levels=levels, scales=scales)
+    net = oracle.OracleNet(C, scale_levels=levels); net.set_params(theta)
+    assert net.nparams == syn.num_params(C, 18, levels) == theta.size
+    assert [(c, k) for (_, c, k) in net.layout()] == [(int(np.prod(s)), {"W": 0, "b": 1, "gamma": 2, "beta": 3}[kd]) for (_, kd, s) in syn.param_layout(C, 18, levels)]
+    ds, rv, tv = net.model_forward(x, cfg)
+    flat = torch.tensor(theta, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64)
+    dt, poses = tr.model_forward(flat, xt, C, scale_levels=levels)
+    assert len(ds) == len(dt) == len(levels)
+    for i, l in enumerate(levels):
+        assert ds[i].shape == tuple(dt[i].shape) == (N, 1, H >> (5 - l), W >> (5 - l)) and rel(ds[i], dt[i].detach().numpy()) < 1e-4
+    lt = tr.loss_from_outputs(xt, dt, poses, torch.tensor(K), torch.tensor(iK), scales=scales)
+    lo = net.train_loss(x, cfg, None, True)
+    assert abs(lo - float(lt)) / float(lt) < 1e-4
+    lt.backward()
+    go = net.get_grads(); gt = flat.grad.numpy()
+    assert float(np.dot(go, gt) / (np.linalg.norm(go) * np.linalg.norm(gt))) > 0.999
+    assert abs(np.linalg.norm(go) - np.linalg.norm(gt)) / np.linalg.norm(gt) < 2e-2

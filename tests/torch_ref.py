@@ -132,8 +132,8 @@ class Params:
         return g, b
 
 
-def model_forward(flat, x, C, target_id=2, source_ids=(1, 3), depth=18):
-    """x (N,L,C,H,W) -> (disps[4] (N,1,h,w), [(rvec (N,3), tvec (N,3))]*2).  src/model.jl:8-20"""
+def model_forward(flat, x, C, target_id=2, source_ids=(1, 3), depth=18, scale_levels=(2, 3, 4, 5)):
+    """x (N,L,C,H,W) -> (disps (N,1,h,w) per scale level, [(rvec (N,3), tvec (N,3))]*2).  src/model.jl:8-20"""
     P = Params(flat); N, L = x.shape[:2]
     h = x.reshape(N * L, C, x.shape[3], x.shape[4])
     # encoder (torchvision ResNet-18 / ResNet-50 trunk)
@@ -165,18 +165,19 @@ def model_forward(flat, x, C, target_id=2, source_ids=(1, 3), depth=18):
     tf = [f[:, target_id - 1] for f in f5]
     # depth decoder
     dec = [256, 128, 64, 32, 16]; inc = [cin, 256, 128, 64, 32]; skc = [feats[3].shape[1], feats[2].shape[1], feats[1].shape[1], 64, 0]
-    dconvs = [(P.conv(inc[b_], dec[b_], 3, True), P.conv(dec[b_] + skc[b_], dec[b_], 3, True)) for b_ in range(5)]
-    heads = [P.conv(dec[l + 1], 1, 3, True) for l in range(4)]
+    nbr = max(scale_levels)                      # DepthDecoder: branches 1..max(scale_levels), one head per listed level (src/depth_decoder.jl:38-46)
+    dconvs = [(P.conv(inc[b_], dec[b_], 3, True), P.conv(dec[b_] + skc[b_], dec[b_], 3, True)) for b_ in range(nbr)]
+    heads = {l: P.conv(dec[l - 1], 1, 3, True) for l in scale_levels}
     rp = lambda a: F.pad(a, (1, 1, 1, 1), mode="reflect")
     xx = tf[4]; disps = []
-    for b_ in range(5):
+    for b_ in range(nbr):
         (w1, b1), (w2, b2) = dconvs[b_]
         xx = F.elu(flux_conv(rp(xx), w1, b1)); xx = F.interpolate(xx, scale_factor=2, mode="bilinear", align_corners=True)
         if b_ < 4:
             xx = torch.cat([xx, tf[3 - b_]], 1)
         xx = F.elu(flux_conv(rp(xx), w2, b2))
-        if b_ >= 1:
-            wh, bh = heads[b_ - 1]; disps.append(torch.sigmoid(flux_conv(rp(xx), wh, bh)))
+        if b_ + 1 in heads:
+            wh, bh = heads[b_ + 1]; disps.append(torch.sigmoid(flux_conv(rp(xx), wh, bh)))
     # pose decoder
     ws, bs = P.conv(cin, 256, 1, True); wp1, bp1 = P.conv(512, 256, 3, True); wp2, bp2 = P.conv(256, 256, 3, True); wp3, bp3 = P.conv(256, 6, 1, True)
     assert P.o == flat.numel(), (P.o, flat.numel())
