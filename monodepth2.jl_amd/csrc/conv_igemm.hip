@@ -1105,7 +1105,9 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------
 // REFLECT / FAST are compile-time so that the steady-state loop is ONE basic block (uniform branches would split it and the ~180
 // address/carry VALU instructions of the loader would run ahead of, instead of between, the 32 MFMAs of a step)
-template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
+// ONE: 1x1 / stride-1 convolution on dense views (pixel m of dy and of x are the same flattened index): the loader is base + m * pixel stride, no (n, oh, ow) bookkeeping --
+// the ResNet-50 bottlenecks' weight gradients (33 launches per step) spent more issue slots on those carries than on their 32 MFMAs per step
+template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {
     // LDS tiles [pixel][channel]: A operand lane (row = channel, k = pixel) reads consecutive channels of one pixel row.
     // 32x32x2: the two 32-lane halves are separate ds_read_b32 groups -> conflict-free for any row length.
@@ -1160,6 +1162,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
         for (int j = 0; j < NLD; ++j) {
             const int f = tid + 256 * j, lc = (f % LPP) * 4;
             const bool in = p_m[j] < a.M;
+            if constexpr (ONE) {
+                const long m = in ? p_m[j] : 0;
+                const uint4 vd = *reinterpret_cast<const uint4*>(a.dy + m * a.dy_ps + c0 + lc);
+                const uint4 vx = *reinterpret_cast<const uint4*>(a.x + m * a.x_ps + i0 + lc);
+                const unsigned md = in ? 0xFFFFFFFFu : 0u;
+                rd[j] = make_float4(__uint_as_float(vd.x & md), __uint_as_float(vd.y & md), __uint_as_float(vd.z & md), __uint_as_float(vd.w & md));
+                if constexpr (XF) {
+                    const float tx = fmaxf(fmaf(__uint_as_float(vx.x), xsc.x, xsh.x), 0.f), ty = fmaxf(fmaf(__uint_as_float(vx.y), xsc.y, xsh.y), 0.f);
+                    const float tz = fmaxf(fmaf(__uint_as_float(vx.z), xsc.z, xsh.z), 0.f), tw = fmaxf(fmaf(__uint_as_float(vx.w), xsc.w, xsh.w), 0.f);
+                    rx[j] = make_float4(__uint_as_float(__float_as_uint(tx) & md), __uint_as_float(__float_as_uint(ty) & md), __uint_as_float(__float_as_uint(tz) & md), __uint_as_float(__float_as_uint(tw) & md));
+                } else
+                rx[j] = make_float4(__uint_as_float(vx.x & md), __uint_as_float(vx.y & md), __uint_as_float(vx.z & md), __uint_as_float(vx.w & md));
+                p_m[j] += BKP;
+                continue;
+            }
             const int n = p_n[j], oh = p_oh[j], ow = p_ow[j];
             int ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
             bool ok = in;
@@ -1315,6 +1332,15 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     const int sps = (steps_total + splitk - 1) / splitk;
     splitk = (steps_total + sps - 1) / sps;
     const dim3 g(tiles * taps * splitk);
+    if constexpr (T >= 64) {
+        static const bool no_one = getenv("MD2_NO_WGRAD_ONE") != nullptr;
+        const bool one = !no_one && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
+        if (one) {
+            if (a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            return;
+        }
+    }
     if (a.in_scale) {
         if constexpr (T >= 64) {
             if (refl) { fprintf(stderr, "md2: conv_wgrad: the input transform is for zero-padded convolutions\n"); abort(); }

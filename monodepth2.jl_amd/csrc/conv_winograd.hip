@@ -29,6 +29,17 @@
 
 namespace md2 {
 
+// exact floor(m / d) for 0 <= m < 2^24, d >= 1 from the float reciprocal with a +-1 correction: ~8 VALU instructions instead of the ~40 of a 32-bit integer division.  The
+// per-workgroup prologue / epilogue of the kernels below held 21 of those per thread -- about a fifth of a workgroup's fixed cost (tools/run_wino3_ablate.sh: the skeleton
+// without loads, MFMAs and transforms is 23-35 % of a launch).
+__device__ __forceinline__ int fdiv24(int m, int d) {
+    int q = (int)((float)m * __builtin_amdgcn_rcpf((float)d));
+    const int r = m - q * d;
+    q += (r >= d) ? 1 : 0; q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int TH, i
         const int m = m0 + lt;
         const bool tv = m < Mt;
         const int mm = tv ? m : 0;
-        const int n = mm / THW, r = mm - n * THW, ty = r / TW, tx = r - ty * TW;
+        const int n = fdiv24(mm, THW), r = mm - n * THW, ty = fdiv24(r, TW), tx = r - ty * TW;
         const unsigned base = (unsigned)((long)n * a.x_bs) + (unsigned)(q * 4);
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int TH, i
     for (int p = 0; p < WT / RP; ++p) {
         const int t = p * RP + rr0, m = m0 + t;
         if (m >= Mt) continue;
-        const int n = m / THW, r = m - n * THW, ty = r / TW, tx = r - ty * TW;
+        const int n = fdiv24(m, THW), r = m - n * THW, ty = fdiv24(r, TW), tx = r - ty * TW;
         float4 Rv[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -374,7 +385,7 @@ __device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __
     for (int p = 0; p < ntile / RP; ++p) {
         const int t = p * RP + rr0, m = m0 + t;
         if (m >= Mt) continue;
-        const int n = m / THW, r = m - n * THW, ty = r / TW, tx = r - ty * TW;
+        const int n = fdiv24(m, THW), r = m - n * THW, ty = fdiv24(r, TW), tx = r - ty * TW;
         float4 Rv[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -469,12 +480,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
         const int slot = (tid + 256 * li) >> 1;
         int k, r, WP, txa, Lk;
         if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
-        else { const int s2 = slot - S0; k = 1 + s2 / S; r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, W2_T - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
-        const int pa = r / WP, pc = r - pa * WP;
+        else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, W2_T - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
+        const int pa = fdiv24(r, WP), pc = r - pa * WP;
         const int rr = rr_first + k;
         const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
         const int rrc = act ? rr : 0;
-        const int n = rrc / TH, ty = rrc - n * TH;
+        const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
         int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
         bool ok = act;
         if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
 #pragma unroll
     for (int th = 0; th < 2; ++th) {
         const int ct = th * 32 + tl;
-        const int u = tx0 + ct, k = u / TW;
+        const int u = tx0 + ct, k = fdiv24(u, TW);
         const int lc = (k == 0) ? ct : (u - k * TW);
         const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, W2_T - L0 - (k - 1) * TW) + 2;
 #pragma unroll
@@ -562,6 +573,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
 #pragma unroll
         for (int th = 0; th < 2; ++th) {
             float4 V[4];
+#ifdef MD2_ABLATE
+            if (abl & 32) { V[0] = V[1] = V[2] = V[3] = make_float4(sg, sg, sg, sg); } else          // timing experiment: no LDS reads, no input transform
+#endif
             {
                 float4 rr[4];
 #pragma unroll
@@ -589,6 +603,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
         if (!(abl & 8)) __syncthreads();
     }
 
+#ifdef MD2_ABLATE
+    if (abl & 64) { if (acc[0][0][0] + acc[1][1][3] + acc[2][0][5] + acc[3][1][7] == 123.456f) a.y[0] = 1.f; return; }          // timing experiment: no output transform / epilogue
+#endif
     // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4])
     constexpr int RLD = COB + 4;
     float* Rl = wsm;

@@ -19,14 +19,20 @@ int main(int argc, char** argv) {
     a.y = y; a.y_bs = (long)H * W * Cout; a.y_ps = Cout; a.Ho = H; a.Wo = W; a.Cout = Cout;
     a.N = N; a.KH = k; a.KW = k; a.stride = 1; a.pad = k / 2; a.dil = 1; a.padmode = 0;
     a.M = N * H * W; a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = H; a.Wl = W; a.kh0 = 0; a.khs = 1; a.nkh = k; a.kw0 = 0; a.kws = 1; a.nkw = k;
+#ifdef MD2_ABLATE
     a.ablate = abl; a.force_tile = tile;
+#endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     if (getenv("WGRAD")) {
         float* dw; hipMalloc(&dw, nw * 4); hipMemset(dw, 0, nw * 4);
         hipMemcpy(y, hx.data(), std::min(nx, ny) * 4, hipMemcpyHostToDevice);
         WgradArgs g{};
         g.x = x; g.x_bs = a.x_bs; g.x_ps = Cin; g.H = H; g.W = W; g.Cin = Cin; g.dy = y; g.dy_bs = a.y_bs; g.dy_ps = Cout; g.Ho = H; g.Wo = W; g.Cout = Cout;
-        g.dw = dw; g.N = N; g.KH = k; g.KW = k; g.stride = 1; g.pad = k / 2; g.padmode = 0; g.M = a.M; g.ablate = abl;
+        g.dw = dw; g.N = N; g.KH = k; g.KW = k; g.stride = 1; g.pad = k / 2; g.padmode = 0; g.M = a.M;
+#ifdef MD2_ABLATE
+        g.ablate = abl;
+#endif
+
         for (int i = 0; i < 3; ++i) launch_conv_wgrad(g, 0);
         hipEventRecord(e0); const int reps = 20; for (int i = 0; i < reps; ++i) launch_conv_wgrad(g, 0); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
