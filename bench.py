@@ -36,6 +36,44 @@ def pmc_traffic(B, C, H, W, depth, precision):
     return d.get("bytes_per_launch", {})
 
 
+def bf16_conv_roofline(md, torch, model, step):
+    """The mixed-precision mode's convolutions (forward + input gradient) on both rooflines.  Its MFMA operands are bf16 but every activation is still stored in fp32, so the
+    class sits far below the bf16 matrix peak and is priced against HBM as well: ALGORITHMIC bytes = each launch reads its input pixels and weights once and writes its output once
+    at the fp32 storage width (from the per-launch records of the library profiler: M output pixels, Cin, Cout, k, stride), over the class time measured with HIP events."""
+    import re, tempfile
+    md.set_two_streams(model, False); md.profile(model, True)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ig = md.profile_get(model, 0)
+    tmp = os.path.join(tempfile.gettempdir(), "md2_bf16_layers_%d.csv" % os.getpid())
+    md.profile_dump(model, tmp); md.profile(model, False); md.set_two_streams(model, True)
+    by = 0.0
+    for line in open(tmp).read().splitlines()[1:]:
+        f = line.split(",", 4)
+        m = re.match(r"igemm M=(\d+) Cout=(\d+) Cin=(\d+) k=(\d+) s=(\d+)", f[4]) if len(f) == 5 and f[0] == "0" else None
+        if m:
+            M, co, ci, k, st = (int(v) for v in m.groups())
+            by += 4.0 * (M * st * st * ci + M * co + k * k * ci * co)
+    os.remove(tmp)
+    if ig["ms"] <= 0:
+        return None
+    traffic_step = None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_cfg5_bf16_pmc_hbm_traffic.json")))
+        if d.get("workload") == {"batch": 8, "channels": 3, "height": 320, "width": 1024, "depth": 18, "precision": "bf16"}:
+            traffic_step = d["bytes_per_step"]["conv_igemm"]
+    except Exception:
+        pass
+    tf = ig["flops"] / (ig["ms"] * 1e-3) / 1e12; gbs = by / (ig["ms"] * 1e-3) / 1e9
+    return {"kernel": "forward + input-gradient convolutions of the bf16 mixed-precision mode (v_mfma_f32_32x32x16_bf16 operands, fp32 storage)", "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / MFMA_BF16_PEAK_TFLOPS else "mfma",
+            "mfma": {"achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS},
+            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": by / 3, "traffic": traffic_step,
+                    "traffic_unit": "HBM bytes per step of this class (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of tools/prof_config.py 8 18 3 320 1024 bf16, profiles/r03_cfg5_bf16_pmc_hbm_traffic.md)"},
+            "ms_per_step": ig["ms"] / 3, "launches_per_step": ig["launches"] / 3,
+            "note": "activations stay fp32 in HBM: the class reads and writes twice the bytes a bf16-storage mode would; that mode is not built (DESIGN.md section 7)"}
+
+
 def valu_insts(kernel, B, C, H, W):
     """SQ_INSTS_VALU per launch of a loss kernel from the committed PMC summary (profiles/r03_loss_pmc.json: {"workload": {...}, "loss_train": n, ...}); None when
     the workload differs from the one measured."""
@@ -293,6 +331,7 @@ def main():
                 md.train_step(m6, x6, a6, c6, p6, True)
             torch.cuda.synchronize(); d6 = time.perf_counter() - t0
             extra["config4_1024x320_bf16_automask_batch8"] = {"value": 8 * n6 / d6, "unit": "triplets/s", "ms_per_step": d6 / n6 * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate"}
+            extra["config4_1024x320_bf16_automask_batch8"]["roofline"] = bf16_conv_roofline(md, torch, m6, lambda: md.train_step(m6, x6, a6, c6, p6, True))
             # and the headline shape in the same mixed precision, for reference next to `value` (which is fp32)
             del m6, x6
             torch.cuda.empty_cache()

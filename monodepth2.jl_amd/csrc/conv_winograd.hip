@@ -455,20 +455,23 @@ __device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __
 //     and with them the loads' wait, to the top of the block).
 // In-model at batch 32 (tools/run_layer_compare.sh): 0.215 -> 0.153 ms on the 64-channel layers, 0.217 -> 0.141 (128), 0.211 -> 0.160 (256), 0.218 -> 0.188 (512).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NLI, int XF, int BST>
-__global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo geo) {
+// NH = 32-tile halves per workgroup.  NH = 2 (64 tiles, two workgroups per CU) halves the U traffic per multiply; NH = 1 (32 tiles, 64 accumulator registers: THREE workgroups per
+// CU, 768 resident on the chip) is for launches with too few 64-tile workgroups to fill 512 slots twice -- the 1/16- and 1/32-scale layers left a third of the wave slots empty
+// (SQ_WAVE_CYCLES of profiles/r03_wino3_pmc.md: 68 % of the slot-time occupied) -- and gives the scheduler a third wave per SIMD to cover the waits of the other two.
+template <int NLI, int XF, int BST, int NH = 2>
+__global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo geo) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
-    constexpr int COB = 32;
+    constexpr int COB = 32, WT = 32 * NH;
     constexpr int PST = 128 * NLI * 8;               // floats per patch stage: every (slot, half) item of the loader has a real slot (those past geo.nslots are never read)
     const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
     const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
     const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_p = bid % ntp, tile_c = bid / ntp;
-    const int m0 = tile_p * W2_T, c0 = tile_c * COB;
+    const int m0 = tile_p * WT, c0 = tile_c * COB;
     const int THW = TH * TW;
     const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
-    const int L0 = min(TW - tx0, W2_T);
-    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, W2_T), S = 4 * (2 * Lf + 2);
+    const int L0 = min(TW - tx0, WT);
+    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, WT), S = 4 * (2 * Lf + 2);
     const int n_rows_total = a.N * TH;
 
     // ---- loader: item f = tid + 256 li = (slot f >> 1, 16-B half f & 1); LDS position = slot * 8 + swizzled half, i.e. l_dst0 + li * 1024 floats
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
         const int slot = (tid + 256 * li) >> 1;
         int k, r, WP, txa, Lk;
         if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
-        else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, W2_T - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
+        else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
         const int pa = fdiv24(r, WP), pc = r - pa * WP;
         const int rr = rr_first + k;
         const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
@@ -520,13 +523,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
     const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
     const float sg = (wi == 1) ? 1.f : -1.f;
     const int tl = lane & 31, ch = lane >> 5;
-    int c_off1[2][4], c_off2[2][4];
+    int c_off1[NH][4], c_off2[NH][4];
 #pragma unroll
-    for (int th = 0; th < 2; ++th) {
+    for (int th = 0; th < NH; ++th) {
         const int ct = th * 32 + tl;
         const int u = tx0 + ct, k = fdiv24(u, TW);
         const int lc = (k == 0) ? ct : (u - k * TW);
-        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, W2_T - L0 - (k - 1) * TW) + 2;
+        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, WT - L0 - (k - 1) * TW) + 2;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
@@ -538,11 +541,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
         }
     }
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NH];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NH; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][t][e] = 0.f;
 
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
                 acc[j_][th_] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf_[3], V[j_].w, acc[j_][th_], 0, 0, 0); \
             } else asm volatile("" :: "v"(uf_[0]), "v"(uf_[1]), "v"(uf_[2]), "v"(uf_[3]), "v"(V[j_].x)); } while (0)
 #pragma unroll
-        for (int th = 0; th < 2; ++th) {
+        for (int th = 0; th < NH; ++th) {
             float4 V[4];
 #ifdef MD2_ABLATE
             if (abl & 32) { V[0] = V[1] = V[2] = V[3] = make_float4(sg, sg, sg, sg); } else          // timing experiment: no LDS reads, no input transform
@@ -592,10 +595,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
             // in-place refill right behind a fragment's last use in this chunk (tile half 1): the next use is three MFMA groups, the commit, the barrier and a transform
             // phase later -- for every j alike
             // (the sched_barriers keep hipcc from collecting the four loads behind the last MFMA)
-            W3_MFMA(th, 0, uf0); if (th == 1 && !(abl & 2)) { uf0 = *reinterpret_cast<const f32x4*>(un); __builtin_amdgcn_sched_barrier(0); }
-            W3_MFMA(th, 1, uf1); if (th == 1 && !(abl & 2)) { uf1 = *reinterpret_cast<const f32x4*>(un + 256); __builtin_amdgcn_sched_barrier(0); }
-            W3_MFMA(th, 2, uf2); if (th == 1 && !(abl & 2)) { uf2 = *reinterpret_cast<const f32x4*>(un + 512); __builtin_amdgcn_sched_barrier(0); }
-            W3_MFMA(th, 3, uf3); if (th == 1 && !(abl & 2)) uf3 = *reinterpret_cast<const f32x4*>(un + 768);
+            W3_MFMA(th, 0, uf0); if (th == NH - 1 && !(abl & 2)) { uf0 = *reinterpret_cast<const f32x4*>(un); __builtin_amdgcn_sched_barrier(0); }
+            W3_MFMA(th, 1, uf1); if (th == NH - 1 && !(abl & 2)) { uf1 = *reinterpret_cast<const f32x4*>(un + 256); __builtin_amdgcn_sched_barrier(0); }
+            W3_MFMA(th, 2, uf2); if (th == NH - 1 && !(abl & 2)) { uf2 = *reinterpret_cast<const f32x4*>(un + 512); __builtin_amdgcn_sched_barrier(0); }
+            W3_MFMA(th, 3, uf3); if (th == NH - 1 && !(abl & 2)) uf3 = *reinterpret_cast<const f32x4*>(un + 768);
         }
 #undef W3_MFMA
         __builtin_amdgcn_sched_barrier(0);
@@ -604,13 +607,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
     }
 
 #ifdef MD2_ABLATE
-    if (abl & 64) { if (acc[0][0][0] + acc[1][1][3] + acc[2][0][5] + acc[3][1][7] == 123.456f) a.y[0] = 1.f; return; }          // timing experiment: no output transform / epilogue
+    if (abl & 64) { if (acc[0][0][0] + acc[1][NH - 1][3] + acc[2][0][5] + acc[3][NH - 1][7] == 123.456f) a.y[0] = 1.f; return; }          // timing experiment: no output transform / epilogue
 #endif
     // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4])
     constexpr int RLD = COB + 4;
     float* Rl = wsm;
 #pragma unroll
-    for (int th = 0; th < 2; ++th)
+    for (int th = 0; th < NH; ++th)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 o0, o1;
@@ -619,50 +622,64 @@ __global__ __launch_bounds__(256, 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo
             o0.z = acc[0][th][4 * g + 2] + acc[1][th][4 * g + 2] + acc[2][th][4 * g + 2]; o1.z = acc[1][th][4 * g + 2] - acc[2][th][4 * g + 2] - acc[3][th][4 * g + 2];
             o0.w = acc[0][th][4 * g + 3] + acc[1][th][4 * g + 3] + acc[2][th][4 * g + 3]; o1.w = acc[1][th][4 * g + 3] - acc[2][th][4 * g + 3] - acc[3][th][4 * g + 3];
             const int col = 8 * g + 4 * ch, ct = th * 32 + tl;
-            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * W2_T + ct) * RLD + col) = o0;
-            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * W2_T + ct) * RLD + col) = o1;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * WT + ct) * RLD + col) = o0;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * WT + ct) * RLD + col) = o1;
         }
     __syncthreads();
-    wino_final_epilogue<256, COB, BST>(a, wsm, m0, W2_T, Mt, THW, TW, c0, tid);
+    wino_final_epilogue<256, COB, BST>(a, wsm, m0, WT, Mt, THW, TW, c0, tid);
 }
 
 // patch slots a block can need at tile-row width TW: worst case over the position of its first tile
-static int wino2_slots(int TW) {
-    const int Lf = std::min(TW, W2_T), S = 4 * (2 * Lf + 2);
+static int wino2_slots(int TW, int T = W2_T) {
+    const int Lf = std::min(TW, T), S = 4 * (2 * Lf + 2);
     int worst = 0;
     for (int tx0 = 0; tx0 < TW; ++tx0) {
-        const int L0 = std::min(TW - tx0, W2_T);
-        const int rest = W2_T - L0, nfull = rest / TW, Lr = rest - nfull * TW;          // whole rows, then a short last segment with rows as wide as it needs
+        const int L0 = std::min(TW - tx0, T);
+        const int rest = T - L0, nfull = rest / TW, Lr = rest - nfull * TW;          // whole rows, then a short last segment with rows as wide as it needs
         worst = std::max(worst, 4 * (2 * L0 + 2) + nfull * S + (Lr ? 4 * (2 * Lr + 2) : 0));
     }
     return (worst + 15) / 16 * 16;
 }
-// third kernel: Cout % 32 == 0, Cin % 8 == 0, up to 640 patch slots per stage (tile rows of at least 4 tiles)
-static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g) {
+// third kernel: Cout % 32 == 0, Cin % 8 == 0; 64 tiles per workgroup with up to 640 patch slots per stage (tile rows of at least 4 tiles), or 32 tiles with up to 384
+static int g_wino_nh = getenv("MD2_WINO_NH") ? atoi(getenv("MD2_WINO_NH")) : 0;          // 0: by workgroup count, 1 / 2: pin the 32- / 64-tile workgroup (tools/conv_bench)
+static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
     static const bool off = getenv("MD2_NO_WINO3") != nullptr;
     if (off || g_wino_on == 2 || a.Cout % 32 != 0 || a.Cin % 8 != 0) return false;
-    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW; g.ntp = (g.Mt + W2_T - 1) / W2_T;
-    g.nslots = wino2_slots(g.TW);
-    if (g.nslots > 128 * 5) return false;
-    return g_wino_on == 3 || (long)g.ntp * (a.Cout / 32) >= g_wino_min_blocks;
+    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW;
+    const int s64 = wino2_slots(g.TW, 64), s32 = wino2_slots(g.TW, 32);
+    const long b64 = (long)((g.Mt + 63) / 64) * (a.Cout / 32), b32 = (long)((g.Mt + 31) / 32) * (a.Cout / 32);
+    const bool ok64 = s64 <= 128 * 5, ok32 = s32 <= 128 * 3;
+    if (!ok64 && !ok32) return false;
+    // 32-tile workgroups by default: measured on every 3x3 / stride-1 shape of the step at batch 32 (tools/run_wino_nh_bench.sh) they are 4-18 % faster on the encoder stages
+    // (0.159 -> 0.140 ms at 256 channels, 0.185 -> 0.152 at 512), 5-12 % on most decoder layers and within +-4 % on the rest; MD2_WINO_SMALL_BLOCKS=n keeps the 64-tile
+    // workgroup for launches with at least n of them
+    static const long small = getenv("MD2_WINO_SMALL_BLOCKS") ? atol(getenv("MD2_WINO_SMALL_BLOCKS")) : (1L << 40);
+    nh = g_wino_nh == 1 ? 1 : (g_wino_nh == 2 ? 2 : (b64 < small ? 1 : 2));
+    if (nh == 1 && !ok32) nh = 2;
+    if (nh == 2 && !ok64) nh = 1;
+    const int T = 32 * nh;
+    g.ntp = (g.Mt + T - 1) / T; g.nslots = nh == 1 ? s32 : s64;
+    // a launch below the threshold keeps the direct kernel and its split-K -- except short reductions (Cin <= 128), where a workgroup's life is mostly fixed cost either way and
+    // 0.6 x the threshold already wins (batch 4, encoder layer 2: 156 workgroups, 0.051 -> 0.040 ms in the model)
+    return g_wino_on == 3 || b64 >= g_wino_min_blocks || (a.Cin <= 128 && b64 * 5 >= (long)g_wino_min_blocks * 3);
 }
-template <int NLI>
+template <int NLI, int NH>
 static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
-    constexpr size_t lds_pipe = (size_t)2 * 128 * NLI * 8 * sizeof(float), lds_epi = (size_t)8 * W2_T * (32 + 4) * sizeof(float);
-    constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
+    constexpr size_t lds_pipe = (size_t)2 * 128 * NLI * 8 * sizeof(float), lds_epi = (size_t)8 * (32 * NH) * (32 + 4) * sizeof(float), lds_st = (size_t)12 * 256 * sizeof(float);
+    constexpr size_t lds = std::max(std::max(lds_pipe, lds_epi), lds_st);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 0, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 1, 0, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 1, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = g.ntp * (a.Cout / 32);
-    if (a.in_scale) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 1, 0>), dim3(grid), dim3(256), lds, s, a, g);
-    else if (a.bst) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 1>), dim3(grid), dim3(256), lds, s, a, g);
-    else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0>), dim3(grid), dim3(256), lds, s, a, g);
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 1, 0, NH>), dim3(grid), dim3(256), lds, s, a, g);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 1, NH>), dim3(grid), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0, NH>), dim3(grid), dim3(256), lds, s, a, g);
 }
-static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) { launch_wino3_t<5>(a, g, s); }
+static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) { if (nh == 1) launch_wino3_t<3, 1>(a, g, s); else launch_wino3_t<5, 2>(a, g, s); }
 
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -870,20 +887,21 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
 }
 
 int g_wino_on = getenv("MD2_NO_WINO") ? 0 : (getenv("MD2_WINO_MODE") ? atoi(getenv("MD2_WINO_MODE")) : 1);          // MD2_WINO_MODE=2/3: pin one kernel (md2_set_winograd)
-int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 160;
+int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 96;
 
 // 3x3, stride 1, dense output lattice, no split-K, fp32; Cin % 16, Cout % 32.  Automatic choice (md2_set_winograd(1, n)): the 64-tile x 32-channel kernel when it
 // launches at least n workgroups (default 160: in-model per-launch timings at batch 32, tools/run_layer_compare.sh -- below that the direct implicit GEMM with its split-K
-// wins), the direct convolution otherwise; the 32-tile kernel only when pinned (mode 2; mode 3 pins the 64-tile one).
-static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g);
+// wins), the direct convolution otherwise; the first (32-tile x 64-channel) kernel only when pinned (mode 2; mode 3 pins conv_wino3_kernel, whose workgroup is 64 or 32 tiles
+// by workgroup count, wino3_eligible).
+static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh);
 bool conv_wino_eligible(const ConvArgs& a) {
     if (!g_wino_on || !a.wino_u || a.bf16) return false;
     if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.oy0 == 0 && a.ox0 == 0 && a.Hl == a.Ho && a.Wl == a.Wo)) return false;
     if (a.Cin % 16 != 0 || a.Cout % 32 != 0 || a.acc_lat) return false;
     if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
     if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
-    Wino2Geo g;
-    if (g_wino_on == 1) return wino3_eligible(a, g);
+    Wino2Geo g; int nh = 2;
+    if (g_wino_on == 1) return wino3_eligible(a, g, nh);
     const long tiles = (long)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2);
     const int cob = a.Cout % 64 == 0 ? 64 : 32;
     return ((tiles + WT - 1) / WT) * (a.Cout / cob) >= g_wino_min_blocks;
@@ -920,8 +938,8 @@ void launch_conv_wino(const ConvArgs& a_in, hipStream_t s) {
     const bool stats_ok = fuse && !a.bias && a.act == ACT_NONE && !a.accumulate && !a.dact_src;
     if (a.stats && !stats_ok) a.stats = nullptr;
     if (a.bst && !fuse) { a.bst = nullptr; a.bstB = nullptr; }
-    Wino2Geo g2;
-    if (wino3_eligible(a, g2)) launch_wino3(a, g2, s);
+    Wino2Geo g2; int nh = 2;
+    if (wino3_eligible(a, g2, nh)) launch_wino3(a, g2, nh, s);
     else if (a.Cout % 64 == 0) launch_wino_t<2>(a, s); else launch_wino_t<1>(a, s);
     View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
     if (a_in.stats && !a.stats) {

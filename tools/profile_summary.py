@@ -6,7 +6,7 @@
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE tallies a 128-B request of a wide coalesced read as 64 B, so reads are
 doubled (MI355X_MICROARCH.md, "HBM" section); the two counters do not fit one pass, hence two runs of the same command.
 """
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 
 
 def klass(name):
@@ -70,7 +70,7 @@ def pmc(df, dw, steps):
     if len(sys.argv) > 5:                       # machine-readable copy that bench.py reads for `roofline.traffic`
         import json
         w = [int(v) for v in sys.argv[6:11]]
-        json.dump({"command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
+        json.dump({"command": os.environ.get("MD2_PMC_COMMAND", "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra") + " (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)",
                    "workload": {"batch": w[0], "channels": w[1], "height": w[2], "width": w[3], "depth": w[4], "precision": sys.argv[11]},
                    "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 tallies 64 B per 128-B request) + WRITE_SIZE KiB x 1024, per launch", "bytes_per_launch": tab,
                    "bytes_per_step": {k: 2 * fe[k][1] * 1024 / steps + wr[k][1] * 1024 / steps for k in ("conv_igemm", "conv_wgrad", "loss_fwd", "loss_train", "other")}},
