@@ -982,7 +982,7 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
 static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
     long tiles128 = 0;
     for (int i = 0; i < n; ++i) { check_igemm_args(k.c[i]); tiles128 += (k.c[i].M + 127) / 128; }
-    static const long big = getenv("MD2_IGEMM_BIG_TILES") ? atol(getenv("MD2_IGEMM_BIG_TILES")) : 3000;
+    static const long big = getenv("MD2_IGEMM_BIG_TILES") ? atol(getenv("MD2_IGEMM_BIG_TILES")) : (1L << 40);          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
     if (tiles128 * (k.c[0].Cout / 64) >= big) launch_classes_t<128>(k, n, s); else launch_classes_t<64>(k, n, s);
 }
 
@@ -1091,7 +1091,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 #endif
     // 64x64 tiles (5 blocks per CU) balance the 256 CUs better than 128x64 (3 per CU) on every encoder layer at batch 32 (624 .. 2496 tiles: 1.6 .. 3.25 rounds of 768
     // resident 128x64 blocks) and are never slower there (tools/conv_bench, round 2: 87.8 / 92.5 / 93.5 / 81.2 vs 87.2 / 91.4 / 85.2 / 65.1 TFLOP/s on the four stage shapes)
-    static const long big = getenv("MD2_IGEMM_BIG_TILES") ? atol(getenv("MD2_IGEMM_BIG_TILES")) : 3000;
+    static const long big = getenv("MD2_IGEMM_BIG_TILES") ? atol(getenv("MD2_IGEMM_BIG_TILES")) : (1L << 40);          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
     if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }

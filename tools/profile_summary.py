@@ -11,10 +11,10 @@ import csv, glob, os, sys, collections
 
 def klass(name):
     # the classes bench.py's HIP-event profile uses: forward + input-gradient convolutions / weight gradients (incl. the direct stem kernels)
+    if "conv_wgrad_kernel" in name or "conv_wino_wgrad" in name or "conv3x3_wgrad" in name or "stem_wgrad_kernel" in name:
+        return "conv_wgrad"
     if "conv_igemm" in name or "conv_wino" in name or "conv3x3_patch_kernel" in name or "stem_fwd_kernel" in name:
         return "conv_igemm"
-    if "conv_wgrad_kernel" in name or "conv3x3_wgrad" in name or "stem_wgrad_kernel" in name:
-        return "conv_wgrad"
     if "loss_fwd_kernel" in name:
         return "loss_fwd"
     if "loss_train_kernel" in name or "loss_bwd_kernel" in name:
