@@ -794,6 +794,17 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
             g_create_err = "md2_create: batch x resolution too large for one handle (an activation tensor must stay below 4 GiB and 2^24 pixels); use a smaller per-GPU batch"; return 2;
         }
     }
+    {   // TrainCache.target_id / source_ids and DepthDecoder scale_levels: pure argument checks, before anything touches the device
+        const int t = cfg->target_id ? cfg->target_id : 2, s0 = cfg->source_ids[0] ? cfg->source_ids[0] : (cfg->source_ids[1] ? 0 : 1), s1 = cfg->source_ids[1] ? cfg->source_ids[1] : (cfg->source_ids[0] ? 0 : 3);
+        if (t < 1 || t > 3 || s0 < 1 || s0 > 3 || s1 < 1 || s1 > 3 || s0 == s1 || s0 == t || s1 == t) { g_create_err = "md2_create: target_id / source_ids must be three distinct frames of the triplet (1..3), two of them sources"; return 2; }
+        bool ended = false;
+        for (int i = 0; i < 5; ++i) {
+            const int l = cfg->scale_levels[i];
+            if (l == 0) { ended = true; continue; }
+            if (ended || l < 1 || l > 5 || (i && l <= cfg->scale_levels[i - 1])) { g_create_err = "md2_create: `scale_levels` should be at most of length 5, ascending, with values in [1, 5] (0-terminated)"; return 2; }
+        }
+        for (int i = 0; i < 5; ++i) if (cfg->scales[i] < 0.0) { g_create_err = "md2_create: `scales` must be non-negative (0 = the default 1 / 2^(5 - level))"; return 2; }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "md2_create: no HIP device (libmd2hip needs an MI355X; there is no CPU fallback)"; return 3; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "md2_create: hipSetDevice failed"; return 3; }
@@ -801,16 +812,14 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     md2_handle* h = new md2_handle();
     h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width; h->net_ok = net_ok;
     h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision == 1;
-    {   // TrainCache.target_id / source_ids (1-based at the boundary)
+    {   // TrainCache.target_id / source_ids (1-based at the boundary; validated above)
         const int t = cfg->target_id ? cfg->target_id : 2, s0 = cfg->source_ids[0] ? cfg->source_ids[0] : (cfg->source_ids[1] ? 0 : 1), s1 = cfg->source_ids[1] ? cfg->source_ids[1] : (cfg->source_ids[0] ? 0 : 3);
-        if (t < 1 || t > 3 || s0 < 1 || s0 > 3 || s1 < 1 || s1 > 3 || s0 == s1 || s0 == t || s1 == t) { g_create_err = "md2_create: target_id / source_ids must be three distinct frames of the triplet (1..3), two of them sources"; delete h; return 2; }
         h->tgt = t - 1; h->src[0] = s0 - 1; h->src[1] = s1 - 1;
         // DepthDecoder scale_levels / TrainCache.scales (all zero: 2:5 and 1 / 2^(5 - level), src/Monodepth.jl:106-107)
         if (cfg->scale_levels[0]) {
             h->ns = 0; for (int b = 0; b < 5; ++b) h->out_of[b] = -1;
             for (int i = 0; i < 5 && cfg->scale_levels[i]; ++i) {
                 const int l = cfg->scale_levels[i];
-                if (l < 1 || l > 5 || (i && l <= h->lv[i - 1])) { g_create_err = "md2_create: `scale_levels` should be at most of length 5, ascending, with values in [1, 5]"; delete h; return 2; }
                 h->lv[i] = l; h->out_of[l - 1] = i; h->ns = i + 1;
             }
             h->nbr = h->lv[h->ns - 1];

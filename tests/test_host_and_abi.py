@@ -57,6 +57,58 @@ def test_config_validation_messages():
     assert L.md2_create(ctypes.byref(bad), ctypes.byref(h)) == 2
 
 
+def test_config_struct_layout_matches_the_header():
+    """md2_config crosses the boundary by pointer: the ctypes mirror (and through it the generated Julia struct) must have the C layout of include/md2hip.h -- size and every
+    field offset, checked against what gcc computes for the header."""
+    import subprocess, tempfile
+    C = md2amd._lib.Md2Config
+    fields = [f[0] for f in C._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "md2hip.h"\nint main(void) { printf("%zu", sizeof(md2_config));' + \
+          "".join(' printf(" %%zu", offsetof(md2_config, %s));' % f for f in fields) + ' return 0; }\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).split()]
+    assert out[0] == ctypes.sizeof(C)
+    assert out[1:] == [getattr(C, f).offset for f in fields]
+    jl = open(os.path.join(ROOT, "monodepth2.jl_amd", "julia", "Monodepth2HIP.jl")).read()
+    struct = jl[jl.index("struct MD2Config"):jl.index("\nend", jl.index("struct MD2Config"))]
+    decl = re.findall(r"(\w+)::([\w{}, ]+?)(?:;|\s*#|\n)", struct)
+    jl_types = {"Int32": ctypes.c_int32, "Float64": ctypes.c_double, "NTuple{5, Int32}": ctypes.c_int32 * 5, "NTuple{5, Float64}": ctypes.c_double * 5}
+    flat = []                                                  # the Julia struct spells source_ids as two Int32 fields: flatten both sides to scalar types
+    for _, t in decl:
+        ct = jl_types[t.strip()]
+        flat += [ct._type_] * ct._length_ if hasattr(ct, "_length_") else [ct]
+    cflat = []
+    for _, ct in C._fields_:
+        cflat += [ct._type_] * ct._length_ if hasattr(ct, "_length_") else [ct]
+    assert flat == cflat                                       # same scalar sequence => same C layout (isbits struct, natural alignment)
+
+
+def test_frame_roles_and_scale_levels_are_validated_before_the_device():
+    """TrainCache.target_id / source_ids and DepthDecoder(; scale_levels) (src/Monodepth.jl:44-55, src/depth_decoder.jl:27-29): bad values are refused with status 2 and a message."""
+    L = md2amd._lib.lib(); h = ctypes.c_void_p(); M = md2amd._lib.Md2Config
+    def create(tid=0, sids=(0, 0), levels=(), scales=()):
+        cfg = M(1, 1, 64, 96, 0, 0, 0.1, 100.0, 1e-3, 1e-4, 18, 0, tid, (ctypes.c_int32 * 2)(*sids), (ctypes.c_int32 * 5)(*levels), (ctypes.c_double * 5)(*scales))
+        return L.md2_create(ctypes.byref(cfg), ctypes.byref(h)), L.md2_last_error(None)
+    for kw in (dict(tid=2, sids=(2, 3)), dict(tid=4, sids=(1, 3)), dict(tid=1, sids=(3, 3)), dict(tid=1, sids=(0, 3))):
+        rc, msg = create(**kw); assert rc == 2 and b"source_ids" in msg, kw
+    for lv in ((0, 2), (3, 2), (2, 2), (6,), (1, 2, 3, 4, 7)):
+        rc, msg = create(levels=lv); assert rc == 2 and b"scale_levels" in msg, lv
+    rc, msg = create(levels=(2, 3), scales=(0.5, -1.0)); assert rc == 2 and b"scales" in msg
+    for kw in (dict(), dict(tid=1, sids=(2, 3)), dict(tid=3, sids=(2, 1)), dict(levels=(1, 2, 3, 4, 5)), dict(levels=(5,)), dict(levels=(1, 3, 4), scales=(0.3, 0.7, 1.1))):
+        rc, msg = create(**kw); assert rc in (0, 3), (kw, msg)                 # valid arguments: only the missing device (3) may stop a CPU-only box
+        if rc == 0:
+            L.md2_destroy(h)
+    md = md2amd.monodepth
+    with pytest.raises(ValueError):
+        md.DepthDecoder([64, 64, 128, 256, 512], [3, 2])                      # ascending, like the reference's constructor walks them
+    assert md.DepthDecoder([64, 64, 128, 256, 512], [1, 3, 4]).scale_levels == [1, 3, 4]
+    for levels in ((1, 3, 4), (1, 2, 3, 4, 5), (5,)):                          # parameter count / order of a decoder with other levels: Python layout == oracle
+        lay = oracle.OracleNet(1, scale_levels=levels).layout(); pl = syn.param_layout(1, 18, levels)
+        assert [(c) for (_, c, _) in lay] == [int(np.prod(s_)) for (_, _, s_) in pl] and sum(c for _, c, _ in lay) == syn.num_params(1, 18, levels)
+
+
 def test_reference_surface_errors():
     md = md2amd.monodepth
     with pytest.raises(ValueError):                          # src/depth_decoder.jl:27-29
