@@ -344,6 +344,23 @@ def main():
                 md.train_step(m7, x7, None, c7, p7, True)
             torch.cuda.synchronize(); d7 = time.perf_counter() - t0
             extra["headline_shape_bf16_mixed"] = {"value": B * n7 / d7, "unit": "triplets/s", "ms_per_step": d7 / n7 * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate"}
+            # and with the forward / input-gradient 3x3 convolutions in "split" mode (md.set_winograd(4)): every fp32 operand as hi + lo bf16 pieces, three bf16 MFMAs per product
+            # group -- fp32 storage and accumulation, ~17-bit operand mantissas: forward + loss stay within the 1e-4 parity bound (tests), gradients are ~5x noisier than with
+            # the fp32 MFMA.  Opt-in; `value` above is measured with the fp32 MFMA.
+            del m7, x7
+            torch.cuda.empty_cache()
+            md.set_winograd(4)
+            m8, p8, c8, x8 = setup(B)
+            for _ in range(3):
+                md.train_step(m8, x8, None, c8, p8, True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            n8 = 10
+            for _ in range(n8):
+                md.train_step(m8, x8, None, c8, p8, True)
+            torch.cuda.synchronize(); d8 = time.perf_counter() - t0
+            md.set_winograd(True)
+            extra["headline_shape_split_bf16x3"] = {"value": B * n8 / d8, "unit": "triplets/s", "ms_per_step": d8 / n8 * 1e3,
+                                                    "dtype": "fp32 storage / accumulation; 3x3 stride-1 forward + input-gradient products as 3 bf16 MFMAs on hi/lo operand pieces (opt-in)"}
         out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W)

@@ -50,9 +50,20 @@ __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
 constexpr int WT = 32;                       // Winograd tiles per block
 constexpr int W_STAGE = 16 * WT * 16;        // floats per LDS stage (32 KB)
 
+// split mode (conv_wino3s_kernel): the same (G g G^T)[i][j] as two bf16 pieces, u = hi + lo, in the A-operand layout of v_mfma_f32_32x32x16_bf16 --
+// [Cout/32][4 (i)][Cin/16][4 (j)][2 (hi, lo)][64 lanes][8]: lane l, element e = (co = 32 ct + (l & 31), ci = 16 c16 + 8 (l >> 5) + e).  Same byte count as the fp32 fragments.
+__device__ __forceinline__ void wino_store_split(float* __restrict__ U, int ct, int i, int j, int Cin, int ci, int co_lo, const float4& u) {
+    typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+    b4 hi, lo;
+    hi[0] = (__bf16)u.x; hi[1] = (__bf16)u.y; hi[2] = (__bf16)u.z; hi[3] = (__bf16)u.w;
+    lo[0] = (__bf16)(u.x - (float)hi[0]); lo[1] = (__bf16)(u.y - (float)hi[1]); lo[2] = (__bf16)(u.z - (float)hi[2]); lo[3] = (__bf16)(u.w - (float)hi[3]);
+    const int c16 = ci >> 4, g = (ci >> 3) & 1, e0 = ci & 4;
+    __bf16* base = reinterpret_cast<__bf16*>(U) + ((((long)(ct * 4 + i) * (Cin >> 4) + c16) * 4 + j) * 2) * 512 + (co_lo + 32 * g) * 8 + e0;
+    *reinterpret_cast<b4*>(base) = hi; *reinterpret_cast<b4*>(base + 512) = lo;
+}
 // ---- weights: w [Cout][9][Cin] (cross-correlation taps, tap = kh*3 + kw) -> U fragments [Cout/32][4 (i)][Cin/8][4 (j)][64 lanes][4]:
 //      lane l, element e of fragment (ct, i, c8, j) = (G g G^T)[i][j] of (co = 32 ct + (l & 31), ci = 8 c8 + 4 (l >> 5) + e)
-__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int split) {
     const int gid = blockIdx.x * 256 + threadIdx.x;          // (ci quad, co): co fastest within 32 so that the 16-B stores of a half-wave are contiguous
     const int co_lo = gid & 31, rest = gid >> 5;
     const int nq = Cin >> 2;
@@ -80,16 +91,18 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
         u[1] = make_float4(0.5f * (a.x + b.x + d.x), 0.5f * (a.y + b.y + d.y), 0.5f * (a.z + b.z + d.z), 0.5f * (a.w + b.w + d.w));
         u[2] = make_float4(0.5f * (a.x - b.x + d.x), 0.5f * (a.y - b.y + d.y), 0.5f * (a.z - b.z + d.z), 0.5f * (a.w - b.w + d.w));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<float4*>(U + ((((long)(ct * 4 + i) * (Cin >> 3) + c8) * 4 + j) * 64 + (co_lo + 32 * h)) * 4) = u[j];
+        for (int j = 0; j < 4; ++j) {
+            if (split) wino_store_split(U, ct, i, j, Cin, ci, co_lo, u[j]);
+            else *reinterpret_cast<float4*>(U + ((((long)(ct * 4 + i) * (Cin >> 3) + c8) * 4 + j) * 64 + (co_lo + 32 * h)) * 4) = u[j];
+        }
     }
 }
 void launch_wino_weights(const float* w, float* U, int Cout, int Cin, hipStream_t s) {
     const long n = (long)(Cout / 32) * (Cin / 4) * 32;
-    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, U, Cout, Cin);
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, U, Cout, Cin, g_wino_on == 4 ? 1 : 0);
 }
 // all eligible layers of a handle in one launch: desc = {w offset, U offset, Cout, Cin} per layer, block ranges by prefix sums in `first`
-__global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* __restrict__ wbase, float* __restrict__ Ubase, const long* __restrict__ desc, int nlayers) {
+__global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* __restrict__ wbase, float* __restrict__ Ubase, const long* __restrict__ desc, int nlayers, int split) {
     int b = blockIdx.x, l = 0;
     for (; l < nlayers; ++l) { const long nb = desc[l * 5 + 4]; if (b < nb) break; b -= (int)nb; }
     if (l >= nlayers) return;
@@ -121,13 +134,15 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
         u[1] = make_float4(0.5f * (a.x + bb.x + d.x), 0.5f * (a.y + bb.y + d.y), 0.5f * (a.z + bb.z + d.z), 0.5f * (a.w + bb.w + d.w));
         u[2] = make_float4(0.5f * (a.x - bb.x + d.x), 0.5f * (a.y - bb.y + d.y), 0.5f * (a.z - bb.z + d.z), 0.5f * (a.w - bb.w + d.w));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<float4*>(U + ((((long)(ct * 4 + i) * (Cin >> 3) + c8) * 4 + j) * 64 + (co_lo + 32 * h)) * 4) = u[j];
+        for (int j = 0; j < 4; ++j) {
+            if (split) wino_store_split(U, ct, i, j, Cin, ci, co_lo, u[j]);
+            else *reinterpret_cast<float4*>(U + ((((long)(ct * 4 + i) * (Cin >> 3) + c8) * 4 + j) * 64 + (co_lo + 32 * h)) * 4) = u[j];
+        }
     }
 }
 void launch_wino_weights_batched(const float* wbase, float* Ubase, const long* desc_dev, int nlayers, int total_blocks, hipStream_t s) {
     if (nlayers <= 0 || total_blocks <= 0) return;
-    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, s, wbase, Ubase, desc_dev, nlayers);
+    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, s, wbase, Ubase, desc_dev, nlayers, g_wino_on == 4 ? 1 : 0);
 }
 long wino_weight_blocks(int Cout, int Cin) { return ((long)(Cout / 32) * (Cin / 4) * 32 + 255) / 256; }
 
@@ -629,6 +644,171 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvAr
     wino_final_epilogue<256, COB, BST>(a, wsm, m0, WT, Mt, THW, TW, c0, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same convolution with the multiplications on the bf16 matrix pipe at fp32 accuracy ("split" mode, md2_set_winograd(on = 4)): every fp32 operand is the exact sum of
+// bf16 pieces, u = u_hi + u_lo (+ 2^-17 |u|), v = v_hi + v_lo, and  u v = u_hi v_hi + u_hi v_lo + u_lo v_hi  up to 2^-16 |u v| -- three v_mfma_f32_32x32x16_bf16 (fp32
+// accumulation, products of bf16 pairs are exact in fp32) instead of eight v_mfma_f32_32x32x2_f32 per 16 channels: 96 instead of 512 matrix-pipe cycles.  More important
+// than the cycle count: profiles/r03_wino3_pmc.md shows SQ_VALU_MFMA_COEXEC_CYCLES = 0 for the fp32 MFMA -- it shares its issue with every vector instruction of the SIMD --
+// whereas the bf16 MFMA is an XDL op that runs beside the other wave's transforms, masks and address arithmetic.  The pieces of V are formed in registers right after the input
+// transform (v_cvt_pk_bf16_f32 + one subtraction per value); the pieces of U are written by the weight transform (same bytes as the fp32 U: 2 x bf16).
+// Workgroup = 32 tiles x 32 channels, 16-channel chunks staged as two 8-channel planes with the layout of conv_wino3_kernel (lane = tile, k-group = plane).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_bf16(const float4& v, wbf16x4& hi, wbf16x4& lo) {
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]); lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+template <int XF, int BST>
+__global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Geo geo) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int COB = 32, WT = 32, NLI = 6;
+    constexpr int PL = 128 * 3 * 8;                  // floats per 8-channel plane (384 slots), two planes per stage
+    constexpr int PST = 2 * PL;
+    const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_p = bid % ntp, tile_c = bid / ntp;
+    const int m0 = tile_p * WT, c0 = tile_c * COB;
+    const int THW = TH * TW;
+    const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
+    const int L0 = min(TW - tx0, WT);
+    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, WT), S = 4 * (2 * Lf + 2);
+    const int n_rows_total = a.N * TH;
+
+    // ---- loader: item f = tid + 256 li = (slot f >> 2, 16-B piece f & 3 of the 16 channels); piece >> 1 = plane, piece & 1 = half inside the plane's 8-float slot
+    unsigned l_off[NLI]; unsigned l_ok = 0;
+    const int piece = tid & 3, pl = piece >> 1, h2 = piece & 1;
+    const int l_dst0 = pl * PL + (tid >> 2) * 8 + ((h2 ^ ((tid >> 5) & 1)) << 2);          // + li * 512 floats (64 slots)
+#pragma unroll
+    for (int li = 0; li < NLI; ++li) {
+        const int slot = (tid + 256 * li) >> 2;
+        int k, r, WP, txa, Lk;
+        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
+        else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }
+        const int pa = fdiv24(r, WP), pc = r - pa * WP;
+        const int rr = rr_first + k;
+        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+        const int rrc = act ? rr : 0;
+        const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
+        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+        bool ok = act;
+        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        l_ok |= ok ? (1u << li) : 0u;
+        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(piece * 4)) * 4u : (unsigned)(piece * 16);
+    }
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    uint4 ra[NLI];
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 64)));
+        if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 16 + piece * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 16 + piece * 4); }
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            const unsigned mk = 0u - ((l_ok >> li) & 1u);
+            uint4 v = ra[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            if constexpr (XF != 0) {
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
+            }
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 512) = v;
+        }
+    };
+
+    // ---- consumer: lane = (tile, k-group g = plane); B^T row i combines patch rows (r1, r2); the lane's 8 channels are the plane's two 16-B pieces
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int tl = lane & 31, g = lane >> 5;
+    int c_off1[4], c_off2[4];          // piece 0 of the slot; piece 1 is at (offset ^ 4)
+    {
+        const int u = tx0 + tl, k = fdiv24(u, TW);
+        const int lc = (k == 0) ? tl : (u - k * TW);
+        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, WT - L0 - (k - 1) * TW) + 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
+            c_off1[b] = g * PL + sl1 * 8 + (((sl1 >> 3) & 1) << 2);
+            c_off2[b] = g * PL + sl2 * 8 + (((sl2 >> 3) & 1) << 2);
+        }
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // U stream of this wave: chunk c16, position j: hi fragment at ub + ((c16 * 4 + j) * 2) * 512 bf16, lo fragment 512 bf16 further (64 lanes x 8)
+    const int nchunks = a.Cin >> 4;
+    const __bf16* ub = reinterpret_cast<const __bf16*>(a.wino_u) + ((long)(tile_c * 4 + wi) * nchunks) * 4 * 1024 + lane * 8;
+    wbf16x8 uh0 = *reinterpret_cast<const wbf16x8*>(ub), ul0 = *reinterpret_cast<const wbf16x8*>(ub + 512);
+    wbf16x8 uh1 = *reinterpret_cast<const wbf16x8*>(ub + 1024), ul1 = *reinterpret_cast<const wbf16x8*>(ub + 1536);
+    wbf16x8 uh2 = *reinterpret_cast<const wbf16x8*>(ub + 2048), ul2 = *reinterpret_cast<const wbf16x8*>(ub + 2560);
+    wbf16x8 uh3 = *reinterpret_cast<const wbf16x8*>(ub + 3072), ul3 = *reinterpret_cast<const wbf16x8*>(ub + 3584);
+
+    gload(0); lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int so = (c & 1) * PST;
+        const int cn = min(c + 1, nchunks - 1);
+        const __bf16* un = ub + (long)cn * 4096;
+        gload(cn);
+        __builtin_amdgcn_sched_barrier(0);
+        wbf16x4 vh[4][2], vl[4][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float4 rr[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + (c_off1[b] ^ (p << 2)));
+                const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + (c_off2[b] ^ (p << 2)));
+                rr[b] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+            }
+            split_bf16(make_float4(rr[0].x - rr[2].x, rr[0].y - rr[2].y, rr[0].z - rr[2].z, rr[0].w - rr[2].w), vh[0][p], vl[0][p]);
+            split_bf16(make_float4(rr[1].x + rr[2].x, rr[1].y + rr[2].y, rr[1].z + rr[2].z, rr[1].w + rr[2].w), vh[1][p], vl[1][p]);
+            split_bf16(make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w), vh[2][p], vl[2][p]);
+            split_bf16(make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w), vh[3][p], vl[3][p]);
+        }
+#define W3S_MFMA(j_, uh_, ul_) do { \
+            const wbf16x8 bh = __builtin_shufflevector(vh[j_][0], vh[j_][1], 0, 1, 2, 3, 4, 5, 6, 7), bl = __builtin_shufflevector(vl[j_][0], vl[j_][1], 0, 1, 2, 3, 4, 5, 6, 7); \
+            acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul_, bh, acc[j_], 0, 0, 0); \
+            acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh_, bl, acc[j_], 0, 0, 0); \
+            acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh_, bh, acc[j_], 0, 0, 0); } while (0)
+        // (small terms first; the refills go in place right behind a fragment pair's use, as in conv_wino3_kernel)
+        W3S_MFMA(0, uh0, ul0); uh0 = *reinterpret_cast<const wbf16x8*>(un); ul0 = *reinterpret_cast<const wbf16x8*>(un + 512); __builtin_amdgcn_sched_barrier(0);
+        W3S_MFMA(1, uh1, ul1); uh1 = *reinterpret_cast<const wbf16x8*>(un + 1024); ul1 = *reinterpret_cast<const wbf16x8*>(un + 1536); __builtin_amdgcn_sched_barrier(0);
+        W3S_MFMA(2, uh2, ul2); uh2 = *reinterpret_cast<const wbf16x8*>(un + 2048); ul2 = *reinterpret_cast<const wbf16x8*>(un + 2560); __builtin_amdgcn_sched_barrier(0);
+        W3S_MFMA(3, uh3, ul3); uh3 = *reinterpret_cast<const wbf16x8*>(un + 3072); ul3 = *reinterpret_cast<const wbf16x8*>(un + 3584);
+#undef W3S_MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(PST - so);
+        __syncthreads();
+    }
+
+    // ---- output transform: column half in registers, row half through LDS (R[i][b][32 tiles][COB + 4]) -- as conv_wino3_kernel
+    constexpr int RLD = COB + 4;
+    float* Rl = wsm;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        float4 o0, o1;
+        o0.x = acc[0][4 * gq + 0] + acc[1][4 * gq + 0] + acc[2][4 * gq + 0]; o1.x = acc[1][4 * gq + 0] - acc[2][4 * gq + 0] - acc[3][4 * gq + 0];
+        o0.y = acc[0][4 * gq + 1] + acc[1][4 * gq + 1] + acc[2][4 * gq + 1]; o1.y = acc[1][4 * gq + 1] - acc[2][4 * gq + 1] - acc[3][4 * gq + 1];
+        o0.z = acc[0][4 * gq + 2] + acc[1][4 * gq + 2] + acc[2][4 * gq + 2]; o1.z = acc[1][4 * gq + 2] - acc[2][4 * gq + 2] - acc[3][4 * gq + 2];
+        o0.w = acc[0][4 * gq + 3] + acc[1][4 * gq + 3] + acc[2][4 * gq + 3]; o1.w = acc[1][4 * gq + 3] - acc[2][4 * gq + 3] - acc[3][4 * gq + 3];
+        const int col = 8 * gq + 4 * g;
+        *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * WT + tl) * RLD + col) = o0;
+        *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * WT + tl) * RLD + col) = o1;
+    }
+    __syncthreads();
+    wino_final_epilogue<256, COB, BST>(a, wsm, m0, WT, Mt, THW, TW, c0, tid);
+}
+
 // patch slots a block can need at tile-row width TW: worst case over the position of its first tile
 static int wino2_slots(int TW, int T = W2_T) {
     const int Lf = std::min(TW, T), S = 4 * (2 * Lf + 2);
@@ -655,6 +835,7 @@ static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
     // workgroup for launches with at least n of them
     static const long small = getenv("MD2_WINO_SMALL_BLOCKS") ? atol(getenv("MD2_WINO_SMALL_BLOCKS")) : (1L << 40);
     nh = g_wino_nh == 1 ? 1 : (g_wino_nh == 2 ? 2 : (b64 < small ? 1 : 2));
+    if (g_wino_on == 4) { if (!ok32 || a.Cin % 16 != 0) return false; nh = 1; }          // split mode: conv_wino3s_kernel (32 tiles, 16-channel chunks) or the direct convolution
     if (nh == 1 && !ok32) nh = 2;
     if (nh == 2 && !ok64) nh = 1;
     const int T = 32 * nh;
@@ -679,7 +860,24 @@ static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) 
     else if (a.bst) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 1, NH>), dim3(grid), dim3(256), lds, s, a, g);
     else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0, NH>), dim3(grid), dim3(256), lds, s, a, g);
 }
-static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) { if (nh == 1) launch_wino3_t<3, 1>(a, g, s); else launch_wino3_t<5, 2>(a, g, s); }
+static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * 2 * 128 * 3 * 8 * sizeof(float);          // two stages of two 8-channel planes (48 KB) > the epilogue's 36 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = g.ntp * (a.Cout / 32);
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino3s_kernel<1, 0>), dim3(grid), dim3(256), lds, s, a, g);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino3s_kernel<0, 1>), dim3(grid), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino3s_kernel<0, 0>), dim3(grid), dim3(256), lds, s, a, g);
+}
+static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) {
+    if (g_wino_on == 4) launch_wino3s(a, g, s);
+    else if (nh == 1) launch_wino3_t<3, 1>(a, g, s); else launch_wino3_t<5, 2>(a, g, s);
+}
 
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -781,6 +979,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][m][e] = 0.f;
     float2 bsum = make_float2(0.f, 0.f);
+    const bool do_bias = a.db && tile_ci == 0 && wi == 0;
 
     if (b_lo < b_hi) {
         gload(b_lo); lstore(0);
@@ -791,14 +990,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
             gload(bn);
             __builtin_amdgcn_sched_barrier(0);
             const int bq = b % geo.BPR, L = min(WG_TB, TW - bq * WG_TB), nk = (L + 1) >> 1;
-            for (int k = 0; k < nk; ++k) {
+            auto kstep = [&](const int k) {
                 const float* xs = wsm + so + k * (4 * 32);
                 const float* ds = wsm + so + dyo + k * (8 * 64);
                 const float2 y00 = *reinterpret_cast<const float2*>(ds), y01 = *reinterpret_cast<const float2*>(ds + 64), y10 = *reinterpret_cast<const float2*>(ds + 128), y11 = *reinterpret_cast<const float2*>(ds + 192);
                 float xv1[4], xv2[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { xv1[c] = xs[xo1 + c * 32]; xv2[c] = xs[xo2 + c * 32]; }
-                bsum.x += (y00.x + y01.x) + (y10.x + y11.x); bsum.y += (y00.y + y01.y) + (y10.y + y11.y);
+                if (do_bias) { bsum.x += (y00.x + y01.x) + (y10.x + y11.x); bsum.y += (y00.y + y01.y) + (y10.y + y11.y); }          // (wave-uniform: one wave of one block column)
                 // dM_(i, 0..3) of both channels
                 const float p0x = ca * y00.x + cb * y10.x, p1x = ca * y01.x + cb * y11.x, p0y = ca * y00.y + cb * y10.y, p1y = ca * y01.y + cb * y11.y;
                 const float mx[4] = {p0x, p0x + p1x, p0x - p1x, -p1x}, my[4] = {p0y, p0y + p1y, p0y - p1y, -p1y};
@@ -812,7 +1011,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
                     acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(mx[j], V[j], acc[j][0], 0, 0, 0);
                     acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(my[j], V[j], acc[j][1], 0, 0, 0);
                 }
-            }
+            };
+            for (int k = 0; k < nk; ++k) kstep(k);
             __builtin_amdgcn_sched_barrier(0);
             lstore(WG_STAGE - so);
             __syncthreads();
@@ -849,7 +1049,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
         }
     }
     // bias gradient: wave 0 of the block column with input-channel tile 0 (every wave read the same dy)
-    if (a.db && tile_ci == 0 && wi == 0) {
+    if (do_bias) {
         bsum.x += __shfl_xor(bsum.x, 32); bsum.y += __shfl_xor(bsum.y, 32);
         if (lh == 0) { atomicAdd(a.db + co0 + 2 * lr, bsum.x); atomicAdd(a.db + co0 + 2 * lr + 1, bsum.y); }
     }
@@ -864,7 +1064,7 @@ bool conv_wino_wgrad_eligible(const WgradArgs& a) {
     if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
     const long x_bytes = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), dy_bytes = 4 * ((long)a.N * a.dy_bs + (long)a.Ho * a.Wo * a.dy_ps);
     if (a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || x_bytes >= (1L << 32) || dy_bytes >= (1L << 32)) return false;
-    return g_wino_on >= 2 || a.M >= min_m;
+    return g_wino_on == 2 || g_wino_on == 3 || a.M >= min_m;
 }
 void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     WinoWgGeo g;
@@ -901,7 +1101,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
     if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
     Wino2Geo g; int nh = 2;
-    if (g_wino_on == 1) return wino3_eligible(a, g, nh);
+    if (g_wino_on == 1 || g_wino_on == 4) return wino3_eligible(a, g, nh);
     const long tiles = (long)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2);
     const int cob = a.Cout % 64 == 0 ? 64 : 32;
     return ((tiles + WT - 1) / WT) * (a.Cout / cob) >= g_wino_min_blocks;

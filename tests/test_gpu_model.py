@@ -977,3 +977,29 @@ def test_depth_decoder_scale_levels_vs_oracle(levels, scales, automask):
     assert_grads_match(model.grads(), net.get_grads(), C, allow=last if automask else (), tag="levels %s" % (levels,), levels=levels)
     gh = model.grads(); m.update(m.ADAM(1e-3), model); net.set_grads(gh); net.adam_step(1e-3)          # same gradients in: the update over this parameter layout must agree tightly
     assert rel(model.params() - theta, net.get_params() - theta) < 5e-3
+
+
+def test_split_bf16_winograd_mode_stays_inside_the_parity_bound():
+    """md.set_winograd(4): the 3x3 / stride-1 forward and input-gradient convolutions multiply hi + lo bf16 pieces of their fp32 operands on the bf16 matrix pipe (three MFMAs per
+    product group, fp32 accumulation).  Opt-in; the statement that makes it usable: at BASELINE config #2 (416x128, B=4) disparities, poses and loss stay within 1e-4 of the
+    oracle and every gradient array within the general bound -- and the default mode is an order of magnitude closer, which is why it stays the default."""
+    N, C, H, W = 4, 1, 128, 416
+    m = md()
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=7)
+    x = syn.synthetic_triplets(N, C, H, W, seed=8); xd = dev(x)
+    cfg = oracle.make_cfg(N, C, H, W, K, iK)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    dso, rvo, tvo = net.model_forward(x, cfg); lo = net.train_loss(x, cfg, None, True); go = net.get_grads()
+    worst = {}
+    try:
+        for mode in (4, 1):
+            m.set_winograd(mode)
+            ds, poses = model(xd, [1, 3], 2)
+            worst[mode] = max(rel(host(d), o) for d, o in zip(ds, dso))
+            assert worst[mode] < 1e-4 and rel(host(poses[0].rvec), rvo[0]) < 1e-4 and rel(host(poses[1].tvec), tvo[1]) < 1e-4
+            loss = m.train_step(model, xd, None, cache, params, do_update=False)
+            assert abs(float(loss) - lo) / lo < 1e-4
+            assert_grads_match(model.grads(), go, C, tag="winograd mode %d" % mode)
+    finally:
+        m.set_winograd(True)
+    assert worst[1] < 2e-5 and worst[1] < worst[4]
