@@ -106,9 +106,12 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host_state, int64_t n);
  * BatchNorm / bias sums.  Process-wide, much slower; for bisecting parity failures. */
 int32_t md2_set_deterministic(int32_t on);
 /* Algorithm choice for the 3x3 / stride-1 convolutions (the reference leaves it to cuDNN behind Flux `Conv`, src/depth_decoder.jl:13-14): on = 1 (default) routes launches
- * with at least min_blocks workgroups (default 160; < 0 keeps the current value) to the fused Winograd F(2x2,3x3) kernels, on = 0 forces the direct implicit GEMM;
- * on = 2 / 3 pin one of the two Winograd kernels (32 tiles x 64 channels per workgroup; 64 tiles x 32 channels) wherever it applies (tests, tuning).
- * Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MIN_BLOCKS in the environment at load time. */
+ * with at least min_blocks workgroups (default 96 64-tile equivalents; < 0 keeps the current value) to the fused Winograd F(2x2,3x3) kernels, on = 0 forces the direct
+ * implicit GEMM; on = 2 / 3 pin one of the two fp32 Winograd kernels wherever it applies (tests, tuning).
+ * on = 4 (opt-in, "split" mode): the forward / input-gradient Winograd products run on the bf16 matrix pipe at close-to-fp32 accuracy -- every fp32 operand is split into
+ * hi + lo bf16 pieces and each product group takes three v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~17-bit operand mantissas; storage, transforms and everything
+ * else stay fp32).  Forward + loss stay inside the 1e-4 parity bound, gradients are ~5x noisier than with the fp32 MFMA; 1.3-1.5x faster on those launches.
+ * Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks);
 /* ADAM moments (Flux parameter layout, host) + running beta powers: the optimiser state the reference's BSON checkpoints
  * (src/Monodepth.jl:191-194) omit; with md2_params_get/set this gives true resume. */
