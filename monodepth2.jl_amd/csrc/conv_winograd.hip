@@ -655,9 +655,16 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvAr
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void split_bf16(const float4& v, wbf16x4& hi, wbf16x4& lo) {
-    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]); lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+// two fp32 values -> one register of two bf16 (round to nearest even), a in the low half: spelled as the instruction because hipcc converts the lanes of a bf16 vector one by one
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// (a, b) = hi + lo up to 2^-17: six vector instructions per pair
+__device__ __forceinline__ void split_pk(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = cvt_pk_bf16(a, b);
+    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ void split_bf16(const float4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
+    split_pk(v.x, v.y, hi[0], lo[0]); split_pk(v.z, v.w, hi[1], lo[1]);
 }
 template <int XF, int BST>
 __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Geo geo) {
@@ -760,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
         const __bf16* un = ub + (long)cn * 4096;
         gload(cn);
         __builtin_amdgcn_sched_barrier(0);
-        wbf16x4 vh[4][2], vl[4][2];
+        unsigned vh[4][2][2], vl[4][2][2];          // [position][piece of 4 channels][register]
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             float4 rr[4];
@@ -776,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
             split_bf16(make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w), vh[3][p], vl[3][p]);
         }
 #define W3S_MFMA(j_, uh_, ul_) do { \
-            const wbf16x8 bh = __builtin_shufflevector(vh[j_][0], vh[j_][1], 0, 1, 2, 3, 4, 5, 6, 7), bl = __builtin_shufflevector(vl[j_][0], vl[j_][1], 0, 1, 2, 3, 4, 5, 6, 7); \
+            const wbf16x8 bh = __builtin_bit_cast(wbf16x8, (wu32x4){vh[j_][0][0], vh[j_][0][1], vh[j_][1][0], vh[j_][1][1]}), bl = __builtin_bit_cast(wbf16x8, (wu32x4){vl[j_][0][0], vl[j_][0][1], vl[j_][1][0], vl[j_][1][1]}); \
             acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul_, bh, acc[j_], 0, 0, 0); \
             acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh_, bl, acc[j_], 0, 0, 0); \
             acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh_, bh, acc[j_], 0, 0, 0); } while (0)
@@ -1055,6 +1062,173 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same weight gradient with the products on the bf16 matrix pipe ("split": dM and V as hi + lo bf16 pieces, three v_mfma_f32_32x32x16_bf16 per position, fp32 accumulation --
+// see conv_wino3s_kernel for the arithmetic).  Here the rounding (2^-16 per product, over ~10^5 pixels) ends in dw and goes nowhere else: it cannot move a forward value or
+// another layer's gradient, which is why this -- unlike the split forward kernel -- is the default for the eligible layers (MD2_WINO_WGRAD_SPLIT=0: the fp32 MFMA kernel).
+// The MFMA's K = 16 is a batch's 16 tiles: lane = (channel, tile group of 8).  Block = 32 output x 32 input channels (64 accumulator registers: the 64-channel block of the
+// fp32 kernel spilled once the piece vectors joined its 128 accumulators), LDS stage = x [160 slots][32 ci] | dy [16 tiles][4 px][32 co].
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WS_DYF = WG_TB * 4 * 32, WS_STAGE = WG_XF + WS_DYF;
+template <int XF>
+__global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, WinoWgGeo geo) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_co = bid % geo.nco, tile_ci = (bid / geo.nco) % geo.nci, ks = bid / (geo.nco * geo.nci);
+    const int co0 = tile_co * 32, ci0 = tile_ci * 32;
+    const int b_lo = ks * geo.bpb, b_hi = min(b_lo + geo.bpb, geo.nb);
+    const int TW = geo.TW, TH = geo.TH;
+
+    // ---- loader items: x as in conv_wino_wgrad_kernel (5 per thread); dy: item f = tid + 256 li (li < 2) = (pixel slot f >> 3 = tile * 4 + (oa * 2 + ob), 16-B piece f & 7 of 32 channels)
+    int x_pa[5], x_pc[5];
+#pragma unroll
+    for (int li = 0; li < 5; ++li) { const int slot = (tid + 256 * li) >> 3; x_pa[li] = slot / WG_WP; x_pc[li] = slot - x_pa[li] * WG_WP; }
+    const int xq = tid & 7;
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + ci0 + xq * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + ci0 + xq * 4); }
+    uint4 rx[5], rd[2]; unsigned okx = 0, okd = 0;
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    const char* db_ = reinterpret_cast<const char*>(a.dy);
+    auto gload = [&](int b) {
+        const int rr = b / geo.BPR, bq = b - rr * geo.BPR;
+        const int n = rr / TH, ty = rr - n * TH, tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
+        okx = 0; okd = 0;
+#pragma unroll
+        for (int li = 0; li < 5; ++li) {
+            int ih = 2 * ty - a.pad + x_pa[li], iw = 2 * tx0 - a.pad + x_pc[li];
+            bool ok = x_pa[li] < 4 && x_pc[li] < 2 * L + 2;
+            if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+            else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            const unsigned off = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(ci0 + xq * 4)) * 4u : (unsigned)(xq * 16);
+            rx[li] = *reinterpret_cast<const uint4*>(xb + off);
+            okx |= ok ? (1u << li) : 0u;
+        }
+#pragma unroll
+        for (int li = 0; li < 2; ++li) {
+            const int ps = (tid + 256 * li) >> 3, t = ps >> 2, oy = 2 * ty + ((ps >> 1) & 1), ox = 2 * (tx0 + t) + (ps & 1);
+            const bool ok = t < L && oy < a.Ho && ox < a.Wo;
+            const unsigned off = ok ? ((unsigned)((long)n * a.dy_bs) + (unsigned)((oy * a.Wo + ox) * a.dy_ps) + (unsigned)(co0 + xq * 4)) * 4u : (unsigned)(xq * 16);
+            rd[li] = *reinterpret_cast<const uint4*>(db_ + off);
+            okd |= ok ? (1u << li) : 0u;
+        }
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < 5; ++li) {
+            const unsigned mk = 0u - ((okx >> li) & 1u);
+            uint4 v = rx[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            if constexpr (XF != 0) {
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
+            }
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + ((tid + 256 * li) >> 3) * 32 + xq * 4) = v;
+        }
+#pragma unroll
+        for (int li = 0; li < 2; ++li) {
+            const unsigned mk = 0u - ((okd >> li) & 1u);
+            uint4 v = rd[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            *reinterpret_cast<uint4*>(wsm + so + WG_XF + ((tid + 256 * li) >> 3) * 32 + xq * 4) = v;
+        }
+    };
+
+    // ---- consumer: wave i; lane = (channel lr, tile group g): tiles 8 g .. 8 g + 7 of the batch
+    const float ca = (wi == 3) ? 0.f : 1.f, cb = (wi == 0) ? 0.f : (wi == 1 ? 1.f : -1.f);
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int lr = lane & 31, g8 = (lane >> 5) * 8;
+    const int xo1 = (r1 * WG_WP + 2 * g8) * 32 + lr, xo2 = (r2 * WG_WP + 2 * g8) * 32 + lr;          // + tile t * 2 slots + column b
+    const int dyo = WG_XF + (g8 * 4) * 32 + lr;                                                      // + tile t * 4 pixel rows + px * 32
+    typedef wbf16x8 b8_t;
+    auto cat8 = [](const unsigned (&v)[4]) { return __builtin_bit_cast(b8_t, (wu32x4){v[0], v[1], v[2], v[3]}); };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = a.db && tile_ci == 0 && wi == 0;
+
+    if (b_lo < b_hi) {
+        gload(b_lo); lstore(0);
+        __syncthreads();
+        for (int b = b_lo; b < b_hi; ++b) {
+            const int so = ((b - b_lo) & 1) * WS_STAGE;
+            const int bn = min(b + 1, b_hi - 1);
+            gload(bn);
+            __builtin_amdgcn_sched_barrier(0);
+            // (tiles past the end of a short last batch were committed as zeros: they contribute nothing)
+            unsigned vh[4][4], vl[4][4], ah[4][4], al[4][4];          // [position][tile pair]: two bf16 (tiles 2 tp, 2 tp + 1) per register
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                float V[2][4], M[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float* xs = wsm + so + (2 * tp + u) * (2 * 32);
+                    float rr[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rr[c] = fmaf(sg, xs[xo2 + c * 32], xs[xo1 + c * 32]);
+                    V[u][0] = rr[0] - rr[2]; V[u][1] = rr[1] + rr[2]; V[u][2] = rr[2] - rr[1]; V[u][3] = rr[1] - rr[3];
+                    const float* ds = wsm + so + dyo + (2 * tp + u) * (4 * 32);
+                    const float y00 = ds[0], y01 = ds[32], y10 = ds[64], y11 = ds[96];
+                    if (do_bias) bsum += (y00 + y01) + (y10 + y11);
+                    const float p0 = ca * y00 + cb * y10, p1 = ca * y01 + cb * y11;
+                    M[u][0] = p0; M[u][1] = p0 + p1; M[u][2] = p0 - p1; M[u][3] = -p1;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { split_pk(V[0][j], V[1][j], vh[j][tp], vl[j][tp]); split_pk(M[0][j], M[1][j], ah[j][tp], al[j][tp]); }
+                __builtin_amdgcn_sched_barrier(0);          // (keeps hipcc from hoisting all 96 LDS reads of the batch: registers)
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const b8_t Ah = cat8(ah[j]), Al = cat8(al[j]), Bh = cat8(vh[j]), Bl = cat8(vl[j]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[j], 0, 0, 0);          // small terms first
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(WS_STAGE - so);
+            __syncthreads();
+        }
+    }
+
+    // ---- dw = G^T dU G (as conv_wino_wgrad_kernel, one pass: row r is output channel co0 + r)
+    float* T = wsm;
+    constexpr int TLD = 33;
+    const int ci = tid & 31, rw = tid >> 5;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float a0 = acc[0][e], a1 = acc[1][e], a2 = acc[2][e], a3 = acc[3][e];
+        const int row = 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        T[((wi * 3 + 0) * 32 + row) * TLD + lr] = a0 + 0.5f * (a1 + a2);
+        T[((wi * 3 + 1) * 32 + row) * TLD + lr] = 0.5f * (a1 - a2);
+        T[((wi * 3 + 2) * 32 + row) * TLD + lr] = 0.5f * (a1 + a2) + a3;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = rw + 8 * k;
+        float* dst = a.dw + ((long)(co0 + row) * 9) * a.Cin + ci0 + ci;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float t0 = T[((0 * 3 + q) * 32 + row) * TLD + ci], t1 = T[((1 * 3 + q) * 32 + row) * TLD + ci], t2 = T[((2 * 3 + q) * 32 + row) * TLD + ci], t3 = T[((3 * 3 + q) * 32 + row) * TLD + ci];
+            atomicAdd(dst + (0 * 3 + q) * a.Cin, t0 + 0.5f * (t1 + t2));
+            atomicAdd(dst + (1 * 3 + q) * a.Cin, 0.5f * (t1 - t2));
+            atomicAdd(dst + (2 * 3 + q) * a.Cin, 0.5f * (t1 + t2) + t3);
+        }
+    }
+    if (do_bias) {          // wave 0 of the block column with input-channel tile 0
+        bsum += __shfl_xor(bsum, 32);
+        if (lane < 32) atomicAdd(a.db + co0 + lr, bsum);
+    }
+}
+
 bool conv_wino_wgrad_eligible(const WgradArgs& a) {
     static const bool off = getenv("MD2_NO_WINO_WGRAD") != nullptr;
     static const long min_m = getenv("MD2_WINO_WGRAD_MIN_M") ? atol(getenv("MD2_WINO_WGRAD_MIN_M")) : 1024;          // (in-model, batch 32: ahead of the all-taps kernel from the 1/32-scale layers up)
@@ -1073,6 +1247,23 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     static const int want = getenv("MD2_WINO_WGRAD_BLOCKS") ? atoi(getenv("MD2_WINO_WGRAD_BLOCKS")) : 512;
     int ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));
     g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
+    static const bool split = !(getenv("MD2_WINO_WGRAD_SPLIT") && atoi(getenv("MD2_WINO_WGRAD_SPLIT")) == 0);          // MD2_WINO_WGRAD_SPLIT=0: the fp32-MFMA kernel
+    if (split) {          // 32 x 32-channel blocks
+        g.nco = a.Cout / 32;
+        ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));
+        g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
+        constexpr size_t lds_s = std::max((size_t)2 * WS_STAGE * sizeof(float), (size_t)12 * 32 * 33 * sizeof(float));
+        static bool attr_s = false;
+        if (!attr_s) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            attr_s = true;
+        }
+        const int grid_s = g.nco * g.nci * ksn;
+        if (a.in_scale) hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<1>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+        else hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<0>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+        return;
+    }
     constexpr size_t lds_pipe = (size_t)2 * WG_STAGE * sizeof(float), lds_epi = (size_t)12 * 32 * 33 * sizeof(float);
     constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
     static bool attr_set = false;
