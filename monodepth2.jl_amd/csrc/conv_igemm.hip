@@ -1107,8 +1107,19 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 // address/carry VALU instructions of the loader would run ahead of, instead of between, the 32 MFMAs of a step)
 // ONE: 1x1 / stride-1 convolution on dense views (pixel m of dy and of x are the same flattened index): the loader is base + m * pixel stride, no (n, oh, ow) bookkeeping --
 // the ResNet-50 bottlenecks' weight gradients (33 launches per step) spent more issue slots on those carries than on their 32 MFMAs per step
-template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
+// SPL ("split", MF == 32 only): the products run on the bf16 matrix pipe at close-to-fp32 accuracy -- each operand fragment (8 pixels of one channel, read as a strided column
+// of the fp32 LDS tile) is split into hi + lo bf16 pieces, x = hi + lo up to 2^-17 |x|, and a 16-pixel k-group takes three v_mfma_f32_32x32x16_bf16 (lo hi, hi lo, hi hi; fp32
+// accumulation) instead of eight v_mfma_f32_32x32x2_f32: 96 instead of 512 matrix-pipe cycles, and -- unlike the fp32 MFMA (profiles/r03_wino3_pmc.md) -- beside the other
+// waves' vector work.  The rounding ends in dw and propagates nowhere, so this is the default for the weight gradients (MD2_WGRAD_SPLIT=0: fp32 MFMAs).
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned wg_cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void wg_split_pk(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = wg_cvt_pk_bf16(a, b);
+    lo = wg_cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false, bool SPL = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {
+    static_assert(!SPL || (MF == 32 && BKP % 16 == 0), "the split path is built on the 32x32x16 bf16 MFMA");
     // LDS tiles [pixel][channel]: A operand lane (row = channel, k = pixel) reads consecutive channels of one pixel row.
     // 32x32x2: the two 32-lane halves are separate ds_read_b32 groups -> conflict-free for any row length.
     // 16x16x4: 4 pixel rows per instruction, LD % 32 == 16 keeps the two 16-lane halves of a group on disjoint banks.
@@ -1227,13 +1238,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
 
     const int wr = KSPLIT ? 0 : (wave & 1), wq = KSPLIT ? 0 : (wave >> 1);
     // operand fragments of one step (KK MFMA k-groups): A = dY[pixel k][channel row], B = x[pixel k][channel col]
-    constexpr int KK = MF == 32 ? BKP / 2 : (KSPLIT ? BKP / 16 : BKP / 4);
-    struct Ops { float a[KK][TW], b[KK][TW]; };
+    constexpr int KK = SPL ? BKP / 16 : (MF == 32 ? BKP / 2 : (KSPLIT ? BKP / 16 : BKP / 4));
+    struct OpsF { float a[KK][TW], b[KK][TW]; };
+    struct OpsS { wg_u32x4 ah[KK][TW], al[KK][TW], bh[KK][TW], bl[KK][TW]; };          // 8 bf16 per register quad: pixels 8 g .. 8 g + 7 of the k-group, hi and lo pieces
+    using Ops = typename std::conditional<SPL, OpsS, OpsF>::type;
     const int lrow = lane & (MF - 1), lkk = lane / MF;       // k within a group: 0..1 (32x32x2) or 0..3 (16x16x4)
     const int kq0 = KSPLIT ? wave * KK : 0;
     auto read_ops = [&](int so, Ops& o) {
         const float* D = smem + so;
         const float* X = smem + so + BKP * LD;
+        if constexpr (SPL) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int k0 = kk * 16 + 8 * lkk;          // lane = (channel, pixel group lkk of 8)
+#pragma unroll
+                for (int i = 0; i < TW; ++i) {
+                    const float* c = D + k0 * LD + wr * (T / 2) + i * MF + lrow;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { unsigned hi, lo; wg_split_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, lo); o.ah[kk][i][e] = hi; o.al[kk][i][e] = lo; }
+                }
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const float* c = X + k0 * LD + wq * (T / 2) + j * MF + lrow;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { unsigned hi, lo; wg_split_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, lo); o.bh[kk][j][e] = hi; o.bl[kk][j][e] = lo; }
+                }
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             const int k = (kq0 + kk) * (MF == 32 ? 2 : 4) + lkk;
@@ -1244,6 +1275,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
         }
     };
     auto mfmas = [&](const Ops& o) {
+        if constexpr (SPL) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int i = 0; i < TW; ++i)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, o.ah[kk][i]), al = __builtin_bit_cast(bf16x8, o.al[kk][i]), bh = __builtin_bit_cast(bf16x8, o.bh[kk][j]), bl = __builtin_bit_cast(bf16x8, o.bl[kk][j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);          // small terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+                    }
+        } else
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
@@ -1333,6 +1377,16 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     splitk = (steps_total + sps - 1) / sps;
     const dim3 g(tiles * taps * splitk);
     if constexpr (T >= 64) {
+        static const bool spl = !(getenv("MD2_WGRAD_SPLIT") && atoi(getenv("MD2_WGRAD_SPLIT")) == 0);
+        if (spl && fast && !refl && !g_deterministic) {          // products on the bf16 matrix pipe (split operands): see conv_wgrad_kernel
+            static const bool no_one1 = getenv("MD2_NO_WGRAD_ONE") != nullptr;
+            const bool one1 = !no_one1 && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
+            if (one1 && a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            else if (one1) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            else if (a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            return;
+        }
         static const bool no_one = getenv("MD2_NO_WGRAD_ONE") != nullptr;
         const bool one = !no_one && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
         if (one) {
