@@ -274,7 +274,7 @@ def main():
         if wg["ms"] > 0:
             a = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
             ax = wg["flops_executed"] / (wg["ms"] * 1e-3) / 1e12
-            extra["roofline_conv_wgrad"] = {"bound": "mfma", "kernel": "conv_wino_wgrad_kernel (Winograd domain: the 3x3 stride-1 layers) + conv_wgrad_kernel<*> + conv3x3_wgrad_*_kernel + stem_wgrad_kernel",
+            extra["roofline_conv_wgrad"] = {"bound": "mfma", "kernel": "conv_wino_wgrad_s_kernel (Winograd domain: the 3x3 stride-1 layers) + conv_wgrad_kernel<*, SPL> (both multiply hi + lo bf16 pieces of their fp32 operands on the bf16 matrix pipe, three v_mfma_f32_32x32x16_bf16 per product group, fp32 accumulation: the fractions below are fp32-EQUIVALENT rates against the fp32 MFMA peak) + conv3x3_wgrad_*_kernel + stem_wgrad_kernel (fp32 MFMA)",
                                             "achieved": a, "peak": peak_tf, "unit": "TFLOP/s", "frac": a / peak_tf, "executed_achieved": ax, "executed_frac": ax / peak_tf, "ms_per_step": wg["ms"] / 3}
         # the training step runs the loss as ONE class: smoothness sums + the fused value-and-pullback kernel ("loss_train"); "loss_fwd" only exists in forward-only calls
         for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_train", lb)):
