@@ -111,6 +111,8 @@ int32_t md2_set_deterministic(int32_t on);
  * on = 4 (opt-in, "split" mode): the forward / input-gradient Winograd products run on the bf16 matrix pipe at close-to-fp32 accuracy -- every fp32 operand is split into
  * hi + lo bf16 pieces and each product group takes three v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~17-bit operand mantissas; storage, transforms and everything
  * else stay fp32).  Forward + loss stay inside the 1e-4 parity bound, gradients are ~5x noisier than with the fp32 MFMA; 1.3-1.5x faster on those launches.
+ * on = 5: the same with three pieces per operand (hi + mid + lo, six MFMAs per product group): every bit of the fp32 operands, results as close to the oracle as the fp32
+ * MFMA's, 1.15-1.25x faster per launch -- but no faster in the step (the kernel is vector-bound and shares the vector units with the weight-gradient stream).
  * Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks);
 /* ADAM moments (Flux parameter layout, host) + running beta powers: the optimiser state the reference's BSON checkpoints

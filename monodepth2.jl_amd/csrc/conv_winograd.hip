@@ -42,6 +42,9 @@ __device__ __forceinline__ int fdiv24(int m, int d) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// pieces per fp32 operand of the split Winograd path: 0 = off (fp32 MFMAs), 2 = hi + lo (md2_set_winograd(4): ~17-bit mantissas, opt-in), 3 = hi + mid + lo (exact; mode 5)
+static inline int wino_split_pieces() { return g_wino_on == 4 ? 2 : (g_wino_on == 5 ? 3 : 0); }
+
 __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -51,15 +54,19 @@ constexpr int WT = 32;                       // Winograd tiles per block
 constexpr int W_STAGE = 16 * WT * 16;        // floats per LDS stage (32 KB)
 
 // split mode (conv_wino3s_kernel): the same (G g G^T)[i][j] as two bf16 pieces, u = hi + lo, in the A-operand layout of v_mfma_f32_32x32x16_bf16 --
-// [Cout/32][4 (i)][Cin/16][4 (j)][2 (hi, lo)][64 lanes][8]: lane l, element e = (co = 32 ct + (l & 31), ci = 16 c16 + 8 (l >> 5) + e).  Same byte count as the fp32 fragments.
-__device__ __forceinline__ void wino_store_split(float* __restrict__ U, int ct, int i, int j, int Cin, int ci, int co_lo, const float4& u) {
+// [Cout/32][4 (i)][Cin/16][4 (j)][np pieces][64 lanes][8]: lane l, element e = (co = 32 ct + (l & 31), ci = 16 c16 + 8 (l >> 5) + e).  np = 2: the byte count of the fp32 fragments,
+// np = 3 (hi + mid + lo: exact): 1.5 x, which is what conv_wino_u_floats reserves.
+__device__ __forceinline__ void wino_store_split(float* __restrict__ U, int ct, int i, int j, int Cin, int ci, int co_lo, const float4& u, int np) {
     typedef __bf16 b4 __attribute__((ext_vector_type(4)));
-    b4 hi, lo;
+    b4 hi, mid, lo;          // np == 2: u = hi + lo (+ 2^-17 |u|); np == 3: u = hi + mid + lo (+ 2^-25 |u|: every bit of the fp32 value)
     hi[0] = (__bf16)u.x; hi[1] = (__bf16)u.y; hi[2] = (__bf16)u.z; hi[3] = (__bf16)u.w;
-    lo[0] = (__bf16)(u.x - (float)hi[0]); lo[1] = (__bf16)(u.y - (float)hi[1]); lo[2] = (__bf16)(u.z - (float)hi[2]); lo[3] = (__bf16)(u.w - (float)hi[3]);
+    const float r0 = u.x - (float)hi[0], r1 = u.y - (float)hi[1], r2 = u.z - (float)hi[2], r3 = u.w - (float)hi[3];
+    mid[0] = (__bf16)r0; mid[1] = (__bf16)r1; mid[2] = (__bf16)r2; mid[3] = (__bf16)r3;
+    lo[0] = (__bf16)(r0 - (float)mid[0]); lo[1] = (__bf16)(r1 - (float)mid[1]); lo[2] = (__bf16)(r2 - (float)mid[2]); lo[3] = (__bf16)(r3 - (float)mid[3]);
     const int c16 = ci >> 4, g = (ci >> 3) & 1, e0 = ci & 4;
-    __bf16* base = reinterpret_cast<__bf16*>(U) + ((((long)(ct * 4 + i) * (Cin >> 4) + c16) * 4 + j) * 2) * 512 + (co_lo + 32 * g) * 8 + e0;
-    *reinterpret_cast<b4*>(base) = hi; *reinterpret_cast<b4*>(base + 512) = lo;
+    __bf16* base = reinterpret_cast<__bf16*>(U) + ((((long)(ct * 4 + i) * (Cin >> 4) + c16) * 4 + j) * np) * 512 + (co_lo + 32 * g) * 8 + e0;
+    *reinterpret_cast<b4*>(base) = hi; *reinterpret_cast<b4*>(base + 512) = mid;
+    if (np == 3) *reinterpret_cast<b4*>(base + 1024) = lo;
 }
 // ---- weights: w [Cout][9][Cin] (cross-correlation taps, tap = kh*3 + kw) -> U fragments [Cout/32][4 (i)][Cin/8][4 (j)][64 lanes][4]:
 //      lane l, element e of fragment (ct, i, c8, j) = (G g G^T)[i][j] of (co = 32 ct + (l & 31), ci = 8 c8 + 4 (l >> 5) + e)
@@ -92,14 +99,14 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
         u[2] = make_float4(0.5f * (a.x - b.x + d.x), 0.5f * (a.y - b.y + d.y), 0.5f * (a.z - b.z + d.z), 0.5f * (a.w - b.w + d.w));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (split) wino_store_split(U, ct, i, j, Cin, ci, co_lo, u[j]);
+            if (split) wino_store_split(U, ct, i, j, Cin, ci, co_lo, u[j], split);
             else *reinterpret_cast<float4*>(U + ((((long)(ct * 4 + i) * (Cin >> 3) + c8) * 4 + j) * 64 + (co_lo + 32 * h)) * 4) = u[j];
         }
     }
 }
 void launch_wino_weights(const float* w, float* U, int Cout, int Cin, hipStream_t s) {
     const long n = (long)(Cout / 32) * (Cin / 4) * 32;
-    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, U, Cout, Cin, g_wino_on == 4 ? 1 : 0);
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, U, Cout, Cin, wino_split_pieces());
 }
 // all eligible layers of a handle in one launch: desc = {w offset, U offset, Cout, Cin} per layer, block ranges by prefix sums in `first`
 __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* __restrict__ wbase, float* __restrict__ Ubase, const long* __restrict__ desc, int nlayers, int split) {
@@ -135,14 +142,14 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
         u[2] = make_float4(0.5f * (a.x - bb.x + d.x), 0.5f * (a.y - bb.y + d.y), 0.5f * (a.z - bb.z + d.z), 0.5f * (a.w - bb.w + d.w));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (split) wino_store_split(U, ct, i, j, Cin, ci, co_lo, u[j]);
+            if (split) wino_store_split(U, ct, i, j, Cin, ci, co_lo, u[j], split);
             else *reinterpret_cast<float4*>(U + ((((long)(ct * 4 + i) * (Cin >> 3) + c8) * 4 + j) * 64 + (co_lo + 32 * h)) * 4) = u[j];
         }
     }
 }
 void launch_wino_weights_batched(const float* wbase, float* Ubase, const long* desc_dev, int nlayers, int total_blocks, hipStream_t s) {
     if (nlayers <= 0 || total_blocks <= 0) return;
-    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, s, wbase, Ubase, desc_dev, nlayers, g_wino_on == 4 ? 1 : 0);
+    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, s, wbase, Ubase, desc_dev, nlayers, wino_split_pieces());
 }
 long wino_weight_blocks(int Cout, int Cin) { return ((long)(Cout / 32) * (Cin / 4) * 32 + 255) / 256; }
 
@@ -663,10 +670,16 @@ __device__ __forceinline__ void split_pk(float a, float b, unsigned& hi, unsigne
     hi = cvt_pk_bf16(a, b);
     lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
-__device__ __forceinline__ void split_bf16(const float4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
-    split_pk(v.x, v.y, hi[0], lo[0]); split_pk(v.z, v.w, hi[1], lo[1]);
+// (a, b) = hi + mid + lo up to 2^-25: every bit of the fp32 values
+__device__ __forceinline__ void split3_pk(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    mid = cvt_pk_bf16(ra, rb);
+    lo = cvt_pk_bf16(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
 }
-template <int XF, int BST>
+// NP = pieces per operand: 2 (hi + lo: three MFMAs per product group, ~17-bit mantissas) or 3 (hi + mid + lo: six MFMAs -- hh, hm, mh, hl, lh, mm; the dropped terms are
+// below 2^-24 of the product -- i.e. fp32 accuracy on the bf16 pipe, still 192 instead of 512 matrix-pipe cycles per 16 channels, and co-executing with the vector work)
+template <int XF, int BST, int NP>
 __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Geo geo) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     constexpr int COB = 32, WT = 32, NLI = 6;
@@ -751,49 +764,62 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
-    // U stream of this wave: chunk c16, position j: hi fragment at ub + ((c16 * 4 + j) * 2) * 512 bf16, lo fragment 512 bf16 further (64 lanes x 8)
+    // U stream of this wave: chunk c16, position j: piece q at ub + ((c16 * 4 + j) * NP + q) * 512 bf16 (64 lanes x 8)
     const int nchunks = a.Cin >> 4;
-    const __bf16* ub = reinterpret_cast<const __bf16*>(a.wino_u) + ((long)(tile_c * 4 + wi) * nchunks) * 4 * 1024 + lane * 8;
-    wbf16x8 uh0 = *reinterpret_cast<const wbf16x8*>(ub), ul0 = *reinterpret_cast<const wbf16x8*>(ub + 512);
-    wbf16x8 uh1 = *reinterpret_cast<const wbf16x8*>(ub + 1024), ul1 = *reinterpret_cast<const wbf16x8*>(ub + 1536);
-    wbf16x8 uh2 = *reinterpret_cast<const wbf16x8*>(ub + 2048), ul2 = *reinterpret_cast<const wbf16x8*>(ub + 2560);
-    wbf16x8 uh3 = *reinterpret_cast<const wbf16x8*>(ub + 3072), ul3 = *reinterpret_cast<const wbf16x8*>(ub + 3584);
+    const __bf16* ub = reinterpret_cast<const __bf16*>(a.wino_u) + ((long)(tile_c * 4 + wi) * nchunks) * 4 * NP * 512 + lane * 8;
+    wbf16x8 u[4][NP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) u[j][q] = *reinterpret_cast<const wbf16x8*>(ub + (j * NP + q) * 512);
 
     gload(0); lstore(0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int so = (c & 1) * PST;
         const int cn = min(c + 1, nchunks - 1);
-        const __bf16* un = ub + (long)cn * 4096;
+        const __bf16* un = ub + (long)cn * (4 * NP * 512);
         gload(cn);
         __builtin_amdgcn_sched_barrier(0);
-        unsigned vh[4][2][2], vl[4][2][2];          // [position][piece of 4 channels][register]
+        // B^T row combination of the lane's 8 channels (two 16-B pieces), kept for the four positions
+        float4 rr[4][2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            float4 rr[4];
+        for (int p = 0; p < 2; ++p)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + (c_off1[b] ^ (p << 2)));
                 const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + (c_off2[b] ^ (p << 2)));
-                rr[b] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+                rr[b][p] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
             }
-            split_bf16(make_float4(rr[0].x - rr[2].x, rr[0].y - rr[2].y, rr[0].z - rr[2].z, rr[0].w - rr[2].w), vh[0][p], vl[0][p]);
-            split_bf16(make_float4(rr[1].x + rr[2].x, rr[1].y + rr[2].y, rr[1].z + rr[2].z, rr[1].w + rr[2].w), vh[1][p], vl[1][p]);
-            split_bf16(make_float4(rr[2].x - rr[1].x, rr[2].y - rr[1].y, rr[2].z - rr[1].z, rr[2].w - rr[1].w), vh[2][p], vl[2][p]);
-            split_bf16(make_float4(rr[1].x - rr[3].x, rr[1].y - rr[3].y, rr[1].z - rr[3].z, rr[1].w - rr[3].w), vh[3][p], vl[3][p]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // V_(i,j) of the 8 channels, split into NP bf16 pieces right here (the pieces of one position live only across its MFMAs)
+            unsigned vp[NP][4];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float4 x0 = rr[j == 0 ? 0 : (j == 2 ? 2 : 1)][p], x1 = rr[j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3))][p];
+                const float sj = (j == 1) ? 1.f : -1.f;
+                const float4 v = make_float4(fmaf(sj, x1.x, x0.x), fmaf(sj, x1.y, x0.y), fmaf(sj, x1.z, x0.z), fmaf(sj, x1.w, x0.w));
+                if constexpr (NP == 2) { split_pk(v.x, v.y, vp[0][2 * p], vp[1][2 * p]); split_pk(v.z, v.w, vp[0][2 * p + 1], vp[1][2 * p + 1]); }
+                else { split3_pk(v.x, v.y, vp[0][2 * p], vp[1][2 * p], vp[2][2 * p]); split3_pk(v.z, v.w, vp[0][2 * p + 1], vp[1][2 * p + 1], vp[2][2 * p + 1]); }
+            }
+            wbf16x8 vb[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) vb[q] = __builtin_bit_cast(wbf16x8, (wu32x4){vp[q][0], vp[q][1], vp[q][2], vp[q][3]});
+            // small terms first
+            if constexpr (NP == 3) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][2], vb[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][0], vb[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][1], vb[1], acc[j], 0, 0, 0);
+            }
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][1], vb[0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][0], vb[1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][0], vb[0], acc[j], 0, 0, 0);
+            // refill in place right behind the position's last use, as in conv_wino3_kernel
+#pragma unroll
+            for (int q = 0; q < NP; ++q) u[j][q] = *reinterpret_cast<const wbf16x8*>(un + (j * NP + q) * 512);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#define W3S_MFMA(j_, uh_, ul_) do { \
-            const wbf16x8 bh = __builtin_bit_cast(wbf16x8, (wu32x4){vh[j_][0][0], vh[j_][0][1], vh[j_][1][0], vh[j_][1][1]}), bl = __builtin_bit_cast(wbf16x8, (wu32x4){vl[j_][0][0], vl[j_][0][1], vl[j_][1][0], vl[j_][1][1]}); \
-            acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ul_, bh, acc[j_], 0, 0, 0); \
-            acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh_, bl, acc[j_], 0, 0, 0); \
-            acc[j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uh_, bh, acc[j_], 0, 0, 0); } while (0)
-        // (small terms first; the refills go in place right behind a fragment pair's use, as in conv_wino3_kernel)
-        W3S_MFMA(0, uh0, ul0); uh0 = *reinterpret_cast<const wbf16x8*>(un); ul0 = *reinterpret_cast<const wbf16x8*>(un + 512); __builtin_amdgcn_sched_barrier(0);
-        W3S_MFMA(1, uh1, ul1); uh1 = *reinterpret_cast<const wbf16x8*>(un + 1024); ul1 = *reinterpret_cast<const wbf16x8*>(un + 1536); __builtin_amdgcn_sched_barrier(0);
-        W3S_MFMA(2, uh2, ul2); uh2 = *reinterpret_cast<const wbf16x8*>(un + 2048); ul2 = *reinterpret_cast<const wbf16x8*>(un + 2560); __builtin_amdgcn_sched_barrier(0);
-        W3S_MFMA(3, uh3, ul3); uh3 = *reinterpret_cast<const wbf16x8*>(un + 3072); ul3 = *reinterpret_cast<const wbf16x8*>(un + 3584);
-#undef W3S_MFMA
-        __builtin_amdgcn_sched_barrier(0);
         lstore(PST - so);
         __syncthreads();
     }
@@ -842,7 +868,7 @@ static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
     // workgroup for launches with at least n of them
     static const long small = getenv("MD2_WINO_SMALL_BLOCKS") ? atol(getenv("MD2_WINO_SMALL_BLOCKS")) : (1L << 40);
     nh = g_wino_nh == 1 ? 1 : (g_wino_nh == 2 ? 2 : (b64 < small ? 1 : 2));
-    if (g_wino_on == 4) { if (!ok32 || a.Cin % 16 != 0) return false; nh = 1; }          // split mode: conv_wino3s_kernel (32 tiles, 16-channel chunks) or the direct convolution
+    if (wino_split_pieces()) { if (!ok32 || a.Cin % 16 != 0) return false; nh = 1; }          // split mode: conv_wino3s_kernel (32 tiles, 16-channel chunks) or the direct convolution
     if (nh == 1 && !ok32) nh = 2;
     if (nh == 2 && !ok64) nh = 1;
     const int T = 32 * nh;
@@ -867,22 +893,24 @@ static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) 
     else if (a.bst) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 1, NH>), dim3(grid), dim3(256), lds, s, a, g);
     else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0, NH>), dim3(grid), dim3(256), lds, s, a, g);
 }
-static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
+template <int NP>
+static void launch_wino3s_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 2 * 128 * 3 * 8 * sizeof(float);          // two stages of two 8-channel planes (48 KB) > the epilogue's 36 KB
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<0, 0, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<1, 0, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<0, 1, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = g.ntp * (a.Cout / 32);
-    if (a.in_scale) hipLaunchKernelGGL((conv_wino3s_kernel<1, 0>), dim3(grid), dim3(256), lds, s, a, g);
-    else if (a.bst) hipLaunchKernelGGL((conv_wino3s_kernel<0, 1>), dim3(grid), dim3(256), lds, s, a, g);
-    else hipLaunchKernelGGL((conv_wino3s_kernel<0, 0>), dim3(grid), dim3(256), lds, s, a, g);
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino3s_kernel<1, 0, NP>), dim3(grid), dim3(256), lds, s, a, g);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino3s_kernel<0, 1, NP>), dim3(grid), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino3s_kernel<0, 0, NP>), dim3(grid), dim3(256), lds, s, a, g);
 }
+static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) { if (wino_split_pieces() == 3) launch_wino3s_t<3>(a, g, s); else launch_wino3s_t<2>(a, g, s); }
 static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) {
-    if (g_wino_on == 4) launch_wino3s(a, g, s);
+    if (wino_split_pieces()) launch_wino3s(a, g, s);
     else if (nh == 1) launch_wino3_t<3, 1>(a, g, s); else launch_wino3_t<5, 2>(a, g, s);
 }
 
@@ -1292,12 +1320,12 @@ bool conv_wino_eligible(const ConvArgs& a) {
     if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
     if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
     Wino2Geo g; int nh = 2;
-    if (g_wino_on == 1 || g_wino_on == 4) return wino3_eligible(a, g, nh);
+    if (g_wino_on == 1 || g_wino_on >= 4) return wino3_eligible(a, g, nh);
     const long tiles = (long)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2);
     const int cob = a.Cout % 64 == 0 ? 64 : 32;
     return ((tiles + WT - 1) / WT) * (a.Cout / cob) >= g_wino_min_blocks;
 }
-size_t conv_wino_u_floats(int Cout, int Cin) { return (size_t)16 * Cout * Cin; }
+size_t conv_wino_u_floats(int Cout, int Cin) { return (size_t)24 * Cout * Cin; }          // 16 fp32 per weight pair, or 16 x 3 bf16 pieces in the exact split mode
 
 template <int NS>
 static void launch_wino_t(const ConvArgs& a, hipStream_t s) {

@@ -1262,7 +1262,7 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host, int64_t n) {
     HIPCHK(hipMemcpy(h->RS, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); return 0;
 }
 int32_t md2_set_deterministic(int32_t on) { g_deterministic = on != 0; return 0; }
-int32_t md2_set_winograd(int32_t on, int32_t min_blocks) { g_wino_on = on < 0 || on > 4 ? 1 : on; if (min_blocks >= 0) g_wino_min_blocks = min_blocks; return 0; }
+int32_t md2_set_winograd(int32_t on, int32_t min_blocks) { g_wino_on = on < 0 || on > 5 ? 1 : on; if (min_blocks >= 0) g_wino_min_blocks = min_blocks; return 0; }
 int32_t md2_set_lr(md2_handle* h, double lr) { if (!(lr > 0)) { h->err = "md2_set_lr: lr must be positive"; return 2; } h->cfg.lr = lr; return 0; }
 
 // ---- op-level hooks for the direct kernels the network uses besides the implicit GEMM (parity tests) ------------------------------------

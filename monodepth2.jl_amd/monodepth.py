@@ -543,7 +543,8 @@ def set_winograd(on=True, min_blocks=-1):
     """Algorithm choice for the 3x3 / stride-1 convolutions: fused Winograd F(2x2,3x3) for launches of at least `min_blocks` workgroups (default policy: 96), or the direct
     implicit GEMM everywhere (on=False).  What cuDNN's heuristics decide for the reference's Flux `Conv` layers.  on = 2 / 3 pin one of the two fp32 kernels (tests);
     on = 4 is the opt-in "split" mode: the Winograd products run as three bf16 MFMAs on hi + lo pieces of the fp32 operands (fp32 storage and accumulation, ~17-bit operand
-    mantissas; forward and loss stay inside the 1e-4 parity bound, gradients get ~5x noisier) -- ~1.4x faster on those kernels."""
+    mantissas; forward and loss stay inside the 1e-4 parity bound, gradients get ~5x noisier) -- ~1.4x faster on those kernels; on = 5 takes three pieces (six MFMAs): exact,
+    1.15-1.25x faster per launch, no faster in the step."""
     _check(_lib.lib().md2_set_winograd(int(on), int(min_blocks)), None, "set_winograd")
 
 

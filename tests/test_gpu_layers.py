@@ -187,7 +187,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.fixture(params=[2, 3, 4], ids=["tile32x64", "tile64x32", "split_bf16"])
+@pytest.fixture(params=[2, 3, 4, 5], ids=["tile32x64", "tile64x32", "split_bf16", "split3_bf16"])
 def forced_winograd(request):
     md().set_winograd(request.param, 1)          # every eligible launch takes the Winograd kernel, however small its grid: the 256-thread / 32-tile one, or the
     yield request.param                           # 64-tile x 32-channel one with row-segment patches (the one the training step uses), wherever it applies
@@ -211,7 +211,7 @@ def test_winograd_conv_fwd_and_input_gradient_vs_oracle(case, forced_winograd):
     y_direct = host(md().conv2d(dev(x), dev(w), dev(b), 1, p, mode, act))
     md().set_winograd(forced_winograd, 1)
     # the two algorithms really are different code paths (the split-bf16 kernel declines maps with one tile per row and channel counts that are not multiples of 16)
-    split_declines = forced_winograd == 4 and (Cin % 16 != 0 or (W + 2 * (p if mode != "reflect" else 1) - 2 + 1) // 2 < 2)
+    split_declines = forced_winograd >= 4 and (Cin % 16 != 0 or (W + 2 * (p if mode != "reflect" else 1) - 2 + 1) // 2 < 2)
     assert rel(y_direct, ref) < 1e-4 and (split_declines or not np.array_equal(y, y_direct))
     dy = rng.standard_normal(zo.shape).astype(np.float32)
     dxo, dwo, dbo = oracle.conv2d_bwd(xin, w, dy, 1, 0 if mode == "reflect" else p)
