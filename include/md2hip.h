@@ -113,7 +113,8 @@ int32_t md2_set_deterministic(int32_t on);
  * else stay fp32).  Forward + loss stay inside the 1e-4 parity bound, gradients are ~5x noisier than with the fp32 MFMA; 1.3-1.5x faster on those launches.
  * on = 5: the same with three pieces per operand (hi + mid + lo, six MFMAs per product group): every bit of the fp32 operands, results as close to the oracle as the fp32
  * MFMA's, 1.15-1.25x faster per launch -- but no faster in the step (the kernel is vector-bound and shares the vector units with the weight-gradient stream).
- * Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
+ * Process-wide; change it between steps, not between md2_train_loss and md2_backward of one step (the transformed weights of a step are written in the layout of the mode
+ * it started in); also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks);
 /* ADAM moments (Flux parameter layout, host) + running beta powers: the optimiser state the reference's BSON checkpoints
  * (src/Monodepth.jl:191-194) omit; with md2_params_get/set this gives true resume. */
