@@ -1195,6 +1195,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
             //   dM_(i,.) = (p0, p0 + p1, p0 - p1, -p1),  V_(i,.) = (r0 - r2, r1 + r2, r2 - r1, r1 - r3)
             // so instead of forming (and splitting) the four dM and four V columns, the SIX products P_ab = sum_t p_a[t] r_b[t] that occur are accumulated and combined once per
             // workgroup (below): 6 instead of 8 values to split per tile and no column transforms -- a third fewer vector instructions in a loop that is bound by them.
+            if (do_bias) {          // one wave of one block column: a loop of its own, or hipcc if-converts the 32 additions into every wave's batch loop
+                float t = 0.f;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) t += wsm[so + dyo + q * 32];
+                bsum += t;
+            }
             unsigned ph[2][4], pl[2][4], rh[4][4], rl[4][4];          // [column][tile pair]: two bf16 (tiles 2 tp, 2 tp + 1) per register
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {
@@ -1206,7 +1212,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
                     for (int c = 0; c < 4; ++c) R[u][c] = fmaf(sg, xs[xo2 + c * 32], xs[xo1 + c * 32]);
                     const float* ds = wsm + so + dyo + (2 * tp + u) * (4 * 32);
                     const float y00 = ds[0], y01 = ds[32], y10 = ds[64], y11 = ds[96];
-                    if (do_bias) bsum += (y00 + y01) + (y10 + y11);
                     Pv[u][0] = ca * y00 + cb * y10; Pv[u][1] = ca * y01 + cb * y11;
                 }
 #pragma unroll
