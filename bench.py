@@ -358,9 +358,23 @@ def main():
             for _ in range(n8):
                 md.train_step(m8, x8, None, c8, p8, True)
             torch.cuda.synchronize(); d8 = time.perf_counter() - t0
-            md.set_winograd(True)
             extra["headline_shape_split_bf16x3"] = {"value": B * n8 / d8, "unit": "triplets/s", "ms_per_step": d8 / n8 * 1e3,
                                                     "dtype": "fp32 storage / accumulation; 3x3 stride-1 forward + input-gradient products as 3 bf16 MFMAs on hi/lo operand pieces (opt-in)"}
+            # the exact variant (md.set_winograd(5)): three pieces per operand, six bf16 MFMAs per product group -- every bit of the fp32 operands, results as close to the oracle
+            # as the fp32 MFMA's (tests/test_gpu_layers.py runs the Winograd cases in this mode too)
+            del m8, x8
+            torch.cuda.empty_cache()
+            md.set_winograd(5)
+            m9, p9, c9, x9 = setup(B)
+            for _ in range(3):
+                md.train_step(m9, x9, None, c9, p9, True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n8):
+                md.train_step(m9, x9, None, c9, p9, True)
+            torch.cuda.synchronize(); d9 = time.perf_counter() - t0
+            md.set_winograd(True)
+            extra["headline_shape_split_bf16x6_exact"] = {"value": B * n8 / d9, "unit": "triplets/s", "ms_per_step": d9 / n8 * 1e3,
+                                                          "dtype": "fp32 storage / accumulation; forward + input-gradient Winograd products as 6 bf16 MFMAs on hi/mid/lo operand pieces: fp32 accuracy (opt-in)"}
         out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W)

@@ -1112,10 +1112,15 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 // accumulation) instead of eight v_mfma_f32_32x32x2_f32: 96 instead of 512 matrix-pipe cycles, and -- unlike the fp32 MFMA (profiles/r03_wino3_pmc.md) -- beside the other
 // waves' vector work.  The rounding ends in dw and propagates nowhere, so this is the default for the weight gradients (MD2_WGRAD_SPLIT=0: fp32 MFMAs).
 typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned wg_cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// (builtins only: see the note on wait states in conv_winograd.hip)
 __device__ __forceinline__ void wg_split_pk(float a, float b, unsigned& hi, unsigned& lo) {
-    hi = wg_cvt_pk_bf16(a, b);
-    lo = wg_cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 h, l; h[0] = (__bf16)a; h[1] = (__bf16)b;
+    unsigned k0 = 0x0000bf80u, k1 = 0xbf800000u; asm("" : "+v"(k0)); asm("" : "+v"(k1));          // (-1, 0) and (0, -1) as register operands: folded into inline constants they select the wrong half
+    const b2 c0 = __builtin_bit_cast(b2, k0), c1 = __builtin_bit_cast(b2, k1);
+    const float ra = __builtin_amdgcn_fdot2_f32_bf16(h, c0, a, false), rb = __builtin_amdgcn_fdot2_f32_bf16(h, c1, b, false);          // x - piece, exactly, one instruction each
+    l[0] = (__bf16)ra; l[1] = (__bf16)rb;
+    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
 }
 template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false, bool SPL = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {

@@ -663,19 +663,30 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvAr
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
-// two fp32 values -> one register of two bf16 (round to nearest even), a in the low half: spelled as the instruction because hipcc converts the lanes of a bf16 vector one by one
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) { unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// (a, b) = hi + lo up to 2^-17: six vector instructions per pair
+// Splitting fp32 values into bf16 pieces, two values per register.  Rounding to bf16 is v_cvt_pk_bf16_f32 (two lanes at once); the residual x - piece is ONE instruction as well:
+// a bf16 dot product with the constants (-1, 0) / (0, -1) and x as the addend (v_dot2c_f32_bf16; exact -- checked bit for bit against shift / mask + subtract on 10^6 values).
+// Everything is written with builtins, not inline asm: the result of a dot instruction needs wait states before its first use, and hipcc inserts them only between
+// instructions it knows (an inline-asm v_cvt_pk right behind the dot read garbage).
+typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wbf16x2 cvt_pk_bf16(float a, float b) { wbf16x2 r; r[0] = (__bf16)a; r[1] = (__bf16)b; return r; }
+// (the constant pair goes through an empty asm so that it stays a register operand: folded into the instruction as the inline constant -1.0 it selects the wrong half)
+__device__ __forceinline__ wbf16x2 bf16_pair_const(unsigned bits) { asm("" : "+v"(bits)); return __builtin_bit_cast(wbf16x2, bits); }
+__device__ __forceinline__ float bf16_resid_lo(float x, wbf16x2 pk) { return __builtin_amdgcn_fdot2_f32_bf16(pk, bf16_pair_const(0x0000bf80u), x, false); }
+__device__ __forceinline__ float bf16_resid_hi(float x, wbf16x2 pk) { return __builtin_amdgcn_fdot2_f32_bf16(pk, bf16_pair_const(0xbf800000u), x, false); }
+// (a, b) = hi + lo up to 2^-17: four vector instructions per pair
 __device__ __forceinline__ void split_pk(float a, float b, unsigned& hi, unsigned& lo) {
-    hi = cvt_pk_bf16(a, b);
-    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+    const wbf16x2 h = cvt_pk_bf16(a, b), l = cvt_pk_bf16(bf16_resid_lo(a, h), bf16_resid_hi(b, h));
+    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
 }
-// (a, b) = hi + mid + lo up to 2^-25: every bit of the fp32 values
+__device__ __forceinline__ void split_bf16(const float4& v, unsigned (&hi)[2], unsigned (&lo)[2]) {
+    split_pk(v.x, v.y, hi[0], lo[0]); split_pk(v.z, v.w, hi[1], lo[1]);
+}
+// (a, b) = hi + mid + lo up to 2^-25: every bit of the fp32 values; seven vector instructions per pair
 __device__ __forceinline__ void split3_pk(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-    mid = cvt_pk_bf16(ra, rb);
-    lo = cvt_pk_bf16(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
+    const wbf16x2 h = cvt_pk_bf16(a, b);
+    const float ra = bf16_resid_lo(a, h), rb = bf16_resid_hi(b, h);
+    const wbf16x2 m = cvt_pk_bf16(ra, rb), l = cvt_pk_bf16(bf16_resid_lo(ra, m), bf16_resid_hi(rb, m));
+    hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
 }
 // NP = pieces per operand: 2 (hi + lo: three MFMAs per product group, ~17-bit mantissas) or 3 (hi + mid + lo: six MFMAs -- hh, hm, mh, hl, lh, mm; the dropped terms are
 // below 2^-24 of the product -- i.e. fp32 accuracy on the bf16 pipe, still 192 instead of 512 matrix-pipe cycles per 16 channels, and co-executing with the vector work)
