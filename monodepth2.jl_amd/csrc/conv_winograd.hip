@@ -1332,7 +1332,7 @@ int g_wino_on = getenv("MD2_NO_WINO") ? 0 : (getenv("MD2_WINO_MODE") ? atoi(gete
 int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 96;
 
 // 3x3, stride 1, dense output lattice, no split-K, fp32; Cin % 16, Cout % 32.  Automatic choice (md2_set_winograd(1, n)): the 64-tile x 32-channel kernel when it
-// launches at least n workgroups (default 160: in-model per-launch timings at batch 32, tools/run_layer_compare.sh -- below that the direct implicit GEMM with its split-K
+// launches at least n workgroups (default 96 64-tile equivalents: in-model per-launch timings at batch 32 and 4, tools/run_layer_compare.sh -- below that the direct implicit GEMM with its split-K
 // wins), the direct convolution otherwise; the first (32-tile x 64-channel) kernel only when pinned (mode 2; mode 3 pins conv_wino3_kernel, whose workgroup is 64 or 32 tiles
 // by workgroup count, wino3_eligible).
 static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh);
