@@ -237,7 +237,10 @@ def main():
 
     out = {"metric": "self-sup training imgs/sec, 416x128 ResNet-18 (1 img = 1 triplet: 3 frames through the encoder)", "value": value, "unit": "triplets/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+           "dtype_note": ("fp32 storage, accumulation, forward and input-gradient MFMAs (v_mfma_f32_32x32x2_f32); the weight-gradient products run as three bf16 MFMAs on hi + lo bf16 pieces of the fp32 operands "
+                          "(fp32 accumulation; the 2^-16 product rounding ends in dw and propagates nowhere -- every gradient array stays inside the parity bounds of tests/)") if args.precision == "f32" else "bf16 MFMA operands, fp32 accumulation / storage / master weights",
+           "data": "synthetic",
            "config": {"workload": "ResNet-%d depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, %s fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4, configs[3] ResNet-50 640x192 batch=16 and configs[4] 1024x320 bf16 automask under extra)" % (
                           args.depth, W, H, C, B, "fp32" if args.precision == "f32" else "bf16 MFMA operands / fp32 accumulate"),
                       "global_batch": world * B, "parallelism": "dp%d" % world, "gradient_exchange": comm_note, "rccl_ranks": rccl_ranks, "loss": final_loss}}
