@@ -36,7 +36,8 @@ typedef struct md2_config {
     double min_depth, max_depth, disparity_smoothness;   /* Params                            */
     double lr;            /* ADAM eta (1e-4, src/Monodepth.jl:125)                           */
     int32_t encoder_depth;/* ResidualNetwork(n): 18 (default when 0; src/Monodepth.jl:117) or 50    */
-    int32_t precision;    /* 0: fp32 everywhere (parity mode, the reference's precision = f32, src/Monodepth.jl:72);
+    int32_t precision;    /* 0: fp32 (parity mode, the reference's precision = f32, src/Monodepth.jl:72): fp32 storage, fp32 accumulation, every product at full fp32 operand
+                             accuracy (fp32 MFMA, or its exact three-bf16-piece decomposition -- md2_set_conv_products below; nothing is rounded to fewer than 24 mantissa bits);
                              1: bf16 mixed precision -- the MFMA operands of the 32-wide conv / weight-gradient tiles are rounded to
                                 bf16, accumulation, activations, master weights, BatchNorm, loss and ADAM stay fp32          */
     int32_t target_id;    /* TrainCache.target_id, 1-based frame of the triplet the depth decoder sees (src/model.jl:16, src/training.jl:25); 0 = the default 2 */
@@ -44,8 +45,9 @@ typedef struct md2_config {
                              target is paired (source, target) and its pose inverted, src/training.jl:29); {0, 0} = the default {1, 3} (src/dtk.jl, src/kitty.jl)     */
     int32_t scale_levels[5]; /* DepthDecoder(; scale_levels) (src/depth_decoder.jl:26-47): ascending levels in 1..5, 0-terminated when fewer than five; output i has the resolution
                              H >> (5 - level_i); branches 1..max level are built, a head after each listed level.  All zero = the default 2:5 (src/Monodepth.jl:106)            */
-    double scales[5];     /* TrainCache.scales (src/Monodepth.jl:54,107): the smoothness weight of output i is disparity_smoothness * scales[i] (src/training.jl:67);
-                             0 = the reference's 1 / 2^(5 - level_i)                                                                                                      */
+    double scales[5];     /* TrainCache.scales (src/Monodepth.jl:54,107): the smoothness weight of output i is disparity_smoothness * scales[i] (src/training.jl:67).
+                             All five 0 (a zero-initialised struct) = the reference's 1 / 2^(5 - level_i) for every output; otherwise each entry is taken as given -- an explicit
+                             0 switches that output's smoothness term off, as in the reference -- and a negative entry asks for that output's default                         */
 } md2_config;
 
 /* ---- handle ------------------------------------------------------------------------------- */
@@ -107,15 +109,23 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host_state, int64_t n);
 int32_t md2_set_deterministic(int32_t on);
 /* Algorithm choice for the 3x3 / stride-1 convolutions (the reference leaves it to cuDNN behind Flux `Conv`, src/depth_decoder.jl:13-14): on = 1 (default) routes launches
  * with at least min_blocks workgroups (default 96 64-tile equivalents; < 0 keeps the current value) to the fused Winograd F(2x2,3x3) kernels, on = 0 forces the direct
- * implicit GEMM; on = 2 / 3 pin one of the two fp32 Winograd kernels wherever it applies (tests, tuning).
- * on = 4 (opt-in, "split" mode): the forward / input-gradient Winograd products run on the bf16 matrix pipe at close-to-fp32 accuracy -- every fp32 operand is split into
- * hi + lo bf16 pieces and each product group takes three v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~17-bit operand mantissas; storage, transforms and everything
- * else stay fp32).  Forward + loss stay inside the 1e-4 parity bound, gradients are ~5x noisier than with the fp32 MFMA; 1.3-1.5x faster on those launches.
- * on = 5: the same with three pieces per operand (hi + mid + lo, six MFMAs per product group): every bit of the fp32 operands, results as close to the oracle as the fp32
- * MFMA's, 1.15-1.25x faster per launch -- but no faster in the step (the kernel is vector-bound and shares the vector units with the weight-gradient stream).
- * Process-wide; change it between steps, not between md2_train_loss and md2_backward of one step (the transformed weights of a step are written in the layout of the mode
- * it started in); also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
+ * implicit GEMM; on = 2 / 3 pin one of the two Winograd kernels wherever it applies (tests, tuning).  on = 4 / 5 are legacy aliases of
+ * md2_set_winograd(1, .) + md2_set_conv_products(2 / 3, -1).  Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks);
+/* How the fp32 products of the convolutions are formed (the role cuDNN's math mode plays behind Flux; the reference computes in fp32, src/Monodepth.jl:72).
+ *   fwd_dgrad: the Winograd forward / input-gradient kernels;  wgrad: the weight-gradient kernels (Winograd-domain and per-tap).  -1 keeps the current value.
+ *   0 = v_mfma_f32_32x32x2_f32, the fp32 MFMA.
+ *   1 = (default) per launch whichever of the two full-accuracy forms 0 and 3 is faster at the launch's shape (the rule is in csrc/md2_internal.h, from in-model timings).
+ *   3 = exact split: every fp32 operand is the exact sum of three bf16 pieces (hi + mid + lo = all 24 mantissa bits); a product group takes six
+ *       v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped cross terms are below 2^-24 of a product, the size of fp32's own product rounding).  Same accuracy as
+ *       the fp32 MFMA -- measured: disparities within 4.6e-6 of the oracle against 4.5e-6 -- on the bf16 matrix pipe, which co-executes with vector instructions.
+ *   2 = REDUCED precision, opt-in, never a default: two pieces (hi + lo, ~16-bit operand mantissas), three MFMAs per product group.
+ * Defaults: 1 / 1 (MD2_DEFAULT_WINO_PIECES / MD2_DEFAULT_WGRAD_PIECES in csrc/md2_internal.h; MD2_WINO_PIECES / MD2_WGRAD_PIECES in the environment at load time), i.e. full
+ * fp32 operand accuracy in every product of md2_config.precision = 0.  Process-wide; the layout a handle's Winograd operands were written in is recorded per handle when they
+ * are refreshed (md2_train_loss / md2_model_forward), so changing the mode at any time -- also between md2_train_loss and md2_backward, or from another handle or
+ * thread -- cannot make a kernel misread them: the change applies from the next refresh. */
+int32_t md2_set_conv_products(int32_t fwd_dgrad, int32_t wgrad);
+int32_t md2_get_conv_products(int32_t* fwd_dgrad, int32_t* wgrad);
 /* ADAM moments (Flux parameter layout, host) + running beta powers: the optimiser state the reference's BSON checkpoints
  * (src/Monodepth.jl:191-194) omit; with md2_params_get/set this gives true resume. */
 int32_t md2_opt_state_get(md2_handle* h, float* host_m, float* host_v, int64_t n, double* beta1p, double* beta2p);

@@ -99,6 +99,8 @@ _SIGS = {
     "md2_bn_state_set": (I32, [P, P, I64]),
     "md2_set_deterministic": (I32, [I32]),
     "md2_set_winograd": (I32, [I32, I32]),
+    "md2_set_conv_products": (I32, [I32, I32]),
+    "md2_get_conv_products": (I32, [C.POINTER(I32), C.POINTER(I32)]),
     "md2_comm_unique_id": (I32, [P]),
     "md2_comm_init": (I32, [P, I32, I32, P]),
     "md2_comm_destroy": (I32, [P]),

@@ -1107,10 +1107,11 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 // address/carry VALU instructions of the loader would run ahead of, instead of between, the 32 MFMAs of a step)
 // ONE: 1x1 / stride-1 convolution on dense views (pixel m of dy and of x are the same flattened index): the loader is base + m * pixel stride, no (n, oh, ow) bookkeeping --
 // the ResNet-50 bottlenecks' weight gradients (33 launches per step) spent more issue slots on those carries than on their 32 MFMAs per step
-// SPL ("split", MF == 32 only): the products run on the bf16 matrix pipe at close-to-fp32 accuracy -- each operand fragment (8 pixels of one channel, read as a strided column
-// of the fp32 LDS tile) is split into hi + lo bf16 pieces, x = hi + lo up to 2^-17 |x|, and a 16-pixel k-group takes three v_mfma_f32_32x32x16_bf16 (lo hi, hi lo, hi hi; fp32
-// accumulation) instead of eight v_mfma_f32_32x32x2_f32: 96 instead of 512 matrix-pipe cycles, and -- unlike the fp32 MFMA (profiles/r03_wino3_pmc.md) -- beside the other
-// waves' vector work.  The rounding ends in dw and propagates nowhere, so this is the default for the weight gradients (MD2_WGRAD_SPLIT=0: fp32 MFMAs).
+// SPL ("split", MF == 32 only; g_wgrad_pieces): the products run on the bf16 matrix pipe -- each operand fragment (8 pixels of one channel, read as a strided column of the
+// fp32 LDS tile) is split into SPL bf16 pieces.  SPL = 3: x = hi + mid + lo exactly (all 24 mantissa bits), a 16-pixel k-group takes six v_mfma_f32_32x32x16_bf16 (lo hi,
+// hi lo, mid mid, mid hi, hi mid, hi hi; fp32 accumulation; the dropped terms are below 2^-24 of the product) instead of eight v_mfma_f32_32x32x2_f32: fp32-MFMA accuracy at
+// 192 instead of 512 matrix-pipe cycles, and -- unlike the fp32 MFMA (profiles/r03_wino3_pmc.md) -- beside the other waves' vector work.  SPL = 2: hi + lo only (x up to
+// 2^-17 |x|), three MFMAs: reduced precision, opt-in (md2_set_conv_products(-1, 2)).
 typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
 // (builtins only: see the note on wait states in conv_winograd.hip)
 __device__ __forceinline__ void wg_split_pk(float a, float b, unsigned& hi, unsigned& lo) {
@@ -1122,9 +1123,21 @@ __device__ __forceinline__ void wg_split_pk(float a, float b, unsigned& hi, unsi
     l[0] = (__bf16)ra; l[1] = (__bf16)rb;
     hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
 }
-template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false, bool SPL = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
+// (a, b) = hi + mid + lo up to 2^-25: every bit of the fp32 values
+__device__ __forceinline__ void wg_split3_pk(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 h, m, l; h[0] = (__bf16)a; h[1] = (__bf16)b;
+    unsigned k0 = 0x0000bf80u, k1 = 0xbf800000u; asm("" : "+v"(k0)); asm("" : "+v"(k1));
+    const b2 c0 = __builtin_bit_cast(b2, k0), c1 = __builtin_bit_cast(b2, k1);
+    const float ra = __builtin_amdgcn_fdot2_f32_bf16(h, c0, a, false), rb = __builtin_amdgcn_fdot2_f32_bf16(h, c1, b, false);
+    m[0] = (__bf16)ra; m[1] = (__bf16)rb;
+    const float sa = __builtin_amdgcn_fdot2_f32_bf16(m, c0, ra, false), sb = __builtin_amdgcn_fdot2_f32_bf16(m, c1, rb, false);
+    l[0] = (__bf16)sa; l[1] = (__bf16)sb;
+    hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
+}
+template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false, int SPL = 0>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {
-    static_assert(!SPL || (MF == 32 && BKP % 16 == 0), "the split path is built on the 32x32x16 bf16 MFMA");
+    static_assert(SPL == 0 || ((SPL == 2 || SPL == 3) && MF == 32 && BKP % 16 == 0), "the split path is built on the 32x32x16 bf16 MFMA");
     // LDS tiles [pixel][channel]: A operand lane (row = channel, k = pixel) reads consecutive channels of one pixel row.
     // 32x32x2: the two 32-lane halves are separate ds_read_b32 groups -> conflict-free for any row length.
     // 16x16x4: 4 pixel rows per instruction, LD % 32 == 16 keeps the two 16-lane halves of a group on disjoint banks.
@@ -1245,14 +1258,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
     // operand fragments of one step (KK MFMA k-groups): A = dY[pixel k][channel row], B = x[pixel k][channel col]
     constexpr int KK = SPL ? BKP / 16 : (MF == 32 ? BKP / 2 : (KSPLIT ? BKP / 16 : BKP / 4));
     struct OpsF { float a[KK][TW], b[KK][TW]; };
-    struct OpsS { wg_u32x4 ah[KK][TW], al[KK][TW], bh[KK][TW], bl[KK][TW]; };          // 8 bf16 per register quad: pixels 8 g .. 8 g + 7 of the k-group, hi and lo pieces
-    using Ops = typename std::conditional<SPL, OpsS, OpsF>::type;
+    constexpr int NPC = SPL ? SPL : 1;
+    struct OpsS { wg_u32x4 ap[NPC][KK][TW], bp[NPC][KK][TW]; };          // 8 bf16 per register quad: pixels 8 g .. 8 g + 7 of the k-group; piece 0 = hi ... NPC - 1 = lo
+    using Ops = typename std::conditional<SPL != 0, OpsS, OpsF>::type;
     const int lrow = lane & (MF - 1), lkk = lane / MF;       // k within a group: 0..1 (32x32x2) or 0..3 (16x16x4)
     const int kq0 = KSPLIT ? wave * KK : 0;
     auto read_ops = [&](int so, Ops& o) {
         const float* D = smem + so;
         const float* X = smem + so + BKP * LD;
-        if constexpr (SPL) {
+        if constexpr (SPL != 0) {
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 const int k0 = kk * 16 + 8 * lkk;          // lane = (channel, pixel group lkk of 8)
@@ -1260,13 +1274,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
                 for (int i = 0; i < TW; ++i) {
                     const float* c = D + k0 * LD + wr * (T / 2) + i * MF + lrow;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { unsigned hi, lo; wg_split_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, lo); o.ah[kk][i][e] = hi; o.al[kk][i][e] = lo; }
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (SPL == 3) { unsigned hi, mid, lo; wg_split3_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, mid, lo); o.ap[0][kk][i][e] = hi; o.ap[1][kk][i][e] = mid; o.ap[2][kk][i][e] = lo; }
+                        else { unsigned hi, lo; wg_split_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, lo); o.ap[0][kk][i][e] = hi; o.ap[NPC - 1][kk][i][e] = lo; }
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < TW; ++j) {
                     const float* c = X + k0 * LD + wq * (T / 2) + j * MF + lrow;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { unsigned hi, lo; wg_split_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, lo); o.bh[kk][j][e] = hi; o.bl[kk][j][e] = lo; }
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (SPL == 3) { unsigned hi, mid, lo; wg_split3_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, mid, lo); o.bp[0][kk][j][e] = hi; o.bp[1][kk][j][e] = mid; o.bp[2][kk][j][e] = lo; }
+                        else { unsigned hi, lo; wg_split_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, lo); o.bp[0][kk][j][e] = hi; o.bp[NPC - 1][kk][j][e] = lo; }
+                    }
                 }
             }
         } else
@@ -1280,16 +1300,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
         }
     };
     auto mfmas = [&](const Ops& o) {
-        if constexpr (SPL) {
+        if constexpr (SPL != 0) {
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
                 for (int i = 0; i < TW; ++i)
 #pragma unroll
                     for (int j = 0; j < TW; ++j) {
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, o.ah[kk][i]), al = __builtin_bit_cast(bf16x8, o.al[kk][i]), bh = __builtin_bit_cast(bf16x8, o.bh[kk][j]), bl = __builtin_bit_cast(bf16x8, o.bl[kk][j]);
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, o.ap[0][kk][i]), al = __builtin_bit_cast(bf16x8, o.ap[NPC - 1][kk][i]), bh = __builtin_bit_cast(bf16x8, o.bp[0][kk][j]), bl = __builtin_bit_cast(bf16x8, o.bp[NPC - 1][kk][j]);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);          // small terms first
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+                        if constexpr (SPL == 3) {
+                            const bf16x8 am = __builtin_bit_cast(bf16x8, o.ap[1][kk][i]), bm = __builtin_bit_cast(bf16x8, o.bp[1][kk][j]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
                     }
         } else
@@ -1382,14 +1408,22 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     splitk = (steps_total + sps - 1) / sps;
     const dim3 g(tiles * taps * splitk);
     if constexpr (T >= 64) {
-        static const bool spl = !(getenv("MD2_WGRAD_SPLIT") && atoi(getenv("MD2_WGRAD_SPLIT")) == 0);
-        if (spl && fast && !refl && !g_deterministic) {          // products on the bf16 matrix pipe (split operands): see conv_wgrad_kernel
+        const int pieces = wgrad_resolve_pieces_tap(g_wgrad_pieces);
+        if (pieces && fast && !refl) {          // products on the bf16 matrix pipe (split operands; 3 = exact, 2 = reduced precision opt-in): see conv_wgrad_kernel.
+            // (bit-reproducible mode keeps this kernel: splitk = 1 above -> one workgroup per (tile, tap), one atomic per weight)
             static const bool no_one1 = getenv("MD2_NO_WGRAD_ONE") != nullptr;
             const bool one1 = !no_one1 && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
-            if (one1 && a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
-            else if (one1) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
-            else if (a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
-            else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            if (pieces == 3) {
+                if (one1 && a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, true, 3>), g, dim3(256), 0, s, a, sps, steps_total);
+                else if (one1) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, true, 3>), g, dim3(256), 0, s, a, sps, steps_total);
+                else if (a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, false, 3>), g, dim3(256), 0, s, a, sps, steps_total);
+                else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, false, 3>), g, dim3(256), 0, s, a, sps, steps_total);
+            } else {
+                if (one1 && a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, true, 2>), g, dim3(256), 0, s, a, sps, steps_total);
+                else if (one1) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, true, 2>), g, dim3(256), 0, s, a, sps, steps_total);
+                else if (a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, false, 2>), g, dim3(256), 0, s, a, sps, steps_total);
+                else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, false, 2>), g, dim3(256), 0, s, a, sps, steps_total);
+            }
             return;
         }
         static const bool no_one = getenv("MD2_NO_WGRAD_ONE") != nullptr;
@@ -1762,13 +1796,13 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     if (a.in_scale && !wgrad_taps32_eligible(a) && !(a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.padmode != PAD_REFLECT)) {
         fprintf(stderr, "md2: conv_wgrad: the input transform is built into the all-taps kernel (3x3, stride 1) and the 64- / 128-wide tile kernels only\n"); abort();
     }
+    if (conv_wino_wgrad_eligible(a)) { launch_conv_wino_wgrad(a, s); return; }          // (bit-reproducible mode included: one workgroup per weight tile, its bias sum a single add)
     if (g_deterministic && a.db && (wgrad_taps32_eligible(a) || wgrad_patch_eligible(a))) {      // the fused bias gradient adds one atomic per wave: use the ordered column sum
         View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s);
         WgradArgs b = a; b.db = nullptr;
         if (wgrad_taps32_eligible(b)) launch_wgrad_taps32(b, s); else if (b.Cout == 16) launch_wgrad_patch<1>(b, s); else launch_wgrad_patch<2>(b, s);
         return;
     }
-    if (conv_wino_wgrad_eligible(a)) { launch_conv_wino_wgrad(a, s); return; }
     if (wgrad_taps32_eligible(a)) { launch_wgrad_taps32(a, s); return; }
     if (wgrad_patch_eligible(a)) { if (a.Cout == 16) launch_wgrad_patch<1>(a, s); else launch_wgrad_patch<2>(a, s); return; }
     if (a.db) { View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s); }

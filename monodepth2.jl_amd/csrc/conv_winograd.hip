@@ -42,8 +42,8 @@ __device__ __forceinline__ int fdiv24(int m, int d) {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// pieces per fp32 operand of the split Winograd path: 0 = off (fp32 MFMAs), 2 = hi + lo (md2_set_winograd(4): ~17-bit mantissas, opt-in), 3 = hi + mid + lo (exact; mode 5)
-static inline int wino_split_pieces() { return g_wino_on == 4 ? 2 : (g_wino_on == 5 ? 3 : 0); }
+// pieces per fp32 operand of the split Winograd path (g_wino_pieces, md2_set_conv_products): 0 = off (fp32 MFMAs), 3 = hi + mid + lo (exact), 2 = hi + lo (~16-bit operand
+// mantissas: reduced precision, opt-in).  A launch never reads the global: the layout its operand U was written in travels in ConvArgs::wino_pieces.
 
 __device__ __forceinline__ int wino_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     const int cq = rest % nq, ct = rest / nq;
     if (ct >= (Cout >> 5)) return;
     const int co = ct * 32 + co_lo, ci = cq * 4;
+    split = wino_resolve_pieces(split, Cin);          // (`split` arrives as the mode: automatic = by the layer's reduction length)
     float4 g[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) g[t] = *reinterpret_cast<const float4*>(w + ((long)co * 9 + t) * Cin + ci);
@@ -104,9 +105,9 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
         }
     }
 }
-void launch_wino_weights(const float* w, float* U, int Cout, int Cin, hipStream_t s) {
+void launch_wino_weights(const float* w, float* U, int Cout, int Cin, int pieces, hipStream_t s) {
     const long n = (long)(Cout / 32) * (Cin / 4) * 32;
-    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, U, Cout, Cin, wino_split_pieces());
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, U, Cout, Cin, pieces);
 }
 // all eligible layers of a handle in one launch: desc = {w offset, U offset, Cout, Cin} per layer, block ranges by prefix sums in `first`
 __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* __restrict__ wbase, float* __restrict__ Ubase, const long* __restrict__ desc, int nlayers, int split) {
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
     const int cq = rest % nq, ct = rest / nq;
     if (ct >= (Cout >> 5)) return;
     const int co = ct * 32 + co_lo, ci = cq * 4;
+    split = wino_resolve_pieces(split, Cin);          // (`split` arrives as the mode: automatic = by the layer's reduction length)
     float4 g[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) g[t] = *reinterpret_cast<const float4*>(w + ((long)co * 9 + t) * Cin + ci);
@@ -147,9 +149,9 @@ __global__ __launch_bounds__(256) void wino_weights_batched_kernel(const float* 
         }
     }
 }
-void launch_wino_weights_batched(const float* wbase, float* Ubase, const long* desc_dev, int nlayers, int total_blocks, hipStream_t s) {
+void launch_wino_weights_batched(const float* wbase, float* Ubase, const long* desc_dev, int nlayers, int total_blocks, int pieces, hipStream_t s) {
     if (nlayers <= 0 || total_blocks <= 0) return;
-    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, s, wbase, Ubase, desc_dev, nlayers, wino_split_pieces());
+    hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, s, wbase, Ubase, desc_dev, nlayers, pieces);
 }
 long wino_weight_blocks(int Cout, int Cin) { return ((long)(Cout / 32) * (Cin / 4) * 32 + 255) / 256; }
 
@@ -879,7 +881,7 @@ static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
     // workgroup for launches with at least n of them
     static const long small = getenv("MD2_WINO_SMALL_BLOCKS") ? atol(getenv("MD2_WINO_SMALL_BLOCKS")) : (1L << 40);
     nh = g_wino_nh == 1 ? 1 : (g_wino_nh == 2 ? 2 : (b64 < small ? 1 : 2));
-    if (wino_split_pieces()) { if (!ok32 || a.Cin % 16 != 0) return false; nh = 1; }          // split mode: conv_wino3s_kernel (32 tiles, 16-channel chunks) or the direct convolution
+    if (a.wino_pieces) { if (!ok32 || a.Cin % 16 != 0) return false; nh = 1; }          // split mode: conv_wino3s_kernel (32 tiles, 16-channel chunks) or the direct convolution
     if (nh == 1 && !ok32) nh = 2;
     if (nh == 2 && !ok64) nh = 1;
     const int T = 32 * nh;
@@ -919,9 +921,9 @@ static void launch_wino3s_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s)
     else if (a.bst) hipLaunchKernelGGL((conv_wino3s_kernel<0, 1, NP>), dim3(grid), dim3(256), lds, s, a, g);
     else hipLaunchKernelGGL((conv_wino3s_kernel<0, 0, NP>), dim3(grid), dim3(256), lds, s, a, g);
 }
-static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) { if (wino_split_pieces() == 3) launch_wino3s_t<3>(a, g, s); else launch_wino3s_t<2>(a, g, s); }
+static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) { if (a.wino_pieces == 3) launch_wino3s_t<3>(a, g, s); else launch_wino3s_t<2>(a, g, s); }
 static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) {
-    if (wino_split_pieces()) launch_wino3s(a, g, s);
+    if (a.wino_pieces) launch_wino3s(a, g, s);
     else if (nh == 1) launch_wino3_t<3, 1>(a, g, s); else launch_wino3_t<5, 2>(a, g, s);
 }
 
@@ -1102,14 +1104,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same weight gradient with the products on the bf16 matrix pipe ("split": dM and V as hi + lo bf16 pieces, three v_mfma_f32_32x32x16_bf16 per position, fp32 accumulation --
-// see conv_wino3s_kernel for the arithmetic).  Here the rounding (2^-16 per product, over ~10^5 pixels) ends in dw and goes nowhere else: it cannot move a forward value or
-// another layer's gradient, which is why this -- unlike the split forward kernel -- is the default for the eligible layers (MD2_WINO_WGRAD_SPLIT=0: the fp32 MFMA kernel).
+// The same weight gradient with the products on the bf16 matrix pipe ("split": dM and V as bf16 pieces of the fp32 values, v_mfma_f32_32x32x16_bf16 with fp32 accumulation --
+// see conv_wino3s_kernel for the arithmetic).  NP = 3 (hi + mid + lo, six MFMAs per product) carries every mantissa bit of both operands: fp32-MFMA accuracy, and it is what
+// g_wgrad_pieces = 3 selects; NP = 2 (hi + lo, three MFMAs) rounds the operands to ~16 bits -- reduced precision, opt-in only (md2_set_conv_products(-1, 2)).
 // The MFMA's K = 16 is a batch's 16 tiles: lane = (channel, tile group of 8).  Block = 32 output x 32 input channels (64 accumulator registers: the 64-channel block of the
 // fp32 kernel spilled once the piece vectors joined its 128 accumulators), LDS stage = x [160 slots][32 ci] | dy [16 tiles][4 px][32 co].
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int WS_DYF = WG_TB * 4 * 32, WS_STAGE = WG_XF + WS_DYF;
-template <int XF>
+// NP = pieces per operand: 3 = hi + mid + lo, six MFMAs per product (lh, hl, mm, mh, hm, hh: the dropped terms are below 2^-24 of the product) -- every bit of both fp32
+// operands enters, i.e. the accuracy of the fp32 MFMA kernel above; 2 = hi + lo, three MFMAs (~16-bit operand mantissas: reduced precision, opt-in)
+template <int XF, int NP>
 __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, WinoWgGeo geo) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
@@ -1212,34 +1216,73 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
                 for (int q = 0; q < 32; ++q) t += wsm[so + dyo + q * 32];
                 bsum += t;
             }
-            unsigned ph[2][4], pl[2][4], rh[4][4], rl[4][4];          // [column][tile pair]: two bf16 (tiles 2 tp, 2 tp + 1) per register
-#pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                float R[2][4], Pv[2][2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float* xs = wsm + so + (2 * tp + u) * (2 * 32);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) R[u][c] = fmaf(sg, xs[xo2 + c * 32], xs[xo1 + c * 32]);
-                    const float* ds = wsm + so + dyo + (2 * tp + u) * (4 * 32);
-                    const float y00 = ds[0], y01 = ds[32], y10 = ds[64], y11 = ds[96];
-                    Pv[u][0] = ca * y00 + cb * y10; Pv[u][1] = ca * y01 + cb * y11;
+            // small terms first (a = dy column pieces, b = patch column pieces; piece index 0 = hi, NP - 1 = lo)
+            auto prod = [&](f32x16& acc, const unsigned (&ap)[NP][4], const unsigned (&bp)[NP][4]) {
+                const b8_t ah = cat8(ap[0]), al = cat8(ap[NP - 1]), bh = cat8(bp[0]), bl = cat8(bp[NP - 1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                if constexpr (NP == 3) {
+                    const b8_t am = cat8(ap[1]), bm = cat8(bp[1]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
                 }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            };
+            if constexpr (NP == 2) {
+                unsigned pp[2][NP][4], rp[4][NP][4];          // [column][piece: hi, lo][tile pair]: two bf16 (tiles 2 tp, 2 tp + 1) per register
 #pragma unroll
-                for (int c = 0; c < 4; ++c) split_pk(R[0][c], R[1][c], rh[c][tp], rl[c][tp]);
+                for (int tp = 0; tp < 4; ++tp) {
+                    float R[2][4], Pv[2][2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) split_pk(Pv[0][q], Pv[1][q], ph[q][tp], pl[q][tp]);
-                __builtin_amdgcn_sched_barrier(0);          // (keeps hipcc from hoisting all 96 LDS reads of the batch: registers)
-            }
-            {
-                const b8_t p0h = cat8(ph[0]), p0l = cat8(pl[0]), p1h = cat8(ph[1]), p1l = cat8(pl[1]);
-#define WGS_PROD(k_, ah_, al_, b_) do { const b8_t bh_ = cat8(rh[b_]), bl_ = cat8(rl[b_]); \
-                    P[k_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bh_, P[k_], 0, 0, 0); \
-                    P[k_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bl_, P[k_], 0, 0, 0); \
-                    P[k_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, P[k_], 0, 0, 0); } while (0)
-                WGS_PROD(0, p0h, p0l, 0); WGS_PROD(1, p0h, p0l, 1); WGS_PROD(2, p0h, p0l, 2);          // P00, P01, P02
-                WGS_PROD(3, p1h, p1l, 1); WGS_PROD(4, p1h, p1l, 2); WGS_PROD(5, p1h, p1l, 3);          // P11, P12, P13
-#undef WGS_PROD
+                    for (int u = 0; u < 2; ++u) {
+                        const float* xs = wsm + so + (2 * tp + u) * (2 * 32);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) R[u][c] = fmaf(sg, xs[xo2 + c * 32], xs[xo1 + c * 32]);
+                        const float* ds = wsm + so + dyo + (2 * tp + u) * (4 * 32);
+                        const float y00 = ds[0], y01 = ds[32], y10 = ds[64], y11 = ds[96];
+                        Pv[u][0] = ca * y00 + cb * y10; Pv[u][1] = ca * y01 + cb * y11;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) split_pk(R[0][c], R[1][c], rp[c][0][tp], rp[c][1][tp]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) split_pk(Pv[0][q], Pv[1][q], pp[q][0][tp], pp[q][1][tp]);
+                    __builtin_amdgcn_sched_barrier(0);          // (keeps hipcc from hoisting all 96 LDS reads of the batch: registers)
+                }
+                prod(P[0], pp[0], rp[0]); prod(P[1], pp[0], rp[1]); prod(P[2], pp[0], rp[2]);          // P00, P01, P02
+                prod(P[3], pp[1], rp[1]); prod(P[4], pp[1], rp[2]); prod(P[5], pp[1], rp[3]);          // P11, P12, P13
+            } else {
+                // three pieces: the dy columns first (24 registers of pieces), then one patch column at a time (12), each followed by the products it takes part in -- all six
+                // columns' pieces at once (72 registers beside 96 accumulators) spilt
+                unsigned pp[2][NP][4];
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    float Pv[2][2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float* ds = wsm + so + dyo + (2 * tp + u) * (4 * 32);
+                        const float y00 = ds[0], y01 = ds[32], y10 = ds[64], y11 = ds[96];
+                        Pv[u][0] = ca * y00 + cb * y10; Pv[u][1] = ca * y01 + cb * y11;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) split3_pk(Pv[0][q], Pv[1][q], pp[q][0][tp], pp[q][1][tp], pp[q][2][tp]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned rc[NP][4];
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) {
+                        const float* x0 = wsm + so + (2 * tp) * (2 * 32) + c * 32;
+                        const float R0 = fmaf(sg, x0[xo2], x0[xo1]), R1 = fmaf(sg, x0[xo2 + 64], x0[xo1 + 64]);
+                        split3_pk(R0, R1, rc[0][tp], rc[1][tp], rc[2][tp]);
+                    }
+                    if (c == 0) prod(P[0], pp[0], rc);                                          // P00
+                    if (c == 1) { prod(P[1], pp[0], rc); prod(P[3], pp[1], rc); }               // P01, P11
+                    if (c == 2) { prod(P[2], pp[0], rc); prod(P[4], pp[1], rc); }               // P02, P12
+                    if (c == 3) prod(P[5], pp[1], rc);                                          // P13
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             lstore(WS_STAGE - so);
@@ -1283,7 +1326,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
 bool conv_wino_wgrad_eligible(const WgradArgs& a) {
     static const bool off = getenv("MD2_NO_WINO_WGRAD") != nullptr;
     static const long min_m = getenv("MD2_WINO_WGRAD_MIN_M") ? atol(getenv("MD2_WINO_WGRAD_MIN_M")) : 1;          // (with the split kernel: ahead of the all-taps kernel at every size -- batch 4: 3.79 -> 3.71 ms per step)
-    if (off || !g_wino_on || g_deterministic || a.bf16) return false;
+    if (off || !g_wino_on || a.bf16) return false;          // (deterministic mode keeps this kernel: one workgroup per weight tile, launch_conv_wino_wgrad)
     if (!(a.KH == 3 && a.KW == 3 && a.stride == 1) || a.Cout % 64 != 0 || a.Cin % 32 != 0) return false;
     if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
     if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
@@ -1298,21 +1341,31 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     static const int want = getenv("MD2_WINO_WGRAD_BLOCKS") ? atoi(getenv("MD2_WINO_WGRAD_BLOCKS")) : 512;
     int ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));
     g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
-    static const bool split = !(getenv("MD2_WINO_WGRAD_SPLIT") && atoi(getenv("MD2_WINO_WGRAD_SPLIT")) == 0);          // MD2_WINO_WGRAD_SPLIT=0: the fp32-MFMA kernel
-    if (split) {          // 32 x 32-channel blocks
+    // bit-reproducible mode: ONE workgroup per weight tile walks every batch, so each weight (and bias) element receives exactly one atomic add onto zero
+    if (g_deterministic) { ksn = 1; g.bpb = g.nb; }
+    const int pieces = wgrad_resolve_pieces_wino(g_wgrad_pieces, a.M, a.Cout, a.Cin);
+    if (pieces) {          // products on the bf16 matrix pipe (3: exact three-piece split; 2: reduced precision, opt-in); 32 x 32-channel blocks
         g.nco = a.Cout / 32;
         ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));
+        if (g_deterministic) ksn = 1;
         g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
         constexpr size_t lds_s = std::max((size_t)2 * WS_STAGE * sizeof(float), (size_t)12 * 32 * 33 * sizeof(float));
         static bool attr_s = false;
         if (!attr_s) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
             attr_s = true;
         }
         const int grid_s = g.nco * g.nci * ksn;
-        if (a.in_scale) hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<1>), dim3(grid_s), dim3(256), lds_s, s, a, g);
-        else hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<0>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+        if (pieces == 3) {
+            if (a.in_scale) hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<1, 3>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+            else hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<0, 3>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+        } else {
+            if (a.in_scale) hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<1, 2>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+            else hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<0, 2>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+        }
         return;
     }
     constexpr size_t lds_pipe = (size_t)2 * WG_STAGE * sizeof(float), lds_epi = (size_t)12 * 32 * 33 * sizeof(float);
@@ -1328,7 +1381,13 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((conv_wino_wgrad_kernel<0>), dim3(grid), dim3(256), lds, s, a, g);
 }
 
-int g_wino_on = getenv("MD2_NO_WINO") ? 0 : (getenv("MD2_WINO_MODE") ? atoi(getenv("MD2_WINO_MODE")) : 1);          // MD2_WINO_MODE=2/3: pin one kernel (md2_set_winograd)
+// load-time defaults (md2_set_winograd / md2_set_conv_products change them): MD2_WINO_MODE=2/3 pins one kernel, 4 / 5 = mode 1 with two / three bf16 pieces per operand;
+// MD2_WINO_PIECES / MD2_WGRAD_PIECES = 0 (fp32 MFMA), 3 (exact split), 2 (reduced precision)
+static int env_wino_mode() { return getenv("MD2_NO_WINO") ? 0 : (getenv("MD2_WINO_MODE") ? atoi(getenv("MD2_WINO_MODE")) : 1); }
+static int env_pieces(const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : dflt; return (v >= 1 && v <= 3) ? v : 0; }
+int g_wino_on = env_wino_mode() >= 4 ? 1 : env_wino_mode();
+int g_wino_pieces = env_pieces("MD2_WINO_PIECES", env_wino_mode() == 4 ? 2 : (env_wino_mode() == 5 ? 3 : MD2_DEFAULT_WINO_PIECES));
+int g_wgrad_pieces = env_pieces("MD2_WGRAD_PIECES", MD2_DEFAULT_WGRAD_PIECES);
 int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 96;
 
 // 3x3, stride 1, dense output lattice, no split-K, fp32; Cin % 16, Cout % 32.  Automatic choice (md2_set_winograd(1, n)): the 64-tile x 32-channel kernel when it
@@ -1343,7 +1402,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
     if (a.padmode == PAD_REFLECT && (a.pad != 1 || a.H < 2 || a.W < 2)) return false;
     Wino2Geo g; int nh = 2;
-    if (g_wino_on == 1 || g_wino_on >= 4) return wino3_eligible(a, g, nh);
+    if (g_wino_on == 1 || a.wino_pieces) return wino3_eligible(a, g, nh);          // (U in bf16 pieces: only conv_wino3s_kernel reads that layout)
     const long tiles = (long)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 1) / 2);
     const int cob = a.Cout % 64 == 0 ? 64 : 32;
     return ((tiles + WT - 1) / WT) * (a.Cout / cob) >= g_wino_min_blocks;

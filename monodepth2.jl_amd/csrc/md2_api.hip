@@ -77,6 +77,8 @@ struct md2_handle {
     long* wdesc_dev = nullptr; int n_wdesc = 0;
     // Winograd operands U = G g G^T of every 3x3 / stride-1 layer, refreshed once per step from P (forward) and WD (input gradient)
     float *UF = nullptr, *UD = nullptr; long n_uf = 0, n_ud = 0; long *udesc_f = nullptr, *udesc_d = nullptr; int n_udf = 0, n_udd = 0, ublk_f = 0, ublk_d = 0; hipEvent_t ev_uf = nullptr;
+    int u_pieces_f = 0, u_pieces_d = 0;      // layout UF / UD were last written in (g_wino_pieces at that refresh): every launch that reads them is told through ConvArgs::wino_pieces,
+                                             // so a md2_set_conv_products between md2_train_loss and md2_backward (or from another handle) cannot make a kernel misread its operand
     // weight gradients run on a second stream, concurrently with the input-gradient / BN-pullback chain of the main stream
     hipStream_t s3 = nullptr; hipStream_t cur = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // pose branch stream; `cur` = stream of the chain being enqueued
     hipStream_t s4 = nullptr; int wg_rr = 0; int n_wg_streams = 1; hipEvent_t ev_join4 = nullptr;
@@ -290,7 +292,9 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
     ConvArgs a = a_in; a.bf16 = h->bf16;
     a.ws = (h->cur && h->cur == h->s3) ? h->ws_pose : h->ws_main; a.ws_cap = h->ws_cap;
     char d[112] = "";
-    if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W);
+    // (alg: the route launch_conv_igemm takes -- conv_igemm_executed_flops applies the same test -- so that a test can see which kernels a step ran: md2_profile_dump)
+    if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d alg=%s", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W,
+                          conv_igemm_executed_flops(a) < conv_igemm_flops(a) ? (a.wino_pieces ? "winograd_split" : "winograd") : "direct");
     h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
     if (h->prof) { h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a); h->prof_exec[CLS_IGEMM] += conv_igemm_executed_flops(a); }
 }
@@ -298,14 +302,14 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
 static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act, double* bn_stats = nullptr) {
     ConvArgs a = conv_args(x, h->P + c.w, y, c.k, c.stride, padmode == PAD_REFLECT ? 1 : c.pad, 1, padmode);
     a.bias = c.bias ? h->P + c.b : nullptr; a.act = act; a.stats = h->testmode ? nullptr : bn_stats;
-    a.wino_u = c.uf >= 0 ? h->UF + c.uf : nullptr;
+    a.wino_u = c.uf >= 0 ? h->UF + c.uf : nullptr; a.wino_pieces = wino_resolve_pieces(h->u_pieces_f, a.Cin);
     run_igemm(h, a);
 }
 // input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
 static ConvArgs dgrad_args(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact, const View* res = nullptr) {
     ConvArgs a = conv_args(dy, h->WD + c.w, dx, c.k, 1, c.k - 1 - pad_fwd, c.stride, PAD_ZERO);
     a.accumulate = accumulate; a.acc_frame = h->tgt;
-    a.wino_u = c.ud >= 0 ? h->UD + c.ud : nullptr;
+    a.wino_u = c.ud >= 0 ? h->UD + c.ud : nullptr; a.wino_pieces = wino_resolve_pieces(h->u_pieces_d, a.Cin);
     if (dact_src) { a.dact_src = dact_src->p; a.da_bs = dact_src->bs; a.da_ps = dact_src->ps; a.dact = dact; }
     if (res) { a.res = res->p; a.res_bs = res->bs; a.res_ps = res->ps; }
     return a;
@@ -332,7 +336,8 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     a.dw = h->G + c.w; a.N = dy.N; a.KH = c.kind == 1 ? 1 : c.k; a.KW = a.KH; a.stride = c.kind == 1 ? 1 : c.stride; a.pad = c.kind == 1 ? 0 : (padmode == PAD_REFLECT ? 1 : c.pad); a.padmode = padmode;
     a.M = dy.N * dy.H * dy.W; a.db = c.bias ? h->G + c.b : nullptr; a.bf16 = h->bf16;
     char d[112] = "";
-    if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode);
+    if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d alg=%s pieces=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode, conv_wino_wgrad_eligible(a) ? "winograd" : "direct",
+                          conv_wino_wgrad_eligible(a) ? wgrad_resolve_pieces_wino(g_wgrad_pieces, a.M, a.Cout, a.Cin) : wgrad_resolve_pieces_tap(g_wgrad_pieces));
     hipStream_t st = wgrad_stream(h);
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
     if (h->prof) {
@@ -400,7 +405,7 @@ static void pose_forward(md2_handle* h, int N) {
 
 // L frames per sample (3 for training, 1 for eval_disparity); tgt = index of the frame the depth decoder sees
 // Winograd operands of the forward convolutions from the current parameters (one launch; ~16/9 of the 3x3 weights are written)
-static void refresh_wino_fwd(md2_handle* h, hipStream_t s) { launch_wino_weights_batched(h->P, h->UF, h->udesc_f, h->n_udf, h->ublk_f, s); }
+static void refresh_wino_fwd(md2_handle* h, hipStream_t s) { h->u_pieces_f = g_wino_pieces; launch_wino_weights_batched(h->P, h->UF, h->udesc_f, h->n_udf, h->ublk_f, h->u_pieces_f, s); }
 static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1, bool with_pose = true, bool with_depth = true, bool wino_on_side = false) {
     hipStream_t s = h->stream;
     if (tgt < 0) tgt = h->tgt;                  // triplets: the configured target frame
@@ -425,7 +430,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
             {   // conv2 gathers relu(bn1(z1)) straight from z1
                 ConvArgs a = conv_args(B.z1, h->P + B.c2.w, B.z2, B.c2.k, B.c2.stride, B.c2.pad, 1, PAD_ZERO);
                 a.in_scale = B.b1.stats + 2 * B.b1.c; a.in_shift = B.b1.stats + 3 * B.b1.c; a.stats = h->testmode ? nullptr : B.b2.acc;
-                a.wino_u = B.c2.uf >= 0 ? h->UF + B.c2.uf : nullptr;
+                a.wino_u = B.c2.uf >= 0 ? h->UF + B.c2.uf : nullptr; a.wino_pieces = wino_resolve_pieces(h->u_pieces_f, a.Cin);
                 run_igemm(h, a);
             }
             bn_stats(h, B.b2, B.z2);
@@ -552,7 +557,8 @@ static int backward_prepare(md2_handle* h, hipStream_t s) {
     HIPCHK(hipMemsetAsync(h->G, 0, (size_t)h->n_int * sizeof(float), s));
     HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
     launch_weight_to_dgrad_batched(h->P, h->WD, h->wdesc_dev, h->n_wdesc, s);
-    launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, s);          // Winograd operands of the input-gradient convolutions
+    h->u_pieces_d = g_wino_pieces;
+    launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions
     KCHK(); return 0;
 }
 static int model_backward(md2_handle* h) {
@@ -803,7 +809,9 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
             if (l == 0) { ended = true; continue; }
             if (ended || l < 1 || l > 5 || (i && l <= cfg->scale_levels[i - 1])) { g_create_err = "md2_create: `scale_levels` should be at most of length 5, ascending, with values in [1, 5] (0-terminated)"; return 2; }
         }
-        for (int i = 0; i < 5; ++i) if (cfg->scales[i] < 0.0) { g_create_err = "md2_create: `scales` must be non-negative (0 = the default 1 / 2^(5 - level))"; return 2; }
+        // scales: all five 0.0 (a zero-initialised config) = the reference's defaults; otherwise every listed level's value is taken as given -- an explicit 0 switches that
+        // level's smoothness term off like in the reference (src/training.jl:67) -- and a negative entry asks for that level's default
+        for (int i = 0; i < 5; ++i) if (cfg->scales[i] != cfg->scales[i]) { g_create_err = "md2_create: `scales` must not be NaN (negative = the default 1 / 2^(5 - level))"; return 2; }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "md2_create: no HIP device (libmd2hip needs an MI355X; there is no CPU fallback)"; return 3; }
@@ -824,7 +832,8 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
             }
             h->nbr = h->lv[h->ns - 1];
         }
-        for (int i = 0; i < h->ns; ++i) h->scl[i] = cfg->scales[i] != 0.0 ? cfg->scales[i] : 1.0 / (double)(1 << (5 - h->lv[i]));
+        bool scales_given = false; for (int i = 0; i < 5; ++i) scales_given |= cfg->scales[i] != 0.0;
+        for (int i = 0; i < h->ns; ++i) h->scl[i] = (scales_given && cfg->scales[i] >= 0.0) ? cfg->scales[i] : 1.0 / (double)(1 << (5 - h->lv[i]));
         for (int k = 0; k < 2; ++k) { const bool before = h->src[k] < h->tgt; h->pose_fr[2 * k] = before ? h->src[k] : h->tgt; h->pose_fr[2 * k + 1] = before ? h->tgt : h->src[k]; }
     }
     for (int i = 0; i < 64; ++i) h->ev_pool[i] = nullptr;
@@ -1112,7 +1121,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* b, float
     ConvArgs a = conv_args(xv, wi, yv, k, stride, p_eff, 1, pad_mode);
     a.bias = b ? bi : nullptr; a.act = act; a.stats = acc;          // stats: fused into the epilogue of the 32-wide tiles, a column-statistics pass otherwise
     float* uw = nullptr;                                            // 3x3 / stride 1: the Winograd operand, as a handle keeps it per layer
-    if (k == 3 && stride == 1 && coutP % 32 == 0) { uw = tmp_alloc(conv_wino_u_floats(coutP, cinP), s); if (!uw) return 3; launch_wino_weights(wi, uw, coutP, cinP, s); a.wino_u = uw; }
+    if (k == 3 && stride == 1 && coutP % 32 == 0) { uw = tmp_alloc(conv_wino_u_floats(coutP, cinP), s); if (!uw) return 3; launch_wino_weights(wi, uw, coutP, cinP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
     // a split-K workspace like a handle's, so that the op-level tests drive the same reduce pass (bias / activation / statistics) the training step uses on small maps
     const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
     float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
@@ -1162,7 +1171,7 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
         a.ws = ws; a.ws_cap = ws_cap;
         float* uw = nullptr;
-        if (k == 3 && stride == 1 && cinP % 32 == 0) { uw = tmp_alloc(conv_wino_u_floats(cinP, coutP), s); if (!uw) return 3; launch_wino_weights(wd, uw, cinP, coutP, s); a.wino_u = uw; }
+        if (k == 3 && stride == 1 && cinP % 32 == 0) { uw = tmp_alloc(conv_wino_u_floats(cinP, coutP), s); if (!uw) return 3; launch_wino_weights(wd, uw, cinP, coutP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
         launch_conv_igemm(a, s);
         (void)hipFreeAsync(ws, s); if (uw) (void)hipFreeAsync(uw, s);
         if (pad_mode == PAD_REFLECT) {
@@ -1262,7 +1271,19 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host, int64_t n) {
     HIPCHK(hipMemcpy(h->RS, host, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); return 0;
 }
 int32_t md2_set_deterministic(int32_t on) { g_deterministic = on != 0; return 0; }
-int32_t md2_set_winograd(int32_t on, int32_t min_blocks) { g_wino_on = on < 0 || on > 5 ? 1 : on; if (min_blocks >= 0) g_wino_min_blocks = min_blocks; return 0; }
+int32_t md2_set_winograd(int32_t on, int32_t min_blocks) {
+    if (on == 4 || on == 5) { g_wino_on = 1; g_wino_pieces = on == 4 ? 2 : 3; }          // legacy aliases of md2_set_winograd(1, .) + md2_set_conv_products(2 / 3, -1)
+    else g_wino_on = on < 0 || on > 3 ? 1 : on;
+    if (min_blocks >= 0) g_wino_min_blocks = min_blocks;
+    return 0;
+}
+int32_t md2_set_conv_products(int32_t fwd_dgrad, int32_t wgrad) {
+    if (fwd_dgrad < -1 || fwd_dgrad > 3 || wgrad < -1 || wgrad > 3) return 2;
+    if (fwd_dgrad >= 0) g_wino_pieces = fwd_dgrad;
+    if (wgrad >= 0) g_wgrad_pieces = wgrad;
+    return 0;
+}
+int32_t md2_get_conv_products(int32_t* fwd_dgrad, int32_t* wgrad) { if (fwd_dgrad) *fwd_dgrad = g_wino_pieces; if (wgrad) *wgrad = g_wgrad_pieces; return 0; }
 int32_t md2_set_lr(md2_handle* h, double lr) { if (!(lr > 0)) { h->err = "md2_set_lr: lr must be positive"; return 2; } h->cfg.lr = lr; return 0; }
 
 // ---- op-level hooks for the direct kernels the network uses besides the implicit GEMM (parity tests) ------------------------------------

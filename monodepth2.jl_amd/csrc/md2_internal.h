@@ -19,6 +19,25 @@ extern int g_deterministic;
 // md2_set_winograd(): the 3x3 / stride-1 layers take the fused Winograd F(2x2,3x3) kernel when the launch has at least g_wino_min_blocks workgroups (MD2_NO_WINO=1 /
 // MD2_WINO_MIN_BLOCKS override the defaults at load time); off = the direct implicit GEMM everywhere
 extern int g_wino_on, g_wino_min_blocks;
+// md2_set_conv_products(): how the fp32 products of the convolutions are formed.  0 = the fp32 MFMA (v_mfma_f32_32x32x2_f32); 3 = every fp32 operand as the exact sum of three
+// bf16 pieces (hi + mid + lo = all 24 mantissa bits), six v_mfma_f32_32x32x16_bf16 per product group with fp32 accumulation -- the same accuracy as the fp32 MFMA on the
+// bf16 matrix pipe; 1 (default) = per launch whichever of those two FULL-ACCURACY forms is faster at the launch's shape (wino_resolve_pieces / wgrad_resolve_pieces below);
+// 2 = two pieces (hi + lo, ~16-bit operand mantissas): REDUCED precision, opt-in only.  g_wino_pieces: Winograd forward / input-gradient kernels (the mode the Winograd
+// operands U were written under is recorded per handle when they are refreshed; the resolved layout travels in ConvArgs::wino_pieces); g_wgrad_pieces: weight-gradient kernels.
+extern int g_wino_pieces, g_wgrad_pieces;
+// load-time defaults of the two (MD2_WINO_PIECES / MD2_WGRAD_PIECES override): every product of the default step carries full fp32 operand accuracy
+#define MD2_DEFAULT_WINO_PIECES 1
+#define MD2_DEFAULT_WGRAD_PIECES 1
+// mode 1 resolved for one launch (in-model HIP-event timings at batch 32 / 4, tools/run_wgrad_pieces_compare.sh, round 4):
+//   forward / input gradient (GEMM-K = the launch's input channels): the exact split wins from 96 channels up (0.131 -> 0.117 ms at 128 -> 128, 0.148 -> 0.125 at 512 -> 512);
+//   short reductions (16 .. 64 channels) spend their time outside the chunk loop, where the split kernel's 16-channel chunks and piece registers only cost.
+//   Used by the weight transform (device) and by the launcher (host): both derive the layout of a layer's U from the same (mode, channels).
+__host__ __device__ inline int wino_resolve_pieces(int mode, int cin) { return mode == 1 ? (cin >= 96 ? 3 : 0) : mode; }
+//   Winograd-domain weight gradient: the split kernel's 32 x 32-channel workgroups fill the chip on small launches (batch 4: 0.050 -> 0.037 ms at 256 -> 256) but repeat the
+//   transforms of a tile for twice as many channel blocks as the fp32 kernel's 64 x 32 ones (batch 32: 0.200 -> 0.295 ms at 512 -> 512): by work, M x Cout x Cin.
+inline int wgrad_resolve_pieces_wino(int mode, long M, int Cout, int Cin) { return mode == 1 ? ((double)M * Cout * Cin < 3e8 ? 3 : 0) : mode; }
+//   per-tap weight gradient (1x1 and stride-2 layers): the exact split is ahead at every size measured (0.146 -> 0.101 ms, 0.046 -> 0.033 ms)
+inline int wgrad_resolve_pieces_tap(int mode) { return mode == 1 ? 3 : mode; }
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
@@ -96,6 +115,7 @@ struct ConvArgs {
     int acc_lat;
     // Winograd F(2x2,3x3) operand of this layer (conv_winograd.hip): U = G g G^T of `w` in MFMA fragment order, refreshed once per step; null = direct convolution only
     const float* wino_u;
+    int wino_pieces;              // layout wino_u was written in: 0 = fp32 fragments, 2 / 3 = bf16 pieces per operand (split kernels); set by whoever refreshed U
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only
 #endif
@@ -107,10 +127,10 @@ double conv_igemm_executed_flops(const ConvArgs& a);      // what the matrix cor
 bool conv_wino_eligible(const ConvArgs& a);
 void launch_conv_wino(const ConvArgs& a, hipStream_t s);
 size_t conv_wino_u_floats(int Cout, int Cin);
-void launch_wino_weights(const float* w /*[Cout][9][Cin]*/, float* U, int Cout, int Cin, hipStream_t s);
+void launch_wino_weights(const float* w /*[Cout][9][Cin]*/, float* U, int Cout, int Cin, int pieces, hipStream_t s);
 long wino_weight_blocks(int Cout, int Cin);
 // desc (device): {w offset, U offset, Cout, Cin, blocks} per layer
-void launch_wino_weights_batched(const float* wbase, float* Ubase, const long* desc_dev, int nlayers, int total_blocks, hipStream_t s);
+void launch_wino_weights_batched(const float* wbase, float* Ubase, const long* desc_dev, int nlayers, int total_blocks, int pieces, hipStream_t s);
 
 // dw[co][(kh*KW+kw)*Cin+ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, ih, iw, ci]   (atomic accumulation, split over pixels)
 struct WgradArgs {

@@ -77,7 +77,14 @@ set_lr!(h, eta) = check(h, md2_set_lr(h.ptr, Float64(eta)), "set_lr")
 testmode!(h, on::Bool=true) = check(h, md2_set_testmode(h.ptr, Int32(on)), "set_testmode")       # Flux.testmode! / trainmode!, src/Monodepth.jl:126,209,237
 trainmode!(h) = testmode!(h, false)
 set_deterministic!(on::Bool) = md2_set_deterministic(Int32(on))
-set_winograd!(on::Bool, min_blocks::Integer=-1) = md2_set_winograd(Int32(on), Int32(min_blocks))     # algorithm choice of the 3x3 / stride-1 convolutions (cuDNN's job behind Flux `Conv`)
+set_winograd!(on::Union{Bool,Integer}, min_blocks::Integer=-1) = md2_set_winograd(Int32(on), Int32(min_blocks))     # algorithm choice of the 3x3 / stride-1 convolutions (cuDNN's job behind Flux `Conv`): 0 direct, 1 automatic, 2 / 3 pin a Winograd kernel
+# how the convolutions form their fp32 products (cuDNN's math mode): 0 fp32 MFMA, 3 exact three-bf16-piece split, 1 (default) the faster of the two per launch, 2 reduced precision (opt-in); -1 keeps
+set_conv_products!(fwd_dgrad::Integer=-1, wgrad::Integer=-1) = md2_set_conv_products(Int32(fwd_dgrad), Int32(wgrad))
+function get_conv_products()
+    f = Ref(Int32(0)); w = Ref(Int32(0))
+    GC.@preserve f w md2_get_conv_products(Base.unsafe_convert(Ptr{Int32}, f), Base.unsafe_convert(Ptr{Int32}, w))
+    return (Int(f[]), Int(w[]))
+end
 set_two_streams!(h, on::Bool) = check(h, md2_set_two_streams(h.ptr, Int32(on)), "set_two_streams")
 
 # ---- Flux.params(model) <-> the library's flat vector ----------------------------------------------------------------------------------------

@@ -323,6 +323,10 @@ class Model:
             if len(cache.scales) != len(self.depth_decoder.scale_levels):
                 raise ValueError("TrainCache.scales needs one entry per DepthDecoder scale level (zip(disparities, cache.scales), src/training.jl:42)")
             extra.update(scales=tuple(float(v) for v in cache.scales))
+            # md2_config.scales: an all-zero array means "not given" (zero-initialised struct = the defaults), a 0 among other entries is taken as given.  A caller
+            # whose scales are ALL 0 wants every smoothness weight disparity_smoothness * scale_i (src/training.jl:67) to be 0: say that through the other factor.
+            if not any(extra["scales"]):
+                extra.update(scales=None, disparity_smoothness=0.0)
         if frames is not None:
             sids, tid = [int(v) for v in frames[0]], int(frames[1])
             if len(sids) != 2 or sorted(sids + [tid]) != [1, 2, 3]:
@@ -534,6 +538,13 @@ def comm_unique_id():
     return bytes(buf)
 
 
+def _need_handle(model, what):
+    """The handle is created by the first call that sees a batch (`_ensure`); entry points that only take the handle must not pass NULL across the C ABI."""
+    if model._h is None:
+        raise RuntimeError("%s: the model has no device handle yet (run a forward / training step first)" % what)
+    return model._h
+
+
 def set_deterministic(on=True):
     """Bit-reproducible (ordered reductions, no split-K) mode of the whole library: for bisecting parity failures, much slower."""
     _check(_lib.lib().md2_set_deterministic(int(bool(on))), None, "set_deterministic")
@@ -541,11 +552,22 @@ def set_deterministic(on=True):
 
 def set_winograd(on=True, min_blocks=-1):
     """Algorithm choice for the 3x3 / stride-1 convolutions: fused Winograd F(2x2,3x3) for launches of at least `min_blocks` workgroups (default policy: 96), or the direct
-    implicit GEMM everywhere (on=False).  What cuDNN's heuristics decide for the reference's Flux `Conv` layers.  on = 2 / 3 pin one of the two fp32 kernels (tests);
-    on = 4 is the opt-in "split" mode: the Winograd products run as three bf16 MFMAs on hi + lo pieces of the fp32 operands (fp32 storage and accumulation, ~17-bit operand
-    mantissas; forward and loss stay inside the 1e-4 parity bound, gradients get ~5x noisier) -- ~1.4x faster on those kernels; on = 5 takes three pieces (six MFMAs): exact,
-    1.15-1.25x faster per launch, no faster in the step."""
+    implicit GEMM everywhere (on=False).  What cuDNN's heuristics decide for the reference's Flux `Conv` layers.  on = 2 / 3 pin one of the two Winograd kernels (tests).
+    How the products are formed is `set_conv_products`' business (on = 4 / 5 remain as aliases of set_winograd(1) + set_conv_products(2 / 3))."""
     _check(_lib.lib().md2_set_winograd(int(on), int(min_blocks)), None, "set_winograd")
+
+
+def set_conv_products(fwd_dgrad=-1, wgrad=-1):
+    """How the convolutions form their fp32 products (md2_set_conv_products): 0 = the fp32 MFMA, 3 = the exact three-bf16-piece split of every operand (fp32-MFMA accuracy on
+    the bf16 matrix pipe), 1 = (default) whichever of those two is faster per launch, 2 = two pieces (~16-bit operand mantissas: REDUCED precision, opt-in).  `fwd_dgrad`: Winograd forward / input-gradient kernels; `wgrad`: the weight
+    gradients; -1 keeps.  The defaults carry full fp32 operand accuracy, like the reference's precision = f32 (src/Monodepth.jl:72)."""
+    _check(_lib.lib().md2_set_conv_products(int(fwd_dgrad), int(wgrad)), None, "set_conv_products")
+
+
+def get_conv_products():
+    f = C.c_int32(0); w = C.c_int32(0)
+    _check(_lib.lib().md2_get_conv_products(C.byref(f), C.byref(w)), None, "get_conv_products")
+    return f.value, w.value
 
 
 class _DevBuf:
@@ -678,22 +700,22 @@ def simple_depth(x, K=None, invK=None, **kw):
 
 def set_two_streams(model: Model, on=True):
     """Overlap the weight-gradient kernels with the rest of the backward pass on a second stream (default on)."""
-    _check(_lib.lib().md2_set_two_streams(model._h, int(on)), model._h)
+    _check(_lib.lib().md2_set_two_streams(_need_handle(model, "set_two_streams"), int(on)), model._h)
 
 
 def profile(model: Model, on=True):
-    _check(_lib.lib().md2_profile_enable(model._h, int(on)), model._h)
+    _check(_lib.lib().md2_profile_enable(_need_handle(model, "profile"), int(on)), model._h)
     if on:
         _check(_lib.lib().md2_profile_reset(model._h), model._h)
 
 
 def profile_dump(model: Model, path):
-    _check(_lib.lib().md2_profile_dump(model._h, str(path).encode()), model._h)
+    _check(_lib.lib().md2_profile_dump(_need_handle(model, "profile_dump"), str(path).encode()), model._h)
 
 
 def profile_get(model: Model, cls):
     ms = C.c_double(); n = C.c_int64(); fl = C.c_double(); by = C.c_double()
-    _check(_lib.lib().md2_profile_get(model._h, cls, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), model._h)
+    _check(_lib.lib().md2_profile_get(_need_handle(model, "profile_get"), cls, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), model._h)
     ex = C.c_double()
     _check(_lib.lib().md2_profile_get_executed(model._h, cls, C.byref(ex)), model._h)
     return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value, flops_executed=ex.value)

@@ -97,13 +97,14 @@ struct o_cfg {
     double min_depth, max_depth, smoothness;
     float K[9], invK[9];
     int target_id, source_ids[2];          // TrainCache.target_id / source_ids (1-based, src/Monodepth.jl:44-55); 0 = the defaults 2 / {1, 3}
-    int scale_levels[5]; double scales[5]; // DepthDecoder scale_levels (0-terminated; all 0 = 2:5) and TrainCache.scales (0 = 1 / 2^(5 - level))
+    int scale_levels[5]; double scales[5]; // DepthDecoder scale_levels (0-terminated; all 0 = 2:5) and TrainCache.scales (all 0 = 1 / 2^(5 - level))
 };
 static LossCfg to_cfg(const o_cfg* c) {
     LossCfg l; l.N = c->N; l.C = c->C; l.H = c->H; l.W = c->W; l.automasking = c->automasking; l.simple = c->simple; if (c->simple) l.nscales = 1;
     if (c->target_id) { l.target_id = c->target_id; l.source_ids[0] = c->source_ids[0]; l.source_ids[1] = c->source_ids[1]; }
     if (c->scale_levels[0] && !c->simple) { l.nscales = 0; for (int i = 0; i < 5 && c->scale_levels[i]; ++i) { l.levels[i] = c->scale_levels[i]; l.nscales = i + 1; } }
-    if (!c->simple) for (int i = 0; i < l.nscales; ++i) l.scales[i] = c->scales[i] != 0.0 ? c->scales[i] : 1.0 / (double)(1 << (5 - l.levels[i]));
+    bool scales_given = false; for (int i = 0; i < 5; ++i) scales_given |= c->scales[i] != 0.0;          // all zero = not given; otherwise as given (an explicit 0 is a weight of 0, negative = default)
+    if (!c->simple) for (int i = 0; i < l.nscales; ++i) l.scales[i] = (scales_given && c->scales[i] >= 0.0) ? c->scales[i] : 1.0 / (double)(1 << (5 - l.levels[i]));
     l.min_depth = c->min_depth; l.max_depth = c->max_depth; l.smoothness = c->smoothness;
     std::memcpy(l.K, c->K, sizeof(l.K)); std::memcpy(l.invK, c->invK, sizeof(l.invK)); return l;
 }

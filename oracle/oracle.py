@@ -55,6 +55,8 @@ def make_cfg(N, Cc, H, W, K, invK, automasking=False, min_depth=0.1, max_depth=1
     c = OCfg()
     for i, l in enumerate(scale_levels or ()):
         c.scale_levels[i] = int(l)
+    if scales is not None and not any(scales):          # all zeros: every smoothness weight smoothness * scale_i (src/training.jl:67) is 0 -- said through the other factor (an all-zero array means "not given")
+        scales, smoothness = None, 0.0
     for i, v in enumerate(scales or ()):
         c.scales[i] = float(v)
     c.target_id = int(target_id); c.source_ids[0], c.source_ids[1] = int(source_ids[0]), int(source_ids[1])

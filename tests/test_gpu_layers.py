@@ -187,11 +187,20 @@ WINO_CASES = [
 ]
 
 
-@pytest.fixture(params=[2, 3, 4, 5], ids=["tile32x64", "tile64x32", "split_bf16", "split3_bf16"])
+# (algorithm pin, pieces per operand of the forward / input-gradient products, pieces of the weight-gradient products): md2_set_winograd / md2_set_conv_products
+WINO_ROUTES = {"tile32x64": (2, 0, 0), "tile64x32": (3, 0, 3), "split_bf16": (3, 2, 2), "split3_bf16": (3, 3, 3)}
+
+
+def _set_route(route):
+    md().set_winograd(route[0], 1); md().set_conv_products(route[1], route[2])
+
+
+@pytest.fixture(params=list(WINO_ROUTES), ids=list(WINO_ROUTES))
 def forced_winograd(request):
-    md().set_winograd(request.param, 1)          # every eligible launch takes the Winograd kernel, however small its grid: the 256-thread / 32-tile one, or the
-    yield request.param                           # 64-tile x 32-channel one with row-segment patches (the one the training step uses), wherever it applies
-    md().set_winograd(True, 96)
+    dflt = md().get_conv_products()
+    _set_route(WINO_ROUTES[request.param])       # every eligible launch takes the Winograd kernel, however small its grid: the 256-thread / 32-tile one, or the
+    yield WINO_ROUTES[request.param]             # 64-tile x 32-channel one with row-segment patches (the one the training step uses), wherever it applies; products by
+    md().set_winograd(True, 96); md().set_conv_products(*dflt)          # fp32 MFMA, the exact three-piece split, or the reduced two-piece one
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
@@ -209,9 +218,9 @@ def test_winograd_conv_fwd_and_input_gradient_vs_oracle(case, forced_winograd):
     assert y.shape == ref.shape and rel(y, ref) < 1e-4
     md().set_winograd(False)
     y_direct = host(md().conv2d(dev(x), dev(w), dev(b), 1, p, mode, act))
-    md().set_winograd(forced_winograd, 1)
+    _set_route(forced_winograd)
     # the two algorithms really are different code paths (the split-bf16 kernel declines maps with one tile per row and channel counts that are not multiples of 16)
-    split_declines = forced_winograd >= 4 and (Cin % 16 != 0 or (W + 2 * (p if mode != "reflect" else 1) - 2 + 1) // 2 < 2)
+    split_declines = forced_winograd[1] != 0 and (Cin % 16 != 0 or (W + 2 * (p if mode != "reflect" else 1) - 2 + 1) // 2 < 2)
     assert rel(y_direct, ref) < 1e-4 and (split_declines or not np.array_equal(y, y_direct))
     dy = rng.standard_normal(zo.shape).astype(np.float32)
     dxo, dwo, dbo = oracle.conv2d_bwd(xin, w, dy, 1, 0 if mode == "reflect" else p)

@@ -128,6 +128,30 @@ def test_loss_half_vs_oracle_and_golden(name):
     assert rel(host(drv), g["drvec"]) < 5e-3 and rel(host(dtv), g["dtvec"]) < 5e-3
 
 
+def test_an_explicit_zero_scale_switches_that_levels_smoothness_off():
+    """TrainCache.scales entries are the caller's numbers (src/training.jl:67): a 0 among them is a weight of 0, not "use the default" (round-3 advisor finding); all zeros = no
+    smoothness term at all."""
+    N, C, H, W = 2, 1, 64, 96
+    x = syn.synthetic_triplets(N, C, H, W, seed=31); xd = dev(x)
+    rng = np.random.default_rng(32)
+    disps = [(0.2 + 0.6 * rng.random((N, 1, H >> (3 - i), W >> (3 - i)))).astype(np.float32) for i in range(4)]
+    rv = (0.01 * rng.standard_normal((2, N, 3))).astype(np.float32); tv = (0.05 * rng.standard_normal((2, N, 3))).astype(np.float32)
+    K, iK = syn.depth10k_intrinsics(W, H)
+    losses = {}
+    for scales in ([0.125, 0.25, 0.5, 1.0], [0.125, 0.0, 0.5, 1.0], [0.0, 0.0, 0.0, 0.0]):
+        model, params, cache, _, _, _ = make(N, C, H, W)
+        params.disparity_smoothness = 0.5          # (large enough that a wrong weight moves the loss far beyond the bound)
+        cache.scales = scales
+        model._ensure(xd, params, cache)
+        loss = float(md().loss_fwd_bwd(model, xd, [dev(d) for d in disps], dev(rv), dev(tv))[0])
+        cfg = oracle.make_cfg(N, C, H, W, K, iK, scales=scales, smoothness=0.5)
+        lo = oracle.loss_fwd_bwd(x, cfg, disps, rv, tv)["loss"]
+        assert abs(loss - lo) / lo < 1e-5, (scales, loss, lo)
+        losses[tuple(scales)] = loss
+        model.close()
+    assert losses[(0.125, 0.25, 0.5, 1.0)] > losses[(0.125, 0.0, 0.5, 1.0)] > losses[(0.0, 0.0, 0.0, 0.0)]
+
+
 def test_loss_half_c3_64x64_vs_oracle_with_automask_and_clamping():
     N, C, H, W = 2, 3, 64, 64
     rng = np.random.default_rng(5)
@@ -740,33 +764,80 @@ def _hip_and_oracle_grads(N, C, H, W, sd, depth=18, automask=False):
     return loss, gh, theta, x, (host(al) if automask else None), K, iK
 
 
-# seeds from tools/run_seed_scan.sh (round 3: Winograd kernels, deterministic AND default mode within 2.5e-3 of the oracle in every array)
+# seeds from tools/run_seed_scan.sh (round 4: every route below -- algorithm automatic / Winograd forced, ordered / default reductions, fp32-MFMA / exact-split products --
+# within 2.5e-3 of the oracle in every array)
 TIGHT_CASES = [(1, 1, 64, 96, 101, False), (2, 1, 64, 96, 107, False), (2, 3, 64, 96, 110, True), (3, 1, 96, 160, 108, False), (5, 3, 64, 64, 105, False),
                (1, 1, 64, 256, 108, False), (2, 3, 64, 256, 106, False)]
+# (name, md2_set_winograd arguments, md2_set_conv_products arguments).  "timed": the configuration bench.py's `value` is measured in.  "winograd forced": the shapes a CPU
+# oracle can afford sit below the workgroup-count threshold of the automatic choice, so the Winograd forward / input-gradient / weight-gradient kernels -- 7.8 of the
+# step's 9.9 ms of convolution time at batch 32 -- are pinned on every layer that qualifies, with the products of the timed configuration and with the other full-accuracy choice.
+TIGHT_ROUTES = [("timed", (1, 96), None), ("winograd forced", (3, 1), None), ("winograd forced, fp32 MFMA products", (3, 1), (0, 0)), ("winograd forced, exact-split products", (3, 1), (3, 3))]
 
 
+_TIGHT_ORACLE = {}
+
+
+def _routes_of(model_factory):
+    """{alg: launches} of one step's convolution launches (md2_profile_dump descriptions)."""
+    import csv, tempfile
+    model, run = model_factory()
+    run(); md().profile(model, True); run(); path = os.path.join(tempfile.mkdtemp(), "p.csv"); md().profile_dump(model, path); md().profile(model, False)
+    out = {}
+    for row in csv.DictReader(open(path)):
+        d = row["desc"]
+        if "alg=" in d:
+            key = ("wgrad " if d.startswith("wgrad") else "conv ") + d.split("alg=")[1].split()[0]
+            out[key] = out.get(key, 0) + 1
+    model.close()
+    return out
+
+
+@pytest.mark.parametrize("route", TIGHT_ROUTES, ids=[r[0].replace(" ", "_").replace(",", "") for r in TIGHT_ROUTES])
 @pytest.mark.parametrize("case", TIGHT_CASES)
-def test_gradient_parity_tight_on_kink_free_seeds(case):
+def test_gradient_parity_tight_on_kink_free_seeds(case, route):
     """Inputs on which no ReLU / max-pool / arg-min / clamp decision differs between the HIP and the oracle arithmetic (found with tools/seed_scan.py): there EVERY
-    parameter array must agree with the oracle to 4e-3 relative, cosine >= 0.9999 (measured 2e-5 .. 2e-3) -- C = 1 and 3, automask on / off, batch 1 .. 5, a
+    parameter array must agree with the oracle to 4e-3 relative, cosine >= 0.9999 (measured 2e-5 .. 2.5e-3) -- C = 1 and 3, automask on / off, batch 1 .. 5, a
     ragged 160x96 frame, and two 256-wide cases in which all four encoder stages take the BatchNorm-folded convolutions (layer4 is 8 wide there).
-    The statement is made ONCE, in deterministic mode (ordered reductions: the same bits every run), with no retry; the default mode (fp32 atomics, split-K, 8-slot
-    statistics) is then held against the deterministic gradient, array by array."""
+    The statement is made on the kernels that are timed: in the default (atomics, split-K) mode AND in deterministic mode -- which since round 4 runs the same
+    algorithms with ordered reductions (one workgroup per weight tile) instead of swapping the Winograd / split weight gradients out -- on every route of TIGHT_ROUTES.
+    No retry in deterministic mode (the same bits every run); the default mode may repeat the step once (a reordered fp32 sum can flip a near-tie)."""
     N, C, H, W, sd, automask = case
-    md().set_deterministic(True)
+    _, wino, products = route
+    dflt = md().get_conv_products()
+    md().set_winograd(*wino)
+    if products is not None:
+        md().set_conv_products(*products)
     try:
-        loss, gh, theta, x, al, K, iK = _hip_and_oracle_grads(N, C, H, W, sd, automask=automask)
+        md().set_deterministic(True)
+        try:
+            loss, gh, theta, x, al, K, iK = _hip_and_oracle_grads(N, C, H, W, sd, automask=automask)
+        finally:
+            md().set_deterministic(False)
+        if case not in _TIGHT_ORACLE:          # (one oracle evaluation per case: the routes share inputs and parameters)
+            net = oracle.OracleNet(C); net.set_params(theta)
+            _TIGHT_ORACLE[case] = (net.train_loss(x, oracle.make_cfg(N, C, H, W, K, iK, automasking=automask), al, True), net.get_grads())
+        lo, go = _TIGHT_ORACLE[case]
+        assert abs(loss - lo) / lo < 1e-4
+        assert_grads_match(gh, go, C, cos_min=0.9999, rel_max=4e-3, tag="tight deterministic %s %s" % (case, route[0]))
+        for attempt in (0, 1):          # default mode, same inputs, the SAME bound against the oracle
+            loss_d, gd, _, _, _, _, _ = _hip_and_oracle_grads(N, C, H, W, sd, automask=automask)
+            assert abs(loss_d - lo) / lo < 1e-4
+            try:
+                assert_grads_match(gd, go, C, cos_min=0.9999, rel_max=4e-3, tag="tight default %s %s" % (case, route[0]))
+                break
+            except AssertionError:
+                if attempt:
+                    raise
+        if wino[0] == 3 and (H, W) == (96, 160):          # the forced routes really run the Winograd kernels (and the split ones when asked to)
+            def factory():
+                model, params, cache, theta2, _, _ = make(N, C, H, W, automask=automask, pseed=sd)
+                xd = dev(x)
+                return model, (lambda: md().train_step(model, xd, None if al is None else dev(al), cache, params, do_update=False))
+            r = _routes_of(factory)
+            want_pieces = md().get_conv_products()
+            assert r.get("wgrad winograd", 0) >= 10 and (r.get("conv winograd_split", 0) if want_pieces[0] else r.get("conv winograd", 0)) >= 20, r
     finally:
-        md().set_deterministic(False)
-    net = oracle.OracleNet(C); net.set_params(theta)
-    lo = net.train_loss(x, oracle.make_cfg(N, C, H, W, K, iK, automasking=automask), al, True); go = net.get_grads()
-    assert abs(loss - lo) / lo < 1e-4
-    assert_grads_match(gh, go, C, cos_min=0.9999, rel_max=4e-3, tag="tight deterministic %s" % (case,))
-    loss_d, gd, _, _, _, _, _ = _hip_and_oracle_grads(N, C, H, W, sd, automask=automask)          # default mode, same inputs
-    assert abs(loss_d - loss) / loss < 1e-5
-    # (a reordered fp32 sum may flip a near-tie in the default mode -- ~1e-2 in the arrays upstream of it, profiles/r02_grad_diag.md -- so this leg carries the general
-    #  bound: what it must catch is a default-mode kernel that computes something else than its ordered twin, which shows as O(1))
-    assert_grads_match(gd, gh, C, tag="default vs deterministic %s" % (case,))
+        md().set_winograd(True, 96); md().set_conv_products(*dflt)
 
 
 def test_resnet50_gradients_are_as_close_to_fp64_as_the_fp32_oracle():
@@ -985,30 +1056,36 @@ def test_depth_decoder_scale_levels_vs_oracle(levels, scales, automask):
     assert rel(model.params() - theta, net.get_params() - theta) < 5e-3
 
 
-def test_split_bf16_winograd_mode_stays_inside_the_parity_bound():
-    """md.set_winograd(4): the 3x3 / stride-1 forward and input-gradient convolutions multiply hi + lo bf16 pieces of their fp32 operands on the bf16 matrix pipe (three MFMAs per
-    product group, fp32 accumulation).  Opt-in; the statement that makes it usable: at BASELINE config #2 (416x128, B=4) disparities, poses and loss stay within 1e-4 of the
-    oracle and every gradient array within the general bound -- and the default mode is an order of magnitude closer, which is why it stays the default."""
+def test_product_modes_against_the_parity_bound():
+    """md2_set_conv_products at BASELINE config #2 (416x128, B=4).  The full-accuracy modes -- fp32 MFMA (0) and the exact three-piece split (3), in the forward / input-gradient
+    and in the weight-gradient kernels -- must be indistinguishable: disparities within 2e-5 of the oracle, loss 1e-4, every gradient array inside the general bound, and
+    within 1e-3 of each other in every weight-gradient array that does not sit behind a kink.  The two-piece mode (2) is reduced precision: it stays inside the 1e-4 forward
+    bound but with an order of magnitude less margin, which is why it is opt-in and never part of the measured default."""
     N, C, H, W = 4, 1, 128, 416
     m = md()
+    dflt = m.get_conv_products()
     model, params, cache, theta, K, iK = make(N, C, H, W, pseed=7)
     x = syn.synthetic_triplets(N, C, H, W, seed=8); xd = dev(x)
     cfg = oracle.make_cfg(N, C, H, W, K, iK)
     net = oracle.OracleNet(C); net.set_params(theta)
     dso, rvo, tvo = net.model_forward(x, cfg); lo = net.train_loss(x, cfg, None, True); go = net.get_grads()
-    worst = {}
+    worst = {}; grads = {}
     try:
-        for mode in (4, 1):
-            m.set_winograd(mode)
+        for mode in ((0, 0), (3, 3), (0, 3), (2, 2)):
+            m.set_conv_products(*mode)
             ds, poses = model(xd, [1, 3], 2)
             worst[mode] = max(rel(host(d), o) for d, o in zip(ds, dso))
             assert worst[mode] < 1e-4 and rel(host(poses[0].rvec), rvo[0]) < 1e-4 and rel(host(poses[1].tvec), tvo[1]) < 1e-4
             loss = m.train_step(model, xd, None, cache, params, do_update=False)
             assert abs(float(loss) - lo) / lo < 1e-4
-            assert_grads_match(model.grads(), go, C, tag="winograd mode %d" % mode)
+            grads[mode] = model.grads()
+            assert_grads_match(grads[mode], go, C, tag="conv products %s" % (mode,))
     finally:
-        m.set_winograd(True)
-    assert worst[1] < 2e-5 and worst[1] < worst[4]
+        m.set_conv_products(*dflt)
+    assert worst[(0, 0)] < 2e-5 and worst[(3, 3)] < 2e-5 and worst[(0, 0)] < worst[(2, 2)]
+    # same forward arithmetic, weight-gradient products fp32 MFMA vs exact split: the gradient arrays agree to accumulation-order noise
+    ta = per_array(grads[(0, 3)], grads[(0, 0)], C)
+    assert max(t[2] for t in ta if t[3] > 1e-7 * max(u[3] for u in ta)) < 1e-3, sorted(ta, key=lambda t: -t[2])[:4]
 
 
 def test_scale_levels_and_frame_roles_with_the_resnet50_encoder():

@@ -95,8 +95,9 @@ def test_frame_roles_and_scale_levels_are_validated_before_the_device():
         rc, msg = create(**kw); assert rc == 2 and b"source_ids" in msg, kw
     for lv in ((0, 2), (3, 2), (2, 2), (6,), (1, 2, 3, 4, 7)):
         rc, msg = create(levels=lv); assert rc == 2 and b"scale_levels" in msg, lv
-    rc, msg = create(levels=(2, 3), scales=(0.5, -1.0)); assert rc == 2 and b"scales" in msg
-    for kw in (dict(), dict(tid=1, sids=(2, 3)), dict(tid=3, sids=(2, 1)), dict(levels=(1, 2, 3, 4, 5)), dict(levels=(5,)), dict(levels=(1, 3, 4), scales=(0.3, 0.7, 1.1))):
+    rc, msg = create(levels=(2, 3), scales=(0.5, float("nan"))); assert rc == 2 and b"scales" in msg
+    for kw in (dict(), dict(tid=1, sids=(2, 3)), dict(tid=3, sids=(2, 1)), dict(levels=(1, 2, 3, 4, 5)), dict(levels=(5,)), dict(levels=(1, 3, 4), scales=(0.3, 0.7, 1.1)),
+               dict(levels=(2, 3), scales=(0.5, -1.0)), dict(levels=(2, 3), scales=(0.0, 0.7))):          # negative = that level's default; an explicit 0 is taken as given
         rc, msg = create(**kw); assert rc in (0, 3), (kw, msg)                 # valid arguments: only the missing device (3) may stop a CPU-only box
         if rc == 0:
             L.md2_destroy(h)

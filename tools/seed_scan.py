@@ -20,20 +20,30 @@ model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDe
 cfg = oracle.make_cfg(N, C, H, W, K, iK, automasking=bool(automask))
 net = oracle.OracleNet(C, depth=depth)
 lay = syn.param_layout(C, depth)
+# every arithmetic route the tight test makes its statement on: algorithm choice automatic / Winograd forced wherever the shape qualifies, ordered / default reductions,
+# fp32-MFMA / exact three-piece products in the forward + input-gradient and in the weight-gradient kernels
+CONFIGS = [(forced, det, fp, wp) for forced in (0, 1) for det in (0, 1) for fp in (0, 3) for wp in (0, 3)]
 for sd in range(first, first + count):
     theta = syn.init_params(C, seed=sd, randomize_affine=True, depth=depth); x = syn.synthetic_triplets(N, C, H, W, seed=sd + 1)
     model.load_params(theta); xd = torch.from_numpy(x).cuda()
     al = md.automasking_loss(md.SSIM(), xd, xd[:, 1].contiguous(), [1, 3]) if automask else None
-    md.train_step(model, xd, al, cache, params, do_update=False); gh = model.grads().astype(np.float64)
     net.set_params(theta); net.train_loss(x, cfg, al.cpu().numpy() if automask else None, True); go = net.get_grads().astype(np.float64)
-    off = 0; worst = 0.0; wname = ""; top = 0.0; rows = []
-    for name, _, shape in lay:
-        n = int(np.prod(shape)); a = gh[off:off + n]; b = go[off:off + n]; off += n; rows.append((name, a, b)); top = max(top, np.linalg.norm(b))
-    for name, a, b in rows:
-        nb = np.linalg.norm(b)
-        if nb < 1e-7 * top:
-            continue
-        r = np.linalg.norm(a - b) / nb
-        if r > worst:
-            worst, wname = r, name
-    print("case %s pseed %d xseed %d: worst per-array rel %.2e (%s)" % (sys.argv[1:7], sd, sd + 1, worst, wname), flush=True)
+    res = []
+    for forced, det, fp, wp in CONFIGS:
+        md.set_winograd(3 if forced else 1, 1 if forced else 96); md.set_deterministic(bool(det)); md.set_conv_products(fp, wp)
+        md.train_step(model, xd, al, cache, params, do_update=False); gh = model.grads().astype(np.float64)
+        off = 0; worst = 0.0; wname = ""; top = 0.0; rows = []
+        for name, _, shape in lay:
+            n = int(np.prod(shape)); a = gh[off:off + n]; b = go[off:off + n]; off += n; rows.append((name, a, b)); top = max(top, np.linalg.norm(b))
+        for name, a, b in rows:
+            nb = np.linalg.norm(b)
+            if nb < 1e-7 * top:
+                continue
+            r = np.linalg.norm(a - b) / nb
+            if r > worst:
+                worst, wname = r, name
+        res.append((worst, wname))
+    md.set_winograd(1, 96); md.set_deterministic(False)
+    w = max(r[0] for r in res)
+    print("case %s pseed %d: worst over %d routes %.2e | " % (" ".join(sys.argv[1:7]), sd, len(CONFIGS), w) +
+          " ".join("%s%s%d%d=%.1e" % ("W" if c[0] else "a", "D" if c[1] else "n", c[2], c[3], r[0]) for c, r in zip(CONFIGS, res)), flush=True)
