@@ -112,20 +112,43 @@ def cpu_baseline(C, H, W):
             "sample": "B=4 triplets (the reference's batch size), %dx%d, C=%d, fwd+loss+bwd+ADAM, 3 warm-up + %d timed steps (median %.2f s/step) on %d OpenMP threads; CPU restatement of the reference algorithm, op by op -- not Flux itself, and not the optimisation target" % (W, H, C, len(times), med, int(threads))}
 
 
-def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent never touches a GPU), relay rank 0's JSON line."""
+def spawn_ranks(n, timeout_s=float(os.environ.get("MD2_BENCH_TIMEOUT", "900"))):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent never touches a GPU), relay rank 0's JSON line.
+    The children are polled: the first one that exits non-zero (or the overall timeout) ends the others -- a rank that died at init would otherwise leave its siblings
+    waiting in a collective, and this parent waiting for them."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL)))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode()); sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=(out0 if r == 0 else subprocess.DEVNULL)))
+    t_end = time.time() + timeout_s
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > t_end:
+            rc = abs(bad[0]) if bad else 124
+            for p in procs:                          # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill(); p.wait()
+            sys.stderr.write("bench.py: %s -- the remaining ranks were ended\n" % ("rank exit codes %s" % codes if bad else "no result after %.0f s" % timeout_s))
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    out0.seek(0); sys.stdout.write(out0.read().decode()); sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -184,30 +207,48 @@ def main():
     if world > 1 and backend == "nccl":
         # the library's communicator is VERIFIED before it is timed: every rank steps once on the same batch, first alone (local gradient), then with the communicator
         # attached -- the bucketed, overlapped all-reduce inside md2_backward must return world x the local gradient on every rank (parallel.verify_rccl)
-        try:
+        # Every rank takes the SAME sequence of collectives whatever happens locally: a rank that fails says so in an agreement all-reduce (MIN of a flag over
+        # torch.distributed) BEFORE the next library collective would be entered, and then all ranks fall back together.
+        def agree(ok):
+            flag = torch.tensor([1.0 if ok else 0.0], device="cuda"); torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            return float(flag.item()) > 0.5
+        why = ""; dpr = None; g_local = None; xc = None
+        try:                                        # (1) local step, no collective
             xc = torch.from_numpy(syn.synthetic_triplets(min(B, 8), C, H, W, seed=7)).cuda().repeat((B + 7) // 8, 1, 1, 1, 1)[:B].contiguous()
             md.train_step(model, xc, None, cache, params, do_update=False)
             g_local = model.grad_buffer().float().clone()
-            dpr = par.DataParallel(model, comm="rccl")
-            dpr._setup(x, params, cache)
-            ok, err = par.verify_rccl(dpr, xc, cache, params, g_local)
-            rccl_ranks = model.comm_world()[1]
-            if not ok or rccl_ranks != world:
-                raise RuntimeError("reduced gradient differs from world x local gradient (rel %.2e) or communicator has %d ranks" % (err, rccl_ranks))
-            dp = dpr
-            comm_note = "libmd2hip RCCL communicator (md2_comm_init), 4 buckets overlapped with the pullback; verified against the local gradient before timing (rel %.1e)" % err
+            ok = True
         except Exception as e:                      # noqa: BLE001
-            comm_note = "torch.distributed RCCL all-reduce of the library's gradient buffer (library communicator not used: %s)" % str(e)[:200]
+            ok = False; why = str(e)[:200]
+        if agree(ok):
+            try:                                    # (2) communicator: id broadcast, ncclCommInitRank, state broadcast
+                dpr = par.DataParallel(model, comm="rccl")
+                dpr._setup(x, params, cache)
+                ok = model.comm_world()[1] == world
+                why = why or ("" if ok else "communicator has %d ranks" % model.comm_world()[1])
+            except Exception as e:                  # noqa: BLE001
+                ok = False; why = str(e)[:200]
+            if agree(ok):
+                try:                                # (3) one step through the bucketed, overlapped all-reduce + the MAX all-reduce of verify_rccl
+                    ok, err = par.verify_rccl(dpr, xc, cache, params, g_local)
+                    why = why or ("" if ok else "reduced gradient differs from world x local gradient (rel %.2e)" % err)
+                except Exception as e:              # noqa: BLE001
+                    ok = False; why = str(e)[:200]
+                ok = agree(ok)
+            else:
+                ok = False
+        else:
+            ok = False
+        if ok:
+            dp = dpr; rccl_ranks = world
+            comm_note = "libmd2hip RCCL communicator (md2_comm_init), 4 buckets overlapped with the pullback; verified against the local gradient before timing (rel %.1e)" % err
+        else:
+            comm_note = "torch.distributed RCCL all-reduce of the library's gradient buffer (library communicator not used: %s)" % (why or "another rank could not verify md2_comm")
             try:
                 model.comm_destroy()
             except Exception:                       # noqa: BLE001
                 model._comm_spec = None
             dp = par.DataParallel(model, comm="torch")
-        # every rank must take the same branch
-        flag = torch.tensor([1.0 if dp.comm == "rccl" else 0.0], device="cuda"); torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        if float(flag.item()) < 0.5 and dp.comm == "rccl":
-            model.comm_destroy()
-            dp = par.DataParallel(model, comm="torch"); comm_note = "torch.distributed RCCL all-reduce (another rank could not verify md2_comm)"
         if dp.comm != "rccl":
             rccl_ranks = 0
     elif world > 1:

@@ -1843,45 +1843,51 @@ void launch_weight_to_dgrad(const float* w_fwd, float* w_dg, int CoutP, int CinP
 // disparity heads: reflect-pad 3x3 conv to ONE channel + sigmoid (src/depth_decoder.jl:43).  Memory-bound GEMV:
 // LPP = Cin/4 lanes share one pixel (one float4 of channels each), shuffle-reduce inside the lane group.
 // ------------------------------------------------------------------------------------------------------------
+// (row-indexed like the element kernels of layers.hip: blockIdx.x owns `rpb` image rows, blockIdx.y a 256 / LPP-pixel chunk of the row -- the flat 64-bit pixel index
+//  this kernel used to decode per pixel cost more vector instructions than its 9 x 16-B gathers)
 template <int LPP>
-__global__ __launch_bounds__(256) void head_fwd_kernel(View x, const float* __restrict__ w, const float* __restrict__ b, View y) {
-    const int g = threadIdx.x / LPP, l = threadIdx.x % LPP;
+__global__ __launch_bounds__(256) void head_fwd_kernel(View x, const float* __restrict__ w, const float* __restrict__ b, View y, int rpb) {
+    const int l = threadIdx.x % LPP;
     constexpr int PPB = 256 / LPP;
+    const int wq = blockIdx.y * PPB + threadIdx.x / LPP;
+    const bool live = wq < x.W;                     // (whole LPP-lane groups live or die together: the shuffles below stay inside a group)
     float4 wv[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(w + t * x.C + l * 4);
     const float bias = b[0];
-    const long P = x.pixels();
-    const int HW = x.H * x.W;
-    for (long p = (long)blockIdx.x * PPB + g; p < P; p += (long)gridDim.x * PPB) {
-        const int n = p / HW, r = p - (long)n * HW, h = r / x.W, wq = r - h * x.W;
+    int iws[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) iws[kw] = refl_idx(min(wq, x.W - 1) + kw - 1, x.W);
+    const int rows = x.N * x.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+        const int n = row / x.H, h = row - n * x.H;
         float s = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = refl_idx(h + kh - 1, x.H);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int iw = refl_idx(wq + kw - 1, x.W);
-                const float4 v = *reinterpret_cast<const float4*>(x.p + (long)n * x.bs + ((long)ih * x.W + iw) * x.ps + l * 4);
+                const float4 v = *reinterpret_cast<const float4*>(x.p + (long)n * x.bs + ((long)ih * x.W + iws[kw]) * x.ps + l * 4);
                 const float4 c = wv[kh * 3 + kw];
                 s += v.x * c.x + v.y * c.y + v.z * c.z + v.w * c.w;
             }
         }
 #pragma unroll
         for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (l == 0) y.p[(long)n * y.bs + (long)r * y.ps] = 1.f / (1.f + expf(-(s + bias)));
+        if (l == 0 && live) y.p[(long)n * y.bs + ((long)h * x.W + wq) * y.ps] = 1.f / (1.f + expf(-(s + bias)));
     }
 }
 void launch_head_fwd(const View& x, const float* w, const float* b, const View& y, hipStream_t s) {
-    const long P = x.pixels();
     const int lpp = x.C / 4, ppb = 256 / lpp;
-    const int grid = (int)std::min<long>((P + ppb - 1) / ppb, 4096);
+    const long rows = (long)x.N * x.H; const int chunks = (x.W + ppb - 1) / ppb;
+    const int rpb = (int)std::min<long>(16, std::max<long>(1, (rows * chunks + 8191) / 8192));
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)chunks);
     switch (lpp) {
-        case 4: hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
-        case 8: hipLaunchKernelGGL(head_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
-        case 16: hipLaunchKernelGGL(head_fwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
-        case 32: hipLaunchKernelGGL(head_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;
-        case 64: hipLaunchKernelGGL(head_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, x, w, b, y); break;          // a head on the first branch (scale level 1, 256 channels)
+        case 4: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;
+        case 8: hipLaunchKernelGGL(head_fwd_kernel<8>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;
+        case 16: hipLaunchKernelGGL(head_fwd_kernel<16>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;
+        case 32: hipLaunchKernelGGL(head_fwd_kernel<32>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;
+        case 64: hipLaunchKernelGGL(head_fwd_kernel<64>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;          // a head on the first branch (scale level 1, 256 channels)
         default: fprintf(stderr, "md2: head_fwd: unsupported Cin=%d\n", x.C); abort();
     }
 }

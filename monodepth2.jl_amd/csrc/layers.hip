@@ -16,6 +16,20 @@ __device__ __forceinline__ float* vptrw(const View& v, int n, long r) { return v
 static inline bool dense_view_h(const View& v) { return v.ps == v.C && v.bs == (long)v.H * v.W * v.C; }
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// ---- row-indexed element kernels ------------------------------------------------------------------------------------
+// The pointwise / stencil kernels below used to decode a flat 64-bit element index per element (i % Q, i / Q, p / HW, r / W: four 64-bit divisions, ~400 vector
+// instructions -- more than the 16 + 16 bytes of traffic per lane they serve, so they ran at the vector rate, not at HBM's).  Now blockIdx.x owns RPB consecutive image
+// rows (n, h: block-uniform, scalar arithmetic), blockIdx.y a 256-wide chunk of the row's W x (C/4) float4 elements, and a thread keeps its (w, channel quad) for life:
+// one 32-bit division per thread, everything per row is uniform.
+struct RowGrid { dim3 grid; int rpb; };
+static inline RowGrid row_grid(long rows, int rowlen, int want_blocks = 8192) {
+    const int chunks = (rowlen + 255) / 256;
+    int rpb = (int)std::max<long>(1, (rows * chunks + want_blocks - 1) / want_blocks);
+    rpb = std::min(rpb, 16);
+    RowGrid g; g.rpb = rpb; g.grid = dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)chunks, 1);
+    return g;
+}
+
 // ---- layout conversion for the op-level entry points --------------------------------------------------------------
 __global__ void nchw_to_view_kernel(const float* __restrict__ src, View v) {
     const long total = (long)v.N * v.H * v.W * v.C;
@@ -208,13 +222,33 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, int slots
 void launch_bn_bwd_finalize(const double* acc, int slots, int C, double count, float* coef, float* dgamma, float* dbeta, const float* stats, const float* gamma, hipStream_t s) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc, slots, C, count, coef, dgamma, dbeta, stats, gamma);
 }
+// FAST also folds bn_bwd_finalize_kernel in: the first Q threads of every block sum the 8 slots of their channel quad (64 L2-resident doubles) into LDS, block 0
+// adds d gamma / d beta -- 19 launches of ~5 us fewer per step, which is what a batch-4 step is made of.  coef keeps receiving m1 | m2 (block 0) for callers that read it.
 template <bool FAST>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, int has_yact, int act, View z, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const float* __restrict__ coef, View dz) {
+                                                           float* __restrict__ coef, View dz, const double* __restrict__ acc, int slots, double count,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int C = z.C, Q = C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
     if (FAST) {                                 // one channel quad per thread: the per-channel constants leave the loop
+        __shared__ float4 sm1[256], sm2[256];
+        if (threadIdx.x < Q) {
+            const int c0 = threadIdx.x * 4;
+            double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+            for (int k = 0; k < slots; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[e] += acc[(size_t)k * 2 * C + c0 + e]; s2[e] += acc[(size_t)k * 2 * C + C + c0 + e]; }
+            const float4 a1 = make_float4((float)(s1[0] / count), (float)(s1[1] / count), (float)(s1[2] / count), (float)(s1[3] / count));
+            const float4 a2 = make_float4((float)(s2[0] / count), (float)(s2[1] / count), (float)(s2[2] / count), (float)(s2[3] / count));
+            sm1[threadIdx.x] = a1; sm2[threadIdx.x] = a2;
+            if (blockIdx.x == 0) {
+                st4(coef + c0, a1); st4(coef + C + c0, a2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dbeta[c0 + e] += (float)s1[e]; dgamma[c0 + e] += (float)s2[e]; }
+            }
+        }
+        __syncthreads();
         const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
-        const float4 m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4), m1 = ld4(coef + q * 4), m2 = ld4(coef + C + q * 4);
+        const float4 m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4), m1 = sm1[q], m2 = sm2[q];
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
             float4 g = ld4(dy.p + i * 4);
             if (has_yact) { const float4 o = ld4(yact.p + i * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
@@ -243,11 +277,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
 }
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc, double count,
                          const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots, float* coef) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((z.C + 255) / 256), dim3(256), 0, s, acc, slots, z.C, count, coef, dgamma, dbeta, (const float*)nullptr, (const float*)nullptr);
     const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(dy) && dense_view_h(dz) && (!yact || dense_view_h(*yact));
-    const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
-    if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz);
+    // (fast: every block re-derives its coefficients -- fewer, longer-lived blocks than the 4096 of the plain element kernels)
+    const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, fast ? 2048 : 4096));
+    if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz, acc, slots, count, dgamma, dbeta);
+    else {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((z.C + 255) / 256), dim3(256), 0, s, acc, slots, z.C, count, coef, dgamma, dbeta, (const float*)nullptr, (const float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz, acc, slots, count, dgamma, dbeta);
+    }
 }
 
 // ---- MaxPool((3,3); pad=1, stride=2): first maximum in (kh,kw) scan order wins; the argmax tap (0..8) is kept ------------
@@ -278,12 +315,14 @@ void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t 
 // Stem tail fused: a = relu(bn(z)) is never read back -- one pass computes the 3x3 / stride-2 max-pool of a on the fly from z, and writes a itself only for the
 // frames the depth decoder's skip connection needs (n % L == tgt; all frames when L == 1).  Replaces bn_apply (read z, write a) + maxpool_fwd (read a).
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              View a, int L, int tgt, View y, uint8_t* __restrict__ arg) {
-    const int Q = z.C / 4; const long total = y.pixels() * Q; const int HWo = y.H * y.W;
-    const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) % Q);              // grid stride is a multiple of Q: one channel quad per thread
+                                                              View a, int L, int tgt, View y, uint8_t* __restrict__ arg, int rpb) {
+    const int Q = z.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= y.W * Q) return;
+    const int ow = idx / Q, q = idx - ow * Q;
     const float4 m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long p = i / Q; const int n = p / HWo; const int r = p - (long)n * HWo; const int oh = r / y.W, ow = r - oh * y.W;
+    const int rows = y.N * y.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+        const int n = row / y.H, oh = row - n * y.H;
         const bool wa = (L == 1) || (n % L) == tgt;
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; uint8_t bi[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -299,13 +338,15 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(View z, const floa
                 if (wa && kh >= 1 && kw >= 1) st4(vptrw(a, n, (long)ih * z.W + iw) + q * 4, make_float4(vv[0], vv[1], vv[2], vv[3]));   // this output owns the 2x2 block (2oh.., 2ow..)
             }
         }
+        const long r = (long)oh * y.W + ow;
         st4(vptrw(y, n, r) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
-        *reinterpret_cast<uchar4*>(arg + (p * z.C + q * 4)) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+        *reinterpret_cast<uchar4*>(arg + (((long)n * y.H * y.W + r) * z.C + q * 4)) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
     }
 }
 void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s) {
     if ((z.H & 1) || (z.W & 1) || y.H != z.H / 2 || y.W != z.W / 2 || z.C % 4 != 0 || (256 % (z.C / 4)) != 0) { fprintf(stderr, "md2: bn_relu_maxpool: unsupported shape\n"); abort(); }
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(y.pixels() * (z.C / 4), 256, 4096)), dim3(256), 0, s, z, stats, gamma, beta, a, L, tgt, y, arg);
+    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (z.C / 4));
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, rg.grid, dim3(256), 0, s, z, stats, gamma, beta, a, L, tgt, y, arg, rg.rpb);
 }
 
 // gather form: input pixel (ih,iw) is covered by outputs oh in {(ih+1)/2 - (0|1)}...; no atomics, deterministic
@@ -314,25 +355,36 @@ void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamm
 // bz / bstat / bacc (optional): dx is the gradient of a BatchNorm output whose input is bz -- the kernel also accumulates that BatchNorm's pullback sums
 // (sum g, sum g*xhat per channel; needs 256 % (C/4) == 0 so that a thread keeps one channel quad) and the separate reduction pass over (g, z) goes away
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View yrelu, int has_yrelu,
-                                                          View bz, const float* __restrict__ bstat, double* __restrict__ bacc, int acc_frame) {
-    const int Q = dx.C / 4; const long total = dx.pixels() * Q; const int HW = dx.H * dx.W, HWo = dy.H * dy.W;
+                                                          View bz, const float* __restrict__ bstat, double* __restrict__ bacc, int acc_frame, int rpb) {
+    const int Q = dx.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    const bool live = idx < dx.W * Q;
+    const int iw = live ? idx / Q : 0, q = live ? idx - iw * Q : 0;
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1;
-    if (bacc) { const int q0 = threadIdx.x % Q; mu = ld4(bstat + q0 * 4); is = ld4(bstat + dx.C + q0 * 4); }
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int ih = r / dx.W, iw = r - ih * dx.W;
+    if (bacc) { mu = ld4(bstat + q * 4); is = ld4(bstat + dx.C + q * 4); }
+    // the (at most two) pooled columns whose 3x3 window covers input column iw, with the window tap kw each sees it through: fixed for the thread's life
+    int ows[2], kws[2], nw = 0;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) { const int u = iw + 1 - kw; if (u >= 0 && !(u & 1) && (u >> 1) < dy.W) { ows[nw] = u >> 1; kws[nw] = kw; ++nw; } }
+    const int rows = dx.N * dx.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    const long HWo = (long)dy.H * dy.W;
+    if (live)
+    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+        const int n = row / dx.H, ih = row - n * dx.H;
         float g[4] = {0.f, 0.f, 0.f, 0.f};
         for (int kh = 0; kh < 3; ++kh) {
-            const int t = ih + 1 - kh; if (t < 0 || (t & 1)) continue; const int oh = t >> 1; if (oh >= dy.H) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-                const int u = iw + 1 - kw; if (u < 0 || (u & 1)) continue; const int ow = u >> 1; if (ow >= dy.W) continue;
-                const long po = (long)n * HWo + (long)oh * dy.W + ow;
-                const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (po * dx.C + q * 4));
-                float4 d = ld4(vptr(dy, n, (long)oh * dy.W + ow) + q * 4);
-                if (has_yrelu) { const float4 o = ld4(vptr(yrelu, n, (long)oh * dy.W + ow) + q * 4); d.x *= act_deriv(o.x, ACT_RELU); d.y *= act_deriv(o.y, ACT_RELU); d.z *= act_deriv(o.z, ACT_RELU); d.w *= act_deriv(o.w, ACT_RELU); }
-                const int tap = kh * 3 + kw;
+            const int t = ih + 1 - kh; if (t < 0 || (t & 1)) continue; const int oh = t >> 1; if (oh >= dy.H) continue;          // (block-uniform)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b >= nw) break;
+                const long ro = (long)oh * dy.W + ows[b];
+                const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (((long)n * HWo + ro) * dx.C + q * 4));
+                float4 d = ld4(vptr(dy, n, ro) + q * 4);
+                if (has_yrelu) { const float4 o = ld4(vptr(yrelu, n, ro) + q * 4); d.x *= act_deriv(o.x, ACT_RELU); d.y *= act_deriv(o.y, ACT_RELU); d.z *= act_deriv(o.z, ACT_RELU); d.w *= act_deriv(o.w, ACT_RELU); }
+                const int tap = kh * 3 + kws[b];
                 if (a.x == tap) g[0] += d.x; if (a.y == tap) g[1] += d.y; if (a.z == tap) g[2] += d.z; if (a.w == tap) g[3] += d.w;
             }
         }
+        const long r = (long)ih * dx.W + iw;
         float* dp = vptrw(dx, n, r) + q * 4;
         if (accumulate == 1 || (accumulate == 2 && (n % 3) == acc_frame)) {      // earlier contributions are already masked
             const float4 o = ld4(dp); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
@@ -343,27 +395,28 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t
             s2.x += g[0] * ((z.x - mu.x) * is.x); s2.y += g[1] * ((z.y - mu.y) * is.y); s2.z += g[2] * ((z.z - mu.z) * is.z); s2.w += g[3] * ((z.w - mu.w) * is.w);
         }
     }
-    if (bacc) {                                   // block reduction over the 256 / Q threads that share a channel quad, then one double atomic per channel and block
+    if (bacc) {                                   // block reduction over the 256 / Q threads that share a channel quad (256 % Q == 0: thread t holds quad t % Q), then one double atomic per channel and block
         __shared__ float red[8 * 256];
         const float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[e * 256 + threadIdx.x] = v[e];
         __syncthreads();
         const int C = dx.C, RG = 256 / Q;
+        const int slot = (blockIdx.x + blockIdx.y) % BN_STAT_SLOTS;
         for (int c = threadIdx.x; c < 2 * C; c += 256) {
             const int which = c / C, ch = c % C, qq = ch / 4, e = ch % 4;
             float t = 0.f;
             for (int gI = 0; gI < RG; ++gI) t += red[(which * 4 + e) * 256 + gI * Q + qq];
-            atomicAdd(bacc + (size_t)(blockIdx.x % BN_STAT_SLOTS) * 2 * C + which * C + ch, (double)t);
+            atomicAdd(bacc + (size_t)slot * 2 * C + which * C + ch, (double)t);
         }
     }
 }
 void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu, hipStream_t s, const View* bz, const float* bstat, double* bacc, int acc_frame) {
     const int Q = dx.C / 4;
     if (bacc && (256 % Q != 0 || !bz)) { fprintf(stderr, "md2: maxpool_bwd: the fused BatchNorm sums need 256 %% (C/4) == 0\n"); abort(); }
-    // (with the fused sums every block ends in 2 C double atomics: measured 371 / 341 / 291 / 277 / 271 us at caps of 1024 / 2048 / 4096 / 8192 / 16384 blocks, B=32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(dx.pixels() * Q, 256, 8192)), dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0,
-                       bz ? *bz : dx, bstat, bacc, acc_frame);
+    const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * Q);          // (with the fused sums every block ends in 2 C double atomics: ~8192 blocks measured best, B=32)
+    hipLaunchKernelGGL(maxpool_bwd_kernel, rg.grid, dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0,
+                       bz ? *bz : dx, bstat, bacc, acc_frame, rg.rpb);
 }
 
 // ---- NNlib.upsample_bilinear(x, (2,2)) (src/depth_decoder.jl:18-19), align-corners mapping --------------------------------
@@ -374,69 +427,155 @@ __device__ __forceinline__ void up_src(int o, int in, int out, int& i0, int& i1,
     i1 = min(i0 + 1, in - 1);
     w1 = s - (float)i0;
 }
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y) {
-    const int Q = x.C / 4; const long total = y.pixels() * Q; const int HWo = y.H * y.W;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int q = i % Q; const long p = i / Q; const int n = p / HWo; const int r = p - (long)n * HWo; const int oh = r / y.W, ow = r - oh * y.W;
-        int h0, h1, w0, w1; float fh, fw; up_src(oh, x.H, y.H, h0, h1, fh); up_src(ow, x.W, y.W, w0, w1, fw);
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y, int rpb) {
+    const int Q = x.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= y.W * Q) return;
+    const int ow = idx / Q, q = idx - ow * Q;
+    int w0, w1; float fw; up_src(ow, x.W, y.W, w0, w1, fw);          // the column taps are the thread's for life
+    const float gw = 1.f - fw;
+    const int rows = y.N * y.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+        const int n = row / y.H, oh = row - n * y.H;
+        int h0, h1; float fh; up_src(oh, x.H, y.H, h0, h1, fh);      // the row taps are block-uniform
         const float4 a = ld4(vptr(x, n, (long)h0 * x.W + w0) + q * 4), b = ld4(vptr(x, n, (long)h0 * x.W + w1) + q * 4);
         const float4 c = ld4(vptr(x, n, (long)h1 * x.W + w0) + q * 4), d = ld4(vptr(x, n, (long)h1 * x.W + w1) + q * 4);
-        const float gh = 1.f - fh, gw = 1.f - fw;
+        const float gh = 1.f - fh;
         float4 o;
         o.x = gh * (gw * a.x + fw * b.x) + fh * (gw * c.x + fw * d.x); o.y = gh * (gw * a.y + fw * b.y) + fh * (gw * c.y + fw * d.y);
         o.z = gh * (gw * a.z + fw * b.z) + fh * (gw * c.z + fw * d.z); o.w = gh * (gw * a.w + fw * b.w) + fh * (gw * c.w + fw * d.w);
-        st4(vptrw(y, n, r) + q * 4, o);
+        st4(vptrw(y, n, (long)oh * y.W + ow) + q * 4, o);
     }
 }
 void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s) {
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(y.pixels() * (x.C / 4), 256, 4096)), dim3(256), 0, s, x, y);
+    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (x.C / 4));
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, rg.grid, dim3(256), 0, s, x, y, rg.rpb);
 }
 // exact adjoint in gather form: every candidate output row/col recomputes the forward's (i0,i1,w1)
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(View dy, View dx, View xact, int has_xact, int act) {
-    const int Q = dx.C / 4; const long total = dx.pixels() * Q; const int HW = dx.H * dx.W;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int h = r / dx.W, w = r - h * dx.W;
-        // outputs oh with source index in (h-1, h+1): oh in [ (h-1)*(Ho-1)/(H-1) , (h+1)*(Ho-1)/(H-1) ]
-        const float rh = dx.H > 1 ? (float)(dy.H - 1) / (float)(dx.H - 1) : 0.f, rw = dx.W > 1 ? (float)(dy.W - 1) / (float)(dx.W - 1) : 0.f;
-        // (a candidate just outside the open interval has weight 0 or a rounding-sized one: no +-1 safety margin, which was 2 of 7 candidates per axis)
-        const int oh_lo = max(0, (int)floorf((h - 1) * rh)), oh_hi = min(dy.H - 1, (int)ceilf((h + 1) * rh));
-        const int ow_lo = max(0, (int)floorf((w - 1) * rw)), ow_hi = min(dy.W - 1, (int)ceilf((w + 1) * rw));
+// candidates of one axis: outputs o with a source index in (i-1, i+1), i.e. o in [(i-1) r, (i+1) r], r = (out-1)/(in-1); their adjoint weights (i0 == i ? 1 - f : 0) + (i1 == i ? f : 0).
+// (a candidate just outside the open interval has weight 0 or a rounding-sized one: no +-1 safety margin.)  At most UP_MAXC candidates carry weight for ratios <= 2.
+constexpr int UP_MAXC = 6;
+__device__ __forceinline__ int up_adjoint_taps(int i, int in, int out, int (&os)[UP_MAXC], float (&cs)[UP_MAXC]) {
+    const float r = in > 1 ? (float)(out - 1) / (float)(in - 1) : 0.f;
+    const int lo = max(0, (int)floorf((i - 1) * r)), hi = min(out - 1, (int)ceilf((i + 1) * r));
+    // slot k <-> candidate lo + k (static indexing keeps the arrays in registers); zero-weight candidates stay in the list with weight 0
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < UP_MAXC; ++k) {
+        const int o = lo + k;
+        int i0, i1; float f; up_src(min(o, out - 1), in, out, i0, i1, f);
+        const float c = o <= hi ? (i0 == i ? 1.f - f : 0.f) + (i1 == i ? f : 0.f) : 0.f;
+        os[k] = min(o, out - 1); cs[k] = c;
+        if (o <= hi) n = k + 1;
+    }
+    return n;
+}
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(View dy, View dx, View xact, int has_xact, int act, int rpb) {
+    const int Q = dx.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= dx.W * Q) return;
+    const int w = idx / Q, q = idx - w * Q;
+    int ows[UP_MAXC]; float cws[UP_MAXC];
+    const int nw = up_adjoint_taps(w, dx.W, dy.W, ows, cws);          // column taps: once per thread
+    const int rows = dx.N * dx.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+        const int n = row / dx.H, h = row - n * dx.H;
+        int ohs[UP_MAXC]; float chs[UP_MAXC];
+        const int nh = up_adjoint_taps(h, dx.H, dy.H, ohs, chs);      // row taps: block-uniform
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
-            int h0, h1; float fh; up_src(oh, dx.H, dy.H, h0, h1, fh);
-            const float ch = (h0 == h ? 1.f - fh : 0.f) + (h1 == h ? fh : 0.f);
-            if (ch == 0.f) continue;
-            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                int w0, w1; float fw; up_src(ow, dx.W, dy.W, w0, w1, fw);
-                const float cw = (w0 == w ? 1.f - fw : 0.f) + (w1 == w ? fw : 0.f);
-                if (cw == 0.f) continue;
-                const float4 d = ld4(vptr(dy, n, (long)oh * dy.W + ow) + q * 4);
-                const float c = ch * cw;
+#pragma unroll
+        for (int a = 0; a < UP_MAXC; ++a) {
+            if (a >= nh) break;
+#pragma unroll
+            for (int b = 0; b < UP_MAXC; ++b) {
+                if (b >= nw) break;
+                const float4 d = ld4(vptr(dy, n, (long)ohs[a] * dy.W + ows[b]) + q * 4);
+                const float c = chs[a] * cws[b];
                 g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w;
             }
         }
+        const long r = (long)h * dx.W + w;
         if (has_xact) { const float4 o = ld4(vptr(xact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
         st4(vptrw(dx, n, r) + q * 4, g);
     }
 }
 void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int act, hipStream_t s) {
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(dx.pixels() * (dx.C / 4), 256, 4096)), dim3(256), 0, s, dy, dx, xact ? *xact : dx, xact ? 1 : 0, act);
+    if (dy.H > 2 * dx.H || dy.W > 2 * dx.W) { fprintf(stderr, "md2: upsample2x_bwd: ratio above 2\n"); abort(); }
+    const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * (dx.C / 4));
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, rg.grid, dim3(256), 0, s, dy, dx, xact ? *xact : dx, xact ? 1 : 0, act, rg.rpb);
 }
 
-// ---- pad_reflect(x,1) pullback: dst[r] = sum over padded u in [-1,size] with refl(u) = r of src_pad[u+1] ----------------------
-__global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, int accumulate, View actsrc, int has_act, int act) {
-    const int Q = dst.C / 4; const long total = dst.pixels() * Q; const int HW = dst.H * dst.W, H = dst.H, W = dst.W;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int q = i % Q; const long p = i / Q; const int n = p / HW; const int r = p - (long)n * HW; const int h = r / W, w = r - h * W;
-        int uys[3], uxs[3], ny = 0, nx = 0;
-        uys[ny++] = h; if (h == 1) uys[ny++] = -1; if (h == H - 2) uys[ny++] = H;
-        uxs[nx++] = w; if (w == 1) uxs[nx++] = -1; if (w == W - 2) uxs[nx++] = W;
+// fold_reflect followed by the adjoint of the bilinear x2 (the two passes between a DecoderBlock's second convolution and its first on the way back, src/depth_decoder.jl:18-19,5):
+//   dx[h][w] = act'(xact) * sum over fine pixels (oh, ow) of the x2 adjoint weights * fold(sp)[oh][ow],   fold(sp)[oh][ow] = sum of the padded positions that mirror onto it.
+// One gather pass over the padded gradient instead of writing and re-reading the folded full-resolution tensor (109 + 109 + 109 MB for the last branch at batch 32).
+__global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, View xact, int has_xact, int act, int rpb) {
+    const int Q = dx.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= dx.W * Q) return;
+    const int w = idx / Q, q = idx - w * Q;
+    const int Hf = sp.H - 2, Wf = sp.W - 2;         // the fine (unpadded) map
+    int ows[UP_MAXC]; float cws[UP_MAXC];
+    const int nw = up_adjoint_taps(w, dx.W, Wf, ows, cws);
+    int ox2[UP_MAXC];                               // second padded column folding onto fine column ows[b] (padded index, i.e. + 1), or -1
+#pragma unroll
+    for (int b = 0; b < UP_MAXC; ++b) ox2[b] = ows[b] == 1 ? 0 : (ows[b] == Wf - 2 ? Wf + 1 : -1);
+    const int rows = dx.N * dx.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+        const int n = row / dx.H, h = row - n * dx.H;
+        int ohs[UP_MAXC]; float chs[UP_MAXC];
+        const int nh = up_adjoint_taps(h, dx.H, Hf, ohs, chs);
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) {
+#pragma unroll
+        for (int a = 0; a < UP_MAXC; ++a) {
+            if (a >= nh) break;
+            const int oy2 = ohs[a] == 1 ? 0 : (ohs[a] == Hf - 2 ? Hf + 1 : -1);
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                const int py = yy == 0 ? ohs[a] + 1 : oy2;
+                if (py < 0) continue;
+#pragma unroll
+                for (int b = 0; b < UP_MAXC; ++b) {
+                    if (b >= nw) break;
+                    const float c = chs[a] * cws[b];
+                    float4 d = ld4(vptr(sp, n, (long)py * sp.W + ows[b] + 1) + q * 4);
+                    if (ox2[b] >= 0) { const float4 e = ld4(vptr(sp, n, (long)py * sp.W + ox2[b]) + q * 4); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+                    g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w;
+                }
+            }
+        }
+        const long r = (long)h * dx.W + w;
+        if (has_xact) { const float4 o = ld4(vptr(xact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        st4(vptrw(dx, n, r) + q * 4, g);
+    }
+}
+void launch_fold_up2_bwd(const View& src_pad, const View& dx, const View* xact, int act, hipStream_t s) {
+    const int Hf = src_pad.H - 2, Wf = src_pad.W - 2;
+    // (maps of at least 4 x 4: on a 3-wide map both frame columns mirror onto column 1, which the one-extra-position bookkeeping above does not cover)
+    if (Hf < 4 || Wf < 4 || Hf > 2 * dx.H || Wf > 2 * dx.W || src_pad.C < dx.C) { fprintf(stderr, "md2: fold_up2_bwd: unsupported shape\n"); abort(); }
+    const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * (dx.C / 4));
+    hipLaunchKernelGGL(fold_up2_bwd_kernel, rg.grid, dim3(256), 0, s, src_pad, dx, xact ? *xact : dx, xact ? 1 : 0, act, rg.rpb);
+}
+
+__global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, int accumulate, View actsrc, int has_act, int act, int rpb) {
+    const int Q = dst.C / 4, H = dst.H, W = dst.W, idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= W * Q) return;
+    const int w = idx / Q, q = idx - w * Q;
+    int uxs[3], nx = 0;                             // padded-domain columns that fold onto column w (pad_reflect mirrors WITHOUT the edge: -1 <-> 1, W <-> W - 2)
+    uxs[nx++] = w; if (w == 1) uxs[nx++] = -1; if (w == W - 2) uxs[nx++] = W;
+    const int rows = dst.N * H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+        const int n = row / H, h = row - n * H;
+        int uys[3], ny = 0;
+        uys[ny++] = h; if (h == 1) uys[ny++] = -1; if (h == H - 2) uys[ny++] = H;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (a >= ny) break;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (b >= nx) break;
                 const float4 d = ld4(vptr(sp, n, (long)(uys[a] + 1) * sp.W + (uxs[b] + 1)) + q * 4);
                 g.x += d.x; g.y += d.y; g.z += d.z; g.w += d.w;
             }
+        }
+        const long r = (long)h * W + w;
         float* dp = vptrw(dst, n, r) + q * 4;
         if (accumulate) { const float4 o = ld4(dp); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
         if (has_act) { const float4 o = ld4(vptr(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
@@ -445,13 +584,18 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, in
 }
 void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, const View* actsrc, int act, hipStream_t s) {
     if (src_pad.H != dst.H + 2 || src_pad.W != dst.W + 2 || src_pad.C < dst.C) { fprintf(stderr, "md2: fold_reflect: shape mismatch\n"); abort(); }
-    hipLaunchKernelGGL(fold_reflect_kernel, dim3(grid_for(dst.pixels() * (dst.C / 4), 256, 4096)), dim3(256), 0, s, src_pad, dst, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act);
+    const RowGrid rg = row_grid((long)dst.N * dst.H, dst.W * (dst.C / 4));
+    hipLaunchKernelGGL(fold_reflect_kernel, rg.grid, dim3(256), 0, s, src_pad, dst, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act, rg.rpb);
 }
 
-__global__ __launch_bounds__(256) void axpy_view_kernel(View src, View dst, float a, int accumulate, View actsrc, int has_act, int act) {
-    const int Q = dst.C / 4; const long total = dst.pixels() * Q; const int HW = dst.H * dst.W;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
+__global__ __launch_bounds__(256) void axpy_view_kernel(View src, View dst, float a, int accumulate, View actsrc, int has_act, int act, int rpb) {
+    const int Q = dst.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= dst.W * Q) return;
+    const int w = idx / Q, q = idx - w * Q;
+    const int rows = dst.N * dst.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+        const int n = row / dst.H, h = row - n * dst.H;
+        const long r = (long)h * dst.W + w;
         float4 g = ld4(vptr(src, n, r) + q * 4);
         g.x *= a; g.y *= a; g.z *= a; g.w *= a;
         if (has_act) { const float4 o = ld4(vptr(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
@@ -461,7 +605,8 @@ __global__ __launch_bounds__(256) void axpy_view_kernel(View src, View dst, floa
     }
 }
 void launch_axpy_view(const View& src, const View& dst, float a, int accumulate, const View* actsrc, int act, hipStream_t s) {
-    hipLaunchKernelGGL(axpy_view_kernel, dim3(grid_for(dst.pixels() * (dst.C / 4), 256, 4096)), dim3(256), 0, s, src, dst, a, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act);
+    const RowGrid rg = row_grid((long)dst.N * dst.H, dst.W * (dst.C / 4));
+    hipLaunchKernelGGL(axpy_view_kernel, rg.grid, dim3(256), 0, s, src, dst, a, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act, rg.rpb);
 }
 
 // ---- bias gradient: out[c] += sum over pixels -----------------------------------------------------------------------------

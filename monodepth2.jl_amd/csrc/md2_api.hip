@@ -83,6 +83,7 @@ struct md2_handle {
     hipStream_t s3 = nullptr; hipStream_t cur = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // pose branch stream; `cur` = stream of the chain being enqueued
     hipStream_t s4 = nullptr; int wg_rr = 0; int n_wg_streams = 1; hipEvent_t ev_join4 = nullptr;
     hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr, ev_p0 = nullptr, ev_p1 = nullptr; bool prep_done = false; bool two_streams = true; bool forked = false; View dz0;
+    bool acc_zeroed = false;            // md2_train_loss: the forward pass's memset covers the pullback / loss accumulators too
     bool net_ok = true;                 // false: the image is too small for the network (H or W < 64): only the loss-half entry points work
     float* RS = nullptr; long n_rs = 0; bool testmode = false;     // BatchNorm running mean / variance (Flux BatchNorm mu, sigma^2; momentum 0.1) and Flux.testmode!
     double* loss_blk = nullptr;         // deterministic mode: per-block partial sums of the loss kernels
@@ -411,7 +412,9 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
     if (tgt < 0) tgt = h->tgt;                  // triplets: the configured target frame
     const int NL = h->z0.N, N = NL / L, H = h->H, W = h->W;
     if (!wino_on_side) refresh_wino_fwd(h, s);          // (md2_train_loss runs it on the side stream, overlapping the stem)
-    HIPCHK(hipMemsetAsync(h->acc_all, 0, h->acc_fwd_count * sizeof(double), s));
+    // every double accumulator of the step in ONE memset: forward statistics | pullback sums | loss partials | pose-gradient sums are adjacent (plan_buffers).  A training
+    // step says so up front (acc_zeroed), and its loss / pullback-preparation phases skip their own memsets.
+    HIPCHK(hipMemsetAsync(h->acc_all, 0, (h->acc_zeroed ? h->acc_count : h->acc_fwd_count) * sizeof(double), s));
     // ---- encoder: stem + BN + ReLU, maxpool, 8 basic blocks
     {   // direct 7x7 stride-2 convolution on the boundary tensor (+ its BatchNorm statistics)
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
@@ -498,7 +501,8 @@ static int loss_forward(md2_handle* h, const float* x, const float* const disp[M
 // loss value and its pullback in one pass (training): fills the loss, ddisp_lo[4], drvec, dtvec
 static int loss_train(md2_handle* h, const float* x, const float* const disp[MD2_MAX_SCALES], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
     hipStream_t s = h->stream;
-    HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)(4 * MD2_MAX_SCALES + 24) * h->N * sizeof(double), s));           // loss_part [20N] and dRt_acc [24N] are adjacent
+    if (!h->acc_zeroed) HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)(4 * MD2_MAX_SCALES + 24) * h->N * sizeof(double), s));           // loss_part [20N] and dRt_acc [24N] are adjacent
+    h->acc_zeroed = false;
     launch_pose_compose(rvec, tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
     if (simple) simple_mode(h, a);
@@ -555,7 +559,7 @@ static void pose_backward(md2_handle* h, int N, int part) {
 // runs it on the (otherwise idle) second stream while the forward pass computes; without that stream it runs at the head of backward.
 static int backward_prepare(md2_handle* h, hipStream_t s) {
     HIPCHK(hipMemsetAsync(h->G, 0, (size_t)h->n_int * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
+    if (!h->acc_zeroed) HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
     launch_weight_to_dgrad_batched(h->P, h->WD, h->wdesc_dev, h->n_wdesc, s);
     h->u_pieces_d = g_wino_pieces;
     launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions
@@ -595,12 +599,13 @@ static int model_backward(md2_handle* h) {
         View dcp = make_view(h->dxpad, N, h->cat[b].H + 2, h->cat[b].W + 2, h->cat[b].C);
         conv_dgrad(h, h->dc2[b], dZ2, dcp, 0, 0, nullptr, ACT_NONE);
         const int dc = h->y1[b].C;
-        launch_fold_reflect(chan_slice(dcp, 0, dc), h->dupv[b], 0, nullptr, ACT_NONE, s);
         if (b < 4) {
             View fv = frame_view(h->feat[3 - b], 3, h->tgt), gv = frame_view(h->Gfeat[3 - b], 3, h->tgt);
             launch_fold_reflect(chan_slice(dcp, dc, fv.C), gv, 0, &fv, ACT_RELU, s);      // first writer of this stage's target frames
         }
-        launch_upsample2x_bwd(h->dupv[b], h->dZ1[b], &h->y1[b], ACT_ELU, s);
+        // the upsampled half of the concat: reflect-pad adjoint and the x2 adjoint in one gather pass (deterministic either way: no atomics); maps narrower than 4 keep the two passes
+        if (h->cat[b].H >= 4 && h->cat[b].W >= 4) launch_fold_up2_bwd(chan_slice(dcp, 0, dc), h->dZ1[b], &h->y1[b], ACT_ELU, s);
+        else { launch_fold_reflect(chan_slice(dcp, 0, dc), h->dupv[b], 0, nullptr, ACT_NONE, s); launch_upsample2x_bwd(h->dupv[b], h->dZ1[b], &h->y1[b], ACT_ELU, s); }
         const View& in = (b == 0) ? frame_view(h->feat[4], 3, h->tgt) : h->y2[b - 1];
         conv_wgrad(h, h->dc1[b], in, h->dZ1[b], PAD_REFLECT);
         View dip = make_view(h->dxpad, N, in.H + 2, in.W + 2, in.C);
@@ -968,13 +973,14 @@ int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, fl
     if (h->cfg.automasking && !auto_loss) { h->err = "md2_train_loss: automasking is on but auto_loss is NULL"; return 2; }
     if (h->testmode) { h->err = "md2_train_loss: the handle is in test mode (md2_set_testmode(h, 0) = Flux.trainmode! first)"; return 2; }
     h->have_fwd = false; h->prep_done = false;
+    h->acc_zeroed = true;                   // model_forward zeroes every accumulator of this step at once (consumed by loss_train below)
     if (h->two_streams && h->s2) {          // ordered after everything already on the caller's stream (the previous ADAM step reads G and writes P)
         (void)hipEventRecord(h->ev_p0, h->stream); (void)hipStreamWaitEvent(h->s2, h->ev_p0, 0);
         refresh_wino_fwd(h, h->s2); (void)hipEventRecord(h->ev_uf, h->s2);
-        if (int r = backward_prepare(h, h->s2)) return r;
+        if (int r = backward_prepare(h, h->s2)) { h->acc_zeroed = false; return r; }
         (void)hipEventRecord(h->ev_p1, h->s2); h->prep_done = true;
     }
-    if (int r = model_forward(h, x, 3, -1, true, true, h->prep_done)) return r;
+    if (int r = model_forward(h, x, 3, -1, true, true, h->prep_done)) { h->acc_zeroed = false; return r; }
     const float* disp[MD2_MAX_SCALES] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p, h->dispv[4].p};
     if (int r = loss_train(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;          // the loss pullback comes out of the same pass: md2_backward starts at the network
     h->x_last = x; h->auto_last = auto_loss; h->have_fwd = true;

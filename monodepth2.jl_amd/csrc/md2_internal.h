@@ -199,6 +199,8 @@ void launch_bn_bwd_finalize(const double* acc, int slots, int C, double count, f
 void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s);
 // dx = adjoint(up2)(dy) * act_deriv(xact)
 void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int act, hipStream_t s);
+// fold_reflect + upsample2x_bwd in one gather pass: dx = adjoint(up2)(fold(src_padded)) * act_deriv(xact)     (fine map at least 4 x 4, ratio <= 2)
+void launch_fold_up2_bwd(const View& src_pad, const View& dx, const View* xact, int act, hipStream_t s);
 // reflect-pad adjoint: dst = ((accumulate ? dst : 0) + fold(src_padded)) * act_deriv(actsrc)
 void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, const View* actsrc, int act, hipStream_t s);
 // dst = (accumulate ? dst : 0) + a*src (optionally * act_deriv(actsrc))
