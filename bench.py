@@ -21,13 +21,14 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (--precision bf16 prices against this one)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+PROFILE_ROUND = "r04"          # profiles/<round>_*.json: the rocprofv3 PMC summaries of THIS round's kernels (tools/make_profiles.sh + tools/summarize_profiles.sh)
 VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s (a wave64 VALU instruction takes 2 cycles of its SIMD)
-# HBM bytes per launch come from the rocprofv3 PMC passes of THIS command (profiles/r03_pmc_hbm_traffic.json, written by tools/profile_summary.py from separate
+# HBM bytes per launch come from the rocprofv3 PMC passes of THIS command (profiles/<round>_pmc_hbm_traffic.json, written by tools/profile_summary.py from separate
 # --pmc FETCH_SIZE / WRITE_SIZE runs: KiB units, FETCH_SIZE x2 because gfx950 tallies 64 B per 128-B request, WRITE_SIZE exact).  PMC counters cannot be read
 # from inside bench.py, so the tracked measurement is reported when its workload equals the one being run, null otherwise.
 def pmc_traffic(B, C, H, W, depth, precision):
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_hbm_traffic.json")))
     except Exception:
         return {}
     w = d.get("workload", {})
@@ -60,7 +61,7 @@ def bf16_conv_roofline(md, torch, model, step):
         return None
     traffic_step = None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_cfg5_bf16_pmc_hbm_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_cfg5_bf16_pmc_hbm_traffic.json")))
         if d.get("workload") == {"batch": 8, "channels": 3, "height": 320, "width": 1024, "depth": 18, "precision": "bf16"}:
             traffic_step = d["bytes_per_step"]["conv_igemm"]
     except Exception:
@@ -69,16 +70,16 @@ def bf16_conv_roofline(md, torch, model, step):
     return {"kernel": "forward + input-gradient convolutions of the bf16 mixed-precision mode (v_mfma_f32_32x32x16_bf16 operands, fp32 storage)", "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / MFMA_BF16_PEAK_TFLOPS else "mfma",
             "mfma": {"achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS},
             "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": by / 3, "traffic": traffic_step,
-                    "traffic_unit": "HBM bytes per step of this class (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of tools/prof_config.py 8 18 3 320 1024 bf16, profiles/r03_cfg5_bf16_pmc_hbm_traffic.md)"},
+                    "traffic_unit": "HBM bytes per step of this class (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of tools/prof_config.py 8 18 3 320 1024 bf16, profiles/" + PROFILE_ROUND + "_cfg5_bf16_pmc_hbm_traffic.md)"},
             "ms_per_step": ig["ms"] / 3, "launches_per_step": ig["launches"] / 3,
             "note": "activations stay fp32 in HBM: the class reads and writes twice the bytes a bf16-storage mode would; that mode is not built (DESIGN.md section 7)"}
 
 
 def valu_insts(kernel, B, C, H, W):
-    """SQ_INSTS_VALU per launch of a loss kernel from the committed PMC summary (profiles/r03_loss_pmc.json: {"workload": {...}, "loss_train": n, ...}); None when
-    the workload differs from the one measured."""
+    """SQ_INSTS_VALU per launch of a kernel / kernel class from the committed PMC summary (profiles/<round>_loss_pmc.json: {"workload": {...}, "loss_train": n, "conv_wgrad": n, ...});
+    None when the workload differs from the one measured."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_loss_pmc.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_loss_pmc.json")))
     except Exception:
         return None
     w = d.get("workload", {})
@@ -192,8 +193,7 @@ def main():
         enc = md.ResidualNetwork(depth, in_channels=C)
         model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), lr=1e-4, precision=precision)
         model.load_params(syn.init_params(C, seed=42, depth=depth))                         # same weights on every rank
-        base = syn.synthetic_triplets(min(batch, 8), C, H, W, seed=42 + rank)
-        x = torch.from_numpy(np.concatenate([base] * ((batch + len(base) - 1) // len(base)))[:batch].copy()).cuda()
+        x = torch.from_numpy(syn.synthetic_triplets(batch, C, H, W, seed=42 + rank)).cuda()          # `batch` distinct triplets per rank
         return model, params, cache, x
 
     model, params, cache, x = setup(B)
@@ -279,12 +279,15 @@ def main():
     out = {"metric": "self-sup training imgs/sec, 416x128 ResNet-18 (1 img = 1 triplet: 3 frames through the encoder)", "value": value, "unit": "triplets/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-           "dtype_note": ("fp32 storage, accumulation, forward and input-gradient MFMAs (v_mfma_f32_32x32x2_f32); the weight-gradient products run as three bf16 MFMAs on hi + lo bf16 pieces of the fp32 operands "
-                          "(fp32 accumulation; the 2^-16 product rounding ends in dw and propagates nowhere -- every gradient array stays inside the parity bounds of tests/)") if args.precision == "f32" else "bf16 MFMA operands, fp32 accumulation / storage / master weights",
+           "dtype_note": ("fp32 storage and fp32 accumulation everywhere; every convolution product carries all 24 mantissa bits of both fp32 operands -- per launch either the fp32 MFMA "
+                          "(v_mfma_f32_32x32x2_f32) or its exact decomposition (each operand = hi + mid + lo bf16 pieces, six v_mfma_f32_32x32x16_bf16 with fp32 accumulation), whichever is faster "
+                          "at the launch's shape (md2_set_conv_products(1, 1), the library default); no operand is rounded to fewer bits than the reference's Float32 anywhere. "
+                          "extra.headline_shape_fp32_mfma_only is the same step with v_mfma_f32_32x32x2_f32 in every convolution") if args.precision == "f32" else "bf16 MFMA operands, fp32 accumulation / storage / master weights",
            "data": "synthetic",
            "config": {"workload": "ResNet-%d depth+pose, %dx%d, C=%d, batch=%d triplets/GPU, %s fwd+loss+bwd+ADAM (BASELINE.json configs[2] per-GPU shape; configs[1] batch=4, configs[3] ResNet-50 640x192 batch=16 and configs[4] 1024x320 bf16 automask under extra)" % (
                           args.depth, W, H, C, B, "fp32" if args.precision == "f32" else "bf16 MFMA operands / fp32 accumulate"),
-                      "global_batch": world * B, "parallelism": "dp%d" % world, "gradient_exchange": comm_note, "rccl_ranks": rccl_ranks, "loss": final_loss}}
+                      "global_batch": world * B, "parallelism": "dp%d" % world, "gradient_exchange": comm_note, "rccl_ranks": rccl_ranks, "loss": final_loss,
+                      "conv_products": "md2_set_conv_products%s: 1 = per launch the faster of fp32 MFMA and the exact three-bf16-piece split (both full fp32 operand accuracy)" % (md.get_conv_products(),)}}
 
     # ---- roofline of the dominant kernel class, measured live with HIP events on the launch stream (3 profiled steps)
     # The timed region above overlaps the weight-gradient kernels with the rest of the backward pass on a second stream; overlapped
@@ -305,21 +308,31 @@ def main():
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         ach_x = ig["flops_executed"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_wino*_kernel (fused Winograd F(2x2,3x3): the 3x3 stride-1 layers) + conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions, fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_wino3s_kernel<.,.,3> / conv_wino3_kernel (fused Winograd F(2x2,3x3): the 3x3 stride-1 layers; products as the exact three-bf16-piece split from 96 input channels up, fp32 MFMA below) + conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions; fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32 outside the split launches)",
                            "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
                            "algorithmic": "achieved / frac count the direct-convolution FLOPs of the layers (SURVEY.md section 8d: 2 M Cout taps Cin), whatever algorithm ran",
                            "executed_achieved": ach_x, "executed_frac": ach_x / peak_tf,
                            "executed": "FLOPs the matrix cores really issued: Winograd launches multiply 16 instead of 36 times per 2x2 output tile -- this is the MFMA pipe utilisation",
                            "traffic": traffic.get("conv_igemm"),
-                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, profiles/r03_pmc_hbm_traffic.md)",
+                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, profiles/" + PROFILE_ROUND + "_pmc_hbm_traffic.md)",
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1),
                            "timing": "HIP events per launch on the launch stream, 3 steps with the second (weight-gradient) stream disabled; `value` is measured with it enabled"}
         extra = {"frames_per_s": 3.0 * value}         # one triplet = 3 frames through the encoder
         if wg["ms"] > 0:
             a = wg["flops"] / (wg["ms"] * 1e-3) / 1e12
             ax = wg["flops_executed"] / (wg["ms"] * 1e-3) / 1e12
-            extra["roofline_conv_wgrad"] = {"bound": "mfma", "kernel": "conv_wino_wgrad_s_kernel (Winograd domain: the 3x3 stride-1 layers) + conv_wgrad_kernel<*, SPL> (both multiply hi + lo bf16 pieces of their fp32 operands on the bf16 matrix pipe, three v_mfma_f32_32x32x16_bf16 per product group, fp32 accumulation: the fractions below are fp32-EQUIVALENT rates against the fp32 MFMA peak) + conv3x3_wgrad_*_kernel + stem_wgrad_kernel (fp32 MFMA)",
-                                            "achieved": a, "peak": peak_tf, "unit": "TFLOP/s", "frac": a / peak_tf, "executed_achieved": ax, "executed_frac": ax / peak_tf, "ms_per_step": wg["ms"] / 3}
+            ent = {"kernel": "conv_wino_wgrad_kernel / conv_wino_wgrad_s_kernel<., 3> (Winograd domain: the 3x3 stride-1 layers) + conv_wgrad_kernel<*, 3> (1x1 / stride-2 layers, exact three-piece split) + conv3x3_wgrad_*_kernel + stem_wgrad_kernel (fp32 MFMA); every product at full fp32 operand accuracy",
+                   "fp32_equivalent": {"achieved": a, "peak": peak_tf, "unit": "TFLOP/s", "frac": a / peak_tf, "executed_achieved": ax, "executed_frac": ax / peak_tf,
+                                       "note": "algorithmic (direct-convolution) and executed (Winograd 16/36) FLOP rates against the fp32 MFMA peak -- a rate, not a utilisation: the split launches run on the bf16 pipe"},
+                   "ms_per_step": wg["ms"] / 3, "launches_per_step": wg["launches"] / 3}
+            vi = valu_insts("conv_wgrad", B, C, H, W)
+            if vi:          # the class is bound by vector / scalar instruction issue (operand splits, transforms, address arithmetic), not by either matrix pipe: report that roofline
+                rate = vi * 64.0 * (wg["launches"] / 3) / (wg["ms"] / 3 * 1e-3) / 1e12
+                ent.update({"bound": "valu", "achieved": rate, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": rate / VALU_PEAK_TLANE,
+                            "valu_wave_instructions_per_launch": vi, "counter": "SQ_INSTS_VALU, class average per launch at this workload (rocprofv3 --pmc, profiles/" + PROFILE_ROUND + "_loss_train_pmc.md)"})
+            else:
+                ent.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": None})
+            extra["roofline_conv_wgrad"] = ent
         # the training step runs the loss as ONE class: smoothness sums + the fused value-and-pullback kernel ("loss_train"); "loss_fwd" only exists in forward-only calls
         for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_train", lb)):
             if p["ms"] > 0:
@@ -388,37 +401,27 @@ def main():
                 md.train_step(m7, x7, None, c7, p7, True)
             torch.cuda.synchronize(); d7 = time.perf_counter() - t0
             extra["headline_shape_bf16_mixed"] = {"value": B * n7 / d7, "unit": "triplets/s", "ms_per_step": d7 / n7 * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate"}
-            # and with the forward / input-gradient 3x3 convolutions in "split" mode (md.set_winograd(4)): every fp32 operand as hi + lo bf16 pieces, three bf16 MFMAs per product
-            # group -- fp32 storage and accumulation, ~17-bit operand mantissas: forward + loss stay within the 1e-4 parity bound (tests), gradients are ~5x noisier than with
-            # the fp32 MFMA.  Opt-in; `value` above is measured with the fp32 MFMA.
+            # the same step under the other md2_set_conv_products modes.  Full accuracy: fp32 MFMA in every convolution (0, 0) and the exact three-piece split wherever it exists
+            # (3, 3) -- `value` is their per-launch mix (1, 1).  Reduced precision, opt-in, never part of `value`: two bf16 pieces per operand (~16-bit mantissas) in the weight
+            # gradients only (1, 2) -- round 3's default -- and in every Winograd product (2, 2).
             del m7, x7
             torch.cuda.empty_cache()
-            md.set_winograd(4)
+            dflt = md.get_conv_products()
             m8, p8, c8, x8 = setup(B)
-            for _ in range(3):
-                md.train_step(m8, x8, None, c8, p8, True)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
             n8 = 10
-            for _ in range(n8):
-                md.train_step(m8, x8, None, c8, p8, True)
-            torch.cuda.synchronize(); d8 = time.perf_counter() - t0
-            extra["headline_shape_split_bf16x3"] = {"value": B * n8 / d8, "unit": "triplets/s", "ms_per_step": d8 / n8 * 1e3,
-                                                    "dtype": "fp32 storage / accumulation; 3x3 stride-1 forward + input-gradient products as 3 bf16 MFMAs on hi/lo operand pieces (opt-in)"}
-            # the exact variant (md.set_winograd(5)): three pieces per operand, six bf16 MFMAs per product group -- every bit of the fp32 operands, results as close to the oracle
-            # as the fp32 MFMA's (tests/test_gpu_layers.py runs the Winograd cases in this mode too)
-            del m8, x8
-            torch.cuda.empty_cache()
-            md.set_winograd(5)
-            m9, p9, c9, x9 = setup(B)
-            for _ in range(3):
-                md.train_step(m9, x9, None, c9, p9, True)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(n8):
-                md.train_step(m9, x9, None, c9, p9, True)
-            torch.cuda.synchronize(); d9 = time.perf_counter() - t0
-            md.set_winograd(True)
-            extra["headline_shape_split_bf16x6_exact"] = {"value": B * n8 / d9, "unit": "triplets/s", "ms_per_step": d9 / n8 * 1e3,
-                                                          "dtype": "fp32 storage / accumulation; forward + input-gradient Winograd products as 6 bf16 MFMAs on hi/mid/lo operand pieces: fp32 accuracy (opt-in)"}
+            for key, mode, note in (("headline_shape_fp32_mfma_only", (0, 0), "v_mfma_f32_32x32x2_f32 in every convolution (full accuracy)"),
+                                    ("headline_shape_exact_split_everywhere", (3, 3), "exact three-bf16-piece products (six bf16 MFMAs, fp32 accumulation) in every Winograd / per-tap weight-gradient launch (full accuracy)"),
+                                    ("headline_shape_reduced_two_piece_wgrad", (1, 2), "REDUCED precision (opt-in): two bf16 pieces per operand in the weight gradients only"),
+                                    ("headline_shape_reduced_two_piece_all", (2, 2), "REDUCED precision (opt-in): two bf16 pieces per operand in every Winograd and weight-gradient product")):
+                md.set_conv_products(*mode)
+                for _ in range(3):
+                    md.train_step(m8, x8, None, c8, p8, True)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(n8):
+                    md.train_step(m8, x8, None, c8, p8, True)
+                torch.cuda.synchronize(); d8 = time.perf_counter() - t0
+                extra[key] = {"value": B * n8 / d8, "unit": "triplets/s", "ms_per_step": d8 / n8 * 1e3, "conv_products": list(mode), "dtype": note}
+            md.set_conv_products(*dflt)
         out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W)

@@ -141,6 +141,10 @@ int32_t md2_comm_unique_id(void* out_128_bytes);
 int32_t md2_comm_init(md2_handle* h, int32_t rank, int32_t world, const void* unique_id_128_bytes);
 int32_t md2_comm_destroy(md2_handle* h);
 int32_t md2_comm_world(md2_handle* h, int32_t* rank, int32_t* world);
+/* The up-to-four [lo, hi) slices (float offsets into the flat gradient buffer of md2_grad_buffer, in the order md2_backward completes and all-reduces them: decoders |
+ * encoder layer 4 | layers 2-3 | stem + layer 1) for a configuration.  Host-only: needs neither a device nor a handle, so the exact tiling of [0, *count) can be
+ * asserted on any machine (tests/test_host_and_abi.py does, for both encoders and every scale_levels subset). */
+int32_t md2_comm_bucket_plan(const md2_config* cfg, int64_t* lo4, int64_t* hi4, int64_t* count);
 int32_t md2_allreduce_grads(md2_handle* h);                 /* sum over ranks of the gradient buffer; no-op when md2_backward already reduced it */
 int32_t md2_comm_allreduce(md2_handle* h, float* dev_buf, int64_t n);   /* in-place sum of any device buffer (loss logging, self-checks) */
 int32_t md2_broadcast_state(md2_handle* h, int32_t root);   /* parameters, ADAM moments + beta powers, BatchNorm running statistics of `root` to every rank */

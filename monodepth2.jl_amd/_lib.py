@@ -105,6 +105,7 @@ _SIGS = {
     "md2_comm_init": (I32, [P, I32, I32, P]),
     "md2_comm_destroy": (I32, [P]),
     "md2_comm_world": (I32, [P, C.POINTER(I32), C.POINTER(I32)]),
+    "md2_comm_bucket_plan": (I32, [C.POINTER(Md2Config), C.POINTER(I64), C.POINTER(I64), C.POINTER(I64)]),
     "md2_allreduce_grads": (I32, [P]),
     "md2_comm_allreduce": (I32, [P, P, I64]),
     "md2_broadcast_state": (I32, [P, I32]),

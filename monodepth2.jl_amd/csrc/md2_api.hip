@@ -74,7 +74,7 @@ struct md2_handle {
     View gA[5], dZ1[5], dupv[5]; float* dxpad = nullptr; float* ddisp_lo[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float *E1 = nullptr, *E2 = nullptr, *E3 = nullptr;
     View dpy3, dpy2, dpy1, dsq;
-    long* wdesc_dev = nullptr; int n_wdesc = 0;
+    long* wdesc_dev = nullptr; int n_wdesc = 0, n_wblocks = 0;
     // Winograd operands U = G g G^T of every 3x3 / stride-1 layer, refreshed once per step from P (forward) and WD (input gradient)
     float *UF = nullptr, *UD = nullptr; long n_uf = 0, n_ud = 0; long *udesc_f = nullptr, *udesc_d = nullptr; int n_udf = 0, n_udd = 0, ublk_f = 0, ublk_d = 0; hipEvent_t ev_uf = nullptr;
     int u_pieces_f = 0, u_pieces_d = 0;      // layout UF / UD were last written in (g_wino_pieces at that refresh): every launch that reads them is told through ConvArgs::wino_pieces,
@@ -558,12 +558,26 @@ static void pose_backward(md2_handle* h, int N, int part) {
 // weight copies for the input-gradient GEMMs (one launch for all layers).  None of it depends on the forward pass, so md2_train_loss
 // runs it on the (otherwise idle) second stream while the forward pass computes; without that stream it runs at the head of backward.
 static int backward_prepare(md2_handle* h, hipStream_t s) {
-    HIPCHK(hipMemsetAsync(h->G, 0, (size_t)h->n_int * sizeof(float), s));
+    launch_weight_prepare(h->P, h->WD, h->wdesc_dev, h->n_wdesc, h->n_wblocks, h->G, h->n_int, s);          // transposed / flipped weight copies + the zeroed gradient buffer, one launch
     if (!h->acc_zeroed) HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
-    launch_weight_to_dgrad_batched(h->P, h->WD, h->wdesc_dev, h->n_wdesc, s);
     h->u_pieces_d = g_wino_pieces;
     launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions
     KCHK(); return 0;
+}
+// The flat gradient buffer is produced back to front; its four all-reduce buckets in the order they complete: [0] depth decoder + heads + pose decoder, [1] encoder layer 4,
+// [2] encoder layers 2-3, [3] stem + encoder layer 1.  They must tile [0, n_int) exactly once for every encoder / scale_levels choice (tests/test_host_and_abi.py checks
+// md2_comm_bucket_plan on the host for both trunks and every level subset); an empty bucket (ResNet layouts where two boundaries coincide) is skipped by comm_bucket.
+struct BucketPlan { long lo[4], hi[4]; int first_l4, first_l2; };
+static BucketPlan bucket_plan(const md2_handle* h) {
+    int stage_first[4] = {0, 0, 0, 0};                                 // first block of encoder layers 1..4
+    for (int i = 0, l = 0; i < h->nblk && l < 4; ++i) if (i == 0 || h->blk[i - 1].stage_end) stage_first[l++] = i;
+    BucketPlan p;
+    p.first_l4 = stage_first[3]; p.first_l2 = stage_first[1];
+    p.lo[0] = h->dc1[0].w;                    p.hi[0] = h->n_int;
+    p.lo[1] = h->blk[stage_first[3]].c1.w;    p.hi[1] = h->dc1[0].w;
+    p.lo[2] = h->blk[stage_first[1]].c1.w;    p.hi[2] = h->blk[stage_first[3]].c1.w;
+    p.lo[3] = 0;                              p.hi[3] = h->blk[stage_first[1]].c1.w;
+    return p;
 }
 static int model_backward(md2_handle* h) {
     hipStream_t s = h->stream;
@@ -574,8 +588,7 @@ static int model_backward(md2_handle* h) {
     // all-reduce by md2_allreduce_grads after the pullback
     static const bool buckets_on = !(getenv("MD2_COMM_BUCKETS") && atoi(getenv("MD2_COMM_BUCKETS")) == 0);
     h->grads_reduced = false; h->n_bucket_done = (h->comm && buckets_on) ? 0 : -1;
-    int stage_first[4] = {0, 0, 0, 0};                                 // first block of encoder layers 1..4
-    for (int i = 0, l = 0; i < h->nblk && l < 4; ++i) if (i == 0 || h->blk[i - 1].stage_end) stage_first[l++] = i;
+    const BucketPlan bp = bucket_plan(h);
     // The gradient accumulators (Gfeat / Gblk / Gpool, 715 MB at B=32) are NOT zeroed: every buffer's first writer overwrites
     // (accumulate 0) and later writers add.  Stage buffers receive decoder / pose contributions in the target frame before the
     // encoder pullback reaches them, so the encoder's first writer uses accumulate mode 2 (add only in target frames).
@@ -619,7 +632,7 @@ static int model_backward(md2_handle* h) {
         h->cur = h->s3; pose_backward(h, N, 1); (void)hipEventRecord(h->ev_c, h->s3); h->cur = nullptr;
         (void)hipStreamWaitEvent(h->stream, h->ev_c, 0);
     } else { pose_backward(h, N, 0); pose_backward(h, N, 1); }
-    if (int r = comm_bucket(h, h->dc1[0].w, h->n_int)) return r;           // depth decoder, heads, pose decoder
+    if (int r = comm_bucket(h, bp.lo[0], bp.hi[0])) return r;           // depth decoder, heads, pose decoder
     // ---- encoder
     // BatchNorm pullbacks need sum g and sum g*xhat over the whole batch before the first dz can be formed.  Where the kernels allow it these sums are accumulated by
     // the epilogue of the input-gradient launch that PRODUCES g (its last writer), so the separate reduction pass over (g, z) disappears; `sums_ready[i]` says whether
@@ -701,8 +714,8 @@ static int model_backward(md2_handle* h) {
         }
         if (B.down && !Bp) conv_dgrad(h, B.cd, B.dzd, *Gin, 0, 1, in_act, ACT_RELU);
         }
-        if (i == stage_first[3]) { if (int r = comm_bucket(h, h->blk[i].c1.w, h->dc1[0].w)) return r; }                                  // encoder layer 4
-        else if (i == stage_first[1] && stage_first[1] != stage_first[3]) { if (int r = comm_bucket(h, h->blk[i].c1.w, h->blk[stage_first[3]].c1.w)) return r; }   // layers 2-3
+        if (i == bp.first_l4) { if (int r = comm_bucket(h, bp.lo[1], bp.hi[1])) return r; }                                  // encoder layer 4
+        else if (i == bp.first_l2 && bp.first_l2 != bp.first_l4) { if (int r = comm_bucket(h, bp.lo[2], bp.hi[2])) return r; }   // layers 2-3
     }
     {   // stem tail pullback: the max-pool pullback also reduces the stem BatchNorm's sums, and the stem's weight gradient forms dz = A g + B z + C0 in its loader:
         // no reduction pass, no dz tensor (Gfeat[0]: decoder skip gradient in the target frames only; ReLU mask from the pooled output)
@@ -720,7 +733,7 @@ static int model_backward(md2_handle* h) {
         if (h->prof) { h->prof_flops[CLS_WGRAD] += fl; h->prof_exec[CLS_WGRAD] += fl; }
     }
     if (h->n_bucket_done >= 0) {            // last bucket (layer 1 + stem), then the caller's stream waits for the communication stream
-        if (int r = comm_bucket(h, 0, h->blk[stage_first[1]].c1.w)) return r;
+        if (int r = comm_bucket(h, bp.lo[3], bp.hi[3])) return r;
         (void)hipEventRecord(h->ev_cdone, h->scomm); (void)hipStreamWaitEvent(h->stream, h->ev_cdone, 0);
         h->grads_reduced = true;
     }
@@ -787,14 +800,14 @@ const char* md2_last_error(md2_handle* h) { return h ? h->err.c_str() : g_create
 
 static void destroy_handle(md2_handle* h);
 
-int32_t md2_create(const md2_config* cfg, md2_handle** out) {
-    if (!cfg || !out) { g_create_err = "null argument"; return 2; }
+// argument checks of md2_create: pure host work, before anything touches the device (also the front end of md2_comm_bucket_plan)
+static int validate_cfg(const md2_config* cfg) {
+    if (!cfg) { g_create_err = "null argument"; return 2; }
     // The network needs height/width multiples of 32 and >= 64 (five stride-2 stages, then reflect padding at 1/32 scale).  Smaller images
     // (multiples of 8, >= 16) give a LOSS-ONLY handle: md2_loss_fwd_bwd / md2_simple_depth_loss / md2_automasking_loss work, the model entry points fail.
     if (cfg->batch < 1 || (cfg->channels != 1 && cfg->channels != 3) || cfg->height % 8 || cfg->width % 8 || cfg->height < 16 || cfg->width < 16) {
         g_create_err = "md2_create: need batch >= 1, channels in {1,3}, height/width multiples of 8 and >= 16 (multiples of 32 and >= 64 for the network)"; return 2;
     }
-    const bool net_ok = cfg->height % 32 == 0 && cfg->width % 32 == 0 && cfg->height >= 64 && cfg->width >= 64;
     if (cfg->encoder_depth != 0 && cfg->encoder_depth != 18 && cfg->encoder_depth != 50) { g_create_err = "md2_create: encoder_depth must be 18 (or 0) or 50"; return 2; }
     if (cfg->precision != 0 && cfg->precision != 1) { g_create_err = "md2_create: precision must be 0 (fp32) or 1 (bf16 mixed precision)"; return 2; }
     {   // shape limits of the kernels (32-bit byte offsets inside one activation tensor, 24-bit pixel counts in the weight gradients): refuse here, with a
@@ -818,29 +831,19 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
         // level's smoothness term off like in the reference (src/training.jl:67) -- and a negative entry asks for that level's default
         for (int i = 0; i < 5; ++i) if (cfg->scales[i] != cfg->scales[i]) { g_create_err = "md2_create: `scales` must not be NaN (negative = the default 1 / 2^(5 - level))"; return 2; }
     }
+    return 0;
+}
+static void apply_cfg(md2_handle* h, const md2_config* cfg);
+int32_t md2_create(const md2_config* cfg, md2_handle** out) {
+    if (!out) { g_create_err = "null argument"; return 2; }
+    if (int r = validate_cfg(cfg)) return r;
+    const bool net_ok = cfg->height % 32 == 0 && cfg->width % 32 == 0 && cfg->height >= 64 && cfg->width >= 64;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "md2_create: no HIP device (libmd2hip needs an MI355X; there is no CPU fallback)"; return 3; }
     if (hipSetDevice(cfg->device) != hipSuccess) { g_create_err = "md2_create: hipSetDevice failed"; return 3; }
     if (const char* e = getenv("MD2_DETERMINISTIC")) g_deterministic = atoi(e) != 0;
     md2_handle* h = new md2_handle();
-    h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width; h->net_ok = net_ok;
-    h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision == 1;
-    {   // TrainCache.target_id / source_ids (1-based at the boundary; validated above)
-        const int t = cfg->target_id ? cfg->target_id : 2, s0 = cfg->source_ids[0] ? cfg->source_ids[0] : (cfg->source_ids[1] ? 0 : 1), s1 = cfg->source_ids[1] ? cfg->source_ids[1] : (cfg->source_ids[0] ? 0 : 3);
-        h->tgt = t - 1; h->src[0] = s0 - 1; h->src[1] = s1 - 1;
-        // DepthDecoder scale_levels / TrainCache.scales (all zero: 2:5 and 1 / 2^(5 - level), src/Monodepth.jl:106-107)
-        if (cfg->scale_levels[0]) {
-            h->ns = 0; for (int b = 0; b < 5; ++b) h->out_of[b] = -1;
-            for (int i = 0; i < 5 && cfg->scale_levels[i]; ++i) {
-                const int l = cfg->scale_levels[i];
-                h->lv[i] = l; h->out_of[l - 1] = i; h->ns = i + 1;
-            }
-            h->nbr = h->lv[h->ns - 1];
-        }
-        bool scales_given = false; for (int i = 0; i < 5; ++i) scales_given |= cfg->scales[i] != 0.0;
-        for (int i = 0; i < h->ns; ++i) h->scl[i] = (scales_given && cfg->scales[i] >= 0.0) ? cfg->scales[i] : 1.0 / (double)(1 << (5 - h->lv[i]));
-        for (int k = 0; k < 2; ++k) { const bool before = h->src[k] < h->tgt; h->pose_fr[2 * k] = before ? h->src[k] : h->tgt; h->pose_fr[2 * k + 1] = before ? h->tgt : h->src[k]; }
-    }
+    apply_cfg(h, cfg); h->net_ok = net_ok;
     for (int i = 0; i < 64; ++i) h->ev_pool[i] = nullptr;
     for (int i = 0; i < 8; ++i) { h->ev_cm[i] = nullptr; h->ev_cs[i] = nullptr; }
     build_layers(h);
@@ -862,8 +865,9 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     }
     {   // layer table of the batched weight transform
         std::vector<long> d;
-        for (ConvL* c : h->convs) if (c->kind == 0) { d.push_back(c->w); d.push_back(c->coutP); d.push_back(c->cinP); d.push_back(c->taps); }
-        h->n_wdesc = (int)d.size() / 4;
+        long first = 0;
+        for (ConvL* c : h->convs) if (c->kind == 0) { d.push_back(c->w); d.push_back(c->coutP); d.push_back(c->cinP); d.push_back(c->taps); d.push_back(first); first += weight_prepare_blocks(c->coutP, c->cinP, c->taps); }
+        h->n_wdesc = (int)d.size() / 5; h->n_wblocks = (int)first;
         if (hipMalloc((void**)&h->wdesc_dev, d.size() * sizeof(long)) != hipSuccess) return fail("hipMalloc(wdesc) failed");
         (void)hipMemcpy(h->wdesc_dev, d.data(), d.size() * sizeof(long), hipMemcpyHostToDevice);
     }
@@ -899,6 +903,27 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     h->n_wg_streams = getenv("MD2_WG_STREAMS") ? atoi(getenv("MD2_WG_STREAMS")) : 1;
     *out = h;
     return 0;
+}
+// the handle's host-side description of a configuration (no device work): sizes, frame roles, scale levels -- what build_layers needs
+static void apply_cfg(md2_handle* h, const md2_config* cfg) {
+    h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width;
+    h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision == 1;
+    {   // TrainCache.target_id / source_ids (1-based at the boundary; validated above)
+        const int t = cfg->target_id ? cfg->target_id : 2, s0 = cfg->source_ids[0] ? cfg->source_ids[0] : (cfg->source_ids[1] ? 0 : 1), s1 = cfg->source_ids[1] ? cfg->source_ids[1] : (cfg->source_ids[0] ? 0 : 3);
+        h->tgt = t - 1; h->src[0] = s0 - 1; h->src[1] = s1 - 1;
+        // DepthDecoder scale_levels / TrainCache.scales (all zero: 2:5 and 1 / 2^(5 - level), src/Monodepth.jl:106-107)
+        if (cfg->scale_levels[0]) {
+            h->ns = 0; for (int b = 0; b < 5; ++b) h->out_of[b] = -1;
+            for (int i = 0; i < 5 && cfg->scale_levels[i]; ++i) {
+                const int l = cfg->scale_levels[i];
+                h->lv[i] = l; h->out_of[l - 1] = i; h->ns = i + 1;
+            }
+            h->nbr = h->lv[h->ns - 1];
+        }
+        bool scales_given = false; for (int i = 0; i < 5; ++i) scales_given |= cfg->scales[i] != 0.0;
+        for (int i = 0; i < h->ns; ++i) h->scl[i] = (scales_given && cfg->scales[i] >= 0.0) ? cfg->scales[i] : 1.0 / (double)(1 << (5 - h->lv[i]));
+        for (int k = 0; k < 2; ++k) { const bool before = h->src[k] < h->tgt; h->pose_fr[2 * k] = before ? h->src[k] : h->tgt; h->pose_fr[2 * k + 1] = before ? h->tgt : h->src[k]; }
+    }
 }
 static void comm_destroy(md2_handle* h);
 static void destroy_handle(md2_handle* h) {          // also the failure path of md2_create: every member is null until it was created
@@ -1403,6 +1428,20 @@ int32_t md2_comm_init(md2_handle* h, int32_t rank, int32_t world, const void* un
     return 0;
 }
 int32_t md2_comm_destroy(md2_handle* h) { HIPCHK(hipStreamSynchronize(h->stream)); if (h->scomm) HIPCHK(hipStreamSynchronize(h->scomm)); comm_destroy(h); return 0; }
+// the four [lo, hi) slices of the flat gradient buffer md2_backward all-reduces, in completion order, for a configuration -- host-only (no device, no handle), so that the
+// tiling of [0, count) can be checked anywhere
+int32_t md2_comm_bucket_plan(const md2_config* cfg, int64_t* lo4, int64_t* hi4, int64_t* count) {
+    if (!lo4 || !hi4 || !count) { g_create_err = "null argument"; return 2; }
+    if (int r = validate_cfg(cfg)) return r;
+    md2_handle* h = new md2_handle();
+    apply_cfg(h, cfg);
+    build_layers(h);
+    const BucketPlan p = bucket_plan(h);
+    for (int i = 0; i < 4; ++i) { lo4[i] = p.lo[i]; hi4[i] = p.hi[i]; }
+    *count = h->n_int;
+    delete h;
+    return 0;
+}
 int32_t md2_comm_world(md2_handle* h, int32_t* rank, int32_t* world) { if (rank) *rank = h->rank; if (world) *world = h->world; return 0; }
 // gradient(theta) summed over the ranks.  md2_backward already did it bucket by bucket (overlapped with the pullback) when a communicator is attached; this is then a no-op.
 int32_t md2_allreduce_grads(md2_handle* h) {

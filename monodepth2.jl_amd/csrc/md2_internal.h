@@ -157,7 +157,9 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s);
 //   fwd    : [CoutP][KH*KW][CinP] cross-correlation taps                       (internal parameter storage)
 //   dgrad  : [CinP][KH*KW flipped][CoutP]                                       (per-step transposed copy)
 void launch_weight_to_dgrad(const float* w_fwd, float* w_dg, int CoutP, int CinP, int taps, hipStream_t s);
-void launch_weight_to_dgrad_batched(const float* w_fwd, float* w_dg, const long* desc_dev, int nlayers, hipStream_t s);
+// every layer's transposed copy in one LDS-tiled launch that also zeroes `zero[0 .. nzero)` (the flat gradient buffer); desc5 = {offset, CoutP, CinP, taps, first block} per layer
+long weight_prepare_blocks(int CoutP, int CinP, int taps);
+void launch_weight_prepare(const float* w_fwd, float* w_dg, const long* desc5_dev, int nlayers, int nblocks_w, float* zero, long nzero, hipStream_t s);
 
 // ---- 3x3 reflect-pad conv with ONE output channel (disparity heads, src/depth_decoder.jl:43) ------
 void launch_head_fwd(const View& x, const float* w /*[9][Cin]*/, const float* b, const View& y /*C=1, sigmoid*/, hipStream_t s);

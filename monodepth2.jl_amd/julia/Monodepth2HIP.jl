@@ -248,6 +248,13 @@ function comm_unique_id(); id = Vector{UInt8}(undef, 128); GC.@preserve id (rc =
 comm_init!(h, rank, world, id::Vector{UInt8}) = GC.@preserve id check(h, md2_comm_init(h.ptr, Int32(rank), Int32(world), hptr(id)), "comm_init")
 comm_destroy!(h) = check(h, md2_comm_destroy(h.ptr), "comm_destroy")
 function comm_world(h); r = Ref(Int32(0)); w = Ref(Int32(1)); GC.@preserve r w md2_comm_world(h.ptr, Base.unsafe_convert(Ptr{Int32}, r), Base.unsafe_convert(Ptr{Int32}, w)); Int(r[]), Int(w[]); end
+# the [lo, hi) slices (0-based float offsets) of the flat gradient buffer md2_backward all-reduces, in completion order; host-only
+function comm_bucket_plan(; batch, channels, width, height, encoder_depth=18, scale_levels=collect(2:5))
+    cfg = Ref(MD2Config(batch, channels, height, width, false, 0, 0.1, 100.0, 1e-3, 1e-4, encoder_depth, 0, 2, 1, 3, pad5(scale_levels, Int32), pad5(Float64[], Float64)))
+    lo = zeros(Int64, 4); hi = zeros(Int64, 4); n = Ref(Int64(0))
+    GC.@preserve lo hi n (rc = md2_comm_bucket_plan(cfg, pointer(lo), pointer(hi), Base.unsafe_convert(Ptr{Int64}, n)); rc == 0 || error("md2_comm_bucket_plan failed ($rc)"))
+    [(lo[i], hi[i]) for i in 1:4 if hi[i] > lo[i]], n[]
+end
 allreduce_grads!(h) = check(h, md2_allreduce_grads(h.ptr), "allreduce_grads")
 comm_allreduce!(h, x::ROCArray{Float32}) = (check(h, md2_comm_allreduce(h.ptr, dptr(x), length(x)), "comm_allreduce"); x)
 broadcast_state!(h, root=0) = check(h, md2_broadcast_state(h.ptr, Int32(root)), "broadcast_state")

@@ -113,6 +113,19 @@ class DataParallel:
         md.update(md.ADAM(self.model.lr), self.model, grad_scale=1.0 / world_size(self.group))
 
 
+def bucket_plan(batch, channels, height, width, depth=18, scale_levels=(2, 3, 4, 5)):
+    """The [lo, hi) slices of the flat gradient buffer that md2_backward all-reduces (in completion order: decoders | encoder layer 4 | layers 2-3 | stem + layer 1) and the
+    buffer's length -- md2_comm_bucket_plan, host-only (no GPU needed)."""
+    import ctypes as C
+    from . import _lib
+    cfg = _lib.Md2Config(batch, channels, height, width, 0, 0, 0.1, 100.0, 1e-3, 1e-4, depth, 0, 2, (C.c_int32 * 2)(1, 3), (C.c_int32 * 5)(*scale_levels), (C.c_double * 5)())
+    lo = (C.c_int64 * 4)(); hi = (C.c_int64 * 4)(); n = C.c_int64(0)
+    rc = _lib.lib().md2_comm_bucket_plan(C.byref(cfg), lo, hi, C.byref(n))
+    if rc:
+        raise RuntimeError("md2_comm_bucket_plan failed (%d): %s" % (rc, _lib.lib().md2_last_error(None).decode()))
+    return [(int(lo[i]), int(hi[i])) for i in range(4) if hi[i] > lo[i]], int(n.value)
+
+
 def verify_rccl(dp, x_common, cache, parameters, g_local, tol=2e-4):
     """Hardware check of the library communicator at world > 1, run before anything is timed: every rank steps on the SAME batch with identical weights, so the bucketed,
     overlapped all-reduce inside md2_backward must return world x the local gradient `g_local` (taken before the communicator was attached) on every rank.

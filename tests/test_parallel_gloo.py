@@ -57,6 +57,61 @@ def test_allreduce_mean_of_shard_gradients(tmp_path):
     assert np.linalg.norm(l0 - l1) > 0                           # the shards really differ
 
 
+# ---- the library's gradient buckets (md2_backward all-reduces them as they complete): a pure host statement about their ranges, then the bucketed exchange on two CPU ranks
+def _all_level_sets():
+    import itertools
+    return [c for k in range(1, 6) for c in itertools.combinations(range(1, 6), k)]
+
+
+def test_gradient_buckets_tile_the_flat_buffer_exactly():
+    """md2_comm_bucket_plan (host-only): for ResNet-18 and -50, C = 1 and 3 and every ascending scale_levels subset of 1:5 the up-to-four [lo, hi) slices are disjoint,
+    ordered back to front (the order the pullback completes them) and cover [0, n) with no gap -- a gap would leave a slice of the gradient un-reduced, an overlap would
+    sum it twice."""
+    par = md2amd.parallel
+    seen = set()
+    for depth in (18, 50):
+        for C in (1, 3):
+            for levels in _all_level_sets():
+                buckets, n = par.bucket_plan(2, C, 64, 96, depth, levels)
+                assert 2 <= len(buckets) <= 4 and n > 0
+                assert all(hi > lo for lo, hi in buckets)
+                assert buckets[0][1] == n and buckets[-1][0] == 0                      # the last-produced bucket starts the buffer, the first-produced one ends it
+                for (lo_a, _), (_, hi_b) in zip(buckets[:-1], buckets[1:]):
+                    assert hi_b == lo_a                                                # each bucket ends exactly where the one completed before it begins
+                assert sum(hi - lo for lo, hi in buckets) == n
+                seen.add((depth, C, levels, n))
+    assert len({n for _, _, _, n in seen}) > 20                                        # the level subsets really change the decoder (and with it the boundaries)
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root]
+    import md2amd as m
+    par = m.parallel
+    par.init_from_env("gloo")
+    res = []
+    for depth, levels in ((18, (2, 3, 4, 5)), (50, (1, 3, 4))):
+        buckets, n = par.bucket_plan(2, 1, 64, 96, depth, levels)
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(n, generator=g)
+        whole = local.clone(); par.allreduce_sum_(whole)                               # the unbucketed exchange (md2_allreduce_grads)
+        bucketed = local.clone()
+        for lo, hi in buckets:                                                         # the bucketed one, slice by slice in completion order (what md2_backward issues)
+            par.allreduce_sum_(bucketed[lo:hi])
+        res.append(bool(torch.equal(whole, bucketed)) and not torch.equal(whole, local))
+    np.save(os.path.join(out_dir, "ok%d.npy" % rank), np.array(res))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_whole_buffer_allreduce_on_two_cpu_ranks(tmp_path):
+    world = 2; port = _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(tmp_path / ("ok%d.npy" % r)).all()
+
+
 # ---- the same exchange on the HIP gradient buffer: two ranks sharing the one card of a GPU box (RCCL refuses two ranks on one device, so the transport is gloo) ----
 def _gpu_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
