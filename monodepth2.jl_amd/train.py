@@ -51,6 +51,9 @@ def train(datasets, log_dir, save_dir, batch_size=4, n_epochs=20, log_iter=50, s
             x = x_host.cuda(non_blocking=True)
             if world > 1 and dp is None:                      # first batch: the handle exists now -> attach the communicator, make the replicas identical
                 dp = par.DataParallel(model, x_like=x, parameters=parameters, cache=cache)
+                if rank == 0 and not quiet:                   # which gradient exchange this run uses (the library's own RCCL communicator is opt-in until a multi-GPU run has verified it)
+                    print("data parallel over %d ranks: gradient exchange = %s" % (world, "libmd2hip RCCL communicator (bucketed, overlapped with the pullback)" if dp.comm == "rccl"
+                                                                                   else "torch.distributed all-reduce of the library's flat gradient buffer"), flush=True)
             auto_loss = None
             if parameters.automasking:                      # computed outside AD (src/Monodepth.jl:159-164)
                 auto_loss = md.automasking_loss(cache.ssim, x, x[:, cache.target_id - 1].contiguous(), cache.source_ids)

@@ -105,9 +105,45 @@ def valu(d, steps, out_json, B, C, H, W):
     json.dump(out, open(out_json, "w"), indent=1)
 
 
+def mfma(dm, dl, dv):
+    """Matrix-pipe / LDS / instruction counters per kernel (three --pmc passes of the same command): how busy the matrix pipe is, whether MFMAs co-execute with vector
+    instructions, vector and scalar instructions per MFMA, LDS bank-conflict ratio."""
+    def load(d):
+        f = glob.glob(d + "/*counter_collection.csv")[0]
+        per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            a = per[name][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+        return per
+    pm, pl, pv = load(dm), load(dl), load(dv)
+    print("# Matrix-pipe, LDS and instruction counters per kernel, batch 32 (round 4): rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra")
+    print("# groups (one pass each): SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE | SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS | SQ_INSTS_VALU ...")
+    print("# per launch averages; matrix busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); SQ_INSTS_VALU counts the MFMAs too (subtracted in the ratio)")
+    print()
+    print("| kernel | launches | shader cycles | MFMAs | matrix pipe busy | co-executing with VALU | VALU per MFMA | SALU per MFMA | LDS conflict / active |")
+    print("|---|---|---|---|---|---|---|---|---|")
+    rows = []
+    for name, c in pm.items():
+        n = c["SQ_INSTS_MFMA"][0]
+        mf = c["SQ_INSTS_MFMA"][1] / max(n, 1)
+        if mf <= 0:
+            continue
+        cyc = c["GRBM_GUI_ACTIVE"][1] / max(c["GRBM_GUI_ACTIVE"][0], 1) / 8.0
+        busy = c["SQ_VALU_MFMA_BUSY_CYCLES"][1] / max(n, 1)
+        co = c["SQ_VALU_MFMA_COEXEC_CYCLES"][1] / max(n, 1)
+        va = pv.get(name, {}).get("SQ_INSTS_VALU", [0, 0.0]); sa = pl.get(name, {}).get("SQ_INSTS_SALU", [0, 0.0])
+        bc = pl.get(name, {}).get("SQ_LDS_BANK_CONFLICT", [0, 0.0]); ia = pl.get(name, {}).get("SQ_LDS_IDX_ACTIVE", [0, 0.0])
+        rows.append((busy * n, "| `%s` | %d | %.4g | %.4g | %.3f | %.3f | %.1f | %.1f | %.2f |" % (
+            name[:70], n, cyc, mf, busy / (1024.0 * cyc), co / max(busy, 1), (va[1] / max(va[0], 1) - mf) / mf, sa[1] / max(sa[0], 1) / mf, bc[1] / max(ia[1], 1))))
+    for _, line in sorted(rows, reverse=True):
+        print(line)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "valu":
         valu(sys.argv[2], int(sys.argv[3]), sys.argv[4], *[int(v) for v in sys.argv[5:9]])
     else:
