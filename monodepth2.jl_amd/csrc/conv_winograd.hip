@@ -26,6 +26,7 @@
 #include "md2_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace md2 {
 
@@ -941,9 +942,12 @@ static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int WG_TB = 16, WG_WP = 2 * WG_TB + 2, WG_XSLOTS = 160;          // tiles per batch, patch row stride (slots), slots allocated (>= 4 * WG_WP = 136: every loader item has a real slot)
 constexpr int WG_XF = WG_XSLOTS * 32, WG_DYF = WG_TB * 4 * 64, WG_STAGE = WG_XF + WG_DYF;      // floats per stage: x [slot][32 ci] | dy [tile][4 px][64 co]
-struct WinoWgGeo { int TH, TW, BPR, nb, bpb, nco, nci; };              // BPR batches per tile row, nb batches in all, bpb batches per block
+// BPR batches per tile row, nb batches in all, bpb batches per block.  Tile rows of at most 8 tiles (the 1/32-scale maps: 7 tiles at 416 wide) would fill a 16-tile batch
+// -- the MFMA's K -- to less than half: there a batch holds RB consecutive tile rows (flattened over (n, ty)) as RB row segments of WPS = 2 TW + 2 patch columns each
+// (RB = 1, WPS = WG_WP: one segment, the layout of the wide maps); nrows = N * TH.
+struct WinoWgGeo { int TH, TW, BPR, nb, bpb, nco, nci, RB, WPS, nrows; };
 
-template <int XF>
+template <int XF, int MR>          // MR = 1: batches of several short tile rows (WinoWgGeo::RB > 1); MR = 0 folds RB = 1 / WPS = WG_WP at compile time: the single-segment code of the wide maps
 __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, WinoWgGeo geo) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
@@ -956,9 +960,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
     // ---- loader items (fixed per thread; the pixel they address changes with the batch)
     //   x : item f = tid + 256 li (li < 5) = (slot f >> 3 = row pa * 34 + column pc, 16-B piece f & 7 of the 32 channels)
     //   dy: item f = tid + 256 li (li < 4) = (pixel slot f >> 4 = tile * 4 + (oa * 2 + ob), 16-B piece f & 15 of the 64 channels)
-    int x_pa[5], x_pc[5];
+    const int RB = MR ? geo.RB : 1, WPS = MR ? geo.WPS : WG_WP;          // row segments per batch, patch columns (slots) per segment row
+    int x_pa[5], x_pc[5], x_sg[5];
 #pragma unroll
-    for (int li = 0; li < 5; ++li) { const int slot = (tid + 256 * li) >> 3; x_pa[li] = slot / WG_WP; x_pc[li] = slot - x_pa[li] * WG_WP; }
+    for (int li = 0; li < 5; ++li) { const int slot = (tid + 256 * li) >> 3; x_sg[li] = slot / (4 * WPS); const int r = slot - x_sg[li] * 4 * WPS; x_pa[li] = r / WPS; x_pc[li] = r - x_pa[li] * WPS; }
+    // dy items: tile t of the batch = segment t / TW (several tile rows per batch), tile column t % TW
+    int d_sg[4], d_tx[4];
+#pragma unroll
+    for (int li = 0; li < 4; ++li) { const int t = (tid + 256 * li) >> 6; d_sg[li] = RB > 1 ? t / TW : 0; d_tx[li] = t - d_sg[li] * TW; }
     const int xq = tid & 7, dq = tid & 15;
     float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + ci0 + xq * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + ci0 + xq * 4); }
@@ -966,13 +975,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
     const char* xb = reinterpret_cast<const char*>(a.x);
     const char* db_ = reinterpret_cast<const char*>(a.dy);
     auto gload = [&](int b) {              // batch b -> registers (+ validity bits); b is block-uniform
-        const int rr = b / geo.BPR, bq = b - rr * geo.BPR;
-        const int n = rr / TH, ty = rr - n * TH, tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
+        const int rr0 = RB > 1 ? b * RB : b / geo.BPR, bq = RB > 1 ? 0 : b - rr0 * geo.BPR;
+        const int tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
         okx = 0; okd = 0;
+        const int n_u = rr0 / TH, ty_u = rr0 - n_u * TH;          // single-segment batches: the image and tile row are block-uniform (scalar arithmetic)
 #pragma unroll
         for (int li = 0; li < 5; ++li) {
+            int n = n_u, ty = ty_u; bool ok = x_sg[li] == 0;
+            if (RB > 1) { const int rr = rr0 + x_sg[li], rrc = min(rr, geo.nrows - 1); n = fdiv24(rrc, TH); ty = rrc - n * TH; ok = x_sg[li] < RB && rr < geo.nrows; }
             int ih = 2 * ty - a.pad + x_pa[li], iw = 2 * tx0 - a.pad + x_pc[li];
-            bool ok = x_pa[li] < 4 && x_pc[li] < 2 * L + 2;
+            ok = ok && x_pa[li] < 4 && x_pc[li] < 2 * L + 2;
             if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
             else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
             const unsigned off = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(ci0 + xq * 4)) * 4u : (unsigned)(xq * 16);
@@ -981,8 +993,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
         }
 #pragma unroll
         for (int li = 0; li < 4; ++li) {
-            const int ps = (tid + 256 * li) >> 4, t = ps >> 2, oy = 2 * ty + ((ps >> 1) & 1), ox = 2 * (tx0 + t) + (ps & 1);
-            const bool ok = t < L && oy < a.Ho && ox < a.Wo;
+            const int ps = (tid + 256 * li) >> 4;
+            int n = n_u, ty = ty_u; bool ok = true;
+            if (RB > 1) { const int rr = rr0 + d_sg[li], rrc = min(rr, geo.nrows - 1); n = fdiv24(rrc, TH); ty = rrc - n * TH; ok = d_sg[li] < RB && rr < geo.nrows; }
+            const int oy = 2 * ty + ((ps >> 1) & 1), ox = 2 * (tx0 + d_tx[li]) + (ps & 1);
+            ok = ok && d_tx[li] < L && oy < a.Ho && ox < a.Wo;
             const unsigned off = ok ? ((unsigned)((long)n * a.dy_bs) + (unsigned)((oy * a.Wo + ox) * a.dy_ps) + (unsigned)(co0 + dq * 4)) * 4u : (unsigned)(dq * 16);
             rd[li] = *reinterpret_cast<const uint4*>(db_ + off);
             okd |= ok ? (1u << li) : 0u;
@@ -1016,7 +1031,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
     const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
     const float sg = (wi == 1) ? 1.f : -1.f;
     const int lr = lane & 31, lh = lane >> 5;
-    const int xo1 = (r1 * WG_WP + 2 * lh) * 32 + lr, xo2 = (r2 * WG_WP + 2 * lh) * 32 + lr;          // + k-step * 4 slots (two tiles) + column b
+    const int xo1 = r1 * WPS * 32 + lr, xo2 = r2 * WPS * 32 + lr;          // + the tile's slot offset (segment * 4 WPS + 2 tile column) * 32 + column b * 32
     const int dyo = WG_XF + (lh * 4) * 64 + 2 * lr;                                                  // + k-step * 8 pixel rows + px * 64
 
     f32x16 acc[4][2];
@@ -1037,9 +1052,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
             const int bn = min(b + 1, b_hi - 1);
             gload(bn);
             __builtin_amdgcn_sched_barrier(0);
-            const int bq = b % geo.BPR, L = min(WG_TB, TW - bq * WG_TB), nk = (L + 1) >> 1;
+            const int bq = RB > 1 ? 0 : b % geo.BPR, L = min(WG_TB, TW - bq * WG_TB);
+            const int ntile = RB > 1 ? min(RB, geo.nrows - b * RB) * TW : L, nk = (ntile + 1) >> 1;
             auto kstep = [&](const int k) {
-                const float* xs = wsm + so + k * (4 * 32);
+                const int t = 2 * k + lh, seg = RB > 1 ? (t >= TW ? fdiv24(t, TW) : 0) : 0;          // this lane's tile of the k-step (tiles past the batch were committed as zeros)
+                const float* xs = wsm + so + (seg * 4 * WPS + 2 * (t - seg * TW)) * 32;
                 const float* ds = wsm + so + dyo + k * (8 * 64);
                 const float2 y00 = *reinterpret_cast<const float2*>(ds), y01 = *reinterpret_cast<const float2*>(ds + 64), y10 = *reinterpret_cast<const float2*>(ds + 128), y11 = *reinterpret_cast<const float2*>(ds + 192);
                 float xv1[4], xv2[4];
@@ -1113,7 +1130,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
 constexpr int WS_DYF = WG_TB * 4 * 32, WS_STAGE = WG_XF + WS_DYF;
 // NP = pieces per operand: 3 = hi + mid + lo, six MFMAs per product (lh, hl, mm, mh, hm, hh: the dropped terms are below 2^-24 of the product) -- every bit of both fp32
 // operands enters, i.e. the accuracy of the fp32 MFMA kernel above; 2 = hi + lo, three MFMAs (~16-bit operand mantissas: reduced precision, opt-in)
-template <int XF, int NP>
+template <int XF, int NP, int MR>
 __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, WinoWgGeo geo) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
@@ -1124,9 +1141,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
     const int TW = geo.TW, TH = geo.TH;
 
     // ---- loader items: x as in conv_wino_wgrad_kernel (5 per thread); dy: item f = tid + 256 li (li < 2) = (pixel slot f >> 3 = tile * 4 + (oa * 2 + ob), 16-B piece f & 7 of 32 channels)
-    int x_pa[5], x_pc[5];
+    const int RB = MR ? geo.RB : 1, WPS = MR ? geo.WPS : WG_WP;          // row segments per batch, patch columns (slots) per segment row (WinoWgGeo; MR as in conv_wino_wgrad_kernel)
+    int x_pa[5], x_pc[5], x_sg[5];
 #pragma unroll
-    for (int li = 0; li < 5; ++li) { const int slot = (tid + 256 * li) >> 3; x_pa[li] = slot / WG_WP; x_pc[li] = slot - x_pa[li] * WG_WP; }
+    for (int li = 0; li < 5; ++li) { const int slot = (tid + 256 * li) >> 3; x_sg[li] = slot / (4 * WPS); const int r = slot - x_sg[li] * 4 * WPS; x_pa[li] = r / WPS; x_pc[li] = r - x_pa[li] * WPS; }
+    int d_sg[2], d_tx[2];
+#pragma unroll
+    for (int li = 0; li < 2; ++li) { const int t = (tid + 256 * li) >> 5; d_sg[li] = RB > 1 ? t / TW : 0; d_tx[li] = t - d_sg[li] * TW; }
     const int xq = tid & 7;
     float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + ci0 + xq * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + ci0 + xq * 4); }
@@ -1134,13 +1155,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
     const char* xb = reinterpret_cast<const char*>(a.x);
     const char* db_ = reinterpret_cast<const char*>(a.dy);
     auto gload = [&](int b) {
-        const int rr = b / geo.BPR, bq = b - rr * geo.BPR;
-        const int n = rr / TH, ty = rr - n * TH, tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
+        const int rr0 = RB > 1 ? b * RB : b / geo.BPR, bq = RB > 1 ? 0 : b - rr0 * geo.BPR;
+        const int tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
         okx = 0; okd = 0;
+        const int n_u = rr0 / TH, ty_u = rr0 - n_u * TH;
 #pragma unroll
         for (int li = 0; li < 5; ++li) {
+            int n = n_u, ty = ty_u; bool ok = x_sg[li] == 0;
+            if (RB > 1) { const int rr = rr0 + x_sg[li], rrc = min(rr, geo.nrows - 1); n = fdiv24(rrc, TH); ty = rrc - n * TH; ok = x_sg[li] < RB && rr < geo.nrows; }
             int ih = 2 * ty - a.pad + x_pa[li], iw = 2 * tx0 - a.pad + x_pc[li];
-            bool ok = x_pa[li] < 4 && x_pc[li] < 2 * L + 2;
+            ok = ok && x_pa[li] < 4 && x_pc[li] < 2 * L + 2;
             if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
             else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
             const unsigned off = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(ci0 + xq * 4)) * 4u : (unsigned)(xq * 16);
@@ -1149,8 +1173,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
         }
 #pragma unroll
         for (int li = 0; li < 2; ++li) {
-            const int ps = (tid + 256 * li) >> 3, t = ps >> 2, oy = 2 * ty + ((ps >> 1) & 1), ox = 2 * (tx0 + t) + (ps & 1);
-            const bool ok = t < L && oy < a.Ho && ox < a.Wo;
+            const int ps = (tid + 256 * li) >> 3;
+            int n = n_u, ty = ty_u; bool ok = true;
+            if (RB > 1) { const int rr = rr0 + d_sg[li], rrc = min(rr, geo.nrows - 1); n = fdiv24(rrc, TH); ty = rrc - n * TH; ok = d_sg[li] < RB && rr < geo.nrows; }
+            const int oy = 2 * ty + ((ps >> 1) & 1), ox = 2 * (tx0 + d_tx[li]) + (ps & 1);
+            ok = ok && d_tx[li] < L && oy < a.Ho && ox < a.Wo;
             const unsigned off = ok ? ((unsigned)((long)n * a.dy_bs) + (unsigned)((oy * a.Wo + ox) * a.dy_ps) + (unsigned)(co0 + xq * 4)) * 4u : (unsigned)(xq * 16);
             rd[li] = *reinterpret_cast<const uint4*>(db_ + off);
             okd |= ok ? (1u << li) : 0u;
@@ -1184,7 +1211,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
     const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
     const float sg = (wi == 1) ? 1.f : -1.f;
     const int lr = lane & 31, g8 = (lane >> 5) * 8;
-    const int xo1 = (r1 * WG_WP + 2 * g8) * 32 + lr, xo2 = (r2 * WG_WP + 2 * g8) * 32 + lr;          // + tile t * 2 slots + column b
+    const int xo1 = r1 * WPS * 32 + lr, xo2 = r2 * WPS * 32 + lr;          // + the tile's slot offset xoff(t) + column b * 32
+    // slot offset (in floats) of tile t = g8 + i of the batch: segment t / TW, tile column t % TW (one segment: 2 t slots)
+    auto xoff = [&](const int i) { const int t = g8 + i, seg = (RB > 1 && t >= TW) ? fdiv24(t, TW) : 0; return (seg * 4 * WPS + 2 * (t - seg * TW)) * 32; };
     const int dyo = WG_XF + (g8 * 4) * 32 + lr;                                                      // + tile t * 4 pixel rows + px * 32
     typedef wbf16x8 b8_t;
     auto cat8 = [](const unsigned (&v)[4]) { return __builtin_bit_cast(b8_t, (wu32x4){v[0], v[1], v[2], v[3]}); };
@@ -1236,7 +1265,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
                     float R[2][4], Pv[2][2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const float* xs = wsm + so + (2 * tp + u) * (2 * 32);
+                        const float* xs = wsm + so + xoff(2 * tp + u);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) R[u][c] = fmaf(sg, xs[xo2 + c * 32], xs[xo1 + c * 32]);
                         const float* ds = wsm + so + dyo + (2 * tp + u) * (4 * 32);
@@ -1255,6 +1284,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
                 // three pieces: the dy columns first (24 registers of pieces), then one patch column at a time (12), each followed by the products it takes part in -- all six
                 // columns' pieces at once (72 registers beside 96 accumulators) spilt
                 unsigned pp[2][NP][4];
+                int xoffs[8];
+#pragma unroll
+                for (int i8 = 0; i8 < 8; ++i8) xoffs[i8] = xoff(i8);
 #pragma unroll
                 for (int tp = 0; tp < 4; ++tp) {
                     float Pv[2][2];
@@ -1273,8 +1305,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
                     unsigned rc[NP][4];
 #pragma unroll
                     for (int tp = 0; tp < 4; ++tp) {
-                        const float* x0 = wsm + so + (2 * tp) * (2 * 32) + c * 32;
-                        const float R0 = fmaf(sg, x0[xo2], x0[xo1]), R1 = fmaf(sg, x0[xo2 + 64], x0[xo1 + 64]);
+                        const float* x0 = wsm + so + xoffs[2 * tp] + c * 32;
+                        const float* x1 = wsm + so + xoffs[2 * tp + 1] + c * 32;
+                        const float R0 = fmaf(sg, x0[xo2], x0[xo1]), R1 = fmaf(sg, x1[xo2], x1[xo1]);
                         split3_pk(R0, R1, rc[0][tp], rc[1][tp], rc[2][tp]);
                     }
                     if (c == 0) prod(P[0], pp[0], rc);                                          // P00
@@ -1334,9 +1367,24 @@ bool conv_wino_wgrad_eligible(const WgradArgs& a) {
     if (a.x_ps % 4 != 0 || a.dy_ps % 4 != 0 || x_bytes >= (1L << 32) || dy_bytes >= (1L << 32)) return false;
     return g_wino_on == 2 || g_wino_on == 3 || a.M >= min_m;
 }
+// opt a kernel into more than 64 KB of dynamic LDS, once per kernel
+static void wino_allow_lds(const void* kern, size_t bytes) {
+    static std::vector<const void*> done;
+    for (const void* k : done) if (k == kern) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done.push_back(kern);
+}
 void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     WinoWgGeo g;
-    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.BPR = (g.TW + WG_TB - 1) / WG_TB; g.nb = a.N * g.TH * g.BPR;
+    g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.BPR = (g.TW + WG_TB - 1) / WG_TB; g.nrows = a.N * g.TH;
+    g.RB = 1; g.WPS = WG_WP;
+    static const bool no_rows = getenv("MD2_WINO_WGRAD_NO_ROWPACK") != nullptr;
+    if (!no_rows && 2 * g.TW <= WG_TB && g.nrows > 1) {          // short tile rows: several per batch (as many as fill the 16 tiles and the 160 staged patch slots)
+        g.WPS = 2 * g.TW + 2;
+        g.RB = std::min(std::min(WG_TB / g.TW, WG_XSLOTS / (4 * g.WPS)), g.nrows);
+        if (g.RB < 2) { g.RB = 1; g.WPS = WG_WP; }
+    }
+    g.nb = g.RB > 1 ? (g.nrows + g.RB - 1) / g.RB : a.N * g.TH * g.BPR;
     g.nco = a.Cout / 64; g.nci = a.Cin / 32;
     static const int want = getenv("MD2_WINO_WGRAD_BLOCKS") ? atoi(getenv("MD2_WINO_WGRAD_BLOCKS")) : 512;
     int ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));
@@ -1350,35 +1398,28 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
         if (g_deterministic) ksn = 1;
         g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
         constexpr size_t lds_s = std::max((size_t)2 * WS_STAGE * sizeof(float), (size_t)12 * 32 * 33 * sizeof(float));
-        static bool attr_s = false;
-        if (!attr_s) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_s_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            attr_s = true;
-        }
         const int grid_s = g.nco * g.nci * ksn;
+        auto go = [&](auto kern) {
+            wino_allow_lds(reinterpret_cast<const void*>(kern), lds_s);
+            hipLaunchKernelGGL(kern, dim3(grid_s), dim3(256), lds_s, s, a, g);
+        };
+        const int xf = a.in_scale ? 1 : 0, mr = g.RB > 1 ? 1 : 0;
         if (pieces == 3) {
-            if (a.in_scale) hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<1, 3>), dim3(grid_s), dim3(256), lds_s, s, a, g);
-            else hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<0, 3>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+            if (xf && mr) go(conv_wino_wgrad_s_kernel<1, 3, 1>); else if (xf) go(conv_wino_wgrad_s_kernel<1, 3, 0>); else if (mr) go(conv_wino_wgrad_s_kernel<0, 3, 1>); else go(conv_wino_wgrad_s_kernel<0, 3, 0>);
         } else {
-            if (a.in_scale) hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<1, 2>), dim3(grid_s), dim3(256), lds_s, s, a, g);
-            else hipLaunchKernelGGL((conv_wino_wgrad_s_kernel<0, 2>), dim3(grid_s), dim3(256), lds_s, s, a, g);
+            if (xf && mr) go(conv_wino_wgrad_s_kernel<1, 2, 1>); else if (xf) go(conv_wino_wgrad_s_kernel<1, 2, 0>); else if (mr) go(conv_wino_wgrad_s_kernel<0, 2, 1>); else go(conv_wino_wgrad_s_kernel<0, 2, 0>);
         }
         return;
     }
     constexpr size_t lds_pipe = (size_t)2 * WG_STAGE * sizeof(float), lds_epi = (size_t)12 * 32 * 33 * sizeof(float);
     constexpr size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     const int grid = g.nco * g.nci * ksn;
-    if (a.in_scale) hipLaunchKernelGGL((conv_wino_wgrad_kernel<1>), dim3(grid), dim3(256), lds, s, a, g);
-    else hipLaunchKernelGGL((conv_wino_wgrad_kernel<0>), dim3(grid), dim3(256), lds, s, a, g);
+    auto go = [&](auto kern) {
+        wino_allow_lds(reinterpret_cast<const void*>(kern), lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, g);
+    };
+    const int xf = a.in_scale ? 1 : 0, mr = g.RB > 1 ? 1 : 0;
+    if (xf && mr) go(conv_wino_wgrad_kernel<1, 1>); else if (xf) go(conv_wino_wgrad_kernel<1, 0>); else if (mr) go(conv_wino_wgrad_kernel<0, 1>); else go(conv_wino_wgrad_kernel<0, 0>);
 }
 
 // load-time defaults (md2_set_winograd / md2_set_conv_products change them): MD2_WINO_MODE=2/3 pins one kernel, 4 / 5 = mode 1 with two / three bf16 pieces per operand;
