@@ -389,7 +389,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs a, int TH, i
 // 5.1 ms: nothing hides that wave's own LDS / transform latency).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int W2_T = 64;
-struct Wino2Geo { int TH, TW, Mt, ntp, nslots; };      // nslots: patch slots allocated per stage (host: worst case over the blocks), multiple of 16
+struct Wino2Geo { int TH, TW, Mt, ntp, nslots; unsigned xbytes; };      // nslots: patch slots allocated per stage (host: worst case over the blocks), multiple of 16; xbytes: byte span of the input view (buffer descriptor range)
+// Patch loads through a buffer descriptor (raw buffer, stride 0, num_records = the view's byte span): an out-of-range voffset returns zeros, so the loader's zero padding costs no
+// instruction -- inactive and padded items carry W_OOB as their offset instead of a mask that four ANDs per 16-byte item would apply at the commit (24 of the ~330 vector instructions
+// per chunk and thread of the split kernel; the channel-chunk offset travels in soffset, which is outside the range check).  Kernels whose loader transforms what it loads (XF:
+// relu(x * scale + shift) of a padding zero is not zero) keep the mask.
+constexpr unsigned W_OOB = 0xFFFFFFF0u;
+typedef unsigned wino_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 wino_buffer_load16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+    const wino_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
 
 template <int NTHR, int COB, int BST>
 __device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __restrict__ wsm, const int m0, const int ntile, const int Mt, const int THW, const int TW, const int c0, const int tid) {
@@ -519,14 +529,18 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvAr
         if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
         else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
         l_ok |= ok ? (1u << li) : 0u;
-        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(h2 * 4)) * 4u : (unsigned)(h2 * 16);
+        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(h2 * 4)) * 4u : (XF != 0 ? (unsigned)(h2 * 16) : W_OOB);
     }
     const char* xb = reinterpret_cast<const char*>(a.x);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
     uint4 ra[NLI];
     float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
     auto gload = [&](int c) {
 #pragma unroll
-        for (int li = 0; li < NLI; ++li) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 32)));
+        for (int li = 0; li < NLI; ++li) {
+            if constexpr (XF != 0) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 32)));
+            else ra[li] = wino_buffer_load16(xrs, l_off[li], c * 32);
+        }
         if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 8 + h2 * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 8 + h2 * 4); }
     };
     auto lstore = [&](int so) {
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvAr
                 v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
                 v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
             }
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            if constexpr (XF != 0) { v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk; }          // (XF == 0: out-of-range items came back as zeros from the buffer load)
             *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 1024) = v;
         }
     };
@@ -730,14 +744,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
         if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
         else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
         l_ok |= ok ? (1u << li) : 0u;
-        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(piece * 4)) * 4u : (unsigned)(piece * 16);
+        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(piece * 4)) * 4u : (XF != 0 ? (unsigned)(piece * 16) : W_OOB);
     }
     const char* xb = reinterpret_cast<const char*>(a.x);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
     uint4 ra[NLI];
     float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
     auto gload = [&](int c) {
 #pragma unroll
-        for (int li = 0; li < NLI; ++li) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 64)));
+        for (int li = 0; li < NLI; ++li) {
+            if constexpr (XF != 0) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 64)));
+            else ra[li] = wino_buffer_load16(xrs, l_off[li], c * 64);
+        }
         if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 16 + piece * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 16 + piece * 4); }
     };
     auto lstore = [&](int so) {
@@ -750,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
                 v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
                 v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
             }
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            if constexpr (XF != 0) { v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk; }
             *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 512) = v;
         }
     };
@@ -887,6 +905,7 @@ static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
     if (nh == 2 && !ok64) nh = 1;
     const int T = 32 * nh;
     g.ntp = (g.Mt + T - 1) / T; g.nslots = nh == 1 ? s32 : s64;
+    g.xbytes = (unsigned)std::min<long>(4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), (long)W_OOB - 16);          // (launch_conv_wino checks the span is below 2^32)
     // a launch below the threshold keeps the direct kernel and its split-K -- except short reductions (Cin <= 128), where a workgroup's life is mostly fixed cost either way and
     // 0.6 x the threshold already wins (batch 4, encoder layer 2: 156 workgroups, 0.051 -> 0.040 ms in the model)
     return g_wino_on == 3 || b64 >= g_wino_min_blocks || (a.Cin <= 128 && b64 * 5 >= (long)g_wino_min_blocks * 3);
@@ -945,7 +964,7 @@ constexpr int WG_XF = WG_XSLOTS * 32, WG_DYF = WG_TB * 4 * 64, WG_STAGE = WG_XF 
 // BPR batches per tile row, nb batches in all, bpb batches per block.  Tile rows of at most 8 tiles (the 1/32-scale maps: 7 tiles at 416 wide) would fill a 16-tile batch
 // -- the MFMA's K -- to less than half: there a batch holds RB consecutive tile rows (flattened over (n, ty)) as RB row segments of WPS = 2 TW + 2 patch columns each
 // (RB = 1, WPS = WG_WP: one segment, the layout of the wide maps); nrows = N * TH.
-struct WinoWgGeo { int TH, TW, BPR, nb, bpb, nco, nci, RB, WPS, nrows; };
+struct WinoWgGeo { int TH, TW, BPR, nb, bpb, nco, nci, RB, WPS, nrows; unsigned xbytes, dybytes; };          // (byte spans of the two views: buffer-descriptor ranges, see W_OOB)
 
 template <int XF, int MR>          // MR = 1: batches of several short tile rows (WinoWgGeo::RB > 1); MR = 0 folds RB = 1 / WPS = WG_WP at compile time: the single-segment code of the wide maps
 __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, WinoWgGeo geo) {
@@ -973,7 +992,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
     if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + ci0 + xq * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + ci0 + xq * 4); }
     uint4 rx[5], rd[4]; unsigned okx = 0, okd = 0;
     const char* xb = reinterpret_cast<const char*>(a.x);
-    const char* db_ = reinterpret_cast<const char*>(a.dy);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, geo.dybytes, 0x00020000);
     auto gload = [&](int b) {              // batch b -> registers (+ validity bits); b is block-uniform
         const int rr0 = RB > 1 ? b * RB : b / geo.BPR, bq = RB > 1 ? 0 : b - rr0 * geo.BPR;
         const int tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
@@ -987,8 +1007,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
             ok = ok && x_pa[li] < 4 && x_pc[li] < 2 * L + 2;
             if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
             else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            const unsigned off = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(ci0 + xq * 4)) * 4u : (unsigned)(xq * 16);
-            rx[li] = *reinterpret_cast<const uint4*>(xb + off);
+            const unsigned off = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(ci0 + xq * 4)) * 4u : (XF != 0 ? (unsigned)(xq * 16) : W_OOB);
+            if constexpr (XF != 0) rx[li] = *reinterpret_cast<const uint4*>(xb + off); else rx[li] = wino_buffer_load16(xrs, off, 0);
             okx |= ok ? (1u << li) : 0u;
         }
 #pragma unroll
@@ -998,8 +1018,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
             if (RB > 1) { const int rr = rr0 + d_sg[li], rrc = min(rr, geo.nrows - 1); n = fdiv24(rrc, TH); ty = rrc - n * TH; ok = d_sg[li] < RB && rr < geo.nrows; }
             const int oy = 2 * ty + ((ps >> 1) & 1), ox = 2 * (tx0 + d_tx[li]) + (ps & 1);
             ok = ok && d_tx[li] < L && oy < a.Ho && ox < a.Wo;
-            const unsigned off = ok ? ((unsigned)((long)n * a.dy_bs) + (unsigned)((oy * a.Wo + ox) * a.dy_ps) + (unsigned)(co0 + dq * 4)) * 4u : (unsigned)(dq * 16);
-            rd[li] = *reinterpret_cast<const uint4*>(db_ + off);
+            const unsigned off = ok ? ((unsigned)((long)n * a.dy_bs) + (unsigned)((oy * a.Wo + ox) * a.dy_ps) + (unsigned)(co0 + dq * 4)) * 4u : W_OOB;
+            rd[li] = wino_buffer_load16(drs, off, 0);
             okd |= ok ? (1u << li) : 0u;
         }
     };
@@ -1013,15 +1033,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
                 v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
                 v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
             }
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            if constexpr (XF != 0) { v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk; }          // (XF == 0: zeros from the range-checked buffer load)
             *reinterpret_cast<uint4*>(wsm + so + ((tid + 256 * li) >> 3) * 32 + xq * 4) = v;
         }
 #pragma unroll
         for (int li = 0; li < 4; ++li) {
-            const unsigned mk = 0u - ((okd >> li) & 1u);
             uint4 v = rd[li];
             asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
             *reinterpret_cast<uint4*>(wsm + so + WG_XF + ((tid + 256 * li) >> 4) * 64 + dq * 4) = v;
         }
     };
@@ -1153,7 +1171,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
     if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + ci0 + xq * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + ci0 + xq * 4); }
     uint4 rx[5], rd[2]; unsigned okx = 0, okd = 0;
     const char* xb = reinterpret_cast<const char*>(a.x);
-    const char* db_ = reinterpret_cast<const char*>(a.dy);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, geo.dybytes, 0x00020000);
     auto gload = [&](int b) {
         const int rr0 = RB > 1 ? b * RB : b / geo.BPR, bq = RB > 1 ? 0 : b - rr0 * geo.BPR;
         const int tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
@@ -1167,8 +1186,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
             ok = ok && x_pa[li] < 4 && x_pc[li] < 2 * L + 2;
             if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
             else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            const unsigned off = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(ci0 + xq * 4)) * 4u : (unsigned)(xq * 16);
-            rx[li] = *reinterpret_cast<const uint4*>(xb + off);
+            const unsigned off = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(ci0 + xq * 4)) * 4u : (XF != 0 ? (unsigned)(xq * 16) : W_OOB);
+            if constexpr (XF != 0) rx[li] = *reinterpret_cast<const uint4*>(xb + off); else rx[li] = wino_buffer_load16(xrs, off, 0);
             okx |= ok ? (1u << li) : 0u;
         }
 #pragma unroll
@@ -1178,8 +1197,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
             if (RB > 1) { const int rr = rr0 + d_sg[li], rrc = min(rr, geo.nrows - 1); n = fdiv24(rrc, TH); ty = rrc - n * TH; ok = d_sg[li] < RB && rr < geo.nrows; }
             const int oy = 2 * ty + ((ps >> 1) & 1), ox = 2 * (tx0 + d_tx[li]) + (ps & 1);
             ok = ok && d_tx[li] < L && oy < a.Ho && ox < a.Wo;
-            const unsigned off = ok ? ((unsigned)((long)n * a.dy_bs) + (unsigned)((oy * a.Wo + ox) * a.dy_ps) + (unsigned)(co0 + xq * 4)) * 4u : (unsigned)(xq * 16);
-            rd[li] = *reinterpret_cast<const uint4*>(db_ + off);
+            const unsigned off = ok ? ((unsigned)((long)n * a.dy_bs) + (unsigned)((oy * a.Wo + ox) * a.dy_ps) + (unsigned)(co0 + xq * 4)) * 4u : W_OOB;
+            rd[li] = wino_buffer_load16(drs, off, 0);
             okd |= ok ? (1u << li) : 0u;
         }
     };
@@ -1193,15 +1212,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
                 v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
                 v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
             }
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
+            if constexpr (XF != 0) { v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk; }          // (XF == 0: zeros from the range-checked buffer load)
             *reinterpret_cast<uint4*>(wsm + so + ((tid + 256 * li) >> 3) * 32 + xq * 4) = v;
         }
 #pragma unroll
         for (int li = 0; li < 2; ++li) {
-            const unsigned mk = 0u - ((okd >> li) & 1u);
             uint4 v = rd[li];
             asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-            v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk;
             *reinterpret_cast<uint4*>(wsm + so + WG_XF + ((tid + 256 * li) >> 3) * 32 + xq * 4) = v;
         }
     };
@@ -1378,6 +1395,8 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     WinoWgGeo g;
     g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.BPR = (g.TW + WG_TB - 1) / WG_TB; g.nrows = a.N * g.TH;
     g.RB = 1; g.WPS = WG_WP;
+    g.xbytes = (unsigned)std::min<long>(4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), (long)W_OOB - 16);          // (conv_wino_wgrad_eligible: both spans are below 2^32)
+    g.dybytes = (unsigned)std::min<long>(4 * ((long)a.N * a.dy_bs + (long)a.Ho * a.Wo * a.dy_ps), (long)W_OOB - 16);
     static const bool no_rows = getenv("MD2_WINO_WGRAD_NO_ROWPACK") != nullptr;
     if (!no_rows && 2 * g.TW <= WG_TB && g.nrows > 1) {          // short tile rows: several per batch (as many as fill the 16 tiles and the 160 staged patch slots)
         g.WPS = 2 * g.TW + 2;
