@@ -315,6 +315,8 @@ def main():
                            "executed": "FLOPs the matrix cores really issued: Winograd launches multiply 16 instead of 36 times per 2x2 output tile -- this is the MFMA pipe utilisation",
                            "traffic": traffic.get("conv_igemm"),
                            "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, profiles/" + PROFILE_ROUND + "_pmc_hbm_traffic.md)",
+                           "matrix_pipe": (lambda m: dict(m, counter="SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles) over the class's launches (fp32 and bf16 MFMAs alike; profiles/" + PROFILE_ROUND + "_mfma_pmc.md)") if m else None)(
+                               (lambda: (json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_mfma_pmc.json"))).get("conv_igemm") if os.path.exists(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_mfma_pmc.json")) else None))()),
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1),
                            "timing": "HIP events per launch on the launch stream, 3 steps with the second (weight-gradient) stream disabled; `value` is measured with it enabled"}
         extra = {"frames_per_s": 3.0 * value}         # one triplet = 3 frames through the encoder
@@ -325,13 +327,23 @@ def main():
                    "fp32_equivalent": {"achieved": a, "peak": peak_tf, "unit": "TFLOP/s", "frac": a / peak_tf, "executed_achieved": ax, "executed_frac": ax / peak_tf,
                                        "note": "algorithmic (direct-convolution) and executed (Winograd 16/36) FLOP rates against the fp32 MFMA peak -- a rate, not a utilisation: the split launches run on the bf16 pipe"},
                    "ms_per_step": wg["ms"] / 3, "launches_per_step": wg["launches"] / 3}
+            # The class is issue-bound: most of its time runs the fp32 MFMA kernels, whose matrix instructions and vector instructions (transforms, address arithmetic) share one
+            # issue stream (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for v_mfma_f32_32x32x2_f32 on gfx950), so the roof is matrix-pipe busy + vector issue, from the counters of this workload.
             vi = valu_insts("conv_wgrad", B, C, H, W)
-            if vi:          # the class is bound by vector / scalar instruction issue (operand splits, transforms, address arithmetic), not by either matrix pipe: report that roofline
+            mp = None
+            try:
+                mp = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_mfma_pmc.json"))).get("conv_wgrad")
+            except Exception:
+                pass
+            ent["bound"] = "issue (matrix pipe + vector instructions, serialised for the fp32 MFMA)"
+            if vi:
                 rate = vi * 64.0 * (wg["launches"] / 3) / (wg["ms"] / 3 * 1e-3) / 1e12
-                ent.update({"bound": "valu", "achieved": rate, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": rate / VALU_PEAK_TLANE,
-                            "valu_wave_instructions_per_launch": vi, "counter": "SQ_INSTS_VALU, class average per launch at this workload (rocprofv3 --pmc, profiles/" + PROFILE_ROUND + "_loss_train_pmc.md)"})
-            else:
-                ent.update({"bound": "valu", "achieved": None, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": None})
+                ent["valu"] = {"achieved": rate, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": rate / VALU_PEAK_TLANE, "valu_wave_instructions_per_launch": vi,
+                               "counter": "SQ_INSTS_VALU, class average per launch at this workload (rocprofv3 --pmc, profiles/" + PROFILE_ROUND + "_loss_train_pmc.md)"}
+            if mp:
+                ent["matrix_pipe"] = dict(mp, counter="SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles), class total at this workload (profiles/" + PROFILE_ROUND + "_mfma_pmc.md)")
+                ent["frac"] = mp["matrix_pipe_busy"] * (1.0 - mp["coexec_share"]) + (ent["valu"]["frac"] if vi else 0.0)
+                ent["frac_note"] = "share of SIMD issue time accounted for: matrix-pipe busy (not co-executing) + vector issue; the remainder is waits (LDS / global latency at 2 waves per SIMD, barriers) and launch tails"
             extra["roofline_conv_wgrad"] = ent
         # the training step runs the loss as ONE class: smoothness sums + the fused value-and-pullback kernel ("loss_train"); "loss_fwd" only exists in forward-only calls
         for nm, p in (("roofline_loss_fwd", lf), ("roofline_loss_train", lb)):

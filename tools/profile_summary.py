@@ -137,6 +137,24 @@ def mfma(dm, dl, dv):
             name[:70], n, cyc, mf, busy / (1024.0 * cyc), co / max(busy, 1), (va[1] / max(va[0], 1) - mf) / mf, sa[1] / max(sa[0], 1) / mf, bc[1] / max(ia[1], 1))))
     for _, line in sorted(rows, reverse=True):
         print(line)
+    # class totals (bench.py reads them): matrix-pipe busy fraction of the class's shader time, share of it co-executing with vector instructions, vector instructions per MFMA
+    import json
+    cls = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0.0, 0.0])          # busy, coexec, cycles, mfmas, valu
+    for name, c in pm.items():
+        k = klass(name)
+        n = max(c["SQ_INSTS_MFMA"][0], 1)
+        cls[k][0] += c["SQ_VALU_MFMA_BUSY_CYCLES"][1]; cls[k][1] += c["SQ_VALU_MFMA_COEXEC_CYCLES"][1]; cls[k][2] += c["GRBM_GUI_ACTIVE"][1] / 8.0; cls[k][3] += c["SQ_INSTS_MFMA"][1]
+        va = pv.get(name, {}).get("SQ_INSTS_VALU", [0, 0.0]); cls[k][4] += va[1] * (c["SQ_INSTS_MFMA"][0] / max(va[0], 1))
+    out = {}
+    print()
+    print("| class | matrix pipe busy | of it co-executing with VALU | vector instructions per MFMA |")
+    print("|---|---|---|---|")
+    for k in ("conv_igemm", "conv_wgrad"):
+        b_, co, cyc, mf, va = cls[k]
+        out[k] = {"matrix_pipe_busy": b_ / (1024.0 * max(cyc, 1)), "coexec_share": co / max(b_, 1), "valu_per_mfma": (va - mf) / max(mf, 1)}
+        print("| %s | %.3f | %.3f | %.1f |" % (k, out[k]["matrix_pipe_busy"], out[k]["coexec_share"], out[k]["valu_per_mfma"]))
+    if len(sys.argv) > 5:
+        json.dump(out, open(sys.argv[5], "w"), indent=1)
 
 
 if __name__ == "__main__":
