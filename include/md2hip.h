@@ -108,7 +108,7 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host_state, int64_t n);
  * BatchNorm / bias sums.  Process-wide, much slower; for bisecting parity failures. */
 int32_t md2_set_deterministic(int32_t on);
 /* Algorithm choice for the 3x3 / stride-1 convolutions (the reference leaves it to cuDNN behind Flux `Conv`, src/depth_decoder.jl:13-14): on = 1 (default) routes launches
- * with at least min_blocks workgroups (default 96 64-tile equivalents; < 0 keeps the current value) to the fused Winograd F(2x2,3x3) kernels, on = 0 forces the direct
+ * with at least min_blocks workgroups (default 48 64-tile equivalents; -1 keeps the current value, -2 restores the default) to the fused Winograd F(2x2,3x3) kernels, on = 0 forces the direct
  * implicit GEMM; on = 2 / 3 pin one of the two Winograd kernels wherever it applies (tests, tuning).  on = 4 / 5 are legacy aliases of
  * md2_set_winograd(1, .) + md2_set_conv_products(2 / 3, -1).  Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks);

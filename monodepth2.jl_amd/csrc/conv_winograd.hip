@@ -1448,10 +1448,13 @@ static int env_pieces(const char* name, int dflt) { const char* e = getenv(name)
 int g_wino_on = env_wino_mode() >= 4 ? 1 : env_wino_mode();
 int g_wino_pieces = env_pieces("MD2_WINO_PIECES", env_wino_mode() == 4 ? 2 : (env_wino_mode() == 5 ? 3 : MD2_DEFAULT_WINO_PIECES));
 int g_wgrad_pieces = env_pieces("MD2_WGRAD_PIECES", MD2_DEFAULT_WGRAD_PIECES);
-int g_wino_min_blocks = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 96;
+// (round 4: 48 instead of 96 64-tile equivalents -- with the split kernel the 256- and 512-channel layers of a batch-4 step are faster as one under-filled round of Winograd
+//  workgroups than as direct convolutions with split-K: 3.42 -> 3.26 ms per step at batch 4, unchanged at batch 32; 16 is too low: 3.32)
+int g_wino_min_blocks_default = getenv("MD2_WINO_MIN_BLOCKS") ? atoi(getenv("MD2_WINO_MIN_BLOCKS")) : 48;
+int g_wino_min_blocks = g_wino_min_blocks_default;
 
 // 3x3, stride 1, dense output lattice, no split-K, fp32; Cin % 16, Cout % 32.  Automatic choice (md2_set_winograd(1, n)): the 64-tile x 32-channel kernel when it
-// launches at least n workgroups (default 96 64-tile equivalents: in-model per-launch timings at batch 32 and 4, tools/run_layer_compare.sh -- below that the direct implicit GEMM with its split-K
+// launches at least n workgroups (default 48 64-tile equivalents; 96 until round 4: in-model per-launch timings at batch 32 and 4, tools/run_layer_compare.sh -- below that the direct implicit GEMM with its split-K
 // wins), the direct convolution otherwise; the first (32-tile x 64-channel) kernel only when pinned (mode 2; mode 3 pins conv_wino3_kernel, whose workgroup is 64 or 32 tiles
 // by workgroup count, wino3_eligible).
 static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh);

@@ -1305,7 +1305,7 @@ int32_t md2_set_deterministic(int32_t on) { g_deterministic = on != 0; return 0;
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks) {
     if (on == 4 || on == 5) { g_wino_on = 1; g_wino_pieces = on == 4 ? 2 : 3; }          // legacy aliases of md2_set_winograd(1, .) + md2_set_conv_products(2 / 3, -1)
     else g_wino_on = on < 0 || on > 3 ? 1 : on;
-    if (min_blocks >= 0) g_wino_min_blocks = min_blocks;
+    if (min_blocks >= 0) g_wino_min_blocks = min_blocks; else if (min_blocks == -2) g_wino_min_blocks = g_wino_min_blocks_default;
     return 0;
 }
 int32_t md2_set_conv_products(int32_t fwd_dgrad, int32_t wgrad) {

@@ -18,7 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 extern int g_deterministic;
 // md2_set_winograd(): the 3x3 / stride-1 layers take the fused Winograd F(2x2,3x3) kernel when the launch has at least g_wino_min_blocks workgroups (MD2_NO_WINO=1 /
 // MD2_WINO_MIN_BLOCKS override the defaults at load time); off = the direct implicit GEMM everywhere
-extern int g_wino_on, g_wino_min_blocks;
+extern int g_wino_on, g_wino_min_blocks, g_wino_min_blocks_default;
 // md2_set_conv_products(): how the fp32 products of the convolutions are formed.  0 = the fp32 MFMA (v_mfma_f32_32x32x2_f32); 3 = every fp32 operand as the exact sum of three
 // bf16 pieces (hi + mid + lo = all 24 mantissa bits), six v_mfma_f32_32x32x16_bf16 per product group with fp32 accumulation -- the same accuracy as the fp32 MFMA on the
 // bf16 matrix pipe; 1 (default) = per launch whichever of those two FULL-ACCURACY forms is faster at the launch's shape (wino_resolve_pieces / wgrad_resolve_pieces below);

@@ -551,7 +551,7 @@ def set_deterministic(on=True):
 
 
 def set_winograd(on=True, min_blocks=-1):
-    """Algorithm choice for the 3x3 / stride-1 convolutions: fused Winograd F(2x2,3x3) for launches of at least `min_blocks` workgroups (default policy: 96), or the direct
+    """Algorithm choice for the 3x3 / stride-1 convolutions: fused Winograd F(2x2,3x3) for launches of at least `min_blocks` workgroups (default policy: 48; -1 keeps the current value, -2 restores the default), or the direct
     implicit GEMM everywhere (on=False).  What cuDNN's heuristics decide for the reference's Flux `Conv` layers.  on = 2 / 3 pin one of the two Winograd kernels (tests).
     How the products are formed is `set_conv_products`' business (on = 4 / 5 remain as aliases of set_winograd(1) + set_conv_products(2 / 3))."""
     _check(_lib.lib().md2_set_winograd(int(on), int(min_blocks)), None, "set_winograd")

@@ -200,7 +200,7 @@ def forced_winograd(request):
     dflt = md().get_conv_products()
     _set_route(WINO_ROUTES[request.param])       # every eligible launch takes the Winograd kernel, however small its grid: the 256-thread / 32-tile one, or the
     yield WINO_ROUTES[request.param]             # 64-tile x 32-channel one with row-segment patches (the one the training step uses), wherever it applies; products by
-    md().set_winograd(True, 96); md().set_conv_products(*dflt)          # fp32 MFMA, the exact three-piece split, or the reduced two-piece one
+    md().set_winograd(True, -2); md().set_conv_products(*dflt)          # fp32 MFMA, the exact three-piece split, or the reduced two-piece one
 
 
 @pytest.mark.parametrize("case", WINO_CASES)

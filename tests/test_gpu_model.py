@@ -771,7 +771,7 @@ TIGHT_CASES = [(1, 1, 64, 96, 101, False), (2, 1, 64, 96, 107, False), (2, 3, 64
 # (name, md2_set_winograd arguments, md2_set_conv_products arguments).  "timed": the configuration bench.py's `value` is measured in.  "winograd forced": the shapes a CPU
 # oracle can afford sit below the workgroup-count threshold of the automatic choice, so the Winograd forward / input-gradient / weight-gradient kernels -- 7.8 of the
 # step's 9.9 ms of convolution time at batch 32 -- are pinned on every layer that qualifies, with the products of the timed configuration and with the other full-accuracy choice.
-TIGHT_ROUTES = [("timed", (1, 96), None), ("winograd forced", (3, 1), None), ("winograd forced, fp32 MFMA products", (3, 1), (0, 0)), ("winograd forced, exact-split products", (3, 1), (3, 3))]
+TIGHT_ROUTES = [("timed", (1, -2), None), ("winograd forced", (3, 1), None), ("winograd forced, fp32 MFMA products", (3, 1), (0, 0)), ("winograd forced, exact-split products", (3, 1), (3, 3))]
 
 
 _TIGHT_ORACLE = {}
@@ -837,7 +837,7 @@ def test_gradient_parity_tight_on_kink_free_seeds(case, route):
             want_pieces = md().get_conv_products()
             assert r.get("wgrad winograd", 0) >= 10 and (r.get("conv winograd_split", 0) if want_pieces[0] else r.get("conv winograd", 0)) >= 20, r
     finally:
-        md().set_winograd(True, 96); md().set_conv_products(*dflt)
+        md().set_winograd(True, -2); md().set_conv_products(*dflt)
 
 
 def test_resnet50_gradients_are_as_close_to_fp64_as_the_fp32_oracle():

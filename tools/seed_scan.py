@@ -30,7 +30,7 @@ for sd in range(first, first + count):
     net.set_params(theta); net.train_loss(x, cfg, al.cpu().numpy() if automask else None, True); go = net.get_grads().astype(np.float64)
     res = []
     for forced, det, fp, wp in CONFIGS:
-        md.set_winograd(3 if forced else 1, 1 if forced else 96); md.set_deterministic(bool(det)); md.set_conv_products(fp, wp)
+        md.set_winograd(3 if forced else 1, 1 if forced else -2); md.set_deterministic(bool(det)); md.set_conv_products(fp, wp)
         md.train_step(model, xd, al, cache, params, do_update=False); gh = model.grads().astype(np.float64)
         off = 0; worst = 0.0; wname = ""; top = 0.0; rows = []
         for name, _, shape in lay:
@@ -43,7 +43,7 @@ for sd in range(first, first + count):
             if r > worst:
                 worst, wname = r, name
         res.append((worst, wname))
-    md.set_winograd(1, 96); md.set_deterministic(False)
+    md.set_winograd(1, -2); md.set_deterministic(False)
     w = max(r[0] for r in res)
     print("case %s pseed %d: worst over %d routes %.2e | " % (" ".join(sys.argv[1:7]), sd, len(CONFIGS), w) +
           " ".join("%s%s%d%d=%.1e" % ("W" if c[0] else "a", "D" if c[1] else "n", c[2], c[3], r[0]) for c, r in zip(CONFIGS, res)), flush=True)
