@@ -1028,6 +1028,8 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
             if (merge && ncls < 4 && b.nkh * b.nkw <= 4 && b.nkh * b.nkw != 3) { b.ksplit = 1; kc.c[ncls++] = b; }
             else launch_conv_igemm_one(b, s);
         }
+    // longest class first: the 4-tap class's workgroups run 4x as long as the 1-tap class's, and workgroups are dispatched in index order -- issued last they were the launch's tail
+    if (ncls > 1) std::stable_sort(kc.c, kc.c + ncls, [](const ConvArgs& x, const ConvArgs& y) { return x.nkh * x.nkw > y.nkh * y.nkw; });
     if (ncls) launch_classes(kc, ncls, s);
     if (a.bst && !fuse_bst) bst_fallback(a, s);
 }
