@@ -137,3 +137,30 @@ def test_shard_range_covers_batch():
             for r in range(world):
                 lo, hi = par.shard_range(gb, r, world); got += list(range(lo, hi))
             assert got == list(range(gb))
+
+
+def test_conv_product_modes_are_validated_and_round_trip_without_a_device():
+    """md2_set_conv_products / md2_get_conv_products (how the fp32 products of the convolutions are formed; the reference computes in Float32, src/Monodepth.jl:72): process-wide host
+    state, no device needed.  The load-time default is the per-launch choice between the two FULL-accuracy forms (1, 1); the reduced two-piece form (2) is opt-in only."""
+    L = md2amd._lib.lib()
+    f = ctypes.c_int32(-7); w = ctypes.c_int32(-7)
+    assert L.md2_get_conv_products(ctypes.byref(f), ctypes.byref(w)) == 0
+    dflt = (f.value, w.value)
+    if not (os.environ.get("MD2_WINO_PIECES") or os.environ.get("MD2_WGRAD_PIECES") or os.environ.get("MD2_WINO_MODE")):
+        assert dflt == (1, 1)                                    # full fp32 operand accuracy in every product, nothing reduced by default
+    try:
+        for bad in ((4, 0), (0, 4), (-2, 0), (0, -3)):
+            assert L.md2_set_conv_products(*bad) == 2
+            assert L.md2_get_conv_products(ctypes.byref(f), ctypes.byref(w)) == 0 and (f.value, w.value) == dflt      # a refused call changes nothing
+        for mode in ((0, 0), (3, 3), (2, 2), (1, 0)):
+            assert L.md2_set_conv_products(*mode) == 0
+            L.md2_get_conv_products(ctypes.byref(f), ctypes.byref(w)); assert (f.value, w.value) == mode
+        assert L.md2_set_conv_products(-1, 3) == 0               # -1 keeps
+        L.md2_get_conv_products(ctypes.byref(f), ctypes.byref(w)); assert (f.value, w.value) == (1, 3)
+        # the legacy aliases of md2_set_winograd: 4 / 5 = automatic algorithm choice + two / three pieces in the forward / input-gradient kernels
+        assert L.md2_set_winograd(5, -1) == 0
+        L.md2_get_conv_products(ctypes.byref(f), ctypes.byref(w)); assert (f.value, w.value) == (3, 3)
+        assert L.md2_set_winograd(1, -2) == 0                    # -2 restores the workgroup-count threshold; the products stay as set
+        L.md2_get_conv_products(ctypes.byref(f), ctypes.byref(w)); assert (f.value, w.value) == (3, 3)
+    finally:
+        L.md2_set_winograd(1, -2); L.md2_set_conv_products(*dflt)
