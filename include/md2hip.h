@@ -39,7 +39,11 @@ typedef struct md2_config {
     int32_t precision;    /* 0: fp32 (parity mode, the reference's precision = f32, src/Monodepth.jl:72): fp32 storage, fp32 accumulation, every product at full fp32 operand
                              accuracy (fp32 MFMA, or its exact three-bf16-piece decomposition -- md2_set_conv_products below; nothing is rounded to fewer than 24 mantissa bits);
                              1: bf16 mixed precision -- the MFMA operands of the 32-wide conv / weight-gradient tiles are rounded to
-                                bf16, accumulation, activations, master weights, BatchNorm, loss and ADAM stay fp32          */
+                                bf16, accumulation, activations, master weights, BatchNorm, loss and ADAM stay fp32;
+                             2: bf16 activation storage (BASELINE config "1024x320 bf16 mixed precision") -- every activation / skip tensor and its gradient is a bf16 tensor in HBM
+                                (round to nearest even on store), the convolutions read per-step bf16 copies of the weights and run v_mfma_f32_32x32x16_bf16 /
+                                16x16x32 with fp32 accumulation; fp32 stay: the master weights and ADAM, BatchNorm statistics and their pullback sums, biases, the
+                                disparity maps, poses, loss and every parameter gradient.  Not a parity mode (the reference is Float32): tests bound it against the fp32 step */
     int32_t target_id;    /* TrainCache.target_id, 1-based frame of the triplet the depth decoder sees (src/model.jl:16, src/training.jl:25); 0 = the default 2 */
     int32_t source_ids[2];/* TrainCache.source_ids, 1-based, two distinct frames other than target_id in the caller's order (src/model.jl:22-35: a source before the
                              target is paired (source, target) and its pose inverted, src/training.jl:29); {0, 0} = the default {1, 3} (src/dtk.jl, src/kitty.jl)     */

@@ -102,7 +102,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // DL (direct load): global_load_lds writes a wave's 64 x 16 B linearly, so the rows are 16 floats without padding and the bank spread comes from an XOR swizzle of the
     // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
     constexpr bool DL = MD2_GLDS != 0 && XF == 0 && BF == 0 && BN == 64;
-    constexpr int ROWF = BF == 0 ? (DL ? 16 : LDK) : 12;
+    // BF == 2 (bf16 activation storage): x, w (and y, res, dact_src, bz) hold bf16 elements.  A K-step is still 64 BYTES per pixel row -- 32 channels -- so the loader, the masks
+    // and the LDS layout below are byte-for-byte those of the fp32 kernel (4 lanes x 16 B per row, 80-B row stride); a lane's 16-B operand read is 8 consecutive channels, which is
+    // what v_mfma_f32_32x32x16_bf16 (2 per tile pair and step) / v_mfma_f32_16x16x32_bf16 (1) take.  Cin == 16 (the full-resolution decoder layers): a step's row is TWO filter
+    // taps x 16 channels (`pair`; 9 taps -> 5 steps, the tenth half masked), the weights [Cout][9][16] being contiguous per output channel.
+    constexpr bool BS = BF == 2;
+    constexpr unsigned ESZ = BS ? 2u : 4u;                     // bytes per element
+    constexpr int ROWF = BF == 1 ? 12 : (DL ? 16 : LDK);
     constexpr int XS = BM * ROWF, STAGE = (BM + BN) * ROWF;    // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,6 +120,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     const int HlWl = a.Hl * a.Wl;
     const int Ktot = a.KH * a.KW * a.Cin;
     const int q = tid & 3;
+    const bool pair = BS && a.Cin == 16;
 
     // per-row (output pixel) constants of this thread's A_LD gather rows
     unsigned a_base[A_LD]; int a_ih[A_LD], a_iw[A_LD]; bool a_ok[A_LD];
@@ -123,14 +130,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         a_ok[j] = m < a.M;
         const int mm = a_ok[j] ? m : 0;
         const int n = mm / HlWl, r = mm - n * HlWl, li = r / a.Wl, lj = r - li * a.Wl;
-        a_base[j] = ((unsigned)((long)n * a.x_bs) + (DL ? (q ^ ((tid >> 4) & 3)) : q) * 4) * 4u;      // BYTE offsets: one VGPR per address (SGPR base + 32-bit offset); DL: swizzled chunk
+        a_base[j] = (unsigned)((long)n * a.x_bs) * ESZ + (unsigned)(DL ? (q ^ ((tid >> 4) & 3)) : (pair ? (q & 1) : q)) * 16u;      // BYTE offsets: one VGPR per address (SGPR base + 32-bit offset); DL: swizzled chunk
         a_ih[j] = (a.oy0 + li * a.ostep) * a.stride - a.pad;
         a_iw[j] = (a.ox0 + lj * a.ostep) * a.stride - a.pad;
     }
     // weights: row (c0 + f>>2), k runs linearly when the tap lattice is dense; per-tap base otherwise
     unsigned b_row[B_LD];
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) b_row[j] = ((unsigned)((c0 + (((tid + 256 * j) >> 2) & (BN - 1))) * Ktot) + (DL ? (q ^ ((tid >> 4) & 3)) : q) * 4) * 4u;
+    for (int j = 0; j < B_LD; ++j) b_row[j] = (unsigned)((c0 + (((tid + 256 * j) >> 2) & (BN - 1))) * Ktot) * ESZ + (unsigned)(DL ? (q ^ ((tid >> 4) & 3)) : q) * 16u;
 
     using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
     acc_t acc[TC][TP];
@@ -152,7 +159,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     }
     float4 ra[A_LD], rb[B_LD];
     // split-K (small grids only): this block covers channel chunks [c_lo, c_hi) of every tap
-    const int cpt_all = a.Cin >> 4;             // 16-channel chunks per tap
+    const int cpt_all = BS ? (pair ? 1 : a.Cin >> 5) : a.Cin >> 4;             // 64-byte channel chunks per tap (16 fp32 / 32 bf16 channels)
     const int c_lo = (int)blockIdx.y * cpt_all / a.ksplit, c_hi = ((int)blockIdx.y + 1) * cpt_all / a.ksplit;
     const int cpt = c_hi - c_lo;
 
@@ -164,12 +171,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     for (int j = 0; j < A_LD; ++j) a_mbits[j] = 0u;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int ikh = t / a.nkw, ikw = t - ikh * a.nkw;
+        const int tl = pair ? 2 * t + (q >> 1) : t;            // the filter tap this lane's 16 bytes of step slot t belong to
+        const bool tap_ok = !pair || tl < a.nkh * a.nkw;
+        const int ikh = tl / a.nkw, ikw = tl - ikh * a.nkw;
         const int kh = a.kh0 + ikh * a.khs, kw = a.kw0 + ikw * a.kws;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             int th = a_ih[j] + kh, tw = a_iw[j] + kw;
-            bool ok = a_ok[j];
+            bool ok = a_ok[j] && tap_ok;
             if (a.dil > 1) {
                 ok = ok && th >= 0 && tw >= 0 && (th % a.dil) == 0 && (tw % a.dil) == 0;
                 th /= a.dil; tw /= a.dil;
@@ -177,9 +186,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
             else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
             a_mbits[j] |= ok ? (1u << t) : 0u;
-            a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * 4u : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address (DL: g_zero_row instead)
+            a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address (DL: g_zero_row instead)
         }
-        b_tap[t] = (unsigned)((kh * a.KW + kw) * a.Cin) * 4u + (unsigned)(c_lo * 64);
+        b_tap[t] = pair ? (unsigned)(t * 64) : (unsigned)((kh * a.KW + kw) * a.Cin) * ESZ + (unsigned)(c_lo * 64);
     }
     const char* xb = reinterpret_cast<const char*>(a.x);
     const char* wb = reinterpret_cast<const char*>(a.w);
@@ -217,9 +226,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         *reinterpret_cast<bf16x4*>(row + q * 2) = h;
     };
     // XF: per-channel scale / shift of the chunk whose data sits in ra[] (4 channels of this thread's k-quad); reloaded when the prefetch enters a new chunk
-    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f), xsc2 = xsc, xsh2 = xsh;      // (bf16 storage: a lane's 16 bytes are 8 channels -> a second quad)
     auto xf_load = [&](int chunk) {
-        if constexpr (XF != 0) {
+        if constexpr (XF != 0 && BS) {
+            const int ch = ((c_lo + chunk) << 5) + q * 8;
+            xsc = *reinterpret_cast<const float4*>(a.in_scale + ch); xsh = *reinterpret_cast<const float4*>(a.in_shift + ch);
+            xsc2 = *reinterpret_cast<const float4*>(a.in_scale + ch + 4); xsh2 = *reinterpret_cast<const float4*>(a.in_shift + ch + 4);
+        } else if constexpr (XF != 0) {
             const int ch = ((c_lo + chunk) << 4) + q * 4;
             xsc = *reinterpret_cast<const float4*>(a.in_scale + ch); xsh = *reinterpret_cast<const float4*>(a.in_shift + ch);
         }
@@ -242,7 +255,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 sa[j] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk), __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
             }
         }
-        if constexpr (XF != 0) {
+        if constexpr (XF != 0 && BS) {
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                unsigned mb = a_mbits[j]; asm volatile("" : "+v"(mb));
+                const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)mb, (unsigned)tt, 1u);
+                const uint4 u = make_uint4(__float_as_uint(sa[j].x), __float_as_uint(sa[j].y), __float_as_uint(sa[j].z), __float_as_uint(sa[j].w));
+                const float4 lo = bf16x4_unpack(make_uint2(u.x, u.y)), hi = bf16x4_unpack(make_uint2(u.z, u.w));
+                const unsigned r0 = bf16x2_pack(fmaxf(fmaf(lo.x, xsc.x, xsh.x), 0.f), fmaxf(fmaf(lo.y, xsc.y, xsh.y), 0.f)), r1 = bf16x2_pack(fmaxf(fmaf(lo.z, xsc.z, xsh.z), 0.f), fmaxf(fmaf(lo.w, xsc.w, xsh.w), 0.f));
+                const unsigned r2 = bf16x2_pack(fmaxf(fmaf(hi.x, xsc2.x, xsh2.x), 0.f), fmaxf(fmaf(hi.y, xsc2.y, xsh2.y), 0.f)), r3 = bf16x2_pack(fmaxf(fmaf(hi.z, xsc2.z, xsh2.z), 0.f), fmaxf(fmaf(hi.w, xsc2.w, xsh2.w), 0.f));
+                sa[j] = make_float4(__uint_as_float(r0 & mk), __uint_as_float(r1 & mk), __uint_as_float(r2 & mk), __uint_as_float(r3 & mk));
+            }
+        } else if constexpr (XF != 0) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) {
                 unsigned mb = a_mbits[j]; asm volatile("" : "+v"(mb));
@@ -254,7 +278,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         }
     };
     auto lstore = [&](int so) {                 // so: float offset of the stage
-        if constexpr (BF != 0) {
+        if constexpr (BF == 1) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) put_bf(smem + so + ((tid + 256 * j) >> 2) * ROWF, sa[j]);
 #pragma unroll
@@ -275,10 +299,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     constexpr int NPL = 1;
     struct OpsF { f32x4 w[TC][NJ], x[TP][NJ]; };
     struct OpsB { bf16x8 w[TC][NPL], x[TP][NPL]; };
-    using Ops = typename std::conditional<BF != 0, OpsB, OpsF>::type;
+    using Ops = typename std::conditional<BF == 1, OpsB, OpsF>::type;
     const int lrow = lane & (MF - 1), lk4 = 4 * (lane / MF);
     auto read_ops = [&](int so, Ops& o) {
-        if constexpr (BF != 0) {
+        if constexpr (BF == 1) {
             const int lh = 4 * (lane >> 5);        // float offset of this lane half's 16 bytes
 #pragma unroll
             for (int i = 0; i < TC; ++i)
@@ -316,6 +340,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             for (int i = 0; i < TC; ++i)
 #pragma unroll
                 for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(o.w[i][0], o.x[j][0], acc[i][j], 0, 0, 0);
+            return;
+        } else if constexpr (BS) {                 // the 16 bytes a lane read per tile and jj are 8 consecutive bf16 channels of its row
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.w[i][jj]), __builtin_bit_cast(bf16x8, o.x[j][jj]), acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, o.w[i][jj]), __builtin_bit_cast(bf16x8, o.x[j][jj]), acc[i][j], 0, 0, 0);
+                    }
             return;
         } else {
 #pragma unroll
@@ -478,33 +513,33 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             const int oy = a.oy0 + li * a.ostep, ox = a.ox0 + lj * a.ostep;
             const long pix = (long)oy * a.Wo + ox;
             float4 v = *reinterpret_cast<const float4*>(T + pr * TLD + q4);
-            if (a.res && (a.ksplit == 1 || blockIdx.y == 0)) { const float4 t = *reinterpret_cast<const float4*>(a.res + (long)n * a.res_bs + pix * a.res_ps + co); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (a.res && (a.ksplit == 1 || blockIdx.y == 0)) { const float4 t = vld4<BS>(a.res, (long)n * a.res_bs + pix * a.res_ps + co); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.dact_src) {
-                d = *reinterpret_cast<const float4*>(a.dact_src + (long)n * a.da_bs + pix * a.da_ps + co);
+                d = vld4<BS>(a.dact_src, (long)n * a.da_bs + pix * a.da_ps + co);
                 if (a.dact_scale) { d.x = fmaf(d.x, dsc.x, dsh.x); d.y = fmaf(d.y, dsc.y, dsh.y); d.z = fmaf(d.z, dsc.z, dsh.z); d.w = fmaf(d.w, dsc.w, dsh.w); }
             }
             if (a.ksplit > 1) {                            // partial sum (see the register epilogue below)
                 if (a.dact_src) { v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact); }
                 if (a.ws) *reinterpret_cast<float4*>(a.ws + ((long)blockIdx.y * a.M + m) * a.Cout + co) = v;
-                else { float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co; atomicAdd(yp, v.x); atomicAdd(yp + 1, v.y); atomicAdd(yp + 2, v.z); atomicAdd(yp + 3, v.w); }
+                else if constexpr (!BS) { float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co; atomicAdd(yp, v.x); atomicAdd(yp + 1, v.y); atomicAdd(yp + 2, v.z); atomicAdd(yp + 3, v.w); }      // (bf16 storage always splits through the workspace)
                 continue;
             }
             v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
             if (a.act != ACT_NONE) { v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act); }
             if (a.dact_src) { v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact); }
-            float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co;
+            const long yo = (long)n * a.y_bs + pix * a.y_ps + co;
             if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame) || (a.acc_lat && oy % a.acc_lat == 0 && ox % a.acc_lat == 0)) {
-                const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                const float4 o = vld4<BS>(a.y, yo); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
-            *reinterpret_cast<float4*>(yp) = v;
+            vst4<BS>(a.y, yo, v);
             if (want_st) { s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
             if constexpr (BST != 0) if (want_b) {
-                const float4 z = *reinterpret_cast<const float4*>(a.bz + (long)n * a.bz_bs + pix * a.bz_ps + co);
+                const float4 z = vld4<BS>(a.bz, (long)n * a.bz_bs + pix * a.bz_ps + co);
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x += v.x * ((z.x - muA.x) * isA.x); s2.y += v.y * ((z.y - muA.y) * isA.y); s2.z += v.z * ((z.z - muA.z) * isA.z); s2.w += v.w * ((z.w - muA.w) * isA.w);
                 if (a.bstB) {
-                    const float4 zb = *reinterpret_cast<const float4*>(a.bzB + (long)n * a.bzB_bs + pix * a.bzB_ps + co);
+                    const float4 zb = vld4<BS>(a.bzB, (long)n * a.bzB_bs + pix * a.bzB_ps + co);
                     s3.x += v.x * ((zb.x - muB.x) * isB.x); s3.y += v.y * ((zb.y - muB.y) * isB.y); s3.z += v.z * ((zb.z - muB.z) * isB.z); s3.w += v.w * ((zb.w - muB.w) * isB.w);
                 }
             }
@@ -547,8 +582,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         if (m >= a.M) continue;
         const int n = m / HlWl, r = m - n * HlWl, li = r / a.Wl, lj = r - li * a.Wl;
         const long pix = (long)(a.oy0 + li * a.ostep) * a.Wo + (a.ox0 + lj * a.ostep);
-        float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps;
-        const float* dp = a.dact_src ? a.dact_src + (long)n * a.da_bs + pix * a.da_ps : nullptr;
+        const long yo = (long)n * a.y_bs + pix * a.y_ps;
+        [[maybe_unused]] float* yp = a.y + yo;                  // (fp32 storage: the atomic split-K path)
+        const bool dp = a.dact_src != nullptr; const long dpo = (long)n * a.da_bs + pix * a.da_ps;
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -556,12 +592,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 const int co = c0 + wc * (BN / WC) + i * MF + (MF == 32 ? 8 * g + 4 * (lane >> 5) : 4 * (lane >> 4));
                 float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (a.res && (a.ksplit == 1 || blockIdx.y == 0)) {        // residual gradient (identity shortcut), once per output element
-                    const float4 rr = *reinterpret_cast<const float4*>(a.res + (long)n * a.res_bs + pix * a.res_ps + co);
+                    const float4 rr = vld4<BS>(a.res, (long)n * a.res_bs + pix * a.res_ps + co);
                     v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                 }
                 float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (dp) {
-                    d = *reinterpret_cast<const float4*>(dp + co);
+                    d = vld4<BS>(a.dact_src, dpo + co);
                     if (a.dact_scale) {                 // dact_src is a raw conv output z: the activation it fed is relu(z * scale + shift)
                         const float4 sc = *reinterpret_cast<const float4*>(a.dact_scale + co), sh = *reinterpret_cast<const float4*>(a.dact_shift + co);
                         d.x = fmaf(d.x, sc.x, sh.x); d.y = fmaf(d.y, sc.y, sh.y); d.z = fmaf(d.z, sc.z, sh.z); d.w = fmaf(d.w, sc.w, sh.w);
@@ -570,7 +606,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 if (a.ksplit > 1) {            // partial sum: (x act') is linear, bias/activation are applied by the launcher's second pass
                     if (dp) { v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
                     if (a.ws) *reinterpret_cast<float4*>(a.ws + ((long)blockIdx.y * a.M + m) * a.Cout + co) = make_float4(v[0], v[1], v[2], v[3]);   // dense launch: row m of slice blockIdx.y
-                    else {                     // (64 lanes = 64 different pixels: 64 cache lines per atomic instruction -- the workspace path exists because of this)
+                    else if constexpr (!BS) {  // (64 lanes = 64 different pixels: 64 cache lines per atomic instruction -- the workspace path exists because of this)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) atomicAdd(yp + co + e, v[e]);
                     }
@@ -583,17 +619,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 }
                 if (dp) { v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
                 if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame) || (a.acc_lat && (a.oy0 + li * a.ostep) % a.acc_lat == 0 && (a.ox0 + lj * a.ostep) % a.acc_lat == 0)) {
-                    const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                    const float4 o = vld4<BS>(a.y, yo + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
                 }
-                *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
+                vst4<BS>(a.y, yo + co, make_float4(v[0], v[1], v[2], v[3]));
                 if constexpr (DO_BST) {
                     if (want_bst) {            // g = the final value just stored; xhat from the BatchNorm input(s) this gradient flows back into
-                        const float4 z = *reinterpret_cast<const float4*>(a.bz + (long)n * a.bz_bs + pix * a.bz_ps + co);
+                        const float4 z = vld4<BS>(a.bz, (long)n * a.bz_bs + pix * a.bz_ps + co);
                         const float4 mu = *reinterpret_cast<const float4*>(a.bstat + co), is = *reinterpret_cast<const float4*>(a.bstat + a.Cout + co);
                         bs1[4 * g + 0] += v[0]; bs1[4 * g + 1] += v[1]; bs1[4 * g + 2] += v[2]; bs1[4 * g + 3] += v[3];
                         bsA[4 * g + 0] += v[0] * ((z.x - mu.x) * is.x); bsA[4 * g + 1] += v[1] * ((z.y - mu.y) * is.y); bsA[4 * g + 2] += v[2] * ((z.z - mu.z) * is.z); bsA[4 * g + 3] += v[3] * ((z.w - mu.w) * is.w);
                         if (a.bstB) {
-                            const float4 zb = *reinterpret_cast<const float4*>(a.bzB + (long)n * a.bzB_bs + pix * a.bzB_ps + co);
+                            const float4 zb = vld4<BS>(a.bzB, (long)n * a.bzB_bs + pix * a.bzB_ps + co);
                             const float4 mb = *reinterpret_cast<const float4*>(a.bstatB + co), ib = *reinterpret_cast<const float4*>(a.bstatB + a.Cout + co);
                             bsB[4 * g + 0] += v[0] * ((zb.x - mb.x) * ib.x); bsB[4 * g + 1] += v[1] * ((zb.y - mb.y) * ib.y); bsB[4 * g + 2] += v[2] * ((zb.z - mb.z) * ib.z); bsB[4 * g + 3] += v[3] * ((zb.w - mb.w) * ib.w);
                         }
@@ -632,7 +668,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 
 // three pipeline stages of (pixel tile + weight tile) rows; the one-tap launches reuse it for their transposed output tile [BM][BN + 4] (or [3][4][256] column sums)
 constexpr int igemm_smem_floats(int BM, int BN, int BF) {
-    const int pipe = 3 * (BM + BN) * (BF == 0 ? LDK : 12), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
+    const int pipe = 3 * (BM + BN) * (BF == 1 ? 12 : LDK), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
     return pipe > tile ? pipe : tile;
 }
 // (the 128x64 tile runs 3 blocks per CU -- its 46 KB of LDS allow no more -- which needs <= 168 registers incl. the 32 accumulators: the variants with the input
@@ -662,6 +698,7 @@ __global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_cl
 // split-K second pass: y = act(sum_k ws[k] + bias) [+ y]; with `stats` also the BatchNorm statistics of the (linear, bias-free) result.
 // block = 256 threads = RG row groups x Q channel quads (the colstats layout); ws rows are dense [ksplit][M][C], y is addressed through its strides.
 struct SplitkBst { double* acc; const float* z; long z_bs; int z_ps; const float* stat; };       // BatchNorm-pullback sums of the final gradient: acc = sum g | sum g*xhat, xhat from (z, mean | invstd)
+template <bool BS>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int M, int C, float* __restrict__ y, long y_bs, int y_ps, int HW,
                                                             const float* __restrict__ bias, int act, int accumulate, int acc_lat, int Wo, double* __restrict__ stats, int rows_per_block, SplitkBst bA, SplitkBst bB, int acc_frame) {
     const int Qall = C / 4, qoff = blockIdx.y * 256, Q = min(Qall - qoff, 256), RG = 256 / Q;
@@ -682,17 +719,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
             if (act != ACT_NONE) { v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act); }
             const int n = p / HW, r = p - n * HW;
-            float* yp = y + (long)n * y_bs + (long)r * y_ps + q * 4;
+            const long yo = (long)n * y_bs + (long)r * y_ps + q * 4;
             if (accumulate == 1 || (accumulate == 2 && (n % 3) == acc_frame) || (acc_lat && (r / Wo) % acc_lat == 0 && (r % Wo) % acc_lat == 0)) {
-                const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                const float4 o = vld4<BS>(y, yo); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
             }
-            *reinterpret_cast<float4*>(yp) = v;
+            vst4<BS>(y, yo, v);
             s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
             if (bA.acc) {
-                const float4 z = *reinterpret_cast<const float4*>(bA.z + (long)n * bA.z_bs + (long)r * bA.z_ps + q * 4);
+                const float4 z = vld4<BS>(bA.z, (long)n * bA.z_bs + (long)r * bA.z_ps + q * 4);
                 s2.x += v.x * ((z.x - muA.x) * isA.x); s2.y += v.y * ((z.y - muA.y) * isA.y); s2.z += v.z * ((z.z - muA.z) * isA.z); s2.w += v.w * ((z.w - muA.w) * isA.w);
                 if (bB.acc) {
-                    const float4 zb = *reinterpret_cast<const float4*>(bB.z + (long)n * bB.z_bs + (long)r * bB.z_ps + q * 4);
+                    const float4 zb = vld4<BS>(bB.z, (long)n * bB.z_bs + (long)r * bB.z_ps + q * 4);
                     s3.x += v.x * ((zb.x - muB.x) * isB.x); s3.y += v.y * ((zb.y - muB.y) * isB.y); s3.z += v.z * ((zb.z - muB.z) * isB.z); s3.w += v.w * ((zb.w - muB.w) * isB.w);
                 }
             } else { s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
@@ -736,17 +773,25 @@ static void launch_splitk_reduce(const ConvArgs& a, const float* bias, int act, 
     const dim3 grid((a.M + rpb - 1) / rpb, (Q + 255) / 256);
     SplitkBst bA{}, bB{};
     if (with_bst && a.bst) { bA.acc = a.bst; bA.z = a.bz; bA.z_bs = a.bz_bs; bA.z_ps = a.bz_ps; bA.stat = a.bstat; if (a.bstB) { bB.acc = a.bstB; bB.z = a.bzB; bB.z_bs = a.bzB_bs; bB.z_ps = a.bzB_ps; bB.stat = a.bstatB; } }
-    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, a.acc_lat, a.Wo, stats, rpb, bA, bB, a.acc_frame);
+    if (a.bf16 == 2) hipLaunchKernelGGL(splitk_reduce_kernel<true>, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, a.acc_lat, a.Wo, stats, rpb, bA, bB, a.acc_frame);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, grid, dim3(256), 0, s, a.ws, a.ksplit, a.M, a.Cout, a.y, a.y_bs, a.y_ps, a.Ho * a.Wo, bias, act, accumulate, a.acc_lat, a.Wo, stats, rpb, bA, bB, a.acc_frame);
 }
 
 // BatchNorm-pullback sums that could not be fused into an epilogue (16-wide tiles, split-K, deterministic mode): one column pass over (g, z)
 static void bst_fallback(const ConvArgs& a, hipStream_t s) {
-    View g; g.p = a.y; g.N = a.N; g.H = a.Ho; g.W = a.Wo; g.C = a.Cout; g.bs = a.y_bs; g.ps = a.y_ps;
+    View g; g.p = a.y; g.N = a.N; g.H = a.Ho; g.W = a.Wo; g.C = a.Cout; g.bs = a.y_bs; g.ps = a.y_ps; g.bf = a.bf16 == 2;
     View z = g; z.p = const_cast<float*>(a.bz); z.bs = a.bz_bs; z.ps = a.bz_ps;
     launch_bn_bwd_reduce(g, nullptr, ACT_NONE, z, a.bstat, a.bst, s);
     if (a.bstB) { View zb = g; zb.p = const_cast<float*>(a.bzB); zb.bs = a.bzB_bs; zb.ps = a.bzB_ps; launch_bn_bwd_reduce(g, nullptr, ACT_NONE, zb, a.bstatB, a.bstB, s); }
 }
 
+// operand / storage form of a launch: ConvArgs::bf16 = 0 fp32 MFMA, 1 bf16 operands from fp32 tensors (32-wide tiles only), 2 bf16 tensors
+template <int BM, int BN, int WP, int WC, int MF, int NT, int XF = 0, int BST = 0>
+static void launch_igemm_form(const ConvArgs& a, const dim3& g, hipStream_t s) {
+    if (a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 2, XF, BST>), g, dim3(256), 0, s, a);
+    else if (a.bf16 == 1 && MF == 32) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 ? 1 : 0), XF, BST>), g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 0, XF, BST>), g, dim3(256), 0, s, a);
+}
 template <int BM, int BN, int WP, int WC, int MF>
 static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     static_assert((BM / WP) % MF == 0 && (BN / WC) % MF == 0, "wave tile must be a multiple of the MFMA tile");
@@ -761,26 +806,31 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
     const dim3 g(grid, a.ksplit);
     if (a.in_scale) {                  // BatchNorm + ReLU of the producer folded into the loader: the encoder's second 3x3 convolutions (Cout % 64 == 0)
         if constexpr (MF == 32 && BN == 64 && WP == 2) {
-            if (ntaps == 9) { if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 1, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 0, 1>), g, dim3(256), 0, s, a); }
-            else if (ntaps == 1) { if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, 1, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, 0, 1>), g, dim3(256), 0, s, a); }
+            if (ntaps == 9) launch_igemm_form<BM, BN, WP, WC, MF, 9, 1, 0>(a, g, s);
+            else if (ntaps == 1) launch_igemm_form<BM, BN, WP, WC, MF, 1, 1, 0>(a, g, s);
             else { fprintf(stderr, "md2: conv_igemm: the input transform is built for 3x3 and 1x1 convolutions\n"); abort(); }
         } else { fprintf(stderr, "md2: conv_igemm: the input transform needs Cout %% 64 == 0\n"); abort(); }
     } else if (a.bst) {
         if constexpr (bst_tile) {
-            if (ntaps == 9) { if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 1, 0, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, 0, 0, 1>), g, dim3(256), 0, s, a); }
-            else { if (a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, 1, 0, 1>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, 0, 0, 1>), g, dim3(256), 0, s, a); }
+            if (ntaps == 9) launch_igemm_form<BM, BN, WP, WC, MF, 9, 0, 1>(a, g, s);
+            else launch_igemm_form<BM, BN, WP, WC, MF, 1, 0, 1>(a, g, s);
         }
     } else
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
-        case 9: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 9>), g, dim3(256), 0, s, a); break;
-        case 4: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 4>), g, dim3(256), 0, s, a); break;
-        case 2: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 2>), g, dim3(256), 0, s, a); break;
-        case 1: if (MF == 32 && a.bf16) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1, (MF == 32 ? 1 : 0)>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 1>), g, dim3(256), 0, s, a); break;
+        case 9:
+            if (a.bf16 == 2 && a.Cin == 16) {          // bf16 storage, 16 input channels: two taps per 64-byte step (dense 3x3 tap lattice only)
+                if (a.nkw != 3 || a.kh0 || a.kw0 || a.khs != 1 || a.kws != 1) { fprintf(stderr, "md2: conv_igemm: the paired-tap form needs a dense 3x3 tap lattice\n"); abort(); }
+                hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, 5, 2>), g, dim3(256), 0, s, a);
+            } else launch_igemm_form<BM, BN, WP, WC, MF, 9>(a, g, s);
+            break;
+        case 4: launch_igemm_form<BM, BN, WP, WC, MF, 4>(a, g, s); break;
+        case 2: launch_igemm_form<BM, BN, WP, WC, MF, 2>(a, g, s); break;
+        case 1: launch_igemm_form<BM, BN, WP, WC, MF, 1>(a, g, s); break;
         default: fprintf(stderr, "md2: conv_igemm: unsupported tap count %d\n", a.nkh * a.nkw); abort();
     }
     if (a_in.stats && !a.stats) {                  // not fused (16-wide tiles, split-K): one more pass over the output
         if (a.ostep != 1 || a_in.bias || a_in.act != ACT_NONE) { fprintf(stderr, "md2: conv_igemm: BatchNorm statistics need a dense, bias-free, linear output\n"); abort(); }
-        View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
+        View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps; yv.bf = a.bf16 == 2;
         launch_colstats(yv, a_in.stats, s);
     }
     if (a_in.bst && !a.bst && a.ksplit == 1 && a.ostep == 1) bst_fallback(a_in, s);       // (split-K: after the bias / activation pass, by launch_conv_igemm_one; sub-lattices: by launch_conv_igemm)
@@ -939,7 +989,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
 static int patch_min_h() { static const int v = getenv("MD2_PATCH_MIN_H") ? atoi(getenv("MD2_PATCH_MIN_H")) : 64; return v; }
 static bool patch_eligible(const ConvArgs& a) {
     static const int off = getenv("MD2_NO_PATCH_CONV") ? 1 : 0;
-    if (off || a.res) return false;
+    if (off || a.res || a.bf16 == 2) return false;          // (fp32 tensors only)
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.Cin % 16 == 0 &&
            (a.Cout == 16 || a.Cout == 32) && a.Cin <= 96 &&
            a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.oy0 == 0 && a.ox0 == 0 && a.Hl == a.Ho && a.Wl == a.Wo &&
@@ -962,6 +1012,7 @@ static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s);
 static void check_igemm_args(const ConvArgs& a) {
     // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
     const long x_elems = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), w_elems = 4 * ((long)a.Cout * a.KH * a.KW * a.Cin);   // byte offsets must fit 32 bits
+    if (a.bf16 == 2 && !(a.Cin == 16 || a.Cin % 32 == 0)) { fprintf(stderr, "md2: conv_igemm: bf16 tensors need Cin == 16 or a multiple of 32 (Cin=%d)\n", a.Cin); abort(); }
     if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) || (a.res && (a.res_ps % 4 != 0 || a.act != ACT_NONE || a.bias)) ||
         a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) || w_elems >= (1L << 32)) {
         fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
@@ -974,9 +1025,11 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
     for (int i = 0; i < 4; ++i) k.first[i + 1] = k.first[i] + (i < n ? ((k.c[i].M + BM - 1) / BM) * (k.c[i].Cout / 64) : 0);
     for (int i = n; i < 4; ++i) k.c[i] = k.c[0];
     if (k.c[0].bst) {
-        if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+        if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+        else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 0, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
-    } else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+    } else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2>), dim3(k.first[4]), dim3(256), 0, s, k);
+    else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32>), dim3(k.first[4]), dim3(256), 0, s, k);
 }
 static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
@@ -994,7 +1047,7 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     if (patch_eligible(a) && !a.in_scale && !a.bst) {
         if (a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || (a.dact_src && a.da_ps % 4 != 0)) { fprintf(stderr, "md2: conv3x3_patch: unaligned view\n"); abort(); }
         if (a.Cout == 16) launch_patch<16>(a, s); else launch_patch<32>(a, s);
-        if (a.stats) { View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps; launch_colstats(yv, a.stats, s); }
+        if (a.stats) { View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps; yv.bf = a.bf16 == 2; launch_colstats(yv, a.stats, s); }
         return;
     }
     if (a.dil <= 1 || a.ostep != 1) { launch_conv_igemm_one(a, s); return; }
@@ -1041,7 +1094,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     // Few tiles with a long serial K loop (batch 4: M = 208 ... 2496 pixels give tens of tiles and up to 288 K-steps; batch 32: the 512-channel layers put
     // 2.4 blocks on a CU, i.e. 3 on some and 2 on others): split the channel chunks over gridDim.y.
     const long tiles64 = (long)((a.M + 63) / 64) * (a.Cout / (a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : 16)));
-    const int cpt = a.Cin / 16;
+    const int cpt = a.bf16 == 2 ? std::max(1, a.Cin / 32) : a.Cin / 16;          // 64-byte channel chunks per tap
     const long steps = (long)cpt * a.nkh * a.nkw;
     static const bool no_ws = getenv("MD2_IGEMM_NO_WS") && atoi(getenv("MD2_IGEMM_NO_WS")) != 0;
     const bool use_ws = a.ws && !no_ws && a.ostep == 1 && splitk_ws_shape_ok(a.Cout) && !g_deterministic;
@@ -1063,10 +1116,10 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
         static const int long_k = getenv("MD2_IGEMM_SPLIT_KSTEPS") ? atoi(getenv("MD2_IGEMM_SPLIT_KSTEPS")) : 256;
         const bool few = tiles64 < 100 || (tiles64 < mid && steps >= long_k);
         // (a serial K loop of fewer than 64 steps -- the 1x1 convolutions -- is cheaper than the fill + atomics + bias/activation passes of a split)
-        if (few && cpt >= 4 && steps >= 64 && want > 0 && !g_deterministic) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
+        if (few && cpt >= 4 && steps >= 64 && want > 0 && !g_deterministic && a.bf16 != 2) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
         a.ws = nullptr;
     }
-    View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
+    View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps; yv.bf = a.bf16 == 2;
     const float* bias2 = nullptr; int act2 = ACT_NONE, acc2 = 0;
     if (a.ksplit > 1) {
         if (a.ostep != 1) a.ksplit = 1;                      // residue-class launches write a sub-lattice: keep them single-pass
@@ -1075,7 +1128,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
             else if (!a.accumulate) launch_fill_view(yv, 0.f, s);
             else if (a.accumulate == 2) {                    // only the middle frame of every triplet holds earlier contributions
                 if (a.N % 3) { fprintf(stderr, "md2: conv_igemm: accumulate mode 2 needs a 3-frame batch\n"); abort(); }
-                for (int l = 0; l < 3; ++l) if (l != a.acc_frame) { View f = yv; f.p = yv.p + (long)l * yv.bs; f.N = yv.N / 3; f.bs = yv.bs * 3; launch_fill_view(f, 0.f, s); }
+                for (int l = 0; l < 3; ++l) if (l != a.acc_frame) { View f = yv; f.p = view_at(yv, (long)l * yv.bs); f.N = yv.N / 3; f.bs = yv.bs * 3; launch_fill_view(f, 0.f, s); }
             }
             bias2 = a.bias; act2 = a.act; a.bias = nullptr; a.act = ACT_NONE;
         }
@@ -1137,9 +1190,11 @@ __device__ __forceinline__ void wg_split3_pk(float a, float b, unsigned& hi, uns
     l[0] = (__bf16)sa; l[1] = (__bf16)sb;
     hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
 }
-template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false, int SPL = 0>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
+// BS: x and dy are bf16 tensors (WgradArgs::bf16 == 2): 8-byte loads widened to fp32 on their way into the (unchanged) LDS tiles; SPL = 1 then rounds the operand
+// fragments back to bf16 -- exactly the stored values -- for ONE v_mfma_f32_32x32x16_bf16 per 16-pixel k-group
+template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false, int SPL = 0, bool BS = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_per_split, int steps_total) {
-    static_assert(SPL == 0 || ((SPL == 2 || SPL == 3) && MF == 32 && BKP % 16 == 0), "the split path is built on the 32x32x16 bf16 MFMA");
+    static_assert(SPL == 0 || ((SPL >= 1 && SPL <= 3) && MF == 32 && BKP % 16 == 0), "the split path is built on the 32x32x16 bf16 MFMA");
     // LDS tiles [pixel][channel]: A operand lane (row = channel, k = pixel) reads consecutive channels of one pixel row.
     // 32x32x2: the two 32-lane halves are separate ds_read_b32 groups -> conflict-free for any row length.
     // 16x16x4: 4 pixel rows per instruction, LD % 32 == 16 keeps the two 16-lane halves of a group on disjoint banks.
@@ -1195,8 +1250,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
             const bool in = p_m[j] < a.M;
             if constexpr (ONE) {
                 const long m = in ? p_m[j] : 0;
-                const uint4 vd = *reinterpret_cast<const uint4*>(a.dy + m * a.dy_ps + c0 + lc);
-                const uint4 vx = *reinterpret_cast<const uint4*>(a.x + m * a.x_ps + i0 + lc);
+                const float4 fd = vld4<BS>(a.dy, m * a.dy_ps + c0 + lc), fx = vld4<BS>(a.x, m * a.x_ps + i0 + lc);
+                const uint4 vd = make_uint4(__float_as_uint(fd.x), __float_as_uint(fd.y), __float_as_uint(fd.z), __float_as_uint(fd.w)), vx = make_uint4(__float_as_uint(fx.x), __float_as_uint(fx.y), __float_as_uint(fx.z), __float_as_uint(fx.w));
                 const unsigned md = in ? 0xFFFFFFFFu : 0u;
                 rd[j] = make_float4(__uint_as_float(vd.x & md), __uint_as_float(vd.y & md), __uint_as_float(vd.z & md), __uint_as_float(vd.w & md));
                 if constexpr (XF) {
@@ -1213,8 +1268,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
             bool ok = in;
             if (REFLECT) { ih = refl_idx(ih, a.H); iw = refl_idx(iw, a.W); }
             else { ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W; ih = ok ? ih : 0; iw = ok ? iw : 0; }
-            const uint4 vd = *reinterpret_cast<const uint4*>(a.dy + (long)n * a.dy_bs + (long)(oh * a.Wo + ow) * a.dy_ps + c0 + lc);
-            const uint4 vx = *reinterpret_cast<const uint4*>(a.x + (long)n * a.x_bs + ((long)ih * a.W + iw) * a.x_ps + i0 + lc);
+            const float4 fd = vld4<BS>(a.dy, (long)n * a.dy_bs + (long)(oh * a.Wo + ow) * a.dy_ps + c0 + lc), fx = vld4<BS>(a.x, (long)n * a.x_bs + ((long)ih * a.W + iw) * a.x_ps + i0 + lc);
+            const uint4 vd = make_uint4(__float_as_uint(fd.x), __float_as_uint(fd.y), __float_as_uint(fd.z), __float_as_uint(fd.w)), vx = make_uint4(__float_as_uint(fx.x), __float_as_uint(fx.y), __float_as_uint(fx.z), __float_as_uint(fx.w));
             const unsigned md = in ? 0xFFFFFFFFu : 0u, mx = ok ? 0xFFFFFFFFu : 0u;       // integer masks keep the loop branch-free
             rd[j] = make_float4(__uint_as_float(vd.x & md), __uint_as_float(vd.y & md), __uint_as_float(vd.z & md), __uint_as_float(vd.w & md));
             if constexpr (XF) {
@@ -1278,6 +1333,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if constexpr (SPL == 3) { unsigned hi, mid, lo; wg_split3_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, mid, lo); o.ap[0][kk][i][e] = hi; o.ap[1][kk][i][e] = mid; o.ap[2][kk][i][e] = lo; }
+                        else if constexpr (SPL == 1) o.ap[0][kk][i][e] = bf16x2_pack(c[(2 * e) * LD], c[(2 * e + 1) * LD]);
                         else { unsigned hi, lo; wg_split_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, lo); o.ap[0][kk][i][e] = hi; o.ap[NPC - 1][kk][i][e] = lo; }
                     }
                 }
@@ -1287,6 +1343,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if constexpr (SPL == 3) { unsigned hi, mid, lo; wg_split3_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, mid, lo); o.bp[0][kk][j][e] = hi; o.bp[1][kk][j][e] = mid; o.bp[2][kk][j][e] = lo; }
+                        else if constexpr (SPL == 1) o.bp[0][kk][j][e] = bf16x2_pack(c[(2 * e) * LD], c[(2 * e + 1) * LD]);
                         else { unsigned hi, lo; wg_split_pk(c[(2 * e) * LD], c[(2 * e + 1) * LD], hi, lo); o.bp[0][kk][j][e] = hi; o.bp[NPC - 1][kk][j][e] = lo; }
                     }
                 }
@@ -1310,8 +1367,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int steps_
 #pragma unroll
                     for (int j = 0; j < TW; ++j) {
                         const bf16x8 ah = __builtin_bit_cast(bf16x8, o.ap[0][kk][i]), al = __builtin_bit_cast(bf16x8, o.ap[NPC - 1][kk][i]), bh = __builtin_bit_cast(bf16x8, o.bp[0][kk][j]), bl = __builtin_bit_cast(bf16x8, o.bp[NPC - 1][kk][j]);
+                        if constexpr (SPL >= 2) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);          // small terms first
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+                        }
                         if constexpr (SPL == 3) {
                             const bf16x8 am = __builtin_bit_cast(bf16x8, o.ap[1][kk][i]), bm = __builtin_bit_cast(bf16x8, o.bp[1][kk][j]);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[i][j], 0, 0, 0);
@@ -1409,45 +1468,42 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     const int sps = (steps_total + splitk - 1) / splitk;
     splitk = (steps_total + sps - 1) / sps;
     const dim3 g(tiles * taps * splitk);
+    const bool bs = a.bf16 == 2;                // bf16 tensors
+#define WG_LAUNCH(REFL, FAST_, XF_, ONE_, SPL_) do { if (bs) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, REFL, FAST_, XF_, ONE_, SPL_, true>), g, dim3(256), 0, s, a, sps, steps_total); \
+                                                     else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, REFL, FAST_, XF_, ONE_, SPL_, false>), g, dim3(256), 0, s, a, sps, steps_total); } while (0)
     if constexpr (T >= 64) {
-        const int pieces = wgrad_resolve_pieces_tap(g_wgrad_pieces);
-        if (pieces && fast && !refl) {          // products on the bf16 matrix pipe (split operands; 3 = exact, 2 = reduced precision opt-in): see conv_wgrad_kernel.
+        // products on the bf16 matrix pipe: bf16 tensors -> their values as they are (1 piece); fp32 tensors -> split operands (3 = exact, 2 = reduced precision opt-in): see conv_wgrad_kernel
+        const int pieces = bs ? 1 : wgrad_resolve_pieces_tap(g_wgrad_pieces);
+        static const bool no_one = getenv("MD2_NO_WGRAD_ONE") != nullptr;
+        const bool one = !no_one && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
+        if (pieces && fast && !refl) {
             // (bit-reproducible mode keeps this kernel: splitk = 1 above -> one workgroup per (tile, tap), one atomic per weight)
-            static const bool no_one1 = getenv("MD2_NO_WGRAD_ONE") != nullptr;
-            const bool one1 = !no_one1 && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
             if (pieces == 3) {
-                if (one1 && a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, true, 3>), g, dim3(256), 0, s, a, sps, steps_total);
-                else if (one1) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, true, 3>), g, dim3(256), 0, s, a, sps, steps_total);
-                else if (a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, false, 3>), g, dim3(256), 0, s, a, sps, steps_total);
-                else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, false, 3>), g, dim3(256), 0, s, a, sps, steps_total);
+                if (one && a.in_scale) WG_LAUNCH(false, true, true, true, 3); else if (one) WG_LAUNCH(false, true, false, true, 3);
+                else if (a.in_scale) WG_LAUNCH(false, true, true, false, 3); else WG_LAUNCH(false, true, false, false, 3);
+            } else if (pieces == 2) {
+                if (one && a.in_scale) WG_LAUNCH(false, true, true, true, 2); else if (one) WG_LAUNCH(false, true, false, true, 2);
+                else if (a.in_scale) WG_LAUNCH(false, true, true, false, 2); else WG_LAUNCH(false, true, false, false, 2);
             } else {
-                if (one1 && a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, true, 2>), g, dim3(256), 0, s, a, sps, steps_total);
-                else if (one1) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, true, 2>), g, dim3(256), 0, s, a, sps, steps_total);
-                else if (a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, false, 2>), g, dim3(256), 0, s, a, sps, steps_total);
-                else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, false, 2>), g, dim3(256), 0, s, a, sps, steps_total);
+                if (one && a.in_scale) WG_LAUNCH(false, true, true, true, 1); else if (one) WG_LAUNCH(false, true, false, true, 1);
+                else if (a.in_scale) WG_LAUNCH(false, true, true, false, 1); else WG_LAUNCH(false, true, false, false, 1);
             }
             return;
         }
-        static const bool no_one = getenv("MD2_NO_WGRAD_ONE") != nullptr;
-        const bool one = !no_one && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
-        if (one) {
-            if (a.in_scale) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
-            else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
-            return;
-        }
+        if (one) { if (a.in_scale) WG_LAUNCH(false, true, true, true, 0); else WG_LAUNCH(false, true, false, true, 0); return; }
     }
     if (a.in_scale) {
         if constexpr (T >= 64) {
             if (refl) { fprintf(stderr, "md2: conv_wgrad: the input transform is for zero-padded convolutions\n"); abort(); }
-            if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
-            else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
+            if (fast) WG_LAUNCH(false, true, true, false, 0); else WG_LAUNCH(false, false, true, false, 0);
             return;
         } else { fprintf(stderr, "md2: conv_wgrad: the input transform needs channel counts that are multiples of 64\n"); abort(); }
     }
-    if (fast && refl) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, true, true>), g, dim3(256), 0, s, a, sps, steps_total);
-    else if (fast) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, true>), g, dim3(256), 0, s, a, sps, steps_total);
-    else if (refl) hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, true, false>), g, dim3(256), 0, s, a, sps, steps_total);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, false, false>), g, dim3(256), 0, s, a, sps, steps_total);
+    if (fast && refl) WG_LAUNCH(true, true, false, false, 0);
+    else if (fast) WG_LAUNCH(false, true, false, false, 0);
+    else if (refl) WG_LAUNCH(true, false, false, false, 0);
+    else WG_LAUNCH(false, false, false, false, 0);
+#undef WG_LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1460,7 +1516,7 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
 // The 9*TCO accumulator tiles live in registers for the block's whole life; one LDS reduction over the 4 waves and one set of
 // fp32 atomics per block at the end.  Next tile's global loads are in flight during the current tile's MFMAs.
 // ------------------------------------------------------------------------------------------------------------
-template <int TCO>        // Cout / 16: 1 or 2
+template <int TCO, bool BS = false>        // Cout / 16: 1 or 2; BS: x and dy are bf16 tensors (widened to fp32 on their way into LDS)
 __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, int tiles_x, int tiles_y, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float psm[];
     float* Ys = psm;                          // [TCO][256][16]
@@ -1482,7 +1538,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, i
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned poff[NPL], yoff[4], yok = 0;       // poff bit 31: the input pixel is outside the image (zero padding); yok bit i: dy slot i is inside
     u32x4 pv[NPL], yv[NYL];
-    const float* xin = a.x; const float* dyin = a.dy;
+    long xin = 0, dyin = 0;                    // element offsets
     const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     for (int s = -1; s < my_tiles; ++s) {                            // s = -1 is the prologue (only issues tile 0's loads)
         if (s >= 0) {
@@ -1501,7 +1557,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, i
         if (s + 1 < my_tiles) {
             const int tile = blockIdx.x + (s + 1) * gridDim.x;
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            xin = a.x + (long)n * a.x_bs + cg * 16; dyin = a.dy + (long)n * a.dy_bs;
+            xin = (long)n * a.x_bs + cg * 16; dyin = (long)n * a.dy_bs;
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 const int f = tid + i * 256, pp = min(f >> 2, PP_N - 1), q = f & 3, pr = pp / PP_W, pc = pp - pr * PP_W;
@@ -1521,9 +1577,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, i
                 yok |= (ok ? 1u : 0u) << i;
             }
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) pv[i] = *reinterpret_cast<const u32x4*>(xin + (poff[i] & 0x7FFFFFFFu));
+            for (int i = 0; i < NPL; ++i) { const float4 f = vld4<BS>(a.x, xin + (poff[i] & 0x7FFFFFFFu)); pv[i] = u32x4{__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)}; }
 #pragma unroll
-            for (int i = 0; i < NYL; ++i) yv[i] = *reinterpret_cast<const u32x4*>(dyin + yoff[i & 3] + (i >> 2) * 16);
+            for (int i = 0; i < NYL; ++i) { const float4 f = vld4<BS>(a.dy, dyin + yoff[i & 3] + (i >> 2) * 16); yv[i] = u32x4{__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)}; }
         }
         if (s < 0) continue;
         // ---- this wave's 64 pixels (tile rows 2*wave, 2*wave+1): 16 k-steps of 4 pixels, 9 taps each
@@ -1582,13 +1638,15 @@ static void launch_wgrad_patch(const WgradArgs& a, hipStream_t s) {
     const size_t lds = (size_t)std::max((TCO * 256 + PP_N) * 16, 9 * TCO * 256) * sizeof(float);
     static int per_cu = 0;
     if (!per_cu) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_patch_kernel<TCO, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_patch_kernel<TCO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_patch_kernel<TCO>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
         per_cu = std::min(per_cu, 4);
     }
     const int total = tiles_x * tiles_y * a.N, groups = a.Cin / 16;
     const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));              // persistent: the co-resident blocks, shared by the channel chunks
-    hipLaunchKernelGGL((conv3x3_wgrad_patch_kernel<TCO>), dim3(gx, groups), dim3(256), lds, s, a, tiles_x, tiles_y, total);
+    if (a.bf16 == 2) hipLaunchKernelGGL((conv3x3_wgrad_patch_kernel<TCO, true>), dim3(gx, groups), dim3(256), lds, s, a, tiles_x, tiles_y, total);
+    else hipLaunchKernelGGL((conv3x3_wgrad_patch_kernel<TCO>), dim3(gx, groups), dim3(256), lds, s, a, tiles_x, tiles_y, total);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1663,7 +1721,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
         if (s + 1 < my_tiles && !(abl & 1)) {
             const int tile = blockIdx.x + (s + 1) * gridDim.x;
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            const float* xin = a.x + (long)n * a.x_bs + cgi * 32 + q * 4; const float* dyin = a.dy + (long)n * a.dy_bs + cgo * 32 + q * 4;
+            const long xin = (long)n * a.x_bs + cgi * 32 + q * 4, dyin = (long)n * a.dy_bs + cgo * 32 + q * 4;       // element offsets (BF == 2: bf16 tensors, widened to fp32 here)
             int iw = tx * TW - a.pad + col;
             if (a.padmode == PAD_REFLECT) iw = refl_idx(max(min(iw, a.W), -1), a.W);
             const bool wok = iw >= 0 && iw < a.W && col < PW;
@@ -1678,13 +1736,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
                 if (a.padmode == PAD_REFLECT) ih = refl_idx(max(min(ih, a.H), -1), a.H);
                 const bool hok = ih >= 0 && ih < a.H;
                 okbits |= ((hok && wok) ? 1u : 0u) << i;
-                pv[i] = *reinterpret_cast<const u32x4*>(xin + (unsigned)(min(max(ih, 0), a.H - 1) * a.W * a.x_ps) + xcol);
+                { const float4 f = vld4<BF == 2>(a.x, xin + (unsigned)(min(max(ih, 0), a.H - 1) * a.W * a.x_ps) + xcol); pv[i] = u32x4{__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)}; }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int oy = ty * 4 + i;
                 okbits |= ((oy < a.Ho && cok) ? 1u : 0u) << (16 + i);
-                yv[i] = *reinterpret_cast<const u32x4*>(dyin + (unsigned)(min(oy, a.Ho - 1) * a.Wo * a.dy_ps) + ycol);
+                { const float4 f = vld4<BF == 2>(a.dy, dyin + (unsigned)(min(oy, a.Ho - 1) * a.Wo * a.dy_ps) + ycol); yv[i] = u32x4{__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)}; }
             }
         }
         if (s < 0) continue;
@@ -1774,13 +1832,15 @@ static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
     if (!per_cu) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<0>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
         per_cu = std::min(per_cu, 2);
         if (getenv("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("MD2_TAPS_PER_CU"))));
     }
     const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
     const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));                    // persistent: the co-resident blocks, shared by the weight tiles
-    if (a.bf16) hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<1>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
+    if (a.bf16 == 2) hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<2>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
+    else if (a.bf16) hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<1>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
     else hipLaunchKernelGGL(conv3x3_wgrad_taps32_kernel<0>, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
 }
 
@@ -1800,14 +1860,14 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     }
     if (conv_wino_wgrad_eligible(a)) { launch_conv_wino_wgrad(a, s); return; }          // (bit-reproducible mode included: one workgroup per weight tile, its bias sum a single add)
     if (g_deterministic && a.db && (wgrad_taps32_eligible(a) || wgrad_patch_eligible(a))) {      // the fused bias gradient adds one atomic per wave: use the ordered column sum
-        View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s);
+        View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; dyv.bf = a.bf16 == 2; launch_colsum(dyv, a.db, s);
         WgradArgs b = a; b.db = nullptr;
         if (wgrad_taps32_eligible(b)) launch_wgrad_taps32(b, s); else if (b.Cout == 16) launch_wgrad_patch<1>(b, s); else launch_wgrad_patch<2>(b, s);
         return;
     }
     if (wgrad_taps32_eligible(a)) { launch_wgrad_taps32(a, s); return; }
     if (wgrad_patch_eligible(a)) { if (a.Cout == 16) launch_wgrad_patch<1>(a, s); else launch_wgrad_patch<2>(a, s); return; }
-    if (a.db) { View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; launch_colsum(dyv, a.db, s); }
+    if (a.db) { View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; dyv.bf = a.bf16 == 2; launch_colsum(dyv, a.db, s); }
     if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && max_t >= 128) launch_wgrad_tile<128, 16, 32>(a, s);
     else if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 32, 32>(a, s);
     else if (a.Cin % 32 == 0 && a.Cout % 32 == 0) launch_wgrad_tile<32, 32, 16>(a, s);
@@ -1874,7 +1934,7 @@ void launch_weight_to_dgrad(const float* w_fwd, float* w_dg, int CoutP, int CinP
 // ------------------------------------------------------------------------------------------------------------
 // (row-indexed like the element kernels of layers.hip: blockIdx.x owns `rpb` image rows, blockIdx.y a 256 / LPP-pixel chunk of the row -- the flat 64-bit pixel index
 //  this kernel used to decode per pixel cost more vector instructions than its 9 x 16-B gathers)
-template <int LPP>
+template <int LPP, bool BS = false>          // BS: x is a bf16 tensor (the disparity map y stays fp32: the loss reads it)
 __global__ __launch_bounds__(256) void head_fwd_kernel(View x, const float* __restrict__ w, const float* __restrict__ b, View y, int rpb) {
     const int l = threadIdx.x % LPP;
     constexpr int PPB = 256 / LPP;
@@ -1896,7 +1956,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(View x, const float* __re
             const int ih = refl_idx(h + kh - 1, x.H);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const float4 v = *reinterpret_cast<const float4*>(x.p + (long)n * x.bs + ((long)ih * x.W + iws[kw]) * x.ps + l * 4);
+                const float4 v = vld4<BS>(x.p, (long)n * x.bs + ((long)ih * x.W + iws[kw]) * x.ps + l * 4);
                 const float4 c = wv[kh * 3 + kw];
                 s += v.x * c.x + v.y * c.y + v.z * c.z + v.w * c.w;
             }
@@ -1912,11 +1972,11 @@ void launch_head_fwd(const View& x, const float* w, const float* b, const View& 
     const int rpb = (int)std::min<long>(16, std::max<long>(1, (rows * chunks + 8191) / 8192));
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)chunks);
     switch (lpp) {
-        case 4: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;
-        case 8: hipLaunchKernelGGL(head_fwd_kernel<8>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;
-        case 16: hipLaunchKernelGGL(head_fwd_kernel<16>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;
-        case 32: hipLaunchKernelGGL(head_fwd_kernel<32>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;
-        case 64: hipLaunchKernelGGL(head_fwd_kernel<64>, grid, dim3(256), 0, s, x, w, b, y, rpb); break;          // a head on the first branch (scale level 1, 256 channels)
+        case 4: if (x.bf) hipLaunchKernelGGL((head_fwd_kernel<4, true>), grid, dim3(256), 0, s, x, w, b, y, rpb); else hipLaunchKernelGGL((head_fwd_kernel<4>), grid, dim3(256), 0, s, x, w, b, y, rpb); break;
+        case 8: if (x.bf) hipLaunchKernelGGL((head_fwd_kernel<8, true>), grid, dim3(256), 0, s, x, w, b, y, rpb); else hipLaunchKernelGGL((head_fwd_kernel<8>), grid, dim3(256), 0, s, x, w, b, y, rpb); break;
+        case 16: if (x.bf) hipLaunchKernelGGL((head_fwd_kernel<16, true>), grid, dim3(256), 0, s, x, w, b, y, rpb); else hipLaunchKernelGGL((head_fwd_kernel<16>), grid, dim3(256), 0, s, x, w, b, y, rpb); break;
+        case 32: if (x.bf) hipLaunchKernelGGL((head_fwd_kernel<32, true>), grid, dim3(256), 0, s, x, w, b, y, rpb); else hipLaunchKernelGGL((head_fwd_kernel<32>), grid, dim3(256), 0, s, x, w, b, y, rpb); break;
+        case 64: if (x.bf) hipLaunchKernelGGL((head_fwd_kernel<64, true>), grid, dim3(256), 0, s, x, w, b, y, rpb); else hipLaunchKernelGGL((head_fwd_kernel<64>), grid, dim3(256), 0, s, x, w, b, y, rpb); break;          // a head on the first branch (scale level 1, 256 channels)
         default: fprintf(stderr, "md2: head_fwd: unsupported Cin=%d\n", x.C); abort();
     }
 }
@@ -1926,7 +1986,7 @@ void launch_head_fwd(const View& x, const float* w, const float* b, const View& 
 // (pixel, channel quad) thread accumulates its 9 weight-gradient taps from LDS and gathers its input gradient (with the reflect-pad
 // adjoint) from the dz tile.  The first version gathered everything from global memory per pixel: ~450 instructions per pixel-lane, most of
 // them 64-bit address arithmetic (0.21 ms for the full-resolution head against 0.04 ms of HBM time).
-template <int LPP>
+template <int LPP, bool BS = false>          // BS: x and dx are bf16 tensors; y, dy (the loss's side) fp32
 __global__ __launch_bounds__(256) void head_bwd_kernel(View x, const float* __restrict__ w, View y, View dy, View dx, int accumulate, int x_act,
                                                        float* __restrict__ dw, float* __restrict__ db, int tiles_x, int tiles_y, int total_tiles) {
     constexpr int PPB = 256 / LPP;                                   // pixels per pass
@@ -1949,7 +2009,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(View x, const float* __re
         for (int f = threadIdx.x; f < XN * LPP; f += 256) {           // x patch: pixel slot f / LPP, channel quad f % LPP
             const int pp = f / LPP, q = f - pp * LPP, pr = pp / XW, pc = pp - pr * XW;
             const int ih = refl_idx(min(max(y0 - 1 + pr, -1), H), H), iw = refl_idx(min(max(x0 - 1 + pc, -1), W), W);
-            *reinterpret_cast<float4*>(Xs + pp * C + q * 4) = *reinterpret_cast<const float4*>(x.p + (long)n * x.bs + ((long)ih * W + iw) * x.ps + q * 4);
+            *reinterpret_cast<float4*>(Xs + pp * C + q * 4) = vld4<BS>(x.p, (long)n * x.bs + ((long)ih * W + iw) * x.ps + q * 4);
         }
         for (int f = threadIdx.x; f < XN; f += 256) {
             const int pr = f / XW, pc = f - pr * XW, ih = y0 - 1 + pr, iw = x0 - 1 + pc;
@@ -2001,9 +2061,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(View x, const float* __re
                 const float4 o = *reinterpret_cast<const float4*>(xs + (XW + 1) * C);
                 gx.x *= act_deriv(o.x, x_act); gx.y *= act_deriv(o.y, x_act); gx.z *= act_deriv(o.z, x_act); gx.w *= act_deriv(o.w, x_act);
             }
-            float* dp = dx.p + (long)n * dx.bs + ((long)h * W + wq) * dx.ps + l * 4;
-            if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(dp); gx.x += o.x; gx.y += o.y; gx.z += o.z; gx.w += o.w; }
-            *reinterpret_cast<float4*>(dp) = gx;
+            const long dpo = (long)n * dx.bs + ((long)h * W + wq) * dx.ps + l * 4;
+            if (accumulate) { const float4 o = vld4<BS>(dx.p, dpo); gx.x += o.x; gx.y += o.y; gx.z += o.z; gx.w += o.w; }
+            vst4<BS>(dx.p, dpo, gx);
         }
     }
     // block reduction of the weight gradient over the PPB pixel groups
@@ -2031,7 +2091,9 @@ template <int LPP>
 static void launch_head_bwd_t(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, int x_act, float* dw, float* db, hipStream_t s) {
     constexpr int PPB = 256 / LPP, TH = LPP <= 8 ? 8 : 4, TW = 4 * PPB / TH;
     const int tiles_x = (x.W + TW - 1) / TW, tiles_y = (x.H + TH - 1) / TH, total = tiles_x * tiles_y * x.N;
-    hipLaunchKernelGGL(head_bwd_kernel<LPP>, dim3(g_deterministic ? 1 : std::min(total, 768)), dim3(256), 0, s, x, w, y, dy, dx, accumulate, x_act, dw, db, tiles_x, tiles_y, total);      // persistent: 3 blocks per CU fit (162 VGPRs)
+    if (x.bf != dx.bf || y.bf || dy.bf) { fprintf(stderr, "md2: head_bwd: x and dx share a storage type, y and dy are fp32\n"); abort(); }
+    if (x.bf) hipLaunchKernelGGL((head_bwd_kernel<LPP, true>), dim3(g_deterministic ? 1 : std::min(total, 768)), dim3(256), 0, s, x, w, y, dy, dx, accumulate, x_act, dw, db, tiles_x, tiles_y, total);
+    else hipLaunchKernelGGL((head_bwd_kernel<LPP>), dim3(g_deterministic ? 1 : std::min(total, 768)), dim3(256), 0, s, x, w, y, dy, dx, accumulate, x_act, dw, db, tiles_x, tiles_y, total);      // persistent: 3 blocks per CU fit (162 VGPRs)
 }
 void launch_head_bwd(const View& x, const float* w, const View& y, const View& dy, const View& dx, int accumulate, int x_act, float* dw, float* db, hipStream_t s) {
     if (x.H < 3 || x.W < 3 || x.ps % 4 != 0 || dx.ps % 4 != 0) { fprintf(stderr, "md2: head_bwd: unsupported view\n"); abort(); }

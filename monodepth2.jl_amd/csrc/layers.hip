@@ -7,12 +7,14 @@
 
 namespace md2 {
 
+// one instantiation per storage type of the activation views (View::bf): fp32 or bf16 elements
+#define LAUNCH_BS(bf, kern, ...) do { if (bf) hipLaunchKernelGGL((kern<true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<false>), __VA_ARGS__); } while (0)
+#define LAUNCH_BSP(bf, kern, pre, ...) do { if (bf) hipLaunchKernelGGL((kern<pre, true>), __VA_ARGS__); else hipLaunchKernelGGL((kern<pre, false>), __VA_ARGS__); } while (0)
+#define MD2_COMMA ,
 static inline int grid_for(long work, int per_block, int cap = 2048) { return (int)std::max<long>(1, std::min<long>((work + per_block - 1) / per_block, cap)); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ const float* vptr(const View& v, int n, long r) { return v.p + (long)n * v.bs + r * v.ps; }
-__device__ __forceinline__ float* vptrw(const View& v, int n, long r) { return v.p + (long)n * v.bs + r * v.ps; }
 static inline bool dense_view_h(const View& v) { return v.ps == v.C && v.bs == (long)v.H * v.W * v.C; }
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -31,32 +33,34 @@ static inline RowGrid row_grid(long rows, int rowlen, int want_blocks = 8192, in
 }
 
 // ---- layout conversion for the op-level entry points --------------------------------------------------------------
+template <bool BS>
 __global__ void nchw_to_view_kernel(const float* __restrict__ src, View v) {
     const long total = (long)v.N * v.H * v.W * v.C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = i % v.C; const long r = i / v.C; const long hw = r % ((long)v.H * v.W); const int n = r / ((long)v.H * v.W);
-        v.p[(long)n * v.bs + hw * v.ps + c] = src[((long)n * v.C + c) * v.H * v.W + hw];
+        vst1<BS>(v.p, (long)n * v.bs + hw * v.ps + c, src[((long)n * v.C + c) * v.H * v.W + hw]);
     }
 }
+template <bool BS>
 __global__ void view_to_nchw_kernel(View v, float* __restrict__ dst) {
     const long total = (long)v.N * v.H * v.W * v.C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long hw = i % ((long)v.H * v.W); const long r = i / ((long)v.H * v.W); const int c = r % v.C; const int n = r / v.C;
-        dst[i] = v.p[(long)n * v.bs + hw * v.ps + c];
+        dst[i] = vld1<BS>(v.p, (long)n * v.bs + hw * v.ps + c);
     }
 }
 void launch_nchw_to_view(const float* src, const View& v, hipStream_t s) {
-    hipLaunchKernelGGL(nchw_to_view_kernel, dim3(grid_for((long)v.N * v.H * v.W * v.C, 256, 4096)), dim3(256), 0, s, src, v);
+    LAUNCH_BS(v.bf, nchw_to_view_kernel, dim3(grid_for((long)v.N * v.H * v.W * v.C, 256, 4096)), dim3(256), 0, s, src, v);
 }
 void launch_nhwc_to_nchw(const float*, const View& v, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(view_to_nchw_kernel, dim3(grid_for((long)v.N * v.H * v.W * v.C, 256, 4096)), dim3(256), 0, s, v, dst);
+    LAUNCH_BS(v.bf, view_to_nchw_kernel, dim3(grid_for((long)v.N * v.H * v.W * v.C, 256, 4096)), dim3(256), 0, s, v, dst);
 }
 void launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s) { launch_nchw_to_view(src, make_view(dst, N, H, W, C), s); }
 
 // ---- per-channel statistics ---------------------------------------------------------------------------------------
 // block = 256 threads = RG row-groups x (C/4) channel quads (C <= 512 -> RG >= 2).  Each thread strides over pixels,
 // LDS-reduces over row groups, then one double atomic per channel per block.
-template <int MODE, bool FLAT>   // 0: sum z, sum z^2 ; 1: sum g, sum g*xhat  (g = dy * act'(yact)); FLAT: dense NHWC views, pixel p at p*C
+template <int MODE, bool FLAT, bool BS>   // 0: sum z, sum z^2 ; 1: sum g, sum g*xhat  (g = dy * act'(yact)); FLAT: dense NHWC views, pixel p at p*C
 __global__ __launch_bounds__(256) void colstats_kernel(View z, View dy, View yact, int has_yact, int act, const float* __restrict__ stats, double* __restrict__ acc, int rows_per_block) {
     const int Qall = z.C / 4;                 // channel quads; more than 256 of them (C = 2048, ResNet-50) are split over blockIdx.y
     const int qoff = blockIdx.y * 256, Q = min(Qall - qoff, 256);
@@ -72,13 +76,13 @@ __global__ __launch_bounds__(256) void colstats_kernel(View z, View dy, View yac
 #pragma unroll 2
         for (long p = p0 + rg; p < p1; p += RG) {
             const int n = FLAT ? 0 : (int)(p / HW); const long r = FLAT ? p : p - (long)n * HW;      // dense: bs == HW*ps, so (0, p) addresses pixel p
-            const float4 v = ld4(vptr(z, n, r) + q * 4);
+            const float4 v = vld4<BS>(z.p, voff(z, n, r) + q * 4);
             if (MODE == 0) {
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
             } else {
-                float4 g = ld4(vptr(dy, n, r) + q * 4);
-                if (has_yact) { const float4 o = ld4(vptr(yact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+                float4 g = vld4<BS>(dy.p, voff(dy, n, r) + q * 4);
+                if (has_yact) { const float4 o = vld4<BS>(yact.p, voff(yact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
                 s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
                 s2.x += g.x * (v.x - mean.x) * istd.x; s2.y += g.y * (v.y - mean.y) * istd.y; s2.z += g.z * (v.z - mean.z) * istd.z; s2.w += g.w * (v.w - mean.w) * istd.w;
             }
@@ -104,8 +108,8 @@ static void colstats_launch(int mode, const View& z, const View* dy, const View*
     const dim3 grid((unsigned)((P + rpb - 1) / rpb), (unsigned)((Qh + 255) / 256));
     View d = dy ? *dy : z, ya = yact ? *yact : z;
     const bool flat = dense_view_h(z) && dense_view_h(d) && dense_view_h(ya);
-    if (mode == 0) { if (flat) hipLaunchKernelGGL((colstats_kernel<0, true>), grid, dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); else hipLaunchKernelGGL((colstats_kernel<0, false>), grid, dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); }
-    else { if (flat) hipLaunchKernelGGL((colstats_kernel<1, true>), grid, dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); else hipLaunchKernelGGL((colstats_kernel<1, false>), grid, dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); }
+    if (mode == 0) { if (flat) LAUNCH_BSP(z.bf, colstats_kernel, 0 MD2_COMMA true, grid, dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); else LAUNCH_BSP(z.bf, colstats_kernel, 0 MD2_COMMA false, grid, dim3(256), 0, s, z, d, ya, 0, 0, stats, acc, rpb); }
+    else { if (flat) LAUNCH_BSP(z.bf, colstats_kernel, 1 MD2_COMMA true, grid, dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); else LAUNCH_BSP(z.bf, colstats_kernel, 1 MD2_COMMA false, grid, dim3(256), 0, s, z, d, ya, yact ? 1 : 0, act, stats, acc, rpb); }
 }
 void launch_colstats(const View& z, double* acc, hipStream_t s) { colstats_launch(0, z, nullptr, nullptr, 0, nullptr, acc, s); }
 void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View& z, const float* stats, double* acc, hipStream_t s) {
@@ -155,7 +159,7 @@ void launch_bn_stats_from_running(const float* running, float* stats, int C, hip
 // no per-element 64-bit divisions).  Every BatchNorm of the encoder qualifies; the generic path serves strided views.
 // rstats / rgamma / rbeta (optional): the residual is itself a BatchNorm output that is not materialised -- the 1x1 shortcut branch of a down-sampling block:
 // y = act(bn(z) + bn_r(res)) in ONE pass instead of bn_r -> buffer -> add
-template <bool FAST>
+template <bool FAST, bool BS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        View res, int has_res, int act, View y, const float* __restrict__ rstats, const float* __restrict__ rgamma, const float* __restrict__ rbeta) {
     const int Q = z.C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
@@ -165,24 +169,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __re
         float4 rm = make_float4(0.f, 0.f, 0.f, 0.f), ris = rm, rg = rm, rb = rm;
         if (rstats) { rm = ld4(rstats + q * 4); ris = ld4(rstats + z.C + q * 4); rg = ld4(rgamma + q * 4); rb = ld4(rbeta + q * 4); }
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-            const float4 v = ld4(z.p + i * 4);
+            const float4 v = vld4<BS>(z.p, i * 4);
             float4 o = make_float4(g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w);
             if (has_res) {
-                float4 rr = ld4(res.p + i * 4);
+                float4 rr = vld4<BS>(res.p, i * 4);
                 if (rstats) rr = make_float4(rg.x * ((rr.x - rm.x) * ris.x) + rb.x, rg.y * ((rr.y - rm.y) * ris.y) + rb.y, rg.z * ((rr.z - rm.z) * ris.z) + rb.z, rg.w * ((rr.w - rm.w) * ris.w) + rb.w);
                 o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
             }
             o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
-            st4(y.p + i * 4, o);
+            vst4<BS>(y.p, i * 4, o);
         }
         return;
     }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
-        const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
+        const float4 v = vld4<BS>(z.p, voff(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
         float4 o = make_float4(g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w);
         if (has_res) {
-            float4 rr = ld4(vptr(res, n, r) + q * 4);
+            float4 rr = vld4<BS>(res.p, voff(res, n, r) + q * 4);
             if (rstats) {
                 const float4 rm = ld4(rstats + q * 4), ris = ld4(rstats + z.C + q * 4), rg = ld4(rgamma + q * 4), rb = ld4(rbeta + q * 4);
                 rr = make_float4(rg.x * ((rr.x - rm.x) * ris.x) + rb.x, rg.y * ((rr.y - rm.y) * ris.y) + rb.y, rg.z * ((rr.z - rm.z) * ris.z) + rb.z, rg.w * ((rr.w - rm.w) * ris.w) + rb.w);
@@ -190,15 +194,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __re
             o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
         }
         o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
-        st4(vptrw(y, n, r) + q * 4, o);
+        vst4<BS>(y.p, voff(y, n, r) + q * 4, o);
     }
 }
 void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s,
                      const float* rstats, const float* rgamma, const float* rbeta) {
     const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(y) && (!residual || dense_view_h(*residual));
     const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
-    if (fast) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
+    if (fast) LAUNCH_BSP(z.bf, bn_apply_kernel, true, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
+    else LAUNCH_BSP(z.bf, bn_apply_kernel, false, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
 }
 
 // sums -> per-channel coefficients, once per BatchNorm (it used to be redone by every thread of the apply kernel): coef = m1 | m2 = sum g / count | sum g*xhat / count;
@@ -224,7 +228,7 @@ void launch_bn_bwd_finalize(const double* acc, int slots, int C, double count, f
 }
 // FAST also folds bn_bwd_finalize_kernel in: the first Q threads of every block sum the 8 slots of their channel quad (64 L2-resident doubles) into LDS, block 0
 // adds d gamma / d beta -- 19 launches of ~5 us fewer per step, which is what a batch-4 step is made of.  coef keeps receiving m1 | m2 (block 0) for callers that read it.
-template <bool FAST>
+template <bool FAST, bool BS>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, int has_yact, int act, View z, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            float* __restrict__ coef, View dz, const double* __restrict__ acc, int slots, double count,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -250,29 +254,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
         const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
         const float4 m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4), m1 = sm1[q], m2 = sm2[q];
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-            float4 g = ld4(dy.p + i * 4);
-            if (has_yact) { const float4 o = ld4(yact.p + i * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-            const float4 v = ld4(z.p + i * 4);
+            float4 g = vld4<BS>(dy.p, i * 4);
+            if (has_yact) { const float4 o = vld4<BS>(yact.p, i * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+            const float4 v = vld4<BS>(z.p, i * 4);
             float4 o;
             o.x = ga.x * is.x * (g.x - m1.x - (v.x - m.x) * is.x * m2.x);
             o.y = ga.y * is.y * (g.y - m1.y - (v.y - m.y) * is.y * m2.y);
             o.z = ga.z * is.z * (g.z - m1.z - (v.z - m.z) * is.z * m2.z);
             o.w = ga.w * is.w * (g.w - m1.w - (v.w - m.w) * is.w * m2.w);
-            st4(dz.p + i * 4, o);
+            vst4<BS>(dz.p, i * 4, o);
         }
         return;
     }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
-        float4 g = ld4(vptr(dy, n, r) + q * 4);
-        if (has_yact) { const float4 o = ld4(vptr(yact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        const float4 v = ld4(vptr(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4), m1 = ld4(coef + q * 4), m2 = ld4(coef + C + q * 4);
+        float4 g = vld4<BS>(dy.p, voff(dy, n, r) + q * 4);
+        if (has_yact) { const float4 o = vld4<BS>(yact.p, voff(yact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        const float4 v = vld4<BS>(z.p, voff(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4), m1 = ld4(coef + q * 4), m2 = ld4(coef + C + q * 4);
         float4 o;
         o.x = ga.x * is.x * (g.x - m1.x - (v.x - m.x) * is.x * m2.x);
         o.y = ga.y * is.y * (g.y - m1.y - (v.y - m.y) * is.y * m2.y);
         o.z = ga.z * is.z * (g.z - m1.z - (v.z - m.z) * is.z * m2.z);
         o.w = ga.w * is.w * (g.w - m1.w - (v.w - m.w) * is.w * m2.w);
-        st4(vptrw(dz, n, r) + q * 4, o);
+        vst4<BS>(dz.p, voff(dz, n, r) + q * 4, o);
     }
 }
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc, double count,
@@ -280,14 +284,15 @@ void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& 
     const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(dy) && dense_view_h(dz) && (!yact || dense_view_h(*yact));
     // (fast: every block re-derives its coefficients -- fewer, longer-lived blocks than the 4096 of the plain element kernels)
     const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, fast ? 2048 : 4096));
-    if (fast) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz, acc, slots, count, dgamma, dbeta);
+    if (fast) LAUNCH_BSP(z.bf, bn_bwd_apply_kernel, true, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz, acc, slots, count, dgamma, dbeta);
     else {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((z.C + 255) / 256), dim3(256), 0, s, acc, slots, z.C, count, coef, dgamma, dbeta, (const float*)nullptr, (const float*)nullptr);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz, acc, slots, count, dgamma, dbeta);
+        LAUNCH_BSP(z.bf, bn_bwd_apply_kernel, false, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz, acc, slots, count, dgamma, dbeta);
     }
 }
 
 // ---- MaxPool((3,3); pad=1, stride=2): first maximum in (kh,kw) scan order wins; the argmax tap (0..8) is kept ------------
+template <bool BS>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(View x, View y, uint8_t* __restrict__ arg) {
     const int Q = x.C / 4; const long total = y.pixels() * Q; const int HWo = y.H * y.W;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -299,21 +304,22 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(View x, View y, uint8_
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = ow * 2 - 1 + kw; if (iw < 0 || iw >= x.W) continue;
-                const float4 v = ld4(vptr(x, n, (long)ih * x.W + iw) + q * 4);
+                const float4 v = vld4<BS>(x.p, voff(x, n, (long)ih * x.W + iw) + q * 4);
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (vv[e] > best[e]) { best[e] = vv[e]; bi[e] = kh * 3 + kw; }
             }
         }
-        st4(vptrw(y, n, r) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
+        vst4<BS>(y.p, voff(y, n, r) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
         *reinterpret_cast<uchar4*>(arg + (p * x.C + q * 4)) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
     }
 }
 void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t s) {
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(y.pixels() * (x.C / 4), 256, 4096)), dim3(256), 0, s, x, y, arg);
+    LAUNCH_BS(x.bf, maxpool_fwd_kernel, dim3(grid_for(y.pixels() * (x.C / 4), 256, 4096)), dim3(256), 0, s, x, y, arg);
 }
 // Stem tail fused: a = relu(bn(z)) is never read back -- one pass computes the 3x3 / stride-2 max-pool of a on the fly from z, and writes a itself only for the
 // frames the depth decoder's skip connection needs (n % L == tgt; all frames when L == 1).  Replaces bn_apply (read z, write a) + maxpool_fwd (read a).
+template <bool BS>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               View a, int L, int tgt, View y, uint8_t* __restrict__ arg, int rpb) {
     const int Q = z.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
@@ -331,22 +337,22 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(View z, const floa
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = ow * 2 - 1 + kw; if (iw < 0 || iw >= z.W) continue;
-                const float4 v = ld4(vptr(z, n, (long)ih * z.W + iw) + q * 4);
+                const float4 v = vld4<BS>(z.p, voff(z, n, (long)ih * z.W + iw) + q * 4);
                 float vv[4] = {g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vv[e] = vv[e] > 0.f ? vv[e] : 0.f; if (vv[e] > best[e]) { best[e] = vv[e]; bi[e] = kh * 3 + kw; } }
-                if (wa && kh >= 1 && kw >= 1) st4(vptrw(a, n, (long)ih * z.W + iw) + q * 4, make_float4(vv[0], vv[1], vv[2], vv[3]));   // this output owns the 2x2 block (2oh.., 2ow..)
+                if (wa && kh >= 1 && kw >= 1) vst4<BS>(a.p, voff(a, n, (long)ih * z.W + iw) + q * 4, make_float4(vv[0], vv[1], vv[2], vv[3]));   // this output owns the 2x2 block (2oh.., 2ow..)
             }
         }
         const long r = (long)oh * y.W + ow;
-        st4(vptrw(y, n, r) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
+        vst4<BS>(y.p, voff(y, n, r) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
         *reinterpret_cast<uchar4*>(arg + (((long)n * y.H * y.W + r) * z.C + q * 4)) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
     }
 }
 void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s) {
     if ((z.H & 1) || (z.W & 1) || y.H != z.H / 2 || y.W != z.W / 2 || z.C % 4 != 0 || (256 % (z.C / 4)) != 0) { fprintf(stderr, "md2: bn_relu_maxpool: unsupported shape\n"); abort(); }
     const RowGrid rg = row_grid((long)y.N * y.H, y.W * (z.C / 4));
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, rg.grid, dim3(256), 0, s, z, stats, gamma, beta, a, L, tgt, y, arg, rg.rpb);
+    LAUNCH_BS(z.bf, bn_relu_maxpool_kernel, rg.grid, dim3(256), 0, s, z, stats, gamma, beta, a, L, tgt, y, arg, rg.rpb);
 }
 
 // gather form: input pixel (ih,iw) is covered by outputs oh in {(ih+1)/2 - (0|1)}...; no atomics, deterministic
@@ -354,6 +360,7 @@ void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamm
 // so the mask is read from the 4x smaller pooled tensor instead of the activations themselves
 // bz / bstat / bacc (optional): dx is the gradient of a BatchNorm output whose input is bz -- the kernel also accumulates that BatchNorm's pullback sums
 // (sum g, sum g*xhat per channel; needs 256 % (C/4) == 0 so that a thread keeps one channel quad) and the separate reduction pass over (g, z) goes away
+template <bool BS>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View yrelu, int has_yrelu,
                                                           View bz, const float* __restrict__ bstat, double* __restrict__ bacc, int acc_frame, int rpb) {
     const int Q = dx.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
@@ -378,19 +385,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t
                 if (b >= nw) break;
                 const long ro = (long)oh * dy.W + ows[b];
                 const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (((long)n * HWo + ro) * dx.C + q * 4));
-                float4 d = ld4(vptr(dy, n, ro) + q * 4);
-                if (has_yrelu) { const float4 o = ld4(vptr(yrelu, n, ro) + q * 4); d.x *= act_deriv(o.x, ACT_RELU); d.y *= act_deriv(o.y, ACT_RELU); d.z *= act_deriv(o.z, ACT_RELU); d.w *= act_deriv(o.w, ACT_RELU); }
+                float4 d = vld4<BS>(dy.p, voff(dy, n, ro) + q * 4);
+                if (has_yrelu) { const float4 o = vld4<BS>(yrelu.p, voff(yrelu, n, ro) + q * 4); d.x *= act_deriv(o.x, ACT_RELU); d.y *= act_deriv(o.y, ACT_RELU); d.z *= act_deriv(o.z, ACT_RELU); d.w *= act_deriv(o.w, ACT_RELU); }
                 const int tap = kh * 3 + kws[b];
                 if (a.x == tap) g[0] += d.x; if (a.y == tap) g[1] += d.y; if (a.z == tap) g[2] += d.z; if (a.w == tap) g[3] += d.w;
             }
         }
         const long r = (long)ih * dx.W + iw;
-        float* dp = vptrw(dx, n, r) + q * 4;
+        const long dpo = voff(dx, n, r) + q * 4;
         if (accumulate == 1 || (accumulate == 2 && (n % 3) == acc_frame)) {      // earlier contributions are already masked
-            const float4 o = ld4(dp); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
-        st4(dp, make_float4(g[0], g[1], g[2], g[3]));
+            const float4 o = vld4<BS>(dx.p, dpo); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
+        if constexpr (BS) { const float4 gr = bf16x4_unpack(bf16x4_pack(make_float4(g[0], g[1], g[2], g[3]))); g[0] = gr.x; g[1] = gr.y; g[2] = gr.z; g[3] = gr.w; }      // the sums below see the stored (rounded) gradient
+        vst4<BS>(dx.p, dpo, make_float4(g[0], g[1], g[2], g[3]));
         if (bacc) {
-            const float4 z = ld4(vptr(bz, n, r) + q * 4);
+            const float4 z = vld4<BS>(bz.p, voff(bz, n, r) + q * 4);
             s1.x += g[0]; s1.y += g[1]; s1.z += g[2]; s1.w += g[3];
             s2.x += g[0] * ((z.x - mu.x) * is.x); s2.y += g[1] * ((z.y - mu.y) * is.y); s2.z += g[2] * ((z.z - mu.z) * is.z); s2.w += g[3] * ((z.w - mu.w) * is.w);
         }
@@ -415,7 +423,7 @@ void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int 
     const int Q = dx.C / 4;
     if (bacc && (256 % Q != 0 || !bz)) { fprintf(stderr, "md2: maxpool_bwd: the fused BatchNorm sums need 256 %% (C/4) == 0\n"); abort(); }
     const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * Q);          // (with the fused sums every block ends in 2 C double atomics: ~8192 blocks measured best, B=32)
-    hipLaunchKernelGGL(maxpool_bwd_kernel, rg.grid, dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0,
+    LAUNCH_BS(dx.bf, maxpool_bwd_kernel, rg.grid, dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0,
                        bz ? *bz : dx, bstat, bacc, acc_frame, rg.rpb);
 }
 
@@ -427,6 +435,7 @@ __device__ __forceinline__ void up_src(int o, int in, int out, int& i0, int& i1,
     i1 = min(i0 + 1, in - 1);
     w1 = s - (float)i0;
 }
+template <bool BS>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y, int rpb) {
     const int Q = x.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= y.W * Q) return;
@@ -437,18 +446,18 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y, int
     for (int row = blockIdx.x * rpb; row < row_end; ++row) {
         const int n = row / y.H, oh = row - n * y.H;
         int h0, h1; float fh; up_src(oh, x.H, y.H, h0, h1, fh);      // the row taps are block-uniform
-        const float4 a = ld4(vptr(x, n, (long)h0 * x.W + w0) + q * 4), b = ld4(vptr(x, n, (long)h0 * x.W + w1) + q * 4);
-        const float4 c = ld4(vptr(x, n, (long)h1 * x.W + w0) + q * 4), d = ld4(vptr(x, n, (long)h1 * x.W + w1) + q * 4);
+        const float4 a = vld4<BS>(x.p, voff(x, n, (long)h0 * x.W + w0) + q * 4), b = vld4<BS>(x.p, voff(x, n, (long)h0 * x.W + w1) + q * 4);
+        const float4 c = vld4<BS>(x.p, voff(x, n, (long)h1 * x.W + w0) + q * 4), d = vld4<BS>(x.p, voff(x, n, (long)h1 * x.W + w1) + q * 4);
         const float gh = 1.f - fh;
         float4 o;
         o.x = gh * (gw * a.x + fw * b.x) + fh * (gw * c.x + fw * d.x); o.y = gh * (gw * a.y + fw * b.y) + fh * (gw * c.y + fw * d.y);
         o.z = gh * (gw * a.z + fw * b.z) + fh * (gw * c.z + fw * d.z); o.w = gh * (gw * a.w + fw * b.w) + fh * (gw * c.w + fw * d.w);
-        st4(vptrw(y, n, (long)oh * y.W + ow) + q * 4, o);
+        vst4<BS>(y.p, voff(y, n, (long)oh * y.W + ow) + q * 4, o);
     }
 }
 void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s) {
     const RowGrid rg = row_grid((long)y.N * y.H, y.W * (x.C / 4));
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, rg.grid, dim3(256), 0, s, x, y, rg.rpb);
+    LAUNCH_BS(x.bf, upsample2x_fwd_kernel, rg.grid, dim3(256), 0, s, x, y, rg.rpb);
 }
 // exact adjoint in gather form: every candidate output row/col recomputes the forward's (i0,i1,w1)
 // candidates of one axis: outputs o with a source index in (i-1, i+1), i.e. o in [(i-1) r, (i+1) r], r = (out-1)/(in-1); their adjoint weights (i0 == i ? 1 - f : 0) + (i1 == i ? f : 0).
@@ -481,6 +490,7 @@ __device__ __forceinline__ void up_adjoint_taps4(int i, int in, int out, int (&o
         cs[k] = s0 == 0 ? c6[k] : (s0 == 1 ? c6[k + 1] : c6[k + 2]);
     }
 }
+template <bool BS>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(View dy, View dx, View xact, int has_xact, int act, int rpb) {
     const int Q = dx.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= dx.W * Q) return;
@@ -499,25 +509,26 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(View dy, View dx, V
 #pragma unroll
             for (int b = 0; b < UP_MAXC; ++b) {
                 if (b >= nw) break;
-                const float4 d = ld4(vptr(dy, n, (long)ohs[a] * dy.W + ows[b]) + q * 4);
+                const float4 d = vld4<BS>(dy.p, voff(dy, n, (long)ohs[a] * dy.W + ows[b]) + q * 4);
                 const float c = chs[a] * cws[b];
                 g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w;
             }
         }
         const long r = (long)h * dx.W + w;
-        if (has_xact) { const float4 o = ld4(vptr(xact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        st4(vptrw(dx, n, r) + q * 4, g);
+        if (has_xact) { const float4 o = vld4<BS>(xact.p, voff(xact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        vst4<BS>(dx.p, voff(dx, n, r) + q * 4, g);
     }
 }
 void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int act, hipStream_t s) {
     if (dy.H > 2 * dx.H || dy.W > 2 * dx.W) { fprintf(stderr, "md2: upsample2x_bwd: ratio above 2\n"); abort(); }
     const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * (dx.C / 4));
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, rg.grid, dim3(256), 0, s, dy, dx, xact ? *xact : dx, xact ? 1 : 0, act, rg.rpb);
+    LAUNCH_BS(dx.bf, upsample2x_bwd_kernel, rg.grid, dim3(256), 0, s, dy, dx, xact ? *xact : dx, xact ? 1 : 0, act, rg.rpb);
 }
 
 // fold_reflect followed by the adjoint of the bilinear x2 (the two passes between a DecoderBlock's second convolution and its first on the way back, src/depth_decoder.jl:18-19,5):
 //   dx[h][w] = act'(xact) * sum over fine pixels (oh, ow) of the x2 adjoint weights * fold(sp)[oh][ow],   fold(sp)[oh][ow] = sum of the padded positions that mirror onto it.
 // One gather pass over the padded gradient instead of writing and re-reading the folded full-resolution tensor (109 + 109 + 109 MB for the last branch at batch 32).
+template <bool BS>
 __global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, View xact, int has_xact, int act, int rpb) {
     const int Q = dx.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= dx.W * Q) return;
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, Vie
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const float4 d = ld4(vptr(sp, n, (long)(ohs[a] + 1) * sp.W + ows[b] + 1) + q * 4);
+                const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)(ohs[a] + 1) * sp.W + ows[b] + 1) + q * 4);
                 const float c = chs[a] * cws[b];
                 g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w;
             }
@@ -555,15 +566,15 @@ __global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, Vie
                 for (int b = 0; b < 4; ++b) {
                     const int ox2 = cws[b] == 0.f ? -1 : (ows[b] == 1 ? 0 : (ows[b] == Wf - 2 ? Wf + 1 : -1));
                     const float c = chs[a] * cws[b];
-                    if (oy2 >= 0) { const float4 d = ld4(vptr(sp, n, (long)oy2 * sp.W + ows[b] + 1) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
-                    if (ox2 >= 0) { const float4 d = ld4(vptr(sp, n, (long)(ohs[a] + 1) * sp.W + ox2) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
-                    if (oy2 >= 0 && ox2 >= 0) { const float4 d = ld4(vptr(sp, n, (long)oy2 * sp.W + ox2) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
+                    if (oy2 >= 0) { const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)oy2 * sp.W + ows[b] + 1) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
+                    if (ox2 >= 0) { const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)(ohs[a] + 1) * sp.W + ox2) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
+                    if (oy2 >= 0 && ox2 >= 0) { const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)oy2 * sp.W + ox2) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
                 }
             }
         }
         const long r = (long)h * dx.W + w;
-        if (has_xact) { const float4 o = ld4(vptr(xact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        st4(vptrw(dx, n, r) + q * 4, g);
+        if (has_xact) { const float4 o = vld4<BS>(xact.p, voff(xact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        vst4<BS>(dx.p, voff(dx, n, r) + q * 4, g);
     }
 }
 void launch_fold_up2_bwd(const View& src_pad, const View& dx, const View* xact, int act, hipStream_t s) {
@@ -571,9 +582,10 @@ void launch_fold_up2_bwd(const View& src_pad, const View& dx, const View* xact, 
     // (maps of at least 4 x 4: on a 3-wide map both frame columns mirror onto column 1, which the one-extra-position bookkeeping above does not cover)
     if (Hf < 4 || Wf < 4 || Hf > 2 * dx.H || Wf > 2 * dx.W || src_pad.C < dx.C) { fprintf(stderr, "md2: fold_up2_bwd: unsupported shape\n"); abort(); }
     const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * (dx.C / 4));          // (more rows per thread were slower: the kernel lives on parallel gathers, 0.224 -> 0.306 ms at four rows)
-    hipLaunchKernelGGL(fold_up2_bwd_kernel, rg.grid, dim3(256), 0, s, src_pad, dx, xact ? *xact : dx, xact ? 1 : 0, act, rg.rpb);
+    LAUNCH_BS(dx.bf, fold_up2_bwd_kernel, rg.grid, dim3(256), 0, s, src_pad, dx, xact ? *xact : dx, xact ? 1 : 0, act, rg.rpb);
 }
 
+template <bool BS>
 __global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, int accumulate, View actsrc, int has_act, int act, int rpb) {
     const int Q = dst.C / 4, H = dst.H, W = dst.W, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= W * Q) return;
@@ -592,23 +604,24 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, in
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 if (b >= nx) break;
-                const float4 d = ld4(vptr(sp, n, (long)(uys[a] + 1) * sp.W + (uxs[b] + 1)) + q * 4);
+                const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)(uys[a] + 1) * sp.W + (uxs[b] + 1)) + q * 4);
                 g.x += d.x; g.y += d.y; g.z += d.z; g.w += d.w;
             }
         }
         const long r = (long)h * W + w;
-        float* dp = vptrw(dst, n, r) + q * 4;
-        if (accumulate) { const float4 o = ld4(dp); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
-        if (has_act) { const float4 o = ld4(vptr(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        st4(dp, g);
+        const long dpo = voff(dst, n, r) + q * 4;
+        if (accumulate) { const float4 o = vld4<BS>(dst.p, dpo); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+        if (has_act) { const float4 o = vld4<BS>(actsrc.p, voff(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        vst4<BS>(dst.p, dpo, g);
     }
 }
 void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, const View* actsrc, int act, hipStream_t s) {
     if (src_pad.H != dst.H + 2 || src_pad.W != dst.W + 2 || src_pad.C < dst.C) { fprintf(stderr, "md2: fold_reflect: shape mismatch\n"); abort(); }
     const RowGrid rg = row_grid((long)dst.N * dst.H, dst.W * (dst.C / 4));
-    hipLaunchKernelGGL(fold_reflect_kernel, rg.grid, dim3(256), 0, s, src_pad, dst, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act, rg.rpb);
+    LAUNCH_BS(dst.bf, fold_reflect_kernel, rg.grid, dim3(256), 0, s, src_pad, dst, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act, rg.rpb);
 }
 
+template <bool BS>
 __global__ __launch_bounds__(256) void axpy_view_kernel(View src, View dst, float a, int accumulate, View actsrc, int has_act, int act, int rpb) {
     const int Q = dst.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= dst.W * Q) return;
@@ -617,20 +630,21 @@ __global__ __launch_bounds__(256) void axpy_view_kernel(View src, View dst, floa
     for (int row = blockIdx.x * rpb; row < row_end; ++row) {
         const int n = row / dst.H, h = row - n * dst.H;
         const long r = (long)h * dst.W + w;
-        float4 g = ld4(vptr(src, n, r) + q * 4);
+        float4 g = vld4<BS>(src.p, voff(src, n, r) + q * 4);
         g.x *= a; g.y *= a; g.z *= a; g.w *= a;
-        if (has_act) { const float4 o = ld4(vptr(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        float* dp = vptrw(dst, n, r) + q * 4;
-        if (accumulate) { const float4 o = ld4(dp); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
-        st4(dp, g);
+        if (has_act) { const float4 o = vld4<BS>(actsrc.p, voff(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
+        const long dpo = voff(dst, n, r) + q * 4;
+        if (accumulate) { const float4 o = vld4<BS>(dst.p, dpo); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
+        vst4<BS>(dst.p, dpo, g);
     }
 }
 void launch_axpy_view(const View& src, const View& dst, float a, int accumulate, const View* actsrc, int act, hipStream_t s) {
     const RowGrid rg = row_grid((long)dst.N * dst.H, dst.W * (dst.C / 4));
-    hipLaunchKernelGGL(axpy_view_kernel, rg.grid, dim3(256), 0, s, src, dst, a, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act, rg.rpb);
+    LAUNCH_BS(dst.bf, axpy_view_kernel, rg.grid, dim3(256), 0, s, src, dst, a, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act, rg.rpb);
 }
 
 // ---- bias gradient: out[c] += sum over pixels -----------------------------------------------------------------------------
+template <bool BS>
 __global__ __launch_bounds__(256) void colsum_kernel(View v, float* __restrict__ out, int rows_per_block) {
     const int Q = v.C / 4, RG = 256 / Q;
     const int q = threadIdx.x % Q, rg = threadIdx.x / Q;
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(View v, float* __restrict__
     if (rg < RG)
         for (long p = p0 + rg; p < p1; p += RG) {
             const int n = p / HW; const long r = p - (long)n * HW;
-            const float4 x = ld4(vptr(v, n, r) + q * 4);
+            const float4 x = vld4<BS>(v.p, voff(v, n, r) + q * 4);
             s1.x += x.x; s1.y += x.y; s1.z += x.z; s1.w += x.w;
         }
     red[0 * 256 + threadIdx.x] = s1.x; red[1 * 256 + threadIdx.x] = s1.y; red[2 * 256 + threadIdx.x] = s1.z; red[3 * 256 + threadIdx.x] = s1.w;
@@ -657,20 +671,22 @@ void launch_colsum(const View& v, float* out, hipStream_t s) {
     const long P = v.pixels();
     int rpb = 2048; while (rpb > 64 && (P + rpb - 1) / rpb < 512) rpb >>= 1;
     if (g_deterministic) rpb = (int)std::min<long>(P, 1 << 30);
-    hipLaunchKernelGGL(colsum_kernel, dim3((int)((P + rpb - 1) / rpb)), dim3(256), 0, s, v, out, rpb);
+    LAUNCH_BS(v.bf, colsum_kernel, dim3((int)((P + rpb - 1) / rpb)), dim3(256), 0, s, v, out, rpb);
 }
 
 // ---- pose squeezer bookkeeping (src/model.jl:30-35, src/pose_decoder.jl:23-25): the 1x1 squeezer runs ONCE over all 3N frames (sq3 [3N][hw][256]); the pose decoder's input
 //      for source s is cat(frame fr[s][0], frame fr[s][1]) with (fr) = ((0,1),(1,2)): sqcat [2][N][hw][512].  Forward = gather, pullback = scatter-add (frame 1 is used twice).
 struct PoseFrames { int f[4]; };              // (first, second) frame of the pair of source 0, of source 1
+template <bool BS>
 __global__ __launch_bounds__(256) void pose_pairs_fwd_kernel(const float* __restrict__ sq3, float* __restrict__ sqcat, int N, int hw, PoseFrames pf) {
     const long total = (long)2 * N * hw * 128;                        // float4 slots of sqcat
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c4 = i % 128; const long r = i / 128; const int px = r % hw; const long sn = r / hw; const int n = sn % N, s = sn / N;
         const int j = c4 >> 6, fr = pf.f[2 * s + j];                  // default frames (0,1) for source 0, (1,2) for source 1
-        st4(sqcat + i * 4, ld4(sq3 + (((long)(n * 3 + fr) * hw + px) * 64 + (c4 & 63)) * 4));
+        vst4<BS>(sqcat, i * 4, vld4<BS>(sq3, (((long)(n * 3 + fr) * hw + px) * 64 + (c4 & 63)) * 4));
     }
 }
+template <bool BS>
 __global__ __launch_bounds__(256) void pose_pairs_bwd_kernel(const float* __restrict__ dsqcat, float* __restrict__ dsq3, int N, int hw, PoseFrames pf) {
     const long total = (long)3 * N * hw * 64;                          // float4 slots of dsq3
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -678,34 +694,36 @@ __global__ __launch_bounds__(256) void pose_pairs_bwd_kernel(const float* __rest
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);                    // a frame collects every use of it (the target frame is used by both pairs)
 #pragma unroll
         for (int sj = 0; sj < 4; ++sj)
-            if (pf.f[sj] == fr) { const float4 t = ld4(dsqcat + ((((long)((sj >> 1) * N + n) * hw + px) * 128) + (sj & 1) * 64 + c4) * 4); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
-        st4(dsq3 + i * 4, g);
+            if (pf.f[sj] == fr) { const float4 t = vld4<BS>(dsqcat, ((((long)((sj >> 1) * N + n) * hw + px) * 128) + (sj & 1) * 64 + c4) * 4); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+        vst4<BS>(dsq3, i * 4, g);
     }
 }
-void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, const int fr[4], hipStream_t s) { PoseFrames pf{{fr[0], fr[1], fr[2], fr[3]}}; hipLaunchKernelGGL(pose_pairs_fwd_kernel, dim3(grid_for((long)2 * N * hw * 128, 256, 2048)), dim3(256), 0, s, sq3, sqcat, N, hw, pf); }
-void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, const int fr[4], hipStream_t s) { PoseFrames pf{{fr[0], fr[1], fr[2], fr[3]}}; hipLaunchKernelGGL(pose_pairs_bwd_kernel, dim3(grid_for((long)3 * N * hw * 64, 256, 2048)), dim3(256), 0, s, dsqcat, dsq3, N, hw, pf); }
+void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, const int fr[4], hipStream_t s, int bf) { PoseFrames pf{{fr[0], fr[1], fr[2], fr[3]}}; LAUNCH_BS(bf, pose_pairs_fwd_kernel, dim3(grid_for((long)2 * N * hw * 128, 256, 2048)), dim3(256), 0, s, sq3, sqcat, N, hw, pf); }
+void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, const int fr[4], hipStream_t s, int bf) { PoseFrames pf{{fr[0], fr[1], fr[2], fr[3]}}; LAUNCH_BS(bf, pose_pairs_bwd_kernel, dim3(grid_for((long)3 * N * hw * 64, 256, 2048)), dim3(256), 0, s, dsqcat, dsq3, N, hw, pf); }
 
 // ---- pose head tail: mean over (W,H) * 0.01 (src/pose_decoder.jl:29-31); y view [B][h*w][>=6 channels] -------------------------
+template <bool BS>
 __global__ void pose_mean_fwd_kernel(View y, float* __restrict__ rvec, float* __restrict__ tvec) {
     const int b = blockIdx.x, c = threadIdx.x >> 5, l = threadIdx.x & 31;   // 6 channels x 32 lanes
     if (c >= 6) return;
     const int HW = y.H * y.W; float s = 0.f;
-    for (int r = l; r < HW; r += 32) s += y.p[(long)b * y.bs + (long)r * y.ps + c];
+    for (int r = l; r < HW; r += 32) s += vld1<BS>(y.p, (long)b * y.bs + (long)r * y.ps + c);
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (l == 0) { const float v = 0.01f * (s / (float)HW); if (c < 3) rvec[b * 3 + c] = v; else tvec[b * 3 + c - 3] = v; }
 }
-void launch_pose_mean_fwd(const View& y, float* rvec, float* tvec, hipStream_t s) { hipLaunchKernelGGL(pose_mean_fwd_kernel, dim3(y.N), dim3(192), 0, s, y, rvec, tvec); }
+void launch_pose_mean_fwd(const View& y, float* rvec, float* tvec, hipStream_t s) { LAUNCH_BS(y.bf, pose_mean_fwd_kernel, dim3(y.N), dim3(192), 0, s, y, rvec, tvec); }
+template <bool BS>
 __global__ void pose_mean_bwd_kernel(const float* __restrict__ drvec, const float* __restrict__ dtvec, View dy) {
     const int HW = dy.H * dy.W; const long total = (long)dy.N * HW * dy.C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = i % dy.C; const long pr = i / dy.C; const int r = pr % HW; const int b = pr / HW;
         float g = 0.f;
         if (c < 3) g = 0.01f * drvec[b * 3 + c] / (float)HW; else if (c < 6) g = 0.01f * dtvec[b * 3 + c - 3] / (float)HW;
-        dy.p[(long)b * dy.bs + (long)r * dy.ps + c] = g;
+        vst1<BS>(dy.p, (long)b * dy.bs + (long)r * dy.ps + c, g);
     }
 }
 void launch_pose_mean_bwd(const float* drvec, const float* dtvec, const View& dy, hipStream_t s) {
-    hipLaunchKernelGGL(pose_mean_bwd_kernel, dim3(grid_for((long)dy.N * dy.H * dy.W * dy.C, 256, 1024)), dim3(256), 0, s, drvec, dtvec, dy);
+    LAUNCH_BS(dy.bf, pose_mean_bwd_kernel, dim3(grid_for((long)dy.N * dy.H * dy.W * dy.C, 256, 1024)), dim3(256), 0, s, drvec, dtvec, dy);
 }
 
 // ---- Flux ADAM (beta 0.9/0.999, eps 1e-8): one fused pass over the flat parameter buffer ------------------------------------------
@@ -736,30 +754,39 @@ void launch_adam(float* p, const float* g, float* m, float* v, long n, float c1,
     const long rem = n - 4 * n4;                        // tail (or everything, for unaligned / tiny arrays such as a 3-vector pose)
     if (rem > 0) hipLaunchKernelGGL(adam_tail_kernel, dim3(grid_for(rem, 256, 4096)), dim3(256), 0, s, p + 4 * n4, g + 4 * n4, m + 4 * n4, v + 4 * n4, rem, c1, c2, lr, gscale);
 }
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) vst4<true>(reinterpret_cast<float*>(dst), i * 4, ld4(src + i * 4));
+}
+void launch_cast_bf16(const float* src, uint16_t* dst, long n, hipStream_t s) {
+    if (n & 3) { fprintf(stderr, "md2: cast_bf16: length must be a multiple of 4\n"); abort(); }
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, s, src, dst, n / 4);
+}
 __global__ void fill_kernel(float* p, long n, float v) { for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v; }
 void launch_fill(float* p, long n, float v, hipStream_t s) { hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, p, n, v); }
 
+template <bool BS>
 __global__ __launch_bounds__(256) void fill_view_kernel(View v, float val) {
     const int Q = v.C / 4; const long total = v.pixels() * Q; const int HW = v.H * v.W;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
-        st4(vptrw(v, n, r) + q * 4, make_float4(val, val, val, val));
+        vst4<BS>(v.p, voff(v, n, r) + q * 4, make_float4(val, val, val, val));
     }
 }
-void launch_fill_view(const View& v, float val, hipStream_t s) { hipLaunchKernelGGL(fill_view_kernel, dim3(grid_for(v.pixels() * (v.C / 4), 256, 4096)), dim3(256), 0, s, v, val); }
+void launch_fill_view(const View& v, float val, hipStream_t s) { LAUNCH_BS(v.bf, fill_view_kernel, dim3(grid_for(v.pixels() * (v.C / 4), 256, 4096)), dim3(256), 0, s, v, val); }
+template <bool BS>
 __global__ __launch_bounds__(256) void bias_act_view_kernel(View y, const float* __restrict__ bias, int act) {
     const int Q = y.C / 4; const long total = y.pixels() * Q; const int HW = y.H * y.W;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
-        float* yp = vptrw(y, n, r) + q * 4;
-        float4 v = ld4(yp);
+        const long ypo = voff(y, n, r) + q * 4;
+        float4 v = vld4<BS>(y.p, ypo);
         if (bias) { const float4 b = ld4(bias + q * 4); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
-        st4(yp, v);
+        vst4<BS>(y.p, ypo, v);
     }
 }
 void launch_bias_act_view(const View& y, const float* bias, int act, hipStream_t s) {
-    hipLaunchKernelGGL(bias_act_view_kernel, dim3(grid_for(y.pixels() * (y.C / 4), 256, 4096)), dim3(256), 0, s, y, bias, act);
+    LAUNCH_BS(y.bf, bias_act_view_kernel, dim3(grid_for(y.pixels() * (y.C / 4), 256, 4096)), dim3(256), 0, s, y, bias, act);
 }
 
 }  // namespace md2

@@ -55,6 +55,7 @@ struct md2_handle {
     float K[9], invK[9];
     long n_int = 0, n_flux = 0;
     float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *WD = nullptr;
+    bool bs = false; uint16_t *Pb = nullptr, *WDb = nullptr;      // precision 2: activations in bf16; bf16 copies of the weights, refreshed from P / WD once per step
     double beta1p = 1.0, beta2p = 1.0;
     ConvL stem; BNL stem_bn; Block blk[16]; int nblk = 8, depth = 18, bf16 = 0; int stages[5] = {64, 64, 128, 256, 512};
     ConvL dc1[5], dc2[5], head[5], squeeze, pose[3];
@@ -98,7 +99,16 @@ struct md2_handle {
         arena_off += count * sizeof(T);
         return p;
     }
-    View alloc_view(int n, int hh, int ww, int c) { return make_view(alloc<float>((size_t)n * hh * ww * c), n, hh, ww, c); }
+    // activation / gradient tensors: bf16 elements when the handle stores activations in bf16 (md2_config.precision = 2), else fp32
+    View alloc_view(int n, int hh, int ww, int c) {
+        if (bs) return make_view(reinterpret_cast<float*>(alloc<uint16_t>((size_t)n * hh * ww * c + 8)), n, hh, ww, c, 1);
+        return make_view(alloc<float>((size_t)n * hh * ww * c), n, hh, ww, c);
+    }
+    View alloc_view_f32(int n, int hh, int ww, int c) { return make_view(alloc<float>((size_t)n * hh * ww * c), n, hh, ww, c); }
+    View scratch_view(float* p, int n, int hh, int ww, int c) const { return make_view(p, n, hh, ww, c, bs ? 1 : 0); }          // a view of shared fp32-sized scratch in the handle's storage type
+    // convolution weights as the kernels of this handle read them: the fp32 master (P / WD) or its per-step bf16 copy (Pb / WDb)
+    const float* wfwd(long off) const { return bs ? reinterpret_cast<const float*>(Pb + off) : P + off; }
+    const float* wdg(long off) const { return bs ? reinterpret_cast<const float*>(WDb + off) : WD + off; }
     hipStream_t chain() const { return cur ? cur : stream; }
     void pbegin(int cls, double flops = 0, const char* desc = "", hipStream_t st = nullptr, bool own = false) { if (prof) { ProfEvt e; e.cls = cls; e.flops = flops; snprintf(e.desc, sizeof(e.desc), "%s", desc); (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); (void)hipEventRecord(e.a, own ? st : chain()); evts.push_back(e); } }
     void pend(hipStream_t st = nullptr, bool own = false) { if (prof) (void)hipEventRecord(evts.back().b, own ? st : chain()); }
@@ -196,16 +206,16 @@ static void plan_buffers(md2_handle* h) {
             static const bool no_fuse = getenv("MD2_NO_BN_FUSE") != nullptr;
             B.fuse = !no_fuse && conv_wgrad_supports_in_transform(hh, ww, co, co);        // conv2 and its weight gradient can fold bn1 + ReLU into their loaders at this size
             B.z1 = h->alloc_view(NL, hh, ww, co); B.z2 = h->alloc_view(NL, hh, ww, co);
-            B.a1 = B.fuse ? make_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co);      // fused: never materialised (the view only carries the shape)
+            B.a1 = B.fuse ? h->scratch_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co);      // fused: never materialised (the view only carries the shape)
         } else {
             const int pl = B.c1.cout, co = B.c3.cout;
             static const bool no_fuse = getenv("MD2_NO_BN_FUSE") != nullptr;
             B.fuse = !no_fuse;                // 1x1 and 3x3 loaders (forward and weight gradient) all take the BatchNorm + ReLU transform at these channel counts (multiples of 64)
-            B.z1 = h->alloc_view(NL, hi, wi, pl); B.a1 = B.fuse ? make_view(nullptr, NL, hi, wi, pl) : h->alloc_view(NL, hi, wi, pl);
-            B.z2 = h->alloc_view(NL, hh, ww, pl); B.a2 = B.fuse ? make_view(nullptr, NL, hh, ww, pl) : h->alloc_view(NL, hh, ww, pl); B.z3 = h->alloc_view(NL, hh, ww, co);
+            B.z1 = h->alloc_view(NL, hi, wi, pl); B.a1 = B.fuse ? h->scratch_view(nullptr, NL, hi, wi, pl) : h->alloc_view(NL, hi, wi, pl);
+            B.z2 = h->alloc_view(NL, hh, ww, pl); B.a2 = B.fuse ? h->scratch_view(nullptr, NL, hh, ww, pl) : h->alloc_view(NL, hh, ww, pl); B.z3 = h->alloc_view(NL, hh, ww, co);
         }
         const int co = B.bottleneck ? B.c3.cout : B.c1.cout;
-        if (B.down) { B.zd = h->alloc_view(NL, hh, ww, co); B.sd = B.fuse ? make_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co); }
+        if (B.down) { B.zd = h->alloc_view(NL, hh, ww, co); B.sd = B.fuse ? h->scratch_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co); }
         B.out = h->alloc_view(NL, hh, ww, co);
         cur = B.out;
         if (B.stage_end) h->feat[stage++] = B.out;
@@ -220,10 +230,10 @@ static void plan_buffers(md2_handle* h) {
         h->cat[b] = h->alloc_view(N, dh, dw, dec[b] + skc[b]);
         h->y2[b] = h->alloc_view(N, dh, dw, dec[b]);
         dxpad_max = std::max(dxpad_max, (size_t)N * (dh + 2) * (dw + 2) * (dec[b] + skc[b]));
-        if (h->out_of[b] >= 0) h->dispv[h->out_of[b]] = h->alloc_view(N, dh, dw, 1);
+        if (h->out_of[b] >= 0) h->dispv[h->out_of[b]] = h->alloc_view_f32(N, dh, dw, 1);          // (the loss reads the disparity maps: fp32 in every mode)
     }
     // a loss-only handle (H, W multiples of 8 but not of 32) has no decoder to derive the disparity sizes from: the loss reads / writes H >> (3 - l) x W >> (3 - l)
-    if (!h->net_ok) for (int l = 0; l < h->ns; ++l) h->dispv[l] = h->alloc_view(N, H >> (5 - h->lv[l]), W >> (5 - h->lv[l]), 1);
+    if (!h->net_ok) for (int l = 0; l < h->ns; ++l) h->dispv[l] = h->alloc_view_f32(N, H >> (5 - h->lv[l]), W >> (5 - h->lv[l]), 1);
     const int ph = H / 32, pw = W / 32;
     h->sq3 = h->alloc_view(3 * N, ph, pw, 256); h->dsq3 = h->alloc_view(3 * N, ph, pw, 256);
     h->sqcat = h->alloc_view(2 * N, ph, pw, 512); h->py1 = h->alloc_view(2 * N, ph, pw, 256); h->py2 = h->alloc_view(2 * N, ph, pw, 256); h->py3 = h->alloc_view(2 * N, ph, pw, 16);
@@ -301,14 +311,14 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
 }
 // forward conv (kind 0) on views.  x.C must equal c.cinP, y.C == c.coutP
 static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act, double* bn_stats = nullptr) {
-    ConvArgs a = conv_args(x, h->P + c.w, y, c.k, c.stride, padmode == PAD_REFLECT ? 1 : c.pad, 1, padmode);
+    ConvArgs a = conv_args(x, h->wfwd(c.w), y, c.k, c.stride, padmode == PAD_REFLECT ? 1 : c.pad, 1, padmode);
     a.bias = c.bias ? h->P + c.b : nullptr; a.act = act; a.stats = h->testmode ? nullptr : bn_stats;
     a.wino_u = c.uf >= 0 ? h->UF + c.uf : nullptr; a.wino_pieces = wino_resolve_pieces(h->u_pieces_f, a.Cin);
     run_igemm(h, a);
 }
 // input gradient: dy (view of the conv output) -> dx view (dims of the conv input; or of the PADDED input for reflect convs)
 static ConvArgs dgrad_args(md2_handle* h, const ConvL& c, const View& dy, const View& dx, int pad_fwd, int accumulate, const View* dact_src, int dact, const View* res = nullptr) {
-    ConvArgs a = conv_args(dy, h->WD + c.w, dx, c.k, 1, c.k - 1 - pad_fwd, c.stride, PAD_ZERO);
+    ConvArgs a = conv_args(dy, h->wdg(c.w), dx, c.k, 1, c.k - 1 - pad_fwd, c.stride, PAD_ZERO);
     a.accumulate = accumulate; a.acc_frame = h->tgt;
     a.wino_u = c.ud >= 0 ? h->UD + c.ud : nullptr; a.wino_pieces = wino_resolve_pieces(h->u_pieces_d, a.Cin);
     if (dact_src) { a.dact_src = dact_src->p; a.da_bs = dact_src->bs; a.da_ps = dact_src->ps; a.dact = dact; }
@@ -397,7 +407,7 @@ static void pose_forward(md2_handle* h, int N) {
     // then the two temporally ordered pairs are gathered: (f1, f2) for source 1, (f2, f3) for source 3 (src/model.jl:30-35)
     View sq3 = h->sq3; sq3.N = 3 * N;
     conv_fwd(h, h->squeeze, h->feat[4], sq3, PAD_ZERO, ACT_RELU);
-    launch_pose_pairs_fwd(h->sq3.p, h->sqcat.p, N, h->sq3.H * h->sq3.W, h->pose_fr, h->chain());
+    launch_pose_pairs_fwd(h->sq3.p, h->sqcat.p, N, h->sq3.H * h->sq3.W, h->pose_fr, h->chain(), h->bs);
     conv_fwd(h, h->pose[0], h->sqcat, h->py1, PAD_ZERO, ACT_RELU);
     conv_fwd(h, h->pose[1], h->py1, h->py2, PAD_ZERO, ACT_RELU);
     conv_fwd(h, h->pose[2], h->py2, h->py3, PAD_ZERO, ACT_NONE);
@@ -412,6 +422,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
     if (tgt < 0) tgt = h->tgt;                  // triplets: the configured target frame
     const int NL = h->z0.N, N = NL / L, H = h->H, W = h->W;
     if (!wino_on_side) refresh_wino_fwd(h, s);          // (md2_train_loss runs it on the side stream, overlapping the stem)
+    if (h->bs) launch_cast_bf16(h->P, h->Pb, h->n_int, s);          // this step's bf16 copy of the forward weights (the stem and the heads read the fp32 master)
     // every double accumulator of the step in ONE memset: forward statistics | pullback sums | loss partials | pose-gradient sums are adjacent (plan_buffers).  A training
     // step says so up front (acc_zeroed), and its loss / pullback-preparation phases skip their own memsets.
     HIPCHK(hipMemsetAsync(h->acc_all, 0, (h->acc_zeroed ? h->acc_count : h->acc_fwd_count) * sizeof(double), s));
@@ -431,14 +442,14 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
         if (B.fuse) {
             conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_stats(h, B.b1, B.z1);
             {   // conv2 gathers relu(bn1(z1)) straight from z1
-                ConvArgs a = conv_args(B.z1, h->P + B.c2.w, B.z2, B.c2.k, B.c2.stride, B.c2.pad, 1, PAD_ZERO);
+                ConvArgs a = conv_args(B.z1, h->wfwd(B.c2.w), B.z2, B.c2.k, B.c2.stride, B.c2.pad, 1, PAD_ZERO);
                 a.in_scale = B.b1.stats + 2 * B.b1.c; a.in_shift = B.b1.stats + 3 * B.b1.c; a.stats = h->testmode ? nullptr : B.b2.acc;
                 a.wino_u = B.c2.uf >= 0 ? h->UF + B.c2.uf : nullptr; a.wino_pieces = wino_resolve_pieces(h->u_pieces_f, a.Cin);
                 run_igemm(h, a);
             }
             bn_stats(h, B.b2, B.z2);
             if (B.bottleneck) {           // ... and the 1x1 conv3 gathers relu(bn2(z2)) from z2
-                ConvArgs a = conv_args(B.z2, h->P + B.c3.w, B.z3, B.c3.k, B.c3.stride, B.c3.pad, 1, PAD_ZERO);
+                ConvArgs a = conv_args(B.z2, h->wfwd(B.c3.w), B.z3, B.c3.k, B.c3.stride, B.c3.pad, 1, PAD_ZERO);
                 a.in_scale = B.b2.stats + 2 * B.b2.c; a.in_shift = B.b2.stats + 3 * B.b2.c; a.stats = h->testmode ? nullptr : B.b3.acc;
                 run_igemm(h, a);
                 bn_stats(h, B.b3, B.z3);
@@ -546,7 +557,7 @@ static void pose_backward(md2_handle* h, int N, int part) {
     }
     // squeezer: scatter-add the pair gradients back onto the 3N frames (frame 2 collects both of its uses), then ONE weight gradient and ONE input gradient.
     // Gfeat[4]: frames 1 and 3 get exactly this contribution (overwrite), frame 2 adds to the depth decoder's (accumulate mode 2)
-    launch_pose_pairs_bwd(h->dsq.p, h->dsq3.p, N, h->dsq3.H * h->dsq3.W, h->pose_fr, h->chain());
+    launch_pose_pairs_bwd(h->dsq.p, h->dsq3.p, N, h->dsq3.H * h->dsq3.W, h->pose_fr, h->chain(), h->bs);
     conv_wgrad(h, h->squeeze, h->feat[4], h->dsq3, PAD_ZERO);
     conv_dgrad(h, h->squeeze, h->dsq3, h->Gfeat[4], 0, 2, &h->feat[4], ACT_RELU);
 }
@@ -559,6 +570,7 @@ static void pose_backward(md2_handle* h, int N, int part) {
 // runs it on the (otherwise idle) second stream while the forward pass computes; without that stream it runs at the head of backward.
 static int backward_prepare(md2_handle* h, hipStream_t s) {
     launch_weight_prepare(h->P, h->WD, h->wdesc_dev, h->n_wdesc, h->n_wblocks, h->G, h->n_int, s);          // transposed / flipped weight copies + the zeroed gradient buffer, one launch
+    if (h->bs) launch_cast_bf16(h->WD, h->WDb, h->n_int, s);
     if (!h->acc_zeroed) HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
     h->u_pieces_d = g_wino_pieces;
     launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions
@@ -609,7 +621,7 @@ static int model_backward(md2_handle* h) {
         // gA[b] now holds d loss / d (pre-ELU output of c2[b])
         const View& dZ2 = h->gA[b];
         conv_wgrad(h, h->dc2[b], h->cat[b], dZ2, PAD_REFLECT);
-        View dcp = make_view(h->dxpad, N, h->cat[b].H + 2, h->cat[b].W + 2, h->cat[b].C);
+        View dcp = h->scratch_view(h->dxpad, N, h->cat[b].H + 2, h->cat[b].W + 2, h->cat[b].C);
         conv_dgrad(h, h->dc2[b], dZ2, dcp, 0, 0, nullptr, ACT_NONE);
         const int dc = h->y1[b].C;
         if (b < 4) {
@@ -621,7 +633,7 @@ static int model_backward(md2_handle* h) {
         else { launch_fold_reflect(chan_slice(dcp, 0, dc), h->dupv[b], 0, nullptr, ACT_NONE, s); launch_upsample2x_bwd(h->dupv[b], h->dZ1[b], &h->y1[b], ACT_ELU, s); }
         const View& in = (b == 0) ? frame_view(h->feat[4], 3, h->tgt) : h->y2[b - 1];
         conv_wgrad(h, h->dc1[b], in, h->dZ1[b], PAD_REFLECT);
-        View dip = make_view(h->dxpad, N, in.H + 2, in.W + 2, in.C);
+        View dip = h->scratch_view(h->dxpad, N, in.H + 2, in.W + 2, in.C);
         conv_dgrad(h, h->dc1[b], h->dZ1[b], dip, 0, 0, nullptr, ACT_NONE);
         if (b == 0) { View fv = frame_view(h->feat[4], 3, h->tgt), gv = frame_view(h->Gfeat[4], 3, h->tgt); launch_fold_reflect(dip, gv, 0, &fv, ACT_RELU, s); }   // first writer of Gfeat[4] frame 1
         else launch_fold_reflect(dip, h->gA[b - 1], h->out_of[b - 1] >= 0 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);        // (adds to the head's contribution where branch b-1 has one)
@@ -646,7 +658,7 @@ static int model_backward(md2_handle* h) {
         const View& Gout = h->Gblk[i];                                  // d / d(pre-ReLU block output), already masked
         const View* Gin = (i == 0) ? &h->Gpool : &h->Gblk[i - 1];
         const View* in_act = (i == 0) ? nullptr : &B.in;                 // ReLU mask of the block input (stage 0: applied in the maxpool pullback)
-        const View& dz1 = B.dz1; View da1 = make_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C);
+        const View& dz1 = B.dz1; View da1 = h->scratch_view(h->E2, NL, B.a1.H, B.a1.W, B.a1.C);
         // first encoder writer of Gin: own buffers (and the pool gradient) are overwritten; stage buffers already hold the decoder's contribution in the target frames
         // (a stage whose skip connection the decoder does not reach -- scale_levels ending below 5 -- has no such contribution: plain overwrite)
         const int first_mode = (i == 0 || !h->blk[i - 1].stage_end || !stage_used[stage_below[i]]) ? 0 : 2;
@@ -654,7 +666,7 @@ static int model_backward(md2_handle* h) {
         Block* Bp = (i > 0 && h->blk[i - 1].fuse) ? &h->blk[i - 1] : nullptr;
         if (B.fuse) {
             if (B.bottleneck) {
-                View da2 = make_view(h->E3, NL, B.a2.H, B.a2.W, B.a2.C);
+                View da2 = h->scratch_view(h->E3, NL, B.a2.H, B.a2.W, B.a2.C);
                 bn_bwd(h, B.b3, Gout, B.z3, B.dz3, sums_ready[i]);
                 conv_wgrad(h, B.c3, B.z2, B.dz3, PAD_ZERO, &B.b2);           // x = relu(bn2(z2)) formed in the loader
                 ConvArgs a = dgrad_args(h, B.c3, B.dz3, da2, 0, 0, &B.z2, ACT_RELU);       // da2 = (W3^T dz3) * relu'(bn2(z2)) + the sums of bn2's pullback
@@ -689,7 +701,7 @@ static int model_backward(md2_handle* h) {
             conv_wgrad(h, B.c2, B.a1, B.dz2, PAD_ZERO);
             conv_dgrad(h, B.c2, B.dz2, da1, 1, 0, &B.a1, ACT_RELU);
         } else {
-            View da2 = make_view(h->E3, NL, B.a2.H, B.a2.W, B.a2.C);
+            View da2 = h->scratch_view(h->E3, NL, B.a2.H, B.a2.W, B.a2.C);
             bn_bwd(h, B.b3, Gout, B.z3, B.dz3);
             conv_wgrad(h, B.c3, B.a2, B.dz3, PAD_ZERO);
             conv_dgrad(h, B.c3, B.dz3, da2, 0, 0, &B.a2, ACT_RELU);
@@ -809,7 +821,7 @@ static int validate_cfg(const md2_config* cfg) {
         g_create_err = "md2_create: need batch >= 1, channels in {1,3}, height/width multiples of 8 and >= 16 (multiples of 32 and >= 64 for the network)"; return 2;
     }
     if (cfg->encoder_depth != 0 && cfg->encoder_depth != 18 && cfg->encoder_depth != 50) { g_create_err = "md2_create: encoder_depth must be 18 (or 0) or 50"; return 2; }
-    if (cfg->precision != 0 && cfg->precision != 1) { g_create_err = "md2_create: precision must be 0 (fp32) or 1 (bf16 mixed precision)"; return 2; }
+    if (cfg->precision < 0 || cfg->precision > 2) { g_create_err = "md2_create: precision must be 0 (fp32), 1 (bf16 MFMA operands, fp32 tensors) or 2 (bf16 activation tensors)"; return 2; }
     {   // shape limits of the kernels (32-bit byte offsets inside one activation tensor, 24-bit pixel counts in the weight gradients): refuse here, with a
         // status code, instead of aborting inside a launcher in the middle of a step
         const double px_half = 3.0 * cfg->batch * (cfg->height / 2.0) * (cfg->width / 2.0);          // pixels of the largest activation (stem output, 64 channels)
@@ -855,6 +867,11 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     const size_t pb = (size_t)h->n_int * sizeof(float);
     if (hipMalloc((void**)&h->P, pb) != hipSuccess || hipMalloc((void**)&h->G, pb) != hipSuccess || hipMalloc((void**)&h->M, pb) != hipSuccess ||
         hipMalloc((void**)&h->V, pb) != hipSuccess || hipMalloc((void**)&h->WD, pb) != hipSuccess) return fail("hipMalloc(params) failed");
+    if (h->bs) {          // bf16 copies of the forward / input-gradient weights (+ 64 elements: the paired-tap loader of the 16-channel layers reads one tap past a weight row)
+        const size_t hb = ((size_t)h->n_int + 64) * sizeof(uint16_t);
+        if (hipMalloc((void**)&h->Pb, hb) != hipSuccess || hipMalloc((void**)&h->WDb, hb) != hipSuccess) return fail("hipMalloc(bf16 weights) failed");
+        (void)hipMemset(h->Pb, 0, hb); (void)hipMemset(h->WDb, 0, hb);
+    }
     (void)hipMemset(h->P, 0, pb); (void)hipMemset(h->G, 0, pb); (void)hipMemset(h->M, 0, pb); (void)hipMemset(h->V, 0, pb); (void)hipMemset(h->WD, 0, pb);
     (void)hipMemset(h->arena, 0, need);
     {   // BatchNorm running statistics: Flux initialises mu = 0, sigma^2 = 1
@@ -907,7 +924,7 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
 // the handle's host-side description of a configuration (no device work): sizes, frame roles, scale levels -- what build_layers needs
 static void apply_cfg(md2_handle* h, const md2_config* cfg) {
     h->cfg = *cfg; h->N = cfg->batch; h->NL = 3 * cfg->batch; h->C = cfg->channels; h->H = cfg->height; h->W = cfg->width;
-    h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision == 1;
+    h->depth = cfg->encoder_depth == 50 ? 50 : 18; h->bf16 = cfg->precision; h->bs = cfg->precision == 2;
     {   // TrainCache.target_id / source_ids (1-based at the boundary; validated above)
         const int t = cfg->target_id ? cfg->target_id : 2, s0 = cfg->source_ids[0] ? cfg->source_ids[0] : (cfg->source_ids[1] ? 0 : 1), s1 = cfg->source_ids[1] ? cfg->source_ids[1] : (cfg->source_ids[0] ? 0 : 3);
         h->tgt = t - 1; h->src[0] = s0 - 1; h->src[1] = s1 - 1;
@@ -936,7 +953,7 @@ static void destroy_handle(md2_handle* h) {          // also the failure path of
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     hipStream_t sts[] = {h->s2, h->s3, h->s4, h->scomm};
     for (hipStream_t st : sts) if (st) (void)hipStreamDestroy(st);
-    (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD); (void)hipFree(h->RS);
+    (void)hipFree(h->wdesc_dev); (void)hipFree(h->arena); (void)hipFree(h->P); (void)hipFree(h->G); (void)hipFree(h->M); (void)hipFree(h->V); (void)hipFree(h->WD); (void)hipFree(h->Pb); (void)hipFree(h->WDb); (void)hipFree(h->RS);
     (void)hipFree(h->UF); (void)hipFree(h->UD); (void)hipFree(h->udesc_f); (void)hipFree(h->udesc_d);
     delete h;
 }

@@ -43,14 +43,42 @@ enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
 
 // NHWC view: element (n,h,w,c) at p[n*bs + (h*W + w)*ps + c]
+// bf: the elements are bf16 (2 bytes; md2_config.precision = 2, "bf16 activation storage"): p is then the BYTE address of element 0 typed as float* only nominally, every
+// offset stays in ELEMENTS and the kernels go through vld4 / vst4 below.  0 = fp32 elements (everything else in the library).
 struct View {
-    float* p = nullptr; int N = 0, H = 0, W = 0, C = 0; long bs = 0; int ps = 0;
+    float* p = nullptr; int N = 0, H = 0, W = 0, C = 0; long bs = 0; int ps = 0; int bf = 0;
     __host__ __device__ long pixels() const { return (long)N * H * W; }
 };
-inline View make_view(float* p, int N, int H, int W, int C) { View v; v.p = p; v.N = N; v.H = H; v.W = W; v.C = C; v.ps = C; v.bs = (long)H * W * C; return v; }
-inline View chan_slice(const View& v, int c0, int c) { View r = v; r.p = v.p + c0; r.C = c; return r; }
+inline View make_view(float* p, int N, int H, int W, int C, int bf = 0) { View v; v.p = p; v.N = N; v.H = H; v.W = W; v.C = C; v.ps = C; v.bs = (long)H * W * C; v.bf = bf; return v; }
+inline float* view_at(const View& v, long elem) { return reinterpret_cast<float*>(reinterpret_cast<char*>(v.p) + elem * (v.bf ? 2 : 4)); }
+inline View chan_slice(const View& v, int c0, int c) { View r = v; r.p = view_at(v, c0); r.C = c; return r; }
 // frame l of a [N*L] batch (batch index n*L + l)
-inline View frame_view(const View& v, int L, int l) { View r = v; r.p = v.p + (long)l * v.bs; r.N = v.N / L; r.bs = v.bs * L; return r; }
+inline View frame_view(const View& v, int L, int l) { View r = v; r.p = view_at(v, (long)l * v.bs); r.N = v.N / L; r.bs = v.bs * L; return r; }
+
+// ---- element access of an activation tensor, fp32 or bf16 storage (BS).  `base` is the tensor's address, `off` an ELEMENT offset (a multiple of 4 for the quads);
+//      bf16 stores round to nearest even (v_cvt_pk_bf16_f32), loads are exact (a bf16 is the upper half of the fp32 with the same value)
+#ifdef __HIPCC__
+__device__ __forceinline__ float4 bf16x4_unpack(uint2 u) { return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)); }
+__device__ __forceinline__ unsigned bf16x2_pack(float a, float b) { typedef __bf16 b2 __attribute__((ext_vector_type(2))); b2 h; h[0] = (__bf16)a; h[1] = (__bf16)b; return __builtin_bit_cast(unsigned, h); }
+__device__ __forceinline__ uint2 bf16x4_pack(float4 v) { return make_uint2(bf16x2_pack(v.x, v.y), bf16x2_pack(v.z, v.w)); }
+template <bool BS> __device__ __forceinline__ float4 vld4(const float* base, long off) {
+    if constexpr (BS) return bf16x4_unpack(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off));
+    else return *reinterpret_cast<const float4*>(base + off);
+}
+template <bool BS> __device__ __forceinline__ void vst4(float* base, long off, float4 v) {
+    if constexpr (BS) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = bf16x4_pack(v);
+    else *reinterpret_cast<float4*>(base + off) = v;
+}
+template <bool BS> __device__ __forceinline__ float vld1(const float* base, long off) {
+    if constexpr (BS) return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(base)[off] << 16);
+    else return base[off];
+}
+template <bool BS> __device__ __forceinline__ void vst1(float* base, long off, float v) {
+    if constexpr (BS) { const __bf16 h = (__bf16)v; reinterpret_cast<unsigned short*>(base)[off] = __builtin_bit_cast(unsigned short, h); }
+    else base[off] = v;
+}
+__device__ __forceinline__ long voff(const View& v, int n, long r) { return (long)n * v.bs + r * v.ps; }
+#endif
 
 __host__ __device__ inline int refl_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
@@ -96,6 +124,8 @@ struct ConvArgs {
     double* stats;
     // bf16 mixed precision (md2_config.precision = 1): the operands of the 32x32 MFMA tiles are rounded to bf16 on their way from LDS to the
     // matrix pipe (v_cvt_pk_bf16_f32 + v_mfma_f32_32x32x16_bf16); accumulation, storage, weights and every other kernel stay fp32
+    // 2 (md2_config.precision = 2, bf16 activation storage): x / y / res / dact_src / bz are bf16 tensors and `w` a bf16 copy of the weights; a K-step is then 32 channels
+    // (the same 64 bytes per pixel row), two v_mfma_f32_32x32x16_bf16 (or one 16x16x32) per tile pair; fp32 accumulation, bias, statistics and split-K workspace
     int bf16;
     // ---- BatchNorm folded into the neighbouring convolutions (the activation a = relu(bn(z)) between two encoder convs is never materialised) ----
     // input transform: the gathered operand is relu(x * in_scale[ci] + in_shift[ci]) (zero padding applies AFTER it); null = the raw tensor
@@ -211,13 +241,15 @@ void launch_axpy_view(const View& src, const View& dst, float a, int accumulate,
 void launch_colsum(const View& v, float* out, hipStream_t s);
 // pose squeezer: sq3 [3N][hw][256] (all frames, squeezed once) <-> sqcat [2][N][hw][512] (the temporally ordered pairs of both sources); the pullback adds frame 1's two uses
 // fr[4] = the two (first, second) frame pairs, temporally ordered: {a0, b0, a1, b1} (0-based; src/model.jl:30-35)
-void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, const int fr[4], hipStream_t s);
-void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, const int fr[4], hipStream_t s);
+void launch_pose_pairs_fwd(const float* sq3, float* sqcat, int N, int hw, const int fr[4], hipStream_t s, int bf = 0);      // bf: the tensors hold bf16 elements
+void launch_pose_pairs_bwd(const float* dsqcat, float* dsq3, int N, int hw, const int fr[4], hipStream_t s, int bf = 0);
 // pose head: y [B][HW][16] -> rvec/tvec [B][3] = 0.01 * mean ; and its adjoint
 void launch_pose_mean_fwd(const View& y, float* rvec, float* tvec, hipStream_t s);
 void launch_pose_mean_bwd(const float* drvec, const float* dtvec, const View& dy, hipStream_t s);
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float c1, float c2, float lr, float gscale, hipStream_t s);
 void launch_fill(float* p, long n, float v, hipStream_t s);
+// dst[i] = bf16(src[i]) (round to nearest even): the per-step bf16 copies of the weights when activations are stored in bf16
+void launch_cast_bf16(const float* src, uint16_t* dst, long n, hipStream_t s);
 void launch_fill_view(const View& v, float val, hipStream_t s);
 // y = act(y + bias[c])   (second pass of a split-K convolution)
 void launch_bias_act_view(const View& y, const float* bias, int act, hipStream_t s);

@@ -42,7 +42,7 @@ __device__ __forceinline__ void stem_load_patch(float* Ps, const float* __restri
 // ------------------------------------------------------------------------------------------------------------
 // forward: block = 8 x 32 output pixels of one image x all 64 channels; wave w owns tile rows 2w, 2w+1
 // ------------------------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool BS = false>          // BS: z is a bf16 tensor
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, View z, int H, int W, int Kpad,
                                                        double* __restrict__ stats, int tiles_x, int tiles_y, int total_tiles) {
     constexpr int K = 49 * C, KP = (K + 1) & ~1, TH = 8, PR = 2 * TH + 5, NP = (C * PR * S_PC + 255) / 256;
@@ -113,12 +113,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
             const int oy = y0 + 2 * wave + j;
             valid[j] = (oy < z.H && ox < z.W) ? 1.f : 0.f;
             if (valid[j] == 0.f) continue;
-            float* zp = z.p + (long)n * z.bs + ((long)oy * z.W + ox) * z.ps;
+            const long zo = (long)n * z.bs + ((long)oy * z.W + ox) * z.ps;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(zp + i * 32 + 8 * g + 4 * half) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    vst4<BS>(z.p, zo + i * 32 + 8 * g + 4 * half, v);
+                }
         }
         // BatchNorm batch statistics of this tile (same halving butterfly as conv_igemm_kernel's epilogue; ragged-tile pixels are masked)
         if (stats) {
@@ -158,19 +160,22 @@ void launch_stem_fwd(const float* x, int NL, int C, int H, int W, const float* w
     int& pc = per_cu[C == 3];
     const void* fn = C == 1 ? reinterpret_cast<const void*>(&stem_fwd_kernel<1>) : reinterpret_cast<const void*>(&stem_fwd_kernel<3>);
     if (!pc) {
+        (void)hipFuncSetAttribute(C == 1 ? reinterpret_cast<const void*>(&stem_fwd_kernel<1, true>) : reinterpret_cast<const void*>(&stem_fwd_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, fn, 256, lds) != hipSuccess || pc < 1) pc = 1;
         pc = std::min(pc, 4);
     }
     const dim3 grid(std::min(total, 256 * pc));                        // persistent: the co-resident blocks
-    if (C == 1) hipLaunchKernelGGL(stem_fwd_kernel<1>, grid, dim3(256), lds, s, x, w, z, H, W, Kpad, stats, tiles_x, tiles_y, total);
-    else hipLaunchKernelGGL(stem_fwd_kernel<3>, grid, dim3(256), lds, s, x, w, z, H, W, Kpad, stats, tiles_x, tiles_y, total);
+    if (z.bf) { if (C == 1) hipLaunchKernelGGL((stem_fwd_kernel<1, true>), grid, dim3(256), lds, s, x, w, z, H, W, Kpad, stats, tiles_x, tiles_y, total);
+                else hipLaunchKernelGGL((stem_fwd_kernel<3, true>), grid, dim3(256), lds, s, x, w, z, H, W, Kpad, stats, tiles_x, tiles_y, total); }
+    else if (C == 1) hipLaunchKernelGGL((stem_fwd_kernel<1>), grid, dim3(256), lds, s, x, w, z, H, W, Kpad, stats, tiles_x, tiles_y, total);
+    else hipLaunchKernelGGL((stem_fwd_kernel<3>), grid, dim3(256), lds, s, x, w, z, H, W, Kpad, stats, tiles_x, tiles_y, total);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // weight gradient: persistent blocks walk 4 x 32 pixel tiles; wave w contracts tile row w (16 steps of 2 pixels); blockIdx.y selects 64 k's
 // ------------------------------------------------------------------------------------------------------------
-template <int C, bool FUSE>
+template <int C, bool FUSE, bool BS = false>          // BS: dz (and zbn) are bf16 tensors
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, View dz, float* __restrict__ dw, int H, int W, int Kpad,
                                                          int tiles_x, int tiles_y, int total_tiles, View zbn, const float* __restrict__ coef) {
     constexpr int K = 49 * C, TH = 4, PR = 2 * TH + 5, NP = (C * PR * S_PC + 255) / 256;
@@ -233,14 +238,20 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
                 const float v = xn[((long)c * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)];
                 pv[i] = ok ? v : 0.f;
             }
-            const float* dn = dz.p + (long)n * dz.bs;
+            const long dn = (long)n * dz.bs;
             yok = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int f = tid + 256 * i, px = f >> 4, q = f & 15, oy = ty * TH + (px >> 5), ox = tx * S_TW + (px & 31);
                 yok |= ((oy < dz.H && ox < dz.W) ? 1u : 0u) << i;
-                yv[i] = *reinterpret_cast<const u32x4*>(dn + ((long)min(oy, dz.H - 1) * dz.W + min(ox, dz.W - 1)) * dz.ps + q * 4);
-                if constexpr (FUSE) zv[i] = *reinterpret_cast<const f32x4v*>(zbn.p + (long)n * zbn.bs + ((long)min(oy, dz.H - 1) * dz.W + min(ox, dz.W - 1)) * zbn.ps + q * 4);
+                {
+                    const float4 f = vld4<BS>(dz.p, dn + ((long)min(oy, dz.H - 1) * dz.W + min(ox, dz.W - 1)) * dz.ps + q * 4);
+                    yv[i] = u32x4{__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)};
+                }
+                if constexpr (FUSE) {
+                    const float4 f = vld4<BS>(zbn.p, (long)n * zbn.bs + ((long)min(oy, dz.H - 1) * dz.W + min(ox, dz.W - 1)) * zbn.ps + q * 4);
+                    zv[i] = f32x4v{f.x, f.y, f.z, f.w};
+                }
             }
         }
         if (s < 0) continue;
@@ -298,6 +309,14 @@ void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& 
     const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * pc / kgroups));       // persistent: the co-resident blocks, shared by the k groups
     const View zz = fuse ? *zbn : dz;
     if (fuse && (zz.C != 64 || zz.H != dz.H || zz.W != dz.W || zz.N != dz.N || zz.ps % 4 != 0)) { fprintf(stderr, "md2: stem_wgrad: BatchNorm input view mismatch\n"); abort(); }
+    if (dz.bf != zz.bf) { fprintf(stderr, "md2: stem_wgrad: dz and the BatchNorm input share a storage type\n"); abort(); }
+    if (dz.bf) {
+        if (C == 1) { if (fuse) hipLaunchKernelGGL((stem_wgrad_kernel<1, true, true>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef);
+                      else hipLaunchKernelGGL((stem_wgrad_kernel<1, false, true>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef); }
+        else { if (fuse) hipLaunchKernelGGL((stem_wgrad_kernel<3, true, true>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef);
+               else hipLaunchKernelGGL((stem_wgrad_kernel<3, false, true>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef); }
+        return;
+    }
     if (C == 1) { if (fuse) hipLaunchKernelGGL((stem_wgrad_kernel<1, true>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef);
                   else hipLaunchKernelGGL((stem_wgrad_kernel<1, false>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef); }
     else { if (fuse) hipLaunchKernelGGL((stem_wgrad_kernel<3, true>), dim3(gx, kgroups), dim3(256), lds, s, x, dz, dw, H, W, Kpad, tiles_x, tiles_y, total, zz, coef);

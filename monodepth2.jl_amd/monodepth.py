@@ -277,6 +277,9 @@ class PoseDecoder:
         self.encoder_out_channels = encoder_out_channels
 
 
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16_storage": 2}          # md2_config.precision
+
+
 class Model:
     """Model(encoder, depth_decoder, pose_decoder); `model(x, source_ids, target_id)` -> (disparities, poses).
 
@@ -286,8 +289,9 @@ class Model:
         self.encoder, self.depth_decoder, self.pose_decoder = encoder, depth_decoder, pose_decoder
         if tuple(depth_decoder.encoder_channels) != tuple(encoder.stages) or pose_decoder.encoder_out_channels != encoder.stages[-1]:
             raise ValueError("decoder channels do not match the encoder's stages")
-        if precision not in ("f32", "bf16"):
-            raise ValueError("precision must be 'f32' (the reference's) or 'bf16' (mixed: bf16 MFMA operands, fp32 everything else)")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be 'f32' (the reference's), 'bf16' (mixed: bf16 MFMA operands, fp32 everything else) or 'bf16_storage' (activations and their gradients "
+                             "stored in bf16, bf16 weight copies for the convolutions; fp32 master weights, accumulation, BatchNorm statistics, loss and ADAM)")
         self._h = None
         self.lr, self.precision = lr, precision
         self._shape = None
@@ -345,7 +349,7 @@ class Model:
         state = self._opt_and_bn_state() if self._h is not None else None
         self.close()
         cfg = _lib.Md2Config(N, Cc, H, W, int(extra["automasking"]), x.device.index or 0, extra["min_depth"], extra["max_depth"], extra["disparity_smoothness"], self.lr,
-                             self.encoder.depth, 1 if self.precision == "bf16" else 0, int(extra["target_id"]), (C.c_int32 * 2)(*extra["source_ids"]),
+                             self.encoder.depth, PRECISIONS[self.precision], int(extra["target_id"]), (C.c_int32 * 2)(*extra["source_ids"]),
                              (C.c_int32 * 5)(*self.depth_decoder.scale_levels), (C.c_double * 5)(*(extra["scales"] or ())))
         h = C.c_void_p()
         _check(_lib.lib().md2_create(C.byref(cfg), C.byref(h)), None, "md2_create")
