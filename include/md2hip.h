@@ -232,6 +232,9 @@ int32_t md2_conv2d_fwd(const float* x, const float* w, const float* b, float* y,
 /* pullbacks wrt input / weights / bias of the conv above (act = none); any of dx,dw,db may be NULL */
 int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin,
                        int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t pad_mode, void* stream);
+/* Test switch (process-wide): 1 = md2_conv2d_fwd / md2_conv2d_bn_fwd / md2_conv2d_bwd run the kernels of md2_config.precision = 2 -- x, y, dy, dx as bf16 tensors, bf16 weight
+ * copies, fp32 accumulation -- so that each of them can be held against a plain fp32 reference of the op on bf16-rounded inputs; 0 (default) = fp32 tensors.  Returns 2 on any other value. */
+int32_t md2_set_op_storage(int32_t bf16);
 /* The encoder's conv -> BatchNorm pair (ResNet.jl via src/model.jl:14): bias-free convolution whose epilogue also accumulates the training-BatchNorm batch
  * statistics; bn_mean / bn_invstd [Cout] = mean and 1/sqrt(biased var + 1e-5) over (N,H,W) of y */
 int32_t md2_conv2d_bnstats_fwd(const float* x, const float* w, float* y, float* bn_mean, float* bn_invstd, int32_t N, int32_t Cin, int32_t H, int32_t W,

@@ -98,6 +98,7 @@ _SIGS = {
     "md2_bn_state_get": (I32, [P, P, I64]),
     "md2_bn_state_set": (I32, [P, P, I64]),
     "md2_set_deterministic": (I32, [I32]),
+    "md2_set_op_storage": (I32, [I32]),
     "md2_set_winograd": (I32, [I32, I32]),
     "md2_set_conv_products": (I32, [I32, I32]),
     "md2_get_conv_products": (I32, [C.POINTER(I32), C.POINTER(I32)]),

@@ -1817,6 +1817,179 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
         atomicAdd(a.dw + ((long)co * 9 + t) * a.Cin + ci, red[i]);
     }
 }
+// ------------------------------------------------------------------------------------------------------------
+// The all-taps weight gradient for bf16 TENSORS (WgradArgs::bf16 == 2): same block / tile scheme as conv3x3_wgrad_taps32_kernel, but the LDS tiles are bf16 and
+// CHANNEL-major, so that an MFMA operand -- 8 consecutive pixels of one channel -- is ONE ds_read_b128 instead of eight scalar reads and four packs:
+//   Ys[32 co][4 rows x 32 px], Xs[32 ci][6 rows x 40 px]; the three column taps of a patch row come out of one 16-pixel window (two reads): kw = 0 its first 8 pixels,
+//   kw = 2 the same registers one dword on, kw = 1 four v_alignbyte.  Per 16-pixel chunk a wave issues 7 reads + 12 vector instructions for its 9 MFMAs (the fp32-tile kernel:
+//   80 reads + 40 packs).  The transpose happens once, on the way in: a thread loads the same 4 channels of two neighbouring pixels (2 x 8 B) and writes 4 dwords.
+//   Bank layout: a channel row is an odd number of 16-B groups (8 consecutive channels -> 8 different groups for the b128 reads), and the group index is XORed with
+//   2 * bit 3 of the channel so that the 8 channel quads of a wave's dword writes fall on four different bank octets.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WB_YW = 32, WB_XW = 40;                               // pixels per tile row / patch row held in LDS (multiples of 8; TW <= 32, TW + 2 <= 34, the window reaches pixel 39)
+constexpr int WB_YCH = (4 * WB_YW / 8 + 1) * 16, WB_XCH = (32 + 1) * 16;          // bytes per channel row: 16 (32: 6 x 5 = 30 used) pixel groups + one pad group
+__device__ __forceinline__ int wb_addr(int c, int p, int chs) { return c * chs + (((p >> 3) ^ (((c >> 3) & 1) << 1)) << 4) + ((p & 7) << 1); }
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs a, int TW, int tiles_x, int tiles_y, int total_tiles, int ci_groups) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    char* Ys = wsm; char* Xs = wsm + 32 * WB_YCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 31, lp = lane >> 5;
+    const int cgi = blockIdx.y % ci_groups, cgo = blockIdx.y / ci_groups;
+    const int PW = TW + 2;
+    f32x16 acc[9];
+    float bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int i = tid; i < (32 * WB_YCH + 32 * WB_XCH) / 16; i += 256) reinterpret_cast<uint4*>(wsm)[i] = make_uint4(0u, 0u, 0u, 0u);      // columns the loader never writes are read as operands of masked pixels: finite
+
+    // loader slots: (row, column pair, channel quad); x patch 6 x 18 x 8 = 864 (4 per thread, the last partly), dy 4 x 16 x 8 = 512 (2 per thread)
+    constexpr int NX = 4, NY = 2, XSLOTS = 6 * 18 * 8;
+    uint2 xv[NX][2], yv[NY][2];
+    unsigned okb = 0;                              // bit 2 i + j: pixel j of x slot i is inside the image; bit 16 + 2 i + j: dy
+    const int q = tid & 7;
+    const bool xf = a.in_scale != nullptr;
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xf) { xsc = *reinterpret_cast<const float4*>(a.in_scale + cgi * 32 + q * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + cgi * 32 + q * 4); }
+    const unsigned short* xg = reinterpret_cast<const unsigned short*>(a.x); const unsigned short* dg = reinterpret_cast<const unsigned short*>(a.dy);
+    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int s = -1; s < my_tiles; ++s) {
+        if (s >= 0) {
+            __syncthreads();                       // the previous tile's MFMAs are done reading LDS (and the zero fill is complete)
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int slot = tid + 256 * i;
+                if (slot < XSLOTS) {
+                    const int rc = slot >> 3, row = rc / 18, cp = rc - row * 18;
+                    uint2 p0 = xv[i][0], p1 = xv[i][1];
+                    if (xf) {
+                        const float4 f0 = bf16x4_unpack(p0), f1 = bf16x4_unpack(p1);
+                        p0 = make_uint2(bf16x2_pack(fmaxf(fmaf(f0.x, xsc.x, xsh.x), 0.f), fmaxf(fmaf(f0.y, xsc.y, xsh.y), 0.f)), bf16x2_pack(fmaxf(fmaf(f0.z, xsc.z, xsh.z), 0.f), fmaxf(fmaf(f0.w, xsc.w, xsh.w), 0.f)));
+                        p1 = make_uint2(bf16x2_pack(fmaxf(fmaf(f1.x, xsc.x, xsh.x), 0.f), fmaxf(fmaf(f1.y, xsc.y, xsh.y), 0.f)), bf16x2_pack(fmaxf(fmaf(f1.z, xsc.z, xsh.z), 0.f), fmaxf(fmaf(f1.w, xsc.w, xsh.w), 0.f)));
+                    }
+                    const unsigned m0 = 0u - ((okb >> (2 * i)) & 1u), m1 = 0u - ((okb >> (2 * i + 1)) & 1u);
+                    p0.x &= m0; p0.y &= m0; p1.x &= m1; p1.y &= m1;
+                    const int pp = row * WB_XW + 2 * cp;
+                    *reinterpret_cast<unsigned*>(Xs + wb_addr(4 * q + 0, pp, WB_XCH)) = (p0.x & 0xFFFFu) | (p1.x << 16);
+                    *reinterpret_cast<unsigned*>(Xs + wb_addr(4 * q + 1, pp, WB_XCH)) = (p0.x >> 16) | (p1.x & 0xFFFF0000u);
+                    *reinterpret_cast<unsigned*>(Xs + wb_addr(4 * q + 2, pp, WB_XCH)) = (p0.y & 0xFFFFu) | (p1.y << 16);
+                    *reinterpret_cast<unsigned*>(Xs + wb_addr(4 * q + 3, pp, WB_XCH)) = (p0.y >> 16) | (p1.y & 0xFFFF0000u);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NY; ++i) {
+                const int slot = tid + 256 * i, cp = (slot >> 3) & 15, row = slot >> 7;
+                uint2 p0 = yv[i][0], p1 = yv[i][1];
+                const unsigned m0 = 0u - ((okb >> (16 + 2 * i)) & 1u), m1 = 0u - ((okb >> (17 + 2 * i)) & 1u);
+                p0.x &= m0; p0.y &= m0; p1.x &= m1; p1.y &= m1;
+                const int pp = row * WB_YW + 2 * cp;
+                *reinterpret_cast<unsigned*>(Ys + wb_addr(4 * q + 0, pp, WB_YCH)) = (p0.x & 0xFFFFu) | (p1.x << 16);
+                *reinterpret_cast<unsigned*>(Ys + wb_addr(4 * q + 1, pp, WB_YCH)) = (p0.x >> 16) | (p1.x & 0xFFFF0000u);
+                *reinterpret_cast<unsigned*>(Ys + wb_addr(4 * q + 2, pp, WB_YCH)) = (p0.y & 0xFFFFu) | (p1.y << 16);
+                *reinterpret_cast<unsigned*>(Ys + wb_addr(4 * q + 3, pp, WB_YCH)) = (p0.y >> 16) | (p1.y & 0xFFFF0000u);
+            }
+            __syncthreads();
+        }
+        if (s + 1 < my_tiles) {
+            const int tile = blockIdx.x + (s + 1) * gridDim.x;
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+            const long xin = (long)n * a.x_bs + cgi * 32 + q * 4, dyin = (long)n * a.dy_bs + cgo * 32 + q * 4;
+            okb = 0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int slot = min(tid + 256 * i, XSLOTS - 1), rc = slot >> 3, row = rc / 18, cp = rc - row * 18;
+                int ih = ty * 4 - a.pad + row;
+                if (a.padmode == PAD_REFLECT) ih = refl_idx(max(min(ih, a.H), -1), a.H);
+                const bool hok = ih >= 0 && ih < a.H;
+                const long rowoff = xin + (long)min(max(ih, 0), a.H - 1) * a.W * a.x_ps;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = 2 * cp + j;
+                    int iw = tx * TW - a.pad + col;
+                    if (a.padmode == PAD_REFLECT) iw = refl_idx(max(min(iw, a.W), -1), a.W);
+                    const bool ok = hok && iw >= 0 && iw < a.W && col < PW;
+                    okb |= (ok ? 1u : 0u) << (2 * i + j);
+                    xv[i][j] = *reinterpret_cast<const uint2*>(xg + rowoff + (long)min(max(iw, 0), a.W - 1) * a.x_ps);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NY; ++i) {
+                const int slot = tid + 256 * i, cp = (slot >> 3) & 15, row = slot >> 7;
+                const int oy = ty * 4 + row;
+                const long rowoff = dyin + (long)min(oy, a.Ho - 1) * a.Wo * a.dy_ps;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = 2 * cp + j, ox = tx * TW + col;
+                    okb |= ((oy < a.Ho && col < TW && ox < a.Wo) ? 1u : 0u) << (16 + 2 * i + j);
+                    yv[i][j] = *reinterpret_cast<const uint2*>(dg + rowoff + (long)min(ox, a.Wo - 1) * a.dy_ps);
+                }
+            }
+        }
+        if (s < 0) continue;
+        // ---- wave w contracts tile row w: 16 pixels per MFMA, lane half lp takes pixels 8 lp .. 8 lp + 7 of the chunk
+        const int nch = (TW + 15) >> 4;
+        for (int ch = 0; ch < nch; ++ch) {
+            const uint4 av = *reinterpret_cast<const uint4*>(Ys + wb_addr(lcol, wave * WB_YW + 16 * ch + 8 * lp, WB_YCH));
+            if (a.db) {
+                const float4 lo = bf16x4_unpack(make_uint2(av.x, av.y)), hi = bf16x4_unpack(make_uint2(av.z, av.w));
+                bsum += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+            }
+            const bf16x8 A = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int pb = (wave + kh) * WB_XW + 16 * ch + 8 * lp;
+                const uint4 d0 = *reinterpret_cast<const uint4*>(Xs + wb_addr(lcol, pb, WB_XCH)), d1 = *reinterpret_cast<const uint4*>(Xs + wb_addr(lcol, pb + 8, WB_XCH));
+                const uint4 b1 = make_uint4(__builtin_amdgcn_alignbyte(d0.y, d0.x, 2), __builtin_amdgcn_alignbyte(d0.z, d0.y, 2), __builtin_amdgcn_alignbyte(d0.w, d0.z, 2), __builtin_amdgcn_alignbyte(d1.x, d0.w, 2));
+                const uint4 b2 = make_uint4(d0.y, d0.z, d0.w, d1.x);
+                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, d0), acc[kh * 3 + 0], 0, 0, 0);
+                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b1), acc[kh * 3 + 1], 0, 0, 0);
+                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b2), acc[kh * 3 + 2], 0, 0, 0);
+            }
+        }
+    }
+    if (a.db && cgi == 0) {                        // one block column per output-channel group owns the bias gradient
+        bsum += __shfl_xor(bsum, 32);
+        if (lp == 0) atomicAdd(a.db + cgo * 32 + lcol, bsum);
+    }
+    // ---- reduce the 4 waves' accumulators through LDS, then one atomic per weight and block (as conv3x3_wgrad_taps32_kernel)
+    float* red = reinterpret_cast<float*>(wsm);    // [9*16][64 lanes]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* dst = red + (t * 16 + e) * 64 + lane;
+                    *dst = w == 0 ? acc[t][e] : *dst + acc[t][e];
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * 16 * 64; i += 256) {
+        const int ln = i & 63, e = (i >> 6) & 15, t = i >> 10;
+        const int co = cgo * 32 + (e >> 2) * 8 + (ln >> 5) * 4 + (e & 3), ci = cgi * 32 + (ln & 31);     // 32x32 D layout
+        atomicAdd(a.dw + ((long)co * 9 + t) * a.Cin + ci, red[i]);
+    }
+}
+static void launch_wgrad_taps_bs(const WgradArgs& a, hipStream_t s) {
+    const int tiles_x = (a.Wo + 31) / 32;
+    int TW = (a.Wo + tiles_x - 1) / tiles_x; TW += TW & 1;                                  // even, <= 32, least padding
+    const int tiles_y = (a.Ho + 3) / 4;
+    const size_t lds = (size_t)std::max(32 * WB_YCH + 32 * WB_XCH, 9 * 16 * 64 * 4);
+    static int per_cu = 0;
+    if (!per_cu) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps_bs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_taps_bs_kernel), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        per_cu = std::min(per_cu, 2);
+        if (getenv("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("MD2_TAPS_PER_CU"))));
+    }
+    const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
+    const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));
+    hipLaunchKernelGGL(conv3x3_wgrad_taps_bs_kernel, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
+}
+
 static bool wgrad_taps32_eligible(const WgradArgs& a) {
     static const int off = getenv("MD2_NO_TAPS_WGRAD") ? 1 : 0;
     if (off) return false;
@@ -1824,6 +1997,8 @@ static bool wgrad_taps32_eligible(const WgradArgs& a) {
            a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.Ho >= 2 && a.Wo >= 8;
 }
 static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
+    static const bool no_bs_taps = getenv("MD2_NO_BS_TAPS") != nullptr;
+    if (a.bf16 == 2 && !no_bs_taps) { launch_wgrad_taps_bs(a, s); return; }          // bf16 tensors: channel-major bf16 LDS tiles
     const int tiles_x = (a.Wo + WT_MAXW - 1) / WT_MAXW;
     int TW = (a.Wo + tiles_x - 1) / tiles_x; TW += TW & 1;                                  // even, <= 32, least padding
     const int tiles_y = (a.Ho + 3) / 4;

@@ -1145,6 +1145,19 @@ int32_t md2_profile_dump(md2_handle* h, const char* path) {
 // ---- op-level layer entry points (NCHW in / out; converted to NHWC views in temporaries) ----------------------------------
 static float* tmp_alloc(size_t n, hipStream_t s) { float* p = nullptr; if (hipMallocAsync((void**)&p, n * sizeof(float), s) != hipSuccess) return nullptr; (void)hipMemsetAsync(p, 0, n * sizeof(float), s); return p; }
 static int pad16(int c) { return (c + 15) / 16 * 16; }
+// md2_set_op_storage(): the op-level convolution entry points (md2_conv2d_fwd / md2_conv2d_bn_fwd / md2_conv2d_bwd) run on bf16 TENSORS with bf16 weight copies -- the kernels
+// of md2_config.precision = 2 -- so that tests can hold each of them against a plain fp32 reference of the same op.  Process-wide, 0 = fp32 tensors (default).
+static int g_op_bs = 0;
+int32_t md2_set_op_storage(int32_t bf16) { if (bf16 != 0 && bf16 != 1) return 2; g_op_bs = bf16; return 0; }
+static int padc(int c) { return g_op_bs ? (c <= 16 ? 16 : (c + 31) / 32 * 32) : pad16(c); }          // bf16 tensors: 16 channels (paired taps) or a multiple of 32 (64-byte K-steps)
+static const float* op_weights(const float* w_f32, size_t n, hipStream_t s) {          // bf16 tensors: a bf16 copy of the (internal-layout) weights, + 64 elements the paired-tap loader may read past a row
+    if (!g_op_bs) return w_f32;
+    uint16_t* wb = nullptr; const size_t n4 = (n + 3) / 4 * 4;
+    if (hipMallocAsync((void**)&wb, (n4 + 64) * sizeof(uint16_t), s) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(wb, 0, (n4 + 64) * sizeof(uint16_t), s);
+    launch_cast_bf16(w_f32, wb, (long)(n / 4 * 4), s);
+    return reinterpret_cast<const float*>(wb);
+}
 // weights Flux [Cout][Cin][k][k] (device) -> internal [CoutP][taps][CinP] (device) via host
 static int upload_weights(const float* w_dev, float* w_int, int cin, int cout, int k, int cinP, int coutP, hipStream_t s) {
     std::vector<float> f((size_t)cin * cout * k * k), in((size_t)coutP * k * k * cinP, 0.f);
@@ -1156,20 +1169,21 @@ static int upload_weights(const float* w_dev, float* w_int, int cin, int cout, i
 }
 static int conv2d_fwd_impl(const float* x, const float* w, const float* b, float* y, float* bn_mean, float* bn_invstd, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad,
                            int32_t pad_mode, int32_t act, hipStream_t s) {
-    const int cinP = pad16(Cin), coutP = pad16(Cout);
+    const int cinP = padc(Cin), coutP = padc(Cout), bs = g_op_bs;
     const int p_eff = pad_mode == PAD_REFLECT ? 1 : pad;
     const int Ho = (H + 2 * p_eff - k) / stride + 1, Wo = (W + 2 * p_eff - k) / stride + 1;
     float *xi = tmp_alloc((size_t)N * H * W * cinP, s), *wi = tmp_alloc((size_t)coutP * k * k * cinP, s), *yi = tmp_alloc((size_t)N * Ho * Wo * coutP, s), *bi = tmp_alloc(coutP, s);
     float* st = bn_mean ? tmp_alloc(2 * coutP, s) : nullptr; double* acc = bn_mean ? (double*)tmp_alloc((size_t)4 * BN_STAT_SLOTS * coutP, s) : nullptr;
     if (!xi || !wi || !yi || !bi || (bn_mean && (!st || !acc))) return 3;
-    View xv = make_view(xi, N, H, W, cinP), yv = make_view(yi, N, Ho, Wo, coutP);
+    View xv = make_view(xi, N, H, W, cinP, bs), yv = make_view(yi, N, Ho, Wo, coutP, bs);
     View xs = xv; xs.C = Cin; launch_nchw_to_view(x, xs, s);
     if (upload_weights(w, wi, Cin, Cout, k, cinP, coutP, s)) return 1;
     if (b) (void)hipMemcpyAsync(bi, b, Cout * sizeof(float), hipMemcpyDeviceToDevice, s);
-    ConvArgs a = conv_args(xv, wi, yv, k, stride, p_eff, 1, pad_mode);
+    const float* wk = op_weights(wi, (size_t)coutP * k * k * cinP, s); if (!wk) return 3;
+    ConvArgs a = conv_args(xv, wk, yv, k, stride, p_eff, 1, pad_mode); a.bf16 = bs ? 2 : 0;
     a.bias = b ? bi : nullptr; a.act = act; a.stats = acc;          // stats: fused into the epilogue of the 32-wide tiles, a column-statistics pass otherwise
     float* uw = nullptr;                                            // 3x3 / stride 1: the Winograd operand, as a handle keeps it per layer
-    if (k == 3 && stride == 1 && coutP % 32 == 0) { uw = tmp_alloc(conv_wino_u_floats(coutP, cinP), s); if (!uw) return 3; launch_wino_weights(wi, uw, coutP, cinP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
+    if (k == 3 && stride == 1 && coutP % 32 == 0 && !bs) { uw = tmp_alloc(conv_wino_u_floats(coutP, cinP), s); if (!uw) return 3; launch_wino_weights(wi, uw, coutP, cinP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
     // a split-K workspace like a handle's, so that the op-level tests drive the same reduce pass (bias / activation / statistics) the training step uses on small maps
     const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
     float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
@@ -1182,6 +1196,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* b, float
         (void)hipFreeAsync(st, s); (void)hipFreeAsync(acc, s);
     }
     View ys = yv; ys.C = Cout; launch_nhwc_to_nchw(nullptr, ys, y, s);
+    if (wk != wi) (void)hipFreeAsync(const_cast<float*>(wk), s);
     (void)hipFreeAsync(xi, s); (void)hipFreeAsync(wi, s); (void)hipFreeAsync(yi, s); (void)hipFreeAsync(bi, s);
     return hipGetLastError() != hipSuccess;
 }
@@ -1198,13 +1213,13 @@ int32_t md2_conv2d_bnstats_fwd(const float* x, const float* w, float* y, float* 
 int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride,
                        int32_t pad, int32_t pad_mode, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    const int cinP = pad16(Cin), coutP = pad16(Cout);
+    const int cinP = padc(Cin), coutP = padc(Cout), bs = g_op_bs;
     const int p_eff = pad_mode == PAD_REFLECT ? 1 : pad;
     const int Ho = (H + 2 * p_eff - k) / stride + 1, Wo = (W + 2 * p_eff - k) / stride + 1;
     const size_t wn = (size_t)coutP * k * k * cinP;
     float *xi = tmp_alloc((size_t)N * H * W * cinP, s), *wi = tmp_alloc(wn, s), *wd = tmp_alloc(wn, s), *gi = tmp_alloc(wn, s), *dyi = tmp_alloc((size_t)N * Ho * Wo * coutP, s), *gb = tmp_alloc(coutP, s);
     if (!xi || !wi || !wd || !gi || !dyi || !gb) return 3;
-    View xv = make_view(xi, N, H, W, cinP), dyv = make_view(dyi, N, Ho, Wo, coutP);
+    View xv = make_view(xi, N, H, W, cinP, bs), dyv = make_view(dyi, N, Ho, Wo, coutP, bs);
     View xs = xv; xs.C = Cin; launch_nchw_to_view(x, xs, s);
     View ds = dyv; ds.C = Cout; launch_nchw_to_view(dy, ds, s);
     if (upload_weights(w, wi, Cin, Cout, k, cinP, coutP, s)) return 1;
@@ -1212,19 +1227,20 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         launch_weight_to_dgrad(wi, wd, coutP, cinP, k * k, s);
         const int Hp = pad_mode == PAD_REFLECT ? H + 2 : H, Wp = pad_mode == PAD_REFLECT ? W + 2 : W;
         float* dxi = tmp_alloc((size_t)N * Hp * Wp * cinP, s); if (!dxi) return 3;
-        View dxp = make_view(dxi, N, Hp, Wp, cinP);
-        ConvArgs a = conv_args(dyv, wd, dxp, k, 1, k - 1 - (pad_mode == PAD_REFLECT ? 0 : pad), stride, PAD_ZERO);
+        View dxp = make_view(dxi, N, Hp, Wp, cinP, bs);
+        const float* wk = op_weights(wd, wn, s); if (!wk) return 3;
+        ConvArgs a = conv_args(dyv, wk, dxp, k, 1, k - 1 - (pad_mode == PAD_REFLECT ? 0 : pad), stride, PAD_ZERO); a.bf16 = bs ? 2 : 0;
         a.accumulate = 1;                                   // dxi is zero-initialised; strided pullbacks may have tap-free residue classes
         const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
         float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
         a.ws = ws; a.ws_cap = ws_cap;
         float* uw = nullptr;
-        if (k == 3 && stride == 1 && cinP % 32 == 0) { uw = tmp_alloc(conv_wino_u_floats(cinP, coutP), s); if (!uw) return 3; launch_wino_weights(wd, uw, cinP, coutP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
+        if (k == 3 && stride == 1 && cinP % 32 == 0 && !bs) { uw = tmp_alloc(conv_wino_u_floats(cinP, coutP), s); if (!uw) return 3; launch_wino_weights(wd, uw, cinP, coutP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
         launch_conv_igemm(a, s);
-        (void)hipFreeAsync(ws, s); if (uw) (void)hipFreeAsync(uw, s);
+        (void)hipFreeAsync(ws, s); if (uw) (void)hipFreeAsync(uw, s); if (wk != wd) (void)hipFreeAsync(const_cast<float*>(wk), s);
         if (pad_mode == PAD_REFLECT) {
             float* dxf = tmp_alloc((size_t)N * H * W * cinP, s); if (!dxf) return 3;
-            View dv = make_view(dxf, N, H, W, cinP);
+            View dv = make_view(dxf, N, H, W, cinP, bs);
             launch_fold_reflect(dxp, dv, 0, nullptr, ACT_NONE, s);
             View o = dv; o.C = Cin; launch_nhwc_to_nchw(nullptr, o, dx, s);
             (void)hipFreeAsync(dxf, s);
@@ -1235,7 +1251,7 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         WgradArgs a{};
         a.x = xv.p; a.x_bs = xv.bs; a.x_ps = xv.ps; a.H = H; a.W = W; a.Cin = cinP;
         a.dy = dyv.p; a.dy_bs = dyv.bs; a.dy_ps = dyv.ps; a.Ho = Ho; a.Wo = Wo; a.Cout = coutP;
-        a.dw = gi; a.N = N; a.KH = k; a.KW = k; a.stride = stride; a.pad = p_eff; a.padmode = pad_mode; a.M = N * Ho * Wo; a.db = gb;
+        a.dw = gi; a.N = N; a.KH = k; a.KW = k; a.stride = stride; a.pad = p_eff; a.padmode = pad_mode; a.M = N * Ho * Wo; a.db = gb; a.bf16 = bs ? 2 : 0;
         launch_conv_wgrad(a, s);
         if (hipStreamSynchronize(s) != hipSuccess) return 1;
         std::vector<float> in(wn), f((size_t)Cin * Cout * k * k), bb(coutP);

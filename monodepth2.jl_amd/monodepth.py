@@ -554,6 +554,11 @@ def set_deterministic(on=True):
     _check(_lib.lib().md2_set_deterministic(int(bool(on))), None, "set_deterministic")
 
 
+def set_op_storage(bf16=False):
+    """Test switch: the op-level convolutions (`conv2d`, `conv2d_pullback`, `conv2d_bn`) run on bf16 tensors with bf16 weight copies -- the kernels of precision='bf16_storage'."""
+    _check(_lib.lib().md2_set_op_storage(int(bool(bf16))), None, "set_op_storage")
+
+
 def set_winograd(on=True, min_blocks=-1):
     """Algorithm choice for the 3x3 / stride-1 convolutions: fused Winograd F(2x2,3x3) for launches of at least `min_blocks` workgroups (default policy: 48; -1 keeps the current value, -2 restores the default), or the direct
     implicit GEMM everywhere (on=False).  What cuDNN's heuristics decide for the reference's Flux `Conv` layers.  on = 2 / 3 pin one of the two Winograd kernels (tests).

@@ -78,6 +78,41 @@ def test_conv_fwd_dgrad_wgrad(case):
     assert rel(host(dx), dxo) < 1e-4 and rel(host(dw), dwo) < 1e-4 and rel(host(db), dbo) < 1e-4
 
 
+def bf16_round(a):
+    """fp32 -> nearest bf16 (ties to even), returned as fp32: what a bf16 tensor holds."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad_on_bf16_tensors(case):
+    """The convolution kernels of md2_config.precision = 2 (bf16 activation tensors, bf16 weight copies, fp32 accumulation: 64-byte K-steps of 32 channels, paired taps for
+    16 channels, channel-major bf16 tiles in the all-taps weight gradient) against the oracle on the bf16-rounded operands.  Products of bf16 values are exact in fp32, so what
+    remains is the summation order (weight / bias gradients: 1e-4) and the final rounding of a bf16 output tensor (2^-9 per element; the reflect-pad pullback rounds twice)."""
+    N, Cin, H, W, Cout, k, s, p, mode = case
+    x = bf16_round(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
+    w = bf16_round((rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xin = oracle.pad_reflect(x) if mode == "reflect" else x
+    yo = oracle.conv2d_fwd(xin, w, b, s, 0 if mode == "reflect" else p)
+    dy = bf16_round(rng.standard_normal(yo.shape).astype(np.float32))
+    dxo, dwo, dbo = oracle.conv2d_bwd(xin, w, dy, s, 0 if mode == "reflect" else p)
+    if mode == "reflect":
+        t = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.pad(t, (1, 1, 1, 1), mode="reflect").backward(torch.tensor(dxo, dtype=torch.float64))
+        dxo = t.grad.numpy()
+    md().set_op_storage(True)
+    try:
+        y = host(md().conv2d(dev(x), dev(w), dev(b), s, p, mode))
+        dx, dw, db = md().conv2d_pullback(dev(x), dev(w), dev(dy), s, p, mode)
+        dx, dw, db = host(dx), host(dw), host(db)
+    finally:
+        md().set_op_storage(False)
+    assert y.shape == yo.shape and rel(y, yo) < 4e-3
+    assert rel(dx, dxo) < 8e-3 and rel(dw, dwo) < 1e-4 and rel(db, dbo) < 1e-4          # (5.6e-3 measured on the 12 x 20 reflect-padded map: border pixels sum two or four rounded values)
+
+
 @pytest.mark.parametrize("hw", [(10, 14), (65, 131)])           # the second shape takes the LDS-patch kernel
 @pytest.mark.parametrize("act", ["relu", "elu", "sigmoid"])
 def test_conv_epilogue_activations(act, hw):
