@@ -1828,7 +1828,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
 // ------------------------------------------------------------------------------------------------------------
 constexpr int WB_YW = 32, WB_XW = 40;                               // pixels per tile row / patch row held in LDS (multiples of 8; TW <= 32, TW + 2 <= 34, the window reaches pixel 39)
 constexpr int WB_YCH = (4 * WB_YW / 8 + 1) * 16, WB_XCH = (32 + 1) * 16;          // bytes per channel row: 16 (32: 6 x 5 = 30 used) pixel groups + one pad group
-__device__ __forceinline__ int wb_addr(int c, int p, int chs) { return c * chs + (((p >> 3) ^ (((c >> 3) & 1) << 1)) << 4) + ((p & 7) << 1); }
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs a, int TW, int tiles_x, int tiles_y, int total_tiles, int ci_groups) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     char* Ys = wsm; char* Xs = wsm + 32 * WB_YCH;

@@ -429,7 +429,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
     // ---- encoder: stem + BN + ReLU, maxpool, 8 basic blocks
     {   // direct 7x7 stride-2 convolution on the boundary tensor (+ its BatchNorm statistics)
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
-        h->pbegin(CLS_IGEMM, fl, "stem fwd 7x7 s2 (direct)"); launch_stem_fwd(x, NL, h->C, H, W, h->P + h->stem.w, h->Kpad, h->z0, (h->testmode || g_deterministic) ? nullptr : h->stem_bn.acc, s); h->pend();
+        h->pbegin(CLS_IGEMM, fl, "stem fwd 7x7 s2 (direct)"); launch_stem_fwd(x, NL, h->C, H, W, h->P + h->stem.w, h->Kpad, h->z0, (h->testmode || g_deterministic) ? nullptr : h->stem_bn.acc, s, h->bs); h->pend();          // (bf16 products in the stem: the bf16-tensor mode only -- precision 1 keeps its round-3 definition)
         if (g_deterministic && !h->testmode) launch_colstats(h->z0, h->stem_bn.acc, s);
         if (h->prof) { h->prof_flops[CLS_IGEMM] += fl; h->prof_exec[CLS_IGEMM] += fl; }
     }
@@ -740,7 +740,7 @@ static int model_backward(md2_handle* h) {
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
         hipStream_t st = wgrad_stream(h);
         h->pbegin(CLS_WGRAD, fl, "stem wgrad 7x7 s2 (direct, BatchNorm pullback in the loader)", st, true);
-        launch_stem_wgrad(h->x_last, NL, h->C, H, W, h->Gfeat[0], h->G + h->stem.w, h->Kpad, st, &h->z0, b.stats + 6 * b.c);
+        launch_stem_wgrad(h->x_last, NL, h->C, H, W, h->Gfeat[0], h->G + h->stem.w, h->Kpad, st, &h->z0, b.stats + 6 * b.c, h->bs);
         h->pend(st, true);
         if (h->prof) { h->prof_flops[CLS_WGRAD] += fl; h->prof_exec[CLS_WGRAD] += fl; }
     }
@@ -1364,9 +1364,9 @@ int32_t md2_stem_conv_fwd(const float* x, const float* w, float* z, float* bn_me
     float *wi = tmp_alloc(in.size(), s), *zi = tmp_alloc((size_t)N * Ho * Wo * 64, s), *st = tmp_alloc(128, s); double* acc = (double*)tmp_alloc((size_t)2 * BN_STAT_SLOTS * 128, s);
     if (!wi || !zi || !st || !acc) return 3;
     if (hipMemcpy(wi, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return 1;
-    View zv = make_view(zi, N, Ho, Wo, 64);
+    View zv = make_view(zi, N, Ho, Wo, 64, g_op_bs);          // (md2_set_op_storage(1): the bf16 modes' kernel -- bf16 products, z a bf16 tensor)
     const bool fused = !g_deterministic;
-    launch_stem_fwd(x, N, C, H, W, wi, Kpad, zv, (bn_mean && fused) ? acc : nullptr, s);
+    launch_stem_fwd(x, N, C, H, W, wi, Kpad, zv, (bn_mean && fused) ? acc : nullptr, s, g_op_bs);
     if (bn_mean && !fused) launch_colstats(zv, acc, s);
     if (bn_mean) {
         launch_bn_finalize(acc, st, 64, (double)zv.pixels(), BN_STAT_SLOTS, nullptr, 0.f, s);
@@ -1383,8 +1383,8 @@ int32_t md2_stem_conv_wgrad(const float* x, const float* dz, float* dw, int32_t 
     const int Kpad = (49 * C + 15) / 16 * 16, Ho = H / 2, Wo = W / 2;
     float *gi = tmp_alloc((size_t)64 * Kpad, s), *di = tmp_alloc((size_t)N * Ho * Wo * 64, s);
     if (!gi || !di) return 3;
-    View dv = make_view(di, N, Ho, Wo, 64); launch_nchw_to_view(dz, dv, s);
-    launch_stem_wgrad(x, N, C, H, W, dv, gi, Kpad, s);
+    View dv = make_view(di, N, Ho, Wo, 64, g_op_bs); launch_nchw_to_view(dz, dv, s);
+    launch_stem_wgrad(x, N, C, H, W, dv, gi, Kpad, s, nullptr, nullptr, g_op_bs);
     std::vector<float> in((size_t)64 * Kpad), f((size_t)64 * C * 49);
     if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(in.data(), gi, in.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
     for (int co = 0; co < 64; ++co) for (int ci = 0; ci < C; ++ci) for (int kh = 0; kh < 7; ++kh) for (int kw = 0; kw < 7; ++kw)

@@ -78,6 +78,9 @@ template <bool BS> __device__ __forceinline__ void vst1(float* base, long off, f
     else base[off] = v;
 }
 __device__ __forceinline__ long voff(const View& v, int n, long r) { return (long)n * v.bs + r * v.ps; }
+// byte offset of (channel c, pixel p) in a CHANNEL-major bf16 LDS tile whose channel rows are `chs` bytes (an odd number of 16-byte groups of 8 pixels): the group index is
+// XORed with 2 * bit 3 of the channel, which spreads the dword writes of a wave's 8 channel quads over four bank octets and keeps 8 consecutive channels' 16-byte reads on 8 groups
+__device__ __forceinline__ int wb_addr(int c, int p, int chs) { return c * chs + (((p >> 3) ^ (((c >> 3) & 1) << 1)) << 4) + ((p & 7) << 1); }
 #endif
 
 __host__ __device__ inline int refl_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -199,10 +202,11 @@ void launch_head_bwd(const View& x, const float* w, const View& y, const View& d
 
 // ---- layer kernels (layers.hip) ----------------------------------------------------------------
 // ---- ResNet stem, 7x7 stride 2 pad 3 on the boundary tensor x [NL][C][H][W] (stem.hip); w / dw: [64][Kpad], k = (kh*7+kw)*C + c
-void launch_stem_fwd(const float* x, int NL, int C, int H, int W, const float* w, int Kpad, const View& z, double* bn_stats /*[BN_STAT_SLOTS][128] or null*/, hipStream_t s);
+// bf16_products (the bf16 modes): operands rounded to bf16 in LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulation
+void launch_stem_fwd(const float* x, int NL, int C, int H, int W, const float* w, int Kpad, const View& z, double* bn_stats /*[BN_STAT_SLOTS][128] or null*/, hipStream_t s, int bf16_products = 0);
 // zbn / coef (optional): dz is not materialised -- the view passed as dz holds g (the gradient of the BatchNorm OUTPUT), zbn the BatchNorm input, and the kernel forms
 // dz = coef[0..64) g + coef[64..128) z + coef[128..192) per channel on the way into LDS
-void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& dz, float* dw, int Kpad, hipStream_t s, const View* zbn = nullptr, const float* coef = nullptr);
+void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& dz, float* dw, int Kpad, hipStream_t s, const View* zbn = nullptr, const float* coef = nullptr, int bf16_products = 0);
 void launch_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, hipStream_t s);
 void launch_nhwc_to_nchw(const float* src, const View& v, float* dst, hipStream_t s);
 void launch_nchw_to_view(const float* src, const View& v, hipStream_t s);

@@ -167,6 +167,32 @@ def test_stem_direct_kernels_vs_oracle(case):
     assert dw.shape == dwo.shape and rel(dw, dwo) < 1e-4          # max over ALL 64*C*49 weights: a wrong MFMA-layout index would move whole rows
 
 
+@pytest.mark.parametrize("case", [(3, 1, 64, 96), (6, 3, 64, 96), (3, 1, 34, 70), (3, 3, 18, 130), (12, 1, 128, 416)])
+def test_stem_kernels_with_bf16_products_vs_oracle(case):
+    """The stem of the bf16 modes (md2_config.precision >= 1) on v_mfma_f32_32x32x16_bf16, the contraction re-ordered into (channel, filter row) blocks of 8.  Forward: bf16
+    weights, the image as hi + lo bf16 planes (16 mantissa bits) -- against the oracle on (fp32 image, bf16-rounded weights) the fp32 accumulators' statistics agree to 1e-4
+    and the stored bf16 z to its final rounding (2^-9 per element).  Weight gradient: image and dz as single bf16 values, channel-major bf16 dz tile -- products of bf16 values
+    are exact in fp32, so on bf16-rounded inputs it agrees with the oracle to summation order (1e-4)."""
+    N, C, H, W = case
+    x = rng.random((N, C, H, W)).astype(np.float32)
+    w = bf16_round((rng.standard_normal((64, C, 7, 7)) / np.sqrt(49 * C)).astype(np.float32))
+    zo = oracle.conv2d_fwd(x, w, None, 2, 3)
+    dz = bf16_round(rng.standard_normal(zo.shape).astype(np.float32))
+    xr = bf16_round(x)
+    _, dwo, _ = oracle.conv2d_bwd(xr, w, dz, 2, 3)
+    md().set_op_storage(True)
+    try:
+        z, mean, invstd = md().stem_conv(dev(x), dev(w))
+        z, mean, invstd = host(z), host(mean), host(invstd)
+        dw = host(md().stem_conv_wgrad(dev(xr), dev(dz)))
+    finally:
+        md().set_op_storage(False)
+    assert z.shape == zo.shape and rel(z, zo) < 4e-3
+    m64 = zo.astype(np.float64).mean((0, 2, 3)); v64 = zo.astype(np.float64).var((0, 2, 3))
+    assert np.abs(mean - m64).max() < 1e-4 * max(1.0, np.abs(m64).max()) and rel(invstd, 1.0 / np.sqrt(v64 + 1e-5)) < 1e-4          # (the statistics come from the fp32 accumulators)
+    assert dw.shape == dwo.shape and rel(dw, dwo) < 1e-4
+
+
 @pytest.mark.parametrize("case", [(2, 16, 20, 37, "elu"), (1, 32, 9, 21, "none"), (3, 64, 6, 11, "none"), (2, 128, 5, 7, "none"), (1, 16, 64, 208, "elu")])
 def test_disparity_head_direct_kernels_vs_oracle(case):
     """head_fwd_kernel / head_bwd_kernel (reflect-pad 3x3 conv to one channel + sigmoid, src/depth_decoder.jl:43): all four channel counts,

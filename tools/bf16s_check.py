@@ -32,3 +32,8 @@ for prec in ("bf16", "bf16_storage"):
     l, d, g = res[prec]
     print(prec, "loss rel %.3e" % (abs(l - l0) / l0), "disp rel", ["%.2e" % (np.linalg.norm(a - b) / np.linalg.norm(b)) for a, b in zip(d, d0)],
           "grad cos %.4f" % (np.dot(g, g0) / (np.linalg.norm(g) * np.linalg.norm(g0))), "norm ratio %.3f" % (np.linalg.norm(g) / np.linalg.norm(g0)))
+    off = 0; rows = []
+    for name, _, shape in syn.param_layout(C, depth, (2, 3, 4, 5)):
+        n = int(np.prod(shape)); a = g[off:off + n].astype(np.float64); b = g0[off:off + n].astype(np.float64); off += n
+        rows.append((float(np.linalg.norm(a - b)), name, float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300)), float(np.linalg.norm(a)), float(np.linalg.norm(b))))
+    for r in sorted(rows, reverse=True)[:6]: print("    |diff| %.3e  %-28s cos %.4f  |g| %.3e  |g_f32| %.3e" % r)
