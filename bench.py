@@ -37,10 +37,11 @@ def pmc_traffic(B, C, H, W, depth, precision):
     return d.get("bytes_per_launch", {})
 
 
-def bf16_conv_roofline(md, torch, model, step):
-    """The mixed-precision mode's convolutions (forward + input gradient) on both rooflines.  Its MFMA operands are bf16 but every activation is still stored in fp32, so the
-    class sits far below the bf16 matrix peak and is priced against HBM as well: ALGORITHMIC bytes = each launch reads its input pixels and weights once and writes its output once
-    at the fp32 storage width (from the per-launch records of the library profiler: M output pixels, Cin, Cout, k, stride), over the class time measured with HIP events."""
+def bf16_conv_roofline(md, torch, model, step, esz=4, precision="bf16"):
+    """The convolutions (forward + input gradient) of a bf16 mode on both rooflines: the class sits far below the bf16 matrix peak and is priced against HBM as well.
+    ALGORITHMIC bytes = each launch reads its input pixels and weights once and writes its output once at the tensors' storage width `esz` (2: bf16 activation storage,
+    precision 'bf16_storage'; 4: the bf16-operand mode on fp32 tensors) -- from the per-launch records of the library profiler (M output pixels, Cin, Cout, k, stride) -- over
+    the class time measured with HIP events.  (The stem is in the class time and flops but has no per-launch record: its bytes are not counted.)"""
     import re, tempfile
     md.set_two_streams(model, False); md.profile(model, True)
     for _ in range(3):
@@ -55,24 +56,24 @@ def bf16_conv_roofline(md, torch, model, step):
         m = re.match(r"igemm M=(\d+) Cout=(\d+) Cin=(\d+) k=(\d+) s=(\d+)", f[4]) if len(f) == 5 and f[0] == "0" else None
         if m:
             M, co, ci, k, st = (int(v) for v in m.groups())
-            by += 4.0 * (M * st * st * ci + M * co + k * k * ci * co)
+            by += float(esz) * (M * st * st * ci + M * co + k * k * ci * co)
     os.remove(tmp)
     if ig["ms"] <= 0:
         return None
     traffic_step = None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_cfg5_bf16_pmc_hbm_traffic.json")))
-        if d.get("workload") == {"batch": 8, "channels": 3, "height": 320, "width": 1024, "depth": 18, "precision": "bf16"}:
+        d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_cfg5_" + precision + "_pmc_hbm_traffic.json")))
+        if d.get("workload") == {"batch": 8, "channels": 3, "height": 320, "width": 1024, "depth": 18, "precision": precision}:
             traffic_step = d["bytes_per_step"]["conv_igemm"]
     except Exception:
         pass
     tf = ig["flops"] / (ig["ms"] * 1e-3) / 1e12; gbs = by / (ig["ms"] * 1e-3) / 1e9
-    return {"kernel": "forward + input-gradient convolutions of the bf16 mixed-precision mode (v_mfma_f32_32x32x16_bf16 operands, fp32 storage)", "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / MFMA_BF16_PEAK_TFLOPS else "mfma",
+    return {"kernel": "forward + input-gradient convolutions (v_mfma_f32_32x32x16_bf16 / 16x16x32, fp32 accumulation) on " + ("bf16 tensors" if esz == 2 else "fp32 tensors"), "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / MFMA_BF16_PEAK_TFLOPS else "mfma",
             "mfma": {"achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS},
             "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": by / 3, "traffic": traffic_step,
-                    "traffic_unit": "HBM bytes per step of this class (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of tools/prof_config.py 8 18 3 320 1024 bf16, profiles/" + PROFILE_ROUND + "_cfg5_bf16_pmc_hbm_traffic.md)"},
+                    "traffic_unit": "HBM bytes per step of this class (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of tools/prof_config.py 8 18 3 320 1024 " + precision + ", profiles/" + PROFILE_ROUND + "_cfg5_" + precision + "_pmc_hbm_traffic.md)"},
             "ms_per_step": ig["ms"] / 3, "launches_per_step": ig["launches"] / 3,
-            "note": "activations stay fp32 in HBM: the class reads and writes twice the bytes a bf16-storage mode would; that mode is not built (DESIGN.md section 7)"}
+            "note": "neither roof binds: 64 x 64-pixel-by-channel workgroups with two bf16 MFMAs per wave and 64-byte K-step are issue / latency bound (DESIGN.md section 4, bf16 tensors)"}
 
 
 def valu_insts(kernel, B, C, H, W):
@@ -162,7 +163,7 @@ def main():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=416)
     ap.add_argument("--depth", type=int, default=18, help="encoder: ResidualNetwork(18) or (50)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="f32 = the reference's precision (parity mode); bf16 = bf16 MFMA operands, fp32 everything else")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16_storage"], help="f32 = the reference's precision (parity mode); bf16 = bf16 MFMA operands, fp32 everything else; bf16_storage = activations stored in bf16 too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -306,7 +307,7 @@ def main():
     if rank == 0:
         traffic = pmc_traffic(B, C, H, W, args.depth, args.precision)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision != "f32" else MFMA_F32_PEAK_TFLOPS
         ach_x = ig["flops_executed"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         out["roofline"] = {"bound": "mfma", "kernel": "conv_wino3s_kernel<.,.,3> / conv_wino3_kernel (fused Winograd F(2x2,3x3): the 3x3 stride-1 layers; products as the exact three-bf16-piece split from 96 input channels up, fp32 MFMA below) + conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions; fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32 outside the split launches)",
                            "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
@@ -385,26 +386,31 @@ def main():
                 md.train_step(m5, x5, None, c5, p5, True)
             torch.cuda.synchronize(); d5 = time.perf_counter() - t0
             extra["config3_resnet50_640x192_batch16"] = {"value": 16 * n5 / d5, "unit": "triplets/s", "ms_per_step": d5 / n5 * 1e3}
-            # BASELINE.json configs[4]: 1024x320, bf16 mixed precision + min-reprojection automask, batch = 8 per GPU (NOT a parity mode:
-            # bf16 MFMA operands, fp32 accumulation / activations / master weights; tests bound its loss to 2 % of the fp32 oracle)
+            # BASELINE.json configs[4]: 1024x320, bf16 mixed precision + min-reprojection automask, batch = 8 per GPU.  NOT a parity mode (the reference computes in Float32):
+            # md2_config.precision = 2 -- activations and their gradients are bf16 tensors in HBM, the convolutions read bf16 weight copies and run bf16 MFMAs with fp32
+            # accumulation; master weights, BatchNorm statistics, disparities, loss and ADAM stay fp32; tests bound its loss to 2 % of the fp32 oracle and its gradient's direction.
+            # The round-3 definition (precision 1: only the MFMA operands are bf16, every tensor fp32) is timed beside it.
             del m5, x5
             torch.cuda.empty_cache()
-            m6, p6, c6, x6 = setup(8, depth=18, C=3, H=320, W=1024, precision="bf16", automask=True)
-            a6 = md.automasking_loss(c6.ssim, x6, x6[:, 1].contiguous(), [1, 3])
-            for _ in range(3):
-                md.train_step(m6, x6, a6, c6, p6, True)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            n6 = 10
-            for _ in range(n6):
-                a6 = md.automasking_loss(c6.ssim, x6, x6[:, 1].contiguous(), [1, 3])        # recomputed per batch like src/Monodepth.jl:159-164
-                md.train_step(m6, x6, a6, c6, p6, True)
-            torch.cuda.synchronize(); d6 = time.perf_counter() - t0
-            extra["config4_1024x320_bf16_automask_batch8"] = {"value": 8 * n6 / d6, "unit": "triplets/s", "ms_per_step": d6 / n6 * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate"}
-            extra["config4_1024x320_bf16_automask_batch8"]["roofline"] = bf16_conv_roofline(md, torch, m6, lambda: md.train_step(m6, x6, a6, c6, p6, True))
-            # and the headline shape in the same mixed precision, for reference next to `value` (which is fp32)
-            del m6, x6
-            torch.cuda.empty_cache()
-            m7, p7, c7, x7 = setup(B, precision="bf16")
+            for key, prec, esz, dtype in (("config4_1024x320_bf16_automask_batch8", "bf16_storage", 2, "bf16 activation / gradient tensors and weight copies, bf16 MFMA, fp32 accumulate; fp32 master weights, BatchNorm statistics, loss, ADAM"),
+                                          ("config4_1024x320_bf16_operands_fp32_tensors_batch8", "bf16", 4, "bf16 MFMA operands, fp32 tensors and accumulation (md2_config.precision = 1)")):
+                m6, p6, c6, x6 = setup(8, depth=18, C=3, H=320, W=1024, precision=prec, automask=True)
+                a6 = md.automasking_loss(c6.ssim, x6, x6[:, 1].contiguous(), [1, 3])
+                for _ in range(3):
+                    md.train_step(m6, x6, a6, c6, p6, True)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                n6 = 10
+                for _ in range(n6):
+                    a6 = md.automasking_loss(c6.ssim, x6, x6[:, 1].contiguous(), [1, 3])        # recomputed per batch like src/Monodepth.jl:159-164
+                    md.train_step(m6, x6, a6, c6, p6, True)
+                torch.cuda.synchronize(); d6 = time.perf_counter() - t0
+                extra[key] = {"value": 8 * n6 / d6, "unit": "triplets/s", "ms_per_step": d6 / n6 * 1e3, "dtype": dtype, "precision": prec}
+                if esz == 2:
+                    extra[key]["roofline"] = bf16_conv_roofline(md, torch, m6, lambda: md.train_step(m6, x6, a6, c6, p6, True), esz=esz, precision=prec)
+                del m6, x6
+                torch.cuda.empty_cache()
+            # and the headline shape in bf16 activation storage, for reference next to `value` (which is fp32)
+            m7, p7, c7, x7 = setup(B, precision="bf16_storage")
             for _ in range(3):
                 md.train_step(m7, x7, None, c7, p7, True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -412,7 +418,7 @@ def main():
             for _ in range(n7):
                 md.train_step(m7, x7, None, c7, p7, True)
             torch.cuda.synchronize(); d7 = time.perf_counter() - t0
-            extra["headline_shape_bf16_mixed"] = {"value": B * n7 / d7, "unit": "triplets/s", "ms_per_step": d7 / n7 * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate"}
+            extra["headline_shape_bf16_storage"] = {"value": B * n7 / d7, "unit": "triplets/s", "ms_per_step": d7 / n7 * 1e3, "dtype": "bf16 activation / gradient tensors and weight copies, bf16 MFMA, fp32 accumulate (md2_config.precision = 2; not a parity mode)"}
             # the same step under the other md2_set_conv_products modes.  Full accuracy: fp32 MFMA in every convolution (0, 0) and the exact three-piece split wherever it exists
             # (3, 3) -- `value` is their per-launch mix (1, 1).  Reduced precision, opt-in, never part of `value`: two bf16 pieces per operand (~16-bit mantissas) in the weight
             # gradients only (1, 2) -- round 3's default -- and in every Winograd product (2, 2).

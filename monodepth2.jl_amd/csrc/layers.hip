@@ -15,6 +15,23 @@ static inline int grid_for(long work, int per_block, int cap = 2048) { return (i
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// a lane's run of consecutive channels: 4 fp32 (16 B) or, on bf16 tensors, 8 (16 B as well: the row-indexed kernels below are instruction-bound at 8-byte accesses)
+template <bool BS> struct LaneN { static constexpr int N = BS ? 8 : 4; };
+template <bool BS> __device__ __forceinline__ void vldn(const float* base, long off, float (&v)[LaneN<BS>::N]) {
+    if constexpr (BS) {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + off);
+        const float4 a = bf16x4_unpack(make_uint2(u.x, u.y)), b = bf16x4_unpack(make_uint2(u.z, u.w));
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else { const float4 a = *reinterpret_cast<const float4*>(base + off); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+}
+template <bool BS> __device__ __forceinline__ void vstn(float* base, long off, const float (&v)[LaneN<BS>::N]) {
+    if constexpr (BS) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(base) + off) = make_uint4(bf16x2_pack(v[0], v[1]), bf16x2_pack(v[2], v[3]), bf16x2_pack(v[4], v[5]), bf16x2_pack(v[6], v[7]));
+    else *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <int N> __device__ __forceinline__ void ldparams(const float* p, float (&v)[N]) {
+#pragma unroll
+    for (int e = 0; e < N; e += 4) { const float4 a = *reinterpret_cast<const float4*>(p + e); v[e] = a.x; v[e + 1] = a.y; v[e + 2] = a.z; v[e + 3] = a.w; }
+}
 static inline bool dense_view_h(const View& v) { return v.ps == v.C && v.bs == (long)v.H * v.W * v.C; }
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -322,36 +339,49 @@ void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t 
 template <bool BS>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               View a, int L, int tgt, View y, uint8_t* __restrict__ arg, int rpb) {
-    const int Q = z.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    constexpr int N = LaneN<BS>::N;
+    const int Q = z.C / N, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= y.W * Q) return;
     const int ow = idx / Q, q = idx - ow * Q;
-    const float4 m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
+    float m[N], is[N], g[N], b[N];
+    ldparams<N>(stats + q * N, m); ldparams<N>(stats + z.C + q * N, is); ldparams<N>(gamma + q * N, g); ldparams<N>(beta + q * N, b);
     const int rows = y.N * y.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
     for (int row = blockIdx.x * rpb; row < row_end; ++row) {
         const int n = row / y.H, oh = row - n * y.H;
         const bool wa = (L == 1) || (n % L) == tgt;
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; uint8_t bi[4] = {0, 0, 0, 0};
+        float best[N]; uint8_t bi[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) { best[e] = -INFINITY; bi[e] = 0; }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * 2 - 1 + kh; if (ih < 0 || ih >= z.H) continue;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = ow * 2 - 1 + kw; if (iw < 0 || iw >= z.W) continue;
-                const float4 v = vld4<BS>(z.p, voff(z, n, (long)ih * z.W + iw) + q * 4);
-                float vv[4] = {g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w};
+                float vv[N];
+                vldn<BS>(z.p, voff(z, n, (long)ih * z.W + iw) + q * N, vv);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vv[e] = vv[e] > 0.f ? vv[e] : 0.f; if (vv[e] > best[e]) { best[e] = vv[e]; bi[e] = kh * 3 + kw; } }
-                if (wa && kh >= 1 && kw >= 1) vst4<BS>(a.p, voff(a, n, (long)ih * z.W + iw) + q * 4, make_float4(vv[0], vv[1], vv[2], vv[3]));   // this output owns the 2x2 block (2oh.., 2ow..)
+                for (int e = 0; e < N; ++e) { vv[e] = g[e] * ((vv[e] - m[e]) * is[e]) + b[e]; vv[e] = vv[e] > 0.f ? vv[e] : 0.f; }
+                if constexpr (BS) {          // the pooled maximum is taken over the values the activation tensor holds (rounded), so that it equals the stored a at its arg-max
+#pragma unroll
+                    for (int e = 0; e < N; e += 2) { const unsigned u = bf16x2_pack(vv[e], vv[e + 1]); vv[e] = __uint_as_float(u << 16); vv[e + 1] = __uint_as_float(u & 0xFFFF0000u); }
+                }
+#pragma unroll
+                for (int e = 0; e < N; ++e) if (vv[e] > best[e]) { best[e] = vv[e]; bi[e] = kh * 3 + kw; }
+                if (wa && kh >= 1 && kw >= 1) vstn<BS>(a.p, voff(a, n, (long)ih * z.W + iw) + q * N, vv);   // this output owns the 2x2 block (2oh.., 2ow..)
             }
         }
         const long r = (long)oh * y.W + ow;
-        vst4<BS>(y.p, voff(y, n, r) + q * 4, make_float4(best[0], best[1], best[2], best[3]));
-        *reinterpret_cast<uchar4*>(arg + (((long)n * y.H * y.W + r) * z.C + q * 4)) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+        vstn<BS>(y.p, voff(y, n, r) + q * N, best);
+        uint8_t* ap = arg + (((long)n * y.H * y.W + r) * z.C + q * N);
+        *reinterpret_cast<uchar4*>(ap) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+        if constexpr (N == 8) *reinterpret_cast<uchar4*>(ap + 4) = make_uchar4(bi[4], bi[5], bi[6], bi[7]);
     }
 }
 void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s) {
-    if ((z.H & 1) || (z.W & 1) || y.H != z.H / 2 || y.W != z.W / 2 || z.C % 4 != 0 || (256 % (z.C / 4)) != 0) { fprintf(stderr, "md2: bn_relu_maxpool: unsupported shape\n"); abort(); }
-    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (z.C / 4));
+    const int ln = z.bf ? 8 : 4;                  // channels per lane
+    if ((z.H & 1) || (z.W & 1) || y.H != z.H / 2 || y.W != z.W / 2 || z.C % ln != 0 || (256 % (z.C / ln)) != 0 || a.bf != z.bf || y.bf != z.bf) { fprintf(stderr, "md2: bn_relu_maxpool: unsupported shape\n"); abort(); }
+    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (z.C / ln));
     LAUNCH_BS(z.bf, bn_relu_maxpool_kernel, rg.grid, dim3(256), 0, s, z, stats, gamma, beta, a, L, tgt, y, arg, rg.rpb);
 }
 
@@ -363,11 +393,14 @@ void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamm
 template <bool BS>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t* __restrict__ arg, View dx, int accumulate, View yrelu, int has_yrelu,
                                                           View bz, const float* __restrict__ bstat, double* __restrict__ bacc, int acc_frame, int rpb) {
-    const int Q = dx.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    constexpr int N = LaneN<BS>::N;
+    const int Q = dx.C / N, idx = blockIdx.y * 256 + threadIdx.x;
     const bool live = idx < dx.W * Q;
     const int iw = live ? idx / Q : 0, q = live ? idx - iw * Q : 0;
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, mu = s1, is = s1;
-    if (bacc) { mu = ld4(bstat + q * 4); is = ld4(bstat + dx.C + q * 4); }
+    float s1[N], s2[N], mu[N], is[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+    if (bacc) { ldparams<N>(bstat + q * N, mu); ldparams<N>(bstat + dx.C + q * N, is); }
     // the (at most two) pooled columns whose 3x3 window covers input column iw, with the window tap kw each sees it through: fixed for the thread's life
     int ows[2], kws[2], nw = 0;
 #pragma unroll
@@ -377,51 +410,68 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(View dy, const uint8_t
     if (live)
     for (int row = blockIdx.x * rpb; row < row_end; ++row) {
         const int n = row / dx.H, ih = row - n * dx.H;
-        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        float g[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) g[e] = 0.f;
         for (int kh = 0; kh < 3; ++kh) {
             const int t = ih + 1 - kh; if (t < 0 || (t & 1)) continue; const int oh = t >> 1; if (oh >= dy.H) continue;          // (block-uniform)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 if (b >= nw) break;
                 const long ro = (long)oh * dy.W + ows[b];
-                const uchar4 a = *reinterpret_cast<const uchar4*>(arg + (((long)n * HWo + ro) * dx.C + q * 4));
-                float4 d = vld4<BS>(dy.p, voff(dy, n, ro) + q * 4);
-                if (has_yrelu) { const float4 o = vld4<BS>(yrelu.p, voff(yrelu, n, ro) + q * 4); d.x *= act_deriv(o.x, ACT_RELU); d.y *= act_deriv(o.y, ACT_RELU); d.z *= act_deriv(o.z, ACT_RELU); d.w *= act_deriv(o.w, ACT_RELU); }
+                const uint8_t* ap = arg + (((long)n * HWo + ro) * dx.C + q * N);
+                uint8_t av[N];
+                { const uchar4 a0 = *reinterpret_cast<const uchar4*>(ap); av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w;
+                  if constexpr (N == 8) { const uchar4 a1 = *reinterpret_cast<const uchar4*>(ap + 4); av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w; } }
+                float d[N];
+                vldn<BS>(dy.p, voff(dy, n, ro) + q * N, d);
+                if (has_yrelu) {
+                    float o[N]; vldn<BS>(yrelu.p, voff(yrelu, n, ro) + q * N, o);
+#pragma unroll
+                    for (int e = 0; e < N; ++e) d[e] *= act_deriv(o[e], ACT_RELU);
+                }
                 const int tap = kh * 3 + kws[b];
-                if (a.x == tap) g[0] += d.x; if (a.y == tap) g[1] += d.y; if (a.z == tap) g[2] += d.z; if (a.w == tap) g[3] += d.w;
+#pragma unroll
+                for (int e = 0; e < N; ++e) if (av[e] == tap) g[e] += d[e];
             }
         }
         const long r = (long)ih * dx.W + iw;
-        const long dpo = voff(dx, n, r) + q * 4;
+        const long dpo = voff(dx, n, r) + q * N;
         if (accumulate == 1 || (accumulate == 2 && (n % 3) == acc_frame)) {      // earlier contributions are already masked
-            const float4 o = vld4<BS>(dx.p, dpo); g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w; }
-        if constexpr (BS) { const float4 gr = bf16x4_unpack(bf16x4_pack(make_float4(g[0], g[1], g[2], g[3]))); g[0] = gr.x; g[1] = gr.y; g[2] = gr.z; g[3] = gr.w; }      // the sums below see the stored (rounded) gradient
-        vst4<BS>(dx.p, dpo, make_float4(g[0], g[1], g[2], g[3]));
+            float o[N]; vldn<BS>(dx.p, dpo, o);
+#pragma unroll
+            for (int e = 0; e < N; ++e) g[e] += o[e];
+        }
+        if constexpr (BS) {                                                      // the sums below see the stored (rounded) gradient
+#pragma unroll
+            for (int e = 0; e < N; e += 2) { const unsigned u = bf16x2_pack(g[e], g[e + 1]); g[e] = __uint_as_float(u << 16); g[e + 1] = __uint_as_float(u & 0xFFFF0000u); }
+        }
+        vstn<BS>(dx.p, dpo, g);
         if (bacc) {
-            const float4 z = vld4<BS>(bz.p, voff(bz, n, r) + q * 4);
-            s1.x += g[0]; s1.y += g[1]; s1.z += g[2]; s1.w += g[3];
-            s2.x += g[0] * ((z.x - mu.x) * is.x); s2.y += g[1] * ((z.y - mu.y) * is.y); s2.z += g[2] * ((z.z - mu.z) * is.z); s2.w += g[3] * ((z.w - mu.w) * is.w);
+            float z[N]; vldn<BS>(bz.p, voff(bz, n, r) + q * N, z);
+#pragma unroll
+            for (int e = 0; e < N; ++e) { s1[e] += g[e]; s2[e] += g[e] * ((z[e] - mu[e]) * is[e]); }
         }
     }
-    if (bacc) {                                   // block reduction over the 256 / Q threads that share a channel quad (256 % Q == 0: thread t holds quad t % Q), then one double atomic per channel and block
-        __shared__ float red[8 * 256];
-        const float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    if (bacc) {                                   // block reduction over the 256 / Q threads that share a channel group (256 % Q == 0: thread t holds group t % Q), then one double atomic per channel and block
+        __shared__ float red[2 * N * 256];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[e * 256 + threadIdx.x] = v[e];
+        for (int e = 0; e < N; ++e) { red[e * 256 + threadIdx.x] = s1[e]; red[(N + e) * 256 + threadIdx.x] = s2[e]; }
         __syncthreads();
         const int C = dx.C, RG = 256 / Q;
         const int slot = (blockIdx.x + blockIdx.y) % BN_STAT_SLOTS;
         for (int c = threadIdx.x; c < 2 * C; c += 256) {
-            const int which = c / C, ch = c % C, qq = ch / 4, e = ch % 4;
+            const int which = c / C, ch = c % C, qq = ch / N, e = ch % N;
             float t = 0.f;
-            for (int gI = 0; gI < RG; ++gI) t += red[(which * 4 + e) * 256 + gI * Q + qq];
+            for (int gI = 0; gI < RG; ++gI) t += red[(which * N + e) * 256 + gI * Q + qq];
             atomicAdd(bacc + (size_t)slot * 2 * C + which * C + ch, (double)t);
         }
     }
 }
 void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int accumulate, const View* yrelu, hipStream_t s, const View* bz, const float* bstat, double* bacc, int acc_frame) {
-    const int Q = dx.C / 4;
-    if (bacc && (256 % Q != 0 || !bz)) { fprintf(stderr, "md2: maxpool_bwd: the fused BatchNorm sums need 256 %% (C/4) == 0\n"); abort(); }
+    const int Q = dx.C / (dx.bf ? 8 : 4);         // channel groups: a lane's 16 bytes
+    if (dx.C % (dx.bf ? 8 : 4) != 0 || dy.bf != dx.bf || (yrelu && yrelu->bf != dx.bf) || (bz && bz->bf != dx.bf)) { fprintf(stderr, "md2: maxpool_bwd: unsupported views\n"); abort(); }
+    if (bacc && (256 % Q != 0 || !bz)) { fprintf(stderr, "md2: maxpool_bwd: the fused BatchNorm sums need 256 %% (channel groups) == 0\n"); abort(); }
     const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * Q);          // (with the fused sums every block ends in 2 C double atomics: ~8192 blocks measured best, B=32)
     LAUNCH_BS(dx.bf, maxpool_bwd_kernel, rg.grid, dim3(256), 0, s, dy, arg, dx, accumulate, yrelu ? *yrelu : dy, yrelu ? 1 : 0,
                        bz ? *bz : dx, bstat, bacc, acc_frame, rg.rpb);

@@ -416,7 +416,7 @@ static void pose_forward(md2_handle* h, int N) {
 
 // L frames per sample (3 for training, 1 for eval_disparity); tgt = index of the frame the depth decoder sees
 // Winograd operands of the forward convolutions from the current parameters (one launch; ~16/9 of the 3x3 weights are written)
-static void refresh_wino_fwd(md2_handle* h, hipStream_t s) { h->u_pieces_f = g_wino_pieces; launch_wino_weights_batched(h->P, h->UF, h->udesc_f, h->n_udf, h->ublk_f, h->u_pieces_f, s); }
+static void refresh_wino_fwd(md2_handle* h, hipStream_t s) { h->u_pieces_f = g_wino_pieces; if (h->bf16) return;          /* (the bf16 modes never take the Winograd kernels) */ launch_wino_weights_batched(h->P, h->UF, h->udesc_f, h->n_udf, h->ublk_f, h->u_pieces_f, s); }
 static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1, bool with_pose = true, bool with_depth = true, bool wino_on_side = false) {
     hipStream_t s = h->stream;
     if (tgt < 0) tgt = h->tgt;                  // triplets: the configured target frame
@@ -573,7 +573,7 @@ static int backward_prepare(md2_handle* h, hipStream_t s) {
     if (h->bs) launch_cast_bf16(h->WD, h->WDb, h->n_int, s);
     if (!h->acc_zeroed) HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
     h->u_pieces_d = g_wino_pieces;
-    launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions
+    if (!h->bf16) launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions
     KCHK(); return 0;
 }
 // The flat gradient buffer is produced back to front; its four all-reduce buckets in the order they complete: [0] depth decoder + heads + pose decoder, [1] encoder layer 4,

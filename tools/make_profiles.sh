@@ -16,9 +16,10 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MF
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/lds -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/lds.log 2>&1
 # ResNet-50 encoder, 640x192, batch 16 (BASELINE configs[3]): kernel stats, one stream
 MD2_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r50 -o t -- python3 $R/tools/prof_config.py 16 50 3 192 640 f32 5 > $O/r50.log 2>&1
-# configuration #5 (1024x320, bf16 mixed precision, batch 8): HBM traffic of its kernel classes for the roofline block bench.py prints with that run
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16 3 > $O/fetch5.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16 3 > $O/write5.log 2>&1
+# configuration #5 (1024x320, bf16 activation storage = md2_config.precision 2, batch 8): kernel stats, and the HBM traffic of its kernel classes for the roofline block bench.py prints with that run
+MD2_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16_storage 5 > $O/cfg5.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16_storage 3 > $O/fetch5.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16_storage 3 > $O/write5.log 2>&1
 cd $R
 tail -1 $O/one.log | cut -c1-300; tail -1 $O/two.log | cut -c1-300; grep ms/step $O/b4.log
 bash tools/summarize_profiles.sh
