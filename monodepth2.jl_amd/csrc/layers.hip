@@ -180,21 +180,30 @@ template <bool FAST, bool BS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        View res, int has_res, int act, View y, const float* __restrict__ rstats, const float* __restrict__ rgamma, const float* __restrict__ rbeta) {
     const int Q = z.C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
-    if (FAST) {
-        const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
-        const float4 m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
-        float4 rm = make_float4(0.f, 0.f, 0.f, 0.f), ris = rm, rg = rm, rb = rm;
-        if (rstats) { rm = ld4(rstats + q * 4); ris = ld4(rstats + z.C + q * 4); rg = ld4(rgamma + q * 4); rb = ld4(rbeta + q * 4); }
-        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-            const float4 v = vld4<BS>(z.p, i * 4);
-            float4 o = make_float4(g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w);
+    if (FAST) {          // a lane keeps one run of N consecutive channels (16 bytes) for life
+        constexpr int N = LaneN<BS>::N;
+        const int QN = z.C / N; const long totalN = z.pixels() * QN;
+        const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (QN - 1));
+        float m[N], is[N], g[N], b[N], rm[N], ris[N], rg[N], rb[N];
+        ldparams<N>(stats + q * N, m); ldparams<N>(stats + z.C + q * N, is); ldparams<N>(gamma + q * N, g); ldparams<N>(beta + q * N, b);
+        if (rstats) { ldparams<N>(rstats + q * N, rm); ldparams<N>(rstats + z.C + q * N, ris); ldparams<N>(rgamma + q * N, rg); ldparams<N>(rbeta + q * N, rb); }
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalN; i += (long)gridDim.x * blockDim.x) {
+            float v[N], o[N];
+            vldn<BS>(z.p, i * N, v);
+#pragma unroll
+            for (int e = 0; e < N; ++e) o[e] = g[e] * ((v[e] - m[e]) * is[e]) + b[e];
             if (has_res) {
-                float4 rr = vld4<BS>(res.p, i * 4);
-                if (rstats) rr = make_float4(rg.x * ((rr.x - rm.x) * ris.x) + rb.x, rg.y * ((rr.y - rm.y) * ris.y) + rb.y, rg.z * ((rr.z - rm.z) * ris.z) + rb.z, rg.w * ((rr.w - rm.w) * ris.w) + rb.w);
-                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                float rr[N]; vldn<BS>(res.p, i * N, rr);
+                if (rstats) {
+#pragma unroll
+                    for (int e = 0; e < N; ++e) rr[e] = rg[e] * ((rr[e] - rm[e]) * ris[e]) + rb[e];
+                }
+#pragma unroll
+                for (int e = 0; e < N; ++e) o[e] += rr[e];
             }
-            o.x = act_apply(o.x, act); o.y = act_apply(o.y, act); o.z = act_apply(o.z, act); o.w = act_apply(o.w, act);
-            vst4<BS>(y.p, i * 4, o);
+#pragma unroll
+            for (int e = 0; e < N; ++e) o[e] = act_apply(o[e], act);
+            vstn<BS>(y.p, i * N, o);
         }
         return;
     }
@@ -216,8 +225,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __re
 }
 void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s,
                      const float* rstats, const float* rgamma, const float* rbeta) {
-    const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(y) && (!residual || dense_view_h(*residual));
-    const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, 4096));
+    const int ln = z.bf ? 8 : 4;                  // channels per lane on the dense path
+    const bool fast = z.C % ln == 0 && pow2(z.C / ln) && z.C / ln <= 256 && dense_view_h(z) && dense_view_h(y) && (!residual || dense_view_h(*residual)) && y.bf == z.bf && (!residual || residual->bf == z.bf);
+    const dim3 grid(grid_for(z.pixels() * (z.C / (fast ? ln : 4)), 256, 4096));
     if (fast) LAUNCH_BSP(z.bf, bn_apply_kernel, true, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
     else LAUNCH_BSP(z.bf, bn_apply_kernel, false, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
 }
@@ -250,9 +260,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
                                                            float* __restrict__ coef, View dz, const double* __restrict__ acc, int slots, double count,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int C = z.C, Q = C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
-    if (FAST) {                                 // one channel quad per thread: the per-channel constants leave the loop
+    if (FAST) {                                 // one run of N channels (16 bytes) per thread: the per-channel constants leave the loop
+        constexpr int N = LaneN<BS>::N;
         __shared__ float4 sm1[256], sm2[256];
-        if (threadIdx.x < Q) {
+        if (threadIdx.x < Q) {                  // (per channel quad, whatever N is)
             const int c0 = threadIdx.x * 4;
             double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
             for (int k = 0; k < slots; ++k)
@@ -268,18 +279,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
             }
         }
         __syncthreads();
-        const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (Q - 1));
-        const float4 m = ld4(stats + q * 4), is = ld4(stats + C + q * 4), ga = ld4(gamma + q * 4), m1 = sm1[q], m2 = sm2[q];
-        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-            float4 g = vld4<BS>(dy.p, i * 4);
-            if (has_yact) { const float4 o = vld4<BS>(yact.p, i * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-            const float4 v = vld4<BS>(z.p, i * 4);
-            float4 o;
-            o.x = ga.x * is.x * (g.x - m1.x - (v.x - m.x) * is.x * m2.x);
-            o.y = ga.y * is.y * (g.y - m1.y - (v.y - m.y) * is.y * m2.y);
-            o.z = ga.z * is.z * (g.z - m1.z - (v.z - m.z) * is.z * m2.z);
-            o.w = ga.w * is.w * (g.w - m1.w - (v.w - m.w) * is.w * m2.w);
-            vst4<BS>(dz.p, i * 4, o);
+        const int QN = C / N; const long totalN = z.pixels() * QN;
+        const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (QN - 1));
+        float m[N], is[N], ga[N], m1[N], m2[N];
+        ldparams<N>(stats + q * N, m); ldparams<N>(stats + C + q * N, is); ldparams<N>(gamma + q * N, ga);
+#pragma unroll
+        for (int e = 0; e < N; e += 4) { const float4 a = sm1[(q * N + e) >> 2], b = sm2[(q * N + e) >> 2]; m1[e] = a.x; m1[e + 1] = a.y; m1[e + 2] = a.z; m1[e + 3] = a.w; m2[e] = b.x; m2[e + 1] = b.y; m2[e + 2] = b.z; m2[e + 3] = b.w; }
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalN; i += (long)gridDim.x * blockDim.x) {
+            float g[N], v[N], o[N];
+            vldn<BS>(dy.p, i * N, g);
+            if (has_yact) {
+                float ya[N]; vldn<BS>(yact.p, i * N, ya);
+#pragma unroll
+                for (int e = 0; e < N; ++e) g[e] *= act_deriv(ya[e], act);
+            }
+            vldn<BS>(z.p, i * N, v);
+#pragma unroll
+            for (int e = 0; e < N; ++e) o[e] = ga[e] * is[e] * (g[e] - m1[e] - (v[e] - m[e]) * is[e] * m2[e]);
+            vstn<BS>(dz.p, i * N, o);
         }
         return;
     }
@@ -298,9 +315,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(View dy, View yact, i
 }
 void launch_bn_bwd_apply(const View& dy, const View* yact, int act, const View& z, const float* stats, const float* gamma, const double* acc, double count,
                          const View& dz, float* dgamma, float* dbeta, hipStream_t s, int slots, float* coef) {
-    const bool fast = pow2(z.C / 4) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(dy) && dense_view_h(dz) && (!yact || dense_view_h(*yact));
+    const int ln = z.bf ? 8 : 4;                  // channels per lane on the dense path
+    const bool fast = z.C % ln == 0 && pow2(z.C / ln) && z.C / 4 <= 256 && dense_view_h(z) && dense_view_h(dy) && dense_view_h(dz) && (!yact || dense_view_h(*yact)) && dy.bf == z.bf && dz.bf == z.bf && (!yact || yact->bf == z.bf);
     // (fast: every block re-derives its coefficients -- fewer, longer-lived blocks than the 4096 of the plain element kernels)
-    const dim3 grid(grid_for(z.pixels() * (z.C / 4), 256, fast ? 2048 : 4096));
+    const dim3 grid(grid_for(z.pixels() * (z.C / (fast ? ln : 4)), 256, fast ? 2048 : 4096));
     if (fast) LAUNCH_BSP(z.bf, bn_bwd_apply_kernel, true, grid, dim3(256), 0, s, dy, yact ? *yact : dy, yact ? 1 : 0, act, z, stats, gamma, coef, dz, acc, slots, count, dgamma, dbeta);
     else {
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((z.C + 255) / 256), dim3(256), 0, s, acc, slots, z.C, count, coef, dgamma, dbeta, (const float*)nullptr, (const float*)nullptr);
@@ -487,7 +505,8 @@ __device__ __forceinline__ void up_src(int o, int in, int out, int& i0, int& i1,
 }
 template <bool BS>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y, int rpb) {
-    const int Q = x.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    constexpr int N = LaneN<BS>::N;
+    const int Q = x.C / N, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= y.W * Q) return;
     const int ow = idx / Q, q = idx - ow * Q;
     int w0, w1; float fw; up_src(ow, x.W, y.W, w0, w1, fw);          // the column taps are the thread's for life
@@ -496,17 +515,18 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y, int
     for (int row = blockIdx.x * rpb; row < row_end; ++row) {
         const int n = row / y.H, oh = row - n * y.H;
         int h0, h1; float fh; up_src(oh, x.H, y.H, h0, h1, fh);      // the row taps are block-uniform
-        const float4 a = vld4<BS>(x.p, voff(x, n, (long)h0 * x.W + w0) + q * 4), b = vld4<BS>(x.p, voff(x, n, (long)h0 * x.W + w1) + q * 4);
-        const float4 c = vld4<BS>(x.p, voff(x, n, (long)h1 * x.W + w0) + q * 4), d = vld4<BS>(x.p, voff(x, n, (long)h1 * x.W + w1) + q * 4);
+        float a[N], b[N], c[N], d[N], o[N];
+        vldn<BS>(x.p, voff(x, n, (long)h0 * x.W + w0) + q * N, a); vldn<BS>(x.p, voff(x, n, (long)h0 * x.W + w1) + q * N, b);
+        vldn<BS>(x.p, voff(x, n, (long)h1 * x.W + w0) + q * N, c); vldn<BS>(x.p, voff(x, n, (long)h1 * x.W + w1) + q * N, d);
         const float gh = 1.f - fh;
-        float4 o;
-        o.x = gh * (gw * a.x + fw * b.x) + fh * (gw * c.x + fw * d.x); o.y = gh * (gw * a.y + fw * b.y) + fh * (gw * c.y + fw * d.y);
-        o.z = gh * (gw * a.z + fw * b.z) + fh * (gw * c.z + fw * d.z); o.w = gh * (gw * a.w + fw * b.w) + fh * (gw * c.w + fw * d.w);
-        vst4<BS>(y.p, voff(y, n, (long)oh * y.W + ow) + q * 4, o);
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = gh * (gw * a[e] + fw * b[e]) + fh * (gw * c[e] + fw * d[e]);
+        vstn<BS>(y.p, voff(y, n, (long)oh * y.W + ow) + q * N, o);
     }
 }
 void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s) {
-    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (x.C / 4));
+    if (x.C % (x.bf ? 8 : 4) != 0 || y.bf != x.bf) { fprintf(stderr, "md2: upsample2x_fwd: unsupported views\n"); abort(); }
+    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (x.C / (x.bf ? 8 : 4)));
     LAUNCH_BS(x.bf, upsample2x_fwd_kernel, rg.grid, dim3(256), 0, s, x, y, rg.rpb);
 }
 // exact adjoint in gather form: every candidate output row/col recomputes the forward's (i0,i1,w1)
@@ -580,7 +600,8 @@ void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int
 // One gather pass over the padded gradient instead of writing and re-reading the folded full-resolution tensor (109 + 109 + 109 MB for the last branch at batch 32).
 template <bool BS>
 __global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, View xact, int has_xact, int act, int rpb) {
-    const int Q = dx.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    constexpr int N = LaneN<BS>::N;
+    const int Q = dx.C / N, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= dx.W * Q) return;
     const int w = idx / Q, q = idx - w * Q;
     const int Hf = sp.H - 2, Wf = sp.W - 2;         // the fine (unpadded) map
@@ -595,15 +616,18 @@ __global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, Vie
         const int n = row / dx.H, h = row - n * dx.H;
         int ohs[4]; float chs[4];
         up_adjoint_taps4(h, dx.H, Hf, ohs, chs);      // block-uniform
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float g[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) g[e] = 0.f;
         // 16 independent gathers, all in flight together (unused slots: weight 0, clamped index)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)(ohs[a] + 1) * sp.W + ows[b] + 1) + q * 4);
+                float d[N]; vldn<BS>(sp.p, voff(sp, n, (long)(ohs[a] + 1) * sp.W + ows[b] + 1) + q * N, d);
                 const float c = chs[a] * cws[b];
-                g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w;
+#pragma unroll
+                for (int e = 0; e < N; ++e) g[e] += c * d[e];
             }
         bool rowx = false;
 #pragma unroll
@@ -616,28 +640,41 @@ __global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, Vie
                 for (int b = 0; b < 4; ++b) {
                     const int ox2 = cws[b] == 0.f ? -1 : (ows[b] == 1 ? 0 : (ows[b] == Wf - 2 ? Wf + 1 : -1));
                     const float c = chs[a] * cws[b];
-                    if (oy2 >= 0) { const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)oy2 * sp.W + ows[b] + 1) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
-                    if (ox2 >= 0) { const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)(ohs[a] + 1) * sp.W + ox2) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
-                    if (oy2 >= 0 && ox2 >= 0) { const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)oy2 * sp.W + ox2) + q * 4); g.x += c * d.x; g.y += c * d.y; g.z += c * d.z; g.w += c * d.w; }
+                    float d[N];
+                    if (oy2 >= 0) { vldn<BS>(sp.p, voff(sp, n, (long)oy2 * sp.W + ows[b] + 1) + q * N, d);
+#pragma unroll
+                        for (int e = 0; e < N; ++e) g[e] += c * d[e]; }
+                    if (ox2 >= 0) { vldn<BS>(sp.p, voff(sp, n, (long)(ohs[a] + 1) * sp.W + ox2) + q * N, d);
+#pragma unroll
+                        for (int e = 0; e < N; ++e) g[e] += c * d[e]; }
+                    if (oy2 >= 0 && ox2 >= 0) { vldn<BS>(sp.p, voff(sp, n, (long)oy2 * sp.W + ox2) + q * N, d);
+#pragma unroll
+                        for (int e = 0; e < N; ++e) g[e] += c * d[e]; }
                 }
             }
         }
         const long r = (long)h * dx.W + w;
-        if (has_xact) { const float4 o = vld4<BS>(xact.p, voff(xact, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        vst4<BS>(dx.p, voff(dx, n, r) + q * 4, g);
+        if (has_xact) {
+            float o[N]; vldn<BS>(xact.p, voff(xact, n, r) + q * N, o);
+#pragma unroll
+            for (int e = 0; e < N; ++e) g[e] *= act_deriv(o[e], act);
+        }
+        vstn<BS>(dx.p, voff(dx, n, r) + q * N, g);
     }
 }
 void launch_fold_up2_bwd(const View& src_pad, const View& dx, const View* xact, int act, hipStream_t s) {
     const int Hf = src_pad.H - 2, Wf = src_pad.W - 2;
     // (maps of at least 4 x 4: on a 3-wide map both frame columns mirror onto column 1, which the one-extra-position bookkeeping above does not cover)
     if (Hf < 4 || Wf < 4 || Hf > 2 * dx.H || Wf > 2 * dx.W || src_pad.C < dx.C) { fprintf(stderr, "md2: fold_up2_bwd: unsupported shape\n"); abort(); }
-    const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * (dx.C / 4));          // (more rows per thread were slower: the kernel lives on parallel gathers, 0.224 -> 0.306 ms at four rows)
+    if (dx.C % (dx.bf ? 8 : 4) != 0 || src_pad.bf != dx.bf || (xact && xact->bf != dx.bf)) { fprintf(stderr, "md2: fold_up2_bwd: unsupported views\n"); abort(); }
+    const RowGrid rg = row_grid((long)dx.N * dx.H, dx.W * (dx.C / (dx.bf ? 8 : 4)));          // (more rows per thread were slower: the kernel lives on parallel gathers, 0.224 -> 0.306 ms at four rows)
     LAUNCH_BS(dx.bf, fold_up2_bwd_kernel, rg.grid, dim3(256), 0, s, src_pad, dx, xact ? *xact : dx, xact ? 1 : 0, act, rg.rpb);
 }
 
 template <bool BS>
 __global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, int accumulate, View actsrc, int has_act, int act, int rpb) {
-    const int Q = dst.C / 4, H = dst.H, W = dst.W, idx = blockIdx.y * 256 + threadIdx.x;
+    constexpr int N = LaneN<BS>::N;
+    const int Q = dst.C / N, H = dst.H, W = dst.W, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= W * Q) return;
     const int w = idx / Q, q = idx - w * Q;
     int uxs[3], nx = 0;                             // padded-domain columns that fold onto column w (pad_reflect mirrors WITHOUT the edge: -1 <-> 1, W <-> W - 2)
@@ -647,49 +684,72 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, in
         const int n = row / H, h = row - n * H;
         int uys[3], ny = 0;
         uys[ny++] = h; if (h == 1) uys[ny++] = -1; if (h == H - 2) uys[ny++] = H;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float g[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) g[e] = 0.f;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             if (a >= ny) break;
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 if (b >= nx) break;
-                const float4 d = vld4<BS>(sp.p, voff(sp, n, (long)(uys[a] + 1) * sp.W + (uxs[b] + 1)) + q * 4);
-                g.x += d.x; g.y += d.y; g.z += d.z; g.w += d.w;
+                float d[N]; vldn<BS>(sp.p, voff(sp, n, (long)(uys[a] + 1) * sp.W + (uxs[b] + 1)) + q * N, d);
+#pragma unroll
+                for (int e = 0; e < N; ++e) g[e] += d[e];
             }
         }
         const long r = (long)h * W + w;
-        const long dpo = voff(dst, n, r) + q * 4;
-        if (accumulate) { const float4 o = vld4<BS>(dst.p, dpo); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
-        if (has_act) { const float4 o = vld4<BS>(actsrc.p, voff(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        vst4<BS>(dst.p, dpo, g);
+        const long dpo = voff(dst, n, r) + q * N;
+        if (accumulate) {
+            float o[N]; vldn<BS>(dst.p, dpo, o);
+#pragma unroll
+            for (int e = 0; e < N; ++e) g[e] += o[e];
+        }
+        if (has_act) {
+            float o[N]; vldn<BS>(actsrc.p, voff(actsrc, n, r) + q * N, o);
+#pragma unroll
+            for (int e = 0; e < N; ++e) g[e] *= act_deriv(o[e], act);
+        }
+        vstn<BS>(dst.p, dpo, g);
     }
 }
 void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, const View* actsrc, int act, hipStream_t s) {
     if (src_pad.H != dst.H + 2 || src_pad.W != dst.W + 2 || src_pad.C < dst.C) { fprintf(stderr, "md2: fold_reflect: shape mismatch\n"); abort(); }
-    const RowGrid rg = row_grid((long)dst.N * dst.H, dst.W * (dst.C / 4));
+    if (dst.C % (dst.bf ? 8 : 4) != 0 || src_pad.bf != dst.bf || (actsrc && actsrc->bf != dst.bf)) { fprintf(stderr, "md2: fold_reflect: unsupported views\n"); abort(); }
+    const RowGrid rg = row_grid((long)dst.N * dst.H, dst.W * (dst.C / (dst.bf ? 8 : 4)));
     LAUNCH_BS(dst.bf, fold_reflect_kernel, rg.grid, dim3(256), 0, s, src_pad, dst, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act, rg.rpb);
 }
 
 template <bool BS>
 __global__ __launch_bounds__(256) void axpy_view_kernel(View src, View dst, float a, int accumulate, View actsrc, int has_act, int act, int rpb) {
-    const int Q = dst.C / 4, idx = blockIdx.y * 256 + threadIdx.x;
+    constexpr int N = LaneN<BS>::N;
+    const int Q = dst.C / N, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= dst.W * Q) return;
     const int w = idx / Q, q = idx - w * Q;
     const int rows = dst.N * dst.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
     for (int row = blockIdx.x * rpb; row < row_end; ++row) {
         const int n = row / dst.H, h = row - n * dst.H;
         const long r = (long)h * dst.W + w;
-        float4 g = vld4<BS>(src.p, voff(src, n, r) + q * 4);
-        g.x *= a; g.y *= a; g.z *= a; g.w *= a;
-        if (has_act) { const float4 o = vld4<BS>(actsrc.p, voff(actsrc, n, r) + q * 4); g.x *= act_deriv(o.x, act); g.y *= act_deriv(o.y, act); g.z *= act_deriv(o.z, act); g.w *= act_deriv(o.w, act); }
-        const long dpo = voff(dst, n, r) + q * 4;
-        if (accumulate) { const float4 o = vld4<BS>(dst.p, dpo); g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w; }
-        vst4<BS>(dst.p, dpo, g);
+        float g[N]; vldn<BS>(src.p, voff(src, n, r) + q * N, g);
+#pragma unroll
+        for (int e = 0; e < N; ++e) g[e] *= a;
+        if (has_act) {
+            float o[N]; vldn<BS>(actsrc.p, voff(actsrc, n, r) + q * N, o);
+#pragma unroll
+            for (int e = 0; e < N; ++e) g[e] *= act_deriv(o[e], act);
+        }
+        const long dpo = voff(dst, n, r) + q * N;
+        if (accumulate) {
+            float o[N]; vldn<BS>(dst.p, dpo, o);
+#pragma unroll
+            for (int e = 0; e < N; ++e) g[e] += o[e];
+        }
+        vstn<BS>(dst.p, dpo, g);
     }
 }
 void launch_axpy_view(const View& src, const View& dst, float a, int accumulate, const View* actsrc, int act, hipStream_t s) {
-    const RowGrid rg = row_grid((long)dst.N * dst.H, dst.W * (dst.C / 4));
+    if (dst.C % (dst.bf ? 8 : 4) != 0 || src.bf != dst.bf || (actsrc && actsrc->bf != dst.bf)) { fprintf(stderr, "md2: axpy_view: unsupported views\n"); abort(); }
+    const RowGrid rg = row_grid((long)dst.N * dst.H, dst.W * (dst.C / (dst.bf ? 8 : 4)));
     LAUNCH_BS(dst.bf, axpy_view_kernel, rg.grid, dim3(256), 0, s, src, dst, a, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act, rg.rpb);
 }
 
