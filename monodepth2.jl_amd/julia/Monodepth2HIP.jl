@@ -18,7 +18,7 @@ struct MD2Config
     batch::Int32; channels::Int32; height::Int32; width::Int32
     automasking::Int32; device::Int32
     min_depth::Float64; max_depth::Float64; disparity_smoothness::Float64; lr::Float64
-    encoder_depth::Int32; precision::Int32       # ResidualNetwork(18 | 50); 0 = f32, 1 = bf16 MFMA operands
+    encoder_depth::Int32; precision::Int32       # ResidualNetwork(18 | 50); 0 = f32, 1 = bf16 MFMA operands on fp32 tensors, 2 = bf16 activation tensors
     target_id::Int32; source_id1::Int32; source_id2::Int32      # TrainCache.target_id / source_ids (1-based; 0 = the defaults 2 / (1, 3))
     scale_levels::NTuple{5, Int32}                               # DepthDecoder(; scale_levels), ascending, 0-terminated (all 0 = 2:5, src/Monodepth.jl:106)
     scales::NTuple{5, Float64}                                   # TrainCache.scales (0 = 1 / 2^(5 - level), src/Monodepth.jl:107)
@@ -77,6 +77,8 @@ set_lr!(h, eta) = check(h, md2_set_lr(h.ptr, Float64(eta)), "set_lr")
 testmode!(h, on::Bool=true) = check(h, md2_set_testmode(h.ptr, Int32(on)), "set_testmode")       # Flux.testmode! / trainmode!, src/Monodepth.jl:126,209,237
 trainmode!(h) = testmode!(h, false)
 set_deterministic!(on::Bool) = md2_set_deterministic(Int32(on))
+# test switch: the op-level convolutions run the bf16-tensor kernels of precision = 2
+set_op_storage!(bf16::Bool) = md2_set_op_storage(Int32(bf16))
 set_winograd!(on::Union{Bool,Integer}, min_blocks::Integer=-1) = md2_set_winograd(Int32(on), Int32(min_blocks))     # algorithm choice of the 3x3 / stride-1 convolutions (cuDNN's job behind Flux `Conv`): 0 direct, 1 automatic, 2 / 3 pin a Winograd kernel
 # how the convolutions form their fp32 products (cuDNN's math mode): 0 fp32 MFMA, 3 exact three-bf16-piece split, 1 (default) the faster of the two per launch, 2 reduced precision (opt-in); -1 keeps
 set_conv_products!(fwd_dgrad::Integer=-1, wgrad::Integer=-1) = md2_set_conv_products(Int32(fwd_dgrad), Int32(wgrad))
