@@ -56,6 +56,11 @@ constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
                           // steps ahead with a counted vmcnt and a raw s_barrier) -- no VGPR round trip, no mask ANDs, no ds_write.  Correct (the layer tests pass with it) but
                           // within +-1.5 % of the register-staged pipeline on all four encoder stage shapes at 5 blocks per CU (tools/conv_bench), with distance 2 as well
 #endif
+#ifndef MD2_IGEMM_BUFLOAD
+#define MD2_IGEMM_BUFLOAD 1   // 1: the pixel operand is gathered with raw buffer loads whose hardware range check returns zeros for the padding taps (their offset is an out-of-range
+                              // sentinel): no mask registers, no four ANDs per 16-byte item (8 of ~26 instructions of a K-step on the 64 x 64 tile).  Not with the input transform
+                              // (relu(shift) of a padded zero is not zero: that variant keeps its masks)
+#endif
 #ifndef MD2_LATE_MASK
 #define MD2_LATE_MASK 1   // 1: zero-padding masks are applied when the gathered rows go to LDS (after the step's MFMAs) instead of right after the global loads
 #endif
@@ -108,6 +113,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // taps x 16 channels (`pair`; 9 taps -> 5 steps, the tenth half masked), the weights [Cout][9][16] being contiguous per output channel.
     constexpr bool BS = BF == 2;
     constexpr unsigned ESZ = BS ? 2u : 4u;                     // bytes per element
+    constexpr bool BUFL = MD2_IGEMM_BUFLOAD != 0 && XF == 0 && !DL;
+    constexpr unsigned A_OOB = 0xFFFFFFF0u;                    // offset of a masked item: beyond any tensor's byte span (check_igemm_args keeps spans below 2^32 - 32)
     constexpr int ROWF = BF == 1 ? 12 : (DL ? 16 : LDK);
     constexpr int XS = BM * ROWF, STAGE = (BM + BN) * ROWF;    // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
 
@@ -186,17 +193,26 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
             else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
             a_mbits[j] |= ok ? (1u << t) : 0u;
-            a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address (DL: g_zero_row instead)
+            if constexpr (BUFL) a_off[t][j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : A_OOB;          // (the chunk offset travels in the scalar offset, outside the range check)
+            else a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address (DL: g_zero_row instead)
         }
         b_tap[t] = pair ? (unsigned)(t * 64) : (unsigned)((kh * a.KW + kw) * a.Cin) * ESZ + (unsigned)(c_lo * 64);
     }
     const char* xb = reinterpret_cast<const char*>(a.x);
     const char* wb = reinterpret_cast<const char*>(a.w);
+    const long xspan = (long)ESZ * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)(xspan < (long)(A_OOB - 16) ? xspan : (long)(A_OOB - 16)), 0x00020000);
     // branch-free: every lane loads; masked rows are zeroed with an integer AND so the steady-state loop stays one basic
     // block and the scheduler can interleave the loads and the LDS stores with the MFMAs
     auto gload = [&](int t, int ci0) {
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
+            if constexpr (BUFL) {
+                typedef unsigned bl_u32x4 __attribute__((ext_vector_type(4)));
+                const bl_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)a_off[t][j], c_lo * 64 + ci0 * 4, 0);
+                ra[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+                continue;
+            }
             const uint4 v = *reinterpret_cast<const uint4*>(xb + (a_off[t][j] + (unsigned)(ci0 * 4)));
             const unsigned mk = (XF || MD2_LATE_MASK) ? 0xFFFFFFFFu : 0u - ((a_mbits[j] >> t) & 1u);          // late: the mask (and the XF transform) are applied in lstore, so the loads' wait sits behind the MFMAs
             ra[j] = make_float4(__uint_as_float(v.x & mk), __uint_as_float(v.y & mk), __uint_as_float(v.z & mk), __uint_as_float(v.w & mk));
@@ -246,7 +262,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         for (int j = 0; j < B_LD; ++j) sb[j] = rb[j];
     };
     auto xf_apply = [&](int tt) {               // tt: filter tap of the data in sa[] (its padding mask)
-        if constexpr (XF == 0 && MD2_LATE_MASK != 0) {
+        if constexpr (XF == 0 && MD2_LATE_MASK != 0 && !BUFL) {
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) {
                 unsigned mb = a_mbits[j]; asm volatile("" : "+v"(mb));            // keeps hipcc from hoisting NT x A_LD mask registers out of the loop
@@ -1014,7 +1030,7 @@ static void check_igemm_args(const ConvArgs& a) {
     const long x_elems = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), w_elems = 4 * ((long)a.Cout * a.KH * a.KW * a.Cin);   // byte offsets must fit 32 bits
     if (a.bf16 == 2 && !(a.Cin == 16 || a.Cin % 32 == 0)) { fprintf(stderr, "md2: conv_igemm: bf16 tensors need Cin == 16 or a multiple of 32 (Cin=%d)\n", a.Cin); abort(); }
     if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) || (a.res && (a.res_ps % 4 != 0 || a.act != ACT_NONE || a.bias)) ||
-        a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) || w_elems >= (1L << 32)) {
+        a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) - 64 || w_elems >= (1L << 32)) {
         fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
         abort();
     }
