@@ -179,10 +179,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tl = pair ? 2 * t + (q >> 1) : t;            // the filter tap this lane's 16 bytes of step slot t belong to
-        // taps per lattice row: static for every tap count but two (1 x 2 or 2 x 1 residue classes) -- a runtime divisor costs ~50 scalar instructions per tap here
-        const int nkw_s = (NT == 9 || NT == 5) ? 3 : (NT == 4 ? 2 : (NT == 1 ? 1 : a.nkw));
-        const bool tap_ok = !pair || tl < 9;
-        const int ikh = tl / nkw_s, ikw = tl - ikh * nkw_s;
+        const bool tap_ok = !pair || tl < a.nkh * a.nkw;
+        const int ikh = tl / a.nkw, ikw = tl - ikh * a.nkw;
         const int kh = a.kh0 + ikh * a.khs, kw = a.kw0 + ikw * a.kws;
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
@@ -834,7 +832,6 @@ static void launch_tile(const ConvArgs& a_in, hipStream_t s) {
             else launch_igemm_form<BM, BN, WP, WC, MF, 1, 0, 1>(a, g, s);
         }
     } else
-    if ((ntaps == 9 && a.nkw != 3) || (ntaps == 4 && a.nkw != 2)) { fprintf(stderr, "md2: conv_igemm: tap lattice %d x %d is not built (3 x 3, 2 x 2, 1 x 2, 2 x 1, 1 x 1)\n", a.nkh, a.nkw); abort(); }
     switch (a.nkh * a.nkw) {       // static tap count: 3x3 (9), 1x1 (1), and the 1/2/4-tap residue classes of a stride-2 input gradient
         case 9:
             if (a.bf16 == 2 && a.Cin == 16) {          // bf16 storage, 16 input channels: two taps per 64-byte step (dense 3x3 tap lattice only)

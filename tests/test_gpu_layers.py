@@ -231,6 +231,25 @@ def test_conv_bn_statistics_epilogue_vs_oracle(case):
     assert np.abs(host(mean) - m64).max() < 1e-5 * max(1.0, np.abs(yo).max()) and rel(host(invstd), 1.0 / np.sqrt(v64 + 1e-5)) < 1e-4
 
 
+@pytest.mark.parametrize("case", [(40, 64, 32, 52, 64, 3, 1, 1), (48, 64, 20, 37, 128, 3, 1, 1), (6, 64, 16, 26, 128, 3, 2, 1), (3, 128, 8, 13, 256, 3, 1, 1)])
+def test_conv_bn_statistics_epilogue_on_bf16_tensors(case):
+    """The same statistics out of the bf16-tensor implicit GEMM (32-channel K-steps; ragged pixel tiles, a stride-2 layer, a split-K candidate).  They come from the fp32
+    accumulators, so against the oracle on the bf16-rounded operands they agree to summation order; the stored bf16 output carries its final rounding."""
+    N, Cin, H, W, Cout, k, s, p = case
+    x = bf16_round(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
+    w = bf16_round((rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    yo = oracle.conv2d_fwd(x, w, None, s, p)
+    md().set_op_storage(True)
+    try:
+        y, mean, invstd = md().conv2d_bnstats(dev(x), dev(w), s, p)
+        y, mean, invstd = host(y), host(mean), host(invstd)
+    finally:
+        md().set_op_storage(False)
+    assert rel(y, yo) < 4e-3
+    m64 = yo.astype(np.float64).mean((0, 2, 3)); v64 = yo.astype(np.float64).var((0, 2, 3))
+    assert np.abs(mean - m64).max() < 1e-5 * max(1.0, np.abs(yo).max()) and rel(invstd, 1.0 / np.sqrt(v64 + 1e-5)) < 1e-4
+
+
 # ---- fused Winograd F(2x2,3x3) kernel (conv_winograd.hip): every 3x3 / stride-1 layer with Cout % 32 == 0, forward and input gradient ---------------------
 WINO_CASES = [
     # N, Cin, H, W, Cout, pad, pad_mode, act

@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
 #ifdef MD2_ABLATE
     a.ablate = abl; a.force_tile = tile;
 #endif
+    a.accumulate_c00 = -1;
     if (getenv("BF16S")) a.bf16 = 2;          // bf16 tensors (the kernels of md2_config.precision = 2): the buffers are read as bf16, their values do not matter for timing
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     if (getenv("WGRAD")) {
