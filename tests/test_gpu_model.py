@@ -575,6 +575,50 @@ def test_bf16_activation_storage_tracks_the_fp32_oracle(cfgd):
     assert np.isfinite(l1) and l1 < l0
 
 
+def test_bf16_activation_storage_on_the_other_entry_points(tmp_path):
+    """The rest of the model surface on a precision = 2 handle: eval_disparity on single frames (encoder batch != 3N), Flux.testmode! (running statistics), the bit-reproducible
+    mode (ordered reductions: two fresh handles agree to the last bit, bf16 rounding is deterministic), a scale_levels subset, and a checkpoint round trip.  Bounds as in
+    test_bf16_activation_storage_tracks_the_fp32_oracle: 5 % on the disparity maps against the fp32 oracle."""
+    N, C, H, W = 3, 1, 64, 96
+    model, params, cache, theta, K, iK = make(N, C, H, W, pseed=6, precision="bf16_storage")
+    frames = syn.synthetic_triplets(N, C, H, W, seed=16)[:, 1]
+    net = oracle.OracleNet(C); net.set_params(theta)
+    for n in (3, 2):
+        ds = md().eval_disparity(model, dev(frames[:n])); do = net.eval_disparity(frames[:n])
+        for i in range(4):
+            assert ds[i].shape == do[i].shape and rel(host(ds[i]), do[i]) < 5e-2
+    xd = dev(syn.synthetic_triplets(N, C, H, W, seed=17))
+    # bit-reproducible mode
+    def run():
+        m2, p2, c2, _, _, _ = make(N, C, H, W, pseed=6, precision="bf16_storage")
+        l = float(md().train_step(m2, xd, None, c2, p2, do_update=True))
+        return l, m2.grads(), m2.params()
+    md().set_deterministic(True)
+    try:
+        a_, b_ = run(), run()
+    finally:
+        md().set_deterministic(False)
+    assert a_[0] == b_[0] and np.array_equal(a_[1], b_[1]) and np.array_equal(a_[2], b_[2])
+    c_ = run()          # the default mode takes its BatchNorm statistics from the fp32 accumulators, the ordered mode from the stored (rounded) tensor: same loss to the mode's own bound (0.5 % measured)
+    assert abs(c_[0] - a_[0]) < 2e-2 * abs(a_[0])
+    # a few steps, then test mode (tracked statistics) and a checkpoint round trip on the same handle
+    for _ in range(3):
+        md().train_step(model, xd, None, cache, params, do_update=True)
+    md().testmode(model, True)
+    try:
+        d1 = [host(t) for t in md().eval_disparity(model, dev(frames))]
+        path = str(tmp_path / "bf16s.npz"); md().save_checkpoint(model, path)
+        m3, p3, c3, _, _, _ = make(N, C, H, W, pseed=99, precision="bf16_storage")
+        md().train_step(m3, xd, None, c3, p3, do_update=False)          # (creates the handle)
+        md().load_checkpoint(m3, path); md().testmode(m3, True)
+        d3 = [host(t) for t in md().eval_disparity(m3, dev(frames))]
+        for u, v in zip(d1, d3):
+            assert np.array_equal(u, v)
+    finally:
+        md().testmode(model, False)
+    assert all(np.isfinite(t).all() for t in d1)
+
+
 def test_eval_poses_matches_the_model_call():
     """eval_poses (src/model.jl:22-35): encoder + pose decoder alone give the poses of the full model call."""
     N, C, H, W = 2, 1, 64, 96
