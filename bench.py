@@ -39,7 +39,7 @@ def pmc_traffic(B, C, H, W, depth, precision):
 
 def bf16_conv_roofline(md, torch, model, step, esz=4, precision="bf16"):
     """The convolutions (forward + input gradient) of a bf16 mode on both rooflines: the class sits far below the bf16 matrix peak and is priced against HBM as well.
-    ALGORITHMIC bytes = each launch reads its input pixels and weights once and writes its output once at the tensors' storage width `esz` (2: bf16 activation storage,
+    ALGORITHMIC bytes = each launch reads its input pixels, its weights and the output-sized operands of its fused epilogue once and writes its output once at the tensors' storage width `esz` (2: bf16 activation storage,
     precision 'bf16_storage'; 4: the bf16-operand mode on fp32 tensors) -- from the per-launch records of the library profiler (M output pixels, Cin, Cout, k, stride) -- over
     the class time measured with HIP events.  (The stem is in the class time and flops but has no per-launch record: its bytes are not counted.)"""
     import re, tempfile
@@ -53,10 +53,10 @@ def bf16_conv_roofline(md, torch, model, step, esz=4, precision="bf16"):
     by = 0.0
     for line in open(tmp).read().splitlines()[1:]:
         f = line.split(",", 4)
-        m = re.match(r"igemm M=(\d+) Cout=(\d+) Cin=(\d+) k=(\d+) s=(\d+)", f[4]) if len(f) == 5 and f[0] == "0" else None
+        m = re.match(r"igemm M=(\d+) Cout=(\d+) Cin=(\d+) k=(\d+) s=(\d+) .* ep=(\d+)", f[4]) if len(f) == 5 and f[0] == "0" else None
         if m:
-            M, co, ci, k, st = (int(v) for v in m.groups())
-            by += float(esz) * (M * st * st * ci + M * co + k * k * ci * co)
+            M, co, ci, k, st, ep = (int(v) for v in m.groups())
+            by += float(esz) * (M * st * st * ci + M * co * (1 + ep) + k * k * ci * co)          # ep: output-sized tensors the fused epilogue reads (residual, activation source, BatchNorm inputs, accumulated y)
     os.remove(tmp)
     if ig["ms"] <= 0:
         return None

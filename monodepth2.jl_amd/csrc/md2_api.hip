@@ -304,7 +304,12 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
     a.ws = (h->cur && h->cur == h->s3) ? h->ws_pose : h->ws_main; a.ws_cap = h->ws_cap;
     char d[112] = "";
     // (alg: the route launch_conv_igemm takes -- conv_igemm_executed_flops applies the same test -- so that a test can see which kernels a step ran: md2_profile_dump)
-    if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d alg=%s", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W,
+    // ep: output-sized tensors the epilogue READS besides writing y (residual, activation-derivative source, BatchNorm inputs of the fused pullback sums, y itself when it
+    // accumulates) -- distinct addresses only: part of the launch's algorithmic bytes (bench.py)
+    int ep = 0;
+    { const void* seen[5]; int ns = 0; const void* cand[5] = {a.res, a.dact_src, a.bz, a.bzB, a.accumulate ? (const void*)a.y : nullptr};
+      for (const void* c : cand) { bool dup = c == nullptr; for (int i = 0; i < ns; ++i) dup = dup || seen[i] == c; if (!dup) { seen[ns++] = c; ++ep; } } }
+    if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d ep=%d alg=%s", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W, ep,
                           conv_igemm_executed_flops(a) < conv_igemm_flops(a) ? (a.wino_pieces ? "winograd_split" : "winograd") : "direct");
     h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
     if (h->prof) { h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a); h->prof_exec[CLS_IGEMM] += conv_igemm_executed_flops(a); }
