@@ -386,6 +386,18 @@ def main():
                 md.train_step(m5, x5, None, c5, p5, True)
             torch.cuda.synchronize(); d5 = time.perf_counter() - t0
             extra["config3_resnet50_640x192_batch16"] = {"value": 16 * n5 / d5, "unit": "triplets/s", "ms_per_step": d5 / n5 * 1e3}
+            # ... and the same configuration with bf16 activation storage (md2_config.precision = 2; not a parity mode): the bottleneck trunk is HBM-bound in its 1x1 layers
+            del m5, x5
+            torch.cuda.empty_cache()
+            m5, p5, c5, x5 = setup(16, depth=50, C=3, H=192, W=640, precision="bf16_storage")
+            for _ in range(3):
+                md.train_step(m5, x5, None, c5, p5, True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n5):
+                md.train_step(m5, x5, None, c5, p5, True)
+            torch.cuda.synchronize(); d5 = time.perf_counter() - t0
+            extra["config3_resnet50_640x192_batch16_bf16_storage"] = {"value": 16 * n5 / d5, "unit": "triplets/s", "ms_per_step": d5 / n5 * 1e3, "precision": "bf16_storage",
+                                                                      "dtype": "bf16 activation / gradient tensors and weight copies, bf16 MFMA, fp32 accumulate (not a parity mode)"}
             # BASELINE.json configs[4]: 1024x320, bf16 mixed precision + min-reprojection automask, batch = 8 per GPU.  NOT a parity mode (the reference computes in Float32):
             # md2_config.precision = 2 -- activations and their gradients are bf16 tensors in HBM, the convolutions read bf16 weight copies and run bf16 MFMAs with fp32
             # accumulation; master weights, BatchNorm statistics, disparities, loss and ADAM stay fp32; tests bound its loss to 2 % of the fp32 oracle and its gradient's direction.
