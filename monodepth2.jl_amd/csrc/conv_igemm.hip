@@ -61,6 +61,13 @@ constexpr int LDK = 20;   // 16 k-values + 4 pad (floats)
                               // sentinel): no mask registers, no four ANDs per 16-byte item (8 of ~26 instructions of a K-step on the 64 x 64 tile).  Not with the input transform
                               // (relu(shift) of a padded zero is not zero: that variant keeps its masks)
 #endif
+#ifndef MD2_T_EPILOGUE_BS
+#define MD2_T_EPILOGUE_BS 1   // bf16 tensors: every tap count takes the LDS-transposed epilogue of the one-tap launches (16 lanes own a pixel's 64 channels: 128-byte rows instead of
+                              // 32 scattered 8-byte pieces per store instruction, statistics reduced through LDS instead of the shuffle butterfly)
+#endif
+#ifndef MD2_T_EPILOGUE_ALL
+#define MD2_T_EPILOGUE_ALL 0  // the same for fp32 tensors (experiment)
+#endif
 #ifndef MD2_LATE_MASK
 #define MD2_LATE_MASK 1   // 1: zero-padding masks are applied when the gathered rows go to LDS (after the step's MFMAs) instead of right after the global loads
 #endif
@@ -501,7 +508,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // ---- epilogue of the one-tap (1x1) launches: their K loop is a handful of steps, so they live or die by how the output tile (and the residual / activation /
     //      BatchNorm-input tensors read beside it) meets HBM.  The accumulators go through LDS once and come back transposed: 16 lanes own the 64 channels (256 B)
     //      of one pixel, so every global access of a wave is four full 256-B rows instead of 64 scattered 16-B pieces.
-    if constexpr (NT == 1 && MF == 32 && TC == 1 && BN == 64 && WC == 2) {
+    if constexpr ((NT == 1 || MD2_T_EPILOGUE_ALL || (BS && MD2_T_EPILOGUE_BS)) && MF == 32 && TC == 1 && BN == 64 && WC == 2) {
         constexpr int TLD = BN + 4;
         __syncthreads();                                   // every wave is done with the operand stages
         float* T = smem;
