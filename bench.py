@@ -10,6 +10,7 @@ ranks, rank 0 prints ONE JSON line.  A step = forward + loss + backward + (all-r
 batch-4 rate is measured as well at N=1 and reported under "extra").
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -364,7 +365,7 @@ def main():
         if world == 1 and not args.no_extra and B != 4:
             # BASELINE.json configs[1]: batch = 4 on one MI355X
             del dp, model
-            torch.cuda.empty_cache()
+            gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()          # (handles freed here, not by a collection inside a timed loop)
             m4, p4, c4, x4 = setup(4)
             for _ in range(5):
                 md.train_step(m4, x4, None, c4, p4, True)
@@ -376,7 +377,7 @@ def main():
             extra["config1_batch4"] = {"value": 4 * n4 / d4, "unit": "triplets/s", "ms_per_step": d4 / n4 * 1e3}
             # BASELINE.json configs[3]: ResNet-50 encoder, 640x192, batch = 16 per GPU (RGB)
             del m4, x4
-            torch.cuda.empty_cache()
+            gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()          # (handles freed here, not by a collection inside a timed loop)
             m5, p5, c5, x5 = setup(16, depth=50, C=3, H=192, W=640)
             for _ in range(3):
                 md.train_step(m5, x5, None, c5, p5, True)
@@ -388,7 +389,7 @@ def main():
             extra["config3_resnet50_640x192_batch16"] = {"value": 16 * n5 / d5, "unit": "triplets/s", "ms_per_step": d5 / n5 * 1e3}
             # ... and the same configuration with bf16 activation storage (md2_config.precision = 2; not a parity mode): the bottleneck trunk is HBM-bound in its 1x1 layers
             del m5, x5
-            torch.cuda.empty_cache()
+            gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()          # (handles freed here, not by a collection inside a timed loop)
             m5, p5, c5, x5 = setup(16, depth=50, C=3, H=192, W=640, precision="bf16_storage")
             for _ in range(3):
                 md.train_step(m5, x5, None, c5, p5, True)
@@ -403,7 +404,7 @@ def main():
             # accumulation; master weights, BatchNorm statistics, disparities, loss and ADAM stay fp32; tests bound its loss to 2 % of the fp32 oracle and its gradient's direction.
             # The round-3 definition (precision 1: only the MFMA operands are bf16, every tensor fp32) is timed beside it.
             del m5, x5
-            torch.cuda.empty_cache()
+            gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()          # (handles freed here, not by a collection inside a timed loop)
             for key, prec, esz, dtype in (("config4_1024x320_bf16_automask_batch8", "bf16_storage", 2, "bf16 activation / gradient tensors and weight copies, bf16 MFMA, fp32 accumulate; fp32 master weights, BatchNorm statistics, loss, ADAM"),
                                           ("config4_1024x320_bf16_operands_fp32_tensors_batch8", "bf16", 4, "bf16 MFMA operands, fp32 tensors and accumulation (md2_config.precision = 1)")):
                 m6, p6, c6, x6 = setup(8, depth=18, C=3, H=320, W=1024, precision=prec, automask=True)
@@ -420,7 +421,7 @@ def main():
                 if esz == 2:
                     extra[key]["roofline"] = bf16_conv_roofline(md, torch, m6, lambda: md.train_step(m6, x6, a6, c6, p6, True), esz=esz, precision=prec)
                 del m6, x6
-                torch.cuda.empty_cache()
+                gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()          # (handles freed here, not by a collection inside a timed loop)
             # and the headline shape in bf16 activation storage, for reference next to `value` (which is fp32)
             m7, p7, c7, x7 = setup(B, precision="bf16_storage")
             for _ in range(3):
@@ -435,7 +436,7 @@ def main():
             # (3, 3) -- `value` is their per-launch mix (1, 1).  Reduced precision, opt-in, never part of `value`: two bf16 pieces per operand (~16-bit mantissas) in the weight
             # gradients only (1, 2) -- round 3's default -- and in every Winograd product (2, 2).
             del m7, x7
-            torch.cuda.empty_cache()
+            gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()          # (handles freed here, not by a collection inside a timed loop)
             dflt = md.get_conv_products()
             m8, p8, c8, x8 = setup(B)
             n8 = 10
@@ -444,6 +445,7 @@ def main():
                                     ("headline_shape_reduced_two_piece_wgrad", (1, 2), "REDUCED precision (opt-in): two bf16 pieces per operand in the weight gradients only"),
                                     ("headline_shape_reduced_two_piece_all", (2, 2), "REDUCED precision (opt-in): two bf16 pieces per operand in every Winograd and weight-gradient product")):
                 md.set_conv_products(*mode)
+                gc.collect()
                 for _ in range(3):
                     md.train_step(m8, x8, None, c8, p8, True)
                 torch.cuda.synchronize(); t0 = time.perf_counter()

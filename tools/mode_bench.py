@@ -32,7 +32,7 @@ def run(B, C, H, W, depth, modes, steps=15):
     model.close()
 
 
-MODES = [(1, 1), (0, 0), (0, 3), (3, 0), (3, 3), (1, 0), (0, 1), (0, 2), (2, 2)]
+MODES = [(1, 1), (0, 0), (0, 3), (3, 0), (3, 3), (1, 0), (0, 1), (0, 2), (1, 2), (2, 2)]
 run(32, 1, 128, 416, 18, MODES)
 if len(sys.argv) > 1:
     run(4, 1, 128, 416, 18, MODES, steps=30)
