@@ -811,8 +811,7 @@ static void bst_fallback(const ConvArgs& a, hipStream_t s) {
 // operand / storage form of a launch: ConvArgs::bf16 = 0 fp32 MFMA, 1 bf16 operands from fp32 tensors (32-wide tiles only), 2 bf16 tensors
 template <int BM, int BN, int WP, int WC, int MF, int NT, int XF = 0, int BST = 0>
 static void launch_igemm_form(const ConvArgs& a, const dim3& g, hipStream_t s) {
-    static const int extra_lds = getenv("MD2_IGEMM_EXTRA_LDS") ? atoi(getenv("MD2_IGEMM_EXTRA_LDS")) : 0;          // (experiment: occupancy sensitivity)
-    if (a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 2, XF, BST>), g, dim3(256), extra_lds, s, a);
+    if (a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 2, XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 1 && MF == 32) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 ? 1 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 0, XF, BST>), g, dim3(256), 0, s, a);
 }
