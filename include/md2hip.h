@@ -195,6 +195,8 @@ int32_t md2_photometric_loss_bwd(const float* pred, const float* target, const f
 int32_t md2_prediction_loss_fwd(const float* preds, int32_t k, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
 /* pullback wrt the k predictions: the gradient of `minimum` goes to the first arg-min; dpreds [k][N][C][H][W] */
 int32_t md2_prediction_loss_bwd(const float* preds, int32_t k, const float* target, const float* dout, float* dpreds, int32_t N, int32_t C, int32_t H, int32_t W, void* stream);
+/* _apply_mask(mask, warp_loss), src/training.jl:17-19: minimum(cat(mask, warp_loss; dims=3); dims=3) of two [N][1][H][W] maps = their elementwise minimum (n elements) */
+int32_t md2_apply_mask(const float* mask, const float* warp_loss, float* out, int64_t n, void* stream);
 /* disparity_to_depth, src/utils.jl:175-179 */
 int32_t md2_disparity_to_depth(const float* d, float* out, int64_t n, double min_depth, double max_depth, void* stream);
 /* Backproject(depth, invK), src/utils.jl:63-65: depth [N][P] -> [N][P][3] */

@@ -72,6 +72,7 @@ _SIGS = {
     "md2_alloc": (I32, [P, I64]),
     "md2_free": (I32, [P]),
     "md2_prediction_loss_fwd": (I32, [P, I32, P, P, I32, I32, I32, I32, P]),
+    "md2_apply_mask": (I32, [P, P, P, I64, P]),
     "md2_disparity_to_depth": (I32, [P, P, I64, F64, F64, P]),
     "md2_backproject": (I32, [P, P, P, I32, I32, I32, P]),
     "md2_project": (I32, [P, P, P, P, P, I32, I32, I32, P]),

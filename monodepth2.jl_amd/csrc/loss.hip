@@ -398,8 +398,13 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
     float acc[24], s_photo = 0.f;
 #pragma unroll
     for (int k = 0; k < 24; ++k) acc[k] = 0.f;
+    if constexpr (C > 1) {                               // three channels: the 24 pose sums live only inside phase 3 -- per tile they are row-reduced into `red` (held across phases 1-2 they went to scratch)
+        for (int i = threadIdx.x; i < 16 * 25; i += 256) (&red[0][0])[i] = 0.f;
+    }
 
     for (int t = 0; t < tpb; ++t) {
+        int tid = threadIdx.x;
+        if (C > 1) asm volatile("" : "+v"(tid));      // three channels: keeps hipcc from hoisting the per-thread tile indices of every phase out of the tile loop (they lived in scratch: 56 spilled registers)
         const int tix = blockIdx.x * tpb + t;
         if (tix >= ntx) break;
         const int tx0 = tix * TW;
@@ -408,11 +413,11 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
         if (dlo) {
             int i1; float f;
             up_src_r(ty0, dh, rh, ci_lo, i1, f); up_src_r(tx0, dw, rw, cj_lo, i1, f);                 // first coarse row / column this tile touches
-            for (int i = threadIdx.x; i < CH * TW; i += 256) crow[i] = 0.f;
-            for (int i = threadIdx.x; i < CH * CW; i += 256) cacc[i] = 0.f;
+            for (int i = tid; i < CH * TW; i += 256) crow[i] = 0.f;
+            for (int i = tid; i < CH * CW; i += 256) cacc[i] = 0.f;
         }
         // ---- phase 1: values at padded positions u in tile + 2 (u clamped into the padded domain [-1, size])
-        for (int i = threadIdx.x; i < VH * VW; i += 256) {
+        for (int i = tid; i < VH * VW; i += 256) {
             const int ry = i / VW, rx = i - ry * VW;
             const int uy = max(-1, min(ty0 - 2 + ry, H)), ux = max(-1, min(tx0 - 2 + rx, W));
             const int py = refl_idx(uy, H), px = refl_idx(ux, W);
@@ -438,13 +443,15 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
         }
         __syncthreads();
         // ---- phase 2: window owners q in tile + 1, OSH vertically adjacent ones per thread
-        for (int st = threadIdx.x; st < OW * NSR; st += 256) {
+#pragma unroll 1
+        for (int st = tid; st < OW * NSR; st += 256) {
             const int k3 = st / OW, rx = st - k3 * OW, ry0 = k3 * OSH;
             float pl[OSH][2], gmx[OSH][2][C], gpxx[OSH][2][C], gpxy[OSH][2][C];
 #pragma unroll
             for (int oo = 0; oo < OSH; ++oo) { pl[oo][0] = 0.f; pl[oo][1] = 0.f; }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
+                if (C > 1 && c) __builtin_amdgcn_sched_barrier(0);      // one channel's window rows at a time: hoisting all three channels' LDS reads pushed the pose sums into scratch
                 float Ry[OSH + 2], Ryy[OSH + 2], yc[OSH + 2], Rx[2][OSH + 2], Rxx[2][OSH + 2], Rxy[2][OSH + 2], xc[2][OSH + 2];
 #pragma unroll
                 for (int j = 0; j < OSH + 2; ++j) {
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
         __syncthreads();
         // ---- phase 3: tile pixels, SH per thread down a column
         {
-            const int lx = threadIdx.x & 31, ly0 = (threadIdx.x >> 5) * SH, px = tx0 + lx;
+            const int lx = tid & 31, ly0 = (tid >> 5) * SH, px = tx0 + lx;
             const float wxm = px == 1 ? 2.f : 1.f, wxp = px == W - 2 ? 2.f : 1.f;          // pad_reflect: column px-1 / px+1 is seen a second time through the padded column
             float rs[3][2][C][3];                                                          // ring of owner-row sums: [row][source][channel][coefficient]
             auto rowsum = [&](int orow, float (&r)[2][C][3]) {
@@ -516,10 +523,48 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                         for (int k = 0; k < 3; ++k) { const float cv = coef[c][k][qi]; r[0][c][k] += m0 * cv; r[1][c][k] += m1 * cv; }
                 }
             };
-            rowsum(ly0, rs[0]); rowsum(ly0 + 1, rs[1]);                                    // owner rows of pixel rows ly0-1 and ly0
+            float gwp[C > 1 ? SH : 1][2][C];                                              // three channels: d loss / d warped_s[r][c] of the thread's SH pixels, one channel at a time
+            if constexpr (C > 1) {                                                        // (the ring of all channels' row sums is 54 registers; per channel it is (SH + 2) x 6)
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (c) __builtin_amdgcn_sched_barrier(0);
+                    float r1[SH + 2][2][3];
+#pragma unroll
+                    for (int r = 0; r < SH + 2; ++r) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { r1[r][0][k] = 0.f; r1[r][1][k] = 0.f; }
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int qi = (ly0 + r) * OW + lx + 1 + dx;
+                            const int am = amin[qi];
+                            const float w = dx < 0 ? wxm : (dx > 0 ? wxp : 1.f);
+                            const float m0 = am == 0 ? w : 0.f, m1 = am == 1 ? w : 0.f;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) { const float cv = coef[c][k][qi]; r1[r][0][k] += m0 * cv; r1[r][1][k] += m1 * cv; }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < SH; ++i) {
+                        const int py = ty0 + ly0 + i, cb = (ly0 + i + 2) * VW + lx + 2;
+                        const float wym = py == 1 ? 2.f : 1.f, wyp = py == H - 2 ? 2.f : 1.f;
+                        const int rwin = amin[(ly0 + i + 1) * OW + lx + 1];
+                        const float xv[2] = {wv[0][c][cb], wv[1][c][cb]}, tv = tg[c][cb];
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float g0 = wym * r1[i][s][0] + r1[i + 1][s][0] + wyp * r1[i + 2][s][0];
+                            const float g1 = wym * r1[i][s][1] + r1[i + 1][s][1] + wyp * r1[i + 2][s][1];
+                            const float g2 = wym * r1[i][s][2] + r1[i + 1][s][2] + wyp * r1[i + 2][s][2];
+                            float g = g0 + 2.f * xv[s] * g1 + tv * g2;
+                            if (rwin == s) { const float df = tv - xv[s]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
+                            gwp[i][s][c] = g;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else { rowsum(ly0, rs[0]); rowsum(ly0 + 1, rs[1]); }                          // owner rows of pixel rows ly0-1 and ly0
 #pragma unroll
             for (int i = 0; i < SH; ++i) {
-                rowsum(ly0 + i + 2, rs[(i + 2) % 3]);
+                if constexpr (C == 1) rowsum(ly0 + i + 2, rs[(i + 2) % 3]);
                 const int ly = ly0 + i, py = ty0 + ly;
                 if (py >= H || px >= W) continue;
                 const float wym = py == 1 ? 2.f : 1.f, wyp = py == H - 2 ? 2.f : 1.f;
@@ -533,11 +578,15 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                     bool any = false;
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
-                        const float g0 = wym * rs[i % 3][s][c][0] + rs[(i + 1) % 3][s][c][0] + wyp * rs[(i + 2) % 3][s][c][0];
-                        const float g1 = wym * rs[i % 3][s][c][1] + rs[(i + 1) % 3][s][c][1] + wyp * rs[(i + 2) % 3][s][c][1];
-                        const float g2 = wym * rs[i % 3][s][c][2] + rs[(i + 1) % 3][s][c][2] + wyp * rs[(i + 2) % 3][s][c][2];
-                        float g = g0 + 2.f * wv[s][c][cb] * g1 + tg[c][cb] * g2;
-                        if (rwin == s) { const float df = tg[c][cb] - wv[s][c][cb]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
+                        float g;
+                        if constexpr (C > 1) g = gwp[i][s][c];
+                        else {
+                            const float g0 = wym * rs[i % 3][s][c][0] + rs[(i + 1) % 3][s][c][0] + wyp * rs[(i + 2) % 3][s][c][0];
+                            const float g1 = wym * rs[i % 3][s][c][1] + rs[(i + 1) % 3][s][c][1] + wyp * rs[(i + 2) % 3][s][c][1];
+                            const float g2 = wym * rs[i % 3][s][c][2] + rs[(i + 1) % 3][s][c][2] + wyp * rs[(i + 2) % 3][s][c][2];
+                            g = g0 + 2.f * wv[s][c][cb] * g1 + tg[c][cb] * g2;
+                            if (rwin == s) { const float df = tg[c][cb] - wv[s][c][cb]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
+                        }
                         gw[c] = g; any = any || g != 0.f;
                     }
                     if (!any) continue;
@@ -593,13 +642,18 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                 } else dd[(long)py * W + px] = gd + gs;
             }
         }
+        if constexpr (C > 1) {
+            const int row = tid >> 4;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) { const float r = row16_sum(acc[k]); if ((tid & 15) == 0) red[row][k] += r; acc[k] = 0.f; }      // (lane 0 of a row is the only writer of red[row][*])
+        }
         // ---- coarse scales: column direction on the few coarse rows, then flush (border rows / columns are shared with the neighbouring tiles -> float atomics)
         if (dlo) {
             __syncthreads();
             int i0, ci_hi, cj_hi; float f;
             up_src_r(min(ty0 + TH, H) - 1, dh, rh, i0, ci_hi, f); up_src_r(min(tx0 + TW, W) - 1, dw, rw, i0, cj_hi, f);
             const int nrow = ci_hi - ci_lo + 1, ncol = cj_hi - cj_lo + 1;
-            for (int it = threadIdx.x; it < nrow * TW; it += 256) {
+            for (int it = tid; it < nrow * TW; it += 256) {
                 const int r = it / TW, p = it - r * TW;
                 if (tx0 + p >= W) continue;
                 int w0, w1; float fw; up_src_r(tx0 + p, dw, rw, w0, w1, fw);
@@ -607,7 +661,7 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                 atomicAdd(cacc + r * CW + w0 - cj_lo, (1.f - fw) * v); atomicAdd(cacc + r * CW + w1 - cj_lo, fw * v);
             }
             __syncthreads();
-            for (int it = threadIdx.x; it < nrow * ncol; it += 256) {
+            for (int it = tid; it < nrow * ncol; it += 256) {
                 const int r = it / ncol, c = it - r * ncol;
                 const float v = cacc[r * CW + c];
                 if (v != 0.f) atomicAdd(dlo + (long)(ci_lo + r) * dw + cj_lo + c, v);
@@ -616,8 +670,10 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
     }
     // ---- block reduction: rows of 16 lanes by DPP, the 16 rows through LDS, one double atomic per value per block
     const int row = threadIdx.x >> 4;
+    if constexpr (C == 1) {
 #pragma unroll
-    for (int k = 0; k < 24; ++k) { const float r = row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[row][k] = r; }
+        for (int k = 0; k < 24; ++k) { const float r = row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[row][k] = r; }
+    }
     { const float r = row16_sum(s_photo); if ((threadIdx.x & 15) == 0) red[row][24] = r; }
     __syncthreads();
     if (threadIdx.x < 25) {
@@ -829,6 +885,9 @@ __global__ void op_prediction_kernel(const float* __restrict__ preds, int k, con
         }
         out[i] = best;
     }
+}
+__global__ void op_apply_mask_kernel(const float* __restrict__ mask, const float* __restrict__ wl, float* __restrict__ out, long n) {      // _apply_mask, src/training.jl:17-19
+    FOR1D(i, n) { const float m = mask[i], w = wl[i]; out[i] = w < m ? w : m; }                  // Julia `minimum` over (mask, warp_loss): the first of equal values, NaN-free inputs
 }
 __global__ void op_d2d_kernel(const float* __restrict__ d, float* __restrict__ out, long n, float min_disp, float max_disp) {
     FOR1D(i, n) out[i] = 1.f / (d[i] * (max_disp - min_disp) + min_disp);
@@ -1083,6 +1142,10 @@ int32_t md2_photometric_loss_fwd(const float* pred, const float* target, float* 
 int32_t md2_prediction_loss_fwd(const float* preds, int32_t k, const float* target, float* out, int32_t N, int32_t C, int32_t H, int32_t W, void* stream) {
     if (H < 2 || W < 2 || k < 1) return 2;
     hipLaunchKernelGGL(op_prediction_kernel, GRID1D((long)N * H * W), 0, S_(stream), preds, k, target, out, N, C, H, W, (long)N * C * H * W, (long)C * H * W, (long)C * H * W); return chk();
+}
+int32_t md2_apply_mask(const float* mask, const float* warp_loss, float* out, int64_t n, void* stream) {
+    if (n < 1) return 2;
+    hipLaunchKernelGGL(op_apply_mask_kernel, GRID1D((long)n), 0, S_(stream), mask, warp_loss, out, (long)n); return chk();
 }
 int32_t md2_ssim_bwd(const float* x, const float* y, const float* dout, float* dx, float* dy, int32_t planes, int32_t H, int32_t W, void* stream) {
     if (H < 2 || W < 2) return 2;

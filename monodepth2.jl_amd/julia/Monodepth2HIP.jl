@@ -308,6 +308,11 @@ function ∇prediction_loss(preds::ROCArray{Float32,5}, target::ROCArray{Float32
 end
 ChainRulesCore.rrule(::typeof(prediction_loss), preds::ROCArray{Float32,5}, target::ROCArray{Float32,4}) =
     prediction_loss(preds, target), Δ -> (NoTangent(), ∇prediction_loss(preds, target, ROCArray{Float32}(unthunk(Δ))), NoTangent())
+# _apply_mask(mask, warp_loss), src/training.jl:17-19
+function _apply_mask(mask::ROCArray{Float32,4}, warp_loss::ROCArray{Float32,4})
+    size(mask) == size(warp_loss) || error("_apply_mask: sizes differ")
+    out = similar(warp_loss); ok(md2_apply_mask(dptr(mask), dptr(warp_loss), dptr(out), length(out), NOSTREAM), "apply_mask"); out
+end
 # disparity_to_depth, src/utils.jl:175-179
 function disparity_to_depth(d::ROCArray{Float32}, min_depth, max_depth)
     out = similar(d); ok(md2_disparity_to_depth(dptr(d), dptr(out), length(d), Float64(min_depth), Float64(max_depth), NOSTREAM), "disparity_to_depth"); out

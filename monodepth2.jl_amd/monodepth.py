@@ -234,9 +234,13 @@ def automasking_loss(ssim, inputs, target, source_ids):
 
 
 def _apply_mask(mask, warp_loss):
-    """`_apply_mask` (src/training.jl:17-19) for the op-level call surface only (the visualization map): an elementwise minimum of two device tensors, host glue through torch.
-    The training step never comes here -- the fused loss kernel applies the mask itself (md2_train_loss, ties -> mask)."""
-    return torch.minimum(mask, warp_loss)
+    """`_apply_mask` (src/training.jl:17-19): minimum over the channel-concatenation of the automask and the warp loss = their elementwise minimum (md2_apply_mask).
+    Op-level call surface (the visualization map); the training step applies the mask inside the fused loss kernel (md2_train_loss, ties -> mask)."""
+    m, w = _f32(mask), _f32(warp_loss)
+    if m.shape != w.shape:
+        raise ValueError("_apply_mask: mask %s and warp_loss %s differ in shape" % (tuple(m.shape), tuple(w.shape)))
+    out = torch.empty_like(w)
+    _check(_lib.lib().md2_apply_mask(_dev(m), _dev(w), _dev(out), m.numel(), _stream())); return out
 
 
 # --------------------------------------------------------------------------------------------

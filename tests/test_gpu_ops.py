@@ -76,6 +76,10 @@ def test_photometric_and_prediction_loss():
     al = host(md().automasking_loss(md().SSIM(), dev(x), dev(x[:, 1]), [1, 3]))
     cfg = oracle.make_cfg(N, C, H, W, *syn.depth10k_intrinsics(W, H))
     assert np.abs(al - oracle.automasking_loss(x, cfg)).max() < 2e-5
+    # _apply_mask (src/training.jl:17-19): minimum over cat(mask, warp_loss; dims=3) -- bit-exact (md2_apply_mask)
+    wl = host(md().prediction_loss(md().SSIM(), [dev(x[:, 0]), dev(x[:, 2])], dev(x[:, 1])))
+    wl2 = (wl + 0.02 * rng.standard_normal(wl.shape)).astype(np.float32)
+    assert np.array_equal(host(md()._apply_mask(dev(al), dev(wl2))), np.minimum(al, wl2))
 
 
 def test_smooth_loss_known_answer_and_random():

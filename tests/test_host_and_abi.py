@@ -164,3 +164,33 @@ def test_conv_product_modes_are_validated_and_round_trip_without_a_device():
         L.md2_get_conv_products(ctypes.byref(f), ctypes.byref(w)); assert (f.value, w.value) == (3, 3)
     finally:
         L.md2_set_winograd(1, -2); L.md2_set_conv_products(*dflt)
+
+
+# Kernels that may keep a private (scratch) segment, with the reason.  Everything else in libmd2hip.so must have `.private_segment_fixed_size: 0` and no spilled
+# VGPR: scratch traffic is HBM traffic the roofline does not see (round 4: loss_train_kernel<3,16> moved 4.8x its algorithmic bytes through a 224-byte segment).
+SCRATCH_ALLOWED = {
+    # opt-in 64-tile Winograd workgroups of the five-row-segment shape (md2_set_winograd NH = 2, not a default route): 5 registers over the 256 budget
+    "conv_wino3_kernel<5, 0, 0, 2>", "conv_wino3_kernel<5, 0, 1, 2>",
+    # the opt-in REDUCED two-piece weight gradient on multi-row batches (md2_set_conv_products(., 2)): never in `value`
+    "conv_wino_wgrad_s_kernel<1, 2, 1>",
+}
+
+
+def test_no_kernel_uses_scratch():
+    """Code-object metadata of every gfx950 kernel in the built library (llvm-readelf --notes; tools/kernel_resources.py): no private segment, no spilled vector register,
+    outside a short allow-list of opt-in instantiations -- and every loss_train_kernel instantiation is spill-free whatever the list says."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    if not os.path.exists(os.path.join(kernel_resources.LLVM, "llvm-readelf")):
+        pytest.skip("no llvm-readelf in this image")
+    rows = kernel_resources.kernel_resources(md2amd._lib.LIB_PATH)
+    assert len(rows) > 300, "the code objects of libmd2hip.so were not found"
+    assert sum("loss_train_kernel" in n for n, _ in rows) >= 2
+    bad = []
+    for name, r in rows:
+        if r["private_segment_fixed_size"] > 0 or r["vgpr_spill_count"] > 0:
+            allowed = any(a in name for a in SCRATCH_ALLOWED) and "loss_train_kernel" not in name
+            if not allowed:
+                bad.append("%s: %d B scratch, %d spilled VGPRs" % (name, r["private_segment_fixed_size"], r["vgpr_spill_count"]))
+    assert not bad, "kernels with a private segment: " + "; ".join(bad)
