@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include <type_traits>
 namespace md2 {
 
 // exact floor(m / d) for 0 <= m < 2^24, d >= 1 from the float reciprocal with a +-1 correction: ~8 VALU instructions instead of the ~40 of a 32-bit integer division.  The
@@ -725,26 +726,41 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
     const int n_rows_total = a.N * TH;
 
     // ---- loader: item f = tid + 256 li = (slot f >> 2, 16-B piece f & 3 of the 16 channels); piece >> 1 = plane, piece & 1 = half inside the plane's 8-float slot
+    // Geometry once per SLOT (round 5): the four 16-byte pieces of a slot share everything but their channel offset, so thread t works out the byte offset of slots t and
+    // t + 256 (or the "nothing to load" marker), the table goes through the second pipeline stage's LDS (nobody writes it before the end of chunk 0, a barrier later) and a thread
+    // picks up its six slots from there -- 2 instead of 6 evaluations of the segment / reflection / bounds arithmetic per thread (~400 of the ~750 prologue vector instructions).
     unsigned l_off[NLI]; unsigned l_ok = 0;
     const int piece = tid & 3, pl = piece >> 1, h2 = piece & 1;
     const int l_dst0 = pl * PL + (tid >> 2) * 8 + ((h2 ^ ((tid >> 5) & 1)) << 2);          // + li * 512 floats (64 slots)
+    {
+        unsigned* tab = reinterpret_cast<unsigned*>(wsm) + PST;
 #pragma unroll
-    for (int li = 0; li < NLI; ++li) {
-        const int slot = (tid + 256 * li) >> 2;
-        int k, r, WP, txa, Lk;
-        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
-        else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }
-        const int pa = fdiv24(r, WP), pc = r - pa * WP;
-        const int rr = rr_first + k;
-        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
-        const int rrc = act ? rr : 0;
-        const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
-        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
-        bool ok = act;
-        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
-        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        l_ok |= ok ? (1u << li) : 0u;
-        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(piece * 4)) * 4u : (XF != 0 ? (unsigned)(piece * 16) : W_OOB);
+        for (int q = 0; q < 2; ++q) {
+            const int slot = tid + 256 * q;
+            if (slot < 384) {
+                int k, r, WP, txa, Lk;
+                if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
+                else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }
+                const int pa = fdiv24(r, WP), pc = r - pa * WP;
+                const int rr = rr_first + k;
+                const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+                const int rrc = act ? rr : 0;
+                const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
+                int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+                bool ok = act;
+                if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+                else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                tab[slot] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps)) * 4u : 0xFFFFFFFFu;          // (valid offsets are multiples of 16 below 2^32 - 16)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            const unsigned v = tab[(tid >> 2) + 64 * li];
+            const bool ok = v != 0xFFFFFFFFu;
+            l_ok |= ok ? (1u << li) : 0u;
+            l_off[li] = ok ? v + (unsigned)(piece * 16) : (XF != 0 ? (unsigned)(piece * 16) : W_OOB);
+        }
     }
     const char* xb = reinterpret_cast<const char*>(a.x);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
@@ -807,8 +823,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
 
     gload(0); lstore(0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int so = (c & 1) * PST;
+    // the chunk loop is unrolled by two with the stage offset a compile-time constant (round 5): the 16 LDS read addresses of a chunk are then base registers + an immediate
+    // instead of 16 v_lshl_add per chunk
+    auto chunk = [&](const int c, auto so_tag) {
+        constexpr int so = decltype(so_tag)::value;
         const int cn = min(c + 1, nchunks - 1);
         const __bf16* un = ub + (long)cn * (4 * NP * 512);
         gload(cn);
@@ -854,6 +872,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
         }
         lstore(PST - so);
         __syncthreads();
+    };
+    {
+        int c = 0;
+        for (; c + 1 < nchunks; c += 2) { chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, PST>{}); }
+        if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
     }
 
     // ---- output transform: column half in registers, row half through LDS (R[i][b][32 tiles][COB + 4]) -- as conv_wino3_kernel
@@ -872,6 +895,253 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
     }
     __syncthreads();
     wino_final_epilogue<256, COB, BST>(a, wsm, m0, WT, Mt, THW, TW, c0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The split kernel with 64 output channels per workgroup (round 5).  conv_wino3s_kernel redoes the input transform and the three-piece split of the same V in every one of
+// its Cout / 32 workgroups per tile block: 12-14.6 vector instructions per MFMA, matrix pipe 0.20 busy (profiles/r04_mfma_pmc.md).  Here a workgroup is 512 threads = 8 waves,
+// wave = (Winograd row i, position pair jp): it forms V_(i, 2 jp) and V_(i, 2 jp + 1) -- three of the four row-combined patch columns, 12 instead of 32 ds_read_b128 per chunk --
+// splits them once and contracts the pieces against the U fragments of BOTH 32-channel halves (24 MFMAs per wave and chunk for half the transform / split work, every LDS
+// read and every loader instruction amortised over twice the products).  The accumulators stay at 64 registers per lane (2 positions x 2 channel halves), the U ring at 48,
+// so the kernel sits near 200 registers where a four-wave form of the same tile (128 accumulators) does not close its budget.  One workgroup per CU
+// (two waves per SIMD, as before).  The two position pairs of a row meet in the output transform: the jp = 0 waves store their column-half partial sums, the jp = 1 waves add
+// theirs in place, then the common epilogue.  Same U layout, loader, LDS patch layout and epilogue contract as conv_wino3s_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int XF, int BST, int NP>
+__global__ __launch_bounds__(512, 2) void conv_wino3w_kernel(ConvArgs a, Wino2Geo geo) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int COB = 64, WT = 32, NLI = 3;
+    constexpr int PL = 128 * 3 * 8;                  // floats per 8-channel plane (384 slots), two planes per stage
+    constexpr int PST = 2 * PL;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wi = wv & 3, jp = wv >> 2;
+    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_p = bid % ntp, tile_c = bid / ntp;
+    const int m0 = tile_p * WT, c0 = tile_c * COB;
+    const int THW = TH * TW;
+    const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
+    const int L0 = min(TW - tx0, WT);
+    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, WT), S = 4 * (2 * Lf + 2);
+    const int n_rows_total = a.N * TH;
+
+    // ---- loader: item f = tid + 512 li = (slot f >> 2, 16-B piece f & 3 of the 16 channels); piece >> 1 = plane, piece & 1 = half inside the plane's 8-float slot
+    unsigned l_off[NLI]; unsigned l_ok = 0;
+    const int piece = tid & 3, pl = piece >> 1, h2 = piece & 1;
+    const int l_dst0 = pl * PL + (tid >> 2) * 8 + ((h2 ^ ((tid >> 5) & 1)) << 2);          // + li * 1024 floats (128 slots)
+#pragma unroll
+    for (int li = 0; li < NLI; ++li) {
+        const int slot = (tid + 512 * li) >> 2;
+        int k, r, WP, txa, Lk;
+        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
+        else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }
+        const int pa = fdiv24(r, WP), pc = r - pa * WP;
+        const int rr = rr_first + k;
+        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+        const int rrc = act ? rr : 0;
+        const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
+        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+        bool ok = act;
+        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        l_ok |= ok ? (1u << li) : 0u;
+        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(piece * 4)) * 4u : (XF != 0 ? (unsigned)(piece * 16) : W_OOB);
+    }
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
+    uint4 ra[NLI];
+    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            if constexpr (XF != 0) ra[li] = *reinterpret_cast<const uint4*>(xb + (l_off[li] + (unsigned)(c * 64)));
+            else ra[li] = wino_buffer_load16(xrs, l_off[li], c * 64);
+        }
+        if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + c * 16 + piece * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + c * 16 + piece * 4); }
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            const unsigned mk = 0u - ((l_ok >> li) & 1u);
+            uint4 v = ra[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            if constexpr (XF != 0) {
+                v.x = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.x), xsc.x, xsh.x), 0.f)); v.y = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.y), xsc.y, xsh.y), 0.f));
+                v.z = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.z), xsc.z, xsh.z), 0.f)); v.w = __float_as_uint(fmaxf(fmaf(__uint_as_float(v.w), xsc.w, xsh.w), 0.f));
+            }
+            if constexpr (XF != 0) { v.x &= mk; v.y &= mk; v.z &= mk; v.w &= mk; }
+            *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 1024) = v;
+        }
+    };
+
+    // ---- consumer: lane = (tile, k-group g = plane); B^T row i combines patch rows (r1, r2).  The wave's two positions need three of the four row-combined columns:
+    //      jp = 0: V_0 = c0 - c2, V_1 = c1 + c2;   jp = 1: V_2 = c2 - c1, V_3 = c1 - c3.   With (P, Q, R) = (c0, c2, c1) / (c2, c1, c3): V_a = P - Q, V_b = Q + s R, s = +1 / -1.
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const float sR = jp ? -1.f : 1.f;
+    const int tl = lane & 31, g = lane >> 5;
+    int c_off1[3], c_off2[3];          // piece 0 of the slot; piece 1 is at (offset ^ 4)
+    {
+        const int u = tx0 + tl, k = fdiv24(u, TW);
+        const int lc = (k == 0) ? tl : (u - k * TW);
+        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, WT - L0 - (k - 1) * TW) + 2;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int col = jp ? (b == 0 ? 2 : (b == 1 ? 1 : 3)) : (b == 0 ? 0 : (b == 1 ? 2 : 1));
+            const int sl1 = base + r1 * WP + 2 * lc + col, sl2 = base + r2 * WP + 2 * lc + col;
+            c_off1[b] = g * PL + sl1 * 8 + (((sl1 >> 3) & 1) << 2);
+            c_off2[b] = g * PL + sl2 * 8 + (((sl2 >> 3) & 1) << 2);
+        }
+    }
+
+    f32x16 acc[2][2];          // [position of the pair][32-channel half]
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jj][cb][e] = 0.f;
+
+    // U stream of this wave: channel half cb, chunk c16, position j = 2 jp + jj, piece q at ub[cb] + ((c16 * 4 + j) * NP + q) * 512 bf16 (64 lanes x 8)
+    const int nchunks = a.Cin >> 4;
+    const __bf16* ub[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) ub[cb] = reinterpret_cast<const __bf16*>(a.wino_u) + ((long)((tile_c * 2 + cb) * 4 + wi) * nchunks) * 4 * NP * 512 + (2 * jp) * NP * 512 + lane * 8;
+    wbf16x8 u[2][2][NP];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) u[jj][cb][q] = *reinterpret_cast<const wbf16x8*>(ub[cb] + (jj * NP + q) * 512);
+#ifdef MD2_ABLATE
+    if (a.ablate & 128) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) u[jj][cb][q] = __builtin_bit_cast(wbf16x8, (wu32x4){(unsigned)lane, 1u, 2u, 3u});
+    }
+#endif
+
+#ifdef MD2_ABLATE
+    const int abl = a.ablate;          // timing experiments (tools/conv_bench): 1 no patch loads / commits, 2 no U refills, 4 no MFMAs, 8 no barrier, 32 no LDS reads / transform / split
+#else
+    constexpr int abl = 0;
+#endif
+    if (!(abl & 128)) { gload(0); lstore(0); }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int so = (c & 1) * PST;
+        const int cn = min(c + 1, nchunks - 1);
+        const long uno = (long)cn * (4 * NP * 512);
+        if (!(abl & 1)) gload(cn);
+        __builtin_amdgcn_sched_barrier(0);
+        // B^T row combination of the lane's 8 channels (two 16-B pieces) for the three columns P, Q, R
+        float4 rr[3][2];
+#ifdef MD2_ABLATE
+        if (abl & 32) { for (int b = 0; b < 3; ++b) rr[b][0] = rr[b][1] = make_float4(sg, sg, sg, sg); } else
+#endif
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + (c_off1[b] ^ (p << 2)));
+                const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + (c_off2[b] ^ (p << 2)));
+                rr[b][p] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+            }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            unsigned vp[NP][4];
+#ifdef MD2_ABLATE
+            if (abl & 32) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { vp[q][0] = vp[q][1] = vp[q][2] = vp[q][3] = 0x3f803f80u + (unsigned)jj; }
+            } else
+#endif
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float4 v;
+                if (jj == 0) v = make_float4(rr[0][p].x - rr[1][p].x, rr[0][p].y - rr[1][p].y, rr[0][p].z - rr[1][p].z, rr[0][p].w - rr[1][p].w);
+                else v = make_float4(fmaf(sR, rr[2][p].x, rr[1][p].x), fmaf(sR, rr[2][p].y, rr[1][p].y), fmaf(sR, rr[2][p].z, rr[1][p].z), fmaf(sR, rr[2][p].w, rr[1][p].w));
+                if constexpr (NP == 2) { split_pk(v.x, v.y, vp[0][2 * p], vp[1][2 * p]); split_pk(v.z, v.w, vp[0][2 * p + 1], vp[1][2 * p + 1]); }
+                else { split3_pk(v.x, v.y, vp[0][2 * p], vp[1][2 * p], vp[2][2 * p]); split3_pk(v.z, v.w, vp[0][2 * p + 1], vp[1][2 * p + 1], vp[2][2 * p + 1]); }
+            }
+            wbf16x8 vb[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) vb[q] = __builtin_bit_cast(wbf16x8, (wu32x4){vp[q][0], vp[q][1], vp[q][2], vp[q][3]});
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                // small terms first
+                if (!(abl & 4)) {
+                if constexpr (NP == 3) {
+                    acc[jj][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[jj][cb][2], vb[0], acc[jj][cb], 0, 0, 0);
+                    acc[jj][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[jj][cb][0], vb[2], acc[jj][cb], 0, 0, 0);
+                    acc[jj][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[jj][cb][1], vb[1], acc[jj][cb], 0, 0, 0);
+                }
+                acc[jj][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[jj][cb][1], vb[0], acc[jj][cb], 0, 0, 0);
+                acc[jj][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[jj][cb][0], vb[1], acc[jj][cb], 0, 0, 0);
+                acc[jj][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[jj][cb][0], vb[0], acc[jj][cb], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) asm volatile("" :: "v"(u[jj][cb][q]), "v"(vb[q]));
+                }
+                // refill in place right behind the fragment set's last use, as in conv_wino3_kernel
+                if (!(abl & 2)) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) u[jj][cb][q] = *reinterpret_cast<const wbf16x8*>(ub[cb] + uno + (jj * NP + q) * 512);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(abl & 1)) lstore(PST - so);
+        if (!(abl & 8)) __syncthreads();
+    }
+
+#ifdef MD2_ABLATE
+    if (abl & 64) { if (acc[0][0][0] + acc[1][1][3] == 123.456f) a.y[0] = 1.f; return; }          // timing experiment: no output transform / epilogue
+    if (abl & 256) {          // timing experiment: plain stores of the accumulators instead of the output transform + epilogue (wrong values, the same bytes)
+        float* yp = a.y + ((long)bid * 512 + tid) * 16;          // (32 tiles x 4 pixels x 64 channels = 512 threads x 16 floats: the workgroup's own output bytes)
+        f32x16 t = acc[0][0];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t[e] += acc[0][1][e] + acc[1][0][e] + acc[1][1][e];
+        if ((long)(bid + 1) * 512 * 16 <= (long)a.N * a.Ho * a.Wo * a.Cout) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<float4*>(yp + gq * 4) = make_float4(t[4 * gq], t[4 * gq + 1], t[4 * gq + 2], t[4 * gq + 3]);
+        }
+        return;
+    }
+#endif
+    // ---- output transform: column half in registers -- o0 = M0 + M1 + M2, o1 = M1 - M2 - M3, the jp = 0 waves hold M0, M1 and store (M0 + M1, M1), the jp = 1 waves hold
+    //      M2, M3 and add (M2, -M2 - M3) in place -- row half through LDS (R[i][b][32 tiles][COB + 4]), as conv_wino3_kernel
+    constexpr int RLD = COB + 4;
+    float* Rl = wsm;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (jp == pass) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float4 o0, o1;
+                    const f32x16& A0 = acc[0][cb]; const f32x16& A1 = acc[1][cb];
+                    if (pass == 0) {
+                        o0 = make_float4(A0[4 * gq + 0] + A1[4 * gq + 0], A0[4 * gq + 1] + A1[4 * gq + 1], A0[4 * gq + 2] + A1[4 * gq + 2], A0[4 * gq + 3] + A1[4 * gq + 3]);
+                        o1 = make_float4(A1[4 * gq + 0], A1[4 * gq + 1], A1[4 * gq + 2], A1[4 * gq + 3]);
+                    } else {
+                        o0 = make_float4(A0[4 * gq + 0], A0[4 * gq + 1], A0[4 * gq + 2], A0[4 * gq + 3]);
+                        o1 = make_float4(-A0[4 * gq + 0] - A1[4 * gq + 0], -A0[4 * gq + 1] - A1[4 * gq + 1], -A0[4 * gq + 2] - A1[4 * gq + 2], -A0[4 * gq + 3] - A1[4 * gq + 3]);
+                    }
+                    const int col = 32 * cb + 8 * gq + 4 * g;
+                    float4* p0 = reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * WT + tl) * RLD + col);
+                    float4* p1 = reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * WT + tl) * RLD + col);
+                    if (pass == 1) { const float4 q0 = *p0, q1 = *p1; o0.x += q0.x; o0.y += q0.y; o0.z += q0.z; o0.w += q0.w; o1.x += q1.x; o1.y += q1.y; o1.z += q1.z; o1.w += q1.w; }
+                    *p0 = o0; *p1 = o1;
+                }
+        }
+        __syncthreads();
+    }
+    wino_final_epilogue<512, COB, BST>(a, wsm, m0, WT, Mt, THW, TW, c0, tid);
 }
 
 // patch slots a block can need at tile-row width TW: worst case over the position of its first tile
@@ -941,7 +1211,26 @@ static void launch_wino3s_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s)
     else if (a.bst) hipLaunchKernelGGL((conv_wino3s_kernel<0, 1, NP>), dim3(grid), dim3(256), lds, s, a, g);
     else hipLaunchKernelGGL((conv_wino3s_kernel<0, 0, NP>), dim3(grid), dim3(256), lds, s, a, g);
 }
-static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) { if (a.wino_pieces == 3) launch_wino3s_t<3>(a, g, s); else launch_wino3s_t<2>(a, g, s); }
+template <int NP>
+static void launch_wino3w_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
+    constexpr size_t lds = (size_t)8 * 32 * (64 + 4) * sizeof(float);          // the output transform's R[i][b][32 tiles][64 + 4] (68 KB) > the two pipeline stages (48 KB)
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3w_kernel<0, 0, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3w_kernel<1, 0, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3w_kernel<0, 1, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = g.ntp * (a.Cout / 64);
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino3w_kernel<1, 0, NP>), dim3(grid), dim3(512), lds, s, a, g);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino3w_kernel<0, 1, NP>), dim3(grid), dim3(512), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino3w_kernel<0, 0, NP>), dim3(grid), dim3(512), lds, s, a, g);
+}
+int g_wino_wide = 0;          // 1 (md2_set_winograd(on + 8, .)): split launches with Cout % 64 == 0 take the 64-channel workgroup (conv_wino3w_kernel: faster alone, slower in the step -- DESIGN.md section 4); 0: the 32-channel one everywhere
+static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
+    if (g_wino_wide && a.Cout % 64 == 0) { if (a.wino_pieces == 3) launch_wino3w_t<3>(a, g, s); else launch_wino3w_t<2>(a, g, s); }
+    else if (a.wino_pieces == 3) launch_wino3s_t<3>(a, g, s); else launch_wino3s_t<2>(a, g, s);
+}
 static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) {
     if (a.wino_pieces) launch_wino3s(a, g, s);
     else if (nh == 1) launch_wino3_t<3, 1>(a, g, s); else launch_wino3_t<5, 2>(a, g, s);

@@ -268,7 +268,7 @@ WINO_CASES = [
 
 
 # (algorithm pin, pieces per operand of the forward / input-gradient products, pieces of the weight-gradient products): md2_set_winograd / md2_set_conv_products
-WINO_ROUTES = {"tile32x64": (2, 0, 0), "tile64x32": (3, 0, 3), "split_bf16": (3, 2, 2), "split3_bf16": (3, 3, 3)}
+WINO_ROUTES = {"tile32x64": (2, 0, 0), "tile64x32": (3, 0, 3), "split_bf16": (3, 2, 2), "split3_bf16": (3, 3, 3), "split3_bf16_64_channel_workgroups": (11, 3, 3), "split_bf16_64_channel_workgroups": (11, 2, 2)}
 
 
 def _set_route(route):

