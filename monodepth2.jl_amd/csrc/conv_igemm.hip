@@ -98,7 +98,31 @@ __device__ __forceinline__ void stats_butterfly_atomic(float (&v)[32], double* _
     atomicAdd(dst + (p & 1) * C + cbase + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), (double)v[0]);
 }
 
-// BF: 0 fp32 MFMA, 1 bf16 operands (mixed precision).  XF: 1 = the pixel operand is relu(x * in_scale[ci] + in_shift[ci]) -- the producer's BatchNorm + ReLU
+// fp32 pairs -> bf16 pieces (two / three per operand), used by the exact-split forms of the implicit GEMM (BF = 3) and of the per-tap weight gradient (SPL)
+__device__ __forceinline__ void wg_split_pk(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 h, l; h[0] = (__bf16)a; h[1] = (__bf16)b;
+    unsigned k0 = 0x0000bf80u, k1 = 0xbf800000u; asm("" : "+v"(k0)); asm("" : "+v"(k1));          // (-1, 0) and (0, -1) as register operands: folded into inline constants they select the wrong half
+    const b2 c0 = __builtin_bit_cast(b2, k0), c1 = __builtin_bit_cast(b2, k1);
+    const float ra = __builtin_amdgcn_fdot2_f32_bf16(h, c0, a, false), rb = __builtin_amdgcn_fdot2_f32_bf16(h, c1, b, false);          // x - piece, exactly, one instruction each
+    l[0] = (__bf16)ra; l[1] = (__bf16)rb;
+    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
+}
+// (a, b) = hi + mid + lo up to 2^-25: every bit of the fp32 values
+__device__ __forceinline__ void wg_split3_pk(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 h, m, l; h[0] = (__bf16)a; h[1] = (__bf16)b;
+    unsigned k0 = 0x0000bf80u, k1 = 0xbf800000u; asm("" : "+v"(k0)); asm("" : "+v"(k1));
+    const b2 c0 = __builtin_bit_cast(b2, k0), c1 = __builtin_bit_cast(b2, k1);
+    const float ra = __builtin_amdgcn_fdot2_f32_bf16(h, c0, a, false), rb = __builtin_amdgcn_fdot2_f32_bf16(h, c1, b, false);
+    m[0] = (__bf16)ra; m[1] = (__bf16)rb;
+    const float sa = __builtin_amdgcn_fdot2_f32_bf16(m, c0, ra, false), sb = __builtin_amdgcn_fdot2_f32_bf16(m, c1, rb, false);
+    l[0] = (__bf16)sa; l[1] = (__bf16)sb;
+    hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
+}
+// BF: 0 fp32 MFMA, 1 bf16 operands (mixed precision), 2 bf16 tensors, 3 (round 5) fp32 tensors with every product formed from the exact three-bf16-piece split of both
+// operand fragments (six v_mfma_f32_32x32x16_bf16 per 16-channel K-step and tile pair instead of eight v_mfma_f32_32x32x2_f32: fp32-MFMA accuracy, 192 instead of 512 matrix-pipe
+// cycles, beside the other waves' vector work) -- loader, LDS layout and epilogue are the fp32 kernel's, only the operand reads' way into the matrix pipe differs.  XF: 1 = the pixel operand is relu(x * in_scale[ci] + in_shift[ci]) -- the producer's BatchNorm + ReLU
 // applied on the way from the global load into LDS, so that activation is never written to (or read from) HBM
 // BST: 1 = the epilogue also reduces the BatchNorm-pullback sums of its output (a.bst); a template parameter because its 48 partial-sum registers would otherwise
 // raise the register count of every instantiation
@@ -374,6 +398,44 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                         if constexpr (MF == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, o.w[i][jj]), __builtin_bit_cast(bf16x8, o.x[j][jj]), acc[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, o.w[i][jj]), __builtin_bit_cast(bf16x8, o.x[j][jj]), acc[i][j], 0, 0, 0);
                     }
+            return;
+        } else if constexpr (BF == 3 && MF == 32) {
+            // the lane's 8 k-values of a 32-row tile (its two 16-byte reads: k = 4h .. 4h+3 and 8 + 4h .. 8 + 4h+3) as hi / mid / lo bf16x8 -- both operands use the same
+            // lane -> k assignment, so the MFMA's own k order does not matter; each operand tile is split once and serves all its tile pairs
+            unsigned wq[TC][3][4], xq[TP][3][4];
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    wg_split3_pk(o.w[i][jj][0], o.w[i][jj][1], wq[i][0][2 * jj], wq[i][1][2 * jj], wq[i][2][2 * jj]);
+                    wg_split3_pk(o.w[i][jj][2], o.w[i][jj][3], wq[i][0][2 * jj + 1], wq[i][1][2 * jj + 1], wq[i][2][2 * jj + 1]);
+                }
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    wg_split3_pk(o.x[j][jj][0], o.x[j][jj][1], xq[j][0][2 * jj], xq[j][1][2 * jj], xq[j][2][2 * jj]);
+                    wg_split3_pk(o.x[j][jj][2], o.x[j][jj][3], xq[j][0][2 * jj + 1], xq[j][1][2 * jj + 1], xq[j][2][2 * jj + 1]);
+                }
+            typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    bf16x8 wv[3], xv[3];
+#pragma unroll
+                    for (int q3 = 0; q3 < 3; ++q3) {
+                        wv[q3] = __builtin_bit_cast(bf16x8, (sp_u32x4){wq[i][q3][0], wq[i][q3][1], wq[i][q3][2], wq[i][q3][3]});
+                        xv[q3] = __builtin_bit_cast(bf16x8, (sp_u32x4){xq[j][q3][0], xq[j][q3][1], xq[j][q3][2], xq[j][q3][3]});
+                    }
+                    // small terms first: lo hi, hi lo, mid mid, mid hi, hi mid, hi hi (the dropped terms are below 2^-24 of a product)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[2], xv[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[0], xv[2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[1], xv[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[1], xv[0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[0], xv[1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[0], xv[0], acc[i][j], 0, 0, 0);
+                }
             return;
         } else {
 #pragma unroll
@@ -812,6 +874,7 @@ static void bst_fallback(const ConvArgs& a, hipStream_t s) {
 template <int BM, int BN, int WP, int WC, int MF, int NT, int XF = 0, int BST = 0>
 static void launch_igemm_form(const ConvArgs& a, const dim3& g, hipStream_t s) {
     if (a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 2, XF, BST>), g, dim3(256), 0, s, a);
+    else if (a.bf16 == 0 && a.split3 && MF == 32 && BN == 64 && WP == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 && BN == 64 && WP == 2 ? 3 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 1 && MF == 32) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 ? 1 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 0, XF, BST>), g, dim3(256), 0, s, a);
 }
@@ -1047,11 +1110,14 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
     k.first[0] = 0;
     for (int i = 0; i < 4; ++i) k.first[i + 1] = k.first[i] + (i < n ? ((k.c[i].M + BM - 1) / BM) * (k.c[i].Cout / 64) : 0);
     for (int i = n; i < 4; ++i) k.c[i] = k.c[0];
+    const bool sp3 = k.c[0].bf16 == 0 && k.c[0].split3;
     if (k.c[0].bst) {
-        if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+        if (sp3) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 3, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+        else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 0, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
-    } else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2>), dim3(k.first[4]), dim3(256), 0, s, k);
+    } else if (sp3) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 3>), dim3(k.first[4]), dim3(256), 0, s, k);
+    else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2>), dim3(k.first[4]), dim3(256), 0, s, k);
     else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32>), dim3(k.first[4]), dim3(256), 0, s, k);
 }
@@ -1192,27 +1258,6 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 // 2^-17 |x|), three MFMAs: reduced precision, opt-in (md2_set_conv_products(-1, 2)).
 typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
 // (builtins only: see the note on wait states in conv_winograd.hip)
-__device__ __forceinline__ void wg_split_pk(float a, float b, unsigned& hi, unsigned& lo) {
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    b2 h, l; h[0] = (__bf16)a; h[1] = (__bf16)b;
-    unsigned k0 = 0x0000bf80u, k1 = 0xbf800000u; asm("" : "+v"(k0)); asm("" : "+v"(k1));          // (-1, 0) and (0, -1) as register operands: folded into inline constants they select the wrong half
-    const b2 c0 = __builtin_bit_cast(b2, k0), c1 = __builtin_bit_cast(b2, k1);
-    const float ra = __builtin_amdgcn_fdot2_f32_bf16(h, c0, a, false), rb = __builtin_amdgcn_fdot2_f32_bf16(h, c1, b, false);          // x - piece, exactly, one instruction each
-    l[0] = (__bf16)ra; l[1] = (__bf16)rb;
-    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
-}
-// (a, b) = hi + mid + lo up to 2^-25: every bit of the fp32 values
-__device__ __forceinline__ void wg_split3_pk(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    b2 h, m, l; h[0] = (__bf16)a; h[1] = (__bf16)b;
-    unsigned k0 = 0x0000bf80u, k1 = 0xbf800000u; asm("" : "+v"(k0)); asm("" : "+v"(k1));
-    const b2 c0 = __builtin_bit_cast(b2, k0), c1 = __builtin_bit_cast(b2, k1);
-    const float ra = __builtin_amdgcn_fdot2_f32_bf16(h, c0, a, false), rb = __builtin_amdgcn_fdot2_f32_bf16(h, c1, b, false);
-    m[0] = (__bf16)ra; m[1] = (__bf16)rb;
-    const float sa = __builtin_amdgcn_fdot2_f32_bf16(m, c0, ra, false), sb = __builtin_amdgcn_fdot2_f32_bf16(m, c1, rb, false);
-    l[0] = (__bf16)sa; l[1] = (__bf16)sb;
-    hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
-}
 // BS: x and dy are bf16 tensors (WgradArgs::bf16 == 2): 8-byte loads widened to fp32 on their way into the (unchanged) LDS tiles; SPL = 1 then rounds the operand
 // fragments back to bf16 -- exactly the stored values -- for ONE v_mfma_f32_32x32x16_bf16 per 16-pixel k-group
 template <int T, int BKP, int MF, bool REFLECT, bool FAST, bool XF = false, bool ONE = false, int SPL = 0, bool BS = false>      // XF: x is relu(x * in_scale[ci] + in_shift[ci]) (the producer's BatchNorm + ReLU), zero padding after it

@@ -301,6 +301,7 @@ static ConvArgs conv_args(const View& x, const float* w, const View& y, int KH, 
 }
 static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
     ConvArgs a = a_in; a.bf16 = h->bf16;
+    a.split3 = h->bf16 ? 0 : igemm_resolve_split(h->u_pieces_f, a.dil > 1 && a.ostep == 1 ? std::max(1, a.KH * a.KW / (a.dil * a.dil)) : a.nkh * a.nkw, a.Cin, a.Cout);          // (the product mode this handle's step was prepared under)
     a.ws = (h->cur && h->cur == h->s3) ? h->ws_pose : h->ws_main; a.ws_cap = h->ws_cap;
     char d[112] = "";
     // (alg: the route launch_conv_igemm takes -- conv_igemm_executed_flops applies the same test -- so that a test can see which kernels a step ran: md2_profile_dump)
@@ -1193,6 +1194,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* b, float
     const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
     float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
     a.ws = ws; a.ws_cap = ws_cap;
+    a.split3 = bs ? 0 : igemm_resolve_split(g_wino_pieces, a.nkh * a.nkw, a.Cin, a.Cout);
     launch_conv_igemm(a, s);
     (void)hipFreeAsync(ws, s); if (uw) (void)hipFreeAsync(uw, s);
     if (bn_mean) {
@@ -1241,6 +1243,7 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         a.ws = ws; a.ws_cap = ws_cap;
         float* uw = nullptr;
         if (k == 3 && stride == 1 && cinP % 32 == 0 && !bs) { uw = tmp_alloc(conv_wino_u_floats(cinP, coutP), s); if (!uw) return 3; launch_wino_weights(wd, uw, cinP, coutP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
+        a.split3 = bs ? 0 : igemm_resolve_split(g_wino_pieces, a.dil > 1 ? std::max(1, k * k / (a.dil * a.dil)) : a.nkh * a.nkw, a.Cin, a.Cout);
         launch_conv_igemm(a, s);
         (void)hipFreeAsync(ws, s); if (uw) (void)hipFreeAsync(uw, s); if (wk != wd) (void)hipFreeAsync(const_cast<float*>(wk), s);
         if (pad_mode == PAD_REFLECT) {

@@ -39,6 +39,10 @@ __host__ __device__ inline int wino_resolve_pieces(int mode, int cin) { return m
 inline int wgrad_resolve_pieces_wino(int mode, long M, int Cout, int Cin) { return mode == 1 ? ((double)M * Cout * Cin < 3e8 ? 3 : 0) : mode; }
 //   per-tap weight gradient (1x1 and stride-2 layers): the exact split is ahead at every size measured (0.146 -> 0.101 ms, 0.046 -> 0.033 ms)
 inline int wgrad_resolve_pieces_tap(int mode) { return mode == 1 ? 3 : mode; }
+//   direct implicit GEMM, forward / input gradient (1x1 and stride-2 layers, the stride-2 input gradients' residue classes, 3x3 launches below the Winograd threshold; round 5):
+//   the exact split is ahead at every shape measured, tools/run_igemm_split_bench.sh -- 0.127 -> 0.107 ms on the 64 -> 128 stride-2 3x3 at batch 32, 0.147 -> 0.114 / 0.143 -> 0.113 ms
+//   on ResNet-50's 512 -> 128 / 1024 -> 256 bottleneck 1x1s at 640x192, 0.028 -> 0.025 on the 64-channel 1x1 shortcut; 64-channel-wide tiles only (Cout % 64 == 0)
+inline int igemm_resolve_split(int mode, int taps, int cin, int cout) { (void)taps; (void)cin; return (cout % 64 == 0 && mode != 0) ? 1 : 0; }
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };
@@ -149,6 +153,7 @@ struct ConvArgs {
     int acc_lat;
     // Winograd F(2x2,3x3) operand of this layer (conv_winograd.hip): U = G g G^T of `w` in MFMA fragment order, refreshed once per step; null = direct convolution only
     const float* wino_u;
+    int split3;                   // fp32 tensors (bf16 == 0): 1 = the direct implicit GEMM forms its products from the exact three-bf16-piece split of both operands (BF = 3; 64-channel-wide 32 x 32 tiles only), see igemm_resolve_split
     int wino_pieces;              // layout wino_u was written in: 0 = fp32 fragments, 2 / 3 = bf16 pieces per operand (split kernels); set by whoever refreshed U
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only

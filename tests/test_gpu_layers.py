@@ -78,6 +78,41 @@ def test_conv_fwd_dgrad_wgrad(case):
     assert rel(host(dx), dxo) < 1e-4 and rel(host(dw), dwo) < 1e-4 and rel(host(db), dbo) < 1e-4
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 64 == 0 or c[1] % 64 == 0])
+@pytest.mark.parametrize("products", [0, 3], ids=["fp32_mfma", "exact_split"])
+def test_direct_conv_product_forms_vs_oracle(case, products):
+    """The direct implicit GEMM (Winograd off) with both full-accuracy product forms of md2_set_conv_products: the fp32 MFMA and -- round 5, conv_igemm_kernel<..., BF = 3> --
+    the exact three-bf16-piece split of both operand fragments on the bf16 matrix pipe (every launch with 64-channel-wide tiles: 1x1, stride 2 and its residue-class input
+    gradients, split-K, the BatchNorm-sum epilogues).  Same 1e-4 bound against the oracle; the two forms agree with each other to fp32 rounding (2e-6 of the largest output)."""
+    N, Cin, H, W, Cout, k, s, p, mode = case
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xin = oracle.pad_reflect(x) if mode == "reflect" else x
+    yo = oracle.conv2d_fwd(xin, w, b, s, 0 if mode == "reflect" else p)
+    dy = rng.standard_normal(yo.shape).astype(np.float32)
+    dxo, dwo, dbo = oracle.conv2d_bwd(xin, w, dy, s, 0 if mode == "reflect" else p)
+    if mode == "reflect":
+        dxo = _reflect_adjoint(dxo, N, Cin, H, W)
+    dflt = md().get_conv_products()
+    md().set_winograd(False)
+    try:
+        md().set_conv_products(products, products)
+        y = host(md().conv2d(dev(x), dev(w), dev(b), s, p, mode))
+        dx, dw, db = md().conv2d_pullback(dev(x), dev(w), dev(dy), s, p, mode)
+        assert y.shape == yo.shape and rel(y, yo) < 1e-4
+        assert rel(host(dx), dxo) < 1e-4 and rel(host(dw), dwo) < 1e-4 and rel(host(db), dbo) < 1e-4
+        if products == 3:
+            md().set_conv_products(0, 0)
+            y0 = host(md().conv2d(dev(x), dev(w), dev(b), s, p, mode))
+            dx0, _, _ = md().conv2d_pullback(dev(x), dev(w), dev(dy), s, p, mode)
+            assert rel(y, y0) < 2e-6 and rel(host(dx), host(dx0)) < 2e-6
+            if Cout % 64 == 0:
+                assert not np.array_equal(y, y0), "the exact-split form did not run"
+    finally:
+        md().set_winograd(True, -2); md().set_conv_products(*dflt)
+
+
 def bf16_round(a):
     """fp32 -> nearest bf16 (ties to even), returned as fp32: what a bf16 tensor holds."""
     u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)

@@ -16,9 +16,11 @@ int main(int argc, char** argv) {
     hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice);
     ConvArgs a{};
     a.x = x; a.x_bs = (long)H * W * Cin; a.x_ps = Cin; a.H = H; a.W = W; a.Cin = Cin; a.w = w;
-    a.y = y; a.y_bs = (long)H * W * Cout; a.y_ps = Cout; a.Ho = H; a.Wo = W; a.Cout = Cout;
-    a.N = N; a.KH = k; a.KW = k; a.stride = 1; a.pad = k / 2; a.dil = 1; a.padmode = 0;
-    a.M = N * H * W; a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = H; a.Wl = W; a.kh0 = 0; a.khs = 1; a.nkh = k; a.kw0 = 0; a.kws = 1; a.nkw = k;
+    const int st = getenv("STRIDE") ? atoi(getenv("STRIDE")) : 1, Ho = (H + 2 * (k / 2) - k) / st + 1, Wo = (W + 2 * (k / 2) - k) / st + 1;          // STRIDE=2: the encoder's down-sampling convolutions
+    a.y = y; a.y_bs = (long)Ho * Wo * Cout; a.y_ps = Cout; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.N = N; a.KH = k; a.KW = k; a.stride = st; a.pad = k / 2; a.dil = 1; a.padmode = 0;
+    a.M = N * Ho * Wo; a.oy0 = 0; a.ox0 = 0; a.ostep = 1; a.Hl = Ho; a.Wl = Wo; a.kh0 = 0; a.khs = 1; a.nkh = k; a.kw0 = 0; a.kws = 1; a.nkw = k;
+    if (getenv("SPLIT3")) a.split3 = 1;       // exact three-piece products in the direct implicit GEMM (conv_igemm_kernel<..., BF = 3, ...>)
 #ifdef MD2_ABLATE
     a.ablate = abl; a.force_tile = tile;
 #endif
@@ -43,7 +45,7 @@ int main(int argc, char** argv) {
     }
     if (getenv("WINO")) {            // fused Winograd F(2x2,3x3): U = G g G^T once, then the same launch entry (WINO=2: also time the weight transform)
         float* U; hipMalloc(&U, conv_wino_u_floats(Cout, Cin) * 4);
-        launch_wino_weights(w, U, Cout, Cin, g_wino_pieces, 0); a.wino_u = U; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, Cin); g_wino_min_blocks = 1; if (getenv("WMODE")) g_wino_on = atoi(getenv("WMODE")); if (getenv("NARROW")) g_wino_wide = 0;          // WMODE=2 / 3: pin the 32-tile / 64-tile kernel
+        launch_wino_weights(w, U, Cout, Cin, g_wino_pieces, 0); a.wino_u = U; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, Cin); g_wino_min_blocks = 1; if (getenv("WMODE")) g_wino_on = atoi(getenv("WMODE")); if (getenv("WIDE")) g_wino_wide = 1;          // WMODE=2 / 3: pin the 32-tile / 64-tile kernel
         if (getenv("XF")) { float* sc; hipMalloc(&sc, Cin * 8); std::vector<float> h2(2 * Cin, 0.5f); hipMemcpy(sc, h2.data(), Cin * 8, hipMemcpyHostToDevice); a.in_scale = sc; a.in_shift = sc + Cin; }
         if (atoi(getenv("WINO")) == 2) {
             hipEventRecord(e0); for (int i = 0; i < 20; ++i) launch_wino_weights(w, U, Cout, Cin, g_wino_pieces, 0); hipEventRecord(e1); hipEventSynchronize(e1);

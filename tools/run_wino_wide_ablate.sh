@@ -4,6 +4,6 @@
 set -e
 for shape in "96 16 52 128 128" "96 32 104 64 64"; do
   for abl in 0 47 111 175 239 303 431; do
-    MD2_WINO_MODE=5 WINO=1 ./tools/conv_bench $shape 3 0 $abl 2>&1 | tee /tmp/abl.out; if grep -q "Memory access fault" /tmp/abl.out; then exit 1; fi
+    WIDE=1 MD2_WINO_MODE=5 WINO=1 ./tools/conv_bench $shape 3 0 $abl 2>&1 | tee /tmp/abl.out; if grep -q "Memory access fault" /tmp/abl.out; then exit 1; fi
   done
 done
