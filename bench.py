@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (--precision bf16 prices against this one)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-PROFILE_ROUND = "r04"          # profiles/<round>_*.json: the rocprofv3 PMC summaries of THIS round's kernels (tools/make_profiles.sh + tools/summarize_profiles.sh)
+PROFILE_ROUND = "r05"          # profiles/<round>_*.json: the rocprofv3 PMC summaries of THIS round's kernels (tools/make_profiles.sh + tools/summarize_profiles.sh)
 VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s (a wave64 VALU instruction takes 2 cycles of its SIMD)
 # HBM bytes per launch come from the rocprofv3 PMC passes of THIS command (profiles/<round>_pmc_hbm_traffic.json, written by tools/profile_summary.py from separate
 # --pmc FETCH_SIZE / WRITE_SIZE runs: KiB units, FETCH_SIZE x2 because gfx950 tallies 64 B per 128-B request, WRITE_SIZE exact).  PMC counters cannot be read
@@ -38,6 +38,33 @@ def pmc_traffic(B, C, H, W, depth, precision):
     return d.get("bytes_per_launch", {})
 
 
+def conv_class_accounting(dump_path, esz, nsteps):
+    """Per-step accounting of the forward + input-gradient convolution class from the library's per-launch profile records (md2_profile_dump: one record per launch with
+    M output pixels, Cin, Cout, k, stride, the output-sized operands `ep` of the fused epilogue, the algorithm `alg` and the product form `prod`):
+      algorithmic_bytes -- each launch reads its input pixels, its weights and the epilogue's output-sized operands once and writes its output once, at `esz` bytes per element;
+      floor_ms          -- the time the launches' EXECUTED matrix instructions need at the rate of the pipe they run on: fp32 MFMA 157.3 TFLOP/s; an exact-split launch issues six
+                           (two-piece: three) bf16 MFMAs per fp32 product group on the 2.5 PFLOP/s bf16 pipe; Winograd launches execute 16/36 of the direct-convolution count.
+    `frac` of the roofline block stays the algorithmic rate; ms_per_step / floor_ms is the distance to the matrix-pipe roof."""
+    import re
+    by = 0.0; floor_s = 0.0; forms = {}
+    for line in open(dump_path).read().splitlines()[1:]:
+        f = line.split(",", 4)
+        if len(f) != 5 or f[0] != "0":
+            continue
+        gflop = float(f[2]); desc = f[4]
+        m = re.match(r"igemm M=(\d+) Cout=(\d+) Cin=(\d+) k=(\d+) s=(\d+) .* ep=(\d+) alg=(\S+)(?: prod=(\S+))?", desc)
+        if m:
+            M, co, ci, k, st, ep = (int(v) for v in m.groups()[:6]); alg = m.group(7); prod = m.group(8) or "fp32"
+            by += float(esz) * (M * st * st * ci + M * co * (1 + ep) + k * k * ci * co)
+            ex = gflop * 1e9 * (16.0 / 36.0 if alg.startswith("winograd") else 1.0)
+        else:                                   # the stem: no per-launch shape record, fp32 MFMA (bf16 MFMA in the bf16-tensor mode)
+            ex = gflop * 1e9; prod = "bf16" if esz == 2 else "fp32"; alg = "stem"
+        rate = {"fp32": MFMA_F32_PEAK_TFLOPS, "split3": MFMA_BF16_PEAK_TFLOPS / 6.0, "split2": MFMA_BF16_PEAK_TFLOPS / 3.0, "bf16": MFMA_BF16_PEAK_TFLOPS}[prod] * 1e12
+        floor_s += ex / rate
+        forms[prod] = forms.get(prod, 0) + 1
+    return {"algorithmic_bytes_per_step": by / nsteps, "floor_ms": floor_s / nsteps * 1e3, "launches_by_product_form": {k: v / nsteps for k, v in forms.items()}}
+
+
 def bf16_conv_roofline(md, torch, model, step, esz=4, precision="bf16"):
     """The convolutions (forward + input gradient) of a bf16 mode on both rooflines: the class sits far below the bf16 matrix peak and is priced against HBM as well.
     ALGORITHMIC bytes = each launch reads its input pixels, its weights and the output-sized operands of its fused epilogue once and writes its output once at the tensors' storage width `esz` (2: bf16 activation storage,
@@ -48,7 +75,7 @@ def bf16_conv_roofline(md, torch, model, step, esz=4, precision="bf16"):
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    ig = md.profile_get(model, 0)
+    ig = md.profile_get(model, 0); lt = md.profile_get(model, 3)
     tmp = os.path.join(tempfile.gettempdir(), "md2_bf16_layers_%d.csv" % os.getpid())
     md.profile_dump(model, tmp); md.profile(model, False); md.set_two_streams(model, True)
     by = 0.0
@@ -61,15 +88,31 @@ def bf16_conv_roofline(md, torch, model, step, esz=4, precision="bf16"):
     os.remove(tmp)
     if ig["ms"] <= 0:
         return None
-    traffic_step = None
+    traffic_step = None; loss_traffic = None; loss_valu = None
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_cfg5_" + precision + "_pmc_hbm_traffic.json")))
         if d.get("workload") == {"batch": 8, "channels": 3, "height": 320, "width": 1024, "depth": 18, "precision": precision}:
-            traffic_step = d["bytes_per_step"]["conv_igemm"]
+            traffic_step = d["bytes_per_step"]["conv_igemm"]; loss_traffic = d["bytes_per_launch"].get("loss_train")
+        dv = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_cfg5_loss_pmc.json")))
+        if dv.get("workload") == {"batch": 8, "channels": 3, "height": 320, "width": 1024}:
+            loss_valu = dv.get("loss_train")
     except Exception:
         pass
     tf = ig["flops"] / (ig["ms"] * 1e-3) / 1e12; gbs = by / (ig["ms"] * 1e-3) / 1e9
-    return {"kernel": "forward + input-gradient convolutions (v_mfma_f32_32x32x16_bf16 / 16x16x32, fp32 accumulation) on " + ("bf16 tensors" if esz == 2 else "fp32 tensors"), "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / MFMA_BF16_PEAK_TFLOPS else "mfma",
+    loss_block = None
+    if lt["ms"] > 0 and lt["launches"] > 0:
+        # loss_train_kernel<3, 16> (three colour channels): its own roofline entry since round 5 -- until round 4 this instantiation kept 224 bytes per lane in scratch and moved
+        # 4.8 x its algorithmic bytes; `traffic` (PMC) against `algorithmic_bytes_per_launch` = 4 P (2 + 3 C) S B is the check that it no longer does
+        ms1 = lt["ms"] / lt["launches"]; a = lt["bytes"] / lt["launches"] / (ms1 * 1e-3) / 1e9
+        loss_block = {"kernel": "loss_train_kernel<3, 16> (value + pullback of all four scales from one pass over the warp, C = 3)", "bound": "valu" if loss_valu else "hbm",
+                      "ms_per_launch": ms1, "hbm": {"achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": lt["bytes"] / lt["launches"], "traffic": loss_traffic,
+                                                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/" + PROFILE_ROUND + "_cfg5_" + precision + "_pmc_hbm_traffic.md)"}}
+        if loss_valu:
+            rate = loss_valu * 64.0 / (ms1 * 1e-3) / 1e12
+            loss_block.update({"achieved": rate, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s", "frac": rate / VALU_PEAK_TLANE, "valu_wave_instructions_per_launch": loss_valu,
+                               "counter": "SQ_INSTS_VALU of this kernel at this workload (rocprofv3 --pmc, profiles/" + PROFILE_ROUND + "_cfg5_loss_train_pmc.md)"})
+    return {"roofline_loss_train": loss_block,
+            "kernel": "forward + input-gradient convolutions (v_mfma_f32_32x32x16_bf16 / 16x16x32, fp32 accumulation) on " + ("bf16 tensors" if esz == 2 else "fp32 tensors"), "bound": "hbm" if gbs / HBM_PEAK_GBS > tf / MFMA_BF16_PEAK_TFLOPS else "mfma",
             "mfma": {"achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS},
             "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": by / 3, "traffic": traffic_step,
                     "traffic_unit": "HBM bytes per step of this class (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of tools/prof_config.py 8 18 3 320 1024 " + precision + ", profiles/" + PROFILE_ROUND + "_cfg5_" + precision + "_pmc_hbm_traffic.md)"},
@@ -302,7 +345,10 @@ def main():
         dp.train_step(x, None, cache, params)
     sync()
     if rank == 0:
+        import tempfile
         ig, wg, lf, lb = (md.profile_get(model, c) for c in range(4))
+        tmp = os.path.join(tempfile.gettempdir(), "md2_bench_layers_%d.csv" % os.getpid())
+        md.profile_dump(model, tmp); acct = conv_class_accounting(tmp, 2 if args.precision == "bf16_storage" else 4, 3); os.remove(tmp)
         md.profile(model, False)
     md.set_two_streams(model, True)
     if rank == 0:
@@ -310,13 +356,20 @@ def main():
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak_tf = MFMA_BF16_PEAK_TFLOPS if args.precision != "f32" else MFMA_F32_PEAK_TFLOPS
         ach_x = ig["flops_executed"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        peak_eff = (ig["flops"] / 3) / (acct["floor_ms"] * 1e-3) / 1e12 if acct["floor_ms"] > 0 else peak_tf
         out["roofline"] = {"bound": "mfma", "kernel": "conv_wino3s_kernel<.,.,3> / conv_wino3_kernel (fused Winograd F(2x2,3x3): the 3x3 stride-1 layers; products as the exact three-bf16-piece split from 96 input channels up, fp32 MFMA below) + conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions; fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32 outside the split launches)",
-                           "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
-                           "algorithmic": "achieved / frac count the direct-convolution FLOPs of the layers (SURVEY.md section 8d: 2 M Cout taps Cin), whatever algorithm ran",
+                           "achieved": ach, "peak": peak_eff, "unit": "TFLOP/s", "frac": ach / peak_eff,
+                           "algorithmic": "achieved counts the direct-convolution FLOPs of the layers (SURVEY.md section 8d: 2 M Cout taps Cin), whatever algorithm ran",
+                           "peak_note": "peak = the same algorithmic FLOPs / floor_ms: the rate at which the matrix instructions this launch mix EXECUTES could retire (fp32 MFMA launches at 157.3 TFLOP/s; exact-split launches issue six bf16 MFMAs per product group at 2.5 PFLOP/s; Winograd launches execute 16/36 of the direct count) -- since round 5, because the algorithmic rate against the fp32 MFMA peak alone had saturated (round 4: 0.99; it is kept as algorithmic_vs_fp32_mfma_peak)",
+                           "algorithmic_vs_fp32_mfma_peak": ach / peak_tf,
                            "executed_achieved": ach_x, "executed_frac": ach_x / peak_tf,
                            "executed": "FLOPs the matrix cores really issued: Winograd launches multiply 16 instead of 36 times per 2x2 output tile -- this is the MFMA pipe utilisation",
+                           "floor_ms": acct["floor_ms"], "ms_over_floor": (ig["ms"] / 3) / acct["floor_ms"] if acct["floor_ms"] > 0 else None,
+                           "floor": "ms per step the class's EXECUTED matrix instructions need at the rate of the pipe each launch runs on (fp32 MFMA 157.3 TFLOP/s; exact-split launches: six bf16 MFMAs per product group at 2.5 PFLOP/s; Winograd: 16/36 of the direct count) -- ms_per_step / floor_ms is the distance to the matrix-pipe roof; what stands between the two is operand delivery (L2 -> CU bandwidth, DESIGN.md section 4), workgroup prologues / epilogues and launch tails",
+                           "launches_by_product_form": acct["launches_by_product_form"],
                            "traffic": traffic.get("conv_igemm"),
-                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, profiles/" + PROFILE_ROUND + "_pmc_hbm_traffic.md)",
+                           "algorithmic_bytes_per_launch": acct["algorithmic_bytes_per_step"] / max(ig["launches"] / 3, 1),
+                           "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this command, profiles/" + PROFILE_ROUND + "_pmc_hbm_traffic.md); algorithmic_bytes_per_launch: inputs + weights + epilogue operands + output, each once, fp32",
                            "matrix_pipe": (lambda m: dict(m, counter="SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles) over the class's launches (fp32 and bf16 MFMAs alike; profiles/" + PROFILE_ROUND + "_mfma_pmc.md)") if m else None)(
                                (lambda: (json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_mfma_pmc.json"))).get("conv_igemm") if os.path.exists(os.path.join(ROOT, "profiles", PROFILE_ROUND + "_mfma_pmc.json")) else None))()),
                            "launches_per_step": ig["launches"] / 3, "ms_per_step": ig["ms"] / 3, "avg_launch_ms": ig["ms"] / max(ig["launches"], 1),
@@ -419,7 +472,10 @@ def main():
                 torch.cuda.synchronize(); d6 = time.perf_counter() - t0
                 extra[key] = {"value": 8 * n6 / d6, "unit": "triplets/s", "ms_per_step": d6 / n6 * 1e3, "dtype": dtype, "precision": prec}
                 if esz == 2:
-                    extra[key]["roofline"] = bf16_conv_roofline(md, torch, m6, lambda: md.train_step(m6, x6, a6, c6, p6, True), esz=esz, precision=prec)
+                    rf = bf16_conv_roofline(md, torch, m6, lambda: md.train_step(m6, x6, a6, c6, p6, True), esz=esz, precision=prec)
+                    if rf:
+                        extra[key]["roofline_loss_train"] = rf.pop("roofline_loss_train", None)
+                    extra[key]["roofline"] = rf
                 del m6, x6
                 gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()          # (handles freed here, not by a collection inside a timed loop)
             # and the headline shape in bf16 activation storage, for reference next to `value` (which is fp32)
@@ -457,6 +513,13 @@ def main():
         out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W)
+        # the figures a reader needs first, repeated at the END of the line (a log viewer that keeps only the tail of stdout still shows them)
+        pick = lambda k: ({"value": extra[k]["value"], "ms_per_step": extra[k]["ms_per_step"]} if k in extra else None)
+        out["summary"] = {"value": value, "unit": "triplets/s", "ms_per_step": dt / args.steps * 1e3, "n_gpus": world, "roofline_frac": out["roofline"]["frac"],
+                          "conv_ms_per_step": out["roofline"]["ms_per_step"], "conv_floor_ms": out["roofline"]["floor_ms"],
+                          "config1_batch4": pick("config1_batch4"), "config3_resnet50_640x192_batch16": pick("config3_resnet50_640x192_batch16"),
+                          "config4_1024x320_bf16_automask_batch8": pick("config4_1024x320_bf16_automask_batch8"), "headline_shape_fp32_mfma_only": pick("headline_shape_fp32_mfma_only"),
+                          "cpu_baseline": (out.get("cpu_baseline") or {}).get("value")}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -1072,9 +1072,9 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
         }
     }
 }
-static int patch_min_h() { static const int v = getenv("MD2_PATCH_MIN_H") ? atoi(getenv("MD2_PATCH_MIN_H")) : 64; return v; }
+static int patch_min_h() { static const int v = md2_tune("MD2_PATCH_MIN_H", 64); return v; }
 static bool patch_eligible(const ConvArgs& a) {
-    static const int off = getenv("MD2_NO_PATCH_CONV") ? 1 : 0;
+    static const int off = md2_tune_set("MD2_NO_PATCH_CONV");
     if (off || a.res || a.bf16 == 2) return false;          // (fp32 tensors only)
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.Cin % 16 == 0 &&
            (a.Cout == 16 || a.Cout == 32) && a.Cin <= 96 &&
@@ -1124,7 +1124,7 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
 static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
     long tiles128 = 0;
     for (int i = 0; i < n; ++i) { check_igemm_args(k.c[i]); tiles128 += (k.c[i].M + 127) / 128; }
-    static const long big = getenv("MD2_IGEMM_BIG_TILES") ? atol(getenv("MD2_IGEMM_BIG_TILES")) : (1L << 40);          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
+    static const long big = md2_tune("MD2_IGEMM_BIG_TILES", (1L << 40));          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
     if (tiles128 * (k.c[0].Cout / 64) >= big) launch_classes_t<128>(k, n, s); else launch_classes_t<64>(k, n, s);
 }
 
@@ -1141,7 +1141,7 @@ void launch_conv_igemm(const ConvArgs& a, hipStream_t s) {
     }
     if (a.dil <= 1 || a.ostep != 1) { launch_conv_igemm_one(a, s); return; }
     ConvClasses kc{}; int ncls = 0;
-    static const bool merge_ok = !getenv("MD2_NO_CLASS_MERGE");
+    static const bool merge_ok = !md2_tune_set("MD2_NO_CLASS_MERGE");
     const bool merge = merge_ok && a.dil == 2 && a.Cout % 64 == 0 && !a.stats;       // the encoder's stride-2 input gradients
     // the BatchNorm-pullback sums are fused only when EVERY residue class runs in the merged launch (each output pixel is then written exactly once by a 32-wide tile)
     bool all_merged = merge && !g_deterministic;
@@ -1185,7 +1185,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     const long tiles64 = (long)((a.M + 63) / 64) * (a.Cout / (a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : 16)));
     const int cpt = a.bf16 == 2 ? std::max(1, a.Cin / 32) : a.Cin / 16;          // 64-byte channel chunks per tap
     const long steps = (long)cpt * a.nkh * a.nkw;
-    static const bool no_ws = getenv("MD2_IGEMM_NO_WS") && atoi(getenv("MD2_IGEMM_NO_WS")) != 0;
+    static const bool no_ws = md2_tune("MD2_IGEMM_NO_WS", 0) != 0;
     const bool use_ws = a.ws && !no_ws && a.ostep == 1 && splitk_ws_shape_ok(a.Cout) && !g_deterministic;
     double* ws_stats = nullptr;
     if (use_ws) {
@@ -1198,11 +1198,11 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
         if (a.ksplit > 1) { ws_stats = a.stats; a.stats = nullptr; }          // the statistics come out of the reduce pass
     } else {
         // no workspace (op-level calls): sum with fp32 atomics into a zeroed output and apply bias / activation in a second elementwise pass.
-        static const int want = getenv("MD2_IGEMM_SPLIT_BLOCKS") ? atoi(getenv("MD2_IGEMM_SPLIT_BLOCKS")) : 512;
+        static const int want = md2_tune("MD2_IGEMM_SPLIT_BLOCKS", 512);
         // ... and the same for up to one tile per CU when the serial K loop is very long (>= 256 steps: the 512-channel 3x3 layers at 1/32 scale;
         // measured: 0.175 -> 0.106 ms and 0.179 -> 0.138 ms there, but 0.092 -> 0.105 ms for the 256-channel layers with 144 steps)
-        static const int mid = getenv("MD2_IGEMM_SPLIT_MID") ? atoi(getenv("MD2_IGEMM_SPLIT_MID")) : 256;
-        static const int long_k = getenv("MD2_IGEMM_SPLIT_KSTEPS") ? atoi(getenv("MD2_IGEMM_SPLIT_KSTEPS")) : 256;
+        static const int mid = md2_tune("MD2_IGEMM_SPLIT_MID", 256);
+        static const int long_k = md2_tune("MD2_IGEMM_SPLIT_KSTEPS", 256);
         const bool few = tiles64 < 100 || (tiles64 < mid && steps >= long_k);
         // (a serial K loop of fewer than 64 steps -- the 1x1 convolutions -- is cheaper than the fill + atomics + bias/activation passes of a split)
         if (few && cpt >= 4 && steps >= 64 && want > 0 && !g_deterministic && a.bf16 != 2) a.ksplit = (int)std::max<long>(1, std::min<long>(cpt / 2, (want + tiles64 - 1) / tiles64));
@@ -1235,7 +1235,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
 #endif
     // 64x64 tiles (5 blocks per CU) balance the 256 CUs better than 128x64 (3 per CU) on every encoder layer at batch 32 (624 .. 2496 tiles: 1.6 .. 3.25 rounds of 768
     // resident 128x64 blocks) and are never slower there (tools/conv_bench, round 2: 87.8 / 92.5 / 93.5 / 81.2 vs 87.2 / 91.4 / 85.2 / 65.1 TFLOP/s on the four stage shapes)
-    static const long big = getenv("MD2_IGEMM_BIG_TILES") ? atol(getenv("MD2_IGEMM_BIG_TILES")) : (1L << 40);          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
+    static const long big = md2_tune("MD2_IGEMM_BIG_TILES", (1L << 40));          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
     if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
@@ -1528,7 +1528,7 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     // Split the pixel (K) range to fill the chip; every split adds one dW tile of fp32 atomics (2.2 GB/step in total at B=32).
     // measured on MI355X (tools/conv_bench, WGRAD=1): the 128-wide tile is resident 2 blocks per CU and is fastest with ONE round of
     // 512 blocks (75 vs 60-69 TFLOP/s at 768-4608); the narrower tiles prefer ~1536 blocks
-    static const int target_env = getenv("MD2_WGRAD_BLOCKS") ? atoi(getenv("MD2_WGRAD_BLOCKS")) : 0;
+    static const int target_env = md2_tune("MD2_WGRAD_BLOCKS", 0);
     const int target = target_env > 0 ? target_env : (T == 128 ? 512 : 1536);
     int splitk = std::max(1, target / (tiles * taps));          // round DOWN: one block over a multiple of the resident capacity costs a whole extra round
     splitk = std::max(1, std::min(splitk, (steps_total + 15) / 16));
@@ -1542,7 +1542,7 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
     if constexpr (T >= 64) {
         // products on the bf16 matrix pipe: bf16 tensors -> their values as they are (1 piece); fp32 tensors -> split operands (3 = exact, 2 = reduced precision opt-in): see conv_wgrad_kernel
         const int pieces = bs ? 1 : wgrad_resolve_pieces_tap(g_wgrad_pieces);
-        static const bool no_one = getenv("MD2_NO_WGRAD_ONE") != nullptr;
+        static const bool no_one = md2_tune_set("MD2_NO_WGRAD_ONE");
         const bool one = !no_one && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
         if (pieces && fast && !refl) {
             // (bit-reproducible mode keeps this kernel: splitk = 1 above -> one workgroup per (tile, tap), one atomic per weight)
@@ -1695,7 +1695,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_patch_kernel(WgradArgs a, i
     }
 }
 static bool wgrad_patch_eligible(const WgradArgs& a) {
-    static const int off = getenv("MD2_NO_PATCH_CONV") ? 1 : 0;
+    static const int off = md2_tune_set("MD2_NO_PATCH_CONV");
     if (off) return false;
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && (a.Cout == 16 || a.Cout == 32) && a.Cin % 16 == 0 && a.Cin <= 96 &&
            a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.Ho >= patch_min_h() && a.Wo >= 2 * patch_min_h();
@@ -2050,7 +2050,7 @@ static void launch_wgrad_taps_bs(const WgradArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps_bs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_taps_bs_kernel), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
         per_cu = std::min(per_cu, 2);
-        if (getenv("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("MD2_TAPS_PER_CU"))));
+        if (md2_tune_set("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, (int)md2_tune("MD2_TAPS_PER_CU", per_cu)));
     }
     const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
     const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));
@@ -2058,13 +2058,13 @@ static void launch_wgrad_taps_bs(const WgradArgs& a, hipStream_t s) {
 }
 
 static bool wgrad_taps32_eligible(const WgradArgs& a) {
-    static const int off = getenv("MD2_NO_TAPS_WGRAD") ? 1 : 0;
+    static const int off = md2_tune_set("MD2_NO_TAPS_WGRAD");
     if (off) return false;
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.Cout % 32 == 0 && a.Cin % 32 == 0 &&
            a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.Ho >= 2 && a.Wo >= 8;
 }
 static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
-    static const bool no_bs_taps = getenv("MD2_NO_BS_TAPS") != nullptr;
+    static const bool no_bs_taps = md2_tune_set("MD2_NO_BS_TAPS");
     if (a.bf16 == 2 && !no_bs_taps) { launch_wgrad_taps_bs(a, s); return; }          // bf16 tensors: channel-major bf16 LDS tiles
     const int tiles_x = (a.Wo + WT_MAXW - 1) / WT_MAXW;
     int TW = (a.Wo + tiles_x - 1) / tiles_x; TW += TW & 1;                                  // even, <= 32, least padding
@@ -2077,7 +2077,7 @@ static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_wgrad_taps32_kernel<0>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
         per_cu = std::min(per_cu, 2);
-        if (getenv("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(getenv("MD2_TAPS_PER_CU"))));
+        if (md2_tune_set("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, (int)md2_tune("MD2_TAPS_PER_CU", per_cu)));
     }
     const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
     const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));                    // persistent: the co-resident blocks, shared by the weight tiles
@@ -2096,7 +2096,7 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
         fprintf(stderr, "md2: conv_wgrad: unsupported shape Cin=%d Cout=%d M=%d\n", a.Cin, a.Cout, a.M);
         abort();
     }
-    static const int max_t = getenv("MD2_WGRAD_MAXT") ? atoi(getenv("MD2_WGRAD_MAXT")) : 128;
+    static const int max_t = md2_tune("MD2_WGRAD_MAXT", 128);
     if (a.in_scale && !wgrad_taps32_eligible(a) && !(a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.padmode != PAD_REFLECT)) {
         fprintf(stderr, "md2: conv_wgrad: the input transform is built into the all-taps kernel (3x3, stride 1) and the 64- / 128-wide tile kernels only\n"); abort();
     }

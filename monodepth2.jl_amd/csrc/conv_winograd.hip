@@ -1156,9 +1156,9 @@ static int wino2_slots(int TW, int T = W2_T) {
     return (worst + 15) / 16 * 16;
 }
 // third kernel: Cout % 32 == 0, Cin % 8 == 0; 64 tiles per workgroup with up to 640 patch slots per stage (tile rows of at least 4 tiles), or 32 tiles with up to 384
-static int g_wino_nh = getenv("MD2_WINO_NH") ? atoi(getenv("MD2_WINO_NH")) : 0;          // 0: by workgroup count, 1 / 2: pin the 32- / 64-tile workgroup (tools/conv_bench)
+static int g_wino_nh = md2_tune("MD2_WINO_NH", 0);          // 0: by workgroup count, 1 / 2: pin the 32- / 64-tile workgroup (tools/conv_bench)
 static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
-    static const bool off = getenv("MD2_NO_WINO3") != nullptr;
+    static const bool off = md2_tune_set("MD2_NO_WINO3");
     if (off || g_wino_on == 2 || a.Cout % 32 != 0 || a.Cin % 8 != 0) return false;
     g.TH = (a.Ho + 1) / 2; g.TW = (a.Wo + 1) / 2; g.Mt = a.N * g.TH * g.TW;
     const int s64 = wino2_slots(g.TW, 64), s32 = wino2_slots(g.TW, 32);
@@ -1168,7 +1168,7 @@ static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
     // 32-tile workgroups by default: measured on every 3x3 / stride-1 shape of the step at batch 32 (tools/run_wino_nh_bench.sh) they are 4-18 % faster on the encoder stages
     // (0.159 -> 0.140 ms at 256 channels, 0.185 -> 0.152 at 512), 5-12 % on most decoder layers and within +-4 % on the rest; MD2_WINO_SMALL_BLOCKS=n keeps the 64-tile
     // workgroup for launches with at least n of them
-    static const long small = getenv("MD2_WINO_SMALL_BLOCKS") ? atol(getenv("MD2_WINO_SMALL_BLOCKS")) : (1L << 40);
+    static const long small = md2_tune("MD2_WINO_SMALL_BLOCKS", (1L << 40));
     nh = g_wino_nh == 1 ? 1 : (g_wino_nh == 2 ? 2 : (b64 < small ? 1 : 2));
     if (a.wino_pieces) { if (!ok32 || a.Cin % 16 != 0) return false; nh = 1; }          // split mode: conv_wino3s_kernel (32 tiles, 16-channel chunks) or the direct convolution
     if (nh == 1 && !ok32) nh = 2;
@@ -1663,8 +1663,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
 }
 
 bool conv_wino_wgrad_eligible(const WgradArgs& a) {
-    static const bool off = getenv("MD2_NO_WINO_WGRAD") != nullptr;
-    static const long min_m = getenv("MD2_WINO_WGRAD_MIN_M") ? atol(getenv("MD2_WINO_WGRAD_MIN_M")) : 1;          // (with the split kernel: ahead of the all-taps kernel at every size -- batch 4: 3.79 -> 3.71 ms per step)
+    static const bool off = md2_tune_set("MD2_NO_WINO_WGRAD");
+    static const long min_m = md2_tune("MD2_WINO_WGRAD_MIN_M", 1);          // (with the split kernel: ahead of the all-taps kernel at every size -- batch 4: 3.79 -> 3.71 ms per step)
     if (off || !g_wino_on || a.bf16) return false;          // (deterministic mode keeps this kernel: one workgroup per weight tile, launch_conv_wino_wgrad)
     if (!(a.KH == 3 && a.KW == 3 && a.stride == 1) || a.Cout % 64 != 0 || a.Cin % 32 != 0) return false;
     if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
@@ -1686,7 +1686,7 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     g.RB = 1; g.WPS = WG_WP;
     g.xbytes = (unsigned)std::min<long>(4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), (long)W_OOB - 16);          // (conv_wino_wgrad_eligible: both spans are below 2^32)
     g.dybytes = (unsigned)std::min<long>(4 * ((long)a.N * a.dy_bs + (long)a.Ho * a.Wo * a.dy_ps), (long)W_OOB - 16);
-    static const bool no_rows = getenv("MD2_WINO_WGRAD_NO_ROWPACK") != nullptr;
+    static const bool no_rows = md2_tune_set("MD2_WINO_WGRAD_NO_ROWPACK");
     if (!no_rows && 2 * g.TW <= WG_TB && g.nrows > 1) {          // short tile rows: several per batch (as many as fill the 16 tiles and the 160 staged patch slots)
         g.WPS = 2 * g.TW + 2;
         g.RB = std::min(std::min(WG_TB / g.TW, WG_XSLOTS / (4 * g.WPS)), g.nrows);
@@ -1694,7 +1694,7 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     }
     g.nb = g.RB > 1 ? (g.nrows + g.RB - 1) / g.RB : a.N * g.TH * g.BPR;
     g.nco = a.Cout / 64; g.nci = a.Cin / 32;
-    static const int want = getenv("MD2_WINO_WGRAD_BLOCKS") ? atoi(getenv("MD2_WINO_WGRAD_BLOCKS")) : 512;
+    static const int want = md2_tune("MD2_WINO_WGRAD_BLOCKS", 512);
     int ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));
     g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
     // bit-reproducible mode: ONE workgroup per weight tile walks every batch, so each weight (and bias) element receives exactly one atomic add onto zero

@@ -713,7 +713,7 @@ void launch_loss_train(const LossArgs& a, double* part, float* const dd[MD2_MAX_
     if ((a.C != 1 && a.C != 3) || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_train: unsupported C=%d H=%d W=%d\n", a.C, a.H, a.W); abort(); }
     LossTrainOut o; o.part = part; o.dRt_acc = dRt_acc; o.blk = blk;
     for (int i = 0; i < MD2_MAX_SCALES; ++i) { o.dd[i] = dd[i]; o.dlo[i] = dlo[i]; }
-    static const int tpb_env = getenv("MD2_LOSS_TPB") ? atoi(getenv("MD2_LOSS_TPB")) : 0;
+    static const int tpb_env = md2_tune("MD2_LOSS_TPB", 0);
     const int ntx = (a.W + TW - 1) / TW, tpb = tpb_env > 0 ? tpb_env : 2;
     const int th = a.C == 1 ? 32 : 16;
     dim3 grid((ntx + tpb - 1) / tpb, (a.H + th - 1) / th, a.N * a.nscales);

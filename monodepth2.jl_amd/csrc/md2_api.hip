@@ -40,7 +40,7 @@ struct BNL { int c = 0; long g = 0, b = 0, fg = 0, fb = 0; long rs = 0; float* s
 // BatchNorm-pullback sums come out of the input-gradient epilogues, and the shortcut BatchNorm is applied inside the block's final bn + add + ReLU pass
 struct Block { ConvL c1, c2, c3, cd; BNL b1, b2, b3, bd; bool down = false, bottleneck = false, stage_end = false, fuse = false; int stride = 1;
                View in, z1, a1, z2, a2, z3, zd, sd, out; View dz1, dz2, dz3, dzd; };
-struct ProfEvt { hipEvent_t a, b; int cls; double flops; char desc[112]; };
+struct ProfEvt { hipEvent_t a, b; int cls; double flops; char desc[144]; };
 enum { CLS_IGEMM = 0, CLS_WGRAD = 1, CLS_LOSS_FWD = 2, CLS_LOSS_BWD = 3, CLS_OTHER = 4 };      // CLS_LOSS_BWD: the training step's fused loss value + pullback kernel (bench.py: roofline_loss_train)
 
 }  // namespace
@@ -203,13 +203,13 @@ static void plan_buffers(md2_handle* h) {
         B.in = cur;
         if (!B.bottleneck) {
             const int co = B.c1.cout;
-            static const bool no_fuse = getenv("MD2_NO_BN_FUSE") != nullptr;
+            static const bool no_fuse = md2_tune_set("MD2_NO_BN_FUSE");
             B.fuse = !no_fuse && conv_wgrad_supports_in_transform(hh, ww, co, co);        // conv2 and its weight gradient can fold bn1 + ReLU into their loaders at this size
             B.z1 = h->alloc_view(NL, hh, ww, co); B.z2 = h->alloc_view(NL, hh, ww, co);
             B.a1 = B.fuse ? h->scratch_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co);      // fused: never materialised (the view only carries the shape)
         } else {
             const int pl = B.c1.cout, co = B.c3.cout;
-            static const bool no_fuse = getenv("MD2_NO_BN_FUSE") != nullptr;
+            static const bool no_fuse = md2_tune_set("MD2_NO_BN_FUSE");
             B.fuse = !no_fuse;                // 1x1 and 3x3 loaders (forward and weight gradient) all take the BatchNorm + ReLU transform at these channel counts (multiples of 64)
             B.z1 = h->alloc_view(NL, hi, wi, pl); B.a1 = B.fuse ? h->scratch_view(nullptr, NL, hi, wi, pl) : h->alloc_view(NL, hi, wi, pl);
             B.z2 = h->alloc_view(NL, hh, ww, pl); B.a2 = B.fuse ? h->scratch_view(nullptr, NL, hh, ww, pl) : h->alloc_view(NL, hh, ww, pl); B.z3 = h->alloc_view(NL, hh, ww, co);
@@ -303,15 +303,18 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
     ConvArgs a = a_in; a.bf16 = h->bf16;
     a.split3 = h->bf16 ? 0 : igemm_resolve_split(h->u_pieces_f, a.dil > 1 && a.ostep == 1 ? std::max(1, a.KH * a.KW / (a.dil * a.dil)) : a.nkh * a.nkw, a.Cin, a.Cout);          // (the product mode this handle's step was prepared under)
     a.ws = (h->cur && h->cur == h->s3) ? h->ws_pose : h->ws_main; a.ws_cap = h->ws_cap;
-    char d[112] = "";
+    char d[144] = "";
     // (alg: the route launch_conv_igemm takes -- conv_igemm_executed_flops applies the same test -- so that a test can see which kernels a step ran: md2_profile_dump)
     // ep: output-sized tensors the epilogue READS besides writing y (residual, activation-derivative source, BatchNorm inputs of the fused pullback sums, y itself when it
     // accumulates) -- distinct addresses only: part of the launch's algorithmic bytes (bench.py)
     int ep = 0;
     { const void* seen[5]; int ns = 0; const void* cand[5] = {a.res, a.dact_src, a.bz, a.bzB, a.accumulate ? (const void*)a.y : nullptr};
       for (const void* c : cand) { bool dup = c == nullptr; for (int i = 0; i < ns; ++i) dup = dup || seen[i] == c; if (!dup) { seen[ns++] = c; ++ep; } } }
-    if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d ep=%d alg=%s", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W, ep,
-                          conv_igemm_executed_flops(a) < conv_igemm_flops(a) ? (a.wino_pieces ? "winograd_split" : "winograd") : "direct");
+    const bool wino = conv_igemm_executed_flops(a) < conv_igemm_flops(a);
+    if (h->prof) snprintf(d, sizeof(d), "igemm M=%d Cout=%d Cin=%d k=%d s=%d dil=%d pm=%d HxW=%dx%d ep=%d alg=%s prod=%s", a.M, a.Cout, a.Cin, a.KH, a.stride, a.dil, a.padmode, a.H, a.W, ep,
+                          wino ? (a.wino_pieces ? "winograd_split" : "winograd") : "direct",
+                          // prod: how the launch forms its products -- fp32 (v_mfma_f32_*), split3 / split2 (bf16 pieces of fp32 operands on the bf16 pipe), bf16 (the bf16 modes); bench.py prices the matrix-pipe floor from it
+                          a.bf16 ? "bf16" : (wino ? (a.wino_pieces == 3 ? "split3" : (a.wino_pieces == 2 ? "split2" : "fp32")) : ((a.split3 && a.Cout % 64 == 0) ? "split3" : "fp32")));
     h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
     if (h->prof) { h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a); h->prof_exec[CLS_IGEMM] += conv_igemm_executed_flops(a); }
 }
@@ -527,7 +530,7 @@ static int loss_train(md2_handle* h, const float* x, const float* const disp[MD2
     // gradient wrt the disparity maps: the full-resolution scale is written directly; the coarse scales receive the adjoint of the bilinear resize from inside the
     // kernel (per-tile partial sums, float atomics) -- or, in deterministic mode, full-resolution maps that the ordered adjoint kernel reduces afterwards
     float *dd[MD2_MAX_SCALES] = {}, *dlo[MD2_MAX_SCALES] = {};
-    static const bool no_scatter = getenv("MD2_LOSS_NOSCATTER") && atoi(getenv("MD2_LOSS_NOSCATTER")) != 0;
+    static const bool no_scatter = md2_tune("MD2_LOSS_NOSCATTER", 0) != 0;
     const bool scatter = !simple && !g_deterministic && !no_scatter;
     bool any_lo = false;
     for (int i = 0; i < a.nscales; ++i) {
@@ -604,7 +607,7 @@ static int model_backward(md2_handle* h) {
     else if (int r = backward_prepare(h, s)) return r;
     // data parallel: the gradient buffer is all-reduced in up to 4 buckets as they complete (decoders | stage 5 | stages 3-4 | stage 2 + stem), MD2_COMM_BUCKETS=0: one
     // all-reduce by md2_allreduce_grads after the pullback
-    static const bool buckets_on = !(getenv("MD2_COMM_BUCKETS") && atoi(getenv("MD2_COMM_BUCKETS")) == 0);
+    static const bool buckets_on = md2_tune("MD2_COMM_BUCKETS", 1) != 0;
     h->grads_reduced = false; h->n_bucket_done = (h->comm && buckets_on) ? 0 : -1;
     const BucketPlan bp = bucket_plan(h);
     // The gradient accumulators (Gfeat / Gblk / Gpool, 715 MB at B=32) are NOT zeroed: every buffer's first writer overwrites
@@ -738,7 +741,7 @@ static int model_backward(md2_handle* h) {
     {   // stem tail pullback: the max-pool pullback also reduces the stem BatchNorm's sums, and the stem's weight gradient forms dz = A g + B z + C0 in its loader:
         // no reduction pass, no dz tensor (Gfeat[0]: decoder skip gradient in the target frames only; ReLU mask from the pooled output)
         const BNL& b = h->stem_bn;
-        const bool fuse = !g_deterministic && !getenv("MD2_NO_BN_FUSE");
+        const bool fuse = !g_deterministic && !md2_tune_set("MD2_NO_BN_FUSE");
         const int acc_frame = stage_used[0] ? h->tgt : -1;           // no decoder skip gradient in Gfeat[0] when the fifth branch is absent
         if (fuse) launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, &h->z0, b.stats, b.acc_b, acc_frame);
         else { launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, nullptr, nullptr, nullptr, acc_frame); launch_bn_bwd_reduce(h->Gfeat[0], nullptr, ACT_NONE, h->z0, b.stats, b.acc_b, s); }
@@ -914,7 +917,7 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     std::memcpy(h->K, Kc, sizeof(Kc)); std::memcpy(h->invK, iKc, sizeof(iKc));
     {   // the weight-gradient stream only fills in around the dependency chain on the caller's stream: lowest priority (MD2_S2_PRIO: 0 default queue priority)
         int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        const int want = getenv("MD2_S2_PRIO") ? atoi(getenv("MD2_S2_PRIO")) : 1;
+        const int want = md2_tune("MD2_S2_PRIO", 1);
         const int prio = want > 0 ? lo : (want < 0 ? hi : 0);
         if (hipStreamCreateWithPriority(&h->s2, hipStreamNonBlocking, prio) != hipSuccess || hipStreamCreateWithFlags(&h->s3, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     }
@@ -923,7 +926,7 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_p0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_p1, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     h->two_streams = getenv("MD2_ONE_STREAM") == nullptr;
     if (hipStreamCreateWithFlags(&h->s4, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_join4, hipEventDisableTiming) != hipSuccess) return fail("hipStreamCreate failed");
-    h->n_wg_streams = getenv("MD2_WG_STREAMS") ? atoi(getenv("MD2_WG_STREAMS")) : 1;
+    h->n_wg_streams = md2_tune("MD2_WG_STREAMS", 1);
     *out = h;
     return 0;
 }

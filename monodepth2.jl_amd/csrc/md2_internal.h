@@ -3,6 +3,7 @@
 // frame slicing (src/model.jl:16,32-34) and channel concat (src/depth_decoder.jl:19, src/pose_decoder.jl:24)
 // cost nothing: producers write straight into channel slices / strided batches.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -43,6 +44,18 @@ inline int wgrad_resolve_pieces_tap(int mode) { return mode == 1 ? 3 : mode; }
 //   the exact split is ahead at every shape measured, tools/run_igemm_split_bench.sh -- 0.127 -> 0.107 ms on the 64 -> 128 stride-2 3x3 at batch 32, 0.147 -> 0.114 / 0.143 -> 0.113 ms
 //   on ResNet-50's 512 -> 128 / 1024 -> 256 bottleneck 1x1s at 640x192, 0.028 -> 0.025 on the 64-channel 1x1 shortcut; 64-channel-wide tiles only (Cout % 64 == 0)
 inline int igemm_resolve_split(int mode, int taps, int cin, int cout) { (void)taps; (void)cin; return (cout % 64 == 0 && mode != 0) ? 1 : 0; }
+
+// Launch-policy constants.  The product library compiles them in: the only environment variables it reads are the documented load-time defaults of the md2_set_* calls
+// (MD2_DETERMINISTIC, MD2_ONE_STREAM, MD2_NO_WINO / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS, MD2_WINO_PIECES / MD2_WGRAD_PIECES; include/md2hip.h).  The measuring tools
+// (tools/conv_bench*.cpp, built with -DMD2_TUNE_ENV -- or -DMD2_ABLATE, which also adds the kernels' timing switches) read the same names from the environment, which is how
+// the values below were chosen.
+#if defined(MD2_TUNE_ENV) || defined(MD2_ABLATE)
+inline long md2_tune(const char* name, long dflt) { const char* e = getenv(name); return e ? atol(e) : dflt; }
+inline bool md2_tune_set(const char* name) { return getenv(name) != nullptr; }
+#else
+constexpr long md2_tune(const char*, long dflt) { return dflt; }
+constexpr bool md2_tune_set(const char*) { return false; }
+#endif
 
 enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 enum PadMode : int { PAD_ZERO = 0, PAD_REFLECT = 1 };

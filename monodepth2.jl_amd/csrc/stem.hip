@@ -212,7 +212,7 @@ void launch_stem_fwd(const float* x, int NL, int C, int H, int W, const float* w
     if ((C != 1 && C != 3) || z.C != 64 || z.H != H / 2 || z.W != W / 2 || z.N != NL || (H & 1) || (W & 1) || z.ps % 4 != 0) {
         fprintf(stderr, "md2: stem_fwd: unsupported shape C=%d %dx%d\n", C, H, W); abort();
     }
-    static const bool no_bfm = getenv("MD2_STEM_FP32") != nullptr;
+    static const bool no_bfm = md2_tune_set("MD2_STEM_FP32");
     const bool bfm = bf16_products && !no_bfm;
 #define STEM_FWD(C_, BS_, BFM_) launch_stem_fwd_t<C_, BS_, BFM_>(x, NL, H, W, w, Kpad, z, stats, s)
     if (C == 1) { if (z.bf) { if (bfm) STEM_FWD(1, true, true); else STEM_FWD(1, true, false); } else { if (bfm) STEM_FWD(1, false, true); else STEM_FWD(1, false, false); } }
@@ -483,7 +483,7 @@ void launch_stem_wgrad(const float* x, int NL, int C, int H, int W, const View& 
     if ((C != 1 && C != 3) || dz.C != 64 || dz.H != H / 2 || dz.W != W / 2 || dz.N != NL || (H & 1) || (W & 1) || dz.ps % 4 != 0) {
         fprintf(stderr, "md2: stem_wgrad: unsupported shape C=%d %dx%d\n", C, H, W); abort();
     }
-    static const bool no_bfm = getenv("MD2_STEM_FP32") != nullptr;
+    static const bool no_bfm = md2_tune_set("MD2_STEM_FP32");
     if (bf16_products && !no_bfm) {
         const View zb = zbn ? *zbn : dz;
         if (zbn && (zb.C != 64 || zb.H != dz.H || zb.W != dz.W || zb.N != dz.N || zb.ps % 4 != 0 || zb.bf != dz.bf)) { fprintf(stderr, "md2: stem_wgrad: BatchNorm input view mismatch\n"); abort(); }

@@ -105,6 +105,32 @@ def valu(d, steps, out_json, B, C, H, W):
     json.dump(out, open(out_json, "w"), indent=1)
 
 
+def l2(d, steps):
+    """L1 -> L2 read requests and L2 hit rate per kernel (one --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE pass): how many bytes a kernel's compute units
+    pull out of the L2 per shader cycle -- the convolution loops of this step are bound by that rate, not by the matrix pipe."""
+    f = glob.glob(d + "/*counter_collection.csv")[0]
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(f)):
+        a = per[r["Kernel_Name"].split("(")[0][:90]][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    print("# L1 -> L2 read requests per kernel, batch 32 (rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra)")
+    print("# per launch averages; shader cycles = GRBM_GUI_ACTIVE / 8 XCDs; B / clk / CU = requests x 64 B / (shader cycles x 256 CUs) -- a TCP -> TCC read request moves one 64-byte")
+    print("# half line (uncalibrated against a known byte count on gfx950: read the column as a lower bound and compare kernels with each other)")
+    print()
+    print("| kernel | launches | shader cycles | L1->L2 read requests | B / clk / CU (64 B per request) | L2 hit rate |")
+    print("|---|---|---|---|---|---|")
+    rows = []
+    for k, c in per.items():
+        n = c["TCP_TCC_READ_REQ_sum"][0]
+        if n == 0:
+            continue
+        cyc = c["GRBM_GUI_ACTIVE"][1] / max(c["GRBM_GUI_ACTIVE"][0], 1) / 8.0
+        req = c["TCP_TCC_READ_REQ_sum"][1] / n
+        hit = c["TCC_HIT_sum"][1]; miss = c["TCC_MISS_sum"][1]
+        rows.append((req * n, k, n, cyc, req, req * 64.0 / max(cyc * 256.0, 1.0), hit / max(hit + miss, 1.0)))
+    for _, k, n, cyc, req, bpc, hr in sorted(rows, reverse=True)[:28]:
+        print("| `%s` | %d | %.4g | %.4g | %.1f | %.3f |" % (k, n, cyc, req, bpc, hr))
+
+
 def mfma(dm, dl, dv):
     """Matrix-pipe / LDS / instruction counters per kernel (three --pmc passes of the same command): how busy the matrix pipe is, whether MFMAs co-execute with vector
     instructions, vector and scalar instructions per MFMA, LDS bank-conflict ratio."""
@@ -162,6 +188,8 @@ if __name__ == "__main__":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4])
     elif sys.argv[1] == "mfma":
         mfma(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "l2":
+        l2(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "valu":
         valu(sys.argv[2], int(sys.argv[3]), sys.argv[4], *[int(v) for v in sys.argv[5:9]])
     else:

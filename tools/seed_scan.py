@@ -22,7 +22,7 @@ net = oracle.OracleNet(C, depth=depth)
 lay = syn.param_layout(C, depth)
 # every arithmetic route the tight test makes its statement on: algorithm choice automatic / Winograd forced wherever the shape qualifies, ordered / default reductions,
 # fp32-MFMA / exact three-piece products in the forward + input-gradient and in the weight-gradient kernels
-CONFIGS = [(forced, det, fp, wp) for forced in (0, 1) for det in (0, 1) for fp in (0, 3) for wp in (0, 3)]
+CONFIGS = [(forced, det, fp, wp) for forced in (0, 1) for det in (0, 1) for fp in (0, 3) for wp in (0, 3)] + [(forced, det, 1, 1) for forced in (0, 1) for det in (0, 1)]          # (1, 1): the per-launch choice of the timed configuration
 for sd in range(first, first + count):
     theta = syn.init_params(C, seed=sd, randomize_affine=True, depth=depth); x = syn.synthetic_triplets(N, C, H, W, seed=sd + 1)
     model.load_params(theta); xd = torch.from_numpy(x).cuda()
