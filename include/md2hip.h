@@ -236,7 +236,9 @@ int32_t md2_conv2d_fwd(const float* x, const float* w, const float* b, float* y,
 int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int32_t N, int32_t Cin,
                        int32_t H, int32_t W, int32_t Cout, int32_t k, int32_t stride, int32_t pad, int32_t pad_mode, void* stream);
 /* Test switch (process-wide): 1 = md2_conv2d_fwd / md2_conv2d_bn_fwd / md2_conv2d_bwd run the kernels of md2_config.precision = 2 -- x, y, dy, dx as bf16 tensors, bf16 weight
- * copies, fp32 accumulation -- so that each of them can be held against a plain fp32 reference of the op on bf16-rounded inputs; 0 (default) = fp32 tensors.  Returns 2 on any other value. */
+ * copies, fp32 accumulation -- so that each of them can be held against a plain fp32 reference of the op on bf16-rounded inputs; 0 (default) = fp32 tensors.  Returns 2 on any other value.
+ * Like md2_set_deterministic / md2_set_winograd / md2_set_conv_products this is an unsynchronised process-wide switch: set it from one thread while no call of the library is in flight
+ * (a handle snapshots the product modes when it prepares a step, so a step never mixes them; the op-level entry points read the switches at call time). */
 int32_t md2_set_op_storage(int32_t bf16);
 /* The encoder's conv -> BatchNorm pair (ResNet.jl via src/model.jl:14): bias-free convolution whose epilogue also accumulates the training-BatchNorm batch
  * statistics; bn_mean / bn_invstd [Cout] = mean and 1/sqrt(biased var + 1e-5) over (N,H,W) of y */

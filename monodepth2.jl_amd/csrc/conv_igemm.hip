@@ -1099,6 +1099,12 @@ static void check_igemm_args(const ConvArgs& a) {
     // host-side shape checks: a kernel fault can reset the whole node, so refuse anything the tiling does not cover
     const long x_elems = 4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), w_elems = 4 * ((long)a.Cout * a.KH * a.KW * a.Cin);   // byte offsets must fit 32 bits
     if (a.bf16 == 2 && !(a.Cin == 16 || a.Cin % 32 == 0)) { fprintf(stderr, "md2: conv_igemm: bf16 tensors need Cin == 16 or a multiple of 32 (Cin=%d)\n", a.Cin); abort(); }
+    // bf16 tensors with 16 input channels take the paired-tap form (two filter taps per 64-byte K-step, b_tap = t * 64): it assumes the dense 3x3 tap lattice (or a single tap)
+    // and has no BatchNorm-in-the-loader / pullback-sum variants -- a stride-2 input gradient's residue classes or a fused launch would multiply by the wrong taps (round-4 advisor finding)
+    if (a.bf16 == 2 && a.Cin == 16 && !((a.nkh * a.nkw == 1) || (a.nkh == 3 && a.nkw == 3 && a.kh0 == 0 && a.kw0 == 0 && a.khs == 1 && a.kws == 1)) ) {
+        fprintf(stderr, "md2: conv_igemm: bf16 tensors with 16 input channels need a 1x1 or a dense 3x3 tap lattice (taps %dx%d from (%d,%d) step (%d,%d))\n", a.nkh, a.nkw, a.kh0, a.kw0, a.khs, a.kws); abort();
+    }
+    if (a.bf16 == 2 && a.Cin == 16 && (a.in_scale || a.bst)) { fprintf(stderr, "md2: conv_igemm: the paired-tap form of 16-channel bf16 tensors has no fused BatchNorm variants\n"); abort(); }
     if (a.Cin % 16 != 0 || a.Cout % 16 != 0 || a.x_ps % 4 != 0 || a.y_ps % 4 != 0 || a.M <= 0 || (a.dact_src && a.da_ps % 4 != 0) || (a.res && (a.res_ps % 4 != 0 || a.act != ACT_NONE || a.bias)) ||
         a.M != a.N * a.Hl * a.Wl || a.nkh < 1 || a.nkw < 1 || a.ostep < 1 || x_elems >= (1L << 32) - 64 || w_elems >= (1L << 32)) {
         fprintf(stderr, "md2: conv_igemm: unsupported shape Cin=%d Cout=%d x_ps=%d y_ps=%d M=%d\n", a.Cin, a.Cout, a.x_ps, a.y_ps, a.M);
@@ -1541,7 +1547,7 @@ static void launch_wgrad_tile(const WgradArgs& a, hipStream_t s) {
                                                      else hipLaunchKernelGGL((conv_wgrad_kernel<T, BKP, MF, REFL, FAST_, XF_, ONE_, SPL_, false>), g, dim3(256), 0, s, a, sps, steps_total); } while (0)
     if constexpr (T >= 64) {
         // products on the bf16 matrix pipe: bf16 tensors -> their values as they are (1 piece); fp32 tensors -> split operands (3 = exact, 2 = reduced precision opt-in): see conv_wgrad_kernel
-        const int pieces = bs ? 1 : wgrad_resolve_pieces_tap(g_wgrad_pieces);
+        const int pieces = bs ? 1 : wgrad_resolve_pieces_tap(a.pieces_mode1 ? a.pieces_mode1 - 1 : g_wgrad_pieces);
         static const bool no_one = md2_tune_set("MD2_NO_WGRAD_ONE");
         const bool one = !no_one && taps == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo && a.x_bs == (long)a.H * a.W * a.x_ps && a.dy_bs == (long)a.Ho * a.Wo * a.dy_ps;
         if (pieces && fast && !refl) {

@@ -1699,7 +1699,7 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
     // bit-reproducible mode: ONE workgroup per weight tile walks every batch, so each weight (and bias) element receives exactly one atomic add onto zero
     if (g_deterministic) { ksn = 1; g.bpb = g.nb; }
-    const int pieces = wgrad_resolve_pieces_wino(g_wgrad_pieces, a.M, a.Cout, a.Cin);
+    const int pieces = wgrad_resolve_pieces_wino(a.pieces_mode1 ? a.pieces_mode1 - 1 : g_wgrad_pieces, a.M, a.Cout, a.Cin);
     if (pieces) {          // products on the bf16 matrix pipe (3: exact three-piece split; 2: reduced precision, opt-in); 32 x 32-channel blocks
         g.nco = a.Cout / 32;
         ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));

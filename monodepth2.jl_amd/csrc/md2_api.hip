@@ -78,6 +78,7 @@ struct md2_handle {
     long* wdesc_dev = nullptr; int n_wdesc = 0, n_wblocks = 0;
     // Winograd operands U = G g G^T of every 3x3 / stride-1 layer, refreshed once per step from P (forward) and WD (input gradient)
     float *UF = nullptr, *UD = nullptr; long n_uf = 0, n_ud = 0; long *udesc_f = nullptr, *udesc_d = nullptr; int n_udf = 0, n_udd = 0, ublk_f = 0, ublk_d = 0; hipEvent_t ev_uf = nullptr;
+    int wg_pieces = MD2_DEFAULT_WGRAD_PIECES;      // g_wgrad_pieces as it stood when this handle's pullback was prepared: every weight-gradient launch of the step takes this mode (WgradArgs::pieces_mode1)
     int u_pieces_f = 0, u_pieces_d = 0;      // layout UF / UD were last written in (g_wino_pieces at that refresh): every launch that reads them is told through ConvArgs::wino_pieces,
                                              // so a md2_set_conv_products between md2_train_loss and md2_backward (or from another handle) cannot make a kernel misread its operand
     // weight gradients run on a second stream, concurrently with the input-gradient / BN-pullback chain of the main stream
@@ -354,10 +355,10 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     a.x = x.p; a.x_bs = x.bs; a.x_ps = x.ps; a.H = x.H; a.W = x.W; a.Cin = x.C;
     a.dy = dy.p; a.dy_bs = dy.bs; a.dy_ps = dy.ps; a.Ho = dy.H; a.Wo = dy.W; a.Cout = dy.C;
     a.dw = h->G + c.w; a.N = dy.N; a.KH = c.kind == 1 ? 1 : c.k; a.KW = a.KH; a.stride = c.kind == 1 ? 1 : c.stride; a.pad = c.kind == 1 ? 0 : (padmode == PAD_REFLECT ? 1 : c.pad); a.padmode = padmode;
-    a.M = dy.N * dy.H * dy.W; a.db = c.bias ? h->G + c.b : nullptr; a.bf16 = h->bf16;
+    a.M = dy.N * dy.H * dy.W; a.db = c.bias ? h->G + c.b : nullptr; a.bf16 = h->bf16; a.pieces_mode1 = h->wg_pieces + 1;
     char d[112] = "";
     if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d alg=%s pieces=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode, conv_wino_wgrad_eligible(a) ? "winograd" : "direct",
-                          conv_wino_wgrad_eligible(a) ? wgrad_resolve_pieces_wino(g_wgrad_pieces, a.M, a.Cout, a.Cin) : wgrad_resolve_pieces_tap(g_wgrad_pieces));
+                          conv_wino_wgrad_eligible(a) ? wgrad_resolve_pieces_wino(h->wg_pieces, a.M, a.Cout, a.Cin) : wgrad_resolve_pieces_tap(h->wg_pieces));
     hipStream_t st = wgrad_stream(h);
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
     if (h->prof) {
@@ -581,7 +582,7 @@ static int backward_prepare(md2_handle* h, hipStream_t s) {
     launch_weight_prepare(h->P, h->WD, h->wdesc_dev, h->n_wdesc, h->n_wblocks, h->G, h->n_int, s);          // transposed / flipped weight copies + the zeroed gradient buffer, one launch
     if (h->bs) launch_cast_bf16(h->WD, h->WDb, h->n_int, s);
     if (!h->acc_zeroed) HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
-    h->u_pieces_d = g_wino_pieces;
+    h->u_pieces_d = g_wino_pieces; h->wg_pieces = g_wgrad_pieces;
     if (!h->bf16) launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions
     KCHK(); return 0;
 }

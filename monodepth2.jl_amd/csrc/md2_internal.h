@@ -192,6 +192,8 @@ struct WgradArgs {
     int N, KH, KW, stride, pad, padmode;
     int M;
     int bf16;                     // same switch for the all-taps weight gradient (conv3x3_wgrad_taps32_kernel)
+    int pieces_mode1;             // md2_set_conv_products' weight-gradient mode + 1 as the CALLER snapshot it (a handle: at the start of its pullback, so that a concurrent
+                                  // md2_set_conv_products cannot mix product forms inside one step); 0 = not given: the process-wide g_wgrad_pieces at launch time
     float* db;                    // optional bias gradient: db[co] += sum_{n,oh,ow} dy (fused into the all-taps kernels, a colsum launch otherwise)
     const float* in_scale; const float* in_shift;      // x operand = relu(x * in_scale[ci] + in_shift[ci]) applied on the way into LDS (all-taps kernel only); null = raw
 #ifdef MD2_ABLATE

@@ -21,7 +21,7 @@ struct MD2Config
     encoder_depth::Int32; precision::Int32       # ResidualNetwork(18 | 50); 0 = f32, 1 = bf16 MFMA operands on fp32 tensors, 2 = bf16 activation tensors
     target_id::Int32; source_id1::Int32; source_id2::Int32      # TrainCache.target_id / source_ids (1-based; 0 = the defaults 2 / (1, 3))
     scale_levels::NTuple{5, Int32}                               # DepthDecoder(; scale_levels), ascending, 0-terminated (all 0 = 2:5, src/Monodepth.jl:106)
-    scales::NTuple{5, Float64}                                   # TrainCache.scales (0 = 1 / 2^(5 - level), src/Monodepth.jl:107)
+    scales::NTuple{5, Float64}                                   # TrainCache.scales: ALL five 0 = the defaults 1 / 2^(5 - level) (src/Monodepth.jl:107); otherwise as given (0 = that output's smoothness off, negative = its default)
 end
 
 include("md2_ccall.jl")        # raw wrappers: md2_create(...), md2_train_step(...), ... one per export
@@ -59,6 +59,11 @@ ones_like(::ROCArray{T}, shape) where T = AMDGPU.ones(T, shape)
 function Handle(; batch, channels, width, height, automasking=false, device=0,
                 min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, lr=1e-4, encoder_depth=18, precision=0, target_id=2, source_ids=[1, 3],
                 scale_levels=collect(2:5), scales=Float64[])
+    # md2_config.scales: an all-zero array means "not given".  A caller whose scales are ALL 0 wants every smoothness weight disparity_smoothness * scale_i (src/training.jl:67)
+    # to be 0: say that through the other factor, as the Python mirror does (monodepth.py, Model._ensure)
+    if !isempty(scales) && all(iszero, scales)
+        scales = Float64[]; disparity_smoothness = 0.0
+    end
     cfg = Ref(MD2Config(batch, channels, height, width, automasking, device, min_depth, max_depth, disparity_smoothness, lr, encoder_depth, precision,
                         target_id, source_ids[1], source_ids[2],           # TrainCache.target_id / source_ids (src/Monodepth.jl:44-55), 1-based like the reference
                         pad5(scale_levels, Int32), pad5(scales, Float64)))
