@@ -118,7 +118,8 @@ int32_t md2_set_deterministic(int32_t on);
  * workgroups wherever Cout % 64 == 0 (round 5: faster launch by launch, slower inside the step, so not the default -- DESIGN.md section 4; tests keep it exercised).  Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks);
 /* How the fp32 products of the convolutions are formed (the role cuDNN's math mode plays behind Flux; the reference computes in fp32, src/Monodepth.jl:72).
- *   fwd_dgrad: the Winograd forward / input-gradient kernels;  wgrad: the weight-gradient kernels (Winograd-domain and per-tap).  -1 keeps the current value.
+ *   fwd_dgrad: the forward / input-gradient kernels -- the fused Winograd kernels and, since round 5, the direct implicit GEMM (1x1, stride 2 and its residue-class input
+ *   gradients, 3x3 launches below the Winograd threshold; 64-channel-wide tiles);  wgrad: the weight-gradient kernels (Winograd-domain and per-tap).  -1 keeps the current value.
  *   0 = v_mfma_f32_32x32x2_f32, the fp32 MFMA.
  *   1 = (default) per launch whichever of the two full-accuracy forms 0 and 3 is faster at the launch's shape (the rule is in csrc/md2_internal.h, from in-model timings).
  *   3 = exact split: every fp32 operand is the exact sum of three bf16 pieces (hi + mid + lo = all 24 mantissa bits); a product group takes six

@@ -494,10 +494,13 @@ __device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __
 // NH = 32-tile halves per workgroup.  NH = 2 (64 tiles, two workgroups per CU) halves the U traffic per multiply; NH = 1 (32 tiles, 64 accumulator registers: THREE workgroups per
 // CU, 768 resident on the chip) is for launches with too few 64-tile workgroups to fill 512 slots twice -- the 1/16- and 1/32-scale layers left a third of the wave slots empty
 // (SQ_WAVE_CYCLES of profiles/r03_wino3_pmc.md: 68 % of the slot-time occupied) -- and gives the scheduler a third wave per SIMD to cover the waits of the other two.
-template <int NLI, int XF, int BST, int NH = 2>
-__global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo geo) {
+// CB (round 5) = 32-channel output blocks per workgroup.  CB = 2 (with NH = 1: 32 tiles x 64 channels, 128 accumulator registers, two workgroups per CU): the input transform of a
+// chunk feeds the MFMAs of both channel blocks -- for the fp32 MFMA, which never co-executes with vector instructions, every transform instruction saved is matrix-pipe time --
+// and a workgroup pulls 44 instead of 2 x 28 KB of operands per chunk into its CU.
+template <int NLI, int XF, int BST, int NH = 2, int CB = 1>
+__global__ __launch_bounds__(256, (NH == 1 && CB == 1) ? 3 : 2) void conv_wino3_kernel(ConvArgs a, Wino2Geo geo) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
-    constexpr int COB = 32, WT = 32 * NH;
+    constexpr int COB = 32 * CB, WT = 32 * NH, NA = NH * CB;          // NA accumulator sets per position: (tile half th, channel block cb) -> th * CB + cb
     constexpr int PST = 128 * NLI * 8;               // floats per patch stage: every (slot, half) item of the loader has a real slot (those past geo.nslots are never read)
     const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
     const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
@@ -581,18 +584,23 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvAr
         }
     }
 
-    f32x16 acc[4][NH];
+    f32x16 acc[4][NA];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < NH; ++t)
+        for (int t = 0; t < NA; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][t][e] = 0.f;
 
     // U stream of this wave: fragment (c8, j) of cout sub-tile tile_c at ub + (c8 * 4 + j) * 256 floats
     const int nchunks = a.Cin >> 3;
-    const float* ub = a.wino_u + ((long)(tile_c * 4 + wi) * nchunks) * 4 * 256 + lane * 4;
-    f32x4 uf0 = *reinterpret_cast<const f32x4*>(ub), uf1 = *reinterpret_cast<const f32x4*>(ub + 256), uf2 = *reinterpret_cast<const f32x4*>(ub + 512), uf3 = *reinterpret_cast<const f32x4*>(ub + 768);
+    const float* ub = a.wino_u + ((long)(tile_c * CB * 4 + wi) * nchunks) * 4 * 256 + lane * 4;          // channel block cb of the workgroup: + cb * ubs
+    const long ubs = (long)4 * nchunks * 4 * 256;
+    f32x4 uf[CB][4];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) uf[cb][j] = *reinterpret_cast<const f32x4*>(ub + cb * ubs + j * 256);
 
 #ifdef MD2_ABLATE
     const int abl = a.ablate;
@@ -635,10 +643,13 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvAr
             // in-place refill right behind a fragment's last use in this chunk (tile half 1): the next use is three MFMA groups, the commit, the barrier and a transform
             // phase later -- for every j alike
             // (the sched_barriers keep hipcc from collecting the four loads behind the last MFMA)
-            W3_MFMA(th, 0, uf0); if (th == NH - 1 && !(abl & 2)) { uf0 = *reinterpret_cast<const f32x4*>(un); __builtin_amdgcn_sched_barrier(0); }
-            W3_MFMA(th, 1, uf1); if (th == NH - 1 && !(abl & 2)) { uf1 = *reinterpret_cast<const f32x4*>(un + 256); __builtin_amdgcn_sched_barrier(0); }
-            W3_MFMA(th, 2, uf2); if (th == NH - 1 && !(abl & 2)) { uf2 = *reinterpret_cast<const f32x4*>(un + 512); __builtin_amdgcn_sched_barrier(0); }
-            W3_MFMA(th, 3, uf3); if (th == NH - 1 && !(abl & 2)) uf3 = *reinterpret_cast<const f32x4*>(un + 768);
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                W3_MFMA(th * CB + cb, 0, uf[cb][0]); if (th == NH - 1 && !(abl & 2)) { uf[cb][0] = *reinterpret_cast<const f32x4*>(un + cb * ubs); __builtin_amdgcn_sched_barrier(0); }
+                W3_MFMA(th * CB + cb, 1, uf[cb][1]); if (th == NH - 1 && !(abl & 2)) { uf[cb][1] = *reinterpret_cast<const f32x4*>(un + cb * ubs + 256); __builtin_amdgcn_sched_barrier(0); }
+                W3_MFMA(th * CB + cb, 2, uf[cb][2]); if (th == NH - 1 && !(abl & 2)) { uf[cb][2] = *reinterpret_cast<const f32x4*>(un + cb * ubs + 512); __builtin_amdgcn_sched_barrier(0); }
+                W3_MFMA(th * CB + cb, 3, uf[cb][3]); if (th == NH - 1 && !(abl & 2)) { uf[cb][3] = *reinterpret_cast<const f32x4*>(un + cb * ubs + 768); if (cb + 1 < CB) __builtin_amdgcn_sched_barrier(0); }
+            }
         }
 #undef W3_MFMA
         __builtin_amdgcn_sched_barrier(0);
@@ -647,21 +658,22 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void conv_wino3_kernel(ConvAr
     }
 
 #ifdef MD2_ABLATE
-    if (abl & 64) { if (acc[0][0][0] + acc[1][NH - 1][3] + acc[2][0][5] + acc[3][NH - 1][7] == 123.456f) a.y[0] = 1.f; return; }          // timing experiment: no output transform / epilogue
+    if (abl & 64) { if (acc[0][0][0] + acc[1][NA - 1][3] + acc[2][0][5] + acc[3][NA - 1][7] == 123.456f) a.y[0] = 1.f; return; }          // timing experiment: no output transform / epilogue
 #endif
     // ---- output transform: column half in registers, row half through LDS (R[i][b][64 tiles][COB + 4])
     constexpr int RLD = COB + 4;
     float* Rl = wsm;
 #pragma unroll
-    for (int th = 0; th < NH; ++th)
+    for (int tc = 0; tc < NA; ++tc)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            const int th = tc / CB, cb = tc % CB;
             float4 o0, o1;
-            o0.x = acc[0][th][4 * g + 0] + acc[1][th][4 * g + 0] + acc[2][th][4 * g + 0]; o1.x = acc[1][th][4 * g + 0] - acc[2][th][4 * g + 0] - acc[3][th][4 * g + 0];
-            o0.y = acc[0][th][4 * g + 1] + acc[1][th][4 * g + 1] + acc[2][th][4 * g + 1]; o1.y = acc[1][th][4 * g + 1] - acc[2][th][4 * g + 1] - acc[3][th][4 * g + 1];
-            o0.z = acc[0][th][4 * g + 2] + acc[1][th][4 * g + 2] + acc[2][th][4 * g + 2]; o1.z = acc[1][th][4 * g + 2] - acc[2][th][4 * g + 2] - acc[3][th][4 * g + 2];
-            o0.w = acc[0][th][4 * g + 3] + acc[1][th][4 * g + 3] + acc[2][th][4 * g + 3]; o1.w = acc[1][th][4 * g + 3] - acc[2][th][4 * g + 3] - acc[3][th][4 * g + 3];
-            const int col = 8 * g + 4 * ch, ct = th * 32 + tl;
+            o0.x = acc[0][tc][4 * g + 0] + acc[1][tc][4 * g + 0] + acc[2][tc][4 * g + 0]; o1.x = acc[1][tc][4 * g + 0] - acc[2][tc][4 * g + 0] - acc[3][tc][4 * g + 0];
+            o0.y = acc[0][tc][4 * g + 1] + acc[1][tc][4 * g + 1] + acc[2][tc][4 * g + 1]; o1.y = acc[1][tc][4 * g + 1] - acc[2][tc][4 * g + 1] - acc[3][tc][4 * g + 1];
+            o0.z = acc[0][tc][4 * g + 2] + acc[1][tc][4 * g + 2] + acc[2][tc][4 * g + 2]; o1.z = acc[1][tc][4 * g + 2] - acc[2][tc][4 * g + 2] - acc[3][tc][4 * g + 2];
+            o0.w = acc[0][tc][4 * g + 3] + acc[1][tc][4 * g + 3] + acc[2][tc][4 * g + 3]; o1.w = acc[1][tc][4 * g + 3] - acc[2][tc][4 * g + 3] - acc[3][tc][4 * g + 3];
+            const int col = 32 * cb + 8 * g + 4 * ch, ct = th * 32 + tl;
             *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * WT + ct) * RLD + col) = o0;
             *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * WT + ct) * RLD + col) = o1;
         }
@@ -1180,21 +1192,21 @@ static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
     // 0.6 x the threshold already wins (batch 4, encoder layer 2: 156 workgroups, 0.051 -> 0.040 ms in the model)
     return g_wino_on == 3 || b64 >= g_wino_min_blocks || (a.Cin <= 128 && b64 * 5 >= (long)g_wino_min_blocks * 3);
 }
-template <int NLI, int NH>
+template <int NLI, int NH, int CB = 1>
 static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
-    constexpr size_t lds_pipe = (size_t)2 * 128 * NLI * 8 * sizeof(float), lds_epi = (size_t)8 * (32 * NH) * (32 + 4) * sizeof(float), lds_st = (size_t)12 * 256 * sizeof(float);
+    constexpr size_t lds_pipe = (size_t)2 * 128 * NLI * 8 * sizeof(float), lds_epi = (size_t)8 * (32 * NH) * (32 * CB + 4) * sizeof(float), lds_st = (size_t)12 * 256 * sizeof(float);
     constexpr size_t lds = std::max(std::max(lds_pipe, lds_epi), lds_st);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 0, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 1, 0, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 1, NH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 0, NH, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 1, 0, NH, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3_kernel<NLI, 0, 1, NH, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int grid = g.ntp * (a.Cout / 32);
-    if (a.in_scale) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 1, 0, NH>), dim3(grid), dim3(256), lds, s, a, g);
-    else if (a.bst) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 1, NH>), dim3(grid), dim3(256), lds, s, a, g);
-    else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0, NH>), dim3(grid), dim3(256), lds, s, a, g);
+    const int grid = g.ntp * (a.Cout / (32 * CB));
+    if (a.in_scale) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 1, 0, NH, CB>), dim3(grid), dim3(256), lds, s, a, g);
+    else if (a.bst) hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 1, NH, CB>), dim3(grid), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino3_kernel<NLI, 0, 0, NH, CB>), dim3(grid), dim3(256), lds, s, a, g);
 }
 template <int NP>
 static void launch_wino3s_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
@@ -1226,6 +1238,10 @@ static void launch_wino3w_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s)
     else if (a.bst) hipLaunchKernelGGL((conv_wino3w_kernel<0, 1, NP>), dim3(grid), dim3(512), lds, s, a, g);
     else hipLaunchKernelGGL((conv_wino3w_kernel<0, 0, NP>), dim3(grid), dim3(512), lds, s, a, g);
 }
+#ifndef MD2_WINO_CB2_DEFAULT
+#define MD2_WINO_CB2_DEFAULT 1
+#endif
+int g_wino_cb2 = MD2_WINO_CB2_DEFAULT;           // fp32-MFMA Winograd launches with Cout % 64 == 0: 32 tiles x 64 channels per workgroup (conv_wino3_kernel<., ., ., 1, 2>); 0: 32 x 32 (tools/conv_bench: CB1)
 int g_wino_wide = 0;          // 1 (md2_set_winograd(on + 8, .)): split launches with Cout % 64 == 0 take the 64-channel workgroup (conv_wino3w_kernel: faster alone, slower in the step -- DESIGN.md section 4); 0: the 32-channel one everywhere
 static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
     if (g_wino_wide && a.Cout % 64 == 0) { if (a.wino_pieces == 3) launch_wino3w_t<3>(a, g, s); else launch_wino3w_t<2>(a, g, s); }
@@ -1233,7 +1249,10 @@ static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
 }
 static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) {
     if (a.wino_pieces) launch_wino3s(a, g, s);
-    else if (nh == 1) launch_wino3_t<3, 1>(a, g, s); else launch_wino3_t<5, 2>(a, g, s);
+    // (two channel blocks per workgroup where that still leaves >= 2 rounds of the 512 resident workgroups: 0.155 -> 0.142 ms on the 64 -> 64 layers at batch 32, 0.167 -> 0.150 with the
+    //  BatchNorm transform in the loader; launches with fewer workgroups lose more to the emptier last round than the shared transform saves -- tools/run_wino_cb_bench.sh)
+    else if (nh == 1) { if (g_wino_cb2 && a.Cout % 64 == 0 && (long)g.ntp * (a.Cout / 64) >= 1024) launch_wino3_t<3, 1, 2>(a, g, s); else launch_wino3_t<3, 1>(a, g, s); }
+    else launch_wino3_t<5, 2>(a, g, s);
 }
 
 

@@ -170,7 +170,7 @@ def test_conv_product_modes_are_validated_and_round_trip_without_a_device():
 # VGPR: scratch traffic is HBM traffic the roofline does not see (round 4: loss_train_kernel<3,16> moved 4.8x its algorithmic bytes through a 224-byte segment).
 SCRATCH_ALLOWED = {
     # opt-in 64-tile Winograd workgroups of the five-row-segment shape (md2_set_winograd NH = 2, not a default route): 5 registers over the 256 budget
-    "conv_wino3_kernel<5, 0, 0, 2>", "conv_wino3_kernel<5, 0, 1, 2>",
+    "conv_wino3_kernel<5, 0, 0, 2, 1>", "conv_wino3_kernel<5, 0, 1, 2, 1>",
     # the opt-in REDUCED two-piece weight gradient on multi-row batches (md2_set_conv_products(., 2)): never in `value`
     "conv_wino_wgrad_s_kernel<1, 2, 1>",
 }
