@@ -514,26 +514,41 @@ __global__ __launch_bounds__(256, (NH == 1 && CB == 1) ? 3 : 2) void conv_wino3_
     const int n_rows_total = a.N * TH;
 
     // ---- loader: item f = tid + 256 li = (slot f >> 1, 16-B half f & 1); LDS position = slot * 8 + swizzled half, i.e. l_dst0 + li * 1024 floats
+    // (round 5) geometry once per SLOT: the two 16-byte halves of a slot share everything but their channel offset -- thread t works out slots t + 256 q, the table goes through
+    // the second pipeline stage's LDS (nobody writes it before the end of chunk 0, a barrier later), a thread picks up its NLI slots from there
     unsigned l_off[NLI]; unsigned l_ok = 0;
     const int h2 = tid & 1;
     const int l_dst0 = (tid >> 1) * 8 + ((h2 ^ ((tid >> 4) & 1)) << 2);
+    {
+        unsigned* tab = reinterpret_cast<unsigned*>(wsm) + PST;
+        constexpr int NSL = 128 * NLI;
 #pragma unroll
-    for (int li = 0; li < NLI; ++li) {
-        const int slot = (tid + 256 * li) >> 1;
-        int k, r, WP, txa, Lk;
-        if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
-        else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
-        const int pa = fdiv24(r, WP), pc = r - pa * WP;
-        const int rr = rr_first + k;
-        const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
-        const int rrc = act ? rr : 0;
-        const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
-        int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
-        bool ok = act;
-        if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
-        else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        l_ok |= ok ? (1u << li) : 0u;
-        l_off[li] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps) + (unsigned)(h2 * 4)) * 4u : (XF != 0 ? (unsigned)(h2 * 16) : W_OOB);
+        for (int q = 0; q < (NSL + 255) / 256; ++q) {
+            const int slot = tid + 256 * q;
+            if (slot < NSL) {
+                int k, r, WP, txa, Lk;
+                if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
+                else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }          // (rows are as wide as the segment: the last one is short)
+                const int pa = fdiv24(r, WP), pc = r - pa * WP;
+                const int rr = rr_first + k;
+                const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+                const int rrc = act ? rr : 0;
+                const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
+                int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+                bool ok = act;
+                if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+                else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                tab[slot] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps)) * 4u : 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            const unsigned v = tab[(tid >> 1) + 128 * li];
+            const bool ok = v != 0xFFFFFFFFu;
+            l_ok |= ok ? (1u << li) : 0u;
+            l_off[li] = ok ? v + (unsigned)(h2 * 16) : (XF != 0 ? (unsigned)(h2 * 16) : W_OOB);
+        }
     }
     const char* xb = reinterpret_cast<const char*>(a.x);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
@@ -609,8 +624,9 @@ __global__ __launch_bounds__(256, (NH == 1 && CB == 1) ? 3 : 2) void conv_wino3_
 #endif
     gload(0); lstore(0);
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int so = (c & 1) * PST;
+    // (round 5) the chunk loop is unrolled by two with the stage offset a compile-time constant: LDS read addresses are base registers + an immediate
+    auto chunk = [&](const int c, auto so_tag) {
+        constexpr int so = decltype(so_tag)::value;
         const int cn = min(c + 1, nchunks - 1);          // past the end: the last chunk again, into the stage nobody reads any more (keeps the loop body branch-free)
         const float* un = ub + (long)cn * 1024;
         if (!(abl & 1)) gload(cn);
@@ -655,6 +671,11 @@ __global__ __launch_bounds__(256, (NH == 1 && CB == 1) ? 3 : 2) void conv_wino3_
         __builtin_amdgcn_sched_barrier(0);
         if (!(abl & 1)) lstore(PST - so);
         if (!(abl & 8)) __syncthreads();
+    };
+    {
+        int c = 0;
+        for (; c + 1 < nchunks; c += 2) { chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, PST>{}); }
+        if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
     }
 
 #ifdef MD2_ABLATE
@@ -1296,12 +1317,41 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
 #pragma unroll
     for (int li = 0; li < 4; ++li) { const int t = (tid + 256 * li) >> 6; d_sg[li] = RB > 1 ? t / TW : 0; d_tx[li] = t - d_sg[li] * TW; }
     const int xq = tid & 7, dq = tid & 15;
+    // single-segment batches on zero-padded layers (every encoder layer; round 5): a batch's geometry is (image n, tile row ty, first tile tx0) -- block-uniform scalars that
+    // advance incrementally from batch to batch -- plus per-thread constants, so an item's address is one add and its validity three compares instead of ~25 vector
+    // instructions per item and two scalar integer divisions per batch
+    const bool fastgeo = !MR && a.padmode != PAD_REFLECT;
+    int x_c[5], x_dpa[5], x_dpc[5], d_c[4];
+#pragma unroll
+    for (int li = 0; li < 5; ++li) { x_dpa[li] = x_pa[li] - a.pad; x_dpc[li] = x_pc[li] - a.pad; x_c[li] = (x_dpa[li] * a.W + x_dpc[li]) * a.x_ps + ci0 + xq * 4; if (x_sg[li] != 0 || x_pa[li] >= 4) x_dpa[li] = -(1 << 20); }
+#pragma unroll
+    for (int li = 0; li < 4; ++li) { const int ps = (tid + 256 * li) >> 4; d_c[li] = (((ps >> 1) & 1) * a.Wo + 2 * (ps >> 2) + (ps & 1)) * a.dy_ps + co0 + dq * 4; }
     float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (XF != 0) { xsc = *reinterpret_cast<const float4*>(a.in_scale + ci0 + xq * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + ci0 + xq * 4); }
     uint4 rx[5], rd[4]; unsigned okx = 0, okd = 0;
     const char* xb = reinterpret_cast<const char*>(a.x);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, geo.dybytes, 0x00020000);
+    auto gload_fast = [&](int n_u, int ty_u, int bq) {              // (fastgeo) batch (image, tile row, 16-tile group of the row) -> registers (+ validity bits)
+        const int tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
+        okx = 0; okd = 0;
+        const int ih0 = 2 * ty_u, iw0 = 2 * tx0;
+        const unsigned ubx = (unsigned)((long)n_u * a.x_bs) + (unsigned)((ih0 * a.W + iw0) * a.x_ps), ubd = (unsigned)((long)n_u * a.dy_bs) + (unsigned)((ih0 * a.Wo + iw0) * a.dy_ps);
+#pragma unroll
+        for (int li = 0; li < 5; ++li) {
+            const bool ok = (unsigned)(ih0 + x_dpa[li]) < (unsigned)a.H && (unsigned)(iw0 + x_dpc[li]) < (unsigned)a.W && x_pc[li] < 2 * L + 2;
+            const unsigned off = ok ? (ubx + (unsigned)x_c[li]) * 4u : (XF != 0 ? (unsigned)(xq * 16) : W_OOB);
+            if constexpr (XF != 0) rx[li] = *reinterpret_cast<const uint4*>(xb + off); else rx[li] = wino_buffer_load16(xrs, off, 0);
+            okx |= ok ? (1u << li) : 0u;
+        }
+#pragma unroll
+        for (int li = 0; li < 4; ++li) {
+            const int ps = (tid + 256 * li) >> 4;
+            const bool ok = (ps >> 2) < L && ih0 + ((ps >> 1) & 1) < a.Ho && iw0 + 2 * (ps >> 2) + (ps & 1) < a.Wo;
+            rd[li] = wino_buffer_load16(drs, ok ? (ubd + (unsigned)d_c[li]) * 4u : W_OOB, 0);
+            okd |= ok ? (1u << li) : 0u;
+        }
+    };
     auto gload = [&](int b) {              // batch b -> registers (+ validity bits); b is block-uniform
         const int rr0 = RB > 1 ? b * RB : b / geo.BPR, bq = RB > 1 ? 0 : b - rr0 * geo.BPR;
         const int tx0 = bq * WG_TB, L = min(WG_TB, TW - tx0);
@@ -1371,14 +1421,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_kernel(WgradArgs a, Wi
     const bool do_bias = a.db && tile_ci == 0 && wi == 0;
 
     if (b_lo < b_hi) {
-        gload(b_lo); lstore(0);
+        // (fastgeo) geometry of the batch in flight: (image, tile row, 16-tile group), advanced by one batch per iteration; cq = the group of the batch being contracted
+        int gq = 0, gty = 0, gn = 0, cq = 0;
+        if (fastgeo) { const int rr0 = b_lo / geo.BPR; gq = b_lo - rr0 * geo.BPR; gn = rr0 / TH; gty = rr0 - gn * TH; cq = gq; gload_fast(gn, gty, gq); } else gload(b_lo);
+        lstore(0);
         __syncthreads();
         for (int b = b_lo; b < b_hi; ++b) {
             const int so = ((b - b_lo) & 1) * WG_STAGE;
             const int bn = min(b + 1, b_hi - 1);
-            gload(bn);
+            if (fastgeo) {
+                cq = gq;
+                if (b + 1 < b_hi) { if (++gq == geo.BPR) { gq = 0; if (++gty == TH) { gty = 0; ++gn; } } }          // (past the end: the last batch again, into the stage nobody reads)
+                gload_fast(gn, gty, gq);
+            } else gload(bn);
             __builtin_amdgcn_sched_barrier(0);
-            const int bq = RB > 1 ? 0 : b % geo.BPR, L = min(WG_TB, TW - bq * WG_TB);
+            const int bq = RB > 1 ? 0 : (fastgeo ? cq : b % geo.BPR), L = min(WG_TB, TW - bq * WG_TB);
             const int ntile = RB > 1 ? min(RB, geo.nrows - b * RB) * TW : L, nk = (ntile + 1) >> 1;
             auto kstep = [&](const int k) {
                 const int t = 2 * k + lh, seg = RB > 1 ? (t >= TW ? fdiv24(t, TW) : 0) : 0;          // this lane's tile of the k-step (tiles past the batch were committed as zeros)
