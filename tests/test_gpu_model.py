@@ -938,7 +938,8 @@ TIGHT_CASES = [(1, 1, 64, 96, 101, False), (2, 1, 64, 96, 104, False), (2, 3, 64
 # (name, md2_set_winograd arguments, md2_set_conv_products arguments).  "timed": the configuration bench.py's `value` is measured in.  "winograd forced": the shapes a CPU
 # oracle can afford sit below the workgroup-count threshold of the automatic choice, so the Winograd forward / input-gradient / weight-gradient kernels -- 7.8 of the
 # step's 9.9 ms of convolution time at batch 32 -- are pinned on every layer that qualifies, with the products of the timed configuration and with the other full-accuracy choice.
-TIGHT_ROUTES = [("timed", (1, -2), None), ("winograd forced", (3, 1), None), ("winograd forced, fp32 MFMA products", (3, 1), (0, 0)), ("winograd forced, exact-split products", (3, 1), (3, 3))]
+TIGHT_ROUTES = [("timed", (1, -2), None), ("winograd forced", (3, 1), None), ("winograd forced, fp32 MFMA products", (3, 1), (0, 0)), ("winograd forced, exact-split products", (3, 1), (3, 3)),
+                ("winograd forced, exact-split products, 64-channel workgroups", (11, 1), (3, 3))]          # (the opt-in conv_wino3w_kernel of round 5: md2_set_winograd(3 + 8, .))
 
 
 _TIGHT_ORACLE = {}
@@ -992,7 +993,7 @@ def test_gradient_parity_tight_on_kink_free_seeds(case, route):
         assert abs(loss_d - lo) / lo < 1e-4
         assert_grads_match(gd, go, C, cos_min=0.9999, rel_max=4e-3, tag="tight default %s %s" % (case, route[0]))
         assert_grads_match(gd, gh, C, tag="default vs deterministic %s %s" % (case, route[0]))
-        if wino[0] == 3 and (H, W) == (96, 160):          # the forced routes really run the Winograd kernels (and the split ones when asked to)
+        if wino[0] in (3, 11) and (H, W) == (96, 160):          # the forced routes really run the Winograd kernels (and the split ones when asked to)
             def factory():
                 model, params, cache, theta2, _, _ = make(N, C, H, W, automask=automask, pseed=sd)
                 xd = dev(x)

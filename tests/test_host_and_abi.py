@@ -194,3 +194,24 @@ def test_no_kernel_uses_scratch():
             if not allowed:
                 bad.append("%s: %d B scratch, %d spilled VGPRs" % (name, r["private_segment_fixed_size"], r["vgpr_spill_count"]))
     assert not bad, "kernels with a private segment: " + "; ".join(bad)
+
+
+def test_bench_convolution_class_accounting(tmp_path):
+    """bench.py prices the forward + input-gradient convolution class from the library's per-launch profile records (md2_profile_dump): algorithmic bytes (inputs + weights +
+    epilogue operands + outputs, once each) and the matrix-pipe floor of the instructions each launch EXECUTES (fp32 MFMA 157.3 TFLOP/s; exact split: six bf16 MFMAs per product
+    group at 2.5 PFLOP/s; Winograd: 16/36 of the direct count).  Host logic on a hand-made dump: no GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("md2_bench", os.path.join(ROOT, "bench.py")); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    M, co, ci = 1000, 64, 128
+    rows = ["cls,ms,gflop,tflops,desc",
+            "0,0.1,8.0,80,stem fwd 7x7 s2 (direct)",
+            "0,0.1,%g,100,igemm M=%d Cout=%d Cin=%d k=3 s=1 dil=1 pm=0 HxW=10x100 ep=1 alg=winograd_split prod=split3" % (2e-9 * M * co * 9 * ci, M, co, ci),
+            "0,0.1,%g,100,igemm M=%d Cout=%d Cin=%d k=1 s=2 dil=1 pm=0 HxW=20x200 ep=0 alg=direct prod=fp32" % (2e-9 * M * co * ci, M, co, ci),
+            "1,0.2,5.0,25,wgrad M=1000 Cout=64 Cin=128 k=3 s=1 pm=0 alg=winograd pieces=0"]
+    pth = tmp_path / "dump.csv"; pth.write_text("\n".join(rows) + "\n")
+    acct = b.conv_class_accounting(str(pth), 4, 1)
+    by = 4.0 * ((M * ci + M * co * 2 + 9 * ci * co) + (M * 4 * ci + M * co + ci * co))
+    assert abs(acct["algorithmic_bytes_per_step"] - by) < 1e-6 * by
+    floor_s = 8.0e9 / 157.3e12 + (2.0 * M * co * 9 * ci) * (16.0 / 36.0) * 6.0 / 2500e12 + (2.0 * M * co * ci) / 157.3e12
+    assert abs(acct["floor_ms"] - floor_s * 1e3) < 1e-6 * floor_s * 1e3
+    assert acct["launches_by_product_form"] == {"fp32": 2.0, "split3": 1.0}
