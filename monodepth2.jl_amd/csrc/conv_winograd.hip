@@ -758,6 +758,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
     const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, WT), S = 4 * (2 * Lf + 2);
     const int n_rows_total = a.N * TH;
 
+    // U stream of this wave: chunk c16, position j: piece q at ub + ((c16 * 4 + j) * NP + q) * 512 bf16 (64 lanes x 8).  The first chunk's fragments are requested before
+    // anything else (round 5): they depend on the workgroup id alone, and behind the barrier of the loader's geometry table their latency was the head of every workgroup's life
+    const int nchunks = a.Cin >> 4;
+    const __bf16* ub = reinterpret_cast<const __bf16*>(a.wino_u) + ((long)(tile_c * 4 + wi) * nchunks) * 4 * NP * 512 + lane * 8;
+    wbf16x8 u[4][NP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) u[j][q] = *reinterpret_cast<const wbf16x8*>(ub + (j * NP + q) * 512);
+
     // ---- loader: item f = tid + 256 li = (slot f >> 2, 16-B piece f & 3 of the 16 channels); piece >> 1 = plane, piece & 1 = half inside the plane's 8-float slot
     // Geometry once per SLOT (round 5): the four 16-byte pieces of a slot share everything but their channel offset, so thread t works out the byte offset of slots t and
     // t + 256 (or the "nothing to load" marker), the table goes through the second pipeline stage's LDS (nobody writes it before the end of chunk 0, a barrier later) and a thread
@@ -844,15 +854,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-
-    // U stream of this wave: chunk c16, position j: piece q at ub + ((c16 * 4 + j) * NP + q) * 512 bf16 (64 lanes x 8)
-    const int nchunks = a.Cin >> 4;
-    const __bf16* ub = reinterpret_cast<const __bf16*>(a.wino_u) + ((long)(tile_c * 4 + wi) * nchunks) * 4 * NP * 512 + lane * 8;
-    wbf16x8 u[4][NP];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) u[j][q] = *reinterpret_cast<const wbf16x8*>(ub + (j * NP + q) * 512);
 
     gload(0); lstore(0);
     __syncthreads();
