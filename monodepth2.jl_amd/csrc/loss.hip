@@ -714,7 +714,7 @@ void launch_loss_train(const LossArgs& a, double* part, float* const dd[MD2_MAX_
     LossTrainOut o; o.part = part; o.dRt_acc = dRt_acc; o.blk = blk;
     for (int i = 0; i < MD2_MAX_SCALES; ++i) { o.dd[i] = dd[i]; o.dlo[i] = dlo[i]; }
     static const int tpb_env = md2_tune("MD2_LOSS_TPB", 0);
-    const int ntx = (a.W + TW - 1) / TW, tpb = tpb_env > 0 ? tpb_env : 2;
+    const int ntx = (a.W + TW - 1) / TW, tpb = tpb_env > 0 ? tpb_env : (a.C == 1 ? 2 : 4);          // (tools/run_loss_tpb.sh, round 5: C = 1 0.433 / 0.427 / 0.429 / 0.489 ms for 1 / 2 / 3 / 4 tiles per workgroup at batch 32; C = 3 at 1024x320, batch 8: 1.231 / 1.203 / 1.210 / 1.183)
     const int th = a.C == 1 ? 32 : 16;
     dim3 grid((ntx + tpb - 1) / tpb, (a.H + th - 1) / th, a.N * a.nscales);
     if (a.C == 1) hipLaunchKernelGGL((loss_train_kernel<1, 32>), grid, dim3(256), 0, s, a, o, tpb, ntx);
