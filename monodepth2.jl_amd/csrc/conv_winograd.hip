@@ -744,6 +744,13 @@ __device__ __forceinline__ void split3_pk(float a, float b, unsigned& hi, unsign
 template <int XF, int BST, int NP>
 __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Geo geo) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
+#ifdef MD2_ABLATE
+#define W3S_STAMP(k_) do { if (a.dbg && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+    W3S_STAMP(0);
+    if (a.dbg && (threadIdx.x & 63) == 0) a.dbg[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+#else
+#define W3S_STAMP(k_) do { } while (0)
+#endif
     constexpr int COB = 32, WT = 32, NLI = 6;
     constexpr int PL = 128 * 3 * 8;                  // floats per 8-channel plane (384 slots), two planes per stage
     constexpr int PST = 2 * PL;
@@ -797,6 +804,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
             }
         }
         __syncthreads();
+        W3S_STAMP(1);
 #pragma unroll
         for (int li = 0; li < NLI; ++li) {
             const unsigned v = tab[(tid >> 2) + 64 * li];
@@ -857,6 +865,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
 
     gload(0); lstore(0);
     __syncthreads();
+    W3S_STAMP(2);
     // the chunk loop is unrolled by two with the stage offset a compile-time constant (round 5): the 16 LDS read addresses of a chunk are then base registers + an immediate
     // instead of 16 v_lshl_add per chunk
     auto chunk = [&](const int c, auto so_tag) {
@@ -912,6 +921,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
         for (; c + 1 < nchunks; c += 2) { chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, PST>{}); }
         if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
     }
+    W3S_STAMP(3);
 
     // ---- output transform: column half in registers, row half through LDS (R[i][b][32 tiles][COB + 4]) -- as conv_wino3_kernel
     constexpr int RLD = COB + 4;
@@ -928,8 +938,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
         *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * WT + tl) * RLD + col) = o1;
     }
     __syncthreads();
+    W3S_STAMP(4);
     wino_final_epilogue<256, COB, BST>(a, wsm, m0, WT, Mt, THW, TW, c0, tid);
+    W3S_STAMP(5);
 }
+#undef W3S_STAMP
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The split kernel with 64 output channels per workgroup (round 5).  conv_wino3s_kernel redoes the input transform and the three-piece split of the same V in every one of

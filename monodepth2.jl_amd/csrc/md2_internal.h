@@ -171,6 +171,7 @@ struct ConvArgs {
     int wino_pieces;              // layout wino_u was written in: 0 = fp32 fragments, 2 / 3 = bf16 pieces per operand (split kernels); set by whoever refreshed U
 #ifdef MD2_ABLATE
     int ablate, force_tile;       // tools/conv_bench only
+    unsigned long long* dbg;      // tools/conv_bench only: per-wave s_memtime stamps of conv_wino3s_kernel ([workgroup][wave][8]: 7 stamps + the hardware id), abl bit 512
 #endif
 };
 void launch_conv_igemm(const ConvArgs& a, hipStream_t s);

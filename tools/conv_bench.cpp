@@ -52,6 +52,37 @@ int main(int argc, char** argv) {
             float ms; hipEventElapsedTime(&ms, e0, e1); printf("wino weight transform %dx%d: %.1f us\n", Cout, Cin, ms / 20 * 1e3);
         }
     }
+#ifdef MD2_ABLATE
+    if (getenv("STAMPS") && a.wino_pieces) {          // per-wave s_memtime stamps of one launch of conv_wino3s_kernel: where a workgroup's life goes, and what runs beside it on its CU
+        for (int i = 0; i < 3; ++i) launch_conv_igemm(a, 0);
+        const int tiles = N * ((H + 1) / 2) * ((W + 1) / 2), nwg = ((tiles + 31) / 32) * (Cout / 32);
+        unsigned long long* dbg; hipMalloc(&dbg, (size_t)nwg * 4 * 8 * 8); hipMemset(dbg, 0, (size_t)nwg * 4 * 8 * 8);
+        a.dbg = dbg; launch_conv_igemm(a, 0); hipDeviceSynchronize(); a.dbg = nullptr;
+        std::vector<unsigned long long> h((size_t)nwg * 32); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0; for (int g = 0; g < nwg; ++g) { t0 = std::min(t0, h[(size_t)g * 32]); t1 = std::max(t1, h[(size_t)g * 32 + 5]); }
+        double ph[5] = {0, 0, 0, 0, 0}, life = 0;          // wave 0 of every workgroup: entry -> table barrier -> loop entry -> loop exit -> transform barrier -> end
+        for (int g = 0; g < nwg; ++g) { const unsigned long long* w = &h[(size_t)g * 32]; for (int k = 0; k < 5; ++k) ph[k] += (double)(w[k + 1] - w[k]); life += (double)(w[5] - w[0]); }
+        printf("stamps: %d workgroups, launch span %llu ticks; per workgroup (wave 0): geometry %.0f, first loads + commit %.0f, chunk loop %.0f (%d chunks: %.0f each), output transform %.0f, epilogue %.0f, life %.0f ticks\n",
+               nwg, t1 - t0, ph[0] / nwg, ph[1] / nwg, ph[2] / nwg, Cin / 16, ph[2] / nwg / (Cin / 16), ph[3] / nwg, ph[4] / nwg, life / nwg);
+        // per CU (xcc, se, sh, cu from the hardware id): workgroups in order of entry, the gap between one's end and the next's entry on the same SIMD-0 slot
+        struct Ev { unsigned long long a, b; int slot; };
+        std::vector<std::vector<Ev>> cu(16 * 8 * 2 * 16);
+        for (int g = 0; g < nwg; ++g) {
+            const unsigned long long id = h[(size_t)g * 32 + 7]; const unsigned hw = (unsigned)id, xcc = (unsigned)(id >> 32) & 15;
+            const int cuid = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7, wave = hw & 15;
+            cu[((xcc * 8 + se) * 2 + sh) * 16 + cuid].push_back({h[(size_t)g * 32], h[(size_t)g * 32 + 5], wave});
+        }
+        double busy2 = 0, busy1 = 0, busy0 = 0; int ncu = 0;
+        for (auto& v : cu) if (!v.empty()) {
+            ++ncu; std::vector<std::pair<unsigned long long, int>> ev; for (auto& e : v) { ev.push_back({e.a, +1}); ev.push_back({e.b, -1}); }
+            std::sort(ev.begin(), ev.end()); int lvl = 0; unsigned long long last = t0;
+            for (auto& e : ev) { const double d = (double)(e.first - last); if (lvl >= 2) busy2 += d; else if (lvl == 1) busy1 += d; else busy0 += d; lvl += e.second; last = e.first; }
+            busy0 += (double)(t1 - last);
+        }
+        printf("stamps: %d CUs seen; share of the launch span with >= 2 / 1 / 0 workgroups resident per group: %.3f / %.3f / %.3f\n", ncu, busy2 / ((double)(t1 - t0) * ncu), busy1 / ((double)(t1 - t0) * ncu), busy0 / ((double)(t1 - t0) * ncu));
+        return 0;
+    }
+#endif
     for (int i = 0; i < 3; ++i) launch_conv_igemm(a, 0);
     hipEventRecord(e0); const int reps = 20; for (int i = 0; i < reps; ++i) launch_conv_igemm(a, 0); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
