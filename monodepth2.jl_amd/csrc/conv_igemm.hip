@@ -137,12 +137,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // padded to a 48-B stride that keeps 16 consecutive rows' 16-B reads on distinct banks
     // DL (direct load): global_load_lds writes a wave's 64 x 16 B linearly, so the rows are 16 floats without padding and the bank spread comes from an XOR swizzle of the
     // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
-    constexpr bool DL = MD2_GLDS != 0 && XF == 0 && BF == 0 && BN == 64;
+    constexpr bool DL = XF == 0 && BN == 64 && ((MD2_GLDS != 0 && BF == 0) || BF == 4);          // BF == 4: bf16 tensors with the direct-to-LDS loader (Cin % 32 == 0, no input transform)
     // BF == 2 (bf16 activation storage): x, w (and y, res, dact_src, bz) hold bf16 elements.  A K-step is still 64 BYTES per pixel row -- 32 channels -- so the loader, the masks
     // and the LDS layout below are byte-for-byte those of the fp32 kernel (4 lanes x 16 B per row, 80-B row stride); a lane's 16-B operand read is 8 consecutive channels, which is
     // what v_mfma_f32_32x32x16_bf16 (2 per tile pair and step) / v_mfma_f32_16x16x32_bf16 (1) take.  Cin == 16 (the full-resolution decoder layers): a step's row is TWO filter
     // taps x 16 channels (`pair`; 9 taps -> 5 steps, the tenth half masked), the weights [Cout][9][16] being contiguous per output channel.
-    constexpr bool BS = BF == 2;
+    constexpr bool BS = BF == 2 || BF == 4;
     constexpr unsigned ESZ = BS ? 2u : 4u;                     // bytes per element
     constexpr bool BUFL = MD2_IGEMM_BUFLOAD != 0 && XF == 0 && !DL;
     constexpr unsigned A_OOB = 0xFFFFFFF0u;                    // offset of a masked item: beyond any tensor's byte span (check_igemm_args keeps spans below 2^32 - 32)
@@ -224,7 +224,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
             else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
             a_mbits[j] |= ok ? (1u << t) : 0u;
-            if constexpr (BUFL) a_off[t][j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : A_OOB;          // (the chunk offset travels in the scalar offset, outside the range check)
+            if constexpr (BUFL || BF == 4) a_off[t][j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : A_OOB;          // (the chunk offset travels in the scalar offset, outside the range check)
             else a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address (DL: g_zero_row instead)
         }
         b_tap[t] = pair ? (unsigned)(t * 64) : (unsigned)((kh * a.KW + kw) * a.Cin) * ESZ + (unsigned)(c_lo * 64);
@@ -254,8 +254,17 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // DL: one global_load_lds_dwordx4 per operand row slot; LDS destination = wave-uniform base + lane * 16 B = row (16 * wave + lane / 4 + 64 j), chunk lane % 4
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, A_OOB - 16u, 0x00020000);
     auto gload_dl = [&](int t, int ci0, int so) {
-        if constexpr (DL) {
+        if constexpr (BF == 4) {
+            // buffer_load_dwordx4 ... lds: 32-bit offsets against two resources; a padding tap's offset is the out-of-range sentinel and the hardware writes zeros for it
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem + so + (wave * 16 + 64 * j) * 16), 16, (int)a_off[t][j], c_lo * 64 + ci0 * 4, 0, 0);
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(smem + so + XS + (wave * 16 + 64 * j) * 16), 16, (int)b_row[j], (int)b_tap[t] + ci0 * 4, 0, 0);
+        } else if constexpr (DL) {
             const char* zero = reinterpret_cast<const char*>(g_zero_row) + q * 16;
 #pragma unroll
             for (int j = 0; j < A_LD; ++j) {
@@ -753,7 +762,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 
 // three pipeline stages of (pixel tile + weight tile) rows; the one-tap launches reuse it for their transposed output tile [BM][BN + 4] (or [3][4][256] column sums)
 constexpr int igemm_smem_floats(int BM, int BN, int BF) {
-    const int pipe = 3 * (BM + BN) * (BF == 1 ? 12 : LDK), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
+    const int pipe = 3 * (BM + BN) * (BF == 1 ? 12 : (BF == 4 ? 16 : LDK)), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
     return pipe > tile ? pipe : tile;
 }
 // (the 128x64 tile runs 3 blocks per CU -- its 46 KB of LDS allow no more -- which needs <= 168 registers incl. the 32 accumulators: the variants with the input
@@ -870,10 +879,13 @@ static void bst_fallback(const ConvArgs& a, hipStream_t s) {
     if (a.bstB) { View zb = g; zb.p = const_cast<float*>(a.bzB); zb.bs = a.bzB_bs; zb.ps = a.bzB_ps; launch_bn_bwd_reduce(g, nullptr, ACT_NONE, zb, a.bstatB, a.bstB, s); }
 }
 
+static bool bs_direct_lds() { static const bool on = md2_tune("MD2_BS_DL", 1) != 0; return on; }
 // operand / storage form of a launch: ConvArgs::bf16 = 0 fp32 MFMA, 1 bf16 operands from fp32 tensors (32-wide tiles only), 2 bf16 tensors
 template <int BM, int BN, int WP, int WC, int MF, int NT, int XF = 0, int BST = 0>
 static void launch_igemm_form(const ConvArgs& a, const dim3& g, hipStream_t s) {
-    if (a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 2, XF, BST>), g, dim3(256), 0, s, a);
+    // bf16 tensors: the direct-to-LDS loader wherever it applies (whole 64-byte channel chunks, no input transform)
+    if (a.bf16 == 2 && bs_direct_lds() && XF == 0 && BN == 64 && MF == 32 && a.Cin % 32 == 0) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (XF == 0 && BN == 64 && MF == 32 ? 4 : 2), XF, BST>), g, dim3(256), 0, s, a);
+    else if (a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 2, XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 0 && a.split3 && MF == 32 && BN == 64 && WP == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 && BN == 64 && WP == 2 ? 3 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 1 && MF == 32) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 ? 1 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 0, XF, BST>), g, dim3(256), 0, s, a);
@@ -1116,13 +1128,15 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
     k.first[0] = 0;
     for (int i = 0; i < 4; ++i) k.first[i + 1] = k.first[i] + (i < n ? ((k.c[i].M + BM - 1) / BM) * (k.c[i].Cout / 64) : 0);
     for (int i = n; i < 4; ++i) k.c[i] = k.c[0];
-    const bool sp3 = k.c[0].bf16 == 0 && k.c[0].split3;
+    const bool sp3 = k.c[0].bf16 == 0 && k.c[0].split3, dl = k.c[0].bf16 == 2 && bs_direct_lds() && k.c[0].Cin % 32 == 0;
     if (k.c[0].bst) {
         if (sp3) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 3, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+        else if (k.c[0].bf16 == 2 && dl) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 4, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 0, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
     } else if (sp3) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 3>), dim3(k.first[4]), dim3(256), 0, s, k);
+    else if (k.c[0].bf16 == 2 && dl) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 4>), dim3(k.first[4]), dim3(256), 0, s, k);
     else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2>), dim3(k.first[4]), dim3(256), 0, s, k);
     else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
     else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32>), dim3(k.first[4]), dim3(256), 0, s, k);
@@ -1131,7 +1145,9 @@ static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
     long tiles128 = 0;
     for (int i = 0; i < n; ++i) { check_igemm_args(k.c[i]); tiles128 += (k.c[i].M + 127) / 128; }
     static const long big = md2_tune("MD2_IGEMM_BIG_TILES", (1L << 40));          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
-    if (tiles128 * (k.c[0].Cout / 64) >= big) launch_classes_t<128>(k, n, s); else launch_classes_t<64>(k, n, s);
+    static const long bs_big = md2_tune("MD2_BS_BIG_TILES", 256);
+    const bool bs128 = k.c[0].bf16 == 2 && bs_direct_lds() && k.c[0].Cin % 32 == 0 && tiles128 * (k.c[0].Cout / 64) >= bs_big;
+    if (bs128 || tiles128 * (k.c[0].Cout / 64) >= big) launch_classes_t<128>(k, n, s); else launch_classes_t<64>(k, n, s);
 }
 
 // Input-gradient of a strided convolution (dil = forward stride): an output pixel of residue class (ph,pw) mod dil only
@@ -1242,7 +1258,10 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     // 64x64 tiles (5 blocks per CU) balance the 256 CUs better than 128x64 (3 per CU) on every encoder layer at batch 32 (624 .. 2496 tiles: 1.6 .. 3.25 rounds of 768
     // resident 128x64 blocks) and are never slower there (tools/conv_bench, round 2: 87.8 / 92.5 / 93.5 / 81.2 vs 87.2 / 91.4 / 85.2 / 65.1 TFLOP/s on the four stage shapes)
     static const long big = md2_tune("MD2_IGEMM_BIG_TILES", (1L << 40));          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
-    if (a.Cout % 64 == 0) { if (tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
+    // bf16 tensors with the direct-to-LDS loader (no staging registers, loads three steps ahead): 128 x 64 is ahead from about one tile per CU on (round 5, tools/run_bs_igemm_bench.sh)
+    static const long bs_big = md2_tune("MD2_BS_BIG_TILES", 256);
+    const bool bs128 = a.bf16 == 2 && bs_direct_lds() && !a.in_scale && a.Cin % 32 == 0 && tiles128 * (a.Cout / 64) * a.ksplit >= bs_big;
+    if (a.Cout % 64 == 0) { if (bs128 || tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
     if (a.ksplit > 1 && a.ws) launch_splitk_reduce(a, bias2, act2, acc2, ws_stats, a.ostep == 1, s);      // (also the BatchNorm-pullback sums of the now final gradient)
