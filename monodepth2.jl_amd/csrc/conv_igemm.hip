@@ -137,7 +137,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // padded to a 48-B stride that keeps 16 consecutive rows' 16-B reads on distinct banks
     // DL (direct load): global_load_lds writes a wave's 64 x 16 B linearly, so the rows are 16 floats without padding and the bank spread comes from an XOR swizzle of the
     // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
-    constexpr bool DL = XF == 0 && BN == 64 && ((MD2_GLDS != 0 && BF == 0) || BF == 4);          // BF == 4: bf16 tensors with the direct-to-LDS loader (Cin % 32 == 0, no input transform)
+    constexpr bool DL = XF == 0 && BN == 64 && ((MD2_GLDS != 0 && BF == 0) || BF == 4);          // BF == 4: bf16 tensors with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
+    constexpr bool BLDS = BF == 4;                             // ... through buffer_load_dwordx4 ... lds
     // BF == 2 (bf16 activation storage): x, w (and y, res, dact_src, bz) hold bf16 elements.  A K-step is still 64 BYTES per pixel row -- 32 channels -- so the loader, the masks
     // and the LDS layout below are byte-for-byte those of the fp32 kernel (4 lanes x 16 B per row, 80-B row stride); a lane's 16-B operand read is 8 consecutive channels, which is
     // what v_mfma_f32_32x32x16_bf16 (2 per tile pair and step) / v_mfma_f32_16x16x32_bf16 (1) take.  Cin == 16 (the full-resolution decoder layers): a step's row is TWO filter
@@ -224,7 +225,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
             if (a.padmode == PAD_REFLECT) { th = refl_idx(th, a.H); tw = refl_idx(tw, a.W); }
             else ok = ok && th >= 0 && th < a.H && tw >= 0 && tw < a.W;
             a_mbits[j] |= ok ? (1u << t) : 0u;
-            if constexpr (BUFL || BF == 4) a_off[t][j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : A_OOB;          // (the chunk offset travels in the scalar offset, outside the range check)
+            if constexpr (BUFL || BLDS) a_off[t][j] = ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : A_OOB;          // (the chunk offset travels in the scalar offset, outside the range check)
             else a_off[t][j] = (ok ? a_base[j] + (unsigned)((th * a.W + tw) * a.x_ps) * ESZ : (unsigned)(q * 16)) + (unsigned)(c_lo * 64);    // masked rows read a valid dummy address (DL: g_zero_row instead)
         }
         b_tap[t] = pair ? (unsigned)(t * 64) : (unsigned)((kh * a.KW + kw) * a.Cin) * ESZ + (unsigned)(c_lo * 64);
@@ -256,7 +257,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, A_OOB - 16u, 0x00020000);
     auto gload_dl = [&](int t, int ci0, int so) {
-        if constexpr (BF == 4) {
+        if constexpr (BLDS) {
             // buffer_load_dwordx4 ... lds: 32-bit offsets against two resources; a padding tap's offset is the out-of-range sentinel and the hardware writes zeros for it
 #pragma unroll
             for (int j = 0; j < A_LD; ++j)
@@ -565,6 +566,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         }
     }
 
+    // direct-to-LDS loads: the clamped re-loads of the last steps may still be in flight, and the epilogue re-uses the stages (transposed tile, column sums) -- a __syncthreads()
+    // does not wait for them (it orders LDS instructions, not the vector-memory counter these writes into LDS are tracked by)
+    if constexpr (DL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef MD2_ABLATE
     if (abl & 16) { if (acc[0][0][0] == 123.456f) a.y[0] = 1.f; return; }      // skip the epilogue stores
 #endif
@@ -1258,7 +1262,7 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     // 64x64 tiles (5 blocks per CU) balance the 256 CUs better than 128x64 (3 per CU) on every encoder layer at batch 32 (624 .. 2496 tiles: 1.6 .. 3.25 rounds of 768
     // resident 128x64 blocks) and are never slower there (tools/conv_bench, round 2: 87.8 / 92.5 / 93.5 / 81.2 vs 87.2 / 91.4 / 85.2 / 65.1 TFLOP/s on the four stage shapes)
     static const long big = md2_tune("MD2_IGEMM_BIG_TILES", (1L << 40));          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
-    // bf16 tensors with the direct-to-LDS loader (no staging registers, loads three steps ahead): 128 x 64 is ahead from about one tile per CU on (round 5, tools/run_bs_igemm_bench.sh)
+    // bf16 tensors with the direct-to-LDS loader (no staging registers, loads three steps ahead): 128 x 64 tiles are ahead from about one tile per CU on (round 5, tools/run_bs_igemm_bench.sh)
     static const long bs_big = md2_tune("MD2_BS_BIG_TILES", 256);
     const bool bs128 = a.bf16 == 2 && bs_direct_lds() && !a.in_scale && a.Cin % 32 == 0 && tiles128 * (a.Cout / 64) * a.ksplit >= bs_big;
     if (a.Cout % 64 == 0) { if (bs128 || tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
