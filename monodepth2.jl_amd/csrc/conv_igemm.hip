@@ -961,7 +961,7 @@ double conv_igemm_flops(const ConvArgs& a) {       // algorithmic: taps that can
 // ------------------------------------------------------------------------------------------------------------
 constexpr int PT_H = 8, PT_W = 32, PP_W = PT_W + 2, PP_N = (PT_H + 2) * PP_W;     // patch: 10 x 34 = 340 pixels
 
-template <int COUT>       // 16 or 32
+template <int COUT, bool BS = false>       // COUT: 16 or 32; BS: bf16 tensors (x, w, y, dact_src), widened to fp32 on their way into the (unchanged) LDS tiles -- products of bf16 values are exact in fp32
 __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tiles_x, int tiles_y, int total_tiles) {
     constexpr int TC = COUT / 16;
     extern __shared__ __attribute__((aligned(16))) float psm[];
@@ -988,8 +988,11 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
     constexpr int NPL = (PP_N * 4 + 255) / 256, NWL = (COUT * 9 * 4 + 255) / 256;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned poff[NPL], okbits = 0, okbits_next = 0;                 // bit i: load slot i is inside the image (zero padding)
-    u32x4 pv[NPL]; f32x4 wv[NWL];
-    const float* xin = a.x;
+    using ld_t = typename std::conditional<BS, uint2, u32x4>::type;          // 4 channels of one pixel / weight row as loaded: 8 bytes of bf16 or 16 of fp32
+    ld_t pv[NPL], wv[NWL];
+    auto widen = [](const ld_t& v) { if constexpr (BS) { const float4 f = bf16x4_unpack(v); return (u32x4){__float_as_uint(f.x), __float_as_uint(f.y), __float_as_uint(f.z), __float_as_uint(f.w)}; } else return v; };
+    constexpr int ESH = BS ? 1 : 2;                                 // log2(bytes per element)
+    const char* xin = reinterpret_cast<const char*>(a.x);
     const int nchunks = a.Cin >> 4;
     const bool wonce = nchunks == 1;                                 // one chunk: the weights are the same for every tile, load them once
     const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1001,13 +1004,13 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 const int f = tid + i * 256;
-                if (f < PP_N * 4) *reinterpret_cast<u32x4*>(Ps + (f >> 2) * LDK + (f & 3) * 4) = pv[i] & (0u - ((okbits >> i) & 1u));
+                if (f < PP_N * 4) *reinterpret_cast<u32x4*>(Ps + (f >> 2) * LDK + (f & 3) * 4) = widen(pv[i]) & (0u - ((okbits >> i) & 1u));
             }
             if (!wonce || s == 0) {
 #pragma unroll
                 for (int i = 0; i < NWL; ++i) {
                     const int f = tid + i * 256;
-                    if (f < COUT * 9 * 4) *reinterpret_cast<f32x4*>(Ws + (f >> 2) * LDK + (f & 3) * 4) = wv[i];
+                    if (f < COUT * 9 * 4) *reinterpret_cast<u32x4*>(Ws + (f >> 2) * LDK + (f & 3) * 4) = widen(wv[i]);
                 }
             }
             __syncthreads();
@@ -1018,7 +1021,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
             if (c1 == 0) {                                           // first chunk of a new tile: its patch addresses
                 const int tile = blockIdx.x + k1 * gridDim.x;
                 const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-                xin = a.x + (long)n * a.x_bs;
+                xin = reinterpret_cast<const char*>(a.x) + (((long)n * a.x_bs) << ESH);
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) {
                     const int f = tid + i * 256, pp = min(f >> 2, PP_N - 1), q = f & 3, pr = pp / PP_W, pc = pp - pr * PP_W;
@@ -1031,12 +1034,12 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) pv[i] = *reinterpret_cast<const u32x4*>(xin + poff[i] + c1 * 16);
+            for (int i = 0; i < NPL; ++i) pv[i] = *reinterpret_cast<const ld_t*>(xin + ((size_t)(poff[i] + c1 * 16) << ESH));
             if (!wonce || s1 == 0) {
 #pragma unroll
                 for (int i = 0; i < NWL; ++i) {
                     const int f = min(tid + i * 256, COUT * 9 * 4 - 1), row = f >> 2, q = f & 3;    // row = co*9 + tap ; global: w[co][tap][Cin]
-                    wv[i] = *reinterpret_cast<const f32x4*>(a.w + (long)row * a.Cin + c1 * 16 + q * 4);
+                    wv[i] = *reinterpret_cast<const ld_t*>(reinterpret_cast<const char*>(a.w) + (((long)row * a.Cin + c1 * 16 + q * 4) << ESH));
                 }
             }
         }
@@ -1067,8 +1070,8 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
             const int oy = ty * PT_H + 2 * wave + (j >> 1), ox = tx * PT_W + 16 * (j & 1) + lrow;
             if (oy < a.Ho && ox < a.Wo) {
                 const long pix = (long)oy * a.Wo + ox;
-                float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps;
-                const float* dp = a.dact_src ? a.dact_src + (long)n * a.da_bs + pix * a.da_ps : nullptr;
+                const long yo = (long)n * a.y_bs + pix * a.y_ps, dpo = (long)n * a.da_bs + pix * a.da_ps;          // element offsets (vld4 / vst4)
+                const bool dp = a.dact_src != nullptr;
 #pragma unroll
                 for (int i = 0; i < TC; ++i) {
                     const int co = i * 16 + lk4;
@@ -1078,9 +1081,9 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
                     }
-                    if (dp) { const float4 d = *reinterpret_cast<const float4*>(dp + co); v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
-                    if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame)) { const float4 o = *reinterpret_cast<const float4*>(yp + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-                    *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (dp) { const float4 d = vld4<BS>(a.dact_src, dpo + co); v[0] *= act_deriv(d.x, a.dact); v[1] *= act_deriv(d.y, a.dact); v[2] *= act_deriv(d.z, a.dact); v[3] *= act_deriv(d.w, a.dact); }
+                    if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame)) { const float4 o = vld4<BS>(a.y, yo + co); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                    vst4<BS>(a.y, yo + co, make_float4(v[0], v[1], v[2], v[3]));
                 }
             }
 #pragma unroll
@@ -1091,23 +1094,25 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
 static int patch_min_h() { static const int v = md2_tune("MD2_PATCH_MIN_H", 64); return v; }
 static bool patch_eligible(const ConvArgs& a) {
     static const int off = md2_tune_set("MD2_NO_PATCH_CONV");
-    if (off || a.res || a.bf16 == 2) return false;          // (fp32 tensors only)
+    if (off || a.res || (a.bf16 == 2 && a.Cout != 16)) return false;          // (bf16 tensors, 32 output channels: the 256 x 32 implicit-GEMM tile is ahead -- 0.20 against 0.32 ms on the 96 -> 32 layer of configs[4])
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.Cin % 16 == 0 &&
            (a.Cout == 16 || a.Cout == 32) && a.Cin <= 96 &&
            a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.oy0 == 0 && a.ox0 == 0 && a.Hl == a.Ho && a.Wl == a.Wo &&
            a.Ho >= patch_min_h() && a.Wo >= 2 * patch_min_h();
 }
-template <int COUT>
-static void launch_patch(const ConvArgs& a, hipStream_t s) {
+template <int COUT, bool BS>
+static void launch_patch_t(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.Wo + PT_W - 1) / PT_W, tiles_y = (a.Ho + PT_H - 1) / PT_H;
     const size_t lds = (size_t)(PP_N + COUT * 9) * LDK * sizeof(float);
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_patch_kernel<COUT, BS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     static int per_cu = 0;
-    if (!per_cu) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_patch_kernel<COUT>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2; }
+    if (!per_cu) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv3x3_patch_kernel<COUT, BS>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2; }
     const int total = tiles_x * tiles_y * a.N, resident = 256 * per_cu;                     // persistent: exactly the co-resident blocks
-    hipLaunchKernelGGL((conv3x3_patch_kernel<COUT>), dim3(std::min(total, resident)), dim3(256), lds, s, a, tiles_x, tiles_y, total);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<COUT, BS>), dim3(std::min(total, resident)), dim3(256), lds, s, a, tiles_x, tiles_y, total);
 }
+template <int COUT>
+static void launch_patch(const ConvArgs& a, hipStream_t s) { if (a.bf16 == 2) launch_patch_t<COUT, true>(a, s); else launch_patch_t<COUT, false>(a, s); }
 
 static void launch_conv_igemm_one(const ConvArgs& a, hipStream_t s);
 
@@ -1951,7 +1956,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
     const unsigned short* xg = reinterpret_cast<const unsigned short*>(a.x); const unsigned short* dg = reinterpret_cast<const unsigned short*>(a.dy);
     const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     for (int s = -1; s < my_tiles; ++s) {
+#ifdef MD2_ABLATE
+        const int abl = a.ablate;                  // 1: global loads for the first tile only, 2: LDS commit for the first tile only, 4: no MFMAs
+        if (s >= 0 && !((abl & 2) && s > 0)) {
+#else
         if (s >= 0) {
+#endif
             __syncthreads();                       // the previous tile's MFMAs are done reading LDS (and the zero fill is complete)
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
@@ -1987,7 +1997,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
             }
             __syncthreads();
         }
+#ifdef MD2_ABLATE
+        if (s + 1 < my_tiles && !((abl & 1) && s >= 0)) {
+#else
         if (s + 1 < my_tiles) {
+#endif
             const int tile = blockIdx.x + (s + 1) * gridDim.x;
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
             const long xin = (long)n * a.x_bs + cgi * 32 + q * 4, dyin = (long)n * a.dy_bs + cgo * 32 + q * 4;
@@ -2024,7 +2038,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
         }
         if (s < 0) continue;
         // ---- wave w contracts tile row w: 16 pixels per MFMA, lane half lp takes pixels 8 lp .. 8 lp + 7 of the chunk
+#ifdef MD2_ABLATE
+        const int nch = (abl & 4) ? 0 : (TW + 15) >> 4;
+#else
         const int nch = (TW + 15) >> 4;
+#endif
         for (int ch = 0; ch < nch; ++ch) {
             const uint4 av = *reinterpret_cast<const uint4*>(Ys + wb_addr(lcol, wave * WB_YW + 16 * ch + 8 * lp, WB_YCH));
             if (a.db) {

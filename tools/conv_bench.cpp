@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
         hipMemcpy(y, hx.data(), std::min(nx, ny) * 4, hipMemcpyHostToDevice);
         WgradArgs g{};
         g.x = x; g.x_bs = a.x_bs; g.x_ps = Cin; g.H = H; g.W = W; g.Cin = Cin; g.dy = y; g.dy_bs = a.y_bs; g.dy_ps = Cout; g.Ho = H; g.Wo = W; g.Cout = Cout;
-        g.dw = dw; g.N = N; g.KH = k; g.KW = k; g.stride = 1; g.pad = k / 2; g.padmode = 0; g.M = a.M;
+        g.dw = dw; g.N = N; g.KH = k; g.KW = k; g.stride = 1; g.pad = k / 2; g.padmode = 0; g.M = a.M; if (getenv("BF16S")) g.bf16 = 2;
 #ifdef MD2_ABLATE
         g.ablate = abl;
 #endif
