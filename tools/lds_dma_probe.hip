@@ -51,36 +51,42 @@ __global__ __launch_bounds__(64) void base_probe(const float* x, unsigned* out, 
 }
 // Two roles on the same CUs: even workgroups keep issuing buffer_load ... lds with out-of-range lanes (zeros into their LDS); odd workgroups issue ORDINARY buffer loads whose
 // offset is out of range and count the lanes that did not get zeros back (what the Winograd / implicit-GEMM loaders rely on for padding).
-__global__ __launch_bounds__(64) void mix_probe(const float* x, unsigned* bad, int iters, int with_dma) {
-    __shared__ __attribute__((aligned(16))) unsigned sm[64 * 4 * 4];
-    const int tid = threadIdx.x;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 1 << 20, 0x00020000);
+__global__ __launch_bounds__(256) void mix_probe(const float* x, const float* x2, unsigned* bad, int iters, int with_dma) {
+    __shared__ __attribute__((aligned(16))) unsigned sm[3 * 128 * 16];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    if ((blockIdx.x & 1) == 0) {
+    if ((blockIdx.x & 1) == 0) {          // the implicit GEMM's loader: two resources (tensor with its span, weights with an open range), scalar offsets, three stages, counted vmcnt, barriers
         if (!with_dma) return;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 1 << 20, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x2), 0, 0xFFFFFFE0u, 0x00020000);
         for (int it = 0; it < iters; ++it) {
-            const unsigned off = ((tid + it) & 3) ? 0xFFFFFFF0u : (unsigned)(((blockIdx.x * 64 + tid) * 4096u + it * 64u) & ((1u << 20) - 16u));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sm + (it & 3) * 256), 16, (int)off, 0, 0, 0);
-            if ((it & 3) == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int st = it % 3;
+            const unsigned off = ((lane + it + wave) % 3 == 0) ? 0xFFFFFFF0u : (unsigned)(((blockIdx.x * 256 + tid) * 64u) & ((1u << 20) - 64u));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(sm + st * 2048 + wave * 256), 16, (int)off, (it & 3) * 64, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_ptr_t)(sm + st * 2048 + 1024 + wave * 256), 16, (int)(tid * 16), (it & 15) * 4096, 0, 0);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
+    // the Winograd loaders: ordinary 16-byte buffer loads, a whole patch row out of range (every lane of some waves), scalar offset in use
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x2), 0, 1 << 18, 0x00020000);
     unsigned nb = 0;
     for (int it = 0; it < iters; ++it) {
-        const bool oob = ((tid + it) & 1) != 0;
-        const unsigned off = oob ? 0xFFFFFFF0u : (unsigned)(((blockIdx.x * 64 + tid) * 4096u + it * 64u) & ((1u << 20) - 16u));
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+        const bool oob = wave == 3 || ((lane + it) & 7) == 0;
+        const unsigned off = oob ? 0xFFFFFFF0u : (unsigned)(((blockIdx.x * 256 + tid) * 64u) & ((1u << 18) - 256u));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, (it & 3) * 32, 0);
         if (oob) nb += (v[0] | v[1] | v[2] | v[3]) != 0u; else nb += v[0] != 0x3f3f3f3fu;
     }
     if (nb) atomicAdd(bad, nb);
 }
 int main() {
     {
-        float* big; hipMalloc(&big, 1 << 20); hipMemset(big, 0x3f, 1 << 20); unsigned* bad; hipMalloc(&bad, 4);
+        float* big; hipMalloc(&big, 1 << 20); hipMemset(big, 0x3f, 1 << 20); float* big2; hipMalloc(&big2, 1 << 20); hipMemset(big2, 0x3f, 1 << 20); unsigned* bad; hipMalloc(&bad, 4);
         for (int dma = 0; dma < 2; ++dma) {
             hipMemset(bad, 0, 4);
-            hipLaunchKernelGGL(mix_probe, dim3(8192), dim3(64), 0, 0, big, bad, 2000, dma); hipDeviceSynchronize();
+            hipLaunchKernelGGL(mix_probe, dim3(4096), dim3(256), 0, 0, big, big2, bad, 3000, dma); hipDeviceSynchronize();
             unsigned hb = 0; hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost);
             printf("mix probe, LDS-DMA neighbours %s: %u ordinary buffer loads returned something other than expected (zeros for out-of-range lanes)\n", dma ? "present" : "absent", hb);
         }
