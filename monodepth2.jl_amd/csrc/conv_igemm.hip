@@ -1920,19 +1920,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps32_kernel(WgradArgs 
     }
 }
 // ------------------------------------------------------------------------------------------------------------
-// The all-taps weight gradient for bf16 TENSORS (WgradArgs::bf16 == 2): same block / tile scheme as conv3x3_wgrad_taps32_kernel, but the LDS tiles are bf16 and
-// CHANNEL-major, so that an MFMA operand -- 8 consecutive pixels of one channel -- is ONE ds_read_b128 instead of eight scalar reads and four packs:
-//   Ys[32 co][4 rows x 32 px], Xs[32 ci][6 rows x 40 px]; the three column taps of a patch row come out of one 16-pixel window (two reads): kw = 0 its first 8 pixels,
-//   kw = 2 the same registers one dword on, kw = 1 four v_alignbyte.  Per 16-pixel chunk a wave issues 7 reads + 12 vector instructions for its 9 MFMAs (the fp32-tile kernel:
-//   80 reads + 40 packs).  The transpose happens once, on the way in: a thread loads the same 4 channels of two neighbouring pixels (2 x 8 B) and writes 4 dwords.
-//   Bank layout: a channel row is an odd number of 16-B groups (8 consecutive channels -> 8 different groups for the b128 reads), and the group index is XORed with
-//   2 * bit 3 of the channel so that the 8 channel quads of a wave's dword writes fall on four different bank octets.
+// The all-taps weight gradient for bf16 TENSORS (WgradArgs::bf16 == 2): block / tile scheme of conv3x3_wgrad_taps32_kernel (32 co x 32 ci x 9 taps per block, persistent over
+// 4-row tiles, wave = tile row), with the LDS tiles left PIXEL-major (NHWC, as the tensors are: Ys[4 x 32 px][32 co], Xs[6 x 34 px][32 ci], 64 bytes per pixel) and the
+// transpose done by the LDS read (round 5; round 4 kept channel-major bf16 tiles, transposed by the loader: 24 ds_write_b32 + ~100 vector instructions per thread and tile): ds_read_b64_tr_b16 hands lane i of a 16-lane group channel i of a 4-pixel x 16-channel block, i.e. two reads give a lane the 8 consecutive
+// pixels of its channel that v_mfma_f32_32x32x16_bf16 takes (K = pixels).  A tap is a 64-byte offset, so the 20 reads of a 16-pixel chunk (2 for dy, 2 x 9 for the patch)
+// are immediates off two base registers; four consecutive pixels are 256 contiguous bytes = every bank once: no padding, no swizzle.  The loader becomes what a loader
+// should be: 16-byte loads (8 channels of a pixel; 5 per thread and tile instead of 12 of 8 bytes) and one ds_write_b128 each -- no pair packing, no dword scatter.
+// 95 / 93 / 92 / 106 -> 77 / 72 / 70 / 80 us on the four encoder shapes of configs[4] (tools/run_bs_wgrad_bench.sh); what is left: the global loads (-25 % without them).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int WB_YW = 32, WB_XW = 40;                               // pixels per tile row / patch row held in LDS (multiples of 8; TW <= 32, TW + 2 <= 34, the window reaches pixel 39)
-constexpr int WB_YCH = (4 * WB_YW / 8 + 1) * 16, WB_XCH = (32 + 1) * 16;          // bytes per channel row: 16 (32: 6 x 5 = 30 used) pixel groups + one pad group
+constexpr int WR_XP = 34, WR_YB = 4 * 32 * 64, WR_XB = 6 * WR_XP * 64;          // patch row length in pixels; bytes of the two tiles
+typedef short wr_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) wr_s16x4* wr_lds_ptr;
+__device__ __forceinline__ bf16x8 wr_read8(const char* p) {          // 8 consecutive pixels of this lane's channel: the blocks at p and 4 pixels (256 bytes) on
+    const wr_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_ptr)(p)), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_ptr)(p + 256));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs a, int TW, int tiles_x, int tiles_y, int total_tiles, int ci_groups) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
-    char* Ys = wsm; char* Xs = wsm + 32 * WB_YCH;
+    char* Ys = wsm; char* Xs = wsm + WR_YB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lcol = lane & 31, lp = lane >> 5;
     const int cgi = blockIdx.y % ci_groups, cgo = blockIdx.y / ci_groups;
@@ -1943,17 +1949,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    for (int i = tid; i < (32 * WB_YCH + 32 * WB_XCH) / 16; i += 256) reinterpret_cast<uint4*>(wsm)[i] = make_uint4(0u, 0u, 0u, 0u);      // columns the loader never writes are read as operands of masked pixels: finite
+    for (int i = tid; i < (WR_YB + WR_XB) / 16; i += 256) reinterpret_cast<uint4*>(wsm)[i] = make_uint4(0u, 0u, 0u, 0u);      // patch columns past PW are never written but are read (against zero dy): finite
 
-    // loader slots: (row, column pair, channel quad); x patch 6 x 18 x 8 = 864 (4 per thread, the last partly), dy 4 x 16 x 8 = 512 (2 per thread)
-    constexpr int NX = 4, NY = 2, XSLOTS = 6 * 18 * 8;
-    uint2 xv[NX][2], yv[NY][2];
-    unsigned okb = 0;                              // bit 2 i + j: pixel j of x slot i is inside the image; bit 16 + 2 i + j: dy
-    const int q = tid & 7;
+    // loader slots: 16-byte pieces (pixel, channel octet); x patch 6 x 34 x 4 = 816 (4 per thread, the last partly), dy 4 x 32 x 4 = 512 (2 per thread)
+    constexpr int NX = 4, NY = 2, XSLOTS = 6 * WR_XP * 4;
+    uint4 xv[NX], yv[NY];
+    unsigned okb = 0;                              // bit i: x slot i is inside the image; bit 8 + i: dy
+    const int q4 = tid & 3;
     const bool xf = a.in_scale != nullptr;
-    float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (xf) { xsc = *reinterpret_cast<const float4*>(a.in_scale + cgi * 32 + q * 4); xsh = *reinterpret_cast<const float4*>(a.in_shift + cgi * 32 + q * 4); }
+    float4 xsc0 = make_float4(1.f, 1.f, 1.f, 1.f), xsc1 = xsc0, xsh0 = make_float4(0.f, 0.f, 0.f, 0.f), xsh1 = xsh0;
+    if (xf) {
+        const int ch = cgi * 32 + q4 * 8;
+        xsc0 = *reinterpret_cast<const float4*>(a.in_scale + ch); xsc1 = *reinterpret_cast<const float4*>(a.in_scale + ch + 4);
+        xsh0 = *reinterpret_cast<const float4*>(a.in_shift + ch); xsh1 = *reinterpret_cast<const float4*>(a.in_shift + ch + 4);
+    }
     const unsigned short* xg = reinterpret_cast<const unsigned short*>(a.x); const unsigned short* dg = reinterpret_cast<const unsigned short*>(a.dy);
+    // operand addressing (fixed per lane): lane 4q + p of group g supplies pixel 8 (g >> 1) + q of the chunk, channels 16 (g & 1) + 4 p ..
+    const int lane_off = ((8 * (lane >> 5) + ((lane >> 2) & 3)) * 64) + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
     const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     for (int s = -1; s < my_tiles; ++s) {
 #ifdef MD2_ABLATE
@@ -1967,33 +1979,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
             for (int i = 0; i < NX; ++i) {
                 const int slot = tid + 256 * i;
                 if (slot < XSLOTS) {
-                    const int rc = slot >> 3, row = rc / 18, cp = rc - row * 18;
-                    uint2 p0 = xv[i][0], p1 = xv[i][1];
+                    uint4 v = xv[i];
                     if (xf) {
-                        const float4 f0 = bf16x4_unpack(p0), f1 = bf16x4_unpack(p1);
-                        p0 = make_uint2(bf16x2_pack(fmaxf(fmaf(f0.x, xsc.x, xsh.x), 0.f), fmaxf(fmaf(f0.y, xsc.y, xsh.y), 0.f)), bf16x2_pack(fmaxf(fmaf(f0.z, xsc.z, xsh.z), 0.f), fmaxf(fmaf(f0.w, xsc.w, xsh.w), 0.f)));
-                        p1 = make_uint2(bf16x2_pack(fmaxf(fmaf(f1.x, xsc.x, xsh.x), 0.f), fmaxf(fmaf(f1.y, xsc.y, xsh.y), 0.f)), bf16x2_pack(fmaxf(fmaf(f1.z, xsc.z, xsh.z), 0.f), fmaxf(fmaf(f1.w, xsc.w, xsh.w), 0.f)));
+                        const float4 f0 = bf16x4_unpack(make_uint2(v.x, v.y)), f1 = bf16x4_unpack(make_uint2(v.z, v.w));
+                        v.x = bf16x2_pack(fmaxf(fmaf(f0.x, xsc0.x, xsh0.x), 0.f), fmaxf(fmaf(f0.y, xsc0.y, xsh0.y), 0.f)); v.y = bf16x2_pack(fmaxf(fmaf(f0.z, xsc0.z, xsh0.z), 0.f), fmaxf(fmaf(f0.w, xsc0.w, xsh0.w), 0.f));
+                        v.z = bf16x2_pack(fmaxf(fmaf(f1.x, xsc1.x, xsh1.x), 0.f), fmaxf(fmaf(f1.y, xsc1.y, xsh1.y), 0.f)); v.w = bf16x2_pack(fmaxf(fmaf(f1.z, xsc1.z, xsh1.z), 0.f), fmaxf(fmaf(f1.w, xsc1.w, xsh1.w), 0.f));
                     }
-                    const unsigned m0 = 0u - ((okb >> (2 * i)) & 1u), m1 = 0u - ((okb >> (2 * i + 1)) & 1u);
-                    p0.x &= m0; p0.y &= m0; p1.x &= m1; p1.y &= m1;
-                    const int pp = row * WB_XW + 2 * cp;
-                    *reinterpret_cast<unsigned*>(Xs + wb_addr(4 * q + 0, pp, WB_XCH)) = (p0.x & 0xFFFFu) | (p1.x << 16);
-                    *reinterpret_cast<unsigned*>(Xs + wb_addr(4 * q + 1, pp, WB_XCH)) = (p0.x >> 16) | (p1.x & 0xFFFF0000u);
-                    *reinterpret_cast<unsigned*>(Xs + wb_addr(4 * q + 2, pp, WB_XCH)) = (p0.y & 0xFFFFu) | (p1.y << 16);
-                    *reinterpret_cast<unsigned*>(Xs + wb_addr(4 * q + 3, pp, WB_XCH)) = (p0.y >> 16) | (p1.y & 0xFFFF0000u);
+                    const unsigned m = 0u - ((okb >> i) & 1u);
+                    *reinterpret_cast<uint4*>(Xs + slot * 16) = make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
                 }
             }
 #pragma unroll
             for (int i = 0; i < NY; ++i) {
-                const int slot = tid + 256 * i, cp = (slot >> 3) & 15, row = slot >> 7;
-                uint2 p0 = yv[i][0], p1 = yv[i][1];
-                const unsigned m0 = 0u - ((okb >> (16 + 2 * i)) & 1u), m1 = 0u - ((okb >> (17 + 2 * i)) & 1u);
-                p0.x &= m0; p0.y &= m0; p1.x &= m1; p1.y &= m1;
-                const int pp = row * WB_YW + 2 * cp;
-                *reinterpret_cast<unsigned*>(Ys + wb_addr(4 * q + 0, pp, WB_YCH)) = (p0.x & 0xFFFFu) | (p1.x << 16);
-                *reinterpret_cast<unsigned*>(Ys + wb_addr(4 * q + 1, pp, WB_YCH)) = (p0.x >> 16) | (p1.x & 0xFFFF0000u);
-                *reinterpret_cast<unsigned*>(Ys + wb_addr(4 * q + 2, pp, WB_YCH)) = (p0.y & 0xFFFFu) | (p1.y << 16);
-                *reinterpret_cast<unsigned*>(Ys + wb_addr(4 * q + 3, pp, WB_YCH)) = (p0.y >> 16) | (p1.y & 0xFFFF0000u);
+                const unsigned m = 0u - ((okb >> (8 + i)) & 1u);
+                *reinterpret_cast<uint4*>(Ys + (tid + 256 * i) * 16) = make_uint4(yv[i].x & m, yv[i].y & m, yv[i].z & m, yv[i].w & m);
             }
             __syncthreads();
         }
@@ -2004,36 +2003,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
 #endif
             const int tile = blockIdx.x + (s + 1) * gridDim.x;
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            const long xin = (long)n * a.x_bs + cgi * 32 + q * 4, dyin = (long)n * a.dy_bs + cgo * 32 + q * 4;
+            const long xin = (long)n * a.x_bs + cgi * 32 + q4 * 8, dyin = (long)n * a.dy_bs + cgo * 32 + q4 * 8;       // element offsets
             okb = 0;
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                const int slot = min(tid + 256 * i, XSLOTS - 1), rc = slot >> 3, row = rc / 18, cp = rc - row * 18;
-                int ih = ty * 4 - a.pad + row;
-                if (a.padmode == PAD_REFLECT) ih = refl_idx(max(min(ih, a.H), -1), a.H);
-                const bool hok = ih >= 0 && ih < a.H;
-                const long rowoff = xin + (long)min(max(ih, 0), a.H - 1) * a.W * a.x_ps;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = 2 * cp + j;
-                    int iw = tx * TW - a.pad + col;
-                    if (a.padmode == PAD_REFLECT) iw = refl_idx(max(min(iw, a.W), -1), a.W);
-                    const bool ok = hok && iw >= 0 && iw < a.W && col < PW;
-                    okb |= (ok ? 1u : 0u) << (2 * i + j);
-                    xv[i][j] = *reinterpret_cast<const uint2*>(xg + rowoff + (long)min(max(iw, 0), a.W - 1) * a.x_ps);
-                }
+                const int pix = min(tid + 256 * i, XSLOTS - 1) >> 2, row = pix / WR_XP, col = pix - row * WR_XP;
+                int ih = ty * 4 - a.pad + row, iw = tx * TW - a.pad + col;
+                if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && col < PW;
+                okb |= (ok ? 1u : 0u) << i;
+                xv[i] = *reinterpret_cast<const uint4*>(xg + xin + ((long)min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)) * a.x_ps);
             }
 #pragma unroll
             for (int i = 0; i < NY; ++i) {
-                const int slot = tid + 256 * i, cp = (slot >> 3) & 15, row = slot >> 7;
-                const int oy = ty * 4 + row;
-                const long rowoff = dyin + (long)min(oy, a.Ho - 1) * a.Wo * a.dy_ps;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = 2 * cp + j, ox = tx * TW + col;
-                    okb |= ((oy < a.Ho && col < TW && ox < a.Wo) ? 1u : 0u) << (16 + 2 * i + j);
-                    yv[i][j] = *reinterpret_cast<const uint2*>(dg + rowoff + (long)min(ox, a.Wo - 1) * a.dy_ps);
-                }
+                const int pix = (tid + 256 * i) >> 2, row = pix >> 5, col = pix & 31;
+                const int oy = ty * 4 + row, ox = tx * TW + col;
+                okb |= ((oy < a.Ho && col < TW && ox < a.Wo) ? 1u : 0u) << (8 + i);
+                yv[i] = *reinterpret_cast<const uint4*>(dg + dyin + ((long)min(oy, a.Ho - 1) * a.Wo + min(ox, a.Wo - 1)) * a.dy_ps);
             }
         }
         if (s < 0) continue;
@@ -2044,21 +2030,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
         const int nch = (TW + 15) >> 4;
 #endif
         for (int ch = 0; ch < nch; ++ch) {
-            const uint4 av = *reinterpret_cast<const uint4*>(Ys + wb_addr(lcol, wave * WB_YW + 16 * ch + 8 * lp, WB_YCH));
+            const bf16x8 A = wr_read8(Ys + (wave * 32 + 16 * ch) * 64 + lane_off);
             if (a.db) {
+                const uint4 av = __builtin_bit_cast(uint4, A);
                 const float4 lo = bf16x4_unpack(make_uint2(av.x, av.y)), hi = bf16x4_unpack(make_uint2(av.z, av.w));
                 bsum += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
             }
-            const bf16x8 A = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const int pb = (wave + kh) * WB_XW + 16 * ch + 8 * lp;
-                const uint4 d0 = *reinterpret_cast<const uint4*>(Xs + wb_addr(lcol, pb, WB_XCH)), d1 = *reinterpret_cast<const uint4*>(Xs + wb_addr(lcol, pb + 8, WB_XCH));
-                const uint4 b1 = make_uint4(__builtin_amdgcn_alignbyte(d0.y, d0.x, 2), __builtin_amdgcn_alignbyte(d0.z, d0.y, 2), __builtin_amdgcn_alignbyte(d0.w, d0.z, 2), __builtin_amdgcn_alignbyte(d1.x, d0.w, 2));
-                const uint4 b2 = make_uint4(d0.y, d0.z, d0.w, d1.x);
-                acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, d0), acc[kh * 3 + 0], 0, 0, 0);
-                acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b1), acc[kh * 3 + 1], 0, 0, 0);
-                acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, b2), acc[kh * 3 + 2], 0, 0, 0);
+                const char* xb = Xs + ((wave + kh) * WR_XP + 16 * ch) * 64 + lane_off;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, wr_read8(xb + kw * 64), acc[kh * 3 + kw], 0, 0, 0);
             }
         }
     }
@@ -2087,11 +2069,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
         atomicAdd(a.dw + ((long)co * 9 + t) * a.Cin + ci, red[i]);
     }
 }
+static bool wgrad_taps_bs_aligned(const WgradArgs& a) {          // 16-byte pieces: channel offsets and strides in multiples of 8 bf16 elements
+    return a.x_ps % 8 == 0 && a.dy_ps % 8 == 0 && a.x_bs % 8 == 0 && a.dy_bs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0;
+}
 static void launch_wgrad_taps_bs(const WgradArgs& a, hipStream_t s) {
     const int tiles_x = (a.Wo + 31) / 32;
     int TW = (a.Wo + tiles_x - 1) / tiles_x; TW += TW & 1;                                  // even, <= 32, least padding
     const int tiles_y = (a.Ho + 3) / 4;
-    const size_t lds = (size_t)std::max(32 * WB_YCH + 32 * WB_XCH, 9 * 16 * 64 * 4);
+    const size_t lds = (size_t)std::max(WR_YB + WR_XB, 9 * 16 * 64 * 4);
     static int per_cu = 0;
     if (!per_cu) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_taps_bs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2107,12 +2092,13 @@ static void launch_wgrad_taps_bs(const WgradArgs& a, hipStream_t s) {
 static bool wgrad_taps32_eligible(const WgradArgs& a) {
     static const int off = md2_tune_set("MD2_NO_TAPS_WGRAD");
     if (off) return false;
+    if (a.bf16 == 2 && !wgrad_taps_bs_aligned(a)) return false;          // (views the 16-byte loader cannot take go to the per-tap kernel)
     return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.Cout % 32 == 0 && a.Cin % 32 == 0 &&
            a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.Ho >= 2 && a.Wo >= 8;
 }
 static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
     static const bool no_bs_taps = md2_tune_set("MD2_NO_BS_TAPS");
-    if (a.bf16 == 2 && !no_bs_taps) { launch_wgrad_taps_bs(a, s); return; }          // bf16 tensors: channel-major bf16 LDS tiles
+    if (a.bf16 == 2 && !no_bs_taps) { launch_wgrad_taps_bs(a, s); return; }          // bf16 tensors: pixel-major bf16 LDS tiles, transposed by the operand reads
     const int tiles_x = (a.Wo + WT_MAXW - 1) / WT_MAXW;
     int TW = (a.Wo + tiles_x - 1) / tiles_x; TW += TW & 1;                                  // even, <= 32, least padding
     const int tiles_y = (a.Ho + 3) / 4;
