@@ -67,6 +67,8 @@ struct md2_handle {
     double* acc_all = nullptr; size_t acc_count = 0; double* acc_bwd = nullptr; size_t acc_fwd_count = 0, acc_bwd_count = 0;
     int Kpad = 64;
     View z0, a0, p0; uint8_t* pool_arg = nullptr;
+    float* bn_ident = nullptr;       // [mean = 0 | 1 / sigma = 1] x 2048 channels: with these as its statistics, bn_apply(gamma = scale, beta = shift) is the loaders' fma(z, scale, shift), bit for bit
+    float* a_fwd = nullptr;          // bf16 tensors: relu(bn(z)) of a fused block, materialised for the FORWARD convolution only (one buffer, the largest block's size); the weight gradient still transforms z in its loader
     View feat[5], y1[5], cat[5], y2[5], dispv[5];
     View sq3, dsq3; View sqcat, py1, py2, py3; float *rvec = nullptr, *tvec = nullptr, *Rt = nullptr;
     double *loss_part = nullptr, *dRt_acc = nullptr; size_t ddisp_lo_count = 0; float *totals = nullptr, *loss_dev = nullptr, *ddisp_full = nullptr, *drvec = nullptr, *dtvec = nullptr;
@@ -197,6 +199,7 @@ static void plan_buffers(md2_handle* h) {
     h->p0 = h->alloc_view(NL, H / 4, W / 4, 64); h->pool_arg = h->alloc<uint8_t>((size_t)NL * (H / 4) * (W / 4) * 64);
     h->feat[0] = h->a0;
     int hh = H / 4, ww = W / 4; View cur = h->p0;
+    size_t a_fwd_elems = 0;
     for (int i = 0, stage = 1; i < h->nblk; ++i) {
         Block& B = h->blk[i];
         const int hi = hh, wi = ww;                      // resolution of the block input (the bottleneck's 1x1 conv1 keeps it)
@@ -208,12 +211,14 @@ static void plan_buffers(md2_handle* h) {
             B.fuse = !no_fuse && conv_wgrad_supports_in_transform(hh, ww, co, co);        // conv2 and its weight gradient can fold bn1 + ReLU into their loaders at this size
             B.z1 = h->alloc_view(NL, hh, ww, co); B.z2 = h->alloc_view(NL, hh, ww, co);
             B.a1 = B.fuse ? h->scratch_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co);      // fused: never materialised (the view only carries the shape)
+            if (B.fuse) a_fwd_elems = std::max(a_fwd_elems, (size_t)NL * hh * ww * co);
         } else {
             const int pl = B.c1.cout, co = B.c3.cout;
             static const bool no_fuse = md2_tune_set("MD2_NO_BN_FUSE");
             B.fuse = !no_fuse;                // 1x1 and 3x3 loaders (forward and weight gradient) all take the BatchNorm + ReLU transform at these channel counts (multiples of 64)
             B.z1 = h->alloc_view(NL, hi, wi, pl); B.a1 = B.fuse ? h->scratch_view(nullptr, NL, hi, wi, pl) : h->alloc_view(NL, hi, wi, pl);
             B.z2 = h->alloc_view(NL, hh, ww, pl); B.a2 = B.fuse ? h->scratch_view(nullptr, NL, hh, ww, pl) : h->alloc_view(NL, hh, ww, pl); B.z3 = h->alloc_view(NL, hh, ww, co);
+            if (B.fuse) a_fwd_elems = std::max(a_fwd_elems, (size_t)NL * hi * wi * pl);
         }
         const int co = B.bottleneck ? B.c3.cout : B.c1.cout;
         if (B.down) { B.zd = h->alloc_view(NL, hh, ww, co); B.sd = B.fuse ? h->scratch_view(nullptr, NL, hh, ww, co) : h->alloc_view(NL, hh, ww, co); }
@@ -221,6 +226,8 @@ static void plan_buffers(md2_handle* h) {
         cur = B.out;
         if (B.stage_end) h->feat[stage++] = B.out;
     }
+    h->a_fwd = (h->bs && a_fwd_elems) ? reinterpret_cast<float*>(h->alloc<uint16_t>(a_fwd_elems + 8)) : nullptr;
+    h->bn_ident = h->a_fwd ? h->alloc<float>(2 * 2048) : nullptr;
     const int dec[5] = {256, 128, 64, 32, 16}, skc[5] = {h->stages[3], h->stages[2], h->stages[1], h->stages[0], 0}, inc[5] = {h->stages[4], 256, 128, 64, 32};
     int dh = H / 32, dw = W / 32;
     size_t dxpad_max = 0;
@@ -451,9 +458,14 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
         Block& B = h->blk[i];
         if (B.fuse) {
             conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_stats(h, B.b1, B.z1);
-            {   // conv2 gathers relu(bn1(z1)) straight from z1
-                ConvArgs a = conv_args(B.z1, h->wfwd(B.c2.w), B.z2, B.c2.k, B.c2.stride, B.c2.pad, 1, PAD_ZERO);
-                a.in_scale = B.b1.stats + 2 * B.b1.c; a.in_shift = B.b1.stats + 3 * B.b1.c; a.stats = h->testmode ? nullptr : B.b2.acc;
+            {   // conv2 gathers relu(bn1(z1)) straight from z1 -- except on bf16 tensors, where the plain launch (LDS loader, 128 x 64 tiles) plus one elementwise pass into a
+                // shared buffer is ahead of the launch with the transform in its register-staged loader (round 5: 55 + 10...35 against 114 us at configs[4])
+                View src = B.z1;
+                // (the pass applies the SAME fused scale / shift as the loaders -- the weight gradient still transforms z1 in its loader and must see the values this convolution saw)
+                if (h->a_fwd) { src = h->scratch_view(h->a_fwd, B.z1.N, B.z1.H, B.z1.W, B.z1.C); launch_bn_apply(B.z1, h->bn_ident + 2048 - B.b1.c, B.b1.stats + 2 * B.b1.c, B.b1.stats + 3 * B.b1.c, nullptr, ACT_RELU, src, s); }
+                ConvArgs a = conv_args(src, h->wfwd(B.c2.w), B.z2, B.c2.k, B.c2.stride, B.c2.pad, 1, PAD_ZERO);
+                if (!h->a_fwd) { a.in_scale = B.b1.stats + 2 * B.b1.c; a.in_shift = B.b1.stats + 3 * B.b1.c; }
+                a.stats = h->testmode ? nullptr : B.b2.acc;
                 a.wino_u = B.c2.uf >= 0 ? h->UF + B.c2.uf : nullptr; a.wino_pieces = wino_resolve_pieces(h->u_pieces_f, a.Cin);
                 run_igemm(h, a);
             }
@@ -884,6 +896,7 @@ int32_t md2_create(const md2_config* cfg, md2_handle** out) {
     }
     (void)hipMemset(h->P, 0, pb); (void)hipMemset(h->G, 0, pb); (void)hipMemset(h->M, 0, pb); (void)hipMemset(h->V, 0, pb); (void)hipMemset(h->WD, 0, pb);
     (void)hipMemset(h->arena, 0, need);
+    if (h->bn_ident) { std::vector<float> id(2 * 2048, 0.f); for (int i = 2048; i < 4096; ++i) id[i] = 1.f; (void)hipMemcpy(h->bn_ident, id.data(), id.size() * sizeof(float), hipMemcpyHostToDevice); }
     {   // BatchNorm running statistics: Flux initialises mu = 0, sigma^2 = 1
         std::vector<float> rs((size_t)h->n_rs, 0.f);
         for (BNL* b : h->bns) for (int i = 0; i < b->c; ++i) rs[b->rs + b->c + i] = 1.f;
