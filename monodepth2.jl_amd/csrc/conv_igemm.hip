@@ -1956,9 +1956,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
     uint4 xv[NX], yv[NY];
     unsigned okb = 0;                              // bit i: x slot i is inside the image; bit 8 + i: dy
     const int q4 = tid & 3;
+    // 16-channel layers (the full-resolution decoder): the upper half of a 32-channel group does not exist -- its pieces are committed as zeros, its weights never added
+    const bool xch = cgi * 32 + q4 * 8 < a.Cin, ych = cgo * 32 + q4 * 8 < a.Cout;
     const bool xf = a.in_scale != nullptr;
     float4 xsc0 = make_float4(1.f, 1.f, 1.f, 1.f), xsc1 = xsc0, xsh0 = make_float4(0.f, 0.f, 0.f, 0.f), xsh1 = xsh0;
-    if (xf) {
+    if (xf && xch) {
         const int ch = cgi * 32 + q4 * 8;
         xsc0 = *reinterpret_cast<const float4*>(a.in_scale + ch); xsc1 = *reinterpret_cast<const float4*>(a.in_scale + ch + 4);
         xsh0 = *reinterpret_cast<const float4*>(a.in_shift + ch); xsh1 = *reinterpret_cast<const float4*>(a.in_shift + ch + 4);
@@ -2003,14 +2005,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
 #endif
             const int tile = blockIdx.x + (s + 1) * gridDim.x;
             const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
-            const long xin = (long)n * a.x_bs + cgi * 32 + q4 * 8, dyin = (long)n * a.dy_bs + cgo * 32 + q4 * 8;       // element offsets
+            const long xin = (long)n * a.x_bs + cgi * 32 + (xch ? q4 * 8 : 0), dyin = (long)n * a.dy_bs + cgo * 32 + (ych ? q4 * 8 : 0);       // element offsets
             okb = 0;
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 const int pix = min(tid + 256 * i, XSLOTS - 1) >> 2, row = pix / WR_XP, col = pix - row * WR_XP;
                 int ih = ty * 4 - a.pad + row, iw = tx * TW - a.pad + col;
                 if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
-                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && col < PW;
+                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && col < PW && xch;
                 okb |= (ok ? 1u : 0u) << i;
                 xv[i] = *reinterpret_cast<const uint4*>(xg + xin + ((long)min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)) * a.x_ps);
             }
@@ -2018,7 +2020,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
             for (int i = 0; i < NY; ++i) {
                 const int pix = (tid + 256 * i) >> 2, row = pix >> 5, col = pix & 31;
                 const int oy = ty * 4 + row, ox = tx * TW + col;
-                okb |= ((oy < a.Ho && col < TW && ox < a.Wo) ? 1u : 0u) << (8 + i);
+                okb |= ((oy < a.Ho && col < TW && ox < a.Wo && ych) ? 1u : 0u) << (8 + i);
                 yv[i] = *reinterpret_cast<const uint4*>(dg + dyin + ((long)min(oy, a.Ho - 1) * a.Wo + min(ox, a.Wo - 1)) * a.dy_ps);
             }
         }
@@ -2046,7 +2048,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
     }
     if (a.db && cgi == 0) {                        // one block column per output-channel group owns the bias gradient
         bsum += __shfl_xor(bsum, 32);
-        if (lp == 0) atomicAdd(a.db + cgo * 32 + lcol, bsum);
+        if (lp == 0 && cgo * 32 + lcol < a.Cout) atomicAdd(a.db + cgo * 32 + lcol, bsum);
     }
     // ---- reduce the 4 waves' accumulators through LDS, then one atomic per weight and block (as conv3x3_wgrad_taps32_kernel)
     float* red = reinterpret_cast<float*>(wsm);    // [9*16][64 lanes]
@@ -2066,7 +2068,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
     for (int i = tid; i < 9 * 16 * 64; i += 256) {
         const int ln = i & 63, e = (i >> 6) & 15, t = i >> 10;
         const int co = cgo * 32 + (e >> 2) * 8 + (ln >> 5) * 4 + (e & 3), ci = cgi * 32 + (ln & 31);     // 32x32 D layout
-        atomicAdd(a.dw + ((long)co * 9 + t) * a.Cin + ci, red[i]);
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((long)co * 9 + t) * a.Cin + ci, red[i]);
     }
 }
 static bool wgrad_taps_bs_aligned(const WgradArgs& a) {          // 16-byte pieces: channel offsets and strides in multiples of 8 bf16 elements
@@ -2084,7 +2086,7 @@ static void launch_wgrad_taps_bs(const WgradArgs& a, hipStream_t s) {
         per_cu = std::min(per_cu, 2);
         if (md2_tune_set("MD2_TAPS_PER_CU")) per_cu = std::max(1, std::min(per_cu, (int)md2_tune("MD2_TAPS_PER_CU", per_cu)));
     }
-    const int total = tiles_x * tiles_y * a.N, ci_groups = a.Cin / 32, groups = ci_groups * (a.Cout / 32);
+    const int total = tiles_x * tiles_y * a.N, ci_groups = (a.Cin + 31) / 32, groups = ci_groups * ((a.Cout + 31) / 32);
     const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));
     hipLaunchKernelGGL(conv3x3_wgrad_taps_bs_kernel, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
 }
@@ -2093,12 +2095,12 @@ static bool wgrad_taps32_eligible(const WgradArgs& a) {
     static const int off = md2_tune_set("MD2_NO_TAPS_WGRAD");
     if (off) return false;
     if (a.bf16 == 2 && !wgrad_taps_bs_aligned(a)) return false;          // (views the 16-byte loader cannot take go to the per-tap kernel)
-    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.Cout % 32 == 0 && a.Cin % 32 == 0 &&
+    const int cm = a.bf16 == 2 ? 16 : 32;                                 // (bf16 tensors: 16-channel layers as half-filled groups -- they are bound by their bytes, not by the matrix pipe)
+    return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.Cout % cm == 0 && a.Cin % cm == 0 &&
            a.Ho == a.H + 2 * a.pad - 2 && a.Wo == a.W + 2 * a.pad - 2 && a.Ho >= 2 && a.Wo >= 8;
 }
 static void launch_wgrad_taps32(const WgradArgs& a, hipStream_t s) {
-    static const bool no_bs_taps = md2_tune_set("MD2_NO_BS_TAPS");
-    if (a.bf16 == 2 && !no_bs_taps) { launch_wgrad_taps_bs(a, s); return; }          // bf16 tensors: pixel-major bf16 LDS tiles, transposed by the operand reads
+    if (a.bf16 == 2) { launch_wgrad_taps_bs(a, s); return; }          // bf16 tensors: pixel-major bf16 LDS tiles, transposed by the operand reads
     const int tiles_x = (a.Wo + WT_MAXW - 1) / WT_MAXW;
     int TW = (a.Wo + tiles_x - 1) / tiles_x; TW += TW & 1;                                  // even, <= 32, least padding
     const int tiles_y = (a.Ho + 3) / 4;
