@@ -2071,6 +2071,110 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_taps_bs_kernel(WgradArgs
         if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((long)co * 9 + t) * a.Cin + ci, red[i]);
     }
 }
+// The stride-2 layers of the encoder on bf16 tensors (3x3 / pad 1 and the 1x1 / pad 0 shortcut), same scheme: block = 32 co x 32 ci x KK^2 taps, persistent over tiles of
+// 4 x 16 OUTPUT pixels (wave = tile row, one 16-pixel MFMA chunk), pixel-major bf16 tiles, operands by transposed reads.  KK = 3: the 9 x 34-pixel input patch is kept as it is
+// in the tensor and a tap's 8 output pixels are every second patch pixel -- the transposed read takes one address per block row, so a stride costs nothing but a 2-way bank
+// overlap (rows 128 bytes apart).  KK = 1: the loader gathers the sampled pixels, the tile is read like a stride-1 one.  Replaces the widen-to-fp32 per-tap kernel
+// (conv_wgrad_kernel<..., SPL = 1, BS>) on these layers: 150 / 110 / 103 us -> see DESIGN.md.
+template <int KK>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_s2_bs_kernel(WgradArgs a, int TW, int tiles_x, int tiles_y, int total_tiles, int ci_groups) {
+    constexpr int XR = KK == 3 ? 9 : 4, XP = KK == 3 ? 34 : 16, NT = KK * KK;          // patch rows / pixels per patch row held in LDS, taps
+    constexpr int YB = 4 * 16 * 64, XB = XR * XP * 64, XSLOTS = XR * XP * 4, NX = (XSLOTS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    char* Ys = wsm; char* Xs = wsm + YB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lcol = lane & 31, lp = lane >> 5;
+    const int cgi = blockIdx.y % ci_groups, cgo = blockIdx.y / ci_groups;
+    const int PW = KK == 3 ? 2 * TW + 1 : TW;          // patch columns this tile width needs
+    f32x16 acc[NT];
+    float bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int i = tid; i < (YB + XB) / 16; i += 256) reinterpret_cast<uint4*>(wsm)[i] = make_uint4(0u, 0u, 0u, 0u);      // (columns past PW are read against zero dy: finite)
+    uint4 xv[NX], yv;
+    unsigned okb = 0;                              // bit i: x slot i is inside the image; bit 8: dy
+    const int q4 = tid & 3;
+    const bool xch = cgi * 32 + q4 * 8 < a.Cin, ych = cgo * 32 + q4 * 8 < a.Cout;
+    const unsigned short* xg = reinterpret_cast<const unsigned short*>(a.x); const unsigned short* dg = reinterpret_cast<const unsigned short*>(a.dy);
+    const int lane_pix = 8 * (lane >> 5) + ((lane >> 2) & 3), lane_ch = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;          // the block row this lane addresses, its 8 bytes of the row
+    const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int s = -1; s < my_tiles; ++s) {
+        if (s >= 0) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int slot = tid + 256 * i;
+                if (slot < XSLOTS) { const unsigned m = 0u - ((okb >> i) & 1u); *reinterpret_cast<uint4*>(Xs + slot * 16) = make_uint4(xv[i].x & m, xv[i].y & m, xv[i].z & m, xv[i].w & m); }
+            }
+            { const unsigned m = 0u - ((okb >> 8) & 1u); *reinterpret_cast<uint4*>(Ys + tid * 16) = make_uint4(yv.x & m, yv.y & m, yv.z & m, yv.w & m); }
+            __syncthreads();
+        }
+        if (s + 1 < my_tiles) {
+            const int tile = blockIdx.x + (s + 1) * gridDim.x;
+            const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+            const long xin = (long)n * a.x_bs + cgi * 32 + (xch ? q4 * 8 : 0), dyin = (long)n * a.dy_bs + cgo * 32 + (ych ? q4 * 8 : 0);       // element offsets
+            okb = 0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const int pix = min(tid + 256 * i, XSLOTS - 1) >> 2, row = pix / XP, col = pix - row * XP;
+                const int ih = KK == 3 ? 2 * ty * 4 - a.pad + row : 2 * (ty * 4 + row), iw = KK == 3 ? 2 * tx * TW - a.pad + col : 2 * (tx * TW + col);
+                const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && col < PW && xch;
+                okb |= (ok ? 1u : 0u) << i;
+                xv[i] = *reinterpret_cast<const uint4*>(xg + xin + ((long)min(max(ih, 0), a.H - 1) * a.W + min(max(iw, 0), a.W - 1)) * a.x_ps);
+            }
+            {
+                const int pix = tid >> 2, row = pix >> 4, col = pix & 15;
+                const int oy = ty * 4 + row, ox = tx * TW + col;
+                okb |= ((oy < a.Ho && col < TW && ox < a.Wo && ych) ? 1u : 0u) << 8;
+                yv = *reinterpret_cast<const uint4*>(dg + dyin + ((long)min(oy, a.Ho - 1) * a.Wo + min(ox, a.Wo - 1)) * a.dy_ps);
+            }
+        }
+        if (s < 0) continue;
+        // ---- wave w contracts tile row w: its 16 output pixels are one MFMA's K
+        const bf16x8 A = wr_read8(Ys + (wave * 16 + lane_pix) * 64 + lane_ch);
+        if (a.db) {
+            const uint4 av = __builtin_bit_cast(uint4, A);
+            const float4 lo = bf16x4_unpack(make_uint2(av.x, av.y)), hi = bf16x4_unpack(make_uint2(av.z, av.w));
+            bsum += ((lo.x + lo.y) + (lo.z + lo.w)) + ((hi.x + hi.y) + (hi.z + hi.w));
+        }
+        if constexpr (KK == 3) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const char* xb = Xs + ((2 * wave + kh) * XP + 2 * lane_pix) * 64 + lane_ch;          // output pixel k of the row sits at patch pixel 2 k + kw
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const wr_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_ptr)(xb + kw * 64)), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_ptr)(xb + kw * 64 + 512));
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7)), acc[kh * 3 + kw], 0, 0, 0);
+                }
+            }
+        } else acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, wr_read8(Xs + (wave * 16 + lane_pix) * 64 + lane_ch), acc[0], 0, 0, 0);
+    }
+    if (a.db && cgi == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (lp == 0 && cgo * 32 + lcol < a.Cout) atomicAdd(a.db + cgo * 32 + lcol, bsum);
+    }
+    float* red = reinterpret_cast<float*>(wsm);    // [NT*16][64 lanes]
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* dst = red + (t * 16 + e) * 64 + lane;
+                    *dst = w == 0 ? acc[t][e] : *dst + acc[t][e];
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NT * 16 * 64; i += 256) {
+        const int ln = i & 63, e = (i >> 6) & 15, t = i >> 10;
+        const int co = cgo * 32 + (e >> 2) * 8 + (ln >> 5) * 4 + (e & 3), ci = cgi * 32 + (ln & 31);
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((long)co * NT + t) * a.Cin + ci, red[i]);
+    }
+}
 static bool wgrad_taps_bs_aligned(const WgradArgs& a) {          // 16-byte pieces: channel offsets and strides in multiples of 8 bf16 elements
     return a.x_ps % 8 == 0 && a.dy_ps % 8 == 0 && a.x_bs % 8 == 0 && a.dy_bs % 8 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0;
 }
@@ -2091,6 +2195,33 @@ static void launch_wgrad_taps_bs(const WgradArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(conv3x3_wgrad_taps_bs_kernel, dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
 }
 
+static bool wgrad_s2_bs_eligible(const WgradArgs& a) {
+    static const bool off = md2_tune_set("MD2_NO_S2_BS_WGRAD");
+    if (off || a.bf16 != 2 || a.stride != 2 || a.in_scale || a.padmode == PAD_REFLECT || !wgrad_taps_bs_aligned(a) || a.Cin % 16 != 0 || a.Cout % 16 != 0) return false;
+    const bool k3 = a.KH == 3 && a.KW == 3 && a.pad == 1, k1 = a.KH == 1 && a.KW == 1 && a.pad == 0;
+    if (!(k3 || k1) || a.Ho != (a.H + 2 * a.pad - a.KH) / 2 + 1 || a.Wo != (a.W + 2 * a.pad - a.KW) / 2 + 1 || a.Wo < 4) return false;
+    // 32 x 32 weight blocks re-read x once per 32 output channels and dy once per 32 input channels, and every workgroup ends in 36 KB of atomics: the form pays while the weight
+    // matrix is small and a workgroup has tiles to amortise its epilogue over (batch 4 and ResNet-50's 512+-channel layers stay on the 128 x 128 per-tap tiles)
+    const long groups = (long)((a.Cin + 31) / 32) * ((a.Cout + 31) / 32), tiles = (long)a.N * ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
+    return groups <= 128 && tiles >= 8 * std::max<long>(1, 512 / groups);
+}
+template <int KK>
+static void launch_wgrad_s2_bs_t(const WgradArgs& a, hipStream_t s) {
+    const int tiles_x = (a.Wo + 15) / 16;
+    int TW = (a.Wo + tiles_x - 1) / tiles_x; TW = std::min(16, TW + (TW & 1));
+    const int tiles_y = (a.Ho + 3) / 4;
+    constexpr int XR = KK == 3 ? 9 : 4, XP = KK == 3 ? 34 : 16;
+    const size_t lds = (size_t)std::max(4 * 16 * 64 + XR * XP * 64, KK * KK * 16 * 64 * 4);
+    static int per_cu = 0;
+    if (!per_cu) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_s2_bs_kernel<KK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_wgrad_s2_bs_kernel<KK>), 256, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+        per_cu = std::min(per_cu, 2);
+    }
+    const int total = tiles_x * tiles_y * a.N, ci_groups = (a.Cin + 31) / 32, groups = ci_groups * ((a.Cout + 31) / 32);
+    const int gx = g_deterministic ? 1 : std::max(1, std::min(total, 256 * per_cu / groups));
+    hipLaunchKernelGGL((conv_wgrad_s2_bs_kernel<KK>), dim3(gx, groups), dim3(256), lds, s, a, TW, tiles_x, tiles_y, total, ci_groups);
+}
 static bool wgrad_taps32_eligible(const WgradArgs& a) {
     static const int off = md2_tune_set("MD2_NO_TAPS_WGRAD");
     if (off) return false;
@@ -2144,6 +2275,7 @@ void launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     }
     if (wgrad_taps32_eligible(a)) { launch_wgrad_taps32(a, s); return; }
     if (wgrad_patch_eligible(a)) { if (a.Cout == 16) launch_wgrad_patch<1>(a, s); else launch_wgrad_patch<2>(a, s); return; }
+    if (wgrad_s2_bs_eligible(a) && !(g_deterministic && a.db)) { if (a.KH == 3) launch_wgrad_s2_bs_t<3>(a, s); else launch_wgrad_s2_bs_t<1>(a, s); return; }
     if (a.db) { View dyv; dyv.p = const_cast<float*>(a.dy); dyv.N = a.N; dyv.H = a.Ho; dyv.W = a.Wo; dyv.C = a.Cout; dyv.bs = a.dy_bs; dyv.ps = a.dy_ps; dyv.bf = a.bf16 == 2; launch_colsum(dyv, a.db, s); }
     if (a.Cin % 128 == 0 && a.Cout % 128 == 0 && max_t >= 128) launch_wgrad_tile<128, 16, 32>(a, s);
     else if (a.Cin % 64 == 0 && a.Cout % 64 == 0) launch_wgrad_tile<64, 32, 32>(a, s);

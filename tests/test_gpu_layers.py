@@ -42,6 +42,8 @@ CONV_CASES = [
     (1, 16, 33, 35, 16, 3, 1, 0, "reflect"),      # ragged pixel count
     (7, 128, 16, 13, 64, 3, 1, 0, "reflect"),
     (40, 64, 32, 52, 64, 3, 1, 1, "zeros"),       # enough tiles to take the 128-wide tile path
+    (8, 128, 64, 128, 128, 3, 2, 1, "zeros"),     # stride 2 with enough 4 x 16 output tiles per weight block for the transposed-read weight gradient of the bf16 tensors (round 5)
+    (8, 128, 64, 128, 128, 1, 2, 0, "zeros"),     # ... and its 1x1 shortcut
     # large enough (Ho >= 64, Wo >= 128) for the LDS-patch 3x3 kernel (forward, and the input gradient with the channel roles swapped)
     (1, 16, 66, 135, 16, 3, 1, 0, "reflect"),     # decoder branch 5: ragged 8x32 tiles, one channel chunk (weights loaded once)
     (1, 96, 64, 128, 32, 3, 1, 0, "reflect"),     # decoder c2 with skip: 6 channel chunks
