@@ -137,7 +137,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // padded to a 48-B stride that keeps 16 consecutive rows' 16-B reads on distinct banks
     // DL (direct load): global_load_lds writes a wave's 64 x 16 B linearly, so the rows are 16 floats without padding and the bank spread comes from an XOR swizzle of the
     // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
-    constexpr bool DL = XF == 0 && BN == 64 && ((MD2_GLDS != 0 && BF == 0) || BF == 4);          // BF == 4: bf16 tensors with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
+    constexpr bool DL = XF == 0 && ((BN == 64 && MD2_GLDS != 0 && BF == 0) || (BF == 4 && (BN == 64 || BN == 32)));          // BF == 4: bf16 tensors with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
     constexpr bool BLDS = BF == 4;                             // ... through buffer_load_dwordx4 ... lds
     // BF == 2 (bf16 activation storage): x, w (and y, res, dact_src, bz) hold bf16 elements.  A K-step is still 64 BYTES per pixel row -- 32 channels -- so the loader, the masks
     // and the LDS layout below are byte-for-byte those of the fp32 kernel (4 lanes x 16 B per row, 80-B row stride); a lane's 16-B operand read is 8 consecutive channels, which is
@@ -148,7 +148,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     constexpr bool BUFL = MD2_IGEMM_BUFLOAD != 0 && XF == 0 && !DL;
     constexpr unsigned A_OOB = 0xFFFFFFF0u;                    // offset of a masked item: beyond any tensor's byte span (check_igemm_args keeps spans below 2^32 - 32)
     constexpr int ROWF = BF == 1 ? 12 : (DL ? 16 : LDK);
-    constexpr int XS = BM * ROWF, STAGE = (BM + BN) * ROWF;    // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
+    constexpr int BNL = BF == 4 ? 64 : BN;                      // weight rows a stage holds: the LDS loader's four waves write 16 rows each (BN = 32: rows 32 .. 63 repeat rows 0 .. 31, never read)
+    constexpr int XS = BM * ROWF, STAGE = (BM + BNL) * ROWF;   // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave % WP, wc = wave / WP;
@@ -766,7 +767,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 
 // three pipeline stages of (pixel tile + weight tile) rows; the one-tap launches reuse it for their transposed output tile [BM][BN + 4] (or [3][4][256] column sums)
 constexpr int igemm_smem_floats(int BM, int BN, int BF) {
-    const int pipe = 3 * (BM + BN) * (BF == 1 ? 12 : (BF == 4 ? 16 : LDK)), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
+    const int pipe = 3 * (BM + (BF == 4 ? 64 : BN)) * (BF == 1 ? 12 : (BF == 4 ? 16 : LDK)), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
     return pipe > tile ? pipe : tile;
 }
 // (the 128x64 tile runs 3 blocks per CU -- its 46 KB of LDS allow no more -- which needs <= 168 registers incl. the 32 accumulators: the variants with the input
@@ -888,7 +889,7 @@ static bool bs_direct_lds() { static const bool on = md2_tune("MD2_BS_DL", 1) !=
 template <int BM, int BN, int WP, int WC, int MF, int NT, int XF = 0, int BST = 0>
 static void launch_igemm_form(const ConvArgs& a, const dim3& g, hipStream_t s) {
     // bf16 tensors: the direct-to-LDS loader wherever it applies (whole 64-byte channel chunks, no input transform)
-    if (a.bf16 == 2 && bs_direct_lds() && XF == 0 && BN == 64 && MF == 32 && a.Cin % 32 == 0) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (XF == 0 && BN == 64 && MF == 32 ? 4 : 2), XF, BST>), g, dim3(256), 0, s, a);
+    if (a.bf16 == 2 && bs_direct_lds() && XF == 0 && (BN == 64 || BN == 32) && MF == 32 && a.Cin % 32 == 0) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (XF == 0 && (BN == 64 || BN == 32) && MF == 32 ? 4 : 2), XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 2, XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 0 && a.split3 && MF == 32 && BN == 64 && WP == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 && BN == 64 && WP == 2 ? 3 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 1 && MF == 32) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 ? 1 : 0), XF, BST>), g, dim3(256), 0, s, a);
