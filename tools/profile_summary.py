@@ -11,7 +11,7 @@ import csv, glob, os, sys, collections
 
 def klass(name):
     # the classes bench.py's HIP-event profile uses: forward + input-gradient convolutions / weight gradients (incl. the direct stem kernels)
-    if "conv_wgrad_kernel" in name or "conv_wino_wgrad" in name or "conv3x3_wgrad" in name or "stem_wgrad_" in name:
+    if "conv_wgrad_kernel" in name or "conv_wgrad_s2_bs_kernel" in name or "conv_wino_wgrad" in name or "conv3x3_wgrad" in name or "stem_wgrad_" in name:
         return "conv_wgrad"
     if "conv_igemm" in name or "conv_wino" in name or "conv3x3_patch_kernel" in name or "stem_fwd_kernel" in name:
         return "conv_igemm"
