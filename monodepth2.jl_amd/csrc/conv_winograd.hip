@@ -1609,7 +1609,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_wgrad_s_kernel(WgradArgs a, 
     const int lr = lane & 31, g8 = (lane >> 5) * 8;
     const int xo1 = r1 * WPS * 32 + lr, xo2 = r2 * WPS * 32 + lr;          // + the tile's slot offset xoff(t) + column b * 32
     // slot offset (in floats) of tile t = g8 + i of the batch: segment t / TW, tile column t % TW (one segment: 2 t slots)
-    auto xoff = [&](const int i) { const int t = g8 + i, seg = (RB > 1 && t >= TW) ? fdiv24(t, TW) : 0; return (seg * 4 * WPS + 2 * (t - seg * TW)) * 32; };
+    // (row-packed batches hold RB * TW <= 16 tiles in at most 160 patch slots: a tile index past them -- the MFMA's K is always 16 -- must not be turned into a slot, it would
+    //  point past the patch region and, for the second stage, past the workgroup's LDS; its dy is zero, any staged patch will do: the last real tile's)
+    auto xoff = [&](const int i) { const int t = RB > 1 ? min(g8 + i, RB * TW - 1) : g8 + i, seg = (RB > 1 && t >= TW) ? fdiv24(t, TW) : 0; return (seg * 4 * WPS + 2 * (t - seg * TW)) * 32; };
     const int dyo = WG_XF + (g8 * 4) * 32 + lr;                                                      // + tile t * 4 pixel rows + px * 32
     typedef wbf16x8 b8_t;
     auto cat8 = [](const unsigned (&v)[4]) { return __builtin_bit_cast(b8_t, (wu32x4){v[0], v[1], v[2], v[3]}); };

@@ -851,9 +851,9 @@ def test_deterministic_mode_is_bit_reproducible(depth):
 @pytest.mark.parametrize("precision", ["f32", "bf16_storage"])
 def test_bit_reproducible_mode_repeats_on_one_handle(precision):
     """Six steps of ONE handle in the bit-reproducible mode, three streams at work: every gradient vector equals the first and is finite.  The shape (15 frames of 64 x 64: 2 x 2
-    maps at 1/32 scale, ragged pixel tiles, padding taps that outnumber the real ones) is the one on which a loader experiment of round 5 -- buffer_load ... lds in the exact-split
-    implicit GEMM of the fp32 tensors, running beside the Winograd kernels -- returned non-finite weight gradients in 11 steps of 12 while every single-launch parity test passed
-    (DESIGN.md section 4); the bf16-tensor mode keeps that loader and is held to the same check."""
+    maps at 1/32 scale, row-packed Winograd weight-gradient batches, ragged pixel tiles, padding taps that outnumber the real ones) is the one on which round 5 found the
+    row-packed exact-split Winograd weight gradient reading LDS past its allocation: harmless beside most neighbours, non-finite weight gradients in 11 steps of 12 beside a
+    kernel that leaves other bit patterns there -- while every single-launch parity test passed.  Both tensor modes are held to the same check."""
     N, C, H, W = 5, 3, 64, 64
     model, params, cache, theta, K, iK = make(N, C, H, W, pseed=21, precision=precision)
     x = dev(syn.synthetic_triplets(N, C, H, W, seed=22))
