@@ -10,7 +10,7 @@ params = md.Params(target_size=(W, H), batch_size=N, automasking=False)
 cache = md.TrainCache(md.SSIM(), md.Backproject(W, H), md.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
 enc = md.ResidualNetwork(18, in_channels=C)
 model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(512), precision=os.environ.get('NANPROBE_PRECISION', 'f32'))
-model.load_params(syn.init_params(C, seed=21))
+model.load_params(syn.init_params(C, seed=21, randomize_affine=bool(os.environ.get('NANPROBE_AFFINE'))))
 x = torch.from_numpy(syn.synthetic_triplets(N, C, H, W, seed=22)).cuda()
 layout = syn.param_layout(C)
 if os.environ.get('NANPROBE_WINO'): md.set_winograd(*[int(v) for v in os.environ['NANPROBE_WINO'].split(',')])
