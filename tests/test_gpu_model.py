@@ -874,6 +874,37 @@ def test_bit_reproducible_mode_repeats_on_one_handle(precision):
         assert np.linalg.norm(g - ref) / np.linalg.norm(ref) < (2e-3 if precision == "f32" else 0.6)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16_storage"])
+def test_step_is_immune_to_foreign_lds_contents(precision):
+    """LDS is not cleared between workgroups: whatever a neighbour left there is what a kernel reads if it reads LDS it never wrote, or past its allocation -- and 0 x NaN is NaN.
+    While a second stream keeps launching a kernel that fills LDS with NaN / Inf bit patterns (tests/native/lds_poison.hip, built by __graft_entry__.build()), steps in the
+    bit-reproducible mode must stay finite and equal the quiet step bit for bit.  On the library as it stood before round 5's fix of the row-packed exact-split Winograd weight
+    gradient, this test returns non-finite gradients in every step of the first shape (tools/poison_probe.py)."""
+    import ctypes
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native", "liblds_poison.so")
+    assert os.path.exists(so), "tests/native/liblds_poison.so is missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(so)
+    lib.lds_poison_launch.restype = ctypes.c_int32
+    lib.lds_poison_launch.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_uint32, ctypes.c_void_p]
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda"); side = torch.cuda.Stream()
+    for (N, C, H, W) in ((5, 3, 64, 64), (2, 1, 128, 416)):
+        model, params, cache, theta, K, iK = make(N, C, H, W, pseed=21, precision=precision)
+        x = dev(syn.synthetic_triplets(N, C, H, W, seed=22))
+        md().set_deterministic(True)
+        try:
+            md().train_step(model, x, None, cache, params, do_update=False); ref = model.grads().copy(); torch.cuda.synchronize()
+            assert np.isfinite(ref).all()
+            for kb, pattern in ((24, 0x7FC00000), (48, 0xFFFFFFFF), (8, 0x7F800000)):
+                for r in range(3):
+                    assert lib.lds_poison_launch(ctypes.c_void_p(side.cuda_stream), 1500, 512, kb, pattern, ctypes.c_void_p(sink.data_ptr())) == 0
+                    md().train_step(model, x, None, cache, params, do_update=False); g = model.grads(); torch.cuda.synchronize()
+                    assert np.isfinite(g).all(), "%dx%d, LDS pattern %08x: non-finite gradient" % (W, H, pattern)
+                    assert np.array_equal(g, ref), "%dx%d, LDS pattern %08x: the step depends on foreign LDS contents" % (W, H, pattern)
+        finally:
+            md().set_deterministic(False)
+        model.close()
+
+
 def test_testmode_eval_and_bn_running_statistics_vs_oracle(tmp_path):
     """Flux.testmode! (what eval_image / eval_video run, src/Monodepth.jl:209,237): train-mode passes track the BatchNorm mu / sigma^2, test-mode
     eval_disparity normalises with them (n = 1 frame included), and the statistics travel with the checkpoint."""
