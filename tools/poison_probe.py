@@ -1,5 +1,5 @@
 """A training step while a second stream keeps filling LDS with NaN bit patterns (tests/native/lds_poison.hip): finite gradients, equal to the quiet step in bit-reproducible mode?
-usage: poison_probe.py N C H W [precision] [reps]"""
+usage: poison_probe.py N C H W [precision] [reps]     env: PP_DEPTH=50, PP_PRODUCTS="f,w" (md2_set_conv_products), PP_WINO="on,min_blocks" (md2_set_winograd)"""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,12 +12,15 @@ lib.lds_poison_launch.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int3
 K, iK = syn.depth10k_intrinsics(W, H)
 params = md.Params(target_size=(W, H), batch_size=N, automasking=False)
 cache = md.TrainCache(md.SSIM(), md.Backproject(W, H), md.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
-enc = md.ResidualNetwork(18, in_channels=C)
-model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(512), precision=prec)
-model.load_params(syn.init_params(C, seed=21, randomize_affine=True))
+depth = int(os.environ.get('PP_DEPTH', '18'))
+enc = md.ResidualNetwork(depth, in_channels=C)
+model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), precision=prec)
+model.load_params(syn.init_params(C, seed=21, randomize_affine=True, depth=depth))
+if os.environ.get('PP_PRODUCTS'): md.set_conv_products(*[int(v) for v in os.environ['PP_PRODUCTS'].split(',')])
+if os.environ.get('PP_WINO'): md.set_winograd(*[int(v) for v in os.environ['PP_WINO'].split(',')])
 x = torch.from_numpy(syn.synthetic_triplets(N, C, H, W, seed=22)).cuda()
 sink = torch.zeros(4, dtype=torch.int32, device="cuda"); side = torch.cuda.Stream()
-layout = syn.param_layout(C)
+layout = syn.param_layout(C, depth=depth)
 md.set_deterministic(True)
 try:
     md.train_step(model, x, None, cache, params, do_update=False); ref = model.grads().copy(); torch.cuda.synchronize()
@@ -34,6 +37,6 @@ try:
                     off += n
                 print("   rep %d non-finite arrays: %s" % (r, names[:8]), flush=True)
             elif not np.array_equal(g, ref): diff += 1
-        print("%s N=%d %dx%d: poison %d KB pattern %08x: %d reps, %d non-finite, %d differing from the quiet step" % (prec, N, W, H, kb, pattern, reps, bad, diff), flush=True)
+        print("%s depth %d products %s wino %s N=%d %dx%d: poison %d KB pattern %08x: %d reps, %d non-finite, %d differing from the quiet step" % (prec, depth, os.environ.get('PP_PRODUCTS', 'default'), os.environ.get('PP_WINO', 'default'), N, W, H, kb, pattern, reps, bad, diff), flush=True)
 finally:
     md.set_deterministic(False)
