@@ -126,7 +126,7 @@ __device__ __forceinline__ void wg_split3_pk(float a, float b, unsigned& hi, uns
 // applied on the way from the global load into LDS, so that activation is never written to (or read from) HBM
 // BST: 1 = the epilogue also reduces the BatchNorm-pullback sums of its output (a.bst); a template parameter because its 48 partial-sum registers would otherwise
 // raise the register count of every instantiation
-template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0, int XF = 0, int BST = 0>
+template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0, int XF = 0, int BST = 0, int DRAIN = 0>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __restrict__ smem, const int block_x, const int nblocks_x) {
     constexpr int TP = BM / WP / MF, TC = BN / WC / MF;       // MFMA tiles per wave (pixels x channels)
     constexpr int NV = MF == 32 ? 4 : 1;                       // float4 groups per accumulator tile
@@ -138,7 +138,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // DL (direct load): global_load_lds writes a wave's 64 x 16 B linearly, so the rows are 16 floats without padding and the bank spread comes from an XOR swizzle of the
     // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
     constexpr bool DL = XF == 0 && ((BN == 64 && MD2_GLDS != 0 && BF == 0) || (BF == 4 && (BN == 64 || BN == 32)));          // BF == 4: bf16 tensors with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
-    constexpr bool BLDS = BF == 4;                             // ... through buffer_load_dwordx4 ... lds
+    constexpr bool BLDS = BF == 4;
+    // LDS loads still in flight when a step ends: the newest step's (counted wait) -- or none in the merged residue-class kernel (DRAIN): the one instantiation in which the
+    // counted wait of the unshipped exact-split form of this loader gave run-to-run differences; five short launches per step, < 0.3 % of it
+    constexpr int DLW = DRAIN ? 0 : A_LD + B_LD;                             // ... through buffer_load_dwordx4 ... lds
     // BF == 2 (bf16 activation storage): x, w (and y, res, dact_src, bz) hold bf16 elements.  A K-step is still 64 BYTES per pixel row -- 32 channels -- so the loader, the masks
     // and the LDS layout below are byte-for-byte those of the fp32 kernel (4 lanes x 16 B per row, 80-B row stride); a lane's 16-B operand read is 8 consecutive channels, which is
     // what v_mfma_f32_32x32x16_bf16 (2 per tile pair and step) / v_mfma_f32_16x16x32_bf16 (1) take.  Cin == 16 (the full-resolution decoder layers): a step's row is TWO filter
@@ -485,7 +488,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         if constexpr (NT >= 3) { gload_dl(1, 0, o1); gload_dl(2, 0, o2); }
         else if constexpr (NT == 2) { gload_dl(1, 0, o1); gload_dl(0, min(1, cpt - 1) << 4, o2); }
         else { gload_dl(0, min(1, cpt - 1) << 4, o1); gload_dl(0, min(2, cpt - 1) << 4, o2); }
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD + B_LD) : "memory");      // steps 0 and 1 have landed, step 2 may still be in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DLW) : "memory");      // steps 0 and 1 have landed, step 2 may still be in flight
         __builtin_amdgcn_s_barrier();
         read_ops(o0, cur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -518,7 +521,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 if (!(abl & 1)) gload_dl(last3 ? NT - 1 : t3, c3 << 4, o0);
                 if (!(abl & 2)) read_ops(o1, nxt);
                 if (!(abl & 4)) mfmas(cur);
-                if (!(abl & 8)) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD + B_LD) : "memory"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                if (!(abl & 8)) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DLW) : "memory"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
                 cur = nxt;
                 { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
                 continue;
@@ -545,7 +548,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 if (MD2_SETPRIO) __builtin_amdgcn_s_setprio(1);
                 mfmas(cur);
                 if (MD2_SETPRIO) __builtin_amdgcn_s_setprio(0);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(A_LD + B_LD) : "memory");          // step s+2's tiles (issued one step ago) have landed; step s+3's stay in flight
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DLW) : "memory");          // step s+2's tiles (issued one step ago) have landed; step s+3's stay in flight
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 cur = nxt;
@@ -788,9 +791,9 @@ __global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_cl
     const int cls = b < k.first[1] ? 0 : (b < k.first[2] ? 1 : (b < k.first[3] ? 2 : 3));
     const int bx = b - k.first[cls], nb = k.first[cls + 1] - k.first[cls];
     switch (k.c[cls].nkh * k.c[cls].nkw) {
-        case 1: conv_igemm_body<BM, BN, WP, WC, MF, 1, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
-        case 2: conv_igemm_body<BM, BN, WP, WC, MF, 2, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
-        default: conv_igemm_body<BM, BN, WP, WC, MF, 4, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
+        case 1: conv_igemm_body<BM, BN, WP, WC, MF, 1, BF, 0, BST, 1>(k.c[cls], smem, bx, nb); break;
+        case 2: conv_igemm_body<BM, BN, WP, WC, MF, 2, BF, 0, BST, 1>(k.c[cls], smem, bx, nb); break;
+        default: conv_igemm_body<BM, BN, WP, WC, MF, 4, BF, 0, BST, 1>(k.c[cls], smem, bx, nb); break;
     }
 }
 
