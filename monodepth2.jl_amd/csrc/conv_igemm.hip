@@ -137,8 +137,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // padded to a 48-B stride that keeps 16 consecutive rows' 16-B reads on distinct banks
     // DL (direct load): global_load_lds writes a wave's 64 x 16 B linearly, so the rows are 16 floats without padding and the bank spread comes from an XOR swizzle of the
     // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
-    constexpr bool DL = XF == 0 && ((BN == 64 && MD2_GLDS != 0 && BF == 0) || (BF == 4 && (BN == 64 || BN == 32)));          // BF == 4: bf16 tensors with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
-    constexpr bool BLDS = BF == 4;
+    constexpr bool DL = XF == 0 && ((BN == 64 && MD2_GLDS != 0 && BF == 0) || (BF == 4 && (BN == 64 || BN == 32)) || (BF == 5 && BN == 64));          // BF == 4: bf16 tensors with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
+    constexpr bool BLDS = BF == 4 || BF == 5;
     // LDS loads still in flight when a step ends: the newest step's (counted wait) -- or none in the merged residue-class kernel (DRAIN): the one instantiation in which the
     // counted wait of the unshipped exact-split form of this loader gave run-to-run differences; five short launches per step, < 0.3 % of it
     constexpr int DLW = DRAIN ? 0 : A_LD + B_LD;                             // ... through buffer_load_dwordx4 ... lds
@@ -151,7 +151,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     constexpr bool BUFL = MD2_IGEMM_BUFLOAD != 0 && XF == 0 && !DL;
     constexpr unsigned A_OOB = 0xFFFFFFF0u;                    // offset of a masked item: beyond any tensor's byte span (check_igemm_args keeps spans below 2^32 - 32)
     constexpr int ROWF = BF == 1 ? 12 : (DL ? 16 : LDK);
-    constexpr int BNL = BF == 4 ? 64 : BN;                      // weight rows a stage holds: the LDS loader's four waves write 16 rows each (BN = 32: rows 32 .. 63 repeat rows 0 .. 31, never read)
+    constexpr int BNL = BLDS ? 64 : BN;                      // weight rows a stage holds: the LDS loader's four waves write 16 rows each (BN = 32: rows 32 .. 63 repeat rows 0 .. 31, never read)
     constexpr int XS = BM * ROWF, STAGE = (BM + BNL) * ROWF;   // floats: pixel tile, then weight tile, per pipeline stage (smem holds 3 stages)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -413,7 +413,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, o.w[i][jj]), __builtin_bit_cast(bf16x8, o.x[j][jj]), acc[i][j], 0, 0, 0);
                     }
             return;
-        } else if constexpr (BF == 3 && MF == 32) {
+        } else if constexpr ((BF == 3 || BF == 5) && MF == 32) {
             // the lane's 8 k-values of a 32-row tile (its two 16-byte reads: k = 4h .. 4h+3 and 8 + 4h .. 8 + 4h+3) as hi / mid / lo bf16x8 -- both operands use the same
             // lane -> k assignment, so the MFMA's own k order does not matter; each operand tile is split once and serves all its tile pairs
             unsigned wq[TC][3][4], xq[TP][3][4];
@@ -770,7 +770,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
 
 // three pipeline stages of (pixel tile + weight tile) rows; the one-tap launches reuse it for their transposed output tile [BM][BN + 4] (or [3][4][256] column sums)
 constexpr int igemm_smem_floats(int BM, int BN, int BF) {
-    const int pipe = 3 * (BM + (BF == 4 ? 64 : BN)) * (BF == 1 ? 12 : (BF == 4 ? 16 : LDK)), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
+    const int pipe = 3 * (BM + ((BF == 4 || BF == 5) ? 64 : BN)) * (BF == 1 ? 12 : ((BF == 4 || BF == 5) ? 16 : LDK)), tile = BM * (BN + 4) > 3072 ? BM * (BN + 4) : 3072;
     return pipe > tile ? pipe : tile;
 }
 // (the 128x64 tile runs 3 blocks per CU -- its 46 KB of LDS allow no more -- which needs <= 168 registers incl. the 32 accumulators: the variants with the input
@@ -887,6 +887,7 @@ static void bst_fallback(const ConvArgs& a, hipStream_t s) {
     if (a.bstB) { View zb = g; zb.p = const_cast<float*>(a.bzB); zb.bs = a.bzB_bs; zb.ps = a.bzB_ps; launch_bn_bwd_reduce(g, nullptr, ACT_NONE, zb, a.bstatB, a.bstB, s); }
 }
 
+static bool split_direct_lds() { static const bool on = md2_tune("MD2_SPLIT_DL", 1) != 0; return on; }
 static bool bs_direct_lds() { static const bool on = md2_tune("MD2_BS_DL", 1) != 0; return on; }
 // operand / storage form of a launch: ConvArgs::bf16 = 0 fp32 MFMA, 1 bf16 operands from fp32 tensors (32-wide tiles only), 2 bf16 tensors
 template <int BM, int BN, int WP, int WC, int MF, int NT, int XF = 0, int BST = 0>
@@ -894,6 +895,7 @@ static void launch_igemm_form(const ConvArgs& a, const dim3& g, hipStream_t s) {
     // bf16 tensors: the direct-to-LDS loader wherever it applies (whole 64-byte channel chunks, no input transform)
     if (a.bf16 == 2 && bs_direct_lds() && XF == 0 && (BN == 64 || BN == 32) && MF == 32 && a.Cin % 32 == 0) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (XF == 0 && (BN == 64 || BN == 32) && MF == 32 ? 4 : 2), XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 2, XF, BST>), g, dim3(256), 0, s, a);
+    else if (a.bf16 == 0 && a.split3 && MF == 32 && BN == 64 && WP == 2 && XF == 0 && split_direct_lds()) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 && BN == 64 && WP == 2 && XF == 0 ? 5 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 0 && a.split3 && MF == 32 && BN == 64 && WP == 2) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 && BN == 64 && WP == 2 ? 3 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else if (a.bf16 == 1 && MF == 32) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, (MF == 32 ? 1 : 0), XF, BST>), g, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WP, WC, MF, NT, 0, XF, BST>), g, dim3(256), 0, s, a);
@@ -1143,12 +1145,14 @@ static void launch_classes_t(ConvClasses& k, int n, hipStream_t s) {
     for (int i = n; i < 4; ++i) k.c[i] = k.c[0];
     const bool sp3 = k.c[0].bf16 == 0 && k.c[0].split3, dl = k.c[0].bf16 == 2 && bs_direct_lds() && k.c[0].Cin % 32 == 0;
     if (k.c[0].bst) {
-        if (sp3) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 3, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+        if (sp3 && split_direct_lds()) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 5, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
+        else if (sp3) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 3, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else if (k.c[0].bf16 == 2 && dl) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 4, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
         else hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 0, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
-    } else if (sp3) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 3>), dim3(k.first[4]), dim3(256), 0, s, k);
+    } else if (sp3 && split_direct_lds()) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 5>), dim3(k.first[4]), dim3(256), 0, s, k);
+    else if (sp3) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 3>), dim3(k.first[4]), dim3(256), 0, s, k);
     else if (k.c[0].bf16 == 2 && dl) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 4>), dim3(k.first[4]), dim3(256), 0, s, k);
     else if (k.c[0].bf16 == 2) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 2>), dim3(k.first[4]), dim3(256), 0, s, k);
     else if (k.c[0].bf16) hipLaunchKernelGGL((conv_igemm_classes_kernel<BM, 64, 2, 2, 32, 1>), dim3(k.first[4]), dim3(256), 0, s, k);
@@ -1158,8 +1162,9 @@ static void launch_classes(ConvClasses& k, int n, hipStream_t s) {
     long tiles128 = 0;
     for (int i = 0; i < n; ++i) { check_igemm_args(k.c[i]); tiles128 += (k.c[i].M + 127) / 128; }
     static const long big = md2_tune("MD2_IGEMM_BIG_TILES", (1L << 40));          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
-    static const long bs_big = md2_tune("MD2_BS_BIG_TILES", 256);
-    const bool bs128 = k.c[0].bf16 == 2 && bs_direct_lds() && k.c[0].Cin % 32 == 0 && tiles128 * (k.c[0].Cout / 64) >= bs_big;
+    static const long bs_big = md2_tune("MD2_BS_BIG_TILES", 256), sp_big = md2_tune("MD2_SPLIT_BIG_TILES", 1400);
+    const bool bs128 = (k.c[0].bf16 == 2 && bs_direct_lds() && k.c[0].Cin % 32 == 0 && tiles128 * (k.c[0].Cout / 64) >= bs_big) ||
+                       (k.c[0].bf16 == 0 && k.c[0].split3 && split_direct_lds() && tiles128 * (k.c[0].Cout / 64) >= sp_big);
     if (bs128 || tiles128 * (k.c[0].Cout / 64) >= big) launch_classes_t<128>(k, n, s); else launch_classes_t<64>(k, n, s);
 }
 
@@ -1271,9 +1276,12 @@ static void launch_conv_igemm_one(const ConvArgs& a_in, hipStream_t s) {
     // 64x64 tiles (5 blocks per CU) balance the 256 CUs better than 128x64 (3 per CU) on every encoder layer at batch 32 (624 .. 2496 tiles: 1.6 .. 3.25 rounds of 768
     // resident 128x64 blocks) and are never slower there (tools/conv_bench, round 2: 87.8 / 92.5 / 93.5 / 81.2 vs 87.2 / 91.4 / 85.2 / 65.1 TFLOP/s on the four stage shapes)
     static const long big = md2_tune("MD2_IGEMM_BIG_TILES", (1L << 40));          // 128x64 tiles only on request: no faster on the ResNet-50 1x1 layers either (38.5 vs 38.3 ms per step at 640x192, batch 16)
-    // bf16 tensors with the direct-to-LDS loader (no staging registers, loads three steps ahead): 128 x 64 tiles are ahead from about one tile per CU on (round 5, tools/run_bs_igemm_bench.sh)
-    static const long bs_big = md2_tune("MD2_BS_BIG_TILES", 256);
-    const bool bs128 = a.bf16 == 2 && bs_direct_lds() && !a.in_scale && a.Cin % 32 == 0 && tiles128 * (a.Cout / 64) * a.ksplit >= bs_big;
+    // the direct-to-LDS loader (no staging registers, loads three steps ahead) makes 128 x 64 tiles pay: bf16 tensors from about one tile per CU on, the exact-split form of the
+    // fp32 tensors from ~1400 tiles (~700 for one tap) on (round 5, tools/run_bs_igemm_bench.sh, profiles/r05_split_lds_loader_bench.txt)
+    static const long bs_big = md2_tune("MD2_BS_BIG_TILES", 256), sp_big = md2_tune("MD2_SPLIT_BIG_TILES", 1400);
+    const long nblk128 = tiles128 * (a.Cout / 64) * a.ksplit;
+    const bool bs128 = (a.bf16 == 2 && bs_direct_lds() && !a.in_scale && a.Cin % 32 == 0 && nblk128 >= bs_big) ||
+                       (a.bf16 == 0 && a.split3 && split_direct_lds() && !a.in_scale && nblk128 >= (a.nkh * a.nkw == 1 ? sp_big / 2 : sp_big));
     if (a.Cout % 64 == 0) { if (bs128 || tiles128 * (a.Cout / 64) >= big) launch_tile<128, 64, 2, 2, 32>(a, s); else launch_tile<64, 64, 2, 2, 32>(a, s); }
     else if (a.Cout % 32 == 0) { if (tiles128 >= 2048) launch_tile<256, 32, 4, 1, 32>(a, s); else if (tiles128 >= 384) launch_tile<128, 32, 4, 1, 32>(a, s); else launch_tile<64, 32, 2, 1 * 2, 16>(a, s); }
     else { if (tiles128 >= 2048) launch_tile<256, 16, 4, 1, 16>(a, s); else if (tiles128 >= 384) launch_tile<128, 16, 4, 1, 16>(a, s); else launch_tile<64, 16, 4, 1, 16>(a, s); }
