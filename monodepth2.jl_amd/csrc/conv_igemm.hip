@@ -122,7 +122,7 @@ __device__ __forceinline__ void wg_split3_pk(float a, float b, unsigned& hi, uns
 }
 // BF: 0 fp32 MFMA, 1 bf16 operands (mixed precision), 2 bf16 tensors, 3 (round 5) fp32 tensors with every product formed from the exact three-bf16-piece split of both
 // operand fragments (six v_mfma_f32_32x32x16_bf16 per 16-channel K-step and tile pair instead of eight v_mfma_f32_32x32x2_f32: fp32-MFMA accuracy, 192 instead of 512 matrix-pipe
-// cycles, beside the other waves' vector work) -- loader, LDS layout and epilogue are the fp32 kernel's, only the operand reads' way into the matrix pipe differs.  XF: 1 = the pixel operand is relu(x * in_scale[ci] + in_shift[ci]) -- the producer's BatchNorm + ReLU
+// cycles, beside the other waves' vector work) -- loader, LDS layout and epilogue are the fp32 kernel's, only the operand reads' way into the matrix pipe differs; 4 / 5 = forms 2 / 3 with the operand tiles loaded by buffer_load_dwordx4 ... lds (32-bit offsets, zeros for padding from the range check, no staging registers, three steps ahead; launches without the input transform).  XF: 1 = the pixel operand is relu(x * in_scale[ci] + in_shift[ci]) -- the producer's BatchNorm + ReLU
 // applied on the way from the global load into LDS, so that activation is never written to (or read from) HBM
 // BST: 1 = the epilogue also reduces the BatchNorm-pullback sums of its output (a.bst); a template parameter because its 48 partial-sum registers would otherwise
 // raise the register count of every instantiation
@@ -137,10 +137,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // padded to a 48-B stride that keeps 16 consecutive rows' 16-B reads on distinct banks
     // DL (direct load): global_load_lds writes a wave's 64 x 16 B linearly, so the rows are 16 floats without padding and the bank spread comes from an XOR swizzle of the
     // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
-    constexpr bool DL = XF == 0 && ((BN == 64 && MD2_GLDS != 0 && BF == 0) || (BF == 4 && (BN == 64 || BN == 32)) || (BF == 5 && BN == 64));          // BF == 4: bf16 tensors with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
+    constexpr bool DL = XF == 0 && ((BN == 64 && MD2_GLDS != 0 && BF == 0) || (BF == 4 && (BN == 64 || BN == 32)) || (BF == 5 && BN == 64));          // BF == 4 / 5: the bf16-tensor / exact-split forms with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
     constexpr bool BLDS = BF == 4 || BF == 5;
     // LDS loads still in flight when a step ends: the newest step's (counted wait) -- or none in the merged residue-class kernel (DRAIN): the one instantiation in which the
-    // counted wait of the unshipped exact-split form of this loader gave run-to-run differences; five short launches per step, < 0.3 % of it
+    // counted wait gave run-to-run differences in bit-reproducible mode (exact-split form); five short launches per step, no measurable cost
     constexpr int DLW = DRAIN ? 0 : A_LD + B_LD;                             // ... through buffer_load_dwordx4 ... lds
     // BF == 2 (bf16 activation storage): x, w (and y, res, dact_src, bz) hold bf16 elements.  A K-step is still 64 BYTES per pixel row -- 32 channels -- so the loader, the masks
     // and the LDS layout below are byte-for-byte those of the fp32 kernel (4 lanes x 16 B per row, 80-B row stride); a lane's 16-B operand read is 8 consecutive channels, which is
