@@ -126,7 +126,7 @@ __device__ __forceinline__ void wg_split3_pk(float a, float b, unsigned& hi, uns
 // applied on the way from the global load into LDS, so that activation is never written to (or read from) HBM
 // BST: 1 = the epilogue also reduces the BatchNorm-pullback sums of its output (a.bst); a template parameter because its 48 partial-sum registers would otherwise
 // raise the register count of every instantiation
-template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0, int XF = 0, int BST = 0, int DRAIN = 0>
+template <int BM, int BN, int WP, int WC, int MF, int NT, int BF = 0, int XF = 0, int BST = 0>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __restrict__ smem, const int block_x, const int nblocks_x) {
     constexpr int TP = BM / WP / MF, TC = BN / WC / MF;       // MFMA tiles per wave (pixels x channels)
     constexpr int NV = MF == 32 ? 4 : 1;                       // float4 groups per accumulator tile
@@ -139,9 +139,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     // 16-B chunk index with bits 2..3 of the row -- applied to the SOURCE address by the loader and to the read address by the MFMA operand reads
     constexpr bool DL = XF == 0 && ((BN == 64 && MD2_GLDS != 0 && BF == 0) || (BF == 4 && (BN == 64 || BN == 32)) || (BF == 5 && BN == 64));          // BF == 4 / 5: the bf16-tensor / exact-split forms with the direct-to-LDS loader (whole 64-byte chunks, no input transform)
     constexpr bool BLDS = BF == 4 || BF == 5;
-    // LDS loads still in flight when a step ends: the newest step's (counted wait) -- or none in the merged residue-class kernel (DRAIN): the one instantiation in which the
-    // counted wait gave run-to-run differences in bit-reproducible mode (exact-split form); five short launches per step, no measurable cost
-    constexpr int DLW = DRAIN ? 0 : A_LD + B_LD;                             // ... through buffer_load_dwordx4 ... lds
+    // LDS loads still in flight when a step ends: the newest step's (counted wait).  Round 5 shipped a full drain in the merged residue-class kernel because the counted wait
+    // "gave run-to-run differences" there; round 6 found the cause in the ISA and it is not the wait: see lds_wait_reads / pin_stage_offsets below
+    constexpr int DLW = A_LD + B_LD;                                         // ... through buffer_load_dwordx4 ... lds
     // BF == 2 (bf16 activation storage): x, w (and y, res, dact_src, bz) hold bf16 elements.  A K-step is still 64 BYTES per pixel row -- 32 channels -- so the loader, the masks
     // and the LDS layout below are byte-for-byte those of the fp32 kernel (4 lanes x 16 B per row, 80-B row stride); a lane's 16-B operand read is 8 consecutive channels, which is
     // what v_mfma_f32_32x32x16_bf16 (2 per tile pair and step) / v_mfma_f32_16x16x32_bf16 (1) take.  Cin == 16 (the full-resolution decoder layers): a step's row is TWO filter
@@ -481,6 +481,28 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
     int o0 = 0, o1 = STAGE, o2 = 2 * STAGE;
     Ops cur, nxt;
     xf_load(0);
+    // ---- ordering of the direct-to-LDS pipeline against the COMPILER (round 6; the root cause of round 5's "race of unknown cause").  The pipeline synchronises with a raw
+    // s_barrier (a __syncthreads() would drain the LDS loads in flight) -- and llvm.amdgcn.s.barrier is declared IntrNoMem: without the fences of __syncthreads() nothing keeps
+    // hipcc from moving a PLAIN LDS load across it, and it does move them across the `asm volatile("s_waitcnt ..." ::: "memory")` beside it as well.  Seen in the ISA of
+    // conv_igemm_classes_kernel<64, 64, ..., BF = 5> built with the counted wait: the four ds_read_b128 of the prologue's read_ops(o0, cur) sat BEHIND the second prologue
+    // barrier (sunk into the loop preheader, past the cpt > 0 branch), i.e. behind the point from which faster waves overwrite stage 0 with step 3's tiles: a WAR race on LDS,
+    // open only while a wave is held up for the ~500 cycles of a load's flight (two streams, a long merged kernel).  The build with the drain happened not to sink them.
+    // Two data dependences make the order independent of what the optimiser believes about LDS:
+    //   * pin_stage_offsets(): behind every barrier the stage offsets pass through an empty asm -- the addresses of the reads (and the M0 of the LDS loads) that follow are
+    //     computed from its outputs, so none of them can be issued ahead of the barrier;
+    //   * lds_wait_reads(o): the s_waitcnt lgkmcnt(0) in front of a barrier takes the operand registers just read as in/out operands -- the reads cannot sink below it, and
+    //     the MFMAs that consume them cannot rise above it (guide rule: register-only MFMAs are hoisted past a bare inline-asm wait).
+    // tests/test_host_and_abi.py::test_lds_pipeline_order_in_the_isa checks both orders in the disassembly of every kernel that issues LDS loads.
+    auto pin_stage_offsets = [&]() { asm volatile("" : "+s"(o0), "+s"(o1), "+s"(o2)); };
+    auto lds_wait_reads = [&](Ops& o) {
+        if constexpr (BF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else {
+            static_assert(BF == 1 || (TC == 1 && NJ == 2 && (TP == 1 || TP == 2)) || !DL, "lds_wait_reads: operand set of this tile is not listed");
+            if constexpr (TC == 1 && NJ == 2 && TP == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.w[0][0]), "+v"(o.w[0][1]), "+v"(o.x[0][0]), "+v"(o.x[0][1]) :: "memory");
+            else if constexpr (TC == 1 && NJ == 2 && TP == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.w[0][0]), "+v"(o.w[0][1]), "+v"(o.x[0][0]), "+v"(o.x[0][1]), "+v"(o.x[1][0]), "+v"(o.x[1][1]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
     if constexpr (DL) {
         // three stages, loads THREE steps ahead: the tile of step s+3 is issued at the top of step s into the stage step s was read from, and only the loads issued
         // one step earlier are waited for before the barrier (counted vmcnt, raw s_barrier) -- a global load has two MFMA clusters to land instead of one
@@ -490,9 +512,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
         else { gload_dl(0, min(1, cpt - 1) << 4, o1); gload_dl(0, min(2, cpt - 1) << 4, o2); }
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DLW) : "memory");      // steps 0 and 1 have landed, step 2 may still be in flight
         __builtin_amdgcn_s_barrier();
+        pin_stage_offsets();
         read_ops(o0, cur);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_wait_reads(cur);
         __builtin_amdgcn_s_barrier();                        // everybody has read stage 0 before step 0 re-targets it
+        pin_stage_offsets();
     } else {
     gload(0, 0); stage(); xf_apply(0); lstore(o0);
     { int t1, c1; step_tc(1, t1, c1); if (NT == 1) { gload(0, c1); stage(); xf_load(c1 >> 4); xf_apply(0); } else { gload(nsteps > 1 ? 1 : 0, 0); stage(); xf_apply(nsteps > 1 ? 1 : 0); } }
@@ -521,9 +545,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 if (!(abl & 1)) gload_dl(last3 ? NT - 1 : t3, c3 << 4, o0);
                 if (!(abl & 2)) read_ops(o1, nxt);
                 if (!(abl & 4)) mfmas(cur);
-                if (!(abl & 8)) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DLW) : "memory"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                if (!(abl & 8)) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DLW) : "memory"); lds_wait_reads(nxt); __builtin_amdgcn_s_barrier(); }
                 cur = nxt;
                 { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
+                pin_stage_offsets();
                 continue;
             }
             if (MD2_PF3) { stage(); if (!(abl & 1)) gload(last3 ? NT - 1 : t3, c3 << 4); }
@@ -549,10 +574,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, float* __rest
                 mfmas(cur);
                 if (MD2_SETPRIO) __builtin_amdgcn_s_setprio(0);
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DLW) : "memory");          // step s+2's tiles (issued one step ago) have landed; step s+3's stay in flight
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                lds_wait_reads(nxt);
                 __builtin_amdgcn_s_barrier();
                 cur = nxt;
                 { const int tmp = o0; o0 = o1; o1 = o2; o2 = tmp; }
+                pin_stage_offsets();
                 continue;
             }
             if (MD2_PF3) { stage(); gload(last3 ? NT - 1 : t3, c3 << 4); }          // sa/sb <- the loads issued one step ago (step s+2's data); step s+3's go in flight
@@ -791,9 +817,9 @@ __global__ __launch_bounds__(256, (BM == 128 && BST) ? 3 : 1) void conv_igemm_cl
     const int cls = b < k.first[1] ? 0 : (b < k.first[2] ? 1 : (b < k.first[3] ? 2 : 3));
     const int bx = b - k.first[cls], nb = k.first[cls + 1] - k.first[cls];
     switch (k.c[cls].nkh * k.c[cls].nkw) {
-        case 1: conv_igemm_body<BM, BN, WP, WC, MF, 1, BF, 0, BST, 1>(k.c[cls], smem, bx, nb); break;
-        case 2: conv_igemm_body<BM, BN, WP, WC, MF, 2, BF, 0, BST, 1>(k.c[cls], smem, bx, nb); break;
-        default: conv_igemm_body<BM, BN, WP, WC, MF, 4, BF, 0, BST, 1>(k.c[cls], smem, bx, nb); break;
+        case 1: conv_igemm_body<BM, BN, WP, WC, MF, 1, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
+        case 2: conv_igemm_body<BM, BN, WP, WC, MF, 2, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
+        default: conv_igemm_body<BM, BN, WP, WC, MF, 4, BF, 0, BST>(k.c[cls], smem, bx, nb); break;
     }
 }
 

@@ -196,6 +196,29 @@ def test_no_kernel_uses_scratch():
     assert not bad, "kernels with a private segment: " + "; ".join(bad)
 
 
+def test_lds_pipeline_order_in_the_isa():
+    """The direct-to-LDS operand pipeline of conv_igemm.hip (`buffer_load ... lds`, counted `s_waitcnt vmcnt`, raw `s_barrier`) is correct only if, in the ISA, the operand
+    reads of a stage sit between the barrier that publishes it and the barrier that releases it for the next load -- and `llvm.amdgcn.s.barrier` is IntrNoMem, so hipcc is free
+    to move plain LDS loads across it.  Round 5's "race of unknown cause" was exactly that: one build had the prologue's stage-0 reads behind the second prologue barrier
+    (DESIGN.md section 4).  The source pins the order with data dependences (conv_igemm_body: pin_stage_offsets / lds_wait_reads); this test reads the order back from the
+    disassembly of every kernel of the built library that issues LDS loads (tools/lds_pipeline_lint.py: rules R1-R3), so a compiler or source change that reopens the race
+    fails the CPU suite instead of one GPU step in a few hundred.  The lint itself is pinned on two hand-made streams: the round-5 failure shape must be flagged."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_pipeline_lint as lint
+    dma = "buffer_load_dwordx4 v1, s[8:11], s0 offen lds"; rd = "ds_read_b128 v[2:5], v6"; mf = "v_mfma_f32_32x32x16_bf16 a[0:15], v[2:5], v[6:9], a[0:15]"
+    good = [dma] * 6 + ["s_waitcnt vmcnt(2)", "s_barrier"] + [rd] * 4 + ["s_waitcnt lgkmcnt(0)", "s_barrier"] + ([dma] * 2 + [rd] * 4 + [mf] * 6 + ["s_waitcnt vmcnt(2)", "s_waitcnt lgkmcnt(0)", "s_barrier"]) * 3 + ["s_endpgm"]
+    sunk = [dma] * 6 + ["s_waitcnt vmcnt(2)", "s_barrier", "s_waitcnt lgkmcnt(0)", "s_barrier"] + [rd] * 4 + ([dma] * 2 + [rd] * 4 + [mf] * 6 + ["s_waitcnt vmcnt(2)", "s_waitcnt lgkmcnt(0)", "s_barrier"]) * 3 + ["s_endpgm"]
+    late = [dma] * 6 + ["s_waitcnt vmcnt(2)", "s_barrier"] + [rd] * 4 + ["s_waitcnt lgkmcnt(0)", "s_barrier"] + [dma] * 2 + [rd] * 2 + [mf] * 6 + ["s_waitcnt vmcnt(2)"] + [rd] * 2 + ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_endpgm"]
+    assert lint.lint_kernel(good) == [] and lint.lint_kernel(["s_barrier", rd, "s_endpgm"]) == []
+    assert any("R2" in v for v in lint.lint_kernel(sunk)) and any("R1" in v for v in lint.lint_kernel(late))
+    if not os.path.exists(os.path.join(lint.LLVM, "llvm-objdump")):
+        pytest.skip("no llvm-objdump in this image")
+    n, bad = lint.lint(md2amd._lib.LIB_PATH)
+    assert n >= 30, "the kernels with the direct-to-LDS loader were not found in libmd2hip.so (%d)" % n
+    assert not bad, "LDS pipeline out of order in: " + "; ".join("%s: %s" % (k, v) for k, v in bad.items())
+
+
 def test_bench_convolution_class_accounting(tmp_path):
     """bench.py prices the forward + input-gradient convolution class from the library's per-launch profile records (md2_profile_dump): algorithmic bytes (inputs + weights +
     epilogue operands + outputs, once each) and the matrix-pipe floor of the instructions each launch EXECUTES (fp32 MFMA 157.3 TFLOP/s; exact split: six bf16 MFMAs per product
