@@ -44,7 +44,9 @@ def conv_class_accounting(dump_path, esz, nsteps):
       algorithmic_bytes -- each launch reads its input pixels, its weights and the epilogue's output-sized operands once and writes its output once, at `esz` bytes per element;
       floor_ms          -- the time the launches' EXECUTED matrix instructions need at the rate of the pipe they run on: fp32 MFMA 157.3 TFLOP/s; an exact-split launch issues six
                            (two-piece: three) bf16 MFMAs per fp32 product group on the 2.5 PFLOP/s bf16 pipe; Winograd launches execute 16/36 of the direct-convolution count.
-    `frac` of the roofline block stays the algorithmic rate; ms_per_step / floor_ms is the distance to the matrix-pipe roof."""
+    Since round 5 the roofline block's `frac` is floor_ms / ms_per_step (= algorithmic rate / the launch mix's effective peak: the share of the class time its executed matrix
+    instructions need at full pipe rate); the rounds-1-to-4 definition, the algorithmic rate against the fp32 MFMA peak alone, is kept as `algorithmic_vs_fp32_mfma_peak`
+    (it passed 1.0 once Winograd and the bf16-pipe split multiplied fewer / cheaper products than the direct count)."""
     import re
     by = 0.0; floor_s = 0.0; forms = {}
     for line in open(dump_path).read().splitlines()[1:]:
@@ -118,6 +120,30 @@ def bf16_conv_roofline(md, torch, model, step, esz=4, precision="bf16"):
                     "traffic_unit": "HBM bytes per step of this class (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of tools/prof_config.py 8 18 3 320 1024 " + precision + ", profiles/" + PROFILE_ROUND + "_cfg5_" + precision + "_pmc_hbm_traffic.md)"},
             "ms_per_step": ig["ms"] / 3, "launches_per_step": ig["launches"] / 3,
             "note": "neither roof binds: 64 x 64-pixel-by-channel workgroups with two bf16 MFMAs per wave and 64-byte K-step are issue / latency bound (DESIGN.md section 4, bf16 tensors)"}
+
+
+def conv_roofline_live(md, torch, model, step, esz=4, peak_tf=MFMA_F32_PEAK_TFLOPS):
+    """The forward + input-gradient convolution class of any configuration, measured live: three profiled one-stream steps (HIP events per launch), algorithmic FLOP rate,
+    the matrix-pipe floor of the executed instructions (conv_class_accounting) and the class's algorithmic bytes.  No committed counters involved."""
+    import tempfile
+    md.set_two_streams(model, False); md.profile(model, True)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ig = md.profile_get(model, 0); wg = md.profile_get(model, 1)
+    tmp = os.path.join(tempfile.gettempdir(), "md2_live_layers_%d.csv" % os.getpid())
+    md.profile_dump(model, tmp); acct = conv_class_accounting(tmp, esz, 3); os.remove(tmp)
+    md.profile(model, False); md.set_two_streams(model, True)
+    if ig["ms"] <= 0:
+        return None
+    ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12; ms = ig["ms"] / 3
+    return {"bound": "mfma", "kernel": "forward + input-gradient convolutions of this configuration (same kernel families as the headline roofline)",
+            "achieved": ach, "peak": (ig["flops"] / 3) / (acct["floor_ms"] * 1e-3) / 1e12, "unit": "TFLOP/s", "frac": acct["floor_ms"] / ms, "frac_definition": "floor_ms / ms_per_step",
+            "algorithmic_vs_fp32_mfma_peak": ach / peak_tf, "floor_ms": acct["floor_ms"], "ms_per_step": ms, "ms_over_floor": ms / acct["floor_ms"],
+            "launches_per_step": ig["launches"] / 3, "launches_by_product_form": acct["launches_by_product_form"],
+            "algorithmic_bytes_per_launch": acct["algorithmic_bytes_per_step"] / max(ig["launches"] / 3, 1), "hbm_frac_of_algorithmic_bytes": acct["algorithmic_bytes_per_step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "weight_gradient_ms_per_step": wg["ms"] / 3,
+            "timing": "HIP events per launch, 3 one-stream steps inside this run"}
 
 
 def valu_insts(kernel, B, C, H, W):
@@ -358,7 +384,8 @@ def main():
         ach_x = ig["flops_executed"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         peak_eff = (ig["flops"] / 3) / (acct["floor_ms"] * 1e-3) / 1e12 if acct["floor_ms"] > 0 else peak_tf
         out["roofline"] = {"bound": "mfma", "kernel": "conv_wino3s_kernel<.,.,3> / conv_wino3_kernel (fused Winograd F(2x2,3x3): the 3x3 stride-1 layers; products as the exact three-bf16-piece split from 96 input channels up, fp32 MFMA below) + conv_igemm_kernel<*> + conv_igemm_classes_kernel<*> + conv3x3_patch_kernel<*> + stem_fwd_kernel (forward + input-gradient convolutions; fp32 v_mfma_f32_32x32x2_f32 / 16x16x4_f32 outside the split launches)",
-                           "achieved": ach, "peak": peak_eff, "unit": "TFLOP/s", "frac": ach / peak_eff,
+                           "achieved": ach, "peak": peak_eff, "unit": "TFLOP/s", "frac": ach / peak_eff, "frac_of_executed_floor": ach / peak_eff,
+                           "frac_definition": "floor_ms / ms_per_step since round 5 (BENCH_r05 on); rounds 1-4 reported algorithmic_vs_fp32_mfma_peak under this key -- the two are not comparable",
                            "algorithmic": "achieved counts the direct-convolution FLOPs of the layers (SURVEY.md section 8d: 2 M Cout taps Cin), whatever algorithm ran",
                            "peak_note": "peak = the same algorithmic FLOPs / floor_ms: the rate at which the matrix instructions this launch mix EXECUTES could retire (fp32 MFMA launches at 157.3 TFLOP/s; exact-split launches issue six bf16 MFMAs per product group at 2.5 PFLOP/s; Winograd launches execute 16/36 of the direct count) -- since round 5, because the algorithmic rate against the fp32 MFMA peak alone had saturated (round 4: 0.99; it is kept as algorithmic_vs_fp32_mfma_peak)",
                            "algorithmic_vs_fp32_mfma_peak": ach / peak_tf,
@@ -440,6 +467,7 @@ def main():
                 md.train_step(m5, x5, None, c5, p5, True)
             torch.cuda.synchronize(); d5 = time.perf_counter() - t0
             extra["config3_resnet50_640x192_batch16"] = {"value": 16 * n5 / d5, "unit": "triplets/s", "ms_per_step": d5 / n5 * 1e3}
+            extra["config3_resnet50_640x192_batch16"]["roofline"] = conv_roofline_live(md, torch, m5, lambda: md.train_step(m5, x5, None, c5, p5, True))
             # ... and the same configuration with bf16 activation storage (md2_config.precision = 2; not a parity mode): the bottleneck trunk is HBM-bound in its 1x1 layers
             del m5, x5
             gc.collect(); torch.cuda.empty_cache(); torch.cuda.synchronize()          # (handles freed here, not by a collection inside a timed loop)
@@ -511,6 +539,14 @@ def main():
                 extra[key] = {"value": B * n8 / d8, "unit": "triplets/s", "ms_per_step": d8 / n8 * 1e3, "conv_products": list(mode), "dtype": note}
             md.set_conv_products(*dflt)
         out["extra"] = extra
+        # which fields of this line are NOT measured by this run: hardware counters cannot be read from inside bench.py, so they come from the committed rocprofv3 --pmc
+        # summaries of the same command (profiles/<PROFILE_ROUND>_*.json, reported only when their workload equals the one being run)
+        out["from_committed_profiles"] = {
+            "round": PROFILE_ROUND,
+            "fields": ["roofline.traffic", "roofline.matrix_pipe", "extra.roofline_conv_wgrad.valu", "extra.roofline_conv_wgrad.matrix_pipe", "extra.roofline_conv_wgrad.frac",
+                       "extra.roofline_loss_train.achieved / .frac / .valu_wave_instructions_per_launch (SQ_INSTS_VALU)", "extra.roofline_loss_train.hbm.traffic", "extra.roofline_loss_fwd.traffic",
+                       "extra.config4_1024x320_bf16_automask_batch8.roofline.hbm.traffic", "extra.config4_1024x320_bf16_automask_batch8.roofline_loss_train.hbm.traffic / .valu_wave_instructions_per_launch"],
+            "measured_live": "everything else: value, ms_per_step, every class time / launch count / FLOP and byte rate (HIP events), floor_ms, frac, cpu_baseline"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, H, W)
         # the figures a reader needs first, repeated at the END of the line (a log viewer that keeps only the tail of stdout still shows them)

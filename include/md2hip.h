@@ -115,7 +115,10 @@ int32_t md2_set_deterministic(int32_t on);
  * with at least min_blocks workgroups (default 48 64-tile equivalents; -1 keeps the current value, -2 restores the default) to the fused Winograd F(2x2,3x3) kernels, on = 0 forces the direct
  * implicit GEMM; on = 2 / 3 pin one of the two Winograd kernels wherever it applies (tests, tuning).  on = 4 / 5 are legacy aliases of
  * md2_set_winograd(1, .) + md2_set_conv_products(2 / 3, -1).  on + 8 (8 .. 11): as `on`, with the split kernels' 64-channel / 512-thread
- * workgroups wherever Cout % 64 == 0 (round 5: faster launch by launch, slower inside the step, so not the default -- DESIGN.md section 4; tests keep it exercised).  Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
+ * workgroups wherever Cout % 64 == 0 (round 5: faster launch by launch, slower inside the step, so not the default -- DESIGN.md section 4; tests keep it exercised).
+ * on + 16 (16 .. 19): as `on`, with the split Winograd kernel in its persistent, tile-looping form (round 6, conv_wino3p_kernel: the resident set of workgroups walks the launch's
+ * items and the head of the next item rides in the last chunks of the current one; bit-identical results, measured equal launch by launch and 1 % behind in the step, so
+ * not the default -- DESIGN.md section 4; a test keeps it exercised).  Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks);
 /* How the fp32 products of the convolutions are formed (the role cuDNN's math mode plays behind Flux; the reference computes in fp32, src/Monodepth.jl:72).
  *   fwd_dgrad: the forward / input-gradient kernels -- the fused Winograd kernels and, since round 5, the direct implicit GEMM (1x1, stride 2 and its residue-class input

@@ -945,6 +945,231 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
 #undef W3S_STAMP
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Persistent (tile-looping) form of conv_wino3s_kernel (round 6).  Round 5's ablation put a third of a launch of that kernel into per-workgroup fixed cost -- 10.5 k ticks of
+// every workgroup's life outside the chunk loop: first U fragments, the loader's geometry through LDS, the first patch loads, their commit, then at the end the output
+// transform and the epilogue -- a latency chain that the second workgroup of the CU only partly covers.  Here the grid is the RESIDENT set (two workgroups per CU, 512) and a
+// workgroup walks its share of (tile group, 32-channel block) items; the head of item k + 1 rides inside the loop of item k:
+//   * chunk n - 2 of an item works out the NEXT item's loader geometry into a table of its own in LDS (published by that chunk's barrier);
+//   * the LAST chunk prefetches, exactly where every chunk prefetches its successor, chunk 0 of the next item: patch loads from the next item's offsets, U refills from
+//     the next item's fragment stream, the commit into stage 0 -- so the next loop starts with its operands in place (the chunk count is even, stage 0 is the free one);
+//   * the output transform and the statistics scratch live behind stage 0 (stage 1 + 12 KB: 62 KB of LDS per workgroup), so the epilogue of item k does not touch what the
+//     last chunk staged; one barrier separates it from the first commit of item k + 1 into stage 1.
+// Items are dealt XCD by XCD in contiguous ranges (blocks b and b + 8 share an XCD): neighbouring items -- same U, adjacent tiles -- run at the same time on one L2, as the
+// hardware's dispatch order did for the one-item workgroups.  No input transform (XF): those launches keep conv_wino3s_kernel.  Same U layout, loader, LDS patch layout,
+// arithmetic order and epilogue contract: results are bit-identical to conv_wino3s_kernel's (tests/test_gpu_layers.py).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BST, int NP>
+__global__ __launch_bounds__(256, 2) void conv_wino3p_kernel(ConvArgs a, Wino2Geo geo, int nitems) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int COB = 32, WT = 32, NLI = 6;
+    constexpr int PL = 128 * 3 * 8;                  // floats per 8-channel plane (384 slots), two planes per stage
+    constexpr int PST = 2 * PL;
+    constexpr int R_OFF = PST;                       // output transform R[8][32][36] (9216 floats = stage 1 + PL) and the statistics scratch
+    constexpr int TAB_OFF = 2 * PST + PL;            // loader geometry of the next item: 384 words
+    const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
+    const int THW = TH * TW;
+    const int Lf = min(TW, WT), S = 4 * (2 * Lf + 2);
+    const int n_rows_total = a.N * TH;
+    const int nchunks = a.Cin >> 4;                  // even, >= 4 (launcher)
+
+    // ---- this workgroup's items: local index it, it + nl, ... of its XCD's contiguous range [it_lo, it_lo + it_cnt)
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, nl = (nwg - xcd + 7) >> 3;
+    const int q8 = nitems >> 3, r8 = nitems & 7;
+    const int it_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, it_cnt = q8 + (xcd < r8 ? 1 : 0);
+    int it = blockIdx.x >> 3;
+    if (it >= it_cnt) return;                        // (workgroup-uniform, ahead of every barrier; does not happen for grid <= nitems)
+    struct Item { int m0, c0, tile_c, rr_first, tx0, L0, S0; };
+    auto decode = [&](int idl) {
+        const int id = it_lo + idl;
+        Item t; t.tile_c = id / ntp; const int tile_p = id - t.tile_c * ntp;
+        t.m0 = tile_p * WT; t.c0 = t.tile_c * COB;
+        t.rr_first = t.m0 / TW; t.tx0 = t.m0 - t.rr_first * TW;
+        t.L0 = min(TW - t.tx0, WT); t.S0 = 4 * (2 * t.L0 + 2);
+        return t;
+    };
+    const long ustride = (long)4 * NP * 512;         // bf16 elements per chunk of a wave's U stream
+    auto ustream = [&](const Item& t) { return reinterpret_cast<const __bf16*>(a.wino_u) + ((long)(t.tile_c * 4 + wi) * nchunks) * ustride + lane * 8; };
+
+    Item cur = decode(it);
+    const __bf16* ub = ustream(cur);
+    wbf16x8 u[4][NP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) u[j][q] = *reinterpret_cast<const wbf16x8*>(ub + (j * NP + q) * 512);
+
+    // ---- loader (as conv_wino3s_kernel): item f = tid + 256 li = (slot f >> 2, 16-B piece f & 3); geometry once per slot through the table
+    unsigned l_off[NLI];
+    const int piece = tid & 3, pl = piece >> 1, h2 = piece & 1;
+    const int l_dst0 = pl * PL + (tid >> 2) * 8 + ((h2 ^ ((tid >> 5) & 1)) << 2);
+    unsigned* tab = reinterpret_cast<unsigned*>(wsm) + TAB_OFF;
+    // (fresh(): the thread index behind an empty asm -- what the per-item helpers derive from it cannot be hoisted out of the item loop, where it would sit in registers across
+    //  every chunk; with the hoisting the kernel needed 20 registers more than conv_wino3s_kernel and its BST form spilled)
+    auto fresh = [&](int v) { asm volatile("" : "+v"(v)); return v; };
+    auto fill_tab = [&](const Item& t, const bool valid) {
+        const int tid = fresh(threadIdx.x);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int slot = tid + 256 * q;
+            if (slot < 384) {
+                int k, r, WP, txa, Lk;
+                if (slot < t.S0) { k = 0; r = slot; WP = 2 * t.L0 + 2; txa = t.tx0; Lk = t.L0; }
+                else { const int s2 = slot - t.S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - t.L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }
+                const int pa = fdiv24(r, WP), pc = r - pa * WP;
+                const int rr = t.rr_first + k;
+                const bool act = valid && slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+                const int rrc = act ? rr : 0;
+                const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
+                int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+                bool ok = act;
+                if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+                else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                tab[slot] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps)) * 4u : 0xFFFFFFFFu;
+            }
+        }
+    };
+    auto read_tab = [&]() {
+        const int tid = fresh(threadIdx.x);
+        const int piece = tid & 3;
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            const unsigned v = tab[(tid >> 2) + 64 * li];
+            l_off[li] = v != 0xFFFFFFFFu ? v + (unsigned)(piece * 16) : W_OOB;
+        }
+    };
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
+    uint4 ra[NLI];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) ra[li] = wino_buffer_load16(xrs, l_off[li], c * 64);
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            uint4 v = ra[li];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+            *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 512) = v;
+        }
+    };
+
+    // ---- consumer (as conv_wino3s_kernel)
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int tl = lane & 31, g = lane >> 5;
+    int c_off1[4], c_off2[4];
+    auto set_consumer = [&](const Item& t) {
+        const int lane = fresh(threadIdx.x) & 63, tl = lane & 31, g = lane >> 5;
+        const int uu = t.tx0 + tl, k = fdiv24(uu, TW);
+        const int lc = (k == 0) ? tl : (uu - k * TW);
+        const int base = (k == 0) ? 0 : t.S0 + (k - 1) * S, WP = (k == 0) ? 2 * t.L0 + 2 : 2 * min(TW, WT - t.L0 - (k - 1) * TW) + 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
+            c_off1[b] = g * PL + sl1 * 8 + (((sl1 >> 3) & 1) << 2);
+            c_off2[b] = g * PL + sl2 * 8 + (((sl2 >> 3) & 1) << 2);
+        }
+    };
+
+    fill_tab(cur, true);
+    __syncthreads();
+    read_tab();
+    set_consumer(cur);
+    gload(0); lstore(0);
+    __syncthreads();
+
+    f32x16 acc[4];
+    // one chunk: prefetch the patches of (cn, with the offsets l_off holds at that moment) and the U fragments at `un`, contract the chunk staged at `so`, commit the prefetch
+    // into the other stage.  The body is conv_wino3s_kernel's.
+    auto chunk = [&](const int cn, const __bf16* un, auto so_tag) {
+        constexpr int so = decltype(so_tag)::value;
+        gload(cn);
+        __builtin_amdgcn_sched_barrier(0);
+        float4 rr[4][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                // (the offsets reach this loop through the item switch: without the hint hipcc no longer sees their 16-byte alignment and reads with 64 ds_read2_b32 per chunk)
+                const float4 d1 = *reinterpret_cast<const float4*>(__builtin_assume_aligned(wsm + so + (c_off1[b] ^ (p << 2)), 16));
+                const float4 d2 = *reinterpret_cast<const float4*>(__builtin_assume_aligned(wsm + so + (c_off2[b] ^ (p << 2)), 16));
+                rr[b][p] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned vp[NP][4];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float4 x0 = rr[j == 0 ? 0 : (j == 2 ? 2 : 1)][p], x1 = rr[j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3))][p];
+                const float sj = (j == 1) ? 1.f : -1.f;
+                const float4 v = make_float4(fmaf(sj, x1.x, x0.x), fmaf(sj, x1.y, x0.y), fmaf(sj, x1.z, x0.z), fmaf(sj, x1.w, x0.w));
+                if constexpr (NP == 2) { split_pk(v.x, v.y, vp[0][2 * p], vp[1][2 * p]); split_pk(v.z, v.w, vp[0][2 * p + 1], vp[1][2 * p + 1]); }
+                else { split3_pk(v.x, v.y, vp[0][2 * p], vp[1][2 * p], vp[2][2 * p]); split3_pk(v.z, v.w, vp[0][2 * p + 1], vp[1][2 * p + 1], vp[2][2 * p + 1]); }
+            }
+            wbf16x8 vb[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) vb[q] = __builtin_bit_cast(wbf16x8, (wu32x4){vp[q][0], vp[q][1], vp[q][2], vp[q][3]});
+            if constexpr (NP == 3) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][2], vb[0], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][0], vb[2], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][1], vb[1], acc[j], 0, 0, 0);
+            }
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][1], vb[0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][0], vb[1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][0], vb[0], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) u[j][q] = *reinterpret_cast<const wbf16x8*>(un + (j * NP + q) * 512);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lstore(PST - so);
+        __syncthreads();
+    };
+
+    while (true) {
+        const int itn = it + nl;
+        const bool has_next = itn < it_cnt;
+        const Item nx = decode(has_next ? itn : it);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        int c = 0;
+        for (; c + 2 < nchunks; c += 2) {
+            chunk(c + 1, ub + (long)(c + 1) * ustride, std::integral_constant<int, 0>{});
+            chunk(c + 2, ub + (long)(c + 2) * ustride, std::integral_constant<int, PST>{});
+        }
+        // the last two chunks: the next item's geometry goes into the table during chunk n - 2 (that chunk's barrier publishes it), and chunk n - 1 prefetches the next
+        // item's chunk 0 -- or, behind the workgroup's last item, out-of-range offsets (zeros, no traffic) and its own U stream once more
+        fill_tab(nx, has_next);
+        chunk(c + 1, ub + (long)(c + 1) * ustride, std::integral_constant<int, 0>{});
+        read_tab();
+        ub = ustream(nx);                              // (this item's stream has been read to its end)
+        chunk(0, ub, std::integral_constant<int, PST>{});
+
+        // ---- output transform: column half in registers, row half through LDS (R[i][b][32 tiles][COB + 4]) behind stage 0
+        constexpr int RLD = COB + 4;
+        float* Rl = wsm + R_OFF;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float4 o0, o1;
+            o0.x = acc[0][4 * gq + 0] + acc[1][4 * gq + 0] + acc[2][4 * gq + 0]; o1.x = acc[1][4 * gq + 0] - acc[2][4 * gq + 0] - acc[3][4 * gq + 0];
+            o0.y = acc[0][4 * gq + 1] + acc[1][4 * gq + 1] + acc[2][4 * gq + 1]; o1.y = acc[1][4 * gq + 1] - acc[2][4 * gq + 1] - acc[3][4 * gq + 1];
+            o0.z = acc[0][4 * gq + 2] + acc[1][4 * gq + 2] + acc[2][4 * gq + 2]; o1.z = acc[1][4 * gq + 2] - acc[2][4 * gq + 2] - acc[3][4 * gq + 2];
+            o0.w = acc[0][4 * gq + 3] + acc[1][4 * gq + 3] + acc[2][4 * gq + 3]; o1.w = acc[1][4 * gq + 3] - acc[2][4 * gq + 3] - acc[3][4 * gq + 3];
+            const int col = 8 * gq + 4 * g;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * WT + tl) * RLD + col) = o0;
+            *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * WT + tl) * RLD + col) = o1;
+        }
+        __syncthreads();
+        wino_final_epilogue<256, COB, BST>(a, Rl, cur.m0, WT, Mt, THW, TW, cur.c0, fresh(threadIdx.x));
+        if (!has_next) break;
+        it = itn; cur = nx;
+        set_consumer(cur);
+        __syncthreads();          // R and the statistics scratch are free before chunk 0 of the next item commits into stage 1
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The split kernel with 64 output channels per workgroup (round 5).  conv_wino3s_kernel redoes the input transform and the three-piece split of the same V in every one of
 // its Cout / 32 workgroups per tile block: 12-14.6 vector instructions per MFMA, matrix pipe 0.20 busy (profiles/r04_mfma_pmc.md).  Here a workgroup is 512 threads = 8 waves,
 // wave = (Winograd row i, position pair jp): it forms V_(i, 2 jp) and V_(i, 2 jp + 1) -- three of the four row-combined patch columns, 12 instead of 32 ds_read_b128 per chunk --
@@ -1278,8 +1503,26 @@ static void launch_wino3w_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s)
 #endif
 int g_wino_cb2 = MD2_WINO_CB2_DEFAULT;           // fp32-MFMA Winograd launches with Cout % 64 == 0: 32 tiles x 64 channels per workgroup (conv_wino3_kernel<., ., ., 1, 2>); 0: 32 x 32 (tools/conv_bench: CB1)
 int g_wino_wide = 0;          // 1 (md2_set_winograd(on + 8, .)): split launches with Cout % 64 == 0 take the 64-channel workgroup (conv_wino3w_kernel: faster alone, slower in the step -- DESIGN.md section 4); 0: the 32-channel one everywhere
+// persistent form (opt-in): launches with more items than the 512 resident workgroups, an even chunk count (every layer of the networks here) and no input transform
+int g_wino_persist = 0;          // md2_set_winograd(on + 16, .) sets it: measured equal to the one-item workgroups launch by launch and 1 % behind them in the step, so opt-in
+template <int NP>
+static void launch_wino3p_t(const ConvArgs& a, const Wino2Geo& g, int nitems, hipStream_t s) {
+    constexpr size_t lds = (size_t)(2 * 2 * 128 * 3 * 8 + 128 * 3 * 8 + 384) * sizeof(float);          // two stages, the output transform's overhang, the geometry table: 62 976 B
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3p_kernel<0, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3p_kernel<1, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = std::min(nitems, 512);
+    if (a.bst) hipLaunchKernelGGL((conv_wino3p_kernel<1, NP>), dim3(grid), dim3(256), lds, s, a, g, nitems);
+    else hipLaunchKernelGGL((conv_wino3p_kernel<0, NP>), dim3(grid), dim3(256), lds, s, a, g, nitems);
+}
 static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
+    const long nitems = (long)g.ntp * (a.Cout / 32);
+    const int nchunks = a.Cin >> 4;
     if (g_wino_wide && a.Cout % 64 == 0) { if (a.wino_pieces == 3) launch_wino3w_t<3>(a, g, s); else launch_wino3w_t<2>(a, g, s); }
+    else if (g_wino_persist && !a.in_scale && nitems > 512 && nitems < (1L << 24) && nchunks >= 4 && (nchunks & 1) == 0) { if (a.wino_pieces == 3) launch_wino3p_t<3>(a, g, (int)nitems, s); else launch_wino3p_t<2>(a, g, (int)nitems, s); }
     else if (a.wino_pieces == 3) launch_wino3s_t<3>(a, g, s); else launch_wino3s_t<2>(a, g, s);
 }
 static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) {

@@ -1361,6 +1361,7 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host, int64_t n) {
 }
 int32_t md2_set_deterministic(int32_t on) { g_deterministic = on != 0; return 0; }
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks) {
+    g_wino_persist = (on >= 16 && on <= 19) ? 1 : 0; if (on >= 16 && on <= 19) on -= 16;          // + 16: the split Winograd kernel in its persistent, tile-looping form (conv_wino3p_kernel; measured, not the default)
     g_wino_wide = (on >= 8 && on <= 11) ? 1 : 0; if (on >= 8 && on <= 11) on -= 8;          // + 8: the split kernel's 64-channel / 512-thread workgroups where Cout % 64 == 0 (conv_wino3w_kernel; measured, not the default)
     if (on == 4 || on == 5) { g_wino_on = 1; g_wino_pieces = on == 4 ? 2 : 3; }          // legacy aliases of md2_set_winograd(1, .) + md2_set_conv_products(2 / 3, -1)
     else g_wino_on = on < 0 || on > 3 ? 1 : on;

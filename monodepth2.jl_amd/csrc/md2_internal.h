@@ -27,7 +27,8 @@ extern int g_wino_on, g_wino_min_blocks, g_wino_min_blocks_default;
 // operands U were written under is recorded per handle when they are refreshed; the resolved layout travels in ConvArgs::wino_pieces); g_wgrad_pieces: weight-gradient kernels.
 extern int g_wino_pieces, g_wgrad_pieces;
 extern int g_wino_cb2;           // conv_winograd.hip: 1 = the fp32-MFMA Winograd kernel takes two 32-channel output blocks per workgroup where Cout % 64 == 0
-extern int g_wino_wide;          // conv_winograd.hip: 1 (default) = split launches with Cout % 64 == 0 take the 64-channel workgroup (conv_wino3w_kernel); md2_set_winograd(on + 8, .) clears it
+extern int g_wino_wide;          // conv_winograd.hip: 0 (default); 1 = split launches with Cout % 64 == 0 take the 64-channel workgroup (conv_wino3w_kernel): md2_set_winograd(on + 8, .) sets it, any other md2_set_winograd call clears it
+extern int g_wino_persist;       // conv_winograd.hip: 0 (default); 1 = split launches with more items than resident workgroups take the persistent kernel (conv_wino3p_kernel): md2_set_winograd(on + 16, .) sets it, any other md2_set_winograd call clears it
 // load-time defaults of the two (MD2_WINO_PIECES / MD2_WGRAD_PIECES override): every product of the default step carries full fp32 operand accuracy
 #define MD2_DEFAULT_WINO_PIECES 1
 #define MD2_DEFAULT_WGRAD_PIECES 1

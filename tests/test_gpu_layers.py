@@ -305,7 +305,7 @@ WINO_CASES = [
 
 
 # (algorithm pin, pieces per operand of the forward / input-gradient products, pieces of the weight-gradient products): md2_set_winograd / md2_set_conv_products
-WINO_ROUTES = {"tile32x64": (2, 0, 0), "tile64x32": (3, 0, 3), "split_bf16": (3, 2, 2), "split3_bf16": (3, 3, 3), "split3_bf16_64_channel_workgroups": (11, 3, 3), "split_bf16_64_channel_workgroups": (11, 2, 2)}
+WINO_ROUTES = {"tile32x64": (2, 0, 0), "tile64x32": (3, 0, 3), "split_bf16": (3, 2, 2), "split3_bf16": (3, 3, 3), "split3_bf16_persistent": (19, 3, 3), "split3_bf16_64_channel_workgroups": (11, 3, 3), "split_bf16_64_channel_workgroups": (11, 2, 2)}
 
 
 def _set_route(route):
@@ -347,7 +347,46 @@ def test_winograd_conv_fwd_and_input_gradient_vs_oracle(case, forced_winograd):
     assert rel(host(dx), dxo) < 1e-4 and rel(host(dw), dwo) < 1e-4 and rel(host(db), dbo) < 1e-4
 
 
-@pytest.mark.parametrize("case", [(40, 64, 32, 52, 64), (3, 128, 8, 13, 256), (2, 256, 4, 13, 512), (4, 64, 7, 9, 32)])
+PERSISTENT_CASES = [
+    # N, Cin, H, W, Cout, pad, pad_mode, act       -- every one has more (32-tile, 32-channel) items than the 512 resident workgroups, so some workgroups walk two items
+    (2, 64, 64, 128, 160, 1, "zeros", "elu"),       # 640 items, four chunks: the loop is nothing but the two tail chunks that carry the next item's head
+    (4, 128, 64, 104, 128, 0, "reflect", "none"),   # 832 items forward AND input gradient, eight chunks, reflect padding
+    (11, 96, 30, 70, 96, 1, "zeros", "relu"),       # 543 items: 31 workgroups take a second item; ragged last tile group (5775 tiles), six chunks, tile rows wider than a group
+]
+
+
+@pytest.mark.parametrize("pieces", [3, 2])
+@pytest.mark.parametrize("case", PERSISTENT_CASES)
+def test_persistent_winograd_kernel_equals_the_one_item_kernel_bit_for_bit(case, pieces):
+    """conv_wino3p_kernel (round 6, md2_set_winograd(on + 16, .): the resident set of workgroups walks the launch's items, the head of the next item rides in the last two
+    chunks of the current one) against the oracle's direct convolution, and BIT FOR BIT against conv_wino3s_kernel: same loader, same arithmetic order, another schedule.
+    (Measured equal to the one-item workgroups launch by launch, so it is not the default route; this test keeps it correct.)"""
+    N, Cin, H, W, Cout, p, mode, act = case
+    x = rng.standard_normal((N, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    dy_shape = (N, Cout, H, W)
+    dy = rng.standard_normal(dy_shape).astype(np.float32)
+    dflt = md().get_conv_products()
+    try:
+        md().set_winograd(19, 1); md().set_conv_products(pieces, pieces)
+        y = host(md().conv2d(dev(x), dev(w), dev(b), 1, p, mode, act)); dx = host(md().conv2d_pullback(dev(x), dev(w), dev(dy), 1, p, mode)[0])
+        md().set_winograd(3, 1)
+        y1 = host(md().conv2d(dev(x), dev(w), dev(b), 1, p, mode, act)); dx1 = host(md().conv2d_pullback(dev(x), dev(w), dev(dy), 1, p, mode)[0])
+    finally:
+        md().set_winograd(True, -2); md().set_conv_products(*dflt)
+    assert np.array_equal(y, y1) and np.array_equal(dx, dx1)
+    xin = oracle.pad_reflect(x) if mode == "reflect" else x
+    zo = oracle.conv2d_fwd(xin, w, b, 1, 0 if mode == "reflect" else p)
+    ref = {"none": zo, "relu": np.maximum(zo, 0), "elu": np.where(zo > 0, zo, np.expm1(zo))}[act]
+    dxo = oracle.conv2d_bwd(xin, w, dy, 1, 0 if mode == "reflect" else p)[0]
+    if mode == "reflect":
+        dxo = _reflect_adjoint(dxo, N, Cin, H, W)
+    tol = 1e-4 if pieces == 3 else 2e-3                             # (two pieces: the reduced-precision opt-in form)
+    assert rel(y, ref) < tol and rel(dx, dxo) < tol
+
+
+@pytest.mark.parametrize("case", [(40, 64, 32, 52, 64), (3, 128, 8, 13, 256), (2, 256, 4, 13, 512), (4, 64, 7, 9, 32), (6, 128, 32, 104, 128)])
 def test_winograd_bn_statistics_epilogue_vs_oracle(case, forced_winograd):
     """BatchNorm batch statistics out of the Winograd epilogue (column sums through LDS + 8-slot double atomics), incl. partly filled blocks and odd maps."""
     N, Cin, H, W, Cout = case

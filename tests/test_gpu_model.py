@@ -589,7 +589,11 @@ def test_bf16_activation_storage_tracks_the_fp32_oracle(cfgd):
     assert np.isfinite(l1) and l1 < l0
 
 
-def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, al, cache, params, theta, C, depth):
+FD_ARRAYS_R18 = ["enc.layer3.0.conv1.W", "enc.layer3.0.down.W", "enc.layer3.1.conv2.W", "enc.layer3.1.bn2.gamma", "enc.layer4.0.conv1.W", "enc.layer4.0.conv2.W", "enc.layer4.0.down.W",
+                 "enc.layer4.1.conv1.W", "enc.layer4.1.conv2.W", "enc.layer4.1.bn1.beta", "dec.branch1.c1.W", "dec.branch1.c2.W", "pose.squeezer.W", "pose.pose1.W"]
+
+
+def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, al, cache, params, theta, C, depth, want=None, steps=(3e-3, 1e-3)):
     """A wrongly wired pullback kernel of the bf16-tensor mode (1x1 ONE path, the in-loader BatchNorm transform, the 2048-channel BatchNorm sums ...) changes some parameter
     array's gradient by O(1) while the loss stays right.  For arrays of every kind of bottleneck layer in stages 3 and 4 (1x1 reductions / expansions up to 2048 channels, the
     stride-2 3x3, the strided 1x1 shortcuts, BatchNorm affine parameters) and the decoder / pose layers that read the 2048-channel features the centred finite difference of the handle's OWN loss along that array's gradient direction must reproduce the array's gradient norm:
@@ -599,7 +603,7 @@ def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, al, cach
     behind them, and the loss as a function of THOSE weights is rough at every step size (stage 2: ratios 0.25 .. 0.9, stage 1: -35 .. +40): no finite difference exists to
     compare with (their kernels are the same instantiations as the later stages', at other channel counts -- and held to the oracle on bf16 tensors in tests/test_gpu_layers.py).
     Deterministic mode: the rounding of every tensor is then a fixed function of the parameters."""
-    want = ["enc.layer3.0.down.W", "enc.layer3.1.conv1.W", "enc.layer3.2.conv2.W", "enc.layer3.2.conv3.W", "enc.layer3.5.conv1.W", "enc.layer3.5.bn2.gamma",
+    want = want or ["enc.layer3.0.down.W", "enc.layer3.1.conv1.W", "enc.layer3.2.conv2.W", "enc.layer3.2.conv3.W", "enc.layer3.5.conv1.W", "enc.layer3.5.bn2.gamma",
             "enc.layer4.0.conv1.W", "enc.layer4.0.conv2.W", "enc.layer4.0.conv3.W", "enc.layer4.0.down.W", "enc.layer4.0.down.bn.beta", "enc.layer4.2.conv1.W", "enc.layer4.2.conv3.W", "enc.layer4.2.bn3.gamma",
             "dec.branch1.c1.W", "dec.branch2.c2.W", "pose.squeezer.W", "pose.pose1.W"]
     layout = syn.param_layout(C, depth); names = [n for n, _, _ in layout]
@@ -613,7 +617,7 @@ def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, al, cach
             n = int(np.prod(shape))
             if name in want:
                 ga = gd[off:off + n]; na = float(np.linalg.norm(ga)); ratios = []
-                for step in (3e-3, 1e-3):
+                for step in steps:
                     eps = step * l_ref / na
                     vals = []
                     for sgn in (+1.0, -1.0):

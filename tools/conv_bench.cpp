@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     }
     if (getenv("WINO")) {            // fused Winograd F(2x2,3x3): U = G g G^T once, then the same launch entry (WINO=2: also time the weight transform)
         float* U; hipMalloc(&U, conv_wino_u_floats(Cout, Cin) * 4);
-        launch_wino_weights(w, U, Cout, Cin, g_wino_pieces, 0); a.wino_u = U; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, Cin); g_wino_min_blocks = 1; if (getenv("WMODE")) g_wino_on = atoi(getenv("WMODE")); if (getenv("WIDE")) g_wino_wide = 1; if (getenv("CB1")) g_wino_cb2 = 0;          // WMODE=2 / 3: pin the 32-tile / 64-tile kernel
+        launch_wino_weights(w, U, Cout, Cin, g_wino_pieces, 0); a.wino_u = U; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, Cin); g_wino_min_blocks = 1; if (getenv("WMODE")) g_wino_on = atoi(getenv("WMODE")); if (getenv("WIDE")) g_wino_wide = 1; if (getenv("CB1")) g_wino_cb2 = 0; if (getenv("PERSIST")) g_wino_persist = atoi(getenv("PERSIST"));          // WMODE=2 / 3: pin the 32-tile / 64-tile kernel
         if (getenv("XF")) { float* sc; hipMalloc(&sc, Cin * 8); std::vector<float> h2(2 * Cin, 0.5f); hipMemcpy(sc, h2.data(), Cin * 8, hipMemcpyHostToDevice); a.in_scale = sc; a.in_shift = sc + Cin; }
         if (atoi(getenv("WINO")) == 2) {
             hipEventRecord(e0); for (int i = 0; i < 20; ++i) launch_wino_weights(w, U, Cout, Cin, g_wino_pieces, 0); hipEventRecord(e1); hipEventSynchronize(e1);
