@@ -9,126 +9,9 @@
 // Algorithmic HBM bytes per sample per scale (fwd): 4P(1+3C).
 // Training uses loss_train_kernel instead: the same tile (+2 px halo) built once, loss value AND pullback out of it -- d loss / d disparity
 // (4P per scale, the coarse scales already resized to their own resolution) plus 24 pose-gradient partials per block (DPP + LDS reduction, no per-pixel atomics).
-#include "md2_internal.h"
-#include <algorithm>
+#include "loss_device.h"
 
 namespace md2 {
-
-constexpr int TW = 32, TH = 16;           // tile
-constexpr int FW = TW + 2, FH = TH + 2;   // fwd region (halo 1)
-constexpr int MAXC = 3;
-
-struct Pose12 { float R[9]; float t[3]; };   // column-major R
-
-// v_rcp_f32 / v_exp_f32 (1 ulp / ~2 ulp): an IEEE fp32 division is ~10 VALU instructions and the fused loss kernels were
-// instruction-bound (~20 divisions per pixel and scale); the 1e-7 relative differences are far inside the 1e-4 parity budget.
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fexp(float x) { return __expf(x); }
-
-__device__ __forceinline__ void up_src_f(int o, int in, int out, int& i0, int& i1, float& w1) {
-    const float ratio = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    const float s = ratio * (float)o;
-    i0 = min((int)floorf(s), in - 1);
-    i1 = min(i0 + 1, in - 1);
-    w1 = s - (float)i0;
-}
-// same with the ratio precomputed on the host (identical fp32 value: (in-1)/(out-1) rounded once)
-__device__ __forceinline__ void up_src_r(int o, int in, float ratio, int& i0, int& i1, float& w1) {
-    const float s = ratio * (float)o;
-    i0 = min((int)floorf(s), in - 1);
-    i1 = min(i0 + 1, in - 1);
-    w1 = s - (float)i0;
-}
-// disparity of scale `sc` at full-resolution pixel (py,px): identity at full res, else NNlib.upsample_bilinear (src/training.jl:44-46)
-__device__ __forceinline__ float disp_at(const float* __restrict__ d, int dh, int dw, int H, int W, int py, int px) {
-    if (dh == H && dw == W) return d[(long)py * W + px];
-    int h0, h1, w0, w1; float fh, fw;
-    const float rh = H > 1 ? (float)(dh - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(dw - 1) / (float)(W - 1) : 0.f;   // block-uniform -> scalar unit
-    up_src_r(py, dh, rh, h0, h1, fh); up_src_r(px, dw, rw, w0, w1, fw);
-    return (1.f - fh) * ((1.f - fw) * d[h0 * dw + w0] + fw * d[h0 * dw + w1]) + fh * ((1.f - fw) * d[h1 * dw + w0] + fw * d[h1 * dw + w1]);
-}
-struct Proj { float x, y, mx, my; float P[3]; float c[3]; float denom; };
-// disparity_to_depth + Backproject + Project + grid-sample coordinate (src/utils.jl:175-179,63-65,95-99; NNlib unnormalize + :border clamp)
-__device__ __forceinline__ void project_px(float d, int py, int px, const float* __restrict__ K, const float* __restrict__ invK, const Pose12& T,
-                                           float min_disp, float max_disp, int H, int W, Proj& o) {
-    const float depth = frcp(d * (max_disp - min_disp) + min_disp);
-    const float cx = (float)(px + 1), cy = (float)(py + 1);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) o.P[i] = depth * (invK[i] * cx + invK[3 + i] * cy + invK[6 + i] * 1.f);
-    float r[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) r[i] = (T.R[i] * o.P[0] + T.R[3 + i] * o.P[1] + T.R[6 + i] * o.P[2]) + T.t[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) o.c[i] = K[i] * r[0] + K[3 + i] * r[1] + K[6 + i] * r[2];
-    o.denom = frcp(o.c[2] + 1e-7f);
-    const float rW = 1.f / (float)(W - 1), rH = 1.f / (float)(H - 1);        // uniform: evaluated once on the scalar/constant path
-    const float gx = (((o.c[0] * o.denom - 1.f) * rW) - 0.5f) * 2.f;
-    const float gy = (((o.c[1] * o.denom - 1.f) * rH) - 0.5f) * 2.f;
-    float x = ((gx + 1.f) * 0.5f) * (float)(W - 1), y = ((gy + 1.f) * 0.5f) * (float)(H - 1);
-    o.mx = 0.5f * (float)(W - 1); o.my = 0.5f * (float)(H - 1);
-    if (!(x > 0.f)) { x = 0.f; o.mx = 0.f; } else if (x >= (float)(W - 1)) { x = (float)(W - 1); o.mx = 0.f; }
-    if (!(y > 0.f)) { y = 0.f; o.my = 0.f; } else if (y >= (float)(H - 1)) { y = (float)(H - 1); o.my = 0.f; }
-    o.x = x; o.y = y;
-}
-struct Samp { int i00, i01, i10, i11; float wx0, wx1, wy0, wy1; bool v01, v10, v11; };
-__device__ __forceinline__ void sample_setup(float x, float y, int H, int W, Samp& s) {
-    const float fx = floorf(x), fy = floorf(y);
-    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
-    s.wx1 = x - fx; s.wx0 = 1.f - s.wx1; s.wy1 = y - fy; s.wy0 = 1.f - s.wy1;
-    const bool vx1 = x1 < W, vy1 = y1 < H;          // x0,y0 always valid after the border clamp
-    s.v01 = vx1; s.v10 = vy1; s.v11 = vx1 && vy1;
-    s.i00 = y0 * W + x0; s.i01 = y0 * W + (vx1 ? x1 : x0); s.i10 = (vy1 ? y1 : y0) * W + x0; s.i11 = (vy1 ? y1 : y0) * W + (vx1 ? x1 : x0);
-}
-// Branch-free gather: a corner that falls outside (only possible for x == W-1 / y == H-1 after the border clamp) is clamped
-// onto a valid texel by sample_setup and its bilinear weight is exactly 0, so it contributes 0 like NNlib's bounds check.
-__device__ __forceinline__ float sample_val(const float* __restrict__ im, const Samp& s) {
-    const float v00 = im[s.i00], v01 = im[s.i01], v10 = im[s.i10], v11 = im[s.i11];
-    return v00 * s.wy0 * s.wx0 + v01 * s.wy0 * s.wx1 + v10 * s.wy1 * s.wx0 + v11 * s.wy1 * s.wx1;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-struct SsimOut { float val; float g_mx, g_pxx, g_pxy; };   // SSIM value and d val / d(pool x, pool x^2, pool xy) (0 outside the clamp)
-// SSIM functor arithmetic (src/utils.jl:28-38) from the nine-sample window sums
-__device__ __forceinline__ void ssim_from_sums(float sx, float sy, float sxx, float syy, float sxy, bool want_grad, SsimOut& o) {
-    const float r9 = 1.f / 9.f;
-    const float mx = sx * r9, my = sy * r9, pxx = sxx * r9, pyy = syy * r9, pxy = sxy * r9;
-    const float c1 = 0.0001f, c2 = 0.0009f;
-    const float vx = pxx - mx * mx, vy = pyy - my * my, vxy = pxy - mx * my;
-    const float n1 = 2.f * mx * my + c1, n2 = 2.f * vxy + c2, d1 = mx * mx + my * my + c1, d2 = vx + vy + c2;
-    const float sn = n1 * n2, sd = d1 * d2, rsd = frcp(sd);
-    const float v = (1.f - sn * rsd) * 0.5f;
-    o.val = fminf(fmaxf(v, 0.f), 1.f);
-    if (want_grad) {
-        const float g = (v >= 0.f && v <= 1.f) ? 1.f : 0.f;
-        const float gsn = -0.5f * g * rsd, gsd = 0.5f * g * sn * rsd * rsd;
-        const float gn1 = gsn * n2, gn2 = gsn * n1, gd1 = gsd * d2, gd2 = gsd * d1;
-        o.g_pxx = gd2; o.g_pxy = 2.f * gn2;
-        o.g_mx = gn1 * 2.f * my + gd1 * 2.f * mx - gd2 * 2.f * mx - 2.f * gn2 * my;
-    }
-}
-
-// =====================================================================================================================
-// forward
-// =====================================================================================================================
-// forward-only projection: c = K (R P + t) = (K R) P + K t, P = depth * ray(px,py): 12 scalars per source instead of K, R, t
-struct ProjF { float M[9]; float v[3]; };       // M = K*R (column-major), v = K*t
-__device__ __forceinline__ void project_fwd(float depth, const float ray[3], const ProjF& T, int H, int W, float& x, float& y) {
-    const float P0 = depth * ray[0], P1 = depth * ray[1], P2 = depth * ray[2];
-    const float c0 = T.M[0] * P0 + T.M[3] * P1 + T.M[6] * P2 + T.v[0];
-    const float c1 = T.M[1] * P0 + T.M[4] * P1 + T.M[7] * P2 + T.v[1];
-    const float c2 = T.M[2] * P0 + T.M[5] * P1 + T.M[8] * P2 + T.v[2];
-    const float denom = frcp(c2 + 1e-7f);
-    const float rW = 1.f / (float)(W - 1), rH = 1.f / (float)(H - 1);
-    const float gx = (((c0 * denom - 1.f) * rW) - 0.5f) * 2.f, gy = (((c1 * denom - 1.f) * rH) - 0.5f) * 2.f;
-    x = ((gx + 1.f) * 0.5f) * (float)(W - 1); y = ((gy + 1.f) * 0.5f) * (float)(H - 1);
-    x = !(x > 0.f) ? 0.f : fminf(x, (float)(W - 1));       // :border clamp (NaN -> 0)
-    y = !(y > 0.f) ? 0.f : fminf(y, (float)(H - 1));
-}
 
 template <int C>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(LossArgs a, double* __restrict__ part, double* __restrict__ blk) {
@@ -260,12 +143,6 @@ void launch_loss_finalize(const LossArgs& a, const double* part, float* totals, 
 // The smoothness pullback is normalised by per-(scale, sample) sums of the whole image (mean disparity, Sx, Sy), so those come first from a
 // cheap pass that touches only the disparities and the target frame (no warp); the main kernel then builds the warped tile ONCE and emits the
 // photometric sum (for the loss value), d loss / d disparity and the pose-gradient partials.
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false)); }
-// sum over each row of 16 lanes, result in every lane of the row: xor-1 / xor-2 quad permutes, then mirror within 8 and within 16 (4 v_add_f32_dpp)
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
-    return v;
-}
 
 // part[(sc*N+n)*4 + {1: sum d, 2: Sx, 3: Sy}]: 32x32 pixel tiles, 4 pixels per thread, the scales in a loop (the edge weights exp(-|dI|) are computed once;
 // the upsampled disparities of tile + 1 go through LDS so that every position is interpolated once)
@@ -330,377 +207,6 @@ __global__ void loss_smooth_reduce_kernel(const double* __restrict__ blk, double
     part[((long)sc * N + n) * 4 + 1 + k] = s;
 }
 
-struct LossTrainOut { double* part; float* dd[MD2_MAX_SCALES]; float* dlo[MD2_MAX_SCALES]; double* dRt_acc; double* blk; };
-// One block = `tpb` consecutive TW x TH tiles of one (scale, sample).  Per tile:
-//  1. warped sources / target / disparity at the padded positions of tile + 2 -> LDS                           (the only global gathers of the forward)
-//  2. window owners q in tile + 1, three per thread in a column (row sums of the five window moments shared between them):
-//     photometric of both sources, arg-min [, automask], SSIM pullback coefficients -> LDS; owners inside the tile add to the loss sum
-//  3. per tile pixel r, TH/8 per thread in a column: d loss / d warped_s[r] = box sum of the winning owners' coefficients (row sums shared
-//     down the column; pad_reflect aliases are weights 2 on the affected row / column), then the pullback through grid_sample, Project,
-//     Backproject and disparity_to_depth, plus the smoothness pullback.
-// The 24 pose-gradient partials and the loss sum stay in registers across the block's tiles and are reduced once.
-#ifndef MD2_LOSS_HOISTED_PROJECTION
-#define MD2_LOSS_HOISTED_PROJECTION 0      // 1: sampling coordinates from the hoisted (K R) P + K t (12 scalars per source, ~4 % faster) -- moves them by ~1e-5 px against
-#endif                                     // the reference's K (R P + t), which on real texture flips a few more arg-min decisions than the oracle comparison likes
-#ifndef MD2_LOSS_WAVES
-#define MD2_LOSS_WAVES 2
-#endif
-template <int C, int TH>
-__global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArgs a, LossTrainOut o, int tpb, int ntx) {
-    constexpr int OSH = C == 1 ? 3 : 2;          // window owners per thread in phase 2 (three colour channels keep 2 x 3 x OSH coefficient triples alive: two owners fit the registers)
-    constexpr int VW = TW + 4, VH = TH + 4, OW = TW + 2, OH = TH + 2, SH = TH / 8, NSR = (OH + OSH - 1) / OSH;
-    __shared__ float wv[2][C][VH * VW];          // warped sources at the padded positions of tile + 2
-    __shared__ float tg[C][VH * VW];
-    __shared__ float dl[VH * VW];
-    __shared__ float coef[C][3][OH * OW];        // d photometric_{s*} / d (pool x, pool x^2, pool xy) at q in tile + 1, pre-scaled
-    __shared__ signed char amin[OH * OW];        // winning source at q, -1: none (outside / masked)
-    __shared__ float red[16][25];
-    constexpr int CW = TW / 2 + 2, CH = TH / 2 + 2;
-    __shared__ float crow[CH * TW];              // coarse scales, resize adjoint of the tile's d loss / d disparity: after the row direction [coarse row][tile column] ...
-    __shared__ float cacc[CH * CW];              // ... and after the column direction [coarse row][coarse column]
-    const int zi = blockIdx.z, sc = zi / a.N, n = zi % a.N;
-    const int H = a.H, W = a.W;
-    const long P = (long)H * W;
-    const int ty0 = blockIdx.y * TH;
-    const float* xn = a.x + (long)n * 3 * C * P;
-    const float* tgt = xn + (long)a.tgt * C * P;
-    const float* srcs[2] = {xn + (long)a.src0 * C * P, xn + (long)a.src1 * C * P};
-    const int dh = a.dh[sc], dw = a.dw[sc];
-    const float* dsp = a.disp[sc] + (long)n * dh * dw;
-    float* dd = o.dd[sc] + (long)n * P;
-    float* dlo = o.dlo[sc] ? o.dlo[sc] + (long)n * dh * dw : nullptr;
-    const float rh = H > 1 ? (float)(dh - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(dw - 1) / (float)(W - 1) : 0.f;
-    Pose12 T[2]; ProjF TF[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const float* rt = a.Rt + ((long)s * a.N + n) * 12;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) T[s].R[i] = rt[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) T[s].t[i] = rt[9 + i];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) TF[s].M[j * 3 + i] = a.K[i] * rt[j * 3] + a.K[3 + i] * rt[j * 3 + 1] + a.K[6 + i] * rt[j * 3 + 2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) TF[s].v[i] = a.K[i] * rt[9] + a.K[3 + i] * rt[10] + a.K[6 + i] * rt[11];
-    }
-    const float alpha = 0.85f, beta = 1.f - alpha, invC = 1.f / (float)C;
-    const float wpix = 1.f / ((float)a.nscales * (float)a.N * (float)P);      // d loss / d warp_loss[q]
-    // smoothness normalisation from the sums of the first pass (same arithmetic as loss_finalize_kernel)
-    const double* pt = o.part + (long)zi * 4;
-    const double cntx = (double)(W - 1) * H * a.N, cnty = (double)W * (H - 1) * a.N;
-    const float mean_d = (float)(pt[1] / (double)P);
-    const float den = a.normalize ? mean_d + 1e-7f : 1.f;
-    const float sw = a.smooth_w[sc] / (float)a.nscales;
-    const float ax = sw / den / (float)cntx, ay = sw / den / (float)cnty;
-    const float corr = a.normalize ? sw * (float)((double)(float)pt[2] / cntx + (double)(float)pt[3] / cnty) / (den * den) / (float)P : 0.f;
-    float acc[24], s_photo = 0.f;
-#pragma unroll
-    for (int k = 0; k < 24; ++k) acc[k] = 0.f;
-    if constexpr (C > 1) {                               // three channels: the 24 pose sums live only inside phase 3 -- per tile they are row-reduced into `red` (held across phases 1-2 they went to scratch)
-        for (int i = threadIdx.x; i < 16 * 25; i += 256) (&red[0][0])[i] = 0.f;
-    }
-
-    for (int t = 0; t < tpb; ++t) {
-        int tid = threadIdx.x;
-        if (C > 1) asm volatile("" : "+v"(tid));      // three channels: keeps hipcc from hoisting the per-thread tile indices of every phase out of the tile loop (they lived in scratch: 56 spilled registers)
-        const int tix = blockIdx.x * tpb + t;
-        if (tix >= ntx) break;
-        const int tx0 = tix * TW;
-        if (t) __syncthreads();                  // the previous tile's phases 3 / 4 still read the LDS tiles
-        int ci_lo = 0, cj_lo = 0;
-        if (dlo) {
-            int i1; float f;
-            up_src_r(ty0, dh, rh, ci_lo, i1, f); up_src_r(tx0, dw, rw, cj_lo, i1, f);                 // first coarse row / column this tile touches
-            for (int i = tid; i < CH * TW; i += 256) crow[i] = 0.f;
-            for (int i = tid; i < CH * CW; i += 256) cacc[i] = 0.f;
-        }
-        // ---- phase 1: values at padded positions u in tile + 2 (u clamped into the padded domain [-1, size])
-        for (int i = tid; i < VH * VW; i += 256) {
-            const int ry = i / VW, rx = i - ry * VW;
-            const int uy = max(-1, min(ty0 - 2 + ry, H)), ux = max(-1, min(tx0 - 2 + rx, W));
-            const int py = refl_idx(uy, H), px = refl_idx(ux, W);
-            const float d = disp_at(dsp, dh, dw, H, W, py, px);
-            dl[i] = d;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-#if MD2_LOSS_HOISTED_PROJECTION
-                const float depth = frcp(d * (a.max_disp - a.min_disp) + a.min_disp);
-                const float cx = (float)(px + 1), cy = (float)(py + 1);
-                const float ray[3] = {a.invK[0] * cx + a.invK[3] * cy + a.invK[6], a.invK[1] * cx + a.invK[4] * cy + a.invK[7], a.invK[2] * cx + a.invK[5] * cy + a.invK[8]};
-                float x, y; project_fwd(depth, ray, TF[s], H, W, x, y);
-                Samp sm; sample_setup(x, y, H, W, sm);
-#else
-                Proj pr; project_px(d, py, px, a.K, a.invK, T[s], a.min_disp, a.max_disp, H, W, pr);      // the reference's order of operations: K (R P + t)
-                Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
-#endif
-#pragma unroll
-                for (int c = 0; c < C; ++c) wv[s][c][i] = sample_val(srcs[s] + (long)c * P, sm);
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) tg[c][i] = tgt[(long)c * P + (long)py * W + px];
-        }
-        __syncthreads();
-        // ---- phase 2: window owners q in tile + 1, OSH vertically adjacent ones per thread
-#pragma unroll 1
-        for (int st = tid; st < OW * NSR; st += 256) {
-            const int k3 = st / OW, rx = st - k3 * OW, ry0 = k3 * OSH;
-            float pl[OSH][2], gmx[OSH][2][C], gpxx[OSH][2][C], gpxy[OSH][2][C];
-#pragma unroll
-            for (int oo = 0; oo < OSH; ++oo) { pl[oo][0] = 0.f; pl[oo][1] = 0.f; }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if (C > 1 && c) __builtin_amdgcn_sched_barrier(0);      // one channel's window rows at a time: hoisting all three channels' LDS reads pushed the pose sums into scratch
-                float Ry[OSH + 2], Ryy[OSH + 2], yc[OSH + 2], Rx[2][OSH + 2], Rxx[2][OSH + 2], Rxy[2][OSH + 2], xc[2][OSH + 2];
-#pragma unroll
-                for (int j = 0; j < OSH + 2; ++j) {
-                    const int b = min(ry0 + j, VH - 1) * VW + rx;       // rows past the value region belong to owners that are never stored
-                    const float y0 = tg[c][b], y1 = tg[c][b + 1], y2 = tg[c][b + 2];
-                    Ry[j] = y0 + y1 + y2; Ryy[j] = y0 * y0 + y1 * y1 + y2 * y2; yc[j] = y1;
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const float x0 = wv[s][c][b], x1 = wv[s][c][b + 1], x2 = wv[s][c][b + 2];
-                        Rx[s][j] = x0 + x1 + x2; Rxx[s][j] = x0 * x0 + x1 * x1 + x2 * x2; Rxy[s][j] = x0 * y0 + x1 * y1 + x2 * y2; xc[s][j] = x1;
-                    }
-                }
-#pragma unroll
-                for (int oo = 0; oo < OSH; ++oo) {
-                    const float sy = Ry[oo] + Ry[oo + 1] + Ry[oo + 2], syy = Ryy[oo] + Ryy[oo + 1] + Ryy[oo + 2];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        SsimOut so;
-                        ssim_from_sums(Rx[s][oo] + Rx[s][oo + 1] + Rx[s][oo + 2], sy, Rxx[s][oo] + Rxx[s][oo + 1] + Rxx[s][oo + 2], syy, Rxy[s][oo] + Rxy[s][oo + 1] + Rxy[s][oo + 2], true, so);
-                        pl[oo][s] += alpha * invC * so.val + beta * invC * fabsf(yc[oo + 1] - xc[s][oo + 1]);
-                        gmx[oo][s][c] = so.g_mx; gpxx[oo][s][c] = so.g_pxx; gpxy[oo][s][c] = so.g_pxy;
-                    }
-                }
-            }
-#pragma unroll
-            for (int oo = 0; oo < OSH; ++oo) {
-                const int ry = ry0 + oo;
-                if (ry >= OH) break;
-                const int qi = ry * OW + rx, qy = ty0 - 1 + ry, qx = tx0 - 1 + rx;
-                signed char win = -1;
-                float m = 0.f;
-                if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
-                    win = pl[oo][1] < pl[oo][0] ? 1 : 0;                                       // first arg-min (Zygote `minimum`)
-                    float wl = win ? pl[oo][1] : pl[oo][0];
-                    if (a.auto_loss) { const float al = a.auto_loss[(long)n * P + (long)qy * W + qx]; if (!(wl < al)) { wl = al; win = -1; } }   // mask wins ties -> no gradient
-                    if (ry >= 1 && ry <= TH && rx >= 1 && rx <= TW) s_photo += wl;          // owners of this tile (the ring belongs to the neighbours)
-                    m = win < 0 ? 0.f : wpix * alpha * invC * (1.f / 9.f);                     // through mean_c, alpha, and the /9 of MeanPool
-                }
-                const bool w1 = win == 1;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {                                                  // select by value: a runtime index would put the arrays in scratch
-                    coef[c][0][qi] = m * (w1 ? gmx[oo][1][c] : gmx[oo][0][c]);
-                    coef[c][1][qi] = m * (w1 ? gpxx[oo][1][c] : gpxx[oo][0][c]);
-                    coef[c][2][qi] = m * (w1 ? gpxy[oo][1][c] : gpxy[oo][0][c]);
-                }
-                amin[qi] = win;
-            }
-        }
-        __syncthreads();
-        // ---- phase 3: tile pixels, SH per thread down a column
-        {
-            const int lx = tid & 31, ly0 = (tid >> 5) * SH, px = tx0 + lx;
-            const float wxm = px == 1 ? 2.f : 1.f, wxp = px == W - 2 ? 2.f : 1.f;          // pad_reflect: column px-1 / px+1 is seen a second time through the padded column
-            float rs[3][2][C][3];                                                          // ring of owner-row sums: [row][source][channel][coefficient]
-            auto rowsum = [&](int orow, float (&r)[2][C][3]) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int c = 0; c < C; ++c) { r[s][c][0] = 0.f; r[s][c][1] = 0.f; r[s][c][2] = 0.f; }
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int qi = orow * OW + lx + 1 + dx;
-                    const int am = amin[qi];
-                    const float w = dx < 0 ? wxm : (dx > 0 ? wxp : 1.f);
-                    const float m0 = am == 0 ? w : 0.f, m1 = am == 1 ? w : 0.f;
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { const float cv = coef[c][k][qi]; r[0][c][k] += m0 * cv; r[1][c][k] += m1 * cv; }
-                }
-            };
-            float gwp[C > 1 ? SH : 1][2][C];                                              // three channels: d loss / d warped_s[r][c] of the thread's SH pixels, one channel at a time
-            if constexpr (C > 1) {                                                        // (the ring of all channels' row sums is 54 registers; per channel it is (SH + 2) x 6)
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    if (c) __builtin_amdgcn_sched_barrier(0);
-                    float r1[SH + 2][2][3];
-#pragma unroll
-                    for (int r = 0; r < SH + 2; ++r) {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { r1[r][0][k] = 0.f; r1[r][1][k] = 0.f; }
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int qi = (ly0 + r) * OW + lx + 1 + dx;
-                            const int am = amin[qi];
-                            const float w = dx < 0 ? wxm : (dx > 0 ? wxp : 1.f);
-                            const float m0 = am == 0 ? w : 0.f, m1 = am == 1 ? w : 0.f;
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) { const float cv = coef[c][k][qi]; r1[r][0][k] += m0 * cv; r1[r][1][k] += m1 * cv; }
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < SH; ++i) {
-                        const int py = ty0 + ly0 + i, cb = (ly0 + i + 2) * VW + lx + 2;
-                        const float wym = py == 1 ? 2.f : 1.f, wyp = py == H - 2 ? 2.f : 1.f;
-                        const int rwin = amin[(ly0 + i + 1) * OW + lx + 1];
-                        const float xv[2] = {wv[0][c][cb], wv[1][c][cb]}, tv = tg[c][cb];
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const float g0 = wym * r1[i][s][0] + r1[i + 1][s][0] + wyp * r1[i + 2][s][0];
-                            const float g1 = wym * r1[i][s][1] + r1[i + 1][s][1] + wyp * r1[i + 2][s][1];
-                            const float g2 = wym * r1[i][s][2] + r1[i + 1][s][2] + wyp * r1[i + 2][s][2];
-                            float g = g0 + 2.f * xv[s] * g1 + tv * g2;
-                            if (rwin == s) { const float df = tv - xv[s]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
-                            gwp[i][s][c] = g;
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else { rowsum(ly0, rs[0]); rowsum(ly0 + 1, rs[1]); }                          // owner rows of pixel rows ly0-1 and ly0
-#pragma unroll
-            for (int i = 0; i < SH; ++i) {
-                if constexpr (C == 1) rowsum(ly0 + i + 2, rs[(i + 2) % 3]);
-                const int ly = ly0 + i, py = ty0 + ly;
-                if (py >= H || px >= W) continue;
-                const float wym = py == 1 ? 2.f : 1.f, wyp = py == H - 2 ? 2.f : 1.f;
-                const int cb = (ly + 2) * VW + lx + 2;          // r in the value region
-                const float d = dl[cb];
-                float gd = 0.f;                                   // d loss / d disparity[r]
-                const int rwin = amin[(ly + 1) * OW + lx + 1];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float gw[C];
-                    bool any = false;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        float g;
-                        if constexpr (C > 1) g = gwp[i][s][c];
-                        else {
-                            const float g0 = wym * rs[i % 3][s][c][0] + rs[(i + 1) % 3][s][c][0] + wyp * rs[(i + 2) % 3][s][c][0];
-                            const float g1 = wym * rs[i % 3][s][c][1] + rs[(i + 1) % 3][s][c][1] + wyp * rs[(i + 2) % 3][s][c][1];
-                            const float g2 = wym * rs[i % 3][s][c][2] + rs[(i + 1) % 3][s][c][2] + wyp * rs[(i + 2) % 3][s][c][2];
-                            g = g0 + 2.f * wv[s][c][cb] * g1 + tg[c][cb] * g2;
-                            if (rwin == s) { const float df = tg[c][cb] - wv[s][c][cb]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
-                        }
-                        gw[c] = g; any = any || g != 0.f;
-                    }
-                    if (!any) continue;
-                    // grid_sample pullback wrt the sampling coordinate
-                    Proj pr; project_px(d, py, px, a.K, a.invK, T[s], a.min_disp, a.max_disp, H, W, pr);
-                    Samp sm; sample_setup(pr.x, pr.y, H, W, sm);
-                    float ggx = 0.f, ggy = 0.f;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const float* im = srcs[s] + (long)c * P;
-                        const float v00 = im[sm.i00], v01 = sm.v01 ? im[sm.i01] : 0.f, v10 = sm.v10 ? im[sm.i10] : 0.f, v11 = sm.v11 ? im[sm.i11] : 0.f;   // NNlib: outside corners read as 0 in the coordinate pullback
-                        ggx += gw[c] * ((v01 - v00) * sm.wy0 + (v11 - v10) * sm.wy1);
-                        ggy += gw[c] * ((v10 - v00) * sm.wx0 + (v11 - v01) * sm.wx1);
-                    }
-                    ggx *= pr.mx; ggy *= pr.my;                  // unnormalise: (size-1)/2, 0 where clamped
-                    // Project pullback (normalise: *2/(size-1))
-                    const float gu = ggx * (2.f / (float)(W - 1)), gv = ggy * (2.f / (float)(H - 1));
-                    const float gc[3] = {gu * pr.denom, gv * pr.denom, -(gu * pr.c[0] + gv * pr.c[1]) * pr.denom * pr.denom};
-                    float gr[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) gr[j] = a.K[j * 3 + 0] * gc[0] + a.K[j * 3 + 1] * gc[1] + a.K[j * 3 + 2] * gc[2];
-                    float gP[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        gP[j] = T[s].R[j * 3 + 0] * gr[0] + T[s].R[j * 3 + 1] * gr[1] + T[s].R[j * 3 + 2] * gr[2];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) acc[s * 12 + j * 3 + k] += gr[k] * pr.P[j];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) acc[s * 12 + 9 + k] += gr[k];
-                    // Backproject + disparity_to_depth pullback
-                    const float cx = (float)(px + 1), cy = (float)(py + 1);
-                    float gdepth = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) gdepth += gP[k] * (a.invK[k] * cx + a.invK[3 + k] * cy + a.invK[6 + k]);
-                    const float ddn = d * (a.max_disp - a.min_disp) + a.min_disp;
-                    const float rdd = frcp(ddn);
-                    gd += -gdepth * (a.max_disp - a.min_disp) * rdd * rdd;
-                }
-                // smooth_loss(d / (mean + eps)) pullback
-                float gs = -corr;
-                auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
-                auto ex = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + 1]); if (C > 1) gi *= invC; return fexp(-gi); };
-                auto ey = [&](int b) { float gi = 0.f; for (int c = 0; c < C; ++c) gi += fabsf(tg[c][b] - tg[c][b + VW]); if (C > 1) gi *= invC; return fexp(-gi); };
-                if (px + 1 < W) gs += ax * sgn(d - dl[cb + 1]) * ex(cb);
-                if (px >= 1) gs -= ax * sgn(dl[cb - 1] - d) * ex(cb - 1);
-                if (py + 1 < H) gs += ay * sgn(d - dl[cb + VW]) * ey(cb);
-                if (py >= 1) gs -= ay * sgn(dl[cb - VW] - d) * ey(cb - VW);
-                if (dlo) {                                        // adjoint of NNlib.upsample_bilinear, row direction: the lanes of a wave hold different columns -> no conflicts
-                    int h0, h1; float fh; up_src_r(py, dh, rh, h0, h1, fh);
-                    const float g = gd + gs;
-                    atomicAdd(crow + (h0 - ci_lo) * TW + lx, (1.f - fh) * g); atomicAdd(crow + (h1 - ci_lo) * TW + lx, fh * g);
-                } else dd[(long)py * W + px] = gd + gs;
-            }
-        }
-        if constexpr (C > 1) {
-            const int row = tid >> 4;
-#pragma unroll
-            for (int k = 0; k < 24; ++k) { const float r = row16_sum(acc[k]); if ((tid & 15) == 0) red[row][k] += r; acc[k] = 0.f; }      // (lane 0 of a row is the only writer of red[row][*])
-        }
-        // ---- coarse scales: column direction on the few coarse rows, then flush (border rows / columns are shared with the neighbouring tiles -> float atomics)
-        if (dlo) {
-            __syncthreads();
-            int i0, ci_hi, cj_hi; float f;
-            up_src_r(min(ty0 + TH, H) - 1, dh, rh, i0, ci_hi, f); up_src_r(min(tx0 + TW, W) - 1, dw, rw, i0, cj_hi, f);
-            const int nrow = ci_hi - ci_lo + 1, ncol = cj_hi - cj_lo + 1;
-            for (int it = tid; it < nrow * TW; it += 256) {
-                const int r = it / TW, p = it - r * TW;
-                if (tx0 + p >= W) continue;
-                int w0, w1; float fw; up_src_r(tx0 + p, dw, rw, w0, w1, fw);
-                const float v = crow[it];
-                atomicAdd(cacc + r * CW + w0 - cj_lo, (1.f - fw) * v); atomicAdd(cacc + r * CW + w1 - cj_lo, fw * v);
-            }
-            __syncthreads();
-            for (int it = tid; it < nrow * ncol; it += 256) {
-                const int r = it / ncol, c = it - r * ncol;
-                const float v = cacc[r * CW + c];
-                if (v != 0.f) atomicAdd(dlo + (long)(ci_lo + r) * dw + cj_lo + c, v);
-            }
-        }
-    }
-    // ---- block reduction: rows of 16 lanes by DPP, the 16 rows through LDS, one double atomic per value per block
-    const int row = threadIdx.x >> 4;
-    if constexpr (C == 1) {
-#pragma unroll
-        for (int k = 0; k < 24; ++k) { const float r = row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[row][k] = r; }
-    }
-    { const float r = row16_sum(s_photo); if ((threadIdx.x & 15) == 0) red[row][24] = r; }
-    __syncthreads();
-    if (threadIdx.x < 25) {
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v += red[r][threadIdx.x];
-        if (o.blk) o.blk[((long)zi * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x) * 25 + threadIdx.x] = (double)v;
-        else if (threadIdx.x == 24) atomicAdd(o.part + (long)zi * 4, (double)v);
-        else if (v != 0.f) { const int s = threadIdx.x / 12, k = threadIdx.x % 12; atomicAdd(o.dRt_acc + ((long)s * a.N + n) * 12 + k, (double)v); }
-    }
-}
-// deterministic mode: photometric sums and pose-gradient partials of loss_train_kernel in (scale, block) order
-__global__ void loss_train_reduce_kernel(const double* __restrict__ blk, double* __restrict__ part, double* __restrict__ dRt_acc, int N, int nscales, int nb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 24 * N) {
-        const int k = i % 12, n = (i / 12) % N, s = i / (12 * N);
-        double acc = 0;
-        for (int sc = 0; sc < nscales; ++sc)
-            for (int b = 0; b < nb; ++b) acc += blk[(((long)sc * N + n) * nb + b) * 25 + s * 12 + k];
-        dRt_acc[((long)s * N + n) * 12 + k] = acc;
-    } else if (i < 24 * N + N * nscales) {
-        const int g = i - 24 * N;
-        double acc = 0;
-        for (int b = 0; b < nb; ++b) acc += blk[((long)g * nb + b) * 25 + 24];
-        part[(long)g * 4] = acc;
-    }
-}
 // launch_loss_smooth_sums fills slots 1..3 of part (zeroed by the caller), launch_loss_train (after it, same stream) slot 0 -- together what launch_loss_fwd gives; dd[sc] = [N][H][W] gradient wrt the full-resolution disparity of scale sc,
 // or dlo[sc] = [N][dh][dw] (zeroed by the caller) its resize adjoint
 void launch_loss_smooth_sums(const LossArgs& a, double* part, double* blk, hipStream_t s) {
@@ -708,18 +214,6 @@ void launch_loss_smooth_sums(const LossArgs& a, double* part, double* blk, hipSt
     if (a.C == 1) hipLaunchKernelGGL(loss_smooth_sums_kernel<1>, grid, dim3(256), 0, s, a, part, blk);
     else hipLaunchKernelGGL(loss_smooth_sums_kernel<3>, grid, dim3(256), 0, s, a, part, blk);
     if (blk) hipLaunchKernelGGL(loss_smooth_reduce_kernel, dim3((a.N * a.nscales * 3 + 63) / 64), dim3(64), 0, s, blk, part, a.N, a.nscales, (int)(grid.x * grid.y));
-}
-void launch_loss_train(const LossArgs& a, double* part, float* const dd[MD2_MAX_SCALES], float* const dlo[MD2_MAX_SCALES], double* dRt_acc, double* blk, hipStream_t s) {
-    if ((a.C != 1 && a.C != 3) || a.H < 2 || a.W < 2) { fprintf(stderr, "md2: loss_train: unsupported C=%d H=%d W=%d\n", a.C, a.H, a.W); abort(); }
-    LossTrainOut o; o.part = part; o.dRt_acc = dRt_acc; o.blk = blk;
-    for (int i = 0; i < MD2_MAX_SCALES; ++i) { o.dd[i] = dd[i]; o.dlo[i] = dlo[i]; }
-    static const int tpb_env = md2_tune("MD2_LOSS_TPB", 0);
-    const int ntx = (a.W + TW - 1) / TW, tpb = tpb_env > 0 ? tpb_env : (a.C == 1 ? 2 : 4);          // (tools/run_loss_tpb.sh, round 5: C = 1 0.433 / 0.427 / 0.429 / 0.489 ms for 1 / 2 / 3 / 4 tiles per workgroup at batch 32; C = 3 at 1024x320, batch 8: 1.231 / 1.203 / 1.210 / 1.183)
-    const int th = a.C == 1 ? 32 : 16;
-    dim3 grid((ntx + tpb - 1) / tpb, (a.H + th - 1) / th, a.N * a.nscales);
-    if (a.C == 1) hipLaunchKernelGGL((loss_train_kernel<1, 32>), grid, dim3(256), 0, s, a, o, tpb, ntx);
-    else hipLaunchKernelGGL((loss_train_kernel<3, 16>), grid, dim3(256), 0, s, a, o, tpb, ntx);
-    if (blk) hipLaunchKernelGGL(loss_train_reduce_kernel, dim3((24 * a.N + a.N * a.nscales + 63) / 64), dim3(64), 0, s, blk, part, dRt_acc, a.N, a.nscales, (int)(grid.x * grid.y));
 }
 
 // =====================================================================================================================

@@ -581,7 +581,9 @@ def test_bf16_activation_storage_tracks_the_fp32_oracle(cfgd):
             # direction of the whole vector is asserted here.  (A finite-difference check is no help at this shape: under the automask even the fp32 loss is locally linear only
             # for steps that change it by < 1e-4 relative -- tools/explore_bs.py -- where the bf16 tensors' rounding is the larger effect.)  The gradient of the benched
             # configuration is held against the fp32 step of the same library at its own batch size: test_full_batch_properties_of_configs_4_and_5[...bf16_storage...].
-            assert cos_all > 0.35
+            # (round 6, advisor: a per-array statistic beside the whole-vector one -- the median cosine of the large weight arrays, measured 0.52 with the lowest arrays at
+            # 0.20 - 0.31; a mis-wired kernel's arrays sit at 0 +- 0.01 and several of them pull the median down)
+            assert cos_all > 0.35 and median > 0.3
     model.load_params(theta)
     l0 = float(md().train_step(model, xd, al, cache, params, do_update=True))
     for _ in range(8):
@@ -631,7 +633,7 @@ def _bf16_storage_gradient_is_the_derivative_of_its_own_loss(model, xd, al, cach
         md().set_deterministic(False)
         model.load_params(theta)
     for r in rows:
-        print("bf16_storage finite difference: %-24s |g| %.4e  (dL/de) / |g| at 3e-3: %.3f  at 1e-3: %.3f" % r)
+        print("bf16_storage finite difference: %-24s |g| %.4e  (dL/de) / |g| at predicted relative loss changes %g: %.3f  %g: %.3f" % (r[0], r[1], steps[0], r[2], steps[1], r[3]))
     bad = [r for r in rows if not any(0.6 < v < 1.4 for v in r[2:])]
     assert not bad, "bf16-storage gradient arrays that are not the derivative of the bf16-storage loss: " + ", ".join("%s (ratios %.3f, %.3f)" % (r[0], r[2], r[3]) for r in bad)
 
@@ -1145,6 +1147,45 @@ def _slices(C, depth):
         n = int(np.prod(shape)); yield off, n; off += n
 
 
+def test_bf16_storage_trains_like_fp32():
+    """Convergence evidence for md2_config.precision = 2 (round-5 review: "no evidence that it trains to the same place"): ResNet-18, 416 x 128, batch 4, ADAM(1e-4), nine
+    passes over 16 fixed synthetic batches (144 steps) from ONE initialisation, bit-reproducible mode, three runs: fp32, fp32 from the same initialisation moved by ~8 ulp
+    (relative noise 1e-6), and bf16 tensors.  The loss is compared per PASS (mean over the 16 batches).
+    What can be asked: the fp32 run does not reproduce ITSELF to 5 % pointwise -- the perturbed fp32 run's pass means differ from the unperturbed run's by up to 7 %
+    (tools/convergence_probe.py: ratios 0.929 .. 1.034 over passes 3 - 9; the trajectory on the loss plateau near 0.09 is chaotic, single steps differ by 25 - 34 %).  So
+    the bf16 run is held to what the second fp32 run is: (a) every run brings the loss from 0.213 to below 0.11 and keeps it there; (b) averaged over passes 3 - 9 the
+    bf16 curve is within 5 % of the fp32 curve (measured +1.8 %; the perturbed fp32 run: -1.9 %); (c) no pass of the bf16 run is further from the fp32 run than twice the
+    largest fp32-to-fp32 distance plus 2 % (measured: bf16 10.0 %, fp32-to-fp32 7.1 %)."""
+    B, C, H, W, nb, passes = 4, 1, 128, 416, 16, 9
+    K, iK = syn.depth10k_intrinsics(W, H)
+    xs = [dev(syn.synthetic_triplets(B, C, H, W, seed=500 + i)) for i in range(nb)]
+    theta = syn.init_params(C, seed=42)
+    rs = np.random.RandomState(7)
+    theta_p = (theta.astype(np.float64) * (1.0 + 1e-6 * rs.standard_normal(theta.shape))).astype(np.float32)
+    curves = {}
+    md().set_deterministic(True)
+    try:
+        for name, prec, th in (("f32", "f32", theta), ("f32_perturbed", "f32", theta_p), ("bf16_storage", "bf16_storage", theta)):
+            m = md()
+            params = m.Params(target_size=(W, H), batch_size=B, automasking=False)
+            cache = m.TrainCache(m.SSIM(), m.Backproject(W, H), m.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
+            enc = m.ResidualNetwork(18, in_channels=C)
+            model = m.Model(enc, m.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), m.PoseDecoder(enc.stages[-1]), lr=1e-4, precision=prec)
+            model.load_params(th)
+            curves[name] = np.array([float(m.train_step(model, xs[i % nb], None, cache, params, True)) for i in range(nb * passes)]).reshape(passes, nb)
+            model.close()
+    finally:
+        md().set_deterministic(False)
+    a, a2, b = (curves[k].mean(1) for k in ("f32", "f32_perturbed", "bf16_storage"))
+    print("pass means fp32 %s\n fp32 perturbed %s\n bf16 tensors %s" % (np.round(a, 5), np.round(a2, 5), np.round(b, 5)))
+    for name, c in curves.items():
+        assert np.isfinite(c).all() and c[0, 0] > 0.2 and (c.mean(1)[2:] < 0.11).all(), name            # (a)
+    self_dev = np.abs(a2[2:] / a[2:] - 1.0); bf_dev = np.abs(b[2:] / a[2:] - 1.0)
+    print("passes 3-9: bf16 / fp32 mean ratio %.4f (max deviation %.4f); fp32 perturbed / fp32 mean ratio %.4f (max deviation %.4f)" % ((b[2:] / a[2:]).mean(), bf_dev.max(), (a2[2:] / a[2:]).mean(), self_dev.max()))
+    assert abs((b[2:] / a[2:]).mean() - 1.0) < 0.05                                                     # (b)
+    assert bf_dev.max() < 2.0 * self_dev.max() + 0.02                                                   # (c)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------
 # the configurations bench.py measures, at their FULL batch
 # ---------------------------------------------------------------------------------------------------------------------------------------
@@ -1197,7 +1238,16 @@ def test_full_batch_properties_of_configs_4_and_5(cfgd):
         tab = per_array(g, g32, C, depth); top = max(t[3] for t in tab)
         big = sorted(t[1] for t in tab if t[0].endswith(".W") and t[3] > 1e-2 * top)
         print("config 5 as benched (bf16 storage + automask, batch %d) vs the fp32 step: loss rel %.2e cos_all %.3f large arrays: worst %.3f median %.3f" % (N, abs(float(l1) - l32) / l32, cos_all, big[0], big[len(big) // 2]))
-        assert cos_all > 0.5 and big[0] > 0.0 and big[len(big) // 2] > 0.25          # (this batch: 0.66 / 0.14 / 0.35; a mis-wired pullback kernel leaves its arrays uncorrelated: cosine ~ 0 +- 0.01 at these sizes)
+        assert cos_all > 0.5 and big[len(big) // 2] > 0.25          # (this batch: 0.66 whole vector / 0.35 median array)
+        # The per-array statement (round 6; until round 5 this line read `big[0] > 0.0`, i.e. nothing): under the automask single arrays of the bf16-tensor step point up to
+        # 80 degrees away from the fp32 step's (mask and arg-min decisions taken on bf16-perturbed disparities), so "same direction as fp32" cannot be asked array by array --
+        # but "derivative of its OWN loss" can: with the automask off, at this shape and batch, the centred finite difference of the bf16-tensor handle's loss along each
+        # stage-3 / stage-4 / decoder / pose array's gradient must reproduce that array's gradient norm.  Calibration (tools/fd_probe_r18.py, same shape, batch 8): the fp32
+        # handle's ratios are 0.76 .. 1.01 at a predicted relative loss change of 1e-3 and 0.95 .. 1.01 at 3e-4; the bf16-tensor handle's 0.72 .. 1.10 and 0.83 .. 1.01.
+        # A mis-wired pullback kernel moves its array's ratio by O(1).
+        mfd, pfd, cfd, thfd, _, _ = make(N, C, H, W, automask=False, pseed=71, depth=depth, precision="bf16_storage")
+        _bf16_storage_gradient_is_the_derivative_of_its_own_loss(mfd, xd, None, cfd, pfd, thfd, C, depth, want=FD_ARRAYS_R18, steps=(1e-3, 3e-4))
+        mfd.close()
     ds, poses = model(xd, [1, 3], 2)
     rvec = torch.stack([poses[0].rvec, poses[1].rvec]); tvec = torch.stack([poses[0].tvec, poses[1].tvec])
     la, _, _, _ = md().loss_fwd_bwd(model, xd, ds, rvec, tvec, auto_loss=al, want_grads=False)

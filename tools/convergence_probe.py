@@ -10,19 +10,20 @@ xs = [torch.from_numpy(syn.synthetic_triplets(B, C, H, W, seed=500 + i)).cuda() 
 theta = syn.init_params(C, seed=42, depth=depth)
 curves = {}
 md.set_deterministic(True)
-for prec in ("f32", "bf16_storage"):
+rs = np.random.RandomState(7); theta_p = (theta.astype(np.float64) * (1.0 + 1e-6 * rs.standard_normal(theta.shape))).astype(np.float32)          # the same initialisation moved by ~8 ulp: what an fp32 run does to itself
+for prec in ("f32", "f32_perturbed_init", "bf16_storage"):
     params = md.Params(target_size=(W, H), batch_size=B, automasking=False)
     cache = md.TrainCache(md.SSIM(), md.Backproject(W, H), md.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
     enc = md.ResidualNetwork(depth, in_channels=C)
-    model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), lr=1e-4, precision=prec)
-    model.load_params(theta)
+    model = md.Model(enc, md.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), md.PoseDecoder(enc.stages[-1]), lr=1e-4, precision=prec.split("_perturbed")[0])
+    model.load_params(theta_p if "perturbed" in prec else theta)
     curves[prec] = np.array([float(md.train_step(model, xs[i % nb], None, cache, params, True)) for i in range(steps)])
     model.close()
 md.set_deterministic(False)
-a, b = curves["f32"], curves["bf16_storage"]
+a, b, a2 = curves["f32"], curves["bf16_storage"], curves["f32_perturbed_init"]
 for s in range(nb, steps + 1, nb):
-    wa, wb = a[s - nb:s].mean(), b[s - nb:s].mean()
-    print("steps %3d..%3d (one pass over the %d batches): fp32 %.6f  bf16 tensors %.6f  ratio %.4f" % (s - nb + 1, s, nb, wa, wb, wb / wa))
+    wa, wb, w2 = a[s - nb:s].mean(), b[s - nb:s].mean(), a2[s - nb:s].mean()
+    print("steps %3d..%3d (one pass over the %d batches): fp32 %.6f  fp32 from the perturbed init %.6f (ratio %.4f)  bf16 tensors %.6f  ratio %.4f" % (s - nb + 1, s, nb, wa, w2, w2 / wa, wb, wb / wa))
 for s in (50, 100, 150):
     if s <= steps: print("window of 16 steps ending at step %d: fp32 %.6f  bf16 tensors %.6f  rel diff %.4f" % (s, a[s - 16:s].mean(), b[s - 16:s].mean(), abs(b[s - 16:s].mean() / a[s - 16:s].mean() - 1)))
 print("per-step max rel diff over the run: %.4f; first loss %.6f / %.6f" % (np.abs(b / a - 1).max(), a[0], b[0]))
