@@ -20,10 +20,10 @@ struct LossTrainOut { double* part; float* dd[MD2_MAX_SCALES]; float* dlo[MD2_MA
 #define MD2_LOSS_HOISTED_PROJECTION 0      // 1: sampling coordinates from the hoisted (K R) P + K t (12 scalars per source, ~4 % faster) -- moves them by ~1e-5 px against
 #endif                                     // the reference's K (R P + t), which on real texture flips a few more arg-min decisions than the oracle comparison likes
 #ifndef MD2_LOSS_WAVES
-#define MD2_LOSS_WAVES 2
-#endif
+#define MD2_LOSS_WAVES 3                   // waves per SIMD of the one-channel kernel (round 6): 3 = phase 3 as a rolled loop (ROLL) and the pose sums reduced per tile (APT), 143 registers, three
+#endif                                     // workgroups per CU -- the loss half 0.397 -> 0.346 ms at the headline shape (2: the round-5 form, 213 registers).  Three channels stay at 2 (55 KB of LDS per workgroup)
 template <int C, int TH>
-__global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArgs a, LossTrainOut o, int tpb, int ntx) {
+__global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_kernel(LossArgs a, LossTrainOut o, int tpb, int ntx) {
     constexpr int OSH = C == 1 ? 3 : 2;          // window owners per thread in phase 2 (three colour channels keep 2 x 3 x OSH coefficient triples alive: two owners fit the registers)
     constexpr int VW = TW + 4, VH = TH + 4, OW = TW + 2, OH = TH + 2, SH = TH / 8, NSR = (OH + OSH - 1) / OSH;
     __shared__ float wv[2][C][VH * VW];          // warped sources at the padded positions of tile + 2
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
     float acc[24], s_photo = 0.f;
 #pragma unroll
     for (int k = 0; k < 24; ++k) acc[k] = 0.f;
+    constexpr bool ROLL = C == 1 && MD2_LOSS_WAVES >= 3;
     constexpr bool APT = C > 1 || MD2_LOSS_WAVES >= 3;   // the 24 pose sums live only inside phase 3 -- per tile they are row-reduced into `red` (three channels: held across phases 1-2 they went to scratch; one channel at three waves per SIMD: 24 of the 168 registers)
     if constexpr (APT) {
         for (int i = threadIdx.x; i < 16 * 25; i += 256) (&red[0][0])[i] = 0.f;
@@ -240,11 +241,9 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else { rowsum(ly0, rs[0]); rowsum(ly0 + 1, rs[1]); }                          // owner rows of pixel rows ly0-1 and ly0
-#pragma unroll
-            for (int i = 0; i < SH; ++i) {
-                if constexpr (C == 1) rowsum(ly0 + i + 2, rs[(i + 2) % 3]);
+            auto pixel = [&](const int i, const float (&ra)[2][C][3], const float (&rb)[2][C][3], const float (&rc)[2][C][3]) {
                 const int ly = ly0 + i, py = ty0 + ly;
-                if (py >= H || px >= W) continue;
+                if (py >= H || px >= W) return;
                 const float wym = py == 1 ? 2.f : 1.f, wyp = py == H - 2 ? 2.f : 1.f;
                 const int cb = (ly + 2) * VW + lx + 2;          // r in the value region
                 const float d = dl[cb];
@@ -259,9 +258,9 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                         float g;
                         if constexpr (C > 1) g = gwp[i][s][c];
                         else {
-                            const float g0 = wym * rs[i % 3][s][c][0] + rs[(i + 1) % 3][s][c][0] + wyp * rs[(i + 2) % 3][s][c][0];
-                            const float g1 = wym * rs[i % 3][s][c][1] + rs[(i + 1) % 3][s][c][1] + wyp * rs[(i + 2) % 3][s][c][1];
-                            const float g2 = wym * rs[i % 3][s][c][2] + rs[(i + 1) % 3][s][c][2] + wyp * rs[(i + 2) % 3][s][c][2];
+                            const float g0 = wym * ra[s][c][0] + rb[s][c][0] + wyp * rc[s][c][0];
+                            const float g1 = wym * ra[s][c][1] + rb[s][c][1] + wyp * rc[s][c][1];
+                            const float g2 = wym * ra[s][c][2] + rb[s][c][2] + wyp * rc[s][c][2];
                             g = g0 + 2.f * wv[s][c][cb] * g1 + tg[c][cb] * g2;
                             if (rwin == s) { const float df = tg[c][cb] - wv[s][c][cb]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
                         }
@@ -318,6 +317,25 @@ __global__ __launch_bounds__(256, MD2_LOSS_WAVES) void loss_train_kernel(LossArg
                     const float g = gd + gs;
                     atomicAdd(crow + (h0 - ci_lo) * TW + lx, (1.f - fh) * g); atomicAdd(crow + (h1 - ci_lo) * TW + lx, fh * g);
                 } else dd[(long)py * W + px] = gd + gs;
+            };
+            // ROLL (one channel at three waves per SIMD): the thread's SH pixels as a rolled loop with an explicitly rotated ring of owner-row sums -- unrolled, hipcc interleaves
+            // the four pixels' projection / sampling chains and needs ~200 registers for this phase alone (phases 1 - 2: 99); rolled it fits the 168 of three waves per SIMD
+            if constexpr (ROLL) {
+#pragma unroll 1
+                for (int i = 0; i < SH; ++i) {
+                    rowsum(ly0 + i + 2, rs[2]);
+                    pixel(i, rs[0], rs[1], rs[2]);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { rs[0][s][0][k] = rs[1][s][0][k]; rs[1][s][0][k] = rs[2][s][0][k]; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SH; ++i) {
+                    if constexpr (C == 1) rowsum(ly0 + i + 2, rs[(i + 2) % 3]);
+                    pixel(i, rs[i % 3], rs[(i + 1) % 3], rs[(i + 2) % 3]);
+                }
             }
         }
         if constexpr (APT) {
