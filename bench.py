@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the fp32 vector rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0 # MI355X_MICROARCH.md: dense bf16 matrix peak (--precision bf16 prices against this one)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-PROFILE_ROUND = "r05"          # profiles/<round>_*.json: the rocprofv3 PMC summaries of THIS round's kernels (tools/make_profiles.sh + tools/summarize_profiles.sh)
+PROFILE_ROUND = "r06"          # profiles/<round>_*.json: the rocprofv3 PMC summaries of THIS round's kernels (tools/make_profiles.sh + tools/summarize_profiles.sh)
 VALU_PEAK_TLANE = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s (a wave64 VALU instruction takes 2 cycles of its SIMD)
 # HBM bytes per launch come from the rocprofv3 PMC passes of THIS command (profiles/<round>_pmc_hbm_traffic.json, written by tools/profile_summary.py from separate
 # --pmc FETCH_SIZE / WRITE_SIZE runs: KiB units, FETCH_SIZE x2 because gfx950 tallies 64 B per 128-B request, WRITE_SIZE exact).  PMC counters cannot be read

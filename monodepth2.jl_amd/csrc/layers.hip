@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __re
             float v[N], o[N];
             vldn<BS>(z.p, i * N, v);
 #pragma unroll
-            for (int e = 0; e < N; ++e) o[e] = g[e] * ((v[e] - m[e]) * is[e]) + b[e];
+            for (int e = 0; e < N; ++e) o[e] = fmaf(g[e], (v[e] - m[e]) * is[e], b[e]);          // (explicit: with identity statistics this IS the convolution loaders' fmaf(z, scale, shift), whatever -ffp-contract says)
             if (has_res) {
                 float rr[N]; vldn<BS>(res.p, i * N, rr);
                 if (rstats) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __re
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int q = i % Q; const long p = i / Q; const int n = p / HW; const long r = p - (long)n * HW;
         const float4 v = vld4<BS>(z.p, voff(z, n, r) + q * 4), m = ld4(stats + q * 4), is = ld4(stats + z.C + q * 4), g = ld4(gamma + q * 4), b = ld4(beta + q * 4);
-        float4 o = make_float4(g.x * ((v.x - m.x) * is.x) + b.x, g.y * ((v.y - m.y) * is.y) + b.y, g.z * ((v.z - m.z) * is.z) + b.z, g.w * ((v.w - m.w) * is.w) + b.w);
+        float4 o = make_float4(fmaf(g.x, (v.x - m.x) * is.x, b.x), fmaf(g.y, (v.y - m.y) * is.y, b.y), fmaf(g.z, (v.z - m.z) * is.z, b.z), fmaf(g.w, (v.w - m.w) * is.w, b.w));
         if (has_res) {
             float4 rr = vld4<BS>(res.p, voff(res, n, r) + q * 4);
             if (rstats) {

@@ -462,6 +462,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
                 // shared buffer is ahead of the launch with the transform in its register-staged loader (round 5: 55 + 10...35 against 114 us at configs[4])
                 View src = B.z1;
                 // (the pass applies the SAME fused scale / shift as the loaders -- the weight gradient still transforms z1 in its loader and must see the values this convolution saw)
+                if (h->a_fwd && (B.b1.c > 2048 || B.b1.c % 4 != 0)) { fprintf(stderr, "md2: fused block: the identity-statistics table covers 2048 channels in quads (C=%d)\n", B.b1.c); abort(); }
                 if (h->a_fwd) { src = h->scratch_view(h->a_fwd, B.z1.N, B.z1.H, B.z1.W, B.z1.C); launch_bn_apply(B.z1, h->bn_ident + 2048 - B.b1.c, B.b1.stats + 2 * B.b1.c, B.b1.stats + 3 * B.b1.c, nullptr, ACT_RELU, src, s); }
                 ConvArgs a = conv_args(src, h->wfwd(B.c2.w), B.z2, B.c2.k, B.c2.stride, B.c2.pad, 1, PAD_ZERO);
                 if (!h->a_fwd) { a.in_scale = B.b1.stats + 2 * B.b1.c; a.in_shift = B.b1.stats + 3 * B.b1.c; }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 profile set, run on the GPU box from the repo root (tools/make_profiles.sh); raw output under gpurun_out/prof_final/, summaries by tools/profile_summary.py.
+# Round-6 profile set, run on the GPU box from the repo root (tools/make_profiles.sh); raw output under gpurun_out/prof_final/, summaries by tools/profile_summary.py.
 # One rocprofv3 pass per purpose: kernel trace + stats (both stream modes, batch 32 and batch 4), then the two HBM counters in separate --pmc passes (never with other trace
 # domains), then the vector-instruction counter of the fused loss kernel (its binding roofline).
 set -e
@@ -20,7 +20,7 @@ MD2_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r50 
 MD2_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16_storage 5 > $O/cfg5.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16_storage 3 > $O/fetch5.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16_storage 3 > $O/write5.log 2>&1
-# vector-instruction counters of the C = 3 loss kernel at configuration #5 (its roofline entry, round 5), and the L1 -> L2 request counters of the headline step's kernels
+# vector-instruction counters of the C = 3 loss kernel at configuration #5 (its roofline entry, round 6), and the L1 -> L2 request counters of the headline step's kernels
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/valu5 -o t -- python3 $R/tools/prof_config.py 8 18 3 320 1024 bf16_storage 3 > $O/valu5.log 2>&1
 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d $O/l2 -o t -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/l2.log 2>&1 || echo "(L2 request counters not collected)"
 cd $R
