@@ -1037,6 +1037,31 @@ TIGHT_ROUTES = [("timed", (1, -2), None), ("winograd forced", (3, 1), None), ("w
                 ("winograd forced, exact-split products, 64-channel workgroups", (11, 1), (3, 3))]          # (the opt-in conv_wino3w_kernel of round 5: md2_set_winograd(3 + 8, .))
 
 
+# The seeds the tight test used until round 5 re-picked them (round-5 advisor finding: re-picking seeds in the change that introduces a new product form leaves the suite
+# unable to tell a near-tie decision flip from a regression of the new kernels).  They stay as cases of their own, at the bound their flipped decision needs -- measured in
+# round 5 with the exact-split direct convolutions: 1.6e-2 on seed 107 -- instead of the 4e-3 of the kink-free seeds: a kernel regression moves arrays by O(1), a flipped
+# ReLU / arg-min decision by ~1e-2 (profiles/r02_grad_diag.md).
+RETIRED_TIGHT_SEEDS = [(2, 1, 64, 96, 107, False), (5, 3, 64, 64, 105, False)]
+
+
+@pytest.mark.parametrize("case", RETIRED_TIGHT_SEEDS)
+def test_gradient_parity_on_the_retired_tight_seeds(case):
+    N, C, H, W, sd, automask = case
+    md().set_deterministic(True)
+    try:
+        loss, gh, theta, x, al, K, iK = _hip_and_oracle_grads(N, C, H, W, sd, automask=automask)
+    finally:
+        md().set_deterministic(False)
+    net = oracle.OracleNet(C); net.set_params(theta)
+    lo = net.train_loss(x, oracle.make_cfg(N, C, H, W, K, iK, automasking=automask), al, True); go = net.get_grads()
+    assert abs(loss - lo) / lo < 1e-4
+    tab = per_array(gh, go, C)
+    top = max(t[3] for t in tab)
+    worst = max((t[2], t[0]) for t in tab if t[3] > 1e-3 * top)
+    print("retired tight seed %s: worst array %s rel %.3e" % (case, worst[1], worst[0]))
+    assert_grads_match(gh, go, C, cos_min=0.9995, rel_max=2.5e-2, tag="retired tight seed %s" % (case,))
+
+
 _TIGHT_ORACLE = {}
 
 
@@ -1147,43 +1172,74 @@ def _slices(C, depth):
         n = int(np.prod(shape)); yield off, n; off += n
 
 
-def test_bf16_storage_trains_like_fp32():
-    """Convergence evidence for md2_config.precision = 2 (round-5 review: "no evidence that it trains to the same place"): ResNet-18, 416 x 128, batch 4, ADAM(1e-4), nine
-    passes over 16 fixed synthetic batches (144 steps) from ONE initialisation, bit-reproducible mode, three runs: fp32, fp32 from the same initialisation moved by ~8 ulp
-    (relative noise 1e-6), and bf16 tensors.  The loss is compared per PASS (mean over the 16 batches).
-    What can be asked: the fp32 run does not reproduce ITSELF to 5 % pointwise -- the perturbed fp32 run's pass means differ from the unperturbed run's by up to 7 %
-    (tools/convergence_probe.py: ratios 0.929 .. 1.034 over passes 3 - 9; the trajectory on the loss plateau near 0.09 is chaotic, single steps differ by 25 - 34 %).  So
-    the bf16 run is held to what the second fp32 run is: (a) every run brings the loss from 0.213 to below 0.11 and keeps it there; (b) averaged over passes 3 - 9 the
-    bf16 curve is within 5 % of the fp32 curve (measured +1.8 %; the perturbed fp32 run: -1.9 %); (c) no pass of the bf16 run is further from the fp32 run than twice the
-    largest fp32-to-fp32 distance plus 2 % (measured: bf16 10.0 %, fp32-to-fp32 7.1 %)."""
-    B, C, H, W, nb, passes = 4, 1, 128, 416, 16, 9
+def test_bf16_storage_trains_like_fp32(tmp_path):
+    """Convergence evidence for md2_config.precision = 2 (round-5 review: "no evidence that it trains to the same place"): ResNet-18, 416 x 128, batch 4, ADAM(1e-4), 16 fixed
+    synthetic batches, bit-reproducible mode; the loss is compared per PASS over the 16 batches.
+    What the curves look like (tools/convergence_probe.py, 640 steps): 0.213 -> a plateau near 0.09 within two passes, then -- after a run-dependent time -- an escape to a
+    second level near 0.057.  The ESCAPE TIME is chaotic: the fp32 run left the plateau at step ~70, the same fp32 run from an initialisation moved by ~8 ulp had not left
+    it after 640 steps, the bf16-tensor run left at step ~470 -- and then sat at 0.0570 - 0.0581 against the fp32 run's 0.0557 - 0.0583.  So "within 5 % at steps 50 / 100 /
+    150 from one initialisation" is not a property the fp32 step has of ITSELF (fp32 against fp32: up to 60 % while one of them is still on the plateau), and the test asks
+    what is one:
+      phase 1 -- from scratch, the first four passes (descent onto the plateau): the bf16 curve stays within max(5 %, 2 x the fp32-to-fp32 distance) of the fp32 curve, pass by pass
+                 (measured 2.7 / 1.5 / 0.2 / 0.2 % against 0.7 / 5.6 / 3.0 / 0.6 %);
+      phase 2 -- "the same place": the fp32 run is continued until it has escaped (pass mean below 0.075, then two more passes), its state (weights, ADAM moments, BatchNorm
+                 statistics) is saved, and THREE runs continue from that checkpoint for six passes: fp32, fp32 with the weights moved by ~8 ulp, bf16 tensors.  All three must
+                 hold the escaped level, and the bf16 run must stay within 5 % of the fp32 run in every pass (measured: within 1.2 %, the jittered fp32 run within 2.4 %;
+                 pass means 0.0565 - 0.0571 / 0.0569 - 0.0586 / 0.0565 - 0.0571).
+    If the fp32 run has not escaped after 40 passes (it does at pass 5 in this build) phase 2 is skipped, visibly."""
+    B, C, H, W, nb = 4, 1, 128, 416, 16
     K, iK = syn.depth10k_intrinsics(W, H)
     xs = [dev(syn.synthetic_triplets(B, C, H, W, seed=500 + i)) for i in range(nb)]
     theta = syn.init_params(C, seed=42)
     rs = np.random.RandomState(7)
-    theta_p = (theta.astype(np.float64) * (1.0 + 1e-6 * rs.standard_normal(theta.shape))).astype(np.float32)
-    curves = {}
+    jitter = lambda th: (th.astype(np.float64) * (1.0 + 1e-6 * rs.standard_normal(th.shape))).astype(np.float32)
+    m = md()
+    def new_run(prec):
+        params = m.Params(target_size=(W, H), batch_size=B, automasking=False)
+        cache = m.TrainCache(m.SSIM(), m.Backproject(W, H), m.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
+        enc = m.ResidualNetwork(18, in_channels=C)
+        model = m.Model(enc, m.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), m.PoseDecoder(enc.stages[-1]), lr=1e-4, precision=prec)
+        return model, params, cache
+    def passes(run, n, start=0):
+        model, params, cache = run
+        return np.array([float(m.train_step(model, xs[(start + i) % nb], None, cache, params, True)) for i in range(nb * n)]).reshape(n, nb).mean(1)
     md().set_deterministic(True)
     try:
-        for name, prec, th in (("f32", "f32", theta), ("f32_perturbed", "f32", theta_p), ("bf16_storage", "bf16_storage", theta)):
-            m = md()
-            params = m.Params(target_size=(W, H), batch_size=B, automasking=False)
-            cache = m.TrainCache(m.SSIM(), m.Backproject(W, H), m.Project(W, H), K, iK, 2, [1, 3], [0.125, 0.25, 0.5, 1.0])
-            enc = m.ResidualNetwork(18, in_channels=C)
-            model = m.Model(enc, m.DepthDecoder(list(enc.stages), [2, 3, 4, 5]), m.PoseDecoder(enc.stages[-1]), lr=1e-4, precision=prec)
-            model.load_params(th)
-            curves[name] = np.array([float(m.train_step(model, xs[i % nb], None, cache, params, True)) for i in range(nb * passes)]).reshape(passes, nb)
-            model.close()
+        # ---- phase 1
+        runs = {}
+        for name, prec, th in (("f32", "f32", theta), ("f32_jitter", "f32", jitter(theta)), ("bf16", "bf16_storage", theta)):
+            runs[name] = new_run(prec); runs[name][0].load_params(th)
+        p1 = {k: passes(r, 4) for k, r in runs.items()}
+        print("phase 1 pass means: fp32 %s | fp32 jittered %s | bf16 tensors %s" % (np.round(p1["f32"], 5), np.round(p1["f32_jitter"], 5), np.round(p1["bf16"], 5)))
+        for k, c in p1.items():
+            assert np.isfinite(c).all() and c[0] < 0.13 and (c[1:] < 0.105).all(), (k, c)          # 0.213 at step 1 -> the plateau
+        self_dev = np.abs(p1["f32_jitter"] / p1["f32"] - 1.0); bf_dev = np.abs(p1["bf16"] / p1["f32"] - 1.0)
+        assert (bf_dev < np.maximum(0.05, 2.0 * self_dev)).all(), (bf_dev, self_dev)
+        runs["f32_jitter"][0].close(); runs["bf16"][0].close()
+        # ---- phase 2: continue the fp32 run to its escape
+        base = runs["f32"]; done = 4; low = 0; hist = []
+        while done < 40 and low < 3:
+            v = float(passes(base, 1)[0]); hist.append(v); done += 1
+            low = low + 1 if v < 0.075 else 0
+        print("fp32 run, passes 5..%d: %s" % (done, np.round(hist, 5)))
+        if low < 3:
+            pytest.skip("the fp32 run has not left the 0.09 plateau after 40 passes in this build: no escaped state to branch from (phase 1 held)")
+        ck = str(tmp_path / "escaped.npz")
+        md().save_checkpoint(base[0], ck)
+        level = float(np.mean(hist[-2:]))
+        branches = {"f32": base}
+        for name, prec in (("f32_jitter", "f32"), ("bf16", "bf16_storage")):
+            r = new_run(prec); r[0]._ensure(xs[0], r[1], r[2]); md().load_checkpoint(r[0], ck)
+            if name == "f32_jitter": r[0].load_params(jitter(r[0].params()))
+            branches[name] = r
+        p2 = {k: passes(r, 6) for k, r in branches.items()}
+        print("phase 2 (from the escaped fp32 state, level %.5f) pass means: fp32 %s | fp32 jittered %s | bf16 tensors %s" % (level, np.round(p2["f32"], 5), np.round(p2["f32_jitter"], 5), np.round(p2["bf16"], 5)))
+        for k, c in p2.items():
+            assert np.isfinite(c).all() and (c < 1.08 * level).all(), (k, c)                         # nobody falls back to the plateau
+        assert (np.abs(p2["bf16"] / p2["f32"] - 1.0) < 0.05).all(), p2
+        for r in branches.values(): r[0].close()
     finally:
         md().set_deterministic(False)
-    a, a2, b = (curves[k].mean(1) for k in ("f32", "f32_perturbed", "bf16_storage"))
-    print("pass means fp32 %s\n fp32 perturbed %s\n bf16 tensors %s" % (np.round(a, 5), np.round(a2, 5), np.round(b, 5)))
-    for name, c in curves.items():
-        assert np.isfinite(c).all() and c[0, 0] > 0.2 and (c.mean(1)[2:] < 0.11).all(), name            # (a)
-    self_dev = np.abs(a2[2:] / a[2:] - 1.0); bf_dev = np.abs(b[2:] / a[2:] - 1.0)
-    print("passes 3-9: bf16 / fp32 mean ratio %.4f (max deviation %.4f); fp32 perturbed / fp32 mean ratio %.4f (max deviation %.4f)" % ((b[2:] / a[2:]).mean(), bf_dev.max(), (a2[2:] / a[2:]).mean(), self_dev.max()))
-    assert abs((b[2:] / a[2:]).mean() - 1.0) < 0.05                                                     # (b)
-    assert bf_dev.max() < 2.0 * self_dev.max() + 0.02                                                   # (c)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
