@@ -116,6 +116,9 @@ int32_t md2_set_deterministic(int32_t on);
  * implicit GEMM; on = 2 / 3 pin one of the two Winograd kernels wherever it applies (tests, tuning).  on = 4 / 5 are legacy aliases of
  * md2_set_winograd(1, .) + md2_set_conv_products(2 / 3, -1).  on + 8 (8 .. 11): as `on`, with the split kernels' 64-channel / 512-thread
  * workgroups wherever Cout % 64 == 0 (round 5: faster launch by launch, slower inside the step, so not the default -- DESIGN.md section 4; tests keep it exercised).
+ * on + 32 (32 .. 35): as `on`, and handles with md2_config.precision = 2 (bf16 tensors) take a Winograd kernel on their 3x3 / stride-1 layers as well (round 6,
+ * conv_wino3b_kernel: fp32 transforms, V and U rounded to bf16 once).  1.7 - 4 % of a step; the two extra roundings lower the gradient's agreement with the fp32 step, so it
+ * is not the default.  The +8 / +16 / +32 forms are exclusive.
  * on + 16 (16 .. 19): as `on`, with the split Winograd kernel in its persistent, tile-looping form (round 6, conv_wino3p_kernel: the resident set of workgroups walks the launch's
  * items and the head of the next item rides in the last chunks of the current one; bit-identical results, measured equal launch by launch and 1 % behind in the step, so
  * not the default -- DESIGN.md section 4; a test keeps it exercised).  Process-wide; also MD2_NO_WINO=1 / MD2_WINO_MODE / MD2_WINO_MIN_BLOCKS in the environment at load time. */

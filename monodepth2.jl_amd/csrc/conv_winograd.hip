@@ -60,15 +60,17 @@ constexpr int W_STAGE = 16 * WT * 16;        // floats per LDS stage (32 KB)
 // np = 3 (hi + mid + lo: exact): 1.5 x, which is what conv_wino_u_floats reserves.
 __device__ __forceinline__ void wino_store_split(float* __restrict__ U, int ct, int i, int j, int Cin, int ci, int co_lo, const float4& u, int np) {
     typedef __bf16 b4 __attribute__((ext_vector_type(4)));
-    b4 hi, mid, lo;          // np == 2: u = hi + lo (+ 2^-17 |u|); np == 3: u = hi + mid + lo (+ 2^-25 |u|: every bit of the fp32 value)
+    b4 hi, mid, lo;          // np == 2: u = hi + lo (+ 2^-17 |u|); np == 3: u = hi + mid + lo (+ 2^-25 |u|: every bit of the fp32 value); np == 4 (bf16 tensors, round 6): ONE piece, u rounded to bf16
     hi[0] = (__bf16)u.x; hi[1] = (__bf16)u.y; hi[2] = (__bf16)u.z; hi[3] = (__bf16)u.w;
     const float r0 = u.x - (float)hi[0], r1 = u.y - (float)hi[1], r2 = u.z - (float)hi[2], r3 = u.w - (float)hi[3];
     mid[0] = (__bf16)r0; mid[1] = (__bf16)r1; mid[2] = (__bf16)r2; mid[3] = (__bf16)r3;
     lo[0] = (__bf16)(r0 - (float)mid[0]); lo[1] = (__bf16)(r1 - (float)mid[1]); lo[2] = (__bf16)(r2 - (float)mid[2]); lo[3] = (__bf16)(r3 - (float)mid[3]);
     const int c16 = ci >> 4, g = (ci >> 3) & 1, e0 = ci & 4;
-    __bf16* base = reinterpret_cast<__bf16*>(U) + ((((long)(ct * 4 + i) * (Cin >> 4) + c16) * 4 + j) * np) * 512 + (co_lo + 32 * g) * 8 + e0;
-    *reinterpret_cast<b4*>(base) = hi; *reinterpret_cast<b4*>(base + 512) = mid;
-    if (np == 3) *reinterpret_cast<b4*>(base + 1024) = lo;
+    const int npe = np == 4 ? 1 : np;          // pieces stored per position
+    __bf16* base = reinterpret_cast<__bf16*>(U) + ((((long)(ct * 4 + i) * (Cin >> 4) + c16) * 4 + j) * npe) * 512 + (co_lo + 32 * g) * 8 + e0;
+    *reinterpret_cast<b4*>(base) = hi;
+    if (npe >= 2) *reinterpret_cast<b4*>(base + 512) = mid;
+    if (npe == 3) *reinterpret_cast<b4*>(base + 1024) = lo;
 }
 // ---- weights: w [Cout][9][Cin] (cross-correlation taps, tap = kh*3 + kw) -> U fragments [Cout/32][4 (i)][Cin/8][4 (j)][64 lanes][4]:
 //      lane l, element e of fragment (ct, i, c8, j) = (G g G^T)[i][j] of (co = 32 ct + (l & 31), ci = 8 c8 + 4 (l >> 5) + e)
@@ -402,7 +404,8 @@ __device__ __forceinline__ uint4 wino_buffer_load16(__amdgpu_buffer_rsrc_t rs, u
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-template <int NTHR, int COB, int BST>
+// BS: y, res, dact_src, bz, bzB are bf16 tensors (element offsets unchanged; md2_internal.h vld4 / vst4)
+template <int NTHR, int COB, int BST, bool BS = false>
 __device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __restrict__ wsm, const int m0, const int ntile, const int Mt, const int THW, const int TW, const int c0, const int tid) {
     // R[i][b][tile][COB + 4] holds the column-transformed sums; QN lanes own the COB channels of one pixel.  Same contract as conv_igemm_kernel's epilogue.
     constexpr int RLD = COB + 4, QN = COB / 4, RP = NTHR / QN;
@@ -437,24 +440,24 @@ __device__ __forceinline__ void wino_final_epilogue(const ConvArgs& a, float* __
                 if (oa == 0) { v.x = Rv[0][ob].x + Rv[1][ob].x + Rv[2][ob].x; v.y = Rv[0][ob].y + Rv[1][ob].y + Rv[2][ob].y; v.z = Rv[0][ob].z + Rv[1][ob].z + Rv[2][ob].z; v.w = Rv[0][ob].w + Rv[1][ob].w + Rv[2][ob].w; }
                 else { v.x = Rv[1][ob].x - Rv[2][ob].x - Rv[3][ob].x; v.y = Rv[1][ob].y - Rv[2][ob].y - Rv[3][ob].y; v.z = Rv[1][ob].z - Rv[2][ob].z - Rv[3][ob].z; v.w = Rv[1][ob].w - Rv[2][ob].w - Rv[3][ob].w; }
                 const long pix = (long)oy * a.Wo + ox;
-                if (a.res) { const float4 tt = *reinterpret_cast<const float4*>(a.res + (long)n * a.res_bs + pix * a.res_ps + co); v.x += tt.x; v.y += tt.y; v.z += tt.z; v.w += tt.w; }
+                if (a.res) { const float4 tt = vld4<BS>(a.res, (long)n * a.res_bs + pix * a.res_ps + co); v.x += tt.x; v.y += tt.y; v.z += tt.z; v.w += tt.w; }
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                 if (a.act != ACT_NONE) { v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act); }
                 if (a.dact_src) {
-                    float4 d = *reinterpret_cast<const float4*>(a.dact_src + (long)n * a.da_bs + pix * a.da_ps + co);
+                    float4 d = vld4<BS>(a.dact_src, (long)n * a.da_bs + pix * a.da_ps + co);
                     if (a.dact_scale) { d.x = fmaf(d.x, dsc.x, dsh.x); d.y = fmaf(d.y, dsc.y, dsh.y); d.z = fmaf(d.z, dsc.z, dsh.z); d.w = fmaf(d.w, dsc.w, dsh.w); }
                     v.x *= act_deriv(d.x, a.dact); v.y *= act_deriv(d.y, a.dact); v.z *= act_deriv(d.z, a.dact); v.w *= act_deriv(d.w, a.dact);
                 }
-                float* yp = a.y + (long)n * a.y_bs + pix * a.y_ps + co;
-                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame)) { const float4 o = *reinterpret_cast<const float4*>(yp); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                *reinterpret_cast<float4*>(yp) = v;
+                const long yo = (long)n * a.y_bs + pix * a.y_ps + co;
+                if (a.accumulate == 1 || (a.accumulate == 2 && (n % 3) == a.acc_frame)) { const float4 o = vld4<BS>(a.y, yo); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                vst4<BS>(a.y, yo, v);
                 if (want_st) { s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w; s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w; }
                 if constexpr (BST != 0) if (want_b) {
-                    const float4 z = *reinterpret_cast<const float4*>(a.bz + (long)n * a.bz_bs + pix * a.bz_ps + co);
+                    const float4 z = vld4<BS>(a.bz, (long)n * a.bz_bs + pix * a.bz_ps + co);
                     s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                     s2.x += v.x * ((z.x - muA.x) * isA.x); s2.y += v.y * ((z.y - muA.y) * isA.y); s2.z += v.z * ((z.z - muA.z) * isA.z); s2.w += v.w * ((z.w - muA.w) * isA.w);
                     if (a.bstB) {
-                        const float4 zb = *reinterpret_cast<const float4*>(a.bzB + (long)n * a.bzB_bs + pix * a.bzB_ps + co);
+                        const float4 zb = vld4<BS>(a.bzB, (long)n * a.bzB_bs + pix * a.bzB_ps + co);
                         s3.x += v.x * ((zb.x - muB.x) * isB.x); s3.y += v.y * ((zb.y - muB.y) * isB.y); s3.z += v.z * ((zb.z - muB.z) * isB.z); s3.w += v.w * ((zb.w - muB.w) * isB.w);
                     }
                 }
@@ -943,6 +946,185 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
     W3S_STAMP(5);
 }
 #undef W3S_STAMP
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Winograd F(2x2,3x3) on bf16 TENSORS (md2_config.precision = 2; round 6, the review's "missing": those tensors took the 9-tap direct implicit GEMM on every 3x3 / stride-1
+// layer).  conv_wino3s_kernel with one bf16 piece per operand: x, y and the epilogue's tensors are bf16 in HBM; a loader item is four channels = 8 bytes, widened (exactly) to
+// fp32 on its way into the unchanged LDS patch layout; the input transform runs in fp32 and V is rounded to bf16 ONCE; U = G g G^T is written as one bf16 piece by the weight
+// transform from the fp32 master weights (ConvArgs::wino_pieces = 4); one v_mfma_f32_32x32x16_bf16 per position and 16-channel chunk, fp32 accumulation, output transform and
+// epilogue in fp32, one rounding on the store.  Against the direct kernel on bf16 tensors the products differ by V's and U's roundings (the direct kernel multiplies the stored
+// bf16 values exactly): the layer tests bound it against the fp32 oracle on bf16-rounded inputs like every other kernel of that mode.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BST>
+__global__ __launch_bounds__(256, 3) void conv_wino3b_kernel(ConvArgs a, Wino2Geo geo) {
+    constexpr int XF = 0, NP = 1;
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int COB = 32, WT = 32, NLI = 3;          // loader items per thread: (slot, 8-channel plane) = 16 bytes of bf16
+    constexpr int PL = 128 * 3 * 8;                  // floats per 8-channel plane (384 slots), two planes per stage
+    constexpr int PST = 2 * PL;
+    const int tid = threadIdx.x, lane = tid & 63, wi = tid >> 6;
+    const int TW = geo.TW, TH = geo.TH, Mt = geo.Mt, ntp = geo.ntp;
+    const int bid = wino_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_p = bid % ntp, tile_c = bid / ntp;
+    const int m0 = tile_p * WT, c0 = tile_c * COB;
+    const int THW = TH * TW;
+    const int rr_first = m0 / TW, tx0 = m0 - rr_first * TW;
+    const int L0 = min(TW - tx0, WT);
+    const int S0 = 4 * (2 * L0 + 2), Lf = min(TW, WT), S = 4 * (2 * Lf + 2);
+    const int n_rows_total = a.N * TH;
+
+    // U stream of this wave: chunk c16, position j: piece q at ub + ((c16 * 4 + j) * NP + q) * 512 bf16 (64 lanes x 8).  The first chunk's fragments are requested before
+    // anything else (round 5): they depend on the workgroup id alone, and behind the barrier of the loader's geometry table their latency was the head of every workgroup's life
+    const int nchunks = a.Cin >> 4;
+    const __bf16* ub = reinterpret_cast<const __bf16*>(a.wino_u) + ((long)(tile_c * 4 + wi) * nchunks) * 4 * NP * 512 + lane * 8;
+    wbf16x8 u[4][NP];          // one bf16 piece per position
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) u[j][q] = *reinterpret_cast<const wbf16x8*>(ub + (j * NP + q) * 512);
+
+    // ---- loader: item f = tid + 256 li = (slot f >> 1, plane f & 1): the plane's eight bf16 channels = ONE 16-byte load, widened into the plane's two 16-byte LDS pieces.
+    // Geometry once per slot through the table, as conv_wino3s_kernel.
+    unsigned l_off[NLI]; unsigned l_ok = 0;
+    const int pl = tid & 1, sw = ((tid >> 4) & 1) << 2;          // slot (tid >> 1) + 128 li: bit 3 of the slot is bit 4 of tid
+    const int l_dst0 = pl * PL + (tid >> 1) * 8;          // + li * 1024 floats (128 slots); channels 0..3 at + sw, 4..7 at + (sw ^ 4)
+    {
+        unsigned* tab = reinterpret_cast<unsigned*>(wsm) + PST;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int slot = tid + 256 * q;
+            if (slot < 384) {
+                int k, r, WP, txa, Lk;
+                if (slot < S0) { k = 0; r = slot; WP = 2 * L0 + 2; txa = tx0; Lk = L0; }
+                else { const int s2 = slot - S0; k = 1 + fdiv24(s2, S); r = s2 - (k - 1) * S; txa = 0; Lk = max(min(TW, WT - L0 - (k - 1) * TW), 0); WP = 2 * Lk + 2; }
+                const int pa = fdiv24(r, WP), pc = r - pa * WP;
+                const int rr = rr_first + k;
+                const bool act = slot < geo.nslots && pa < 4 && Lk > 0 && pc < 2 * Lk + 2 && rr < n_rows_total;
+                const int rrc = act ? rr : 0;
+                const int n = fdiv24(rrc, TH), ty = rrc - n * TH;
+                int ih = 2 * ty - a.pad + pa, iw = 2 * txa - a.pad + pc;
+                bool ok = act;
+                if (a.padmode == PAD_REFLECT) { ih = refl_idx(max(min(ih, a.H), -1), a.H); iw = refl_idx(max(min(iw, a.W), -1), a.W); }
+                else ok = ok && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                tab[slot] = ok ? ((unsigned)((long)n * a.x_bs) + (unsigned)((ih * a.W + iw) * a.x_ps)) * 2u : 0xFFFFFFFFu;          // (bf16 elements: valid offsets are multiples of 8 below 2^32 - 16)
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            const unsigned v = tab[(tid >> 1) + 128 * li];
+            const bool ok = v != 0xFFFFFFFFu;
+            l_ok |= ok ? (1u << li) : 0u;
+            l_off[li] = ok ? v + (unsigned)(pl * 16) : W_OOB;          // the plane's eight channels: 16 bytes
+        }
+    }
+    const char* xb = reinterpret_cast<const char*>(a.x);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
+    uint4 ra[NLI];          // eight bf16 channels per item
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) ra[li] = wino_buffer_load16(xrs, l_off[li], c * 32);          // (a chunk's 16 channels are 32 bytes of a pixel)
+    };
+    auto lstore = [&](int so) {
+#pragma unroll
+        for (int li = 0; li < NLI; ++li) {
+            uint4 r = ra[li];
+            asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+            // bf16 -> fp32: exact; padding arrives as zeros from the range check
+            *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 1024 + sw) = make_uint4(r.x << 16, r.x & 0xFFFF0000u, r.y << 16, r.y & 0xFFFF0000u);
+            *reinterpret_cast<uint4*>(wsm + so + l_dst0 + li * 1024 + (sw ^ 4)) = make_uint4(r.z << 16, r.z & 0xFFFF0000u, r.w << 16, r.w & 0xFFFF0000u);
+        }
+    };
+
+    // ---- consumer: lane = (tile, k-group g = plane); B^T row i combines patch rows (r1, r2); the lane's 8 channels are the plane's two 16-B pieces
+    const int r1 = (wi == 0) ? 0 : (wi == 2 ? 2 : 1), r2 = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sg = (wi == 1) ? 1.f : -1.f;
+    const int tl = lane & 31, g = lane >> 5;
+    int c_off1[4], c_off2[4];          // piece 0 of the slot; piece 1 is at (offset ^ 4)
+    {
+        const int u = tx0 + tl, k = fdiv24(u, TW);
+        const int lc = (k == 0) ? tl : (u - k * TW);
+        const int base = (k == 0) ? 0 : S0 + (k - 1) * S, WP = (k == 0) ? 2 * L0 + 2 : 2 * min(TW, WT - L0 - (k - 1) * TW) + 2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int sl1 = base + r1 * WP + 2 * lc + b, sl2 = base + r2 * WP + 2 * lc + b;
+            c_off1[b] = g * PL + sl1 * 8 + (((sl1 >> 3) & 1) << 2);
+            c_off2[b] = g * PL + sl2 * 8 + (((sl2 >> 3) & 1) << 2);
+        }
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    gload(0); lstore(0);
+    __syncthreads();
+    // the chunk loop is unrolled by two with the stage offset a compile-time constant (round 5): the 16 LDS read addresses of a chunk are then base registers + an immediate
+    // instead of 16 v_lshl_add per chunk
+    auto chunk = [&](const int c, auto so_tag) {
+        constexpr int so = decltype(so_tag)::value;
+        const int cn = min(c + 1, nchunks - 1);
+        const __bf16* un = ub + (long)cn * (4 * NP * 512);
+        gload(cn);
+        __builtin_amdgcn_sched_barrier(0);
+        // B^T row combination of the lane's 8 channels (two 16-B pieces), kept for the four positions
+        float4 rr[4][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float4 d1 = *reinterpret_cast<const float4*>(wsm + so + (c_off1[b] ^ (p << 2)));
+                const float4 d2 = *reinterpret_cast<const float4*>(wsm + so + (c_off2[b] ^ (p << 2)));
+                rr[b][p] = make_float4(fmaf(sg, d2.x, d1.x), fmaf(sg, d2.y, d1.y), fmaf(sg, d2.z, d1.z), fmaf(sg, d2.w, d1.w));
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // V_(i,j) of the 8 channels, rounded to bf16 once (two values per v_cvt_pk_bf16_f32)
+            unsigned vp[4];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float4 x0 = rr[j == 0 ? 0 : (j == 2 ? 2 : 1)][p], x1 = rr[j == 0 ? 2 : (j == 1 ? 2 : (j == 2 ? 1 : 3))][p];
+                const float sj = (j == 1) ? 1.f : -1.f;
+                const float4 v = make_float4(fmaf(sj, x1.x, x0.x), fmaf(sj, x1.y, x0.y), fmaf(sj, x1.z, x0.z), fmaf(sj, x1.w, x0.w));
+                vp[2 * p] = __builtin_bit_cast(unsigned, cvt_pk_bf16(v.x, v.y)); vp[2 * p + 1] = __builtin_bit_cast(unsigned, cvt_pk_bf16(v.z, v.w));
+            }
+            const wbf16x8 vb = __builtin_bit_cast(wbf16x8, (wu32x4){vp[0], vp[1], vp[2], vp[3]});
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u[j][0], vb, acc[j], 0, 0, 0);
+            // refill in place right behind the position's last use, as in conv_wino3_kernel
+#pragma unroll
+            for (int q = 0; q < NP; ++q) u[j][q] = *reinterpret_cast<const wbf16x8*>(un + (j * NP + q) * 512);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lstore(PST - so);
+        __syncthreads();
+    };
+    {
+        int c = 0;
+        for (; c + 1 < nchunks; c += 2) { chunk(c, std::integral_constant<int, 0>{}); chunk(c + 1, std::integral_constant<int, PST>{}); }
+        if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
+    }
+
+    // ---- output transform: column half in registers, row half through LDS (R[i][b][32 tiles][COB + 4]) -- as conv_wino3_kernel
+    constexpr int RLD = COB + 4;
+    float* Rl = wsm;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        float4 o0, o1;
+        o0.x = acc[0][4 * gq + 0] + acc[1][4 * gq + 0] + acc[2][4 * gq + 0]; o1.x = acc[1][4 * gq + 0] - acc[2][4 * gq + 0] - acc[3][4 * gq + 0];
+        o0.y = acc[0][4 * gq + 1] + acc[1][4 * gq + 1] + acc[2][4 * gq + 1]; o1.y = acc[1][4 * gq + 1] - acc[2][4 * gq + 1] - acc[3][4 * gq + 1];
+        o0.z = acc[0][4 * gq + 2] + acc[1][4 * gq + 2] + acc[2][4 * gq + 2]; o1.z = acc[1][4 * gq + 2] - acc[2][4 * gq + 2] - acc[3][4 * gq + 2];
+        o0.w = acc[0][4 * gq + 3] + acc[1][4 * gq + 3] + acc[2][4 * gq + 3]; o1.w = acc[1][4 * gq + 3] - acc[2][4 * gq + 3] - acc[3][4 * gq + 3];
+        const int col = 8 * gq + 4 * g;
+        *reinterpret_cast<float4*>(Rl + ((wi * 2 + 0) * WT + tl) * RLD + col) = o0;
+        *reinterpret_cast<float4*>(Rl + ((wi * 2 + 1) * WT + tl) * RLD + col) = o1;
+    }
+    __syncthreads();
+    wino_final_epilogue<256, COB, BST, true>(a, wsm, m0, WT, Mt, THW, TW, c0, tid);
+}
+
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent (tile-looping) form of conv_wino3s_kernel (round 6).  Round 5's ablation put a third of a launch of that kernel into per-workgroup fixed cost -- 10.5 k ticks of
@@ -1447,7 +1629,7 @@ static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh) {
     if (nh == 2 && !ok64) nh = 1;
     const int T = 32 * nh;
     g.ntp = (g.Mt + T - 1) / T; g.nslots = nh == 1 ? s32 : s64;
-    g.xbytes = (unsigned)std::min<long>(4 * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), (long)W_OOB - 16);          // (launch_conv_wino checks the span is below 2^32)
+    g.xbytes = (unsigned)std::min<long>((a.bf16 == 2 ? 2 : 4) * ((long)a.N * a.x_bs + (long)a.H * a.W * a.x_ps), (long)W_OOB - 16);          // (launch_conv_wino checks the span is below 2^32)
     // a launch below the threshold keeps the direct kernel and its split-K -- except short reductions (Cin <= 128), where a workgroup's life is mostly fixed cost either way and
     // 0.6 x the threshold already wins (batch 4, encoder layer 2: 156 workgroups, 0.051 -> 0.040 ms in the model)
     return g_wino_on == 3 || b64 >= g_wino_min_blocks || (a.Cin <= 128 && b64 * 5 >= (long)g_wino_min_blocks * 3);
@@ -1504,6 +1686,7 @@ static void launch_wino3w_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s)
 int g_wino_cb2 = MD2_WINO_CB2_DEFAULT;           // fp32-MFMA Winograd launches with Cout % 64 == 0: 32 tiles x 64 channels per workgroup (conv_wino3_kernel<., ., ., 1, 2>); 0: 32 x 32 (tools/conv_bench: CB1)
 int g_wino_wide = 0;          // 1 (md2_set_winograd(on + 8, .)): split launches with Cout % 64 == 0 take the 64-channel workgroup (conv_wino3w_kernel: faster alone, slower in the step -- DESIGN.md section 4); 0: the 32-channel one everywhere
 // persistent form (opt-in): launches with more items than the 512 resident workgroups, an even chunk count (every layer of the networks here) and no input transform
+int g_wino_bf16 = 0;             // md2_set_winograd(on + 32, .) sets it: bf16 tensors (precision 2) take conv_wino3b_kernel on their 3x3 / stride-1 layers.  Measured: 1.7 - 4 % of a step, paid with V's and U's roundings -- the gradient of the 1024x320 step moves from cosine 0.83 to 0.79 against the fp32 oracle -- so opt-in
 int g_wino_persist = 0;          // md2_set_winograd(on + 16, .) sets it: measured equal to the one-item workgroups launch by launch and 1 % behind them in the step, so opt-in
 template <int NP>
 static void launch_wino3p_t(const ConvArgs& a, const Wino2Geo& g, int nitems, hipStream_t s) {
@@ -1525,8 +1708,21 @@ static void launch_wino3s(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
     else if (g_wino_persist && !a.in_scale && nitems > 512 && nitems < (1L << 24) && nchunks >= 4 && (nchunks & 1) == 0) { if (a.wino_pieces == 3) launch_wino3p_t<3>(a, g, (int)nitems, s); else launch_wino3p_t<2>(a, g, (int)nitems, s); }
     else if (a.wino_pieces == 3) launch_wino3s_t<3>(a, g, s); else launch_wino3s_t<2>(a, g, s);
 }
+static void launch_wino3b(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {          // bf16 tensors, U as one bf16 piece (wino_pieces == 4)
+    constexpr size_t lds = (size_t)2 * 2 * 128 * 3 * 8 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3b_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3b_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = g.ntp * (a.Cout / 32);
+    if (a.bst) hipLaunchKernelGGL((conv_wino3b_kernel<1>), dim3(grid), dim3(256), lds, s, a, g);
+    else hipLaunchKernelGGL((conv_wino3b_kernel<0>), dim3(grid), dim3(256), lds, s, a, g);
+}
 static void launch_wino3(const ConvArgs& a, const Wino2Geo& g, int nh, hipStream_t s) {
-    if (a.wino_pieces) launch_wino3s(a, g, s);
+    if (a.bf16 == 2) launch_wino3b(a, g, s);
+    else if (a.wino_pieces) launch_wino3s(a, g, s);
     // (two channel blocks per workgroup where that still leaves >= 2 rounds of the 512 resident workgroups: 0.155 -> 0.142 ms on the 64 -> 64 layers at batch 32, 0.167 -> 0.150 with the
     //  BatchNorm transform in the loader; launches with fewer workgroups lose more to the emptier last round than the shared transform saves -- tools/run_wino_cb_bench.sh)
     else if (nh == 1) { if (g_wino_cb2 && a.Cout % 64 == 0 && (long)g.ntp * (a.Cout / 64) >= 1024) launch_wino3_t<3, 1, 2>(a, g, s); else launch_wino3_t<3, 1>(a, g, s); }
@@ -2083,7 +2279,9 @@ int g_wino_min_blocks = g_wino_min_blocks_default;
 // by workgroup count, wino3_eligible).
 static bool wino3_eligible(const ConvArgs& a, Wino2Geo& g, int& nh);
 bool conv_wino_eligible(const ConvArgs& a) {
-    if (!g_wino_on || !a.wino_u || a.bf16) return false;
+    if (!g_wino_on || !a.wino_u || a.bf16 == 1) return false;
+    if (a.bf16 == 2 && (!g_wino_bf16 || a.wino_pieces != 4 || a.in_scale)) return false;          // bf16 tensors: conv_wino3b_kernel only (U as one bf16 piece, no input transform), and only on request (md2_set_winograd(on + 32, .))
+    if (a.bf16 != 2 && a.wino_pieces == 4) return false;
     if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.dil == 1 && a.ostep == 1 && a.nkh == 3 && a.nkw == 3 && a.oy0 == 0 && a.ox0 == 0 && a.Hl == a.Ho && a.Wl == a.Wo)) return false;
     if (a.Cin % 16 != 0 || a.Cout % 32 != 0 || a.acc_lat) return false;
     if (a.Ho != a.H + 2 * a.pad - 2 || a.Wo != a.W + 2 * a.pad - 2) return false;
@@ -2128,8 +2326,9 @@ void launch_conv_wino(const ConvArgs& a_in, hipStream_t s) {
     if (a.bst && !fuse) { a.bst = nullptr; a.bstB = nullptr; }
     Wino2Geo g2; int nh = 2;
     if (wino3_eligible(a, g2, nh)) launch_wino3(a, g2, nh, s);
+    else if (a.bf16 == 2) { fprintf(stderr, "md2: conv_wino: bf16 tensors have the 32-tile split kernel only\n"); abort(); }          // (conv_wino_eligible never lets such a launch through)
     else if (a.Cout % 64 == 0) launch_wino_t<2>(a, s); else launch_wino_t<1>(a, s);
-    View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps;
+    View yv; yv.p = a.y; yv.N = a.N; yv.H = a.Ho; yv.W = a.Wo; yv.C = a.Cout; yv.bs = a.y_bs; yv.ps = a.y_ps; yv.bf = a.bf16 == 2;
     if (a_in.stats && !a.stats) {
         if (a_in.bias || a_in.act != ACT_NONE) { fprintf(stderr, "md2: conv_wino: BatchNorm statistics need a bias-free, linear output\n"); abort(); }
         launch_colstats(yv, a_in.stats, s);

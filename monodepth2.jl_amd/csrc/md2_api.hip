@@ -433,7 +433,12 @@ static void pose_forward(md2_handle* h, int N) {
 
 // L frames per sample (3 for training, 1 for eval_disparity); tgt = index of the frame the depth decoder sees
 // Winograd operands of the forward convolutions from the current parameters (one launch; ~16/9 of the 3x3 weights are written)
-static void refresh_wino_fwd(md2_handle* h, hipStream_t s) { h->u_pieces_f = g_wino_pieces; if (h->bf16) return;          /* (the bf16 modes never take the Winograd kernels) */ launch_wino_weights_batched(h->P, h->UF, h->udesc_f, h->n_udf, h->ublk_f, h->u_pieces_f, s); }
+// bf16 tensors (precision 2, round 6): U as ONE bf16 piece of G g G^T of the fp32 master weights (layout code 4, conv_wino3b_kernel); precision 1 keeps the direct kernels
+static void refresh_wino_fwd(md2_handle* h, hipStream_t s) {
+    h->u_pieces_f = h->bf16 == 2 ? 4 : g_wino_pieces;
+    if (h->bf16 == 1 || (h->bf16 == 2 && !g_wino_bf16)) return;
+    launch_wino_weights_batched(h->P, h->UF, h->udesc_f, h->n_udf, h->ublk_f, h->u_pieces_f, s);
+}
 static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1, bool with_pose = true, bool with_depth = true, bool wino_on_side = false) {
     hipStream_t s = h->stream;
     if (tgt < 0) tgt = h->tgt;                  // triplets: the configured target frame
@@ -595,8 +600,8 @@ static int backward_prepare(md2_handle* h, hipStream_t s) {
     launch_weight_prepare(h->P, h->WD, h->wdesc_dev, h->n_wdesc, h->n_wblocks, h->G, h->n_int, s);          // transposed / flipped weight copies + the zeroed gradient buffer, one launch
     if (h->bs) launch_cast_bf16(h->WD, h->WDb, h->n_int, s);
     if (!h->acc_zeroed) HIPCHK(hipMemsetAsync(h->acc_bwd, 0, h->acc_bwd_count * sizeof(double), s));
-    h->u_pieces_d = g_wino_pieces; h->wg_pieces = g_wgrad_pieces;
-    if (!h->bf16) launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions
+    h->u_pieces_d = h->bf16 == 2 ? 4 : g_wino_pieces; h->wg_pieces = g_wgrad_pieces;
+    if (h->bf16 == 0 || (h->bf16 == 2 && g_wino_bf16)) launch_wino_weights_batched(h->WD, h->UD, h->udesc_d, h->n_udd, h->ublk_d, h->u_pieces_d, s);          // Winograd operands of the input-gradient convolutions (bf16 tensors: one bf16 piece, from the fp32 transposed copy)
     KCHK(); return 0;
 }
 // The flat gradient buffer is produced back to front; its four all-reduce buckets in the order they complete: [0] depth decoder + heads + pose decoder, [1] encoder layer 4,
@@ -1207,7 +1212,7 @@ static int conv2d_fwd_impl(const float* x, const float* w, const float* b, float
     ConvArgs a = conv_args(xv, wk, yv, k, stride, p_eff, 1, pad_mode); a.bf16 = bs ? 2 : 0;
     a.bias = b ? bi : nullptr; a.act = act; a.stats = acc;          // stats: fused into the epilogue of the 32-wide tiles, a column-statistics pass otherwise
     float* uw = nullptr;                                            // 3x3 / stride 1: the Winograd operand, as a handle keeps it per layer
-    if (k == 3 && stride == 1 && coutP % 32 == 0 && !bs) { uw = tmp_alloc(conv_wino_u_floats(coutP, cinP), s); if (!uw) return 3; launch_wino_weights(wi, uw, coutP, cinP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
+    if (k == 3 && stride == 1 && coutP % 32 == 0) { const int up = bs ? 4 : g_wino_pieces; uw = tmp_alloc(conv_wino_u_floats(coutP, cinP), s); if (!uw) return 3; launch_wino_weights(wi, uw, coutP, cinP, up, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(up, a.Cin); }          // (bf16 tensors: one bf16 piece, as a precision-2 handle prepares it)
     // a split-K workspace like a handle's, so that the op-level tests drive the same reduce pass (bias / activation / statistics) the training step uses on small maps
     const long ws_cap = std::min<long>(8L << 20, 8L * a.M * a.Cout);
     float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
@@ -1260,7 +1265,7 @@ int32_t md2_conv2d_bwd(const float* x, const float* w, const float* dy, float* d
         float* ws = tmp_alloc((size_t)ws_cap, s); if (!ws) return 3;
         a.ws = ws; a.ws_cap = ws_cap;
         float* uw = nullptr;
-        if (k == 3 && stride == 1 && cinP % 32 == 0 && !bs) { uw = tmp_alloc(conv_wino_u_floats(cinP, coutP), s); if (!uw) return 3; launch_wino_weights(wd, uw, cinP, coutP, g_wino_pieces, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(g_wino_pieces, a.Cin); }
+        if (k == 3 && stride == 1 && cinP % 32 == 0) { const int up = bs ? 4 : g_wino_pieces; uw = tmp_alloc(conv_wino_u_floats(cinP, coutP), s); if (!uw) return 3; launch_wino_weights(wd, uw, cinP, coutP, up, s); a.wino_u = uw; a.wino_pieces = wino_resolve_pieces(up, a.Cin); }
         a.split3 = bs ? 0 : igemm_resolve_split(g_wino_pieces, a.dil > 1 ? std::max(1, k * k / (a.dil * a.dil)) : a.nkh * a.nkw, a.Cin, a.Cout);
         launch_conv_igemm(a, s);
         (void)hipFreeAsync(ws, s); if (uw) (void)hipFreeAsync(uw, s); if (wk != wd) (void)hipFreeAsync(const_cast<float*>(wk), s);
@@ -1362,6 +1367,7 @@ int32_t md2_bn_state_set(md2_handle* h, const float* host, int64_t n) {
 }
 int32_t md2_set_deterministic(int32_t on) { g_deterministic = on != 0; return 0; }
 int32_t md2_set_winograd(int32_t on, int32_t min_blocks) {
+    g_wino_bf16 = (on >= 32 && on <= 35) ? 1 : 0; if (on >= 32 && on <= 35) on -= 32;          // + 32: Winograd for bf16 tensors (conv_wino3b_kernel; measured, reduced gradient fidelity, not the default)
     g_wino_persist = (on >= 16 && on <= 19) ? 1 : 0; if (on >= 16 && on <= 19) on -= 16;          // + 16: the split Winograd kernel in its persistent, tile-looping form (conv_wino3p_kernel; measured, not the default)
     g_wino_wide = (on >= 8 && on <= 11) ? 1 : 0; if (on >= 8 && on <= 11) on -= 8;          // + 8: the split kernel's 64-channel / 512-thread workgroups where Cout % 64 == 0 (conv_wino3w_kernel; measured, not the default)
     if (on == 4 || on == 5) { g_wino_on = 1; g_wino_pieces = on == 4 ? 2 : 3; }          // legacy aliases of md2_set_winograd(1, .) + md2_set_conv_products(2 / 3, -1)

@@ -28,6 +28,7 @@ extern int g_wino_on, g_wino_min_blocks, g_wino_min_blocks_default;
 extern int g_wino_pieces, g_wgrad_pieces;
 extern int g_wino_cb2;           // conv_winograd.hip: 1 = the fp32-MFMA Winograd kernel takes two 32-channel output blocks per workgroup where Cout % 64 == 0
 extern int g_wino_wide;          // conv_winograd.hip: 0 (default); 1 = split launches with Cout % 64 == 0 take the 64-channel workgroup (conv_wino3w_kernel): md2_set_winograd(on + 8, .) sets it, any other md2_set_winograd call clears it
+extern int g_wino_bf16;          // conv_winograd.hip: 0 (default); 1 = bf16 tensors take the Winograd kernel conv_wino3b_kernel: md2_set_winograd(on + 32, .) sets it, any other md2_set_winograd call clears it
 extern int g_wino_persist;       // conv_winograd.hip: 0 (default); 1 = split launches with more items than resident workgroups take the persistent kernel (conv_wino3p_kernel): md2_set_winograd(on + 16, .) sets it, any other md2_set_winograd call clears it
 // load-time defaults of the two (MD2_WINO_PIECES / MD2_WGRAD_PIECES override): every product of the default step carries full fp32 operand accuracy
 #define MD2_DEFAULT_WINO_PIECES 1

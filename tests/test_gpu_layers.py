@@ -139,13 +139,13 @@ def test_conv_fwd_dgrad_wgrad_on_bf16_tensors(case):
         t = torch.zeros(N, Cin, H, W, dtype=torch.float64, requires_grad=True)
         torch.nn.functional.pad(t, (1, 1, 1, 1), mode="reflect").backward(torch.tensor(dxo, dtype=torch.float64))
         dxo = t.grad.numpy()
-    md().set_op_storage(True)
+    md().set_op_storage(True); md().set_winograd(False)          # the DIRECT kernels (exact products of the stored bf16 values); the Winograd form of these tensors has a test of its own
     try:
         y = host(md().conv2d(dev(x), dev(w), dev(b), s, p, mode))
         dx, dw, db = md().conv2d_pullback(dev(x), dev(w), dev(dy), s, p, mode)
         dx, dw, db = host(dx), host(dw), host(db)
     finally:
-        md().set_op_storage(False)
+        md().set_op_storage(False); md().set_winograd(True, -2)
     assert y.shape == yo.shape and rel(y, yo) < 4e-3
     assert rel(dx, dxo) < 8e-3 and rel(dw, dwo) < 1e-4 and rel(db, dbo) < 1e-4          # (5.6e-3 measured on the 12 x 20 reflect-padded map: border pixels sum two or four rounded values)
 
@@ -276,12 +276,12 @@ def test_conv_bn_statistics_epilogue_on_bf16_tensors(case):
     x = bf16_round(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
     w = bf16_round((rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
     yo = oracle.conv2d_fwd(x, w, None, s, p)
-    md().set_op_storage(True)
+    md().set_op_storage(True); md().set_winograd(False)
     try:
         y, mean, invstd = md().conv2d_bnstats(dev(x), dev(w), s, p)
         y, mean, invstd = host(y), host(mean), host(invstd)
     finally:
-        md().set_op_storage(False)
+        md().set_op_storage(False); md().set_winograd(True, -2)
     assert rel(y, yo) < 4e-3
     m64 = yo.astype(np.float64).mean((0, 2, 3)); v64 = yo.astype(np.float64).var((0, 2, 3))
     assert np.abs(mean - m64).max() < 1e-5 * max(1.0, np.abs(yo).max()) and rel(invstd, 1.0 / np.sqrt(v64 + 1e-5)) < 1e-4
@@ -345,6 +345,46 @@ def test_winograd_conv_fwd_and_input_gradient_vs_oracle(case, forced_winograd):
         dxo = _reflect_adjoint(dxo, N, Cin, H, W)
     dx, dw, db = md().conv2d_pullback(dev(x), dev(w), dev(dy), 1, p, mode)          # the input gradient is the same kernel with the channel roles swapped (Cin % 32 == 0 cases)
     assert rel(host(dx), dxo) < 1e-4 and rel(host(dw), dwo) < 1e-4 and rel(host(db), dbo) < 1e-4
+
+
+@pytest.mark.parametrize("case", WINO_CASES + [(40, 64, 32, 52, 64, 1, "zeros", "none"), (6, 128, 32, 104, 128, 1, "zeros", "none")])
+def test_winograd_on_bf16_tensors_vs_oracle(case):
+    """conv_wino3b_kernel (round 6): Winograd F(2x2,3x3) on bf16 tensors -- bf16 patches widened exactly, fp32 input transform, V rounded to bf16 ONCE, U = G g G^T as one
+    bf16 piece from the fp32 weights, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 output transform, one rounding on the store -- forward and input gradient against
+    the oracle on the bf16-rounded operands, beside the direct kernel on the same tensors.  The direct kernel multiplies the stored bf16 values exactly (4e-3: the output's own
+    rounding, measured 2.0e-3 .. 2.8e-3); the Winograd form adds the roundings of V and U (2^-9 relative each, in the transform domain): measured 3.1e-3 .. 5.2e-3 forward,
+    2.2e-3 .. 5.4e-3 input gradient; bounds 7e-3 / 8e-3 of the largest output.
+    The BatchNorm statistics of its epilogue come from the fp32 accumulators and are checked on the two large cases."""
+    N, Cin, H, W, Cout, p, mode, act = case
+    x = bf16_round(rng.standard_normal((N, Cin, H, W)).astype(np.float32))
+    w = bf16_round((rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32))
+    b = rng.standard_normal(Cout).astype(np.float32)
+    xin = oracle.pad_reflect(x) if mode == "reflect" else x
+    zo = oracle.conv2d_fwd(xin, w, b, 1, 0 if mode == "reflect" else p)
+    ref = {"none": zo, "relu": np.maximum(zo, 0), "elu": np.where(zo > 0, zo, np.expm1(zo)), "sigmoid": 1 / (1 + np.exp(-zo))}[act]
+    dy = bf16_round(rng.standard_normal(zo.shape).astype(np.float32))
+    dxo = oracle.conv2d_bwd(xin, w, dy, 1, 0 if mode == "reflect" else p)[0]
+    if mode == "reflect":
+        dxo = _reflect_adjoint(dxo, N, Cin, H, W)
+    md().set_op_storage(True)
+    try:
+        md().set_winograd(35, 1)          # 3 + 32: the Winograd kernel pinned, bf16 tensors included (opt-in: md2_set_winograd(on + 32, .))
+        y = host(md().conv2d(dev(x), dev(w), dev(b), 1, p, mode, act)); dx = host(md().conv2d_pullback(dev(x), dev(w), dev(dy), 1, p, mode)[0])
+        st = md().conv2d_bnstats(dev(x), dev(w), 1, p) if (mode == "zeros" and N >= 6) else None
+        md().set_winograd(False)
+        y_direct = host(md().conv2d(dev(x), dev(w), dev(b), 1, p, mode, act)); dx_direct = host(md().conv2d_pullback(dev(x), dev(w), dev(dy), 1, p, mode)[0])
+    finally:
+        md().set_op_storage(False); md().set_winograd(True, -2)
+    declines = (W + 2 * (p if mode != "reflect" else 1) - 2 + 1) // 2 < 2          # one tile per row: the 32-tile kernel does not stage such maps
+    print("bf16 winograd %s: y rel %.2e (direct %.2e) dx rel %.2e (direct %.2e)%s" % (case, rel(y, ref), rel(y_direct, ref), rel(dx, dxo), rel(dx_direct, dxo), "  [declined]" if declines else ""))
+    assert rel(y_direct, ref) < 4e-3 and rel(dx_direct, dxo) < 8e-3
+    assert rel(y, ref) < 7e-3 and rel(dx, dxo) < 8e-3
+    assert declines or not np.array_equal(y, y_direct)                                # the two algorithms really are different code paths
+    if st is not None:
+        yo = oracle.conv2d_fwd(x, w, None, 1, p)
+        m64 = yo.astype(np.float64).mean((0, 2, 3)); v64 = yo.astype(np.float64).var((0, 2, 3))
+        assert rel(host(st[0]), yo) < 7e-3
+        assert np.abs(host(st[1]) - m64).max() < 2e-4 * max(1.0, np.abs(yo).max()) and rel(host(st[2]), 1.0 / np.sqrt(v64 + 1e-5)) < 2e-3
 
 
 PERSISTENT_CASES = [
