@@ -20,7 +20,7 @@ struct LossTrainOut { double* part; float* dd[MD2_MAX_SCALES]; float* dlo[MD2_MA
 #define MD2_LOSS_HOISTED_PROJECTION 0      // 1: sampling coordinates from the hoisted (K R) P + K t (12 scalars per source, ~4 % faster) -- moves them by ~1e-5 px against
 #endif                                     // the reference's K (R P + t), which on real texture flips a few more arg-min decisions than the oracle comparison likes
 #ifndef MD2_LOSS_WAVES
-#define MD2_LOSS_WAVES 3                   // waves per SIMD of the one-channel kernel (round 6): 3 = phase 3 as a rolled loop (ROLL) and the pose sums reduced per tile (APT), 143 registers, three
+#define MD2_LOSS_WAVES 3                   // waves per SIMD of the one-channel kernel (round 6): 3 = phase 3 as a rolled loop (ROLL), 149 registers, three
 #endif                                     // workgroups per CU -- the loss half 0.397 -> 0.346 ms at the headline shape (2: the round-5 form, 213 registers).  Three channels stay at 2 (55 KB of LDS per workgroup)
 template <int C, int TH>
 __global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_kernel(LossArgs a, LossTrainOut o, int tpb, int ntx) {
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_k
 #pragma unroll
     for (int k = 0; k < 24; ++k) acc[k] = 0.f;
     constexpr bool ROLL = C == 1 && MD2_LOSS_WAVES >= 3;
-    constexpr bool APT = C > 1 || MD2_LOSS_WAVES >= 3;   // the 24 pose sums live only inside phase 3 -- per tile they are row-reduced into `red` (three channels: held across phases 1-2 they went to scratch; one channel at three waves per SIMD: 24 of the 168 registers)
+    constexpr bool APT = C > 1;                          // three channels: the 24 pose sums live only inside phase 3 -- per tile they are row-reduced into `red` (held across phases 1-2 they went to scratch).  One channel: with the rolled phase 3 they fit beside everything else (149 registers, three waves per SIMD) and the per-tile reduction (~30 instructions per pixel) is not worth 6 registers: 0.348 -> 0.336 ms
     if constexpr (APT) {
         for (int i = threadIdx.x; i < 16 * 25; i += 256) (&red[0][0])[i] = 0.f;
     }
