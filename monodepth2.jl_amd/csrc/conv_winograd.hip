@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino3s_kernel(ConvArgs a, Wino2Ge
 // ---------------------------------------------------------------------------------------------------------------------
 template <int BST>
 __global__ __launch_bounds__(256, 3) void conv_wino3b_kernel(ConvArgs a, Wino2Geo geo) {
-    constexpr int XF = 0, NP = 1;
+    constexpr int NP = 1;
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     constexpr int COB = 32, WT = 32, NLI = 3;          // loader items per thread: (slot, 8-channel plane) = 16 bytes of bf16
     constexpr int PL = 128 * 3 * 8;                  // floats per 8-channel plane (384 slots), two planes per stage
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino3b_kernel(ConvArgs a, Wino2Ge
 
     // ---- loader: item f = tid + 256 li = (slot f >> 1, plane f & 1): the plane's eight bf16 channels = ONE 16-byte load, widened into the plane's two 16-byte LDS pieces.
     // Geometry once per slot through the table, as conv_wino3s_kernel.
-    unsigned l_off[NLI]; unsigned l_ok = 0;
+    unsigned l_off[NLI];
     const int pl = tid & 1, sw = ((tid >> 4) & 1) << 2;          // slot (tid >> 1) + 128 li: bit 3 of the slot is bit 4 of tid
     const int l_dst0 = pl * PL + (tid >> 1) * 8;          // + li * 1024 floats (128 slots); channels 0..3 at + sw, 4..7 at + (sw ^ 4)
     {
@@ -1013,12 +1013,9 @@ __global__ __launch_bounds__(256, 3) void conv_wino3b_kernel(ConvArgs a, Wino2Ge
 #pragma unroll
         for (int li = 0; li < NLI; ++li) {
             const unsigned v = tab[(tid >> 1) + 128 * li];
-            const bool ok = v != 0xFFFFFFFFu;
-            l_ok |= ok ? (1u << li) : 0u;
-            l_off[li] = ok ? v + (unsigned)(pl * 16) : W_OOB;          // the plane's eight channels: 16 bytes
+            l_off[li] = v != 0xFFFFFFFFu ? v + (unsigned)(pl * 16) : W_OOB;          // the plane's eight channels: 16 bytes
         }
     }
-    const char* xb = reinterpret_cast<const char*>(a.x);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, geo.xbytes, 0x00020000);
     uint4 ra[NLI];          // eight bf16 channels per item
     auto gload = [&](int c) {
