@@ -1061,7 +1061,10 @@ def _hip_and_oracle_grads(N, C, H, W, sd, depth=18, automask=False):
 # automatic / Winograd forced, ordered / default reductions, fp32-MFMA / exact-split / per-launch products in the forward + input-gradient and in the weight-gradient kernels --
 # within 2.2e-3 of the oracle in every array; the round-4 seed of the second case, 107, sits next to a decision that the new product form flips: 1.6e-2)
 TIGHT_CASES = [(1, 1, 64, 96, 101, False), (2, 1, 64, 96, 104, False), (2, 3, 64, 96, 110, True), (3, 1, 96, 160, 108, False), (5, 3, 64, 64, 115, False),
-               (1, 1, 64, 256, 108, False), (2, 3, 64, 256, 106, False)]
+               (1, 1, 64, 256, 108, False), (2, 3, 64, 256, 106, False),
+               # round 6: the HEADLINE resolution (round-5 review: "nothing at 416 x 128 is held tighter than 5e-2").  60 seeds scanned at 416 x 128, one triplet
+               # (tools/seed_scan.py 1 1 128 416 18 0 100 60): one is kink-free on all 20 routes -- seed 119, worst array 2.2e-3; the next best sit at 5.1e-3 .. 8e-3
+               (1, 1, 128, 416, 119, False)]
 # (name, md2_set_winograd arguments, md2_set_conv_products arguments).  "timed": the configuration bench.py's `value` is measured in.  "winograd forced": the shapes a CPU
 # oracle can afford sit below the workgroup-count threshold of the automatic choice, so the Winograd forward / input-gradient / weight-gradient kernels -- 7.8 of the
 # step's 9.9 ms of convolution time at batch 32 -- are pinned on every layer that qualifies, with the products of the timed configuration and with the other full-accuracy choice.
