@@ -15,26 +15,31 @@ struct LossTrainOut { double* part; float* dd[MD2_MAX_SCALES]; float* dlo[MD2_MA
 //  3. per tile pixel r, TH/8 per thread in a column: d loss / d warped_s[r] = box sum of the winning owners' coefficients (row sums shared
 //     down the column; pad_reflect aliases are weights 2 on the affected row / column), then the pullback through grid_sample, Project,
 //     Backproject and disparity_to_depth, plus the smoothness pullback.
-// The 24 pose-gradient partials and the loss sum stay in registers across the block's tiles and are reduced once.
+// The 24 pose-gradient partials and the loss sum stay in registers across the block's tiles and are reduced once (through the value tiles' LDS, when the tiles are done).
 #ifndef MD2_LOSS_HOISTED_PROJECTION
 #define MD2_LOSS_HOISTED_PROJECTION 0      // 1: sampling coordinates from the hoisted (K R) P + K t (12 scalars per source, ~4 % faster) -- moves them by ~1e-5 px against
 #endif                                     // the reference's K (R P + t), which on real texture flips a few more arg-min decisions than the oracle comparison likes
-#ifndef MD2_LOSS_WAVES
-#define MD2_LOSS_WAVES 3                   // waves per SIMD of the one-channel kernel (round 6): 3 = phase 3 as a rolled loop (ROLL), 149 registers, three
-#endif                                     // workgroups per CU -- the loss half 0.397 -> 0.346 ms at the headline shape (2: the round-5 form, 213 registers).  Three channels stay at 2 (55 KB of LDS per workgroup)
+// Occupancy (round 6): <1, 32> runs at FOUR waves per SIMD (121 registers, 38 KB of LDS per workgroup), <3, 16> at THREE (163 registers, 52.7 KB).  Round 5 left both at
+// two (245 registers each; <1, 32> went to three earlier this round, 149 registers, <3, 16> stood at 221).  What the registers had gone to was not the algorithm but the compiler's freedom: (a) hipcc interleaved the unrolled per-pixel
+// chains of phase 3 (projection, sampling, pullback) -- one channel: a rolled loop with an explicitly rotated ring of owner-row sums; (b) it DELAYED arithmetic whose inputs
+// were ready -- the SSIM coefficients of phase 2 and the per-channel box sums of phase 3 stayed alive as their ~3x larger sets of inputs until the consumer; an empty
+// `asm volatile("" : "+v"(x))` on each finished value pins the computation where it is written (three channels: 221 -> 124 registers from the pins alone, no instruction
+// added); (c) it hoisted per-thread tile indices out of the tile loop (an opaque copy of threadIdx.x per tile).  LDS: the column pass of the coarse scales' resize adjoint
+// is a gather now (no second accumulator tile) and the 16 x 25 block-reduction scratch stands in the value tiles' place once they are done: 55,044 -> 52,724 bytes for
+// three channels, which is what three workgroups per CU need -- 54,324 did NOT fit (measured: no change), the allocation granule of the 160 KB LDS is coarser than 512 bytes.
+// Loss half at the headline shape 0.332 -> 0.294 ms, at configuration 5 1.090 -> 0.79 ms (tools/run_loss_variants.sh, profiles/r06_loss_variants.txt).
 template <int C, int TH>
-__global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_kernel(LossArgs a, LossTrainOut o, int tpb, int ntx) {
-    constexpr int OSH = C == 1 ? 3 : 2;          // window owners per thread in phase 2 (three colour channels keep 2 x 3 x OSH coefficient triples alive: two owners fit the registers)
+__global__ __launch_bounds__(256, C == 1 ? 4 : 3) void loss_train_kernel(LossArgs a, LossTrainOut o, int tpb, int ntx) {
+    constexpr int OSH = 3;                       // window owners per thread in phase 2: (TW + 2) x ceil((TH + 2) / 3) owner triples -- 408 for <1, 32>, 204 for <3, 16> (one pass of the 256 threads)
     constexpr int VW = TW + 4, VH = TH + 4, OW = TW + 2, OH = TH + 2, SH = TH / 8, NSR = (OH + OSH - 1) / OSH;
     __shared__ float wv[2][C][VH * VW];          // warped sources at the padded positions of tile + 2
     __shared__ float tg[C][VH * VW];
     __shared__ float dl[VH * VW];
     __shared__ float coef[C][3][OH * OW];        // d photometric_{s*} / d (pool x, pool x^2, pool xy) at q in tile + 1, pre-scaled
     __shared__ signed char amin[OH * OW];        // winning source at q, -1: none (outside / masked)
-    __shared__ float red[16][25];
-    constexpr int CW = TW / 2 + 2, CH = TH / 2 + 2;
+    float (*red)[25] = reinterpret_cast<float (*)[25]>(&wv[0][0][0]);          // the 16 x 25 partials of the block reduction are needed once the tiles are done: in the value tiles' place
+    constexpr int CH = TH / 2 + 2;
     __shared__ float crow[CH * TW];              // coarse scales, resize adjoint of the tile's d loss / d disparity: after the row direction [coarse row][tile column] ...
-    __shared__ float cacc[CH * CW];              // ... and after the column direction [coarse row][coarse column]
     const int zi = blockIdx.z, sc = zi / a.N, n = zi % a.N;
     const int H = a.H, W = a.W;
     const long P = (long)H * W;
@@ -75,15 +80,9 @@ __global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_k
     float acc[24], s_photo = 0.f;
 #pragma unroll
     for (int k = 0; k < 24; ++k) acc[k] = 0.f;
-    constexpr bool ROLL = C == 1 && MD2_LOSS_WAVES >= 3;
-    constexpr bool APT = C > 1;                          // three channels: the 24 pose sums live only inside phase 3 -- per tile they are row-reduced into `red` (held across phases 1-2 they went to scratch).  One channel: with the rolled phase 3 they fit beside everything else (149 registers, three waves per SIMD) and the per-tile reduction (~30 instructions per pixel) is not worth 6 registers: 0.348 -> 0.336 ms
-    if constexpr (APT) {
-        for (int i = threadIdx.x; i < 16 * 25; i += 256) (&red[0][0])[i] = 0.f;
-    }
-
     for (int t = 0; t < tpb; ++t) {
         int tid = threadIdx.x;
-        if (C > 1) asm volatile("" : "+v"(tid));      // three channels: keeps hipcc from hoisting the per-thread tile indices of every phase out of the tile loop (they lived in scratch: 56 spilled registers)
+        asm volatile("" : "+v"(tid));              // keeps hipcc from hoisting the per-thread tile indices of every phase out of the tile loop (they lived in scratch: 56 spilled registers with three channels)
         const int tix = blockIdx.x * tpb + t;
         if (tix >= ntx) break;
         const int tx0 = tix * TW;
@@ -93,7 +92,6 @@ __global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_k
             int i1; float f;
             up_src_r(ty0, dh, rh, ci_lo, i1, f); up_src_r(tx0, dw, rw, cj_lo, i1, f);                 // first coarse row / column this tile touches
             for (int i = tid; i < CH * TW; i += 256) crow[i] = 0.f;
-            for (int i = tid; i < CH * CW; i += 256) cacc[i] = 0.f;
         }
         // ---- phase 1: values at padded positions u in tile + 2 (u clamped into the padded domain [-1, size])
         for (int i = tid; i < VH * VW; i += 256) {
@@ -152,6 +150,7 @@ __global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_k
                         ssim_from_sums(Rx[s][oo] + Rx[s][oo + 1] + Rx[s][oo + 2], sy, Rxx[s][oo] + Rxx[s][oo + 1] + Rxx[s][oo + 2], syy, Rxy[s][oo] + Rxy[s][oo + 1] + Rxy[s][oo + 2], true, so);
                         pl[oo][s] += alpha * invC * so.val + beta * invC * fabsf(yc[oo + 1] - xc[s][oo + 1]);
                         gmx[oo][s][c] = so.g_mx; gpxx[oo][s][c] = so.g_pxx; gpxy[oo][s][c] = so.g_pxy;
+                        asm volatile("" : "+v"(gmx[oo][s][c]), "+v"(gpxx[oo][s][c]), "+v"(gpxy[oo][s][c]), "+v"(pl[oo][s]));      // finished values: computed HERE (see the header)
                     }
                 }
             }
@@ -202,46 +201,8 @@ __global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_k
                         for (int k = 0; k < 3; ++k) { const float cv = coef[c][k][qi]; r[0][c][k] += m0 * cv; r[1][c][k] += m1 * cv; }
                 }
             };
-            float gwp[C > 1 ? SH : 1][2][C];                                              // three channels: d loss / d warped_s[r][c] of the thread's SH pixels, one channel at a time
-            if constexpr (C > 1) {                                                        // (the ring of all channels' row sums is 54 registers; per channel it is (SH + 2) x 6)
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    if (c) __builtin_amdgcn_sched_barrier(0);
-                    float r1[SH + 2][2][3];
-#pragma unroll
-                    for (int r = 0; r < SH + 2; ++r) {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { r1[r][0][k] = 0.f; r1[r][1][k] = 0.f; }
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int qi = (ly0 + r) * OW + lx + 1 + dx;
-                            const int am = amin[qi];
-                            const float w = dx < 0 ? wxm : (dx > 0 ? wxp : 1.f);
-                            const float m0 = am == 0 ? w : 0.f, m1 = am == 1 ? w : 0.f;
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) { const float cv = coef[c][k][qi]; r1[r][0][k] += m0 * cv; r1[r][1][k] += m1 * cv; }
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < SH; ++i) {
-                        const int py = ty0 + ly0 + i, cb = (ly0 + i + 2) * VW + lx + 2;
-                        const float wym = py == 1 ? 2.f : 1.f, wyp = py == H - 2 ? 2.f : 1.f;
-                        const int rwin = amin[(ly0 + i + 1) * OW + lx + 1];
-                        const float xv[2] = {wv[0][c][cb], wv[1][c][cb]}, tv = tg[c][cb];
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const float g0 = wym * r1[i][s][0] + r1[i + 1][s][0] + wyp * r1[i + 2][s][0];
-                            const float g1 = wym * r1[i][s][1] + r1[i + 1][s][1] + wyp * r1[i + 2][s][1];
-                            const float g2 = wym * r1[i][s][2] + r1[i + 1][s][2] + wyp * r1[i + 2][s][2];
-                            float g = g0 + 2.f * xv[s] * g1 + tv * g2;
-                            if (rwin == s) { const float df = tv - xv[s]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
-                            gwp[i][s][c] = g;
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else { rowsum(ly0, rs[0]); rowsum(ly0 + 1, rs[1]); }                          // owner rows of pixel rows ly0-1 and ly0
-            auto pixel = [&](const int i, const float (&ra)[2][C][3], const float (&rb)[2][C][3], const float (&rc)[2][C][3]) {
+            if constexpr (C == 1) { rowsum(ly0, rs[0]); rowsum(ly0 + 1, rs[1]); }            // owner rows of pixel rows ly0-1 and ly0
+            auto pixel = [&](const int i, const float (&ra)[2][C][3], const float (&rb)[2][C][3], const float (&rc)[2][C][3], const float (&gwc)[2][C]) {
                 const int ly = ly0 + i, py = ty0 + ly;
                 if (py >= H || px >= W) return;
                 const float wym = py == 1 ? 2.f : 1.f, wyp = py == H - 2 ? 2.f : 1.f;
@@ -256,7 +217,7 @@ __global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_k
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         float g;
-                        if constexpr (C > 1) g = gwp[i][s][c];
+                        if constexpr (C > 1) g = gwc[s][c];
                         else {
                             const float g0 = wym * ra[s][c][0] + rb[s][c][0] + wyp * rc[s][c][0];
                             const float g1 = wym * ra[s][c][1] + rb[s][c][1] + wyp * rc[s][c][1];
@@ -318,58 +279,94 @@ __global__ __launch_bounds__(256, C == 1 ? MD2_LOSS_WAVES : 2) void loss_train_k
                     atomicAdd(crow + (h0 - ci_lo) * TW + lx, (1.f - fh) * g); atomicAdd(crow + (h1 - ci_lo) * TW + lx, fh * g);
                 } else dd[(long)py * W + px] = gd + gs;
             };
-            // ROLL (one channel at three waves per SIMD): the thread's SH pixels as a rolled loop with an explicitly rotated ring of owner-row sums -- unrolled, hipcc interleaves
-            // the four pixels' projection / sampling chains and needs ~200 registers for this phase alone (phases 1 - 2: 99); rolled it fits the 168 of three waves per SIMD
-            if constexpr (ROLL) {
+            if constexpr (C == 1) {
+                // one channel: the thread's SH pixels as a ROLLED loop with an explicitly rotated ring of owner-row sums -- unrolled, hipcc interleaves the four pixels'
+                // projection / sampling chains and needs ~200 registers for this phase alone
+                float nogw[2][C] = {};
 #pragma unroll 1
                 for (int i = 0; i < SH; ++i) {
                     rowsum(ly0 + i + 2, rs[2]);
-                    pixel(i, rs[0], rs[1], rs[2]);
+                    pixel(i, rs[0], rs[1], rs[2], nogw);
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
                         for (int k = 0; k < 3; ++k) { rs[0][s][0][k] = rs[1][s][0][k]; rs[1][s][0][k] = rs[2][s][0][k]; }
                 }
             } else {
+                // three channels: d loss / d warped_s[r][c] of the thread's SH = 2 pixels from the same four owner rows, one channel at a time (a ring of all channels' row
+                // sums would be 54 registers), each finished value pinned; then the pixels one after the other
+                float gwp[SH][2][C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (c) __builtin_amdgcn_sched_barrier(0);
+                    float r1[SH + 2][2][3];
+#pragma unroll
+                    for (int r = 0; r < SH + 2; ++r) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { r1[r][0][k] = 0.f; r1[r][1][k] = 0.f; }
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int qi = (ly0 + r) * OW + lx + 1 + dx;
+                            const int am = amin[qi];
+                            const float w = dx < 0 ? wxm : (dx > 0 ? wxp : 1.f);
+                            const float m0 = am == 0 ? w : 0.f, m1 = am == 1 ? w : 0.f;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) { const float cv = coef[c][k][qi]; r1[r][0][k] += m0 * cv; r1[r][1][k] += m1 * cv; }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < SH; ++i) {
+                        const int py = ty0 + ly0 + i, cb = (ly0 + i + 2) * VW + lx + 2;
+                        const float wym = py == 1 ? 2.f : 1.f, wyp = py == H - 2 ? 2.f : 1.f;
+                        const int rwin = amin[(ly0 + i + 1) * OW + lx + 1];
+                        const float xv[2] = {wv[0][c][cb], wv[1][c][cb]}, tv = tg[c][cb];
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const float g0 = wym * r1[i][s][0] + r1[i + 1][s][0] + wyp * r1[i + 2][s][0];
+                            const float g1 = wym * r1[i][s][1] + r1[i + 1][s][1] + wyp * r1[i + 2][s][1];
+                            const float g2 = wym * r1[i][s][2] + r1[i + 1][s][2] + wyp * r1[i + 2][s][2];
+                            float g = g0 + 2.f * xv[s] * g1 + tv * g2;
+                            if (rwin == s) { const float df = tv - xv[s]; g += -(df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * beta * invC * wpix; }
+                            gwp[i][s][c] = g;
+                            asm volatile("" : "+v"(gwp[i][s][c]));          // finished value: computed HERE (see the header)
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < SH; ++i) {
-                    if constexpr (C == 1) rowsum(ly0 + i + 2, rs[(i + 2) % 3]);
-                    pixel(i, rs[i % 3], rs[(i + 1) % 3], rs[(i + 2) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pixel(i, rs[0], rs[1], rs[2], gwp[i]);
                 }
             }
         }
-        if constexpr (APT) {
-            const int row = tid >> 4;
-#pragma unroll
-            for (int k = 0; k < 24; ++k) { const float r = row16_sum(acc[k]); if ((tid & 15) == 0) red[row][k] += r; acc[k] = 0.f; }      // (lane 0 of a row is the only writer of red[row][*])
-        }
-        // ---- coarse scales: column direction on the few coarse rows, then flush (border rows / columns are shared with the neighbouring tiles -> float atomics)
+        // ---- coarse scales: column direction on the few coarse rows as a GATHER (round 6: each coarse (row, column) sums the tile columns that resize onto it, in column
+        // order, and goes straight to global memory -- no second LDS accumulator, no LDS atomics, one barrier less), border rows / columns are shared with the
+        // neighbouring tiles -> float atomics
         if (dlo) {
             __syncthreads();
             int i0, ci_hi, cj_hi; float f;
             up_src_r(min(ty0 + TH, H) - 1, dh, rh, i0, ci_hi, f); up_src_r(min(tx0 + TW, W) - 1, dw, rw, i0, cj_hi, f);
-            const int nrow = ci_hi - ci_lo + 1, ncol = cj_hi - cj_lo + 1;
-            for (int it = tid; it < nrow * TW; it += 256) {
-                const int r = it / TW, p = it - r * TW;
-                if (tx0 + p >= W) continue;
-                int w0, w1; float fw; up_src_r(tx0 + p, dw, rw, w0, w1, fw);
-                const float v = crow[it];
-                atomicAdd(cacc + r * CW + w0 - cj_lo, (1.f - fw) * v); atomicAdd(cacc + r * CW + w1 - cj_lo, fw * v);
-            }
-            __syncthreads();
+            const int nrow = ci_hi - ci_lo + 1, ncol = cj_hi - cj_lo + 1, pw = min(TW, W - tx0);
+            const float irw = rw > 0.f ? 1.f / rw : 0.f;
             for (int it = tid; it < nrow * ncol; it += 256) {
-                const int r = it / ncol, c = it - r * ncol;
-                const float v = cacc[r * CW + c];
-                if (v != 0.f) atomicAdd(dlo + (long)(ci_lo + r) * dw + cj_lo + c, v);
+                const int r = it / ncol, c = it - r * ncol, cj = cj_lo + c;
+                // tile columns p whose source coordinate rw (tx0 + p) lies in [cj - 1, cj + 1): one column of margin either side, the exact test is below
+                const int p_lo = rw > 0.f ? max((int)((float)(cj - 1) * irw) - tx0 - 1, 0) : 0, p_hi = rw > 0.f ? min((int)((float)(cj + 1) * irw) - tx0 + 2, pw) : pw;
+                float v = 0.f;
+                for (int p = p_lo; p < p_hi; ++p) {
+                    int w0, w1; float fw; up_src_r(tx0 + p, dw, rw, w0, w1, fw);
+                    const float x = crow[r * TW + p];
+                    v += (w0 == cj ? (1.f - fw) * x : 0.f) + (w1 == cj ? fw * x : 0.f);
+                }
+                if (v != 0.f) atomicAdd(dlo + (long)(ci_lo + r) * dw + cj, v);
             }
         }
     }
     // ---- block reduction: rows of 16 lanes by DPP, the 16 rows through LDS, one double atomic per value per block
     const int row = threadIdx.x >> 4;
-    if constexpr (!APT) {
+    __syncthreads();                             // the last tile's phase 3 reads the value tiles `red` stands in
 #pragma unroll
-        for (int k = 0; k < 24; ++k) { const float r = row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[row][k] = r; }
-    }
+    for (int k = 0; k < 24; ++k) { const float r = row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[row][k] = r; }
     { const float r = row16_sum(s_photo); if ((threadIdx.x & 15) == 0) red[row][24] = r; }
     __syncthreads();
     if (threadIdx.x < 25) {
@@ -403,7 +400,7 @@ void launch_loss_train(const LossArgs& a, double* part, float* const dd[MD2_MAX_
     LossTrainOut o; o.part = part; o.dRt_acc = dRt_acc; o.blk = blk;
     for (int i = 0; i < MD2_MAX_SCALES; ++i) { o.dd[i] = dd[i]; o.dlo[i] = dlo[i]; }
     static const int tpb_env = md2_tune("MD2_LOSS_TPB", 0);
-    const int ntx = (a.W + TW - 1) / TW, tpb = tpb_env > 0 ? tpb_env : (a.C == 1 ? 2 : 4);          // (tools/run_loss_tpb.sh, round 5: C = 1 0.433 / 0.427 / 0.429 / 0.489 ms for 1 / 2 / 3 / 4 tiles per workgroup at batch 32; C = 3 at 1024x320, batch 8: 1.231 / 1.203 / 1.210 / 1.183)
+    const int ntx = (a.W + TW - 1) / TW, tpb = tpb_env > 0 ? tpb_env : 2;          // (tools/run_loss_tpb.sh, round 6, at four / three waves per SIMD: C = 1 0.292 / 0.294 / 0.303 / 0.327 / 0.340 ms for 1 / 2 / 3 / 4 / 6 tiles per workgroup at batch 32; C = 3 at 1024x320, batch 8: 0.819 / 0.787 / 0.801 / 0.796 / 0.894)
     const int th = a.C == 1 ? 32 : 16;
     dim3 grid((ntx + tpb - 1) / tpb, (a.H + th - 1) / th, a.N * a.nscales);
     if (a.C == 1) hipLaunchKernelGGL((loss_train_kernel<1, 32>), grid, dim3(256), 0, s, a, o, tpb, ntx);
