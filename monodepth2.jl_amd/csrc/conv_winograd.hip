@@ -1649,7 +1649,8 @@ static void launch_wino3_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) 
 }
 template <int NP>
 static void launch_wino3s_t(const ConvArgs& a, const Wino2Geo& g, hipStream_t s) {
-    constexpr size_t lds = (size_t)2 * 2 * 128 * 3 * 8 * sizeof(float);          // two stages of two 8-channel planes (48 KB) > the epilogue's 36 KB
+    // two stages of two 8-channel planes (48 KB) > the epilogue's 36 KB; MD2_WINO_LDS_PAD (tuning builds only): extra bytes, to time the kernel at ONE workgroup per CU (tools/run_wino_occupancy_probe.sh)
+    static const size_t lds = (size_t)2 * 2 * 128 * 3 * 8 * sizeof(float) + (size_t)md2_tune("MD2_WINO_LDS_PAD", 0);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino3s_kernel<0, 0, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
