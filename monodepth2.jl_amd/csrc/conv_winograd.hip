@@ -2223,10 +2223,11 @@ void launch_conv_wino_wgrad(const WgradArgs& a, hipStream_t s) {
     }
     g.nb = g.RB > 1 ? (g.nrows + g.RB - 1) / g.RB : a.N * g.TH * g.BPR;
     g.nco = a.Cout / 64; g.nci = a.Cin / 32;
-    // workgroups a launch is split-K'd up to.  256, not the chip's 512 slots (round 6): these launches run on the weight-gradient stream BESIDE the dependency chain, and at batch 4 a
-    // launch that takes every CU slows the chain it overlaps by more than it gains itself -- 3.19-3.21 -> 3.11-3.14 ms per step, batch 32 and ResNet-50 unchanged
-    // (tools/run_wgrad_blocks_ab.sh, profiles/r06_wgrad_blocks.txt)
-    static const int want = md2_tune("MD2_WINO_WGRAD_BLOCKS", 256);
+    // workgroups a launch is split-K'd up to: the chip's 512 slots when it runs alone, 256 (round 6) on the weight-gradient stream BESIDE the dependency chain -- at batch 4 a
+    // launch that takes every CU slows the chain it overlaps by more than it gains itself: 3.19-3.21 -> 3.11-3.14 ms per step, batch 32 and ResNet-50 unchanged
+    // (tools/run_wgrad_blocks_ab.sh, profiles/r06_wgrad_blocks.txt; alone -- one stream, the op-level call -- 256 costs 5 % of a batch-32 step)
+    static const int want_env = md2_tune("MD2_WINO_WGRAD_BLOCKS", 0);
+    const int want = want_env > 0 ? want_env : (a.overlapped ? 256 : 512);
     int ksn = std::max(1, std::min(g.nb, (want + g.nco * g.nci - 1) / (g.nco * g.nci)));
     g.bpb = (g.nb + ksn - 1) / ksn; ksn = (g.nb + g.bpb - 1) / g.bpb;
     // bit-reproducible mode: ONE workgroup per weight tile walks every batch, so each weight (and bias) element receives exactly one atomic add onto zero

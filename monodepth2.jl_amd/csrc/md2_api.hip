@@ -367,6 +367,7 @@ static void conv_wgrad(md2_handle* h, const ConvL& c, const View& x, const View&
     if (h->prof) snprintf(d, sizeof(d), "wgrad M=%d Cout=%d Cin=%d k=%d s=%d pm=%d alg=%s pieces=%d", a.M, a.Cout, a.Cin, a.KH, a.stride, a.padmode, conv_wino_wgrad_eligible(a) ? "winograd" : "direct",
                           conv_wino_wgrad_eligible(a) ? wgrad_resolve_pieces_wino(h->wg_pieces, a.M, a.Cout, a.Cin) : wgrad_resolve_pieces_tap(h->wg_pieces));
     hipStream_t st = wgrad_stream(h);
+    a.overlapped = st != h->chain();
     h->pbegin(CLS_WGRAD, 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin, d, st, true); launch_conv_wgrad(a, st); h->pend(st, true);
     if (h->prof) {
         const double fl = 2.0 * a.M * a.Cout * a.KH * a.KW * a.Cin;

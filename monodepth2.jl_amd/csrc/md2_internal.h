@@ -196,6 +196,7 @@ struct WgradArgs {
     int N, KH, KW, stride, pad, padmode;
     int M;
     int bf16;                     // same switch for the all-taps weight gradient (conv3x3_wgrad_taps32_kernel)
+    int overlapped;               // 1: the launch runs on the weight-gradient stream beside the pullback's dependency chain -- split-K'd up to 256 workgroups instead of the chip's 512 (round 6)
     int pieces_mode1;             // md2_set_conv_products' weight-gradient mode + 1 as the CALLER snapshot it (a handle: at the start of its pullback, so that a concurrent
                                   // md2_set_conv_products cannot mix product forms inside one step); 0 = not given: the process-wide g_wgrad_pieces at launch time
     float* db;                    // optional bias gradient: db[co] += sum_{n,oh,ow} dy (fused into the all-taps kernels, a colsum launch otherwise)
