@@ -135,25 +135,45 @@ void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View&
 
 // running (optional, [mean[C] | var[C]]): Flux BatchNorm's tracked statistics, mu = (1 - mtm) mu + mtm mean, sigma^2 = (1 - mtm) sigma^2 + mtm * m/(m-1) * var
 // (Flux `_track_stats!`, momentum 0.1, unbiased correction of the batch variance)
+// one channel's batch statistics from its double accumulators: what bn_finalize_kernel writes, shared with the consumers that finalise in their own prologue (BnFin)
+struct BnChan { float mean, invstd; double mean_d, var_d; };
+__device__ __forceinline__ BnChan bn_finalize_channel(const double* __restrict__ acc, int C, int c, double count, int slots) {
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < slots; ++k) { s1 += acc[(size_t)k * 2 * C + c]; s2 += acc[(size_t)k * 2 * C + C + c]; }
+    BnChan r;
+    r.mean_d = s1 / count;
+    r.var_d = s2 / count - r.mean_d * r.mean_d;        // biased variance (Flux BatchNorm train mode)
+    if (r.var_d < 0) r.var_d = 0;
+    r.mean = (float)r.mean_d;
+    r.invstd = (float)(1.0 / sqrt(r.var_d + 1e-5));
+    return r;
+}
+// stats = mean | invstd | scale | shift (y = z * scale + shift == gamma * (z - mean) * invstd + beta: what a consumer's loader applies on the fly); running: Flux `_track_stats!`
+__device__ __forceinline__ void bn_store_channel(const BnChan& r, float* __restrict__ stats, int C, int c, double count, float* __restrict__ running, float momentum,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta) {
+    stats[c] = r.mean; stats[C + c] = r.invstd;
+    if (gamma) { const float sc = gamma[c] * r.invstd; stats[2 * C + c] = sc; stats[3 * C + c] = fmaf(-r.mean, sc, beta[c]); }
+    if (running) {
+        const float corr = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
+        running[c] = (1.f - momentum) * running[c] + momentum * (float)r.mean_d;
+        running[C + c] = (1.f - momentum) * running[C + c] + momentum * corr * (float)r.var_d;
+    }
+}
 __global__ void bn_finalize_kernel(const double* __restrict__ acc, float* __restrict__ stats, int C, double count, int slots, float* __restrict__ running, float momentum,
                                    const float* __restrict__ gamma, const float* __restrict__ beta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0, s2 = 0;
-    for (int k = 0; k < slots; ++k) { s1 += acc[(size_t)k * 2 * C + c]; s2 += acc[(size_t)k * 2 * C + C + c]; }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;             // biased variance (Flux BatchNorm train mode)
-    if (var < 0) var = 0;
-    stats[c] = (float)mean;
-    stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
-    if (gamma) {                                       // y = z * scale + shift == gamma * (z - mean) * invstd + beta: what a consumer's loader applies on the fly
-        const float sc = gamma[c] * stats[C + c];
-        stats[2 * C + c] = sc; stats[3 * C + c] = beta[c] - stats[c] * sc;
-    }
-    if (running) {
-        const float corr = count > 1.0 ? (float)(count / (count - 1.0)) : 1.f;
-        running[c] = (1.f - momentum) * running[c] + momentum * (float)mean;
-        running[C + c] = (1.f - momentum) * running[C + c] + momentum * corr * (float)var;
+    bn_store_channel(bn_finalize_channel(acc, C, c, count, slots), stats, C, c, count, running, momentum, gamma, beta);
+}
+// Consumer-side finalisation (round 6): a BatchNorm whose FIRST reader is an elementwise kernel (bn_apply, bn_relu_maxpool) has no bn_finalize launch of its own -- every
+// workgroup of that reader derives mean | invstd of the channels from the accumulators into LDS (slots x 2 L2-resident doubles per channel), workgroup 0 also writes the
+// stats block (and the running statistics) for the later readers: the pullback kernels and the weight-gradient loaders.  Same arithmetic as bn_finalize_kernel.
+constexpr int BN_FIN_MAXC = 1024;
+__device__ __forceinline__ void bn_fin_prologue(const BnFin& f, int C, const float* __restrict__ gamma, const float* __restrict__ beta, bool writer, float* __restrict__ sm /*[2C]*/) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const BnChan r = bn_finalize_channel(f.acc, C, c, f.count, f.slots);
+        sm[c] = r.mean; sm[C + c] = r.invstd;
+        if (writer) bn_store_channel(r, f.stats, C, c, f.count, f.running, f.momentum, gamma, beta);
     }
 }
 void launch_bn_finalize(const double* acc, float* stats, int C, double count, int slots, float* running, float momentum, hipStream_t s, const float* gamma, const float* beta) {
@@ -178,15 +198,26 @@ void launch_bn_stats_from_running(const float* running, float* stats, int C, hip
 // y = act(bn(z) + bn_r(res)) in ONE pass instead of bn_r -> buffer -> add
 template <bool FAST, bool BS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       View res, int has_res, int act, View y, const float* __restrict__ rstats, const float* __restrict__ rgamma, const float* __restrict__ rbeta) {
+                                                       View res, int has_res, int act, View y, const float* __restrict__ rstats, const float* __restrict__ rgamma, const float* __restrict__ rbeta,
+                                                       BnFin fin, BnFin rfin) {
     const int Q = z.C / 4; const long total = z.pixels() * Q; const int HW = z.H * z.W;
     if (FAST) {          // a lane keeps one run of N consecutive channels (16 bytes) for life
         constexpr int N = LaneN<BS>::N;
         const int QN = z.C / N; const long totalN = z.pixels() * QN;
         const int q = (int)((blockIdx.x * (long)blockDim.x + threadIdx.x) & (QN - 1));
         float m[N], is[N], g[N], b[N], rm[N], ris[N], rg[N], rb[N];
-        ldparams<N>(stats + q * N, m); ldparams<N>(stats + z.C + q * N, is); ldparams<N>(gamma + q * N, g); ldparams<N>(beta + q * N, b);
-        if (rstats) { ldparams<N>(rstats + q * N, rm); ldparams<N>(rstats + z.C + q * N, ris); ldparams<N>(rgamma + q * N, rg); ldparams<N>(rbeta + q * N, rb); }
+        __shared__ float sfin[4 * BN_FIN_MAXC];          // mean | invstd of this BatchNorm, then of the residual's (fin / rfin: statistics finalised here, launcher: C <= BN_FIN_MAXC)
+        if (fin.acc || rfin.acc) {
+            if (fin.acc) bn_fin_prologue(fin, z.C, gamma, beta, blockIdx.x == 0, sfin);
+            if (rfin.acc) bn_fin_prologue(rfin, z.C, rgamma, rbeta, blockIdx.x == 0, sfin + 2 * z.C);
+            __syncthreads();
+        }
+        if (fin.acc) { ldparams<N>(sfin + q * N, m); ldparams<N>(sfin + z.C + q * N, is); } else { ldparams<N>(stats + q * N, m); ldparams<N>(stats + z.C + q * N, is); }
+        ldparams<N>(gamma + q * N, g); ldparams<N>(beta + q * N, b);
+        if (rstats) {
+            if (rfin.acc) { ldparams<N>(sfin + 2 * z.C + q * N, rm); ldparams<N>(sfin + 3 * z.C + q * N, ris); } else { ldparams<N>(rstats + q * N, rm); ldparams<N>(rstats + z.C + q * N, ris); }
+            ldparams<N>(rgamma + q * N, rg); ldparams<N>(rbeta + q * N, rb);
+        }
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < totalN; i += (long)gridDim.x * blockDim.x) {
             float v[N], o[N];
             vldn<BS>(z.p, i * N, v);
@@ -224,12 +255,22 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(View z, const float* __re
     }
 }
 void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s,
-                     const float* rstats, const float* rgamma, const float* rbeta) {
+                     const float* rstats, const float* rgamma, const float* rbeta, const BnFin* fin, const BnFin* rfin) {
     const int ln = z.bf ? 8 : 4;                  // channels per lane on the dense path
     const bool fast = z.C % ln == 0 && pow2(z.C / ln) && z.C / ln <= 256 && dense_view_h(z) && dense_view_h(y) && (!residual || dense_view_h(*residual)) && y.bf == z.bf && (!residual || residual->bf == z.bf);
-    const dim3 grid(grid_for(z.pixels() * (z.C / (fast ? ln : 4)), 256, 4096));
-    if (fast) LAUNCH_BSP(z.bf, bn_apply_kernel, true, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
-    else LAUNCH_BSP(z.bf, bn_apply_kernel, false, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta);
+    BnFin f{}, rf{};
+    if (fin && (fin->stats != stats || (rfin && rfin->stats != rstats))) { fprintf(stderr, "md2: bn_apply: the statistics finalised here must be the ones applied\n"); abort(); }
+    if (fin || rfin) {
+        if (fast && z.C <= BN_FIN_MAXC && z.C % 4 == 0) { if (fin) f = *fin; if (rfin) rf = *rfin; }          // finalised in the kernel's prologue
+        else {                                                                                                  // shapes off the dense path keep the separate launches
+            if (fin) launch_bn_finalize(fin->acc, fin->stats, z.C, fin->count, fin->slots, fin->running, fin->momentum, s, gamma, beta);
+            if (rfin) launch_bn_finalize(rfin->acc, rfin->stats, z.C, rfin->count, rfin->slots, rfin->running, rfin->momentum, s, rgamma, rbeta);
+        }
+    }
+    // (finalising blocks re-derive the statistics: fewer, longer-lived blocks, as in bn_bwd_apply)
+    const dim3 grid(grid_for(z.pixels() * (z.C / (fast ? ln : 4)), 256, (f.acc || rf.acc) ? 2048 : 4096));
+    if (fast) LAUNCH_BSP(z.bf, bn_apply_kernel, true, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta, f, rf);
+    else LAUNCH_BSP(z.bf, bn_apply_kernel, false, grid, dim3(256), 0, s, z, stats, gamma, beta, residual ? *residual : z, residual ? 1 : 0, act, y, rstats, rgamma, rbeta, f, rf);
 }
 
 // sums -> per-channel coefficients, once per BatchNorm (it used to be redone by every thread of the apply kernel): coef = m1 | m2 = sum g / count | sum g*xhat / count;
@@ -356,13 +397,16 @@ void launch_maxpool_fwd(const View& x, const View& y, uint8_t* arg, hipStream_t 
 // frames the depth decoder's skip connection needs (n % L == tgt; all frames when L == 1).  Replaces bn_apply (read z, write a) + maxpool_fwd (read a).
 template <bool BS>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(View z, const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              View a, int L, int tgt, View y, uint8_t* __restrict__ arg, int rpb) {
+                                                              View a, int L, int tgt, View y, uint8_t* __restrict__ arg, int rpb, BnFin fin) {
     constexpr int N = LaneN<BS>::N;
     const int Q = z.C / N, idx = blockIdx.y * 256 + threadIdx.x;
+    __shared__ float sfin[2 * 256];          // (fin: the stem BatchNorm's statistics are finalised here, launcher: C <= 256)
+    if (fin.acc) { bn_fin_prologue(fin, z.C, gamma, beta, blockIdx.x == 0 && blockIdx.y == 0, sfin); __syncthreads(); }
     if (idx >= y.W * Q) return;
     const int ow = idx / Q, q = idx - ow * Q;
     float m[N], is[N], g[N], b[N];
-    ldparams<N>(stats + q * N, m); ldparams<N>(stats + z.C + q * N, is); ldparams<N>(gamma + q * N, g); ldparams<N>(beta + q * N, b);
+    if (fin.acc) { ldparams<N>(sfin + q * N, m); ldparams<N>(sfin + z.C + q * N, is); } else { ldparams<N>(stats + q * N, m); ldparams<N>(stats + z.C + q * N, is); }
+    ldparams<N>(gamma + q * N, g); ldparams<N>(beta + q * N, b);
     const int rows = y.N * y.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
     for (int row = blockIdx.x * rpb; row < row_end; ++row) {
         const int n = row / y.H, oh = row - n * y.H;
@@ -396,11 +440,14 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(View z, const floa
         if constexpr (N == 8) *reinterpret_cast<uchar4*>(ap + 4) = make_uchar4(bi[4], bi[5], bi[6], bi[7]);
     }
 }
-void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s) {
+void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s, const BnFin* fin) {
     const int ln = z.bf ? 8 : 4;                  // channels per lane
     if ((z.H & 1) || (z.W & 1) || y.H != z.H / 2 || y.W != z.W / 2 || z.C % ln != 0 || (256 % (z.C / ln)) != 0 || a.bf != z.bf || y.bf != z.bf) { fprintf(stderr, "md2: bn_relu_maxpool: unsupported shape\n"); abort(); }
-    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (z.C / ln));
-    LAUNCH_BS(z.bf, bn_relu_maxpool_kernel, rg.grid, dim3(256), 0, s, z, stats, gamma, beta, a, L, tgt, y, arg, rg.rpb);
+    BnFin f{};
+    if (fin && fin->stats != stats) { fprintf(stderr, "md2: bn_relu_maxpool: the statistics finalised here must be the ones applied\n"); abort(); }
+    if (fin) { if (z.C <= 256) f = *fin; else launch_bn_finalize(fin->acc, fin->stats, z.C, fin->count, fin->slots, fin->running, fin->momentum, s, gamma, beta); }
+    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (z.C / ln), f.acc ? 4096 : 8192);
+    LAUNCH_BS(z.bf, bn_relu_maxpool_kernel, rg.grid, dim3(256), 0, s, z, stats, gamma, beta, a, L, tgt, y, arg, rg.rpb, f);
 }
 
 // gather form: input pixel (ih,iw) is covered by outputs oh in {(ih+1)/2 - (0|1)}...; no atomics, deterministic
@@ -503,15 +550,25 @@ __device__ __forceinline__ void up_src(int o, int in, int out, int& i0, int& i1,
     i1 = min(i0 + 1, in - 1);
     w1 = s - (float)i0;
 }
+// sk (optional): the encoder skip connection that shares y's channel axis behind x's channels -- cat(upsample(x), skip) of src/depth_decoder.jl:60-61 in ONE pass
+// (y is the whole concat buffer then: C = x.C + sk.C; the skip quads of a row are plain copies)
 template <bool BS>
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y, int rpb) {
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y, int rpb, View sk, int has_sk) {
     constexpr int N = LaneN<BS>::N;
-    const int Q = x.C / N, idx = blockIdx.y * 256 + threadIdx.x;
+    const int Qx = x.C / N, Q = has_sk ? Qx + sk.C / N : Qx, idx = blockIdx.y * 256 + threadIdx.x;
     if (idx >= y.W * Q) return;
     const int ow = idx / Q, q = idx - ow * Q;
+    const int rows = y.N * y.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
+    if (q >= Qx) {
+        for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+            const int n = row / y.H, oh = row - n * y.H;
+            float v[N]; vldn<BS>(sk.p, voff(sk, n, (long)oh * y.W + ow) + (q - Qx) * N, v);
+            vstn<BS>(y.p, voff(y, n, (long)oh * y.W + ow) + q * N, v);
+        }
+        return;
+    }
     int w0, w1; float fw; up_src(ow, x.W, y.W, w0, w1, fw);          // the column taps are the thread's for life
     const float gw = 1.f - fw;
-    const int rows = y.N * y.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
     for (int row = blockIdx.x * rpb; row < row_end; ++row) {
         const int n = row / y.H, oh = row - n * y.H;
         int h0, h1; float fh; up_src(oh, x.H, y.H, h0, h1, fh);      // the row taps are block-uniform
@@ -524,10 +581,12 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(View x, View y, int
         vstn<BS>(y.p, voff(y, n, (long)oh * y.W + ow) + q * N, o);
     }
 }
-void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s) {
-    if (x.C % (x.bf ? 8 : 4) != 0 || y.bf != x.bf) { fprintf(stderr, "md2: upsample2x_fwd: unsupported views\n"); abort(); }
-    const RowGrid rg = row_grid((long)y.N * y.H, y.W * (x.C / (x.bf ? 8 : 4)));
-    LAUNCH_BS(x.bf, upsample2x_fwd_kernel, rg.grid, dim3(256), 0, s, x, y, rg.rpb);
+void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s, const View* skip) {
+    const int ln = x.bf ? 8 : 4;
+    if (x.C % ln != 0 || y.bf != x.bf) { fprintf(stderr, "md2: upsample2x_fwd: unsupported views\n"); abort(); }
+    if (skip && (skip->C % ln != 0 || skip->bf != x.bf || y.C != x.C + skip->C || skip->H != y.H || skip->W != y.W || skip->N != y.N)) { fprintf(stderr, "md2: upsample2x_fwd: the skip connection does not fit the concat buffer\n"); abort(); }
+    const RowGrid rg = row_grid((long)y.N * y.H, y.W * ((x.C + (skip ? skip->C : 0)) / ln));
+    LAUNCH_BS(x.bf, upsample2x_fwd_kernel, rg.grid, dim3(256), 0, s, x, y, rg.rpb, skip ? *skip : x, skip ? 1 : 0);
 }
 // exact adjoint in gather form: every candidate output row/col recomputes the forward's (i0,i1,w1)
 // candidates of one axis: outputs o with a source index in (i-1, i+1), i.e. o in [(i-1) r, (i+1) r], r = (out-1)/(in-1); their adjoint weights (i0 == i ? 1 - f : 0) + (i1 == i ? f : 0).
@@ -599,9 +658,9 @@ void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int
 //   dx[h][w] = act'(xact) * sum over fine pixels (oh, ow) of the x2 adjoint weights * fold(sp)[oh][ow],   fold(sp)[oh][ow] = sum of the padded positions that mirror onto it.
 // One gather pass over the padded gradient instead of writing and re-reading the folded full-resolution tensor (109 + 109 + 109 MB for the last branch at batch 32).
 template <bool BS>
-__global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, View xact, int has_xact, int act, int rpb) {
+__device__ __forceinline__ void fold_up2_bwd_body(const View& sp, const View& dx, const View& xact, int has_xact, int act, int rpb, int bx, int by) {
     constexpr int N = LaneN<BS>::N;
-    const int Q = dx.C / N, idx = blockIdx.y * 256 + threadIdx.x;
+    const int Q = dx.C / N, idx = by * 256 + threadIdx.x;
     if (idx >= dx.W * Q) return;
     const int w = idx / Q, q = idx - w * Q;
     const int Hf = sp.H - 2, Wf = sp.W - 2;         // the fine (unpadded) map
@@ -611,8 +670,8 @@ __global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, Vie
     bool colx = false;
 #pragma unroll
     for (int b = 0; b < 4; ++b) colx = colx || (cws[b] != 0.f && (ows[b] == 1 || ows[b] == Wf - 2));
-    const int rows = dx.N * dx.H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
-    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+    const int rows = dx.N * dx.H, row_end = min(rows, (bx + 1) * rpb);
+    for (int row = bx * rpb; row < row_end; ++row) {
         const int n = row / dx.H, h = row - n * dx.H;
         int ohs[4]; float chs[4];
         up_adjoint_taps4(h, dx.H, Hf, ohs, chs);      // block-uniform
@@ -662,6 +721,10 @@ __global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, Vie
         vstn<BS>(dx.p, voff(dx, n, r) + q * N, g);
     }
 }
+template <bool BS>
+__global__ __launch_bounds__(256) void fold_up2_bwd_kernel(View sp, View dx, View xact, int has_xact, int act, int rpb) {
+    fold_up2_bwd_body<BS>(sp, dx, xact, has_xact, act, rpb, (int)blockIdx.x, (int)blockIdx.y);
+}
 void launch_fold_up2_bwd(const View& src_pad, const View& dx, const View* xact, int act, hipStream_t s) {
     const int Hf = src_pad.H - 2, Wf = src_pad.W - 2;
     // (maps of at least 4 x 4: on a 3-wide map both frame columns mirror onto column 1, which the one-extra-position bookkeeping above does not cover)
@@ -672,15 +735,15 @@ void launch_fold_up2_bwd(const View& src_pad, const View& dx, const View* xact, 
 }
 
 template <bool BS>
-__global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, int accumulate, View actsrc, int has_act, int act, int rpb) {
+__device__ __forceinline__ void fold_reflect_body(const View& sp, const View& dst, int accumulate, const View& actsrc, int has_act, int act, int rpb, int bx, int by) {
     constexpr int N = LaneN<BS>::N;
-    const int Q = dst.C / N, H = dst.H, W = dst.W, idx = blockIdx.y * 256 + threadIdx.x;
+    const int Q = dst.C / N, H = dst.H, W = dst.W, idx = by * 256 + threadIdx.x;
     if (idx >= W * Q) return;
     const int w = idx / Q, q = idx - w * Q;
     int uxs[3], nx = 0;                             // padded-domain columns that fold onto column w (pad_reflect mirrors WITHOUT the edge: -1 <-> 1, W <-> W - 2)
     uxs[nx++] = w; if (w == 1) uxs[nx++] = -1; if (w == W - 2) uxs[nx++] = W;
-    const int rows = dst.N * H, row_end = min(rows, (int)(blockIdx.x + 1) * rpb);
-    for (int row = blockIdx.x * rpb; row < row_end; ++row) {
+    const int rows = dst.N * H, row_end = min(rows, (bx + 1) * rpb);
+    for (int row = bx * rpb; row < row_end; ++row) {
         const int n = row / H, h = row - n * H;
         int uys[3], ny = 0;
         uys[ny++] = h; if (h == 1) uys[ny++] = -1; if (h == H - 2) uys[ny++] = H;
@@ -712,6 +775,29 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, in
         }
         vstn<BS>(dst.p, dpo, g);
     }
+}
+template <bool BS>
+__global__ __launch_bounds__(256) void fold_reflect_kernel(View sp, View dst, int accumulate, View actsrc, int has_act, int act, int rpb) {
+    fold_reflect_body<BS>(sp, dst, accumulate, actsrc, has_act, act, rpb, (int)blockIdx.x, (int)blockIdx.y);
+}
+// The two adjoints that split a DecoderBlock's padded concat gradient (src/depth_decoder.jl:60-61 backwards) in ONE launch: workgroups [0, nbx_up) gather the upsampled
+// half's channels into the coarse map (fold_up2_bwd), the rest fold the skip connection's channels onto the encoder feature's gradient (fold_reflect) -- they read
+// disjoint channel slices of the same tensor and write different ones, so nothing orders them; one launch instead of two back-to-back ones.
+template <bool BS>
+__global__ __launch_bounds__(256) void fold_cat_bwd_kernel(View sp_up, View dx, View xact, int has_xact, int act_up, int rpb_up, int nbx_up,
+                                                           View sp_sk, View dst, int accumulate, View actsrc, int has_act, int act_sk, int rpb_sk) {
+    if ((int)blockIdx.x < nbx_up) fold_up2_bwd_body<BS>(sp_up, dx, xact, has_xact, act_up, rpb_up, (int)blockIdx.x, (int)blockIdx.y);
+    else fold_reflect_body<BS>(sp_sk, dst, accumulate, actsrc, has_act, act_sk, rpb_sk, (int)blockIdx.x - nbx_up, (int)blockIdx.y);
+}
+void launch_fold_cat_bwd(const View& pad_up, const View& dx, const View* xact, int act_up, const View& pad_sk, const View& dst, int accumulate, const View* actsrc, int act_sk, hipStream_t s) {
+    const int Hf = pad_up.H - 2, Wf = pad_up.W - 2, ln = dx.bf ? 8 : 4;
+    if (Hf < 4 || Wf < 4 || Hf > 2 * dx.H || Wf > 2 * dx.W || pad_up.C < dx.C) { fprintf(stderr, "md2: fold_cat_bwd: unsupported shape (upsampled half)\n"); abort(); }
+    if (pad_sk.H != dst.H + 2 || pad_sk.W != dst.W + 2 || pad_sk.C < dst.C) { fprintf(stderr, "md2: fold_cat_bwd: shape mismatch (skip half)\n"); abort(); }
+    if (dx.C % ln != 0 || dst.C % ln != 0 || pad_up.bf != dx.bf || pad_sk.bf != dx.bf || dst.bf != dx.bf || (xact && xact->bf != dx.bf) || (actsrc && actsrc->bf != dx.bf)) { fprintf(stderr, "md2: fold_cat_bwd: unsupported views\n"); abort(); }
+    const RowGrid ru = row_grid((long)dx.N * dx.H, dx.W * (dx.C / ln)), rs = row_grid((long)dst.N * dst.H, dst.W * (dst.C / ln));
+    const dim3 grid(ru.grid.x + rs.grid.x, std::max(ru.grid.y, rs.grid.y), 1);          // (a body returns at once for a chunk index beyond its own row length)
+    LAUNCH_BS(dx.bf, fold_cat_bwd_kernel, grid, dim3(256), 0, s, pad_up, dx, xact ? *xact : dx, xact ? 1 : 0, act_up, ru.rpb, (int)ru.grid.x,
+              pad_sk, dst, accumulate, actsrc ? *actsrc : dst, actsrc ? 1 : 0, act_sk, rs.rpb);
 }
 void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, const View* actsrc, int act, hipStream_t s) {
     if (src_pad.H != dst.H + 2 || src_pad.W != dst.W + 2 || src_pad.C < dst.C) { fprintf(stderr, "md2: fold_reflect: shape mismatch\n"); abort(); }

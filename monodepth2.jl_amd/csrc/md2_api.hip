@@ -88,6 +88,11 @@ struct md2_handle {
     hipStream_t s4 = nullptr; int wg_rr = 0; int n_wg_streams = 1; hipEvent_t ev_join4 = nullptr;
     hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr, ev_p0 = nullptr, ev_p1 = nullptr; bool prep_done = false; bool two_streams = true; bool forked = false; View dz0;
     bool acc_zeroed = false;            // md2_train_loss: the forward pass's memset covers the pullback / loss accumulators too
+    // launches md2_train_step takes off the caller's stream (round 6, batch 4 is a chain of ~200 dependent launches): the coarse disparity gradients are zeroed on the
+    // preparation stream at the head of the step (ddisp_zeroed), the pose stream composes Rt right behind the pose decoder (Rt_ready), and the loss's tail -- the
+    // scalar's finalisation and the pose pullback's first kernel, neither read by the depth decoder's pullback -- opens the pose stream's part of model_backward (tail)
+    bool ddisp_zeroed = false, Rt_ready = false, defer_tail = false;
+    struct LossTail { bool pending = false; LossArgs a; float* loss_out = nullptr; const float *rvec = nullptr, *tvec = nullptr; } tail;
     bool net_ok = true;                 // false: the image is too small for the network (H or W < 64): only the loss-half entry points work
     float* RS = nullptr; long n_rs = 0; bool testmode = false;     // BatchNorm running mean / variance (Flux BatchNorm mu, sigma^2; momentum 0.1) and Flux.testmode!
     double* loss_blk = nullptr;         // deterministic mode: per-block partial sums of the loss kernels
@@ -382,9 +387,18 @@ static void bn_stats(md2_handle* h, const BNL& b, const View& z) {
     if (h->testmode) launch_bn_stats_from_running(h->RS + b.rs, b.stats, b.c, h->chain(), h->P + b.g, h->P + b.b);
     else launch_bn_finalize(b.acc, b.stats, b.c, (double)z.pixels(), BN_STAT_SLOTS, h->RS + b.rs, 0.1f, h->chain(), h->P + b.g, h->P + b.b);
 }
+// the same for a BatchNorm whose first reader is an elementwise kernel: that kernel finalises the statistics in its prologue (BnFin, md2_internal.h) -- no launch here.
+// (test mode has nothing to finalise: the caller runs bn_stats as before when this returns false)
+static bool bn_fin(md2_handle* h, const BNL& b, const View& z, BnFin& f) {
+    static const bool off = md2_tune_set("MD2_NO_BN_FIN");
+    if (h->testmode || off) return false;
+    f.acc = b.acc; f.count = (double)z.pixels(); f.slots = BN_STAT_SLOTS; f.stats = b.stats; f.running = h->RS + b.rs; f.momentum = 0.1f;
+    return true;
+}
 static void bn_fwd(md2_handle* h, const BNL& b, const View& z, const View* residual, int act, const View& y) {
-    bn_stats(h, b, z);
-    launch_bn_apply(z, b.stats, h->P + b.g, h->P + b.b, residual, act, y, h->chain());
+    BnFin f; const bool fin = bn_fin(h, b, z, f);
+    if (!fin) bn_stats(h, b, z);
+    launch_bn_apply(z, b.stats, h->P + b.g, h->P + b.b, residual, act, y, h->chain(), nullptr, nullptr, nullptr, fin ? &f : nullptr);
 }
 // dy: gradient wrt the BN output (already masked by any following ReLU) -> dz.  have_sums: the producer of dy already accumulated sum dy / sum dy*xhat into b.acc_b
 static void bn_bwd(md2_handle* h, const BNL& b, const View& dy, const View& z, const View& dz, bool have_sums = false) {
@@ -457,8 +471,9 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
         if (h->prof) { h->prof_flops[CLS_IGEMM] += fl; h->prof_exec[CLS_IGEMM] += fl; }
     }
     // stem tail in one pass: BatchNorm + ReLU + max-pool; a0 is written only where the decoder's skip connection reads it (the target frames)
-    bn_stats(h, h->stem_bn, h->z0);
-    launch_bn_relu_maxpool(h->z0, h->stem_bn.stats, h->P + h->stem_bn.g, h->P + h->stem_bn.b, h->a0, L, tgt, h->p0, h->pool_arg, s);
+    {   BnFin f; const bool fin = bn_fin(h, h->stem_bn, h->z0, f);          // (the statistics are finalised by the pass that applies them)
+        if (!fin) bn_stats(h, h->stem_bn, h->z0);
+        launch_bn_relu_maxpool(h->z0, h->stem_bn.stats, h->P + h->stem_bn.g, h->P + h->stem_bn.b, h->a0, L, tgt, h->p0, h->pool_arg, s, fin ? &f : nullptr); }
     if (wino_on_side) (void)hipStreamWaitEvent(s, h->ev_uf, 0);          // the first Winograd convolution is block 0's conv1
     for (int i = 0; i < h->nblk; ++i) {
         Block& B = h->blk[i];
@@ -476,18 +491,21 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
                 a.wino_u = B.c2.uf >= 0 ? h->UF + B.c2.uf : nullptr; a.wino_pieces = wino_resolve_pieces(h->u_pieces_f, a.Cin);
                 run_igemm(h, a);
             }
-            bn_stats(h, B.b2, B.z2);
             if (B.bottleneck) {           // ... and the 1x1 conv3 gathers relu(bn2(z2)) from z2
+                bn_stats(h, B.b2, B.z2);
                 ConvArgs a = conv_args(B.z2, h->wfwd(B.c3.w), B.z3, B.c3.k, B.c3.stride, B.c3.pad, 1, PAD_ZERO);
                 a.in_scale = B.b2.stats + 2 * B.b2.c; a.in_shift = B.b2.stats + 3 * B.b2.c; a.stats = h->testmode ? nullptr : B.b3.acc;
                 run_igemm(h, a);
-                bn_stats(h, B.b3, B.z3);
             }
+            // the block's last BatchNorm (and the shortcut's) is read first by the elementwise pass below, which finalises the statistics itself
             const BNL& bo = B.bottleneck ? B.b3 : B.b2; const View& zo = B.bottleneck ? B.z3 : B.z2;
+            BnFin fo, fd; const bool fin = bn_fin(h, bo, zo, fo);
+            if (!fin) bn_stats(h, bo, zo);
             if (B.down) {                 // out = relu(bn(z) + bnd(zd)): the shortcut's BatchNorm output is never written
-                conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc); bn_stats(h, B.bd, B.zd);
-                launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.zd, ACT_RELU, B.out, s, B.bd.stats, h->P + B.bd.g, h->P + B.bd.b);
-            } else launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.in, ACT_RELU, B.out, s);
+                conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc);
+                if (!bn_fin(h, B.bd, B.zd, fd)) bn_stats(h, B.bd, B.zd);
+                launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.zd, ACT_RELU, B.out, s, B.bd.stats, h->P + B.bd.g, h->P + B.bd.b, fin ? &fo : nullptr, fin ? &fd : nullptr);
+            } else launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.in, ACT_RELU, B.out, s, nullptr, nullptr, nullptr, fin ? &fo : nullptr);
             continue;
         }
         conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_fwd(h, B.b1, B.z1, nullptr, ACT_RELU, B.a1);
@@ -502,22 +520,36 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
     }
     // ---- pose decoder on its own stream, concurrently with the depth decoder (both only read the encoder features)
     const bool pose_async = with_pose && h->two_streams && h->s3;
+    // (a training step -- wino_on_side marks md2_train_loss -- also composes Rt there, and the pose stream then takes the heads of every branch but the last: each
+    //  waits for its branch only, and none of them stands between two convolutions of the decoder chain)
+    static const bool heads_aside_on = !md2_tune_set("MD2_NO_HEADS_ASIDE");
+    const bool heads_aside = pose_async && with_depth && heads_aside_on;
     if (with_pose) {
         if (pose_async) { (void)hipEventRecord(h->ev_a, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_a, 0); h->cur = h->s3; }
         pose_forward(h, N);
-        if (pose_async) { (void)hipEventRecord(h->ev_b, h->s3); h->cur = nullptr; }
+        if (pose_async && wino_on_side) { launch_pose_compose(h->rvec, h->tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, h->s3); h->Rt_ready = true; }
+        if (pose_async) { if (!heads_aside) (void)hipEventRecord(h->ev_b, h->s3); h->cur = nullptr; }
     }
     // ---- depth decoder on the target-frame features (src/model.jl:16-17, src/depth_decoder.jl:49-65)
     View x5 = frame_view(h->feat[4], L, tgt);
     for (int b = 0; b < (with_depth ? h->nbr : 0); ++b) {
         const View& in = (b == 0) ? x5 : h->y2[b - 1];
         conv_fwd(h, h->dc1[b], in, h->y1[b], PAD_REFLECT, ACT_ELU);
-        launch_upsample2x_fwd(h->y1[b], chan_slice(h->cat[b], 0, h->y1[b].C), s);
-        if (b < 4) { View sk = frame_view(h->feat[3 - b], L, tgt); launch_axpy_view(sk, chan_slice(h->cat[b], h->y1[b].C, sk.C), 1.f, 0, nullptr, ACT_NONE, s); }
+        // cat(upsample(y1), skip) in one pass over the concat buffer
+        if (b < 4) { View sk = frame_view(h->feat[3 - b], L, tgt); launch_upsample2x_fwd(h->y1[b], h->cat[b], s, &sk); }
+        else launch_upsample2x_fwd(h->y1[b], chan_slice(h->cat[b], 0, h->y1[b].C), s);
         conv_fwd(h, h->dc2[b], h->cat[b], h->y2[b], PAD_REFLECT, ACT_ELU);
-        if (const int o = h->out_of[b]; o >= 0) launch_head_fwd(h->y2[b], h->P + h->head[o].w, h->P + h->head[o].b, h->dispv[o], s);
+        if (const int o = h->out_of[b]; o >= 0) {
+            hipStream_t hs = s;
+            if (heads_aside && b < h->nbr - 1) {          // fork: y2[b] is complete on the chain
+                hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
+                (void)hipEventRecord(ev, s); (void)hipStreamWaitEvent(h->s3, ev, 0); hs = h->s3;
+            }
+            launch_head_fwd(h->y2[b], h->P + h->head[o].w, h->P + h->head[o].b, h->dispv[o], hs);
+        }
     }
-    if (pose_async) (void)hipStreamWaitEvent(h->stream, h->ev_b, 0);       // join: the loss needs the poses
+    if (heads_aside) (void)hipEventRecord(h->ev_b, h->s3);
+    if (pose_async) (void)hipStreamWaitEvent(h->stream, h->ev_b, 0);       // join: the loss needs the poses (and the disparities of the heads on the pose stream)
     KCHK();
     return 0;
 }
@@ -538,20 +570,34 @@ static int loss_forward(md2_handle* h, const float* x, const float* const disp[M
     KCHK();
     return 0;
 }
+// the coarse levels' disparity gradients are scatter-accumulated (float atomics) unless the reductions are ordered; those levels come first in the block, a
+// full-resolution last level is written, not accumulated -- the bytes a scattering loss pass needs zeroed
+static bool loss_scatters() { static const bool no_scatter = md2_tune("MD2_LOSS_NOSCATTER", 0) != 0; return !g_deterministic && !no_scatter; }
+static size_t ddisp_lo_zero_bytes(const md2_handle* h) {
+    const bool last_full = (h->H >> (5 - h->lv[h->ns - 1])) == h->H && (h->W >> (5 - h->lv[h->ns - 1])) == h->W;
+    return last_full ? (size_t)((const char*)h->ddisp_lo[h->ns - 1] - (const char*)h->ddisp_lo[0]) : h->ddisp_lo_count * sizeof(float);
+}
+// what follows the fused loss kernel and is not read by the depth decoder's pullback: the scalar loss and the pose pullback's first step
+static int loss_tail(md2_handle* h, const LossArgs& a, float* loss_out, const float* rvec, const float* tvec, hipStream_t s) {
+    launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
+    if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
+    launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
+    return 0;
+}
 // loss value and its pullback in one pass (training): fills the loss, ddisp_lo[4], drvec, dtvec
 static int loss_train(md2_handle* h, const float* x, const float* const disp[MD2_MAX_SCALES], const float* rvec, const float* tvec, const float* auto_loss, float* loss_out, bool simple = false) {
     hipStream_t s = h->stream;
     if (!h->acc_zeroed) HIPCHK(hipMemsetAsync(h->loss_part, 0, (size_t)(4 * MD2_MAX_SCALES + 24) * h->N * sizeof(double), s));           // loss_part [20N] and dRt_acc [24N] are adjacent
     h->acc_zeroed = false;
-    launch_pose_compose(rvec, tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
+    if (!(h->Rt_ready && rvec == h->rvec && tvec == h->tvec)) launch_pose_compose(rvec, tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
+    h->Rt_ready = false;
     LossArgs a = loss_args(h, x, disp, h->Rt, auto_loss);
     if (simple) simple_mode(h, a);
     const size_t P = (size_t)h->H * h->W;
     // gradient wrt the disparity maps: the full-resolution scale is written directly; the coarse scales receive the adjoint of the bilinear resize from inside the
     // kernel (per-tile partial sums, float atomics) -- or, in deterministic mode, full-resolution maps that the ordered adjoint kernel reduces afterwards
     float *dd[MD2_MAX_SCALES] = {}, *dlo[MD2_MAX_SCALES] = {};
-    static const bool no_scatter = md2_tune("MD2_LOSS_NOSCATTER", 0) != 0;
-    const bool scatter = !simple && !g_deterministic && !no_scatter;
+    const bool scatter = !simple && loss_scatters();
     bool any_lo = false;
     for (int i = 0; i < a.nscales; ++i) {
         const bool full = !simple && a.dh[i] == h->H && a.dw[i] == h->W;
@@ -559,14 +605,15 @@ static int loss_train(md2_handle* h, const float* x, const float* const disp[MD2
         dlo[i] = (scatter && !full) ? h->ddisp_lo[i] : nullptr; any_lo |= dlo[i] != nullptr;
     }
     // (the coarse levels come first in the block; a full-resolution last level is written, not accumulated)
-    if (any_lo) HIPCHK(hipMemsetAsync(h->ddisp_lo[0], 0, dlo[h->ns - 1] ? h->ddisp_lo_count * sizeof(float) : (size_t)((char*)h->ddisp_lo[h->ns - 1] - (char*)h->ddisp_lo[0]), s));
+    if (any_lo && !h->ddisp_zeroed) HIPCHK(hipMemsetAsync(h->ddisp_lo[0], 0, ddisp_lo_zero_bytes(h), s));
+    h->ddisp_zeroed = false;
     launch_loss_smooth_sums(a, h->loss_part, g_deterministic ? h->loss_blk : nullptr, s);
     h->pbegin(CLS_LOSS_BWD); launch_loss_train(a, h->loss_part, dd, dlo, h->dRt_acc, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
     if (h->prof) h->prof_bytes[CLS_LOSS_BWD] += 4.0 * h->H * h->W * (2 + 3 * h->C) * a.nscales * h->N;
-    launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
-    if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!simple) for (int i = 0; i < a.nscales; ++i) if (!dlo[i] && dd[i] != h->ddisp_lo[i]) launch_upsample_planar_bwd(dd[i], h->ddisp_lo[i], h->N, a.dh[i], a.dw[i], h->H, h->W, s);
-    launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
+    if (h->defer_tail && !simple) { h->tail.pending = true; h->tail.a = a; h->tail.loss_out = loss_out; h->tail.rvec = rvec; h->tail.tvec = tvec; }      // model_backward runs it on the pose stream
+    else { h->tail.pending = false; if (int r = loss_tail(h, a, loss_out, rvec, tvec, s)) return r; }
+    h->defer_tail = false;
     KCHK();
     return 0;
 }
@@ -637,15 +684,30 @@ static int model_backward(md2_handle* h) {
     // ---- pose decoder pullback on its own stream, overlapping the depth decoder pullback.  Its last four launches accumulate into
     //      Gfeat[4] (frame 1 on top of the depth decoder's first write), so they wait for the depth decoder (ev_b) — see pose_backward.
     const bool pose_async = h->two_streams && h->s3;
-    if (pose_async) { (void)hipEventRecord(h->ev_a, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_a, 0); h->cur = h->s3; pose_backward(h, N, 0); h->cur = nullptr; }
-    // ---- depth decoder
     const int nbr = h->nbr;
-    for (int l = 0; l < h->ns; ++l) {
+    // The heads' pullbacks are independent of each other and latency-bound (their epilogues are weight-gradient atomics).  The decoder chain below starts from the LAST
+    // branch and meets the other heads' gradients only when it folds into gA[b - 1]: with the pose stream available the other heads run there, beside the chain's first
+    // convolutions (ev_heads orders the first fold after them); alone on the stream they run back to back as before.
+    static const bool heads_aside_on = !md2_tune_set("MD2_NO_HEADS_ASIDE");
+    const bool heads_aside = pose_async && heads_aside_on && h->ns > 1;
+    hipEvent_t ev_heads = nullptr;
+    auto head_bwd = [&](int l, hipStream_t st) {
         const int b = h->lv[l] - 1;
         View dyv = make_view(h->ddisp_lo[l], N, h->dispv[l].H, h->dispv[l].W, 1);
         // last branch: only its head consumes it, so the ELU derivative of its y2 is applied right there
-        launch_head_bwd(h->y2[b], h->P + h->head[l].w, h->dispv[l], dyv, h->gA[b], 0, b == nbr - 1 ? ACT_ELU : ACT_NONE, h->G + h->head[l].w, h->G + h->head[l].b, s);
+        launch_head_bwd(h->y2[b], h->P + h->head[l].w, h->dispv[l], dyv, h->gA[b], 0, b == nbr - 1 ? ACT_ELU : ACT_NONE, h->G + h->head[l].w, h->G + h->head[l].b, st);
+    };
+    if (pose_async) {
+        (void)hipEventRecord(h->ev_a, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_a, 0);
+        if (h->tail.pending) { h->tail.pending = false; if (int r = loss_tail(h, h->tail.a, h->tail.loss_out, h->tail.rvec, h->tail.tvec, h->s3)) return r; }
+        if (heads_aside) {
+            for (int l = h->ns - 2; l >= 0; --l) head_bwd(l, h->s3);          // (finest first: the order the chain needs them in)
+            ev_heads = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64; (void)hipEventRecord(ev_heads, h->s3);
+        }
+        h->cur = h->s3; pose_backward(h, N, 0); h->cur = nullptr;
     }
+    // ---- depth decoder
+    for (int l = heads_aside ? h->ns - 1 : 0; l < h->ns; ++l) head_bwd(l, s);
     for (int b = nbr - 1; b >= 0; --b) {
         // gA[b] now holds d loss / d (pre-ELU output of c2[b])
         const View& dZ2 = h->gA[b];
@@ -653,19 +715,26 @@ static int model_backward(md2_handle* h) {
         View dcp = h->scratch_view(h->dxpad, N, h->cat[b].H + 2, h->cat[b].W + 2, h->cat[b].C);
         conv_dgrad(h, h->dc2[b], dZ2, dcp, 0, 0, nullptr, ACT_NONE);
         const int dc = h->y1[b].C;
+        const bool gather_up = h->cat[b].H >= 4 && h->cat[b].W >= 4;
+        static const bool fold_pair = !md2_tune_set("MD2_NO_FOLD_PAIR");
         if (b < 4) {
             View fv = frame_view(h->feat[3 - b], 3, h->tgt), gv = frame_view(h->Gfeat[3 - b], 3, h->tgt);
-            launch_fold_reflect(chan_slice(dcp, dc, fv.C), gv, 0, &fv, ACT_RELU, s);      // first writer of this stage's target frames
+            // first writer of this stage's target frames -- in one launch with the upsampled half's adjoint where that is the gather pass
+            if (gather_up && fold_pair) launch_fold_cat_bwd(chan_slice(dcp, 0, dc), h->dZ1[b], &h->y1[b], ACT_ELU, chan_slice(dcp, dc, fv.C), gv, 0, &fv, ACT_RELU, s);
+            else launch_fold_reflect(chan_slice(dcp, dc, fv.C), gv, 0, &fv, ACT_RELU, s);
         }
         // the upsampled half of the concat: reflect-pad adjoint and the x2 adjoint in one gather pass (deterministic either way: no atomics); maps narrower than 4 keep the two passes
-        if (h->cat[b].H >= 4 && h->cat[b].W >= 4) launch_fold_up2_bwd(chan_slice(dcp, 0, dc), h->dZ1[b], &h->y1[b], ACT_ELU, s);
+        if (gather_up) { if (!(b < 4 && fold_pair)) launch_fold_up2_bwd(chan_slice(dcp, 0, dc), h->dZ1[b], &h->y1[b], ACT_ELU, s); }
         else { launch_fold_reflect(chan_slice(dcp, 0, dc), h->dupv[b], 0, nullptr, ACT_NONE, s); launch_upsample2x_bwd(h->dupv[b], h->dZ1[b], &h->y1[b], ACT_ELU, s); }
         const View& in = (b == 0) ? frame_view(h->feat[4], 3, h->tgt) : h->y2[b - 1];
         conv_wgrad(h, h->dc1[b], in, h->dZ1[b], PAD_REFLECT);
         View dip = h->scratch_view(h->dxpad, N, in.H + 2, in.W + 2, in.C);
         conv_dgrad(h, h->dc1[b], h->dZ1[b], dip, 0, 0, nullptr, ACT_NONE);
         if (b == 0) { View fv = frame_view(h->feat[4], 3, h->tgt), gv = frame_view(h->Gfeat[4], 3, h->tgt); launch_fold_reflect(dip, gv, 0, &fv, ACT_RELU, s); }   // first writer of Gfeat[4] frame 1
-        else launch_fold_reflect(dip, h->gA[b - 1], h->out_of[b - 1] >= 0 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);        // (adds to the head's contribution where branch b-1 has one)
+        else {
+            if (ev_heads && h->out_of[b - 1] >= 0) { (void)hipStreamWaitEvent(s, ev_heads, 0); ev_heads = nullptr; }    // the heads on the pose stream have written their gA
+            launch_fold_reflect(dip, h->gA[b - 1], h->out_of[b - 1] >= 0 ? 1 : 0, &h->y2[b - 1], ACT_ELU, s);        // (adds to the head's contribution where branch b-1 has one)
+        }
     }
     // ---- pose branch, second half: accumulate into Gfeat[4] after the depth decoder's write; then join (the encoder pullback reads Gfeat[4])
     if (pose_async) {
@@ -1044,15 +1113,17 @@ int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, fl
     if (!h->net_ok) { h->err = "this handle is loss-only (height/width below 64 or not multiples of 32): the model entry points are unavailable"; return 2; }
     if (h->cfg.automasking && !auto_loss) { h->err = "md2_train_loss: automasking is on but auto_loss is NULL"; return 2; }
     if (h->testmode) { h->err = "md2_train_loss: the handle is in test mode (md2_set_testmode(h, 0) = Flux.trainmode! first)"; return 2; }
-    h->have_fwd = false; h->prep_done = false;
+    h->have_fwd = false; h->prep_done = false; h->ddisp_zeroed = false; h->Rt_ready = false;
     h->acc_zeroed = true;                   // model_forward zeroes every accumulator of this step at once (consumed by loss_train below)
     if (h->two_streams && h->s2) {          // ordered after everything already on the caller's stream (the previous ADAM step reads G and writes P)
         (void)hipEventRecord(h->ev_p0, h->stream); (void)hipStreamWaitEvent(h->s2, h->ev_p0, 0);
+        // (the scattering loss pass accumulates the coarse levels' disparity gradients: zeroed here, off the caller's stream; ordered before the loss through ev_uf)
+        if (h->ns > 0 && loss_scatters() && ddisp_lo_zero_bytes(h) > 0) { HIPCHK(hipMemsetAsync(h->ddisp_lo[0], 0, ddisp_lo_zero_bytes(h), h->s2)); h->ddisp_zeroed = true; }
         refresh_wino_fwd(h, h->s2); (void)hipEventRecord(h->ev_uf, h->s2);
         if (int r = backward_prepare(h, h->s2)) { h->acc_zeroed = false; return r; }
         (void)hipEventRecord(h->ev_p1, h->s2); h->prep_done = true;
     }
-    if (int r = model_forward(h, x, 3, -1, true, true, h->prep_done)) { h->acc_zeroed = false; return r; }
+    if (int r = model_forward(h, x, 3, -1, true, true, h->prep_done)) { h->acc_zeroed = false; h->ddisp_zeroed = false; h->Rt_ready = false; return r; }
     const float* disp[MD2_MAX_SCALES] = {h->dispv[0].p, h->dispv[1].p, h->dispv[2].p, h->dispv[3].p, h->dispv[4].p};
     if (int r = loss_train(h, x, disp, h->rvec, h->tvec, auto_loss, loss)) return r;          // the loss pullback comes out of the same pass: md2_backward starts at the network
     h->x_last = x; h->auto_last = auto_loss; h->have_fwd = true;
@@ -1068,7 +1139,8 @@ int32_t md2_adam_step(md2_handle* h, float grad_scale) {
     KCHK(); return 0;
 }
 int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, float* loss, int32_t do_update) {
-    if (int r = md2_train_loss(h, x, auto_loss, loss)) return r;
+    h->defer_tail = h->two_streams && h->s3;            // the pullback follows at once: the loss's tail opens its pose stream (loss_train / model_backward)
+    if (int r = md2_train_loss(h, x, auto_loss, loss)) { h->defer_tail = false; h->tail.pending = false; return r; }
     if (int r = md2_backward(h)) return r;
     if (h->comm) { if (int r = md2_allreduce_grads(h)) return r; }                  // data parallel: gradient of the global batch = mean over the ranks
     if (do_update) return md2_adam_step(h, h->comm ? 1.f / (float)h->world : 1.f);

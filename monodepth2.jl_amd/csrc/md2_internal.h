@@ -243,10 +243,16 @@ void launch_colstats(const View& z, double* acc, hipStream_t s);
 void launch_bn_finalize(const double* acc /*[slots][2C]*/, float* stats, int C, double count, int slots, float* running /* [2C] or null */, float momentum, hipStream_t s,
                         const float* gamma = nullptr, const float* beta = nullptr);
 void launch_bn_stats_from_running(const float* running, float* stats, int C, hipStream_t s, const float* gamma = nullptr, const float* beta = nullptr);
-void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s);
+// Batch statistics still in their double accumulators: an elementwise kernel that is the FIRST reader of a BatchNorm finalises them in its own prologue (every workgroup
+// into LDS, workgroup 0 also writes `stats` and the running statistics for the later readers) -- the arithmetic of bn_finalize_kernel without its launch.
+// `stats` must be the array the same call applies.
+struct BnFin { const double* acc = nullptr; double count = 0; int slots = 0; float* stats = nullptr; float* running = nullptr; float momentum = 0.f; };
+void launch_bn_relu_maxpool(const View& z, const float* stats, const float* gamma, const float* beta, const View& a, int L, int tgt, const View& y, uint8_t* arg, hipStream_t s,
+                            const BnFin* fin = nullptr);
 // y = act(gamma*(z-mean)*invstd + beta + residual)
 void launch_bn_apply(const View& z, const float* stats, const float* gamma, const float* beta, const View* residual, int act, const View& y, hipStream_t s,
-                     const float* rstats = nullptr, const float* rgamma = nullptr, const float* rbeta = nullptr);      // r*: the residual is a raw conv output, BatchNorm'ed on the fly
+                     const float* rstats = nullptr, const float* rgamma = nullptr, const float* rbeta = nullptr,      // r*: the residual is a raw conv output, BatchNorm'ed on the fly
+                     const BnFin* fin = nullptr, const BnFin* rfin = nullptr);                                        // fin / rfin: finalise stats / rstats here (no bn_finalize launch)
 // g = dy * act_deriv(yact) ; acc[0..C) += sum g ; acc[C..2C) += sum g*xhat          (acc double, zeroed by caller)
 void launch_bn_bwd_reduce(const View& dy, const View* yact, int act, const View& z, const float* stats, double* acc, hipStream_t s);
 // dz = gamma*invstd*(g - s1/M - xhat*s2/M) ; dgamma += s2, dbeta += s1 (written by block 0)
@@ -258,11 +264,13 @@ void launch_maxpool_bwd(const View& dy, const uint8_t* arg, const View& dx, int 
                         const View* bz = nullptr, const float* bstat = nullptr, double* bacc = nullptr, int acc_frame = 1);       // optional: BatchNorm-pullback sums of dx w.r.t. BatchNorm input bz
 // sums -> coef = m1 | m2 [| A | B | C0 with stats / gamma: dz = A g + B z + C0], d gamma / d beta accumulated
 void launch_bn_bwd_finalize(const double* acc, int slots, int C, double count, float* coef, float* dgamma, float* dbeta, const float* stats, const float* gamma, hipStream_t s);
-void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s);
+void launch_upsample2x_fwd(const View& x, const View& y, hipStream_t s, const View* skip = nullptr);      // skip: y is the concat buffer, its channels behind x's receive a copy of *skip
 // dx = adjoint(up2)(dy) * act_deriv(xact)
 void launch_upsample2x_bwd(const View& dy, const View& dx, const View* xact, int act, hipStream_t s);
 // fold_reflect + upsample2x_bwd in one gather pass: dx = adjoint(up2)(fold(src_padded)) * act_deriv(xact)     (fine map at least 4 x 4, ratio <= 2)
 void launch_fold_up2_bwd(const View& src_pad, const View& dx, const View* xact, int act, hipStream_t s);
+// both halves of a DecoderBlock's padded concat gradient in one launch: fold_up2_bwd on the upsampled channels, fold_reflect on the skip connection's
+void launch_fold_cat_bwd(const View& pad_up, const View& dx, const View* xact, int act_up, const View& pad_sk, const View& dst, int accumulate, const View* actsrc, int act_sk, hipStream_t s);
 // reflect-pad adjoint: dst = ((accumulate ? dst : 0) + fold(src_padded)) * act_deriv(actsrc)
 void launch_fold_reflect(const View& src_pad, const View& dst, int accumulate, const View* actsrc, int act, hipStream_t s);
 // dst = (accumulate ? dst : 0) + a*src (optionally * act_deriv(actsrc))
