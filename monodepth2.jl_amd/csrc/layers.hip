@@ -120,7 +120,9 @@ static void colstats_launch(int mode, const View& z, const View* dy, const View*
     const int Qh = z.C / 4;
     if (z.C % 4 != 0 || (Qh <= 256 ? 256 % Qh != 0 : Qh % 256 != 0)) { fprintf(stderr, "md2: colstats: unsupported C=%d\n", z.C); abort(); }
     const long P = z.pixels();
-    int rpb = 2048; while (rpb > 64 && (P + rpb - 1) / rpb < 1024) rpb >>= 1;
+    // (a small map -- the deepest stage at batch 4 is 624 pixels -- is a latency chain of its few workgroups' row loops: shorter ones there, 20 -> 8 us)
+    const int rpb_min = P < 2048 ? 16 : 64;
+    int rpb = 2048; while (rpb > rpb_min && (P + rpb - 1) / rpb < 1024) rpb >>= 1;
     if (g_deterministic) rpb = (int)std::min<long>(P, 1 << 30);          // one workgroup per channel group: one atomic per channel
     const dim3 grid((unsigned)((P + rpb - 1) / rpb), (unsigned)((Qh + 255) / 256));
     View d = dy ? *dy : z, ya = yact ? *yact : z;

@@ -425,6 +425,13 @@ static LossArgs loss_args(md2_handle* h, const float* x, const float* const disp
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
+// the coarse levels' disparity gradients are scatter-accumulated (float atomics) unless the reductions are ordered; those levels come first in the block, a
+// full-resolution last level is written, not accumulated -- the bytes a scattering loss pass needs zeroed
+static bool loss_scatters() { static const bool no_scatter = md2_tune("MD2_LOSS_NOSCATTER", 0) != 0; return !g_deterministic && !no_scatter; }
+static size_t ddisp_lo_zero_bytes(const md2_handle* h) {
+    const bool last_full = (h->H >> (5 - h->lv[h->ns - 1])) == h->H && (h->W >> (5 - h->lv[h->ns - 1])) == h->W;
+    return last_full ? (size_t)((const char*)h->ddisp_lo[h->ns - 1] - (const char*)h->ddisp_lo[0]) : h->ddisp_lo_count * sizeof(float);
+}
 // Temporarily re-batch every activation view: n_enc encoder images, n_dec decoder samples (<= the sizes the arena was planned for).
 static void set_batch(md2_handle* h, int n_enc, int n_dec) {
     h->z0.N = h->a0.N = h->p0.N = n_enc;
@@ -526,6 +533,8 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
     const bool heads_aside = pose_async && with_depth && heads_aside_on;
     if (with_pose) {
         if (pose_async) { (void)hipEventRecord(h->ev_a, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_a, 0); h->cur = h->s3; }
+        // (the scattering loss pass accumulates the coarse levels' disparity gradients: zeroed here, off the caller's stream; ordered before the loss through ev_b)
+        if (pose_async && wino_on_side && with_depth && h->ns > 0 && loss_scatters() && ddisp_lo_zero_bytes(h) > 0) { HIPCHK(hipMemsetAsync(h->ddisp_lo[0], 0, ddisp_lo_zero_bytes(h), h->s3)); h->ddisp_zeroed = true; }
         pose_forward(h, N);
         if (pose_async && wino_on_side) { launch_pose_compose(h->rvec, h->tvec, h->Rt, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, h->s3); h->Rt_ready = true; }
         if (pose_async) { if (!heads_aside) (void)hipEventRecord(h->ev_b, h->s3); h->cur = nullptr; }
@@ -569,13 +578,6 @@ static int loss_forward(md2_handle* h, const float* x, const float* const disp[M
     if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
     KCHK();
     return 0;
-}
-// the coarse levels' disparity gradients are scatter-accumulated (float atomics) unless the reductions are ordered; those levels come first in the block, a
-// full-resolution last level is written, not accumulated -- the bytes a scattering loss pass needs zeroed
-static bool loss_scatters() { static const bool no_scatter = md2_tune("MD2_LOSS_NOSCATTER", 0) != 0; return !g_deterministic && !no_scatter; }
-static size_t ddisp_lo_zero_bytes(const md2_handle* h) {
-    const bool last_full = (h->H >> (5 - h->lv[h->ns - 1])) == h->H && (h->W >> (5 - h->lv[h->ns - 1])) == h->W;
-    return last_full ? (size_t)((const char*)h->ddisp_lo[h->ns - 1] - (const char*)h->ddisp_lo[0]) : h->ddisp_lo_count * sizeof(float);
 }
 // what follows the fused loss kernel and is not read by the depth decoder's pullback: the scalar loss and the pose pullback's first step
 static int loss_tail(md2_handle* h, const LossArgs& a, float* loss_out, const float* rvec, const float* tvec, hipStream_t s) {
@@ -1117,8 +1119,6 @@ int32_t md2_train_loss(md2_handle* h, const float* x, const float* auto_loss, fl
     h->acc_zeroed = true;                   // model_forward zeroes every accumulator of this step at once (consumed by loss_train below)
     if (h->two_streams && h->s2) {          // ordered after everything already on the caller's stream (the previous ADAM step reads G and writes P)
         (void)hipEventRecord(h->ev_p0, h->stream); (void)hipStreamWaitEvent(h->s2, h->ev_p0, 0);
-        // (the scattering loss pass accumulates the coarse levels' disparity gradients: zeroed here, off the caller's stream; ordered before the loss through ev_uf)
-        if (h->ns > 0 && loss_scatters() && ddisp_lo_zero_bytes(h) > 0) { HIPCHK(hipMemsetAsync(h->ddisp_lo[0], 0, ddisp_lo_zero_bytes(h), h->s2)); h->ddisp_zeroed = true; }
         refresh_wino_fwd(h, h->s2); (void)hipEventRecord(h->ev_uf, h->s2);
         if (int r = backward_prepare(h, h->s2)) { h->acc_zeroed = false; return r; }
         (void)hipEventRecord(h->ev_p1, h->s2); h->prep_done = true;
