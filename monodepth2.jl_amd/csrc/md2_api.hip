@@ -684,7 +684,7 @@ static int model_backward(md2_handle* h) {
     // encoder pullback reaches them, so the encoder's first writer uses accumulate mode 2 (add only in target frames).
 
     // ---- pose decoder pullback on its own stream, overlapping the depth decoder pullback.  Its last four launches accumulate into
-    //      Gfeat[4] (frame 1 on top of the depth decoder's first write), so they wait for the depth decoder (ev_b) — see pose_backward.
+    //      Gfeat[4] (frame 1 on top of the depth decoder's first write): they follow the depth decoder on the caller's stream — see pose_backward.
     const bool pose_async = h->two_streams && h->s3;
     const int nbr = h->nbr;
     // The heads' pullbacks are independent of each other and latency-bound (their epilogues are weight-gradient atomics).  The decoder chain below starts from the LAST
@@ -739,10 +739,11 @@ static int model_backward(md2_handle* h) {
         }
     }
     // ---- pose branch, second half: accumulate into Gfeat[4] after the depth decoder's write; then join (the encoder pullback reads Gfeat[4])
+    // (on the caller's stream: the encoder pullback needs it at once, and a hop to the pose stream and back only adds two event latencies to the chain -- batch 4:
+    //  48 us between the decoder's last fold and the encoder's first kernel, profiles/r06_b4_two_stream_trace.txt; the pose stream's first half finished long before)
     if (pose_async) {
-        (void)hipEventRecord(h->ev_b, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_b, 0);
-        h->cur = h->s3; pose_backward(h, N, 1); (void)hipEventRecord(h->ev_c, h->s3); h->cur = nullptr;
-        (void)hipStreamWaitEvent(h->stream, h->ev_c, 0);
+        (void)hipEventRecord(h->ev_c, h->s3); (void)hipStreamWaitEvent(h->stream, h->ev_c, 0);
+        pose_backward(h, N, 1);
     } else { pose_backward(h, N, 0); pose_backward(h, N, 1); }
     if (int r = comm_bucket(h, bp.lo[0], bp.hi[0])) return r;           // depth decoder, heads, pose decoder
     // ---- encoder
@@ -838,7 +839,10 @@ static int model_backward(md2_handle* h) {
         else { launch_maxpool_bwd(h->Gpool, h->pool_arg, h->Gfeat[0], 2, &h->p0, s, nullptr, nullptr, nullptr, acc_frame); launch_bn_bwd_reduce(h->Gfeat[0], nullptr, ACT_NONE, h->z0, b.stats, b.acc_b, s); }
         launch_bn_bwd_finalize(b.acc_b, BN_STAT_SLOTS, b.c, (double)h->z0.pixels(), b.stats + 4 * b.c, h->G + b.g, h->G + b.b, b.stats, h->P + b.g, s);
         const double fl = 2.0 * NL * (H / 2) * (W / 2) * 64.0 * 49.0 * h->C;
-        hipStream_t st = wgrad_stream(h);
+        // the last launch of the pullback stays on the caller's stream, which has nothing else left: beside the weight-gradient stream's tail instead of behind it, and
+        // without the fork / join hop (batch 4: 56 us between bn_bwd_finalize and ADAM for this 35 us kernel)
+        static const bool stem_on_chain = !md2_tune_set("MD2_STEM_WGRAD_FORK");
+        hipStream_t st = stem_on_chain ? s : wgrad_stream(h);
         h->pbegin(CLS_WGRAD, fl, "stem wgrad 7x7 s2 (direct, BatchNorm pullback in the loader)", st, true);
         launch_stem_wgrad(h->x_last, NL, h->C, H, W, h->Gfeat[0], h->G + h->stem.w, h->Kpad, st, &h->z0, b.stats + 6 * b.c, h->bs);
         h->pend(st, true);
