@@ -87,6 +87,7 @@ struct md2_handle {
     hipStream_t s3 = nullptr; hipStream_t cur = nullptr; hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // pose branch stream; `cur` = stream of the chain being enqueued
     hipStream_t s4 = nullptr; int wg_rr = 0; int n_wg_streams = 1; hipEvent_t ev_join4 = nullptr;
     hipStream_t s2 = nullptr; hipEvent_t ev_pool[64]; int ev_next = 0; hipEvent_t ev_join = nullptr, ev_p0 = nullptr, ev_p1 = nullptr; bool prep_done = false; bool two_streams = true; bool forked = false; View dz0;
+    int wg_idx = 0, wg_total = 0;       // weight-gradient launches of the running pullback / of the last complete one (wgrad_stream)
     bool acc_zeroed = false;            // md2_train_loss: the forward pass's memset covers the pullback / loss accumulators too
     // launches md2_train_step takes off the caller's stream (round 6, batch 4 is a chain of ~200 dependent launches): the coarse disparity gradients are zeroed on the
     // preparation stream at the head of the step (ddisp_zeroed), the pose stream composes Rt right behind the pose decoder (Rt_ready), and the loss's tail -- the
@@ -353,6 +354,16 @@ static void conv_dgrad(md2_handle* h, const ConvL& c, const View& dy, const View
 // stream a weight gradient is enqueued on: the side stream, forked by event from the chain at this point (its dy is complete)
 static hipStream_t wgrad_stream(md2_handle* h) {
     hipStream_t st = h->chain();
+    // The pullback's last two weight gradients stay on the chain where the weight-gradient stream ends the step with a backlog -- large batches: its launches are capped at
+    // 256 workgroups and run ~40 % longer beside the chain, so at batch 32 the stream drains alone, half-wide, after the chain's last kernel.  Measured on one box
+    // (tools/env_probe.sh, profiles/r06_wgrad_tail_probe.txt): batch 32 10.86 -> 10.71 ms with 2 (3: 10.72, 4: 10.76, 8: 10.88); batch 4 2.98 -> 3.01 and batch 16
+    // 6.14 -> 6.17 (no backlog there: the launches only lose their overlap); ResNet-50 640x192 and 1024x320 unchanged.  Hence by size: from 1.5 M target pixels per step.
+    // (the count of launches is the previous pullback's; MD2_WGRAD_TAIL_CHAIN / MD2_WGRAD_HEAD_CHAIN: tuning builds)
+    static const int tail_env = md2_tune("MD2_WGRAD_TAIL_CHAIN", -1), head_on_chain = md2_tune("MD2_WGRAD_HEAD_CHAIN", 0);
+    const int tail_on_chain = tail_env >= 0 ? tail_env : ((long)h->N * h->H * h->W >= 1500000L ? 2 : 0);
+    const int idx = h->wg_idx++;
+    if (tail_on_chain > 0 && h->wg_total > 0 && idx >= h->wg_total - tail_on_chain) return st;
+    if (idx < head_on_chain) return st;
     if (h->two_streams && h->s2) {          // fork: everything enqueued on this chain's stream so far happens-before this weight gradient
         hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
         hipStream_t tgt = (h->n_wg_streams > 1 && (h->wg_rr++ & 1)) ? h->s4 : h->s2;      // round-robin over the weight-gradient streams
@@ -677,7 +688,7 @@ static int model_backward(md2_handle* h) {
     // data parallel: the gradient buffer is all-reduced in up to 4 buckets as they complete (decoders | stage 5 | stages 3-4 | stage 2 + stem), MD2_COMM_BUCKETS=0: one
     // all-reduce by md2_allreduce_grads after the pullback
     static const bool buckets_on = md2_tune("MD2_COMM_BUCKETS", 1) != 0;
-    h->grads_reduced = false; h->n_bucket_done = (h->comm && buckets_on) ? 0 : -1;
+    h->grads_reduced = false; h->n_bucket_done = (h->comm && buckets_on) ? 0 : -1; h->wg_idx = 0;
     const BucketPlan bp = bucket_plan(h);
     // The gradient accumulators (Gfeat / Gblk / Gpool, 715 MB at B=32) are NOT zeroed: every buffer's first writer overwrites
     // (accumulate 0) and later writers add.  Stage buffers receive decoder / pose contributions in the target frame before the
@@ -853,6 +864,7 @@ static int model_backward(md2_handle* h) {
         (void)hipEventRecord(h->ev_cdone, h->scomm); (void)hipStreamWaitEvent(h->stream, h->ev_cdone, 0);
         h->grads_reduced = true;
     }
+    h->wg_total = h->wg_idx;
     if (h->forked) {                        // join: the gradient buffer is complete only when the weight-gradient stream has drained
         (void)hipEventRecord(h->ev_join, h->s2); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); h->forked = false;
         if (h->n_wg_streams > 1) { (void)hipEventRecord(h->ev_join4, h->s4); (void)hipStreamWaitEvent(h->stream, h->ev_join4, 0); }
