@@ -585,15 +585,13 @@ static int loss_forward(md2_handle* h, const float* x, const float* const disp[M
     if (simple) simple_mode(h, a);
     h->pbegin(CLS_LOSS_FWD); launch_loss_fwd(a, h->loss_part, g_deterministic ? h->loss_blk : nullptr, s); h->pend();
     if (h->prof) h->prof_bytes[CLS_LOSS_FWD] += 4.0 * h->H * h->W * (1 + 3 * h->C) * a.nscales * h->N;
-    launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
-    if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
+    launch_loss_finalize(a, h->loss_part, h->totals, loss_out ? loss_out : h->loss_dev, s);          // (straight into the caller's device scalar: no 4-byte copy behind it)
     KCHK();
     return 0;
 }
 // what follows the fused loss kernel and is not read by the depth decoder's pullback: the scalar loss and the pose pullback's first step
 static int loss_tail(md2_handle* h, const LossArgs& a, float* loss_out, const float* rvec, const float* tvec, hipStream_t s) {
-    launch_loss_finalize(a, h->loss_part, h->totals, h->loss_dev, s);
-    if (loss_out && loss_out != h->loss_dev) HIPCHK(hipMemcpyAsync(loss_out, h->loss_dev, sizeof(float), hipMemcpyDeviceToDevice, s));
+    launch_loss_finalize(a, h->loss_part, h->totals, loss_out ? loss_out : h->loss_dev, s);          // (straight into the caller's device scalar: no 4-byte copy behind it)
     launch_pose_compose_bwd(rvec, tvec, h->dRt_acc, h->drvec, h->dtvec, h->N, h->src[0] < h->tgt, h->src[1] < h->tgt, s);
     return 0;
 }
@@ -1155,7 +1153,8 @@ int32_t md2_adam_step(md2_handle* h, float grad_scale) {
     KCHK(); return 0;
 }
 int32_t md2_train_step(md2_handle* h, const float* x, const float* auto_loss, float* loss, int32_t do_update) {
-    h->defer_tail = h->two_streams && h->s3;            // the pullback follows at once: the loss's tail opens its pose stream (loss_train / model_backward)
+    static const bool no_defer = md2_tune_set("MD2_NO_DEFER_TAIL");
+    h->defer_tail = h->two_streams && h->s3 && !no_defer;            // the pullback follows at once: the loss's tail opens its pose stream (loss_train / model_backward)
     if (int r = md2_train_loss(h, x, auto_loss, loss)) { h->defer_tail = false; h->tail.pending = false; return r; }
     if (int r = md2_backward(h)) return r;
     if (h->comm) { if (int r = md2_allreduce_grads(h)) return r; }                  // data parallel: gradient of the global batch = mean over the ranks
