@@ -332,6 +332,26 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
     h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
     if (h->prof) { h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a); h->prof_exec[CLS_IGEMM] += conv_igemm_executed_flops(a); }
 }
+// A short independent branch on the pose stream (idle while the encoder runs): side_begin forks it from the chain (everything enqueued so far happens-before it) and makes
+// it the chain being enqueued; side_end returns the event the caller's stream must wait for before it reads the branch's results.  Used for the 1x1 shortcut of a
+// down-sampling block, forward and pullback: small, latency-bound launches that need not stand in the dependency chain (round 6).
+static bool side_branch_ok(const md2_handle* h, bool pullback) {
+    static const bool off = md2_tune_set("MD2_NO_SIDE_SHORTCUT"), off_f = md2_tune_set("MD2_NO_SIDE_SHORTCUT_FWD"), off_b = md2_tune_set("MD2_NO_SIDE_SHORTCUT_BWD");
+    static const long big = md2_tune("MD2_SIDE_SHORTCUT_MAXPIX", 1500000L);
+    // measured on one box (tools/env_probe.sh, profiles/r06_side_shortcut_probe.txt): batch 4 2.97 -> 2.92 ms with both halves; at batch 16 / 32 the forward half alone is
+    // best or equal (6.14 -> 6.11, 10.69 -> 10.69) and the pullback half costs 0.3 % -- the pullback already shares the chip with the weight-gradient stream there -- so the
+    // pullback half is for steps below 1.5 M target pixels
+    return !off && !(pullback ? off_b : off_f) && (!pullback || (long)h->N * h->H * h->W < big) && h->two_streams && h->s3 && !h->cur;
+}
+static void side_begin(md2_handle* h) {
+    hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
+    (void)hipEventRecord(ev, h->stream); (void)hipStreamWaitEvent(h->s3, ev, 0); h->cur = h->s3;
+}
+static hipEvent_t side_end(md2_handle* h) {
+    hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
+    (void)hipEventRecord(ev, h->s3); h->cur = nullptr;
+    return ev;
+}
 // forward conv (kind 0) on views.  x.C must equal c.cinP, y.C == c.coutP
 static void conv_fwd(md2_handle* h, const ConvL& c, const View& x, const View& y, int padmode, int act, double* bn_stats = nullptr) {
     ConvArgs a = conv_args(x, h->wfwd(c.w), y, c.k, c.stride, padmode == PAD_REFLECT ? 1 : c.pad, 1, padmode);
@@ -496,6 +516,9 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
     for (int i = 0; i < h->nblk; ++i) {
         Block& B = h->blk[i];
         if (B.fuse) {
+            // the 1x1 shortcut convolution of a down-sampling block reads only the block input: beside the main path, on the pose stream
+            hipEvent_t ev_sc = nullptr;
+            if (B.down && side_branch_ok(h, false)) { side_begin(h); conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc); ev_sc = side_end(h); }
             conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_stats(h, B.b1, B.z1);
             {   // conv2 gathers relu(bn1(z1)) straight from z1 -- except on bf16 tensors, where the plain launch (LDS loader, 128 x 64 tiles) plus one elementwise pass into a
                 // shared buffer is ahead of the launch with the transform in its register-staged loader (round 5: 55 + 10...35 against 114 us at configs[4])
@@ -520,7 +543,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
             BnFin fo, fd; const bool fin = bn_fin(h, bo, zo, fo);
             if (!fin) bn_stats(h, bo, zo);
             if (B.down) {                 // out = relu(bn(z) + bnd(zd)): the shortcut's BatchNorm output is never written
-                conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc);
+                if (ev_sc) (void)hipStreamWaitEvent(s, ev_sc, 0); else conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc);
                 if (!bn_fin(h, B.bd, B.zd, fd)) bn_stats(h, B.bd, B.zd);
                 launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.zd, ACT_RELU, B.out, s, B.bd.stats, h->P + B.bd.g, h->P + B.bd.b, fin ? &fo : nullptr, fin ? &fd : nullptr);
             } else launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.in, ACT_RELU, B.out, s, nullptr, nullptr, nullptr, fin ? &fo : nullptr);
@@ -775,6 +798,16 @@ static int model_backward(md2_handle* h) {
         // the launch that completes Gin also reduces the BatchNorm-pullback sums of the block below (bn2 / bn3 and, for a down-sampling block, the shortcut's BatchNorm)
         Block* Bp = (i > 0 && h->blk[i - 1].fuse) ? &h->blk[i - 1] : nullptr;
         if (B.fuse) {
+            // the shortcut's pullback (BatchNorm, weight gradient, input gradient into its quarter of Gin) depends on Gout alone: beside the main path, on the pose
+            // stream; the main path's last launch -- conv1's input gradient, which completes Gin on top of it -- waits for it
+            hipEvent_t ev_sc = nullptr;
+            auto shortcut_bwd = [&]() {
+                bn_bwd(h, B.bd, Gout, B.zd, B.dzd, sums_ready[i]);
+                conv_wgrad(h, B.cd, B.in, B.dzd, PAD_ZERO);
+                ConvArgs ad = dgrad_args(h, B.cd, B.dzd, *Gin, 0, first_mode, in_act, ACT_RELU); ad.skip_empty = 1;
+                run_igemm(h, ad);
+            };
+            if (B.down && side_branch_ok(h, true)) { side_begin(h); shortcut_bwd(); ev_sc = side_end(h); }
             if (B.bottleneck) {
                 View da2 = h->scratch_view(h->E3, NL, B.a2.H, B.a2.W, B.a2.C);
                 bn_bwd(h, B.b3, Gout, B.z3, B.dz3, sums_ready[i]);
@@ -796,10 +829,7 @@ static int model_backward(md2_handle* h) {
             bn_bwd(h, B.b1, da1, B.z1, dz1, true);
             conv_wgrad(h, B.c1, B.in, dz1, PAD_ZERO);
             if (B.down) {           // the 1x1 / stride-2 shortcut writes its quarter of the pixels FIRST; the 3x3's residue classes then complete every pixel exactly once
-                bn_bwd(h, B.bd, Gout, B.zd, B.dzd, sums_ready[i]);
-                conv_wgrad(h, B.cd, B.in, B.dzd, PAD_ZERO);
-                ConvArgs ad = dgrad_args(h, B.cd, B.dzd, *Gin, 0, first_mode, in_act, ACT_RELU); ad.skip_empty = 1;
-                run_igemm(h, ad);
+                if (ev_sc) (void)hipStreamWaitEvent(s, ev_sc, 0); else shortcut_bwd();
             }
             ConvArgs a = dgrad_args(h, B.c1, dz1, *Gin, B.c1.pad, first_mode, in_act, ACT_RELU, B.down ? nullptr : &Gout);
             if (B.down) { if (B.bottleneck) a.acc_lat = B.cd.stride; else a.accumulate_c00 = 1; }      // (the bottleneck's conv1 is a dense 1x1: it adds on the shortcut's pixel lattice)
