@@ -332,7 +332,7 @@ static void run_igemm(md2_handle* h, const ConvArgs& a_in) {
     h->pbegin(CLS_IGEMM, conv_igemm_flops(a), d); launch_conv_igemm(a, h->chain()); h->pend();
     if (h->prof) { h->prof_flops[CLS_IGEMM] += conv_igemm_flops(a); h->prof_exec[CLS_IGEMM] += conv_igemm_executed_flops(a); }
 }
-// A short independent branch on the pose stream (idle while the encoder runs): side_begin forks it from the chain (everything enqueued so far happens-before it) and makes
+// A short independent branch on the pose stream (idle while the encoder runs): side_fork marks the fork point on the chain (everything enqueued so far happens-before the branch), side_enter makes
 // it the chain being enqueued; side_end returns the event the caller's stream must wait for before it reads the branch's results.  Used for the 1x1 shortcut of a
 // down-sampling block, forward and pullback: small, latency-bound launches that need not stand in the dependency chain (round 6).
 static bool side_branch_ok(const md2_handle* h, bool pullback) {
@@ -343,10 +343,14 @@ static bool side_branch_ok(const md2_handle* h, bool pullback) {
     // pullback half is for steps below 1.5 M target pixels
     return !off && !(pullback ? off_b : off_f) && (!pullback || (long)h->N * h->H * h->W < big) && h->two_streams && h->s3 && !h->cur;
 }
-static void side_begin(md2_handle* h) {
+// (side_fork marks the point on the chain; the branch itself is ENQUEUED after the main path's launches -- side_enter -- so that a host that is only just ahead of the
+//  GPU feeds the dependency chain first; on the GPU the branch may start as soon as the fork point is reached)
+static hipEvent_t side_fork(md2_handle* h) {
     hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
-    (void)hipEventRecord(ev, h->stream); (void)hipStreamWaitEvent(h->s3, ev, 0); h->cur = h->s3;
+    (void)hipEventRecord(ev, h->stream);
+    return ev;
 }
+static void side_enter(md2_handle* h, hipEvent_t fork) { (void)hipStreamWaitEvent(h->s3, fork, 0); h->cur = h->s3; }
 static hipEvent_t side_end(md2_handle* h) {
     hipEvent_t ev = h->ev_pool[h->ev_next]; h->ev_next = (h->ev_next + 1) % 64;
     (void)hipEventRecord(ev, h->s3); h->cur = nullptr;
@@ -517,8 +521,7 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
         Block& B = h->blk[i];
         if (B.fuse) {
             // the 1x1 shortcut convolution of a down-sampling block reads only the block input: beside the main path, on the pose stream
-            hipEvent_t ev_sc = nullptr;
-            if (B.down && side_branch_ok(h, false)) { side_begin(h); conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc); ev_sc = side_end(h); }
+            const hipEvent_t ev_fork = (B.down && side_branch_ok(h, false)) ? side_fork(h) : nullptr;
             conv_fwd(h, B.c1, B.in, B.z1, PAD_ZERO, ACT_NONE, B.b1.acc); bn_stats(h, B.b1, B.z1);
             {   // conv2 gathers relu(bn1(z1)) straight from z1 -- except on bf16 tensors, where the plain launch (LDS loader, 128 x 64 tiles) plus one elementwise pass into a
                 // shared buffer is ahead of the launch with the transform in its register-staged loader (round 5: 55 + 10...35 against 114 us at configs[4])
@@ -543,7 +546,8 @@ static int model_forward(md2_handle* h, const float* x, int L = 3, int tgt = -1,
             BnFin fo, fd; const bool fin = bn_fin(h, bo, zo, fo);
             if (!fin) bn_stats(h, bo, zo);
             if (B.down) {                 // out = relu(bn(z) + bnd(zd)): the shortcut's BatchNorm output is never written
-                if (ev_sc) (void)hipStreamWaitEvent(s, ev_sc, 0); else conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc);
+                if (ev_fork) { side_enter(h, ev_fork); conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc); (void)hipStreamWaitEvent(s, side_end(h), 0); }
+                else conv_fwd(h, B.cd, B.in, B.zd, PAD_ZERO, ACT_NONE, B.bd.acc);
                 if (!bn_fin(h, B.bd, B.zd, fd)) bn_stats(h, B.bd, B.zd);
                 launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.zd, ACT_RELU, B.out, s, B.bd.stats, h->P + B.bd.g, h->P + B.bd.b, fin ? &fo : nullptr, fin ? &fd : nullptr);
             } else launch_bn_apply(zo, bo.stats, h->P + bo.g, h->P + bo.b, &B.in, ACT_RELU, B.out, s, nullptr, nullptr, nullptr, fin ? &fo : nullptr);
@@ -732,7 +736,9 @@ static int model_backward(md2_handle* h) {
         launch_head_bwd(h->y2[b], h->P + h->head[l].w, h->dispv[l], dyv, h->gA[b], 0, b == nbr - 1 ? ACT_ELU : ACT_NONE, h->G + h->head[l].w, h->G + h->head[l].b, st);
     };
     if (pose_async) {
-        (void)hipEventRecord(h->ev_a, h->stream); (void)hipStreamWaitEvent(h->s3, h->ev_a, 0);
+        (void)hipEventRecord(h->ev_a, h->stream);
+        if (heads_aside) head_bwd(h->ns - 1, s);          // (host order: the chain's own head before the pose stream's ~30 enqueues; the pose stream does not wait for it)
+        (void)hipStreamWaitEvent(h->s3, h->ev_a, 0);
         if (h->tail.pending) { h->tail.pending = false; if (int r = loss_tail(h, h->tail.a, h->tail.loss_out, h->tail.rvec, h->tail.tvec, h->s3)) return r; }
         if (heads_aside) {
             for (int l = h->ns - 2; l >= 0; --l) head_bwd(l, h->s3);          // (finest first: the order the chain needs them in)
@@ -741,7 +747,7 @@ static int model_backward(md2_handle* h) {
         h->cur = h->s3; pose_backward(h, N, 0); h->cur = nullptr;
     }
     // ---- depth decoder
-    for (int l = heads_aside ? h->ns - 1 : 0; l < h->ns; ++l) head_bwd(l, s);
+    if (!heads_aside) for (int l = 0; l < h->ns; ++l) head_bwd(l, s);
     for (int b = nbr - 1; b >= 0; --b) {
         // gA[b] now holds d loss / d (pre-ELU output of c2[b])
         const View& dZ2 = h->gA[b];
@@ -800,14 +806,13 @@ static int model_backward(md2_handle* h) {
         if (B.fuse) {
             // the shortcut's pullback (BatchNorm, weight gradient, input gradient into its quarter of Gin) depends on Gout alone: beside the main path, on the pose
             // stream; the main path's last launch -- conv1's input gradient, which completes Gin on top of it -- waits for it
-            hipEvent_t ev_sc = nullptr;
+            const hipEvent_t ev_fork = (B.down && side_branch_ok(h, true)) ? side_fork(h) : nullptr;
             auto shortcut_bwd = [&]() {
                 bn_bwd(h, B.bd, Gout, B.zd, B.dzd, sums_ready[i]);
                 conv_wgrad(h, B.cd, B.in, B.dzd, PAD_ZERO);
                 ConvArgs ad = dgrad_args(h, B.cd, B.dzd, *Gin, 0, first_mode, in_act, ACT_RELU); ad.skip_empty = 1;
                 run_igemm(h, ad);
             };
-            if (B.down && side_branch_ok(h, true)) { side_begin(h); shortcut_bwd(); ev_sc = side_end(h); }
             if (B.bottleneck) {
                 View da2 = h->scratch_view(h->E3, NL, B.a2.H, B.a2.W, B.a2.C);
                 bn_bwd(h, B.b3, Gout, B.z3, B.dz3, sums_ready[i]);
@@ -829,7 +834,7 @@ static int model_backward(md2_handle* h) {
             bn_bwd(h, B.b1, da1, B.z1, dz1, true);
             conv_wgrad(h, B.c1, B.in, dz1, PAD_ZERO);
             if (B.down) {           // the 1x1 / stride-2 shortcut writes its quarter of the pixels FIRST; the 3x3's residue classes then complete every pixel exactly once
-                if (ev_sc) (void)hipStreamWaitEvent(s, ev_sc, 0); else shortcut_bwd();
+                if (ev_fork) { side_enter(h, ev_fork); shortcut_bwd(); (void)hipStreamWaitEvent(s, side_end(h), 0); } else shortcut_bwd();
             }
             ConvArgs a = dgrad_args(h, B.c1, dz1, *Gin, B.c1.pad, first_mode, in_act, ACT_RELU, B.down ? nullptr : &Gout);
             if (B.down) { if (B.bottleneck) a.acc_lat = B.cd.stride; else a.accumulate_c00 = 1; }      // (the bottleneck's conv1 is a dense 1x1: it adds on the shortcut's pixel lattice)
