@@ -742,23 +742,26 @@ __device__ __forceinline__ void fold_reflect_body(const View& sp, const View& ds
     const int Q = dst.C / N, H = dst.H, W = dst.W, idx = by * 256 + threadIdx.x;
     if (idx >= W * Q) return;
     const int w = idx / Q, q = idx - w * Q;
-    int uxs[3], nx = 0;                             // padded-domain columns that fold onto column w (pad_reflect mirrors WITHOUT the edge: -1 <-> 1, W <-> W - 2)
-    uxs[nx++] = w; if (w == 1) uxs[nx++] = -1; if (w == W - 2) uxs[nx++] = W;
+    // padded-domain columns / rows that fold onto column w / row h (pad_reflect mirrors WITHOUT the edge: -1 <-> 1, W <-> W - 2): the position itself, then the two
+    // frame positions where they apply -- as scalars selected by the unrolled loop index (indexed local arrays went to scratch in the bf16 instantiation)
+    constexpr int NONE = -0x40000000;
+    const int ux1 = w == 1 ? -1 : NONE, ux2 = w == W - 2 ? W : NONE;
     const int rows = dst.N * H, row_end = min(rows, (bx + 1) * rpb);
     for (int row = bx * rpb; row < row_end; ++row) {
         const int n = row / H, h = row - n * H;
-        int uys[3], ny = 0;
-        uys[ny++] = h; if (h == 1) uys[ny++] = -1; if (h == H - 2) uys[ny++] = H;
+        const int uy1 = h == 1 ? -1 : NONE, uy2 = h == H - 2 ? H : NONE;
         float g[N];
 #pragma unroll
         for (int e = 0; e < N; ++e) g[e] = 0.f;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            if (a >= ny) break;
+            const int uy = a == 0 ? h : (a == 1 ? uy1 : uy2);
+            if (uy == NONE) continue;
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-                if (b >= nx) break;
-                float d[N]; vldn<BS>(sp.p, voff(sp, n, (long)(uys[a] + 1) * sp.W + (uxs[b] + 1)) + q * N, d);
+                const int ux = b == 0 ? w : (b == 1 ? ux1 : ux2);
+                if (ux == NONE) continue;
+                float d[N]; vldn<BS>(sp.p, voff(sp, n, (long)(uy + 1) * sp.W + (ux + 1)) + q * N, d);
 #pragma unroll
                 for (int e = 0; e < N; ++e) g[e] += d[e];
             }
