@@ -965,6 +965,41 @@ def test_bit_reproducible_mode_holds_for_64_consecutive_steps(shape, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16_storage"])
+@pytest.mark.parametrize("shape", ["416x128_b4", "resnet50_96x160", "416x128_b32"])
+def test_stream_placement_does_not_change_a_bit(shape, precision):
+    """The step is enqueued on three HIP streams (the caller's dependency chain; the weight gradients; the pose decoder, the heads of every branch but the last, the loss's
+    tail and the 1 x 1 shortcut branches of the down-sampling blocks -- DESIGN.md section 4, "what runs on which stream") or, with md2_set_two_streams(h, 0), on ONE.  In the
+    bit-reproducible mode every reduction is ordered, so WHERE a launch is enqueued must not move a single bit: a missing fork / join edge between two streams shows as a
+    difference (or as run-to-run noise) between the two programs.  Four training steps WITH the update from one initialisation on each: the loss, every gradient vector, the
+    parameters after ADAM and the BatchNorm running statistics are compared bit for bit.  (Both tensor modes; ResNet-18 at BASELINE configs[1], a ResNet-50, and the
+    headline batch of 32 -- above the 1.5 M pixels from which the pullback's last weight gradients stay on the caller's stream and the shortcut's pullback leaves the pose stream.)"""
+    N, C, H, W, depth = (32, 1, 128, 416, 18) if shape == "416x128_b32" else STRESS_SHAPES[shape]
+    xd = dev(np.concatenate([syn.synthetic_triplets(min(N, 4), C, H, W, seed=42 + i) for i in range((N + 3) // 4)])[:N].copy())
+    md().set_deterministic(True)
+    try:
+        runs = []
+        for two in (True, False):
+            model, params, cache, theta, K, iK = make(N, C, H, W, pseed=41, precision=precision, depth=depth)
+            model._ensure(xd, params, cache)
+            md().set_two_streams(model, two)
+            rec = []
+            for r in range(4):
+                loss = md().train_step(model, xd, None, cache, params, do_update=True)
+                rec.append((np.float32(float(loss)), model.grads().copy()))
+            runs.append((rec, model.params().copy(), model.bn_state().copy()))
+            model.close()
+    finally:
+        md().set_deterministic(False)
+    (ra, pa, ba), (rb, pb, bb) = runs
+    for r, ((la, ga), (lb, gb)) in enumerate(zip(ra, rb)):
+        assert np.isfinite(ga).all() and np.isfinite(gb).all(), "step %d: non-finite gradient" % r
+        assert la == lb, "step %d: loss %r (three streams) vs %r (one stream)" % (r, la, lb)
+        assert np.array_equal(ga, gb), "step %d: %d gradient elements differ between the three-stream and the one-stream program" % (r, int((ga != gb).sum()))
+    assert np.array_equal(pa, pb), "%d parameters differ after four updates" % int((pa != pb).sum())
+    assert np.array_equal(ba, bb), "%d BatchNorm running statistics differ" % int((ba != bb).sum())
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16_storage"])
 def test_step_is_immune_to_foreign_lds_contents(precision):
     """LDS is not cleared between workgroups: whatever a neighbour left there is what a kernel reads if it reads LDS it never wrote, or past its allocation -- and 0 x NaN is NaN.
     While a second stream keeps launching a kernel that fills LDS with NaN / Inf bit patterns (tests/native/lds_poison.hip, built by __graft_entry__.build()), steps in the
