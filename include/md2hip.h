@@ -173,8 +173,11 @@ int32_t md2_loss_fwd_bwd(md2_handle* h, const float* x, const float* disp0, cons
 int32_t md2_simple_depth_loss(md2_handle* h, const float* x, const float* disp, const float* rvec, const float* tvec, float* loss,
                               float* ddisp, float* drvec, float* dtvec);
 
-/* Run the weight-gradient kernels on a second internal stream, overlapped with the input-gradient / BatchNorm-pullback chain
- * (default 1; MD2_ONE_STREAM=1 in the environment sets the default to 0).  Results are identical up to fp32-atomic ordering. */
+/* Use the library's internal side streams (default 1; MD2_ONE_STREAM=1 in the environment sets the default to 0): the weight-gradient
+ * kernels beside the input-gradient / BatchNorm-pullback chain, and the pose decoder, the disparity heads, the loss's tail and the 1x1
+ * shortcut branches beside the depth decoder / encoder.  Every side stream is forked from and joined back to the handle's stream by
+ * event, so stream order on the handle's stream is all a caller sees.  0: everything on the handle's stream.  Results are identical up
+ * to fp32-atomic ordering, and bit-identical in the bit-reproducible mode (md2_set_deterministic). */
 int32_t md2_set_two_streams(md2_handle* h, int32_t on);
 
 /* per-kernel-class device timing (HIP events on the handle's stream) for bench.py's roofline */
